@@ -1,0 +1,112 @@
+/*
+ * rssync_c.h -- flat C-ABI over the ISyncProblem surface of librssync_core.so.
+ *
+ * The reference exposes only a C++ vtable (src/core/public/rssync.h:9-31).
+ * A host that is not C++ (ctypes, cgo, JNI, N-API ...) binds these entry
+ * points instead; each one forwards to exactly one ISyncProblem method, named
+ * in its comment.  INTEGRATION.md shows both bindings.
+ *
+ * Unlike the C++ surface, these calls can report a failure instead of ending
+ * the process: with rssync_set_panic_mode(1) a "panic" (invalid input, device
+ * error) makes the call return non-zero and rssync_last_error() gives the
+ * reason; with mode 0 (default) the reference behaviour applies (panic.txt,
+ * exit(1)).
+ *
+ * The rssync_ext_* entry points are extensions the reference does not have:
+ * every hyper-parameter in the reference is a literal and its sampler is
+ * seeded from std::random_device, so a reproducible, benchmarkable and
+ * multi-GPU build needs a few knobs.  None of them changes the meaning of the
+ * six ISyncProblem calls at their defaults.
+ */
+#ifndef RSSYNC_C_H
+#define RSSYNC_C_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rssync_problem rssync_problem;
+
+/* CreateSyncProblem()  (rssync.h:31).  NULL if no HIP device is usable
+ * (there is no CPU fallback in this library). */
+rssync_problem* rssync_create(void);
+/* delete through the virtual destructor (rssync.h:11) */
+void rssync_destroy(rssync_problem* p);
+const char* rssync_last_error(void);
+void rssync_set_panic_mode(int mode); /* 0 = panic.txt + exit(1); 1 = return status */
+
+/* ISyncProblem::SetGyroQuaternions(const double*, size_t, double, double)  (rssync.h:13-14) */
+int rssync_set_gyro_quaternions(rssync_problem* p, const double* data, size_t count,
+                                double sample_rate, double first_timestamp);
+/* ISyncProblem::SetGyroQuaternions(const int64_t*, const double*, size_t)  (rssync.h:15-16) */
+int rssync_set_gyro_quaternions_ts(rssync_problem* p, const int64_t* timestamps_us,
+                                   const double* quats, size_t count);
+/* ISyncProblem::SetTrackResult  (rssync.h:17-18) */
+int rssync_set_track_result(rssync_problem* p, int64_t frame, const double* ts_a,
+                            const double* ts_b, const double* rays_a, const double* rays_b,
+                            size_t count);
+/* ISyncProblem::PreSync  (rssync.h:19-21); pair -> two out-parameters */
+int rssync_pre_sync(rssync_problem* p, double initial_delay, int64_t frame_begin,
+                    int64_t frame_end, double search_step, double search_radius, double* cost,
+                    double* delay);
+/* ISyncProblem::Sync  (rssync.h:22-24) */
+int rssync_sync(rssync_problem* p, double initial_delay, int64_t frame_begin, int64_t frame_end,
+                double search_center, double search_radius, double* cost, double* delay);
+/* ISyncProblem::DebugPreSync  (rssync.h:26-28) */
+int rssync_debug_pre_sync(rssync_problem* p, double initial_delay, int64_t frame_begin,
+                          int64_t frame_end, double search_radius, double* delays, double* costs,
+                          int point_count);
+
+/* ---------------- extensions (not in the reference) ---------------- */
+
+/* seed of the hypothesis sampler (default 0x5EED0000, env RSSYNC_SEED) */
+int rssync_ext_set_seed(rssync_problem* p, uint64_t seed);
+/* cap on Sync's outer iterations (reference literal 400, core_private.cpp:309; env RSSYNC_MAX_OUTER_ITERS) */
+int rssync_ext_set_max_outer_iters(rssync_problem* p, int iters);
+/* 0 silences the "delay step" progress lines Sync writes to stderr (core_private.cpp:330; env RSSYNC_QUIET=1) */
+int rssync_ext_set_verbose(rssync_problem* p, int verbose);
+/* run the kernels on a caller-owned hipStream_t (NULL = internal stream) */
+int rssync_ext_set_stream(rssync_problem* p, void* hip_stream);
+
+/* Multi-GPU: frames are sharded over ranks (one process per GPU); the only
+ * exchange on the path is a sum of a few doubles (PreSync: the candidate cost
+ * vector; Sync: loss/gradient and the line-search losses).  The hook must sum
+ * buf[0..n) in place over all ranks (e.g. an RCCL all-reduce).  NULL = single rank. */
+typedef void (*rssync_reduce_fn)(double* buf, size_t n, void* user);
+int rssync_ext_set_reduce_hook(rssync_problem* p, rssync_reduce_fn fn, void* user);
+
+/* diagnostics used by the parity tests and the benchmark */
+int rssync_ext_sample_rate(rssync_problem* p, double* sample_rate, double* quats_start,
+                           size_t* n_knots);
+int rssync_ext_gyro_knots(rssync_problem* p, double* out, size_t cap); /* [4*n_knots] */
+/* PreSync's whole curve: delays/costs [cap], optional per-frame matrices [n][n_frames] */
+int rssync_ext_presync_curve(rssync_problem* p, double initial_delay, int64_t frame_begin,
+                             int64_t frame_end, double search_step, double search_radius,
+                             double* delays, double* costs, int cap, int* n_out,
+                             double* frame_costs, int32_t* best_h, int* n_frames);
+/* residual matrix of one frame (fp32, N x 3) and its d/d-delay at one delay */
+int rssync_ext_problem_matrix(rssync_problem* p, int64_t frame, double delay, float* P, float* dP,
+                              size_t cap_rows, size_t* n_rows);
+/* Sync's GuessMotion/GuessK on frames [begin, end]; M[3n], k[n] in ascending frame order */
+int rssync_ext_init_motion(rssync_problem* p, double delay, int64_t frame_begin, int64_t frame_end,
+                           double* M, double* k, int cap, int* n_frames);
+/* per-frame L-BFGS at a fixed delay on the current selection (after init_motion / Sync) */
+int rssync_ext_opt_motion(rssync_problem* p, double delay, double* M, double* k, int cap,
+                          int* n_frames, uint64_t* iters, uint64_t* evals);
+int rssync_ext_set_motion(rssync_problem* p, const double* M, const double* k, int n_frames);
+/* sum over the current selection of loss (and analytic d/d-delay) at n delays */
+int rssync_ext_loss(rssync_problem* p, const double* delays, int n, double* loss, double* grad);
+/* trace of the last Sync: rows of {delay_after, step, loss_at_x0, grad_at_x0, t, trials} */
+int rssync_ext_sync_trace(rssync_problem* p, double* trace, int cap_rows, int* n_rows);
+/* HIP-event kernel timing: kind 0 LMedS tile, 1 loss, 2 motion, 3 reduce */
+int rssync_ext_profile(rssync_problem* p, int enable);
+int rssync_ext_profile_get(rssync_problem* p, int kind, uint64_t* launches, double* total_ms);
+int rssync_ext_profile_reset(rssync_problem* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,115 @@
+/*
+ * rssync_hip.h -- thin C-ABI between the C++ host solver (sync_problem.cpp)
+ * and the gfx950 kernels (rssync_kernels.hip).  Plain pointers and sizes, int
+ * status codes (0 = ok), no C++ types and no exceptions across it.
+ *
+ * This is the INTERNAL boundary of librssync_core.so.  The drop-in surface a
+ * client of the reference binds is the C++ vtable in rssync.h (and its flat C
+ * mirror rssync_c.h).  Each entry below names the reference code it takes
+ * over (paths relative to VladimirP1/rs-sync src/).
+ *
+ * Conventions
+ *  - a "delay" reaches the device as  delay * sample_rate = kd + fd  with kd an
+ *    int32 knot count and fd an fp32 fraction in [0,1): absolute times are
+ *    never rounded to fp32;
+ *  - rays live in HBM as two float4 streams per frame, {ax,ay,az,ta} and
+ *    {bx,by,bz,tb}, where ta/tb are the ray's spline parameter minus the
+ *    frame's integer base knot (32 B per ray pair);
+ *  - spline coefficients are 4 float4 per knot: y, b, c, d over [w,x,y,z];
+ *  - every call is synchronous on return (results are in the host buffers).
+ */
+#ifndef RSSYNC_HIP_H
+#define RSSYNC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rship_ctx rship_ctx;
+
+/* one record of the device frame table (32 bytes) */
+typedef struct rship_frame {
+    uint32_t ray_offset; /* first ray of the frame in the two float4 streams */
+    uint32_t n_rays;
+    int32_t base_knot; /* floor(min over rays of (ts - start) * fs) */
+    float tmin, tmax;  /* min / max of the per-ray offsets ta, tb */
+    uint32_t reserved;
+    int64_t id; /* caller's frame number (keys the hypothesis sampler) */
+} rship_frame;
+
+/* status bits reported by the LMedS kernel; the host turns them into the
+ * reference's panic messages (core_private.cpp:76-83) */
+#define RSHIP_BAD_P 1u
+#define RSHIP_BAD_M 2u
+#define RSHIP_BAD_R 4u
+#define RSHIP_BAD_RHO 8u
+
+/* kernel kinds for rship_profile_get */
+#define RSHIP_K_LMEDS 0  /* PreSync tile kernel (also Sync's GuessMotion/GuessK) */
+#define RSHIP_K_LOSS 1   /* residual + robust loss (+ analytic d/d-delay) */
+#define RSHIP_K_MOTION 2 /* per-frame motion L-BFGS */
+#define RSHIP_K_REDUCE 3 /* over-frames sums */
+#define RSHIP_K_COUNT 4
+
+int rship_create(rship_ctx** out, int device /* -1 = current device */);
+void rship_destroy(rship_ctx* c);
+const char* rship_last_error(const rship_ctx* c);
+/* launch on a caller-owned hipStream_t (NULL = the context's own stream) */
+int rship_set_stream(rship_ctx* c, void* hip_stream);
+int rship_max_tracks(void); /* largest per-frame track count the kernels accept */
+
+/* OptData::quats (core_private.hpp:18): coefficient table built on the host by
+ * the spline solver that replaces minispline.cpp:3-46 */
+int rship_upload_spline(rship_ctx* c, const float* coef16, uint32_t n_knots, double sample_rate);
+
+/* OptData::frame_data (core_private.hpp:21): all frames, packed */
+int rship_upload_frames(rship_ctx* c, const float* rays_a4, const float* rays_b4,
+                        uint64_t total_rays, const rship_frame* table, uint32_t n_frames);
+
+/* the frames a PreSync/Sync call works on (indices into the table; replaces the
+ * frame filters at core_private.cpp:65-68, :218-219, :340-343) */
+int rship_select_frames(rship_ctx* c, const uint32_t* idx, uint32_t n);
+
+/* pre_sync's per-frame body for every (selected frame, candidate delay):
+ * opt_compute_problem + opt_guess_translational_motion(P, n_hyp) + cost
+ * (core_private.cpp:75-85).  costs[n_cand] = sum over selected frames.
+ * Optional debug outputs (may be NULL): frame_costs / best_h [n_cand][n_sel]. */
+int rship_presync_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand,
+                        uint32_t n_hyp, uint32_t stream_base, uint64_t seed, double* costs,
+                        uint32_t* flags, double* frame_costs, int32_t* best_h);
+
+/* FrameState::GuessMotion + GuessK (core_private.cpp:125-133) for every
+ * selected frame at one delay; results stay on the device */
+int rship_init_motion(rship_ctx* c, int32_t kd, float fd, uint32_t n_hyp, uint32_t stream,
+                      uint64_t seed);
+
+/* do_opt_motion (core_private.cpp:262-296): per-frame L-BFGS on the motion
+ * vector at a fixed delay.  stats (optional) = {sum of iterations, sum of evaluations} */
+int rship_opt_motion(rship_ctx* c, int32_t kd, float fd, uint64_t* stats);
+
+/* sum over selected frames of FrameState::Loss at n_delays delays
+ * (core_private.cpp:117-123); with grad != NULL also the analytic d/d-delay
+ * that replaces the central difference at :96-97,112 */
+int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_delays, double* loss,
+               double* grad);
+
+/* per-frame state (selected frames, ascending selection order): M[3n], k[n] */
+int rship_get_motion(rship_ctx* c, double* M, double* k, uint32_t cap, uint32_t* n);
+int rship_set_motion(rship_ctx* c, const double* M, const double* k, uint32_t n);
+
+/* residual matrix P (fp32, row-major N x 3) of one selected frame at one delay (tests) */
+int rship_debug_problem(rship_ctx* c, uint32_t sel_index, int32_t kd, float fd, float* P,
+                        float* dP, uint32_t cap_rows);
+
+/* HIP-event timing of every launch, accumulated per kernel kind */
+int rship_profile_enable(rship_ctx* c, int on);
+int rship_profile_get(rship_ctx* c, int kind, uint64_t* launches, double* total_ms);
+int rship_profile_reset(rship_ctx* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1220 @@
+// rssync_kernels.hip -- gfx950 (CDNA4) kernels for the rs-sync PreSync/Sync hot
+// path and the thin C-ABI the host solver calls (include/rssync_hip.h).
+//
+// Kernels (all wave64, 256-thread workgroups, no MFMA: the path has no dense
+// contraction):
+//   lmeds_kernel       one workgroup per (frame, chunk of candidate delays): residual
+//                      matrix P into an LDS tile, LMedS hypothesis search with an exact
+//                      lower-quartile selection, robust PreSync cost.  The same kernel
+//                      in INIT mode is Sync's GuessMotion/GuessK.
+//   loss_kernel        one workgroup per frame: residual + robust loss (+ analytic
+//                      d/d-delay) for a batch of delays, rays held in registers.
+//   opt_motion_kernel  one workgroup per frame: P in registers, restated L-BFGS on the
+//                      3-vector motion estimate.
+//   reduce_rows_kernel fixed-order fp64 sums over frames.
+// Data layout and the roofline that bounds each kernel: DESIGN.md.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rssync_hip.h"
+#include "device_math.hpp"
+
+using rs::f3;
+using rs::f4;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWinMax = 128; // knots of the spline staged in LDS per workgroup
+constexpr uint32_t kInfBits = 0x7f800000u;
+
+// ---------------------------------------------------------------------------
+// wave64 / workgroup reductions.  DPP row shifts + row broadcasts (gfx9 forms):
+// after the six steps lane 63 holds the wave total.
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
+    int v = (int)x;
+    v += dpp_i<0x111, 0xf>(v); // row_shr:1
+    v += dpp_i<0x112, 0xf>(v); // row_shr:2
+    v += dpp_i<0x114, 0xf>(v); // row_shr:4
+    v += dpp_i<0x118, 0xf>(v); // row_shr:8
+    v += dpp_i<0x142, 0xa>(v); // row_bcast:15 -> rows 1,3
+    v += dpp_i<0x143, 0xc>(v); // row_bcast:31 -> rows 2,3
+    return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v += dpp_f<0x111, 0xf>(v);
+    v += dpp_f<0x112, 0xf>(v);
+    v += dpp_f<0x114, 0xf>(v);
+    v += dpp_f<0x118, 0xf>(v);
+    v += dpp_f<0x142, 0xa>(v);
+    v += dpp_f<0x143, 0xc>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_d<0x111, 0xf>(v);
+    v += dpp_d<0x112, 0xf>(v);
+    v += dpp_d<0x114, 0xf>(v);
+    v += dpp_d<0x118, 0xf>(v);
+    v += dpp_d<0x142, 0xa>(v);
+    v += dpp_d<0x143, 0xc>(v);
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// workgroup sum of a per-thread fp32 partial: fp32 inside the wave, fp64 across
+// the four waves.  `slot` is a 4-double LDS scratch; two barriers.
+__device__ __forceinline__ double block_sum(float v, double* slot) {
+    float w = wave_sum_f32(v);
+    __syncthreads(); // previous readers of slot are done
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = (double)w;
+    __syncthreads();
+    return slot[0] + slot[1] + slot[2] + slot[3];
+}
+
+__device__ __forceinline__ bool finite_f(float x) { return (__float_as_uint(x) & kInfBits) != kInfBits; }
+
+// ---------------------------------------------------------------------------
+// spline window in LDS: SoA by coefficient kind so that neighbouring knots
+// fall into different banks (ds_read_b128 of kind k, knot j at (k*kWinMax + j) * 16 B).
+
+struct Spline {
+    const f4* __restrict__ g; // global table, 4 f4 per knot
+    const f4* lds;            // [4][kWinMax]
+    int n;                    // knots
+    int w0, wlen;             // staged range [w0, w0 + wlen)
+};
+
+__device__ __forceinline__ void stage_window(Spline& s, f4* s_win, int lo, int hi) {
+    const int n = s.n;
+    lo = lo < 0 ? 0 : (lo > n - 1 ? n - 1 : lo);
+    hi = hi < 0 ? 0 : (hi > n - 1 ? n - 1 : hi);
+    int wlen = hi - lo + 1;
+    if (wlen > kWinMax) wlen = kWinMax;
+    s.w0 = lo;
+    s.wlen = wlen;
+    s.lds = s_win;
+    for (int e = threadIdx.x; e < wlen * 4; e += kBlock) {
+        int knot = e >> 2, kind = e & 3;
+        s_win[kind * kWinMax + knot] = s.g[(size_t)(lo + knot) * 4 + kind];
+    }
+}
+
+__device__ __forceinline__ void fetch_coef(const Spline& s, int ci, f4& y, f4& b, f4& c, f4& d) {
+    unsigned rel = (unsigned)(ci - s.w0);
+    if (rel < (unsigned)s.wlen) {
+        y = s.lds[rel];
+        b = s.lds[kWinMax + rel];
+        c = s.lds[2 * kWinMax + rel];
+        d = s.lds[3 * kWinMax + rel];
+    } else { // outside the staged window (wild trial delays, very fast gyros): L2 path
+        const f4* p = s.g + (size_t)ci * 4;
+        y = p[0]; b = p[1]; c = p[2]; d = p[3];
+    }
+}
+
+// one row of P = ar x br (core_private.cpp:24-28) and, if DERIV, dP/dx (x in knots)
+template <bool DERIV>
+__device__ __forceinline__ void residual_row(const Spline& s, f4 ra, f4 rb, int base, float fd, f3& P, f3& dP) {
+    f4 y, b, c, d;
+    f3 ar, br, dar, dbr;
+    rs::Knot ka = rs::spline_locate(ra.w, base, fd, s.n);
+    fetch_coef(s, ka.ci, y, b, c, d);
+    rs::rotate_ray<DERIV>(y, b, c, d, ka, f3{ra.x, ra.y, ra.z}, ar, dar);
+    rs::Knot kb = rs::spline_locate(rb.w, base, fd, s.n);
+    fetch_coef(s, kb.ci, y, b, c, d);
+    rs::rotate_ray<DERIV>(y, b, c, d, kb, f3{rb.x, rb.y, rb.z}, br, dbr);
+    P = rs::cross(ar, br);
+    if (DERIV) dP = rs::add(rs::cross(dar, br), rs::cross(ar, dbr));
+}
+
+struct FrameRec { // == rship_frame
+    uint32_t off, n;
+    int32_t base_knot;
+    float tmin, tmax;
+    uint32_t reserved;
+    int64_t id;
+};
+static_assert(sizeof(FrameRec) == sizeof(rship_frame), "frame record layout");
+
+// ---------------------------------------------------------------------------
+// K2: LMedS tile kernel
+
+struct LmedsParams {
+    const f4* rays_a;
+    const f4* rays_b;
+    const FrameRec* frames;
+    const uint32_t* sel;
+    uint32_t n_sel;
+    const f4* coef;
+    int n_knots;
+    const int32_t* kd;
+    const float* fd;
+    uint32_t n_cand, chunk, n_chunks;
+    uint32_t n_hyp, stream_base;
+    uint64_t seed;
+    double* frame_cost; // [n_cand][n_sel]
+    int32_t* best_h;    // [n_cand][n_sel] or null
+    double* M;          // INIT mode: per table frame [3]
+    double* k;          // INIT mode
+    uint32_t* flags;
+};
+
+// hypothesis direction v = safe_normalize(P[i0] x P[i1]) (core_private.cpp:45-46)
+__device__ __forceinline__ f3 hypothesis(const f4* tile, uint64_t seed, int64_t frame, uint32_t stream, uint32_t h,
+                                         uint32_t n) {
+    uint32_t i0, i1;
+    rs::sample_pair(seed, frame, stream, h, n, i0, i1);
+    f4 a = tile[i0], b = tile[i1];
+    f3 v = rs::cross(f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z});
+    float nn = sqrtf(rs::dot(v, v));
+    if (!(nn < 1e-12f)) { // inline_utils.hpp:5-11
+        float inv = 1.0f / nn;
+        v = rs::scale(v, inv);
+    }
+    return v;
+}
+
+// waves per SIMD each kernel is compiled for (second __launch_bounds__ argument): the
+// LMedS tile is LDS-limited to 3 workgroups per CU at 8 rows per thread
+__host__ __device__ constexpr int lmeds_waves(int rpt) { return rpt >= 8 ? 3 : 4; }
+__host__ __device__ constexpr int loss_waves(int rpt, bool grad) { return (grad || rpt >= 8) ? 3 : 4; }
+
+template <int RPT, int MODE> // MODE 0: PreSync cost per candidate; 1: GuessMotion + GuessK
+__global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsParams p) {
+    constexpr int NR = 4 * RPT; // residual registers per lane: a wave spans the whole tile
+    __shared__ f4 s_tile[kBlock * RPT];
+    __shared__ f4 s_win[4 * kWinMax];
+    __shared__ double s_red[4];
+    __shared__ uint32_t s_bestT[4];
+    __shared__ int s_bestH[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // blocks b and b+8 share an XCD (round-robin dispatch): keep the chunks of one
+    // frame on one XCD so its rays are fetched into one L2 only
+    const uint32_t per = 8u * p.n_chunks;
+    const uint32_t grp = blockIdx.x / per, within = blockIdx.x % per;
+    const uint32_t sf = grp * 8u + (within & 7u);
+    const uint32_t chunk = within >> 3;
+    if (sf >= p.n_sel) return;
+    const uint32_t fi = p.sel[sf];
+    const FrameRec fr = p.frames[fi];
+    const uint32_t N = fr.n;
+    const uint32_t kq = N / 4; // core_private.cpp:52
+
+    // rays are re-read per candidate: the chunks of a frame share an XCD, so after the
+    // first touch they come from that XCD's L2 (keeping them in registers costs 64 VGPRs)
+    const f4* __restrict__ rays_a = p.rays_a + fr.off;
+    const f4* __restrict__ rays_b = p.rays_b + fr.off;
+
+    const uint32_t c0 = chunk * p.chunk;
+    const uint32_t c1 = (c0 + p.chunk < p.n_cand) ? c0 + p.chunk : p.n_cand;
+    if (c0 >= c1) return;
+
+    Spline sp;
+    sp.g = p.coef;
+    sp.n = p.n_knots;
+    {
+        int kd_lo = p.kd[c0], kd_hi = p.kd[c0];
+        for (uint32_t c = c0 + 1; c < c1; ++c) {
+            int v = p.kd[c];
+            kd_lo = v < kd_lo ? v : kd_lo;
+            kd_hi = v > kd_hi ? v : kd_hi;
+        }
+        stage_window(sp, s_win, fr.base_knot + (int)floorf(fr.tmin) + kd_lo,
+                     fr.base_knot + (int)floorf(fr.tmax) + kd_hi + 1);
+    }
+    __syncthreads();
+
+    for (uint32_t c = c0; c < c1; ++c) {
+        const int base = fr.base_knot + p.kd[c];
+        const float fd = p.fd[c];
+        uint32_t bad = 0;
+        // ---- stage A: P rows -> LDS tile as {Px, Py, Pz, 1/|P|} ----
+#pragma unroll 2
+        for (int j = 0; j < RPT; ++j) {
+            uint32_t row = j * kBlock + tid;
+            f4 t = f4{0, 0, 0, 0};
+            if (row < N) {
+                f3 P, dP;
+                residual_row<false>(sp, rays_a[row], rays_b[row], base, fd, P, dP);
+                if (!(finite_f(P.x) && finite_f(P.y) && finite_f(P.z))) bad |= RSHIP_BAD_P;
+                float nn = sqrtf(rs::dot(P, P));
+                float inv = (nn < 1e-12f) ? 1.f : 1.0f / nn; // safe_normalize, core_private.cpp:35-36
+                t = f4{P.x, P.y, P.z, inv};
+            }
+            s_tile[row] = t;
+        }
+        __syncthreads();
+
+        // ---- stage C: hypotheses h = wave, wave+4, ...; wave-local best ----
+        uint32_t T = kInfBits; // best quantile so far as an ordered bit pattern (r^2 >= 0)
+        int bh = -1;
+        for (uint32_t h = wave; h < p.n_hyp; h += 4) {
+            f3 v = hypothesis(s_tile, p.seed, fr.id, p.stream_base + c, h, N);
+            uint32_t r2[NR];
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                // keep at most four 16-byte tile reads in flight: hoisting all NR of them
+                // would cost 4 VGPRs each
+                if ((m & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                uint32_t row = m * 64 + lane;
+                f4 t = s_tile[row];
+                float r = rs::dot(f3{t.x, t.y, t.z}, v) * t.w; // core_private.cpp:48
+                uint32_t bits = (row < N) ? __float_as_uint(r * r) : kInfBits;
+                r2[m] = bits;
+                cnt += (bits < T) ? 1u : 0u;
+            }
+            // med < least_med  <=>  more than kq residuals lie below least_med (core_private.cpp:51-53)
+            if (wave_sum_u32(cnt) > kq) {
+                // exact kq-th smallest by bisection over the bit pattern
+                uint32_t res = 0;
+                for (int bit = 30; bit >= 0; --bit) {
+                    uint32_t trial = res | (1u << bit);
+                    uint32_t c2 = 0;
+#pragma unroll
+                    for (int m = 0; m < NR; ++m) c2 += (r2[m] < trial) ? 1u : 0u;
+                    if (wave_sum_u32(c2) <= kq) res = trial;
+                }
+                T = res;
+                bh = (int)h;
+            }
+        }
+        if (lane == 0) {
+            s_bestT[wave] = T;
+            s_bestH[wave] = bh;
+        }
+        __syncthreads();
+        uint32_t bT = s_bestT[0];
+        int bH = s_bestH[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            uint32_t t = s_bestT[w];
+            int hh = s_bestH[w];
+            if (hh >= 0 && (bH < 0 || t < bT || (t == bT && hh < bH))) {
+                bT = t;
+                bH = hh;
+            }
+        }
+        f3 Mv = f3{0, 0, 0};
+        if (bH >= 0) Mv = hypothesis(s_tile, p.seed, fr.id, p.stream_base + c, (uint32_t)bH, N);
+        if (!(finite_f(Mv.x) && finite_f(Mv.y) && finite_f(Mv.z))) bad |= RSHIP_BAD_M;
+
+        // ---- stage D: k = clamp(100 / |P M|), cost = sqrt(sum sqrt(log1p(r^2))) ----
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            f4 t = s_tile[j * kBlock + tid];
+            float pm = rs::dot(f3{t.x, t.y, t.z}, Mv);
+            ss = fmaf(pm, pm, ss);
+        }
+        double ss_tot = block_sum(ss, s_red);
+        float kf = 100.0f / sqrtf((float)ss_tot); // core_private.cpp:79
+        kf = (kf < 10.f) ? 10.f : ((1000.f < kf) ? 1000.f : kf);
+        if (MODE == 1) {
+            if (tid == 0) {
+                p.M[3 * fi + 0] = (double)Mv.x;
+                p.M[3 * fi + 1] = (double)Mv.y;
+                p.M[3 * fi + 2] = (double)Mv.z;
+                p.k[fi] = (double)kf;
+            }
+        } else {
+            float sc = kf / sqrtf(rs::dot(Mv, Mv)); // core_private.cpp:80
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                uint32_t row = j * kBlock + tid;
+                if (row < N) {
+                    f4 t = s_tile[row];
+                    float r = rs::dot(f3{t.x, t.y, t.z}, Mv) * sc;
+                    if (!finite_f(r)) bad |= RSHIP_BAD_R;
+                    float rho = log1pf(r * r); // core_private.cpp:82
+                    if (!finite_f(rho)) bad |= RSHIP_BAD_RHO;
+                    acc += sqrtf(rho);
+                }
+            }
+            double acc_tot = block_sum(acc, s_red);
+            if (tid == 0) {
+                p.frame_cost[(size_t)c * p.n_sel + sf] = sqrt(acc_tot); // core_private.cpp:85
+                if (p.best_h) p.best_h[(size_t)c * p.n_sel + sf] = bH;
+            }
+        }
+        if (bad) atomicOr(p.flags, bad);
+        __syncthreads(); // tile is rewritten by the next candidate
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1: residual + robust loss (+ analytic d/d-delay) per frame for a batch of delays
+
+struct LossParams {
+    const f4* rays_a;
+    const f4* rays_b;
+    const FrameRec* frames;
+    const uint32_t* sel;
+    uint32_t n_sel;
+    const f4* coef;
+    int n_knots;
+    float fs;
+    const int32_t* kd;
+    const float* fd;
+    uint32_t n_delays;
+    const double* M;
+    const double* k;
+    double* part_loss; // [n_delays][n_sel]
+    double* part_grad; // [n_delays][n_sel] (GRAD)
+};
+
+template <int RPT, bool GRAD>
+__global__ __launch_bounds__(kBlock, loss_waves(RPT, GRAD)) void loss_kernel(LossParams p) {
+    __shared__ f4 s_win[4 * kWinMax];
+    __shared__ double s_red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t sf = blockIdx.x;
+    const uint32_t fi = p.sel[sf];
+    const FrameRec fr = p.frames[fi];
+    const uint32_t N = fr.n;
+
+    // each delay of the batch re-reads the frame's rays; only the first read comes from
+    // HBM, the rest from L2 (the frame is 32 B x N, far below one XCD's 4 MiB)
+    const f4* __restrict__ rays_a = p.rays_a + fr.off;
+    const f4* __restrict__ rays_b = p.rays_b + fr.off;
+    const double Mx = p.M[3 * fi], My = p.M[3 * fi + 1], Mz = p.M[3 * fi + 2], kk = p.k[fi];
+    const f3 Mv = f3{(float)Mx, (float)My, (float)Mz};
+    // r = (P.M) k / |M|  (core_private.cpp:120)  ->  u = (P.M)^2 * inv_s
+    const float inv_s = (float)(kk * kk / (Mx * Mx + My * My + Mz * Mz));
+
+    Spline sp;
+    sp.g = p.coef;
+    sp.n = p.n_knots;
+    for (uint32_t b = 0; b < p.n_delays; ++b) {
+        const int kd = p.kd[b];
+        const float fd = p.fd[b];
+        __syncthreads(); // window and s_red reuse
+        stage_window(sp, s_win, fr.base_knot + (int)floorf(fr.tmin) + kd, fr.base_knot + (int)floorf(fr.tmax) + kd + 1);
+        __syncthreads();
+        const int base = fr.base_knot + kd;
+        float L = 0.f, G = 0.f;
+#pragma unroll 1
+        for (int j = 0; j < RPT; ++j) {
+            uint32_t row = j * kBlock + tid;
+            if (row < N) {
+                f3 P, dP;
+                residual_row<GRAD>(sp, rays_a[row], rays_b[row], base, fd, P, dP);
+                float pm = rs::dot(P, Mv);
+                float u = pm * pm * inv_s;
+                L += log1pf(u); // core_private.cpp:121-122
+                if (GRAD) {
+                    // dL/dd = sum 1/(1+u) * (2 pm / s) * (dP/dd . M), dP/dd = fs * dP/dx
+                    float w = rs::rcp_fast(1.f + u);
+                    G = fmaf(w * 2.f * pm * inv_s, rs::dot(dP, Mv), G);
+                }
+            }
+        }
+        double Lw = wave_sum_f64((double)L);
+        double Gw = GRAD ? wave_sum_f64((double)G) : 0.0;
+        if (lane == 0) {
+            s_red[0][wave] = Lw;
+            s_red[1][wave] = Gw;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            p.part_loss[(size_t)b * p.n_sel + sf] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+            if (GRAD)
+                p.part_grad[(size_t)b * p.n_sel + sf] =
+                    (s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3]) * (double)p.fs;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3: per-frame L-BFGS on the motion vector, P resident in registers.
+// Restates ens::L_BFGS as called at core_private.cpp:264-294 (MaxIterations 200,
+// MinGradientNorm 1e-4, library defaults otherwise); the algorithm and the one
+// stated choice (re-evaluate at the best step when it is not the last one tried)
+// are those of oracle/rssync_oracle.c:lbfgs_minimise.  Control flow is uniform:
+// every thread runs the same fp64 scalar logic on the same reduced sums.
+
+struct MotionParams {
+    const f4* rays_a;
+    const f4* rays_b;
+    const FrameRec* frames;
+    const uint32_t* sel;
+    uint32_t n_sel;
+    const f4* coef;
+    int n_knots;
+    int32_t kd;
+    float fd;
+    double* M;
+    const double* k;
+    unsigned long long* stats; // [0] += iterations, [1] += evaluations
+};
+
+constexpr int kNB = 10; // numBasis
+
+template <int RPT>
+struct MotionEval {
+    f3 P[RPT];
+    double (*part)[4][5]; // [2][4][5] LDS, double-buffered
+    int buf;
+    double k2;
+    int evals;
+
+    // loss and dL/dM at x (core_private.cpp:99-114 in closed form)
+    __device__ __forceinline__ double operator()(const double x[3], double g[3]) {
+        const double s = (x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) / k2;
+        const float inv_s = (float)(1.0 / s);
+        const f3 xv = f3{(float)x[0], (float)x[1], (float)x[2]};
+        float L = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, gs = 0.f;
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            float pm = rs::dot(P[j], xv);
+            float v2 = pm * pm;
+            float u = v2 * inv_s;
+            L += log1pf(u);
+            float w = rs::rcp_fast(1.f + u);
+            float a = w * 2.f * pm * inv_s;
+            a0 = fmaf(a, P[j].x, a0);
+            a1 = fmaf(a, P[j].y, a1);
+            a2 = fmaf(a, P[j].z, a2);
+            gs = fmaf(w * v2, inv_s * inv_s, gs);
+        }
+        double r0 = wave_sum_f64((double)L), r1 = wave_sum_f64((double)a0), r2 = wave_sum_f64((double)a1),
+               r3 = wave_sum_f64((double)a2), r4 = wave_sum_f64((double)gs);
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+            part[buf][wave][0] = r0; part[buf][wave][1] = r1; part[buf][wave][2] = r2;
+            part[buf][wave][3] = r3; part[buf][wave][4] = r4;
+        }
+        __syncthreads();
+        double t[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) t[q] = part[buf][0][q] + part[buf][1][q] + part[buf][2][q] + part[buf][3][q];
+        buf ^= 1;
+        ++evals;
+        const double tt = t[4] * 2.0 / k2;
+        g[0] = t[1] - tt * x[0];
+        g[1] = t[2] - tt * x[1];
+        g[2] = t[3] - tt * x[2];
+        return t[0];
+    }
+};
+
+__device__ __forceinline__ double dot3d(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+template <int RPT>
+__global__ __launch_bounds__(kBlock, 4) void opt_motion_kernel(MotionParams p) {
+    __shared__ f4 s_win[4 * kWinMax];
+    __shared__ double s_part[2][4][5];
+    __shared__ double s_S[kNB][3], s_Y[kNB][3];
+    // two-loop scratch: every thread writes the same values and reads them back itself;
+    // the barrier inside each evaluation separates one iteration's use from the next
+    __shared__ double s_rho[kNB], s_alpha[kNB];
+    const int tid = threadIdx.x;
+    const uint32_t sf = blockIdx.x;
+    const uint32_t fi = p.sel[sf];
+    const FrameRec fr = p.frames[fi];
+    const uint32_t N = fr.n;
+
+    Spline sp;
+    sp.g = p.coef;
+    sp.n = p.n_knots;
+    stage_window(sp, s_win, fr.base_knot + (int)floorf(fr.tmin) + p.kd, fr.base_knot + (int)floorf(fr.tmax) + p.kd + 1);
+    __syncthreads();
+
+    MotionEval<RPT> ev;
+    ev.part = s_part;
+    ev.buf = 0;
+    ev.evals = 0;
+    const double kk = p.k[fi];
+    ev.k2 = kk * kk;
+    const int base = fr.base_knot + p.kd;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        uint32_t row = j * kBlock + tid;
+        f3 P = f3{0, 0, 0}, dP;
+        if (row < N) residual_row<false>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], base, p.fd, P, dP);
+        ev.P[j] = P; // zero rows contribute log1p(0) = 0 and no gradient
+    }
+
+    const int maxIterations = 200;       // core_private.cpp:265
+    const double minGradientNorm = 1e-4; // core_private.cpp:266
+    const double armijo = 1e-4, wolfe = 0.9, factr = 1e-15, minStep = 1e-20, maxStep = 1e20;
+    const int maxLineSearchTrials = 50;
+
+    double x[3] = {p.M[3 * fi], p.M[3 * fi + 1], p.M[3 * fi + 2]};
+    double g[3], oldx[3], oldg[3], dir[3];
+    double fval = ev(x, g);
+    int it = 0;
+    for (; it != maxIterations; ++it) {
+        const double prev = fval;
+        if (sqrt(dot3d(g, g)) < minGradientNorm) break;
+        if (fval != fval) break;
+        double scale;
+        if (it > 0) {
+            const int pp = (it - 1) % kNB;
+            const double yy = dot3d(s_Y[pp], s_Y[pp]);
+            scale = dot3d(s_S[pp], s_Y[pp]) / ((yy >= 1e-10) ? yy : 1.0);
+        } else {
+            const double gn = sqrt(dot3d(g, g));
+            scale = (gn >= 1e-5) ? 1.0 / gn : 1.0;
+        }
+        if (scale == 0.0 || scale != scale) break;
+        // two-loop recursion
+        dir[0] = g[0]; dir[1] = g[1]; dir[2] = g[2];
+        const int limit = (kNB > it) ? 0 : (it - kNB);
+#pragma unroll 1
+        for (int i = it; i != limit; --i) {
+            const int tp = (i + (kNB - 1)) % kNB;
+            const double r = 1.0 / dot3d(s_Y[tp], s_S[tp]);
+            const double al = r * dot3d(s_S[tp], dir);
+            s_rho[it - i] = r; // it - i in [0, kNB)
+            s_alpha[it - i] = al;
+            dir[0] -= al * s_Y[tp][0]; dir[1] -= al * s_Y[tp][1]; dir[2] -= al * s_Y[tp][2];
+        }
+        dir[0] *= scale; dir[1] *= scale; dir[2] *= scale;
+#pragma unroll 1
+        for (int i = limit; i < it; ++i) {
+            const int tp = i % kNB;
+            const double beta = s_rho[it - i - 1] * dot3d(s_Y[tp], dir);
+            const double cf = s_alpha[it - i - 1] - beta;
+            dir[0] += cf * s_S[tp][0]; dir[1] += cf * s_S[tp][1]; dir[2] += cf * s_S[tp][2];
+        }
+        dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2];
+        oldx[0] = x[0]; oldx[1] = x[1]; oldx[2] = x[2];
+        oldg[0] = g[0]; oldg[1] = g[1]; oldg[2] = g[2];
+        // line search
+        const double dg0 = dot3d(g, dir);
+        if (dg0 > 0.0) break;
+        const double f0 = fval, lin = armijo * dg0;
+        double step = 1.0, bestStep = 1.0, bestObj = 1.79769313486231570e308, lastStep = 1.0;
+        int trials = 0;
+        for (;;) {
+            double xn[3] = {x[0] + step * dir[0], x[1] + step * dir[1], x[2] + step * dir[2]};
+            fval = ev(xn, g);
+            lastStep = step;
+            if (fval < bestObj) { bestStep = step; bestObj = fval; }
+            ++trials;
+            double width;
+            if (fval > f0 + step * lin) {
+                width = 0.5;
+            } else {
+                const double dg = dot3d(g, dir);
+                if (dg < wolfe * dg0) width = 2.1;
+                else if (dg > -wolfe * dg0) width = 0.5;
+                else break;
+            }
+            if (step < minStep || step > maxStep || trials >= maxLineSearchTrials) break;
+            step *= width;
+        }
+        x[0] += bestStep * dir[0]; x[1] += bestStep * dir[1]; x[2] += bestStep * dir[2];
+        if (bestStep != lastStep) fval = ev(x, g);
+        if (bestStep == 0.0) break;
+        const double denom = fmax(fmax(fabs(prev), fabs(fval)), 1.0);
+        if ((prev - fval) / denom <= factr) break;
+        const int op = it % kNB;
+        __syncthreads(); // every thread has finished reading the history for this iteration
+        if (tid == 0) {
+            for (int c = 0; c < 3; ++c) { s_S[op][c] = x[c] - oldx[c]; s_Y[op][c] = g[c] - oldg[c]; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        p.M[3 * fi] = x[0]; p.M[3 * fi + 1] = x[1]; p.M[3 * fi + 2] = x[2];
+        if (p.stats) {
+            atomicAdd(&p.stats[0], (unsigned long long)it);
+            atomicAdd(&p.stats[1], (unsigned long long)ev.evals);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// out[r] = sum over columns of in[r][*], fixed association (bitwise reproducible)
+
+__global__ __launch_bounds__(kBlock) void reduce_rows_kernel(const double* __restrict__ in, double* __restrict__ out,
+                                                            uint32_t n_cols) {
+    __shared__ double s_red[4];
+    const double* row = in + (size_t)blockIdx.x * n_cols;
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < n_cols; i += kBlock) acc += row[i];
+    double w = wave_sum_f64(acc);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+// debug: P (and dP/dd) rows of one frame
+struct DebugParams {
+    const f4* rays_a;
+    const f4* rays_b;
+    const FrameRec* frames;
+    uint32_t fi;
+    const f4* coef;
+    int n_knots;
+    float fs;
+    int32_t kd;
+    float fd;
+    float* P;
+    float* dP;
+};
+
+__global__ __launch_bounds__(kBlock) void debug_problem_kernel(DebugParams p) {
+    __shared__ f4 s_win[4 * kWinMax];
+    const FrameRec fr = p.frames[p.fi];
+    Spline sp;
+    sp.g = p.coef;
+    sp.n = p.n_knots;
+    stage_window(sp, s_win, fr.base_knot + (int)floorf(fr.tmin) + p.kd, fr.base_knot + (int)floorf(fr.tmax) + p.kd + 1);
+    __syncthreads();
+    for (uint32_t row = blockIdx.x * kBlock + threadIdx.x; row < fr.n; row += gridDim.x * kBlock) {
+        f3 P, dP;
+        residual_row<true>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], fr.base_knot + p.kd, p.fd, P, dP);
+        p.P[3 * row] = P.x; p.P[3 * row + 1] = P.y; p.P[3 * row + 2] = P.z;
+        if (p.dP) { p.dP[3 * row] = dP.x * p.fs; p.dP[3 * row + 1] = dP.y * p.fs; p.dP[3 * row + 2] = dP.z * p.fs; }
+    }
+}
+
+} // namespace
+
+// ===========================================================================
+// host side of the C-ABI
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct rship_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // problem data
+    DevBuf coef, rays_a, rays_b, frames, sel, M, k;
+    uint32_t n_knots = 0, n_frames = 0, n_sel = 0, max_n = 0;
+    uint64_t total_rays = 0;
+    double fs = 0;
+    std::vector<uint32_t> h_frame_n; // per table frame
+    std::vector<uint32_t> h_sel;
+    // scratch
+    DevBuf kd, fd, frame_cost, best_h, costs, part, flags, stats;
+    void* pinned = nullptr;
+    size_t pinned_cap = 0;
+    // profiling
+    bool prof = false;
+    struct Pending { int kind; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    uint64_t launches[RSHIP_K_COUNT] = {0, 0, 0, 0};
+    double total_ms[RSHIP_K_COUNT] = {0, 0, 0, 0};
+};
+
+namespace {
+
+int set_err(rship_ctx* c, const char* what, hipError_t e) {
+    c->err = std::string(what) + ": " + hipGetErrorString(e);
+    return 1;
+}
+int set_err(rship_ctx* c, const std::string& what) {
+    c->err = what;
+    return 1;
+}
+
+#define RS_HIP(call)                                         \
+    do {                                                     \
+        hipError_t e__ = (call);                             \
+        if (e__ != hipSuccess) return set_err(c, #call, e__); \
+    } while (0)
+
+int ensure(rship_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return 0;
+    if (b.p) RS_HIP(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    RS_HIP(hipMalloc(&b.p, want));
+    b.cap = want;
+    return 0;
+}
+
+int ensure_pinned(rship_ctx* c, size_t bytes) {
+    if (bytes <= c->pinned_cap) return 0;
+    if (c->pinned) RS_HIP(hipHostFree(c->pinned));
+    c->pinned = nullptr;
+    c->pinned_cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    RS_HIP(hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
+    c->pinned_cap = want;
+    return 0;
+}
+
+struct ProfScope {
+    rship_ctx* c;
+    int kind;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(rship_ctx* c_, int kind_) : c(c_), kind(kind_) {
+        if (!c->prof) return;
+        auto get = [&]() {
+            hipEvent_t e = nullptr;
+            if (!c->pool.empty()) { e = c->pool.back(); c->pool.pop_back(); }
+            else (void)hipEventCreate(&e);
+            return e;
+        };
+        a = get();
+        b = get();
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~ProfScope() {
+        if (!c->prof) return;
+        (void)hipEventRecord(b, c->stream);
+        c->pending.push_back({kind, a, b});
+    }
+};
+
+// called after a stream synchronisation: fold finished event pairs into the totals
+void prof_collect(rship_ctx* c) {
+    for (auto& pd : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pd.a, pd.b) == hipSuccess) {
+            c->launches[pd.kind] += 1;
+            c->total_ms[pd.kind] += (double)ms;
+        }
+        c->pool.push_back(pd.a);
+        c->pool.push_back(pd.b);
+    }
+    c->pending.clear();
+}
+
+int sync_stream(rship_ctx* c) {
+    RS_HIP(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return 0;
+}
+
+int rpt_for(uint32_t max_n) {
+    int rpt = 1;
+    while ((uint32_t)rpt * kBlock < max_n) rpt *= 2;
+    return rpt;
+}
+
+constexpr int kMaxRpt = 8;
+
+uint32_t sel_max_n(const rship_ctx* c) {
+    uint32_t m = 0;
+    for (uint32_t i : c->h_sel) m = c->h_frame_n[i] > m ? c->h_frame_n[i] : m;
+    return m;
+}
+
+template <int MODE>
+int launch_lmeds(rship_ctx* c, const LmedsParams& p, int rpt, uint32_t grid) {
+    ProfScope ps(c, RSHIP_K_LMEDS);
+    switch (rpt) {
+        case 1: hipLaunchKernelGGL((lmeds_kernel<1, MODE>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+        case 2: hipLaunchKernelGGL((lmeds_kernel<2, MODE>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+        case 4: hipLaunchKernelGGL((lmeds_kernel<4, MODE>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+        case 8: hipLaunchKernelGGL((lmeds_kernel<8, MODE>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+        default: return set_err(c, "lmeds: unsupported rows-per-thread");
+    }
+    RS_HIP(hipGetLastError());
+    return 0;
+}
+
+template <bool GRAD>
+int launch_loss(rship_ctx* c, const LossParams& p, int rpt) {
+    ProfScope ps(c, RSHIP_K_LOSS);
+    switch (rpt) {
+        case 1: hipLaunchKernelGGL((loss_kernel<1, GRAD>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        case 2: hipLaunchKernelGGL((loss_kernel<2, GRAD>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        case 4: hipLaunchKernelGGL((loss_kernel<4, GRAD>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        case 8: hipLaunchKernelGGL((loss_kernel<8, GRAD>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        default: return set_err(c, "loss: unsupported rows-per-thread");
+    }
+    RS_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_motion(rship_ctx* c, const MotionParams& p, int rpt) {
+    ProfScope ps(c, RSHIP_K_MOTION);
+    switch (rpt) {
+        case 1: hipLaunchKernelGGL((opt_motion_kernel<1>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        case 2: hipLaunchKernelGGL((opt_motion_kernel<2>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        case 4: hipLaunchKernelGGL((opt_motion_kernel<4>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        case 8: hipLaunchKernelGGL((opt_motion_kernel<8>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        default: return set_err(c, "motion: unsupported rows-per-thread");
+    }
+    RS_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_reduce(rship_ctx* c, const double* in, double* out, uint32_t rows, uint32_t cols) {
+    ProfScope ps(c, RSHIP_K_REDUCE);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(rows), dim3(kBlock), 0, c->stream, in, out, cols);
+    RS_HIP(hipGetLastError());
+    return 0;
+}
+
+int check_ready(rship_ctx* c) {
+    if (!c->n_knots) return set_err(c, "no gyro spline uploaded");
+    if (!c->n_frames) return set_err(c, "no frames uploaded");
+    if (!c->n_sel) return set_err(c, "no frames selected");
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int rship_max_tracks(void) { return kMaxRpt * kBlock; }
+
+int rship_create(rship_ctx** out, int device) {
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return 2; // no GPU: the product path has no CPU fallback
+    rship_ctx* c = new rship_ctx();
+    if (device >= 0) {
+        e = hipSetDevice(device);
+        if (e != hipSuccess) { delete c; return 3; }
+        c->device = device;
+    } else {
+        (void)hipGetDevice(&c->device);
+    }
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return 4; }
+    c->stream = c->own_stream;
+    *out = c;
+    return 0;
+}
+
+void rship_destroy(rship_ctx* c) {
+    if (!c) return;
+    (void)hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    DevBuf* bufs[] = {&c->coef, &c->rays_a, &c->rays_b, &c->frames, &c->sel, &c->M, &c->k, &c->kd, &c->fd,
+                      &c->frame_cost, &c->best_h, &c->costs, &c->part, &c->flags, &c->stats};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char* rship_last_error(const rship_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int rship_set_stream(rship_ctx* c, void* hip_stream) {
+    RS_HIP(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return 0;
+}
+
+int rship_upload_spline(rship_ctx* c, const float* coef16, uint32_t n_knots, double sample_rate) {
+    if (n_knots < 2) return set_err(c, "spline: need >= 2 knots");
+    size_t bytes = (size_t)n_knots * 64;
+    if (ensure(c, c->coef, bytes)) return 1;
+    RS_HIP(hipMemcpyAsync(c->coef.p, coef16, bytes, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipStreamSynchronize(c->stream));
+    c->n_knots = n_knots;
+    c->fs = sample_rate;
+    return 0;
+}
+
+int rship_upload_frames(rship_ctx* c, const float* rays_a4, const float* rays_b4, uint64_t total_rays,
+                        const rship_frame* table, uint32_t n_frames) {
+    c->n_frames = 0;
+    c->n_sel = 0;
+    c->h_sel.clear();
+    c->h_frame_n.assign(n_frames, 0);
+    for (uint32_t i = 0; i < n_frames; ++i) {
+        if ((uint64_t)table[i].ray_offset + table[i].n_rays > total_rays) return set_err(c, "frame table exceeds ray buffer");
+        if (table[i].n_rays > (uint32_t)rship_max_tracks())
+            return set_err(c, "frame has more tracks than the kernels accept (" + std::to_string(rship_max_tracks()) + ")");
+        c->h_frame_n[i] = table[i].n_rays;
+    }
+    size_t rb = (size_t)total_rays * 16;
+    if (ensure(c, c->rays_a, rb ? rb : 16) || ensure(c, c->rays_b, rb ? rb : 16)) return 1;
+    if (ensure(c, c->frames, (size_t)n_frames * sizeof(rship_frame) + 32)) return 1;
+    if (ensure(c, c->M, (size_t)n_frames * 24 + 24) || ensure(c, c->k, (size_t)n_frames * 8 + 8)) return 1;
+    if (rb) {
+        RS_HIP(hipMemcpyAsync(c->rays_a.p, rays_a4, rb, hipMemcpyHostToDevice, c->stream));
+        RS_HIP(hipMemcpyAsync(c->rays_b.p, rays_b4, rb, hipMemcpyHostToDevice, c->stream));
+    }
+    if (n_frames) RS_HIP(hipMemcpyAsync(c->frames.p, table, (size_t)n_frames * sizeof(rship_frame), hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemsetAsync(c->M.p, 0, (size_t)n_frames * 24 + 24, c->stream));
+    RS_HIP(hipMemsetAsync(c->k.p, 0, (size_t)n_frames * 8 + 8, c->stream));
+    RS_HIP(hipStreamSynchronize(c->stream));
+    c->n_frames = n_frames;
+    c->total_rays = total_rays;
+    return 0;
+}
+
+int rship_select_frames(rship_ctx* c, const uint32_t* idx, uint32_t n) {
+    for (uint32_t i = 0; i < n; ++i)
+        if (idx[i] >= c->n_frames) return set_err(c, "select: frame index out of range");
+    if (ensure(c, c->sel, (size_t)n * 4 + 4)) return 1;
+    if (n) RS_HIP(hipMemcpyAsync(c->sel.p, idx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipStreamSynchronize(c->stream));
+    c->h_sel.assign(idx, idx + n);
+    c->n_sel = n;
+    c->max_n = sel_max_n(c);
+    return 0;
+}
+
+int rship_presync_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand, uint32_t n_hyp,
+                        uint32_t stream_base, uint64_t seed, double* costs, uint32_t* flags, double* frame_costs,
+                        int32_t* best_h) {
+    if (check_ready(c)) return 1;
+    if (!n_cand) return 0;
+    const uint32_t ns = c->n_sel;
+    if (ensure(c, c->kd, (size_t)n_cand * 4) || ensure(c, c->fd, (size_t)n_cand * 4)) return 1;
+    if (ensure(c, c->frame_cost, (size_t)n_cand * ns * 8) || ensure(c, c->costs, (size_t)n_cand * 8)) return 1;
+    if (best_h && ensure(c, c->best_h, (size_t)n_cand * ns * 4)) return 1;
+    if (ensure(c, c->flags, 16)) return 1;
+    RS_HIP(hipMemcpyAsync(c->kd.p, kd, (size_t)n_cand * 4, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemcpyAsync(c->fd.p, fd, (size_t)n_cand * 4, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemsetAsync(c->flags.p, 0, 16, c->stream));
+
+    LmedsParams p{};
+    p.rays_a = (const f4*)c->rays_a.p;
+    p.rays_b = (const f4*)c->rays_b.p;
+    p.frames = (const FrameRec*)c->frames.p;
+    p.sel = (const uint32_t*)c->sel.p;
+    p.n_sel = ns;
+    p.coef = (const f4*)c->coef.p;
+    p.n_knots = (int)c->n_knots;
+    p.kd = (const int32_t*)c->kd.p;
+    p.fd = (const float*)c->fd.p;
+    p.n_cand = n_cand;
+    // enough workgroups to fill 256 CUs several times over, chunks long enough to
+    // amortise the ray loads (registers) and the spline window (LDS)
+    uint64_t work = (uint64_t)n_cand * ns;
+    uint32_t chunk = (uint32_t)(work / 8192);
+    if (chunk < 1) chunk = 1;
+    if (chunk > 32) chunk = 32;
+    if (chunk > n_cand) chunk = n_cand;
+    p.chunk = chunk;
+    p.n_chunks = (n_cand + chunk - 1) / chunk;
+    p.n_hyp = n_hyp;
+    p.stream_base = stream_base;
+    p.seed = seed;
+    p.frame_cost = (double*)c->frame_cost.p;
+    p.best_h = best_h ? (int32_t*)c->best_h.p : nullptr;
+    p.flags = (uint32_t*)c->flags.p;
+    uint32_t groups = (ns + 7) / 8;
+    uint64_t grid = (uint64_t)groups * 8 * p.n_chunks;
+    if (grid > 0x7fffffffull) return set_err(c, "presync: grid too large");
+    if (launch_lmeds<0>(c, p, rpt_for(c->max_n), (uint32_t)grid)) return 1;
+    if (launch_reduce(c, p.frame_cost, (double*)c->costs.p, n_cand, ns)) return 1;
+
+    size_t need = (size_t)n_cand * 8 + 16;
+    if (ensure_pinned(c, need)) return 1;
+    RS_HIP(hipMemcpyAsync(c->pinned, c->costs.p, (size_t)n_cand * 8, hipMemcpyDeviceToHost, c->stream));
+    RS_HIP(hipMemcpyAsync((char*)c->pinned + (size_t)n_cand * 8, c->flags.p, 4, hipMemcpyDeviceToHost, c->stream));
+    if (sync_stream(c)) return 1;
+    memcpy(costs, c->pinned, (size_t)n_cand * 8);
+    if (flags) memcpy(flags, (char*)c->pinned + (size_t)n_cand * 8, 4);
+    if (frame_costs) RS_HIP(hipMemcpy(frame_costs, c->frame_cost.p, (size_t)n_cand * ns * 8, hipMemcpyDeviceToHost));
+    if (best_h) RS_HIP(hipMemcpy(best_h, c->best_h.p, (size_t)n_cand * ns * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rship_init_motion(rship_ctx* c, int32_t kd, float fd, uint32_t n_hyp, uint32_t stream, uint64_t seed) {
+    if (check_ready(c)) return 1;
+    if (ensure(c, c->kd, 4) || ensure(c, c->fd, 4) || ensure(c, c->flags, 16)) return 1;
+    RS_HIP(hipMemcpyAsync(c->kd.p, &kd, 4, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemcpyAsync(c->fd.p, &fd, 4, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemsetAsync(c->flags.p, 0, 16, c->stream));
+    LmedsParams p{};
+    p.rays_a = (const f4*)c->rays_a.p;
+    p.rays_b = (const f4*)c->rays_b.p;
+    p.frames = (const FrameRec*)c->frames.p;
+    p.sel = (const uint32_t*)c->sel.p;
+    p.n_sel = c->n_sel;
+    p.coef = (const f4*)c->coef.p;
+    p.n_knots = (int)c->n_knots;
+    p.kd = (const int32_t*)c->kd.p;
+    p.fd = (const float*)c->fd.p;
+    p.n_cand = 1;
+    p.chunk = 1;
+    p.n_chunks = 1;
+    p.n_hyp = n_hyp;
+    p.stream_base = stream;
+    p.seed = seed;
+    p.M = (double*)c->M.p;
+    p.k = (double*)c->k.p;
+    p.flags = (uint32_t*)c->flags.p;
+    uint32_t groups = (c->n_sel + 7) / 8;
+    if (launch_lmeds<1>(c, p, rpt_for(c->max_n), groups * 8)) return 1;
+    return sync_stream(c);
+}
+
+int rship_opt_motion(rship_ctx* c, int32_t kd, float fd, uint64_t* stats) {
+    if (check_ready(c)) return 1;
+    if (ensure(c, c->stats, 16)) return 1;
+    RS_HIP(hipMemsetAsync(c->stats.p, 0, 16, c->stream));
+    MotionParams p{};
+    p.rays_a = (const f4*)c->rays_a.p;
+    p.rays_b = (const f4*)c->rays_b.p;
+    p.frames = (const FrameRec*)c->frames.p;
+    p.sel = (const uint32_t*)c->sel.p;
+    p.n_sel = c->n_sel;
+    p.coef = (const f4*)c->coef.p;
+    p.n_knots = (int)c->n_knots;
+    p.kd = kd;
+    p.fd = fd;
+    p.M = (double*)c->M.p;
+    p.k = (const double*)c->k.p;
+    p.stats = (unsigned long long*)c->stats.p;
+    if (launch_motion(c, p, rpt_for(c->max_n))) return 1;
+    if (stats) {
+        if (ensure_pinned(c, 16)) return 1;
+        RS_HIP(hipMemcpyAsync(c->pinned, c->stats.p, 16, hipMemcpyDeviceToHost, c->stream));
+        if (sync_stream(c)) return 1;
+        memcpy(stats, c->pinned, 16);
+        return 0;
+    }
+    return 0; // stays queued: the next loss call is ordered behind it on the stream
+}
+
+int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_delays, double* loss, double* grad) {
+    if (check_ready(c)) return 1;
+    if (!n_delays) return 0;
+    const uint32_t ns = c->n_sel;
+    if (ensure(c, c->kd, (size_t)n_delays * 4) || ensure(c, c->fd, (size_t)n_delays * 4)) return 1;
+    if (ensure(c, c->part, (size_t)n_delays * ns * 16) || ensure(c, c->costs, (size_t)n_delays * 16)) return 1;
+    RS_HIP(hipMemcpyAsync(c->kd.p, kd, (size_t)n_delays * 4, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemcpyAsync(c->fd.p, fd, (size_t)n_delays * 4, hipMemcpyHostToDevice, c->stream));
+    LossParams p{};
+    p.rays_a = (const f4*)c->rays_a.p;
+    p.rays_b = (const f4*)c->rays_b.p;
+    p.frames = (const FrameRec*)c->frames.p;
+    p.sel = (const uint32_t*)c->sel.p;
+    p.n_sel = ns;
+    p.coef = (const f4*)c->coef.p;
+    p.n_knots = (int)c->n_knots;
+    p.fs = (float)c->fs;
+    p.kd = (const int32_t*)c->kd.p;
+    p.fd = (const float*)c->fd.p;
+    p.n_delays = n_delays;
+    p.M = (const double*)c->M.p;
+    p.k = (const double*)c->k.p;
+    p.part_loss = (double*)c->part.p;
+    p.part_grad = p.part_loss + (size_t)n_delays * ns;
+    const int rpt = rpt_for(c->max_n);
+    if (grad ? launch_loss<true>(c, p, rpt) : launch_loss<false>(c, p, rpt)) return 1;
+    // rows [0, n_delays) = loss, [n_delays, 2 n_delays) = grad
+    uint32_t rows = grad ? 2 * n_delays : n_delays;
+    if (launch_reduce(c, p.part_loss, (double*)c->costs.p, rows, ns)) return 1;
+    if (ensure_pinned(c, (size_t)rows * 8)) return 1;
+    RS_HIP(hipMemcpyAsync(c->pinned, c->costs.p, (size_t)rows * 8, hipMemcpyDeviceToHost, c->stream));
+    if (sync_stream(c)) return 1;
+    memcpy(loss, c->pinned, (size_t)n_delays * 8);
+    if (grad) memcpy(grad, (char*)c->pinned + (size_t)n_delays * 8, (size_t)n_delays * 8);
+    return 0;
+}
+
+int rship_get_motion(rship_ctx* c, double* M, double* k, uint32_t cap, uint32_t* n) {
+    if (sync_stream(c)) return 1;
+    std::vector<double> hM((size_t)c->n_frames * 3 + 3), hk((size_t)c->n_frames + 1);
+    if (c->n_frames) {
+        RS_HIP(hipMemcpy(hM.data(), c->M.p, (size_t)c->n_frames * 24, hipMemcpyDeviceToHost));
+        RS_HIP(hipMemcpy(hk.data(), c->k.p, (size_t)c->n_frames * 8, hipMemcpyDeviceToHost));
+    }
+    uint32_t cnt = 0;
+    for (uint32_t i = 0; i < c->n_sel && cnt < cap; ++i, ++cnt) {
+        uint32_t fi = c->h_sel[i];
+        M[3 * cnt] = hM[3 * fi]; M[3 * cnt + 1] = hM[3 * fi + 1]; M[3 * cnt + 2] = hM[3 * fi + 2];
+        k[cnt] = hk[fi];
+    }
+    if (n) *n = cnt;
+    return 0;
+}
+
+int rship_set_motion(rship_ctx* c, const double* M, const double* k, uint32_t n) {
+    if (n != c->n_sel) return set_err(c, "set_motion: count differs from the selection");
+    if (sync_stream(c)) return 1;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t fi = c->h_sel[i];
+        RS_HIP(hipMemcpy((double*)c->M.p + 3 * (size_t)fi, M + 3 * i, 24, hipMemcpyHostToDevice));
+        RS_HIP(hipMemcpy((double*)c->k.p + fi, k + i, 8, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+int rship_debug_problem(rship_ctx* c, uint32_t sel_index, int32_t kd, float fd, float* P, float* dP, uint32_t cap_rows) {
+    if (check_ready(c)) return 1;
+    if (sel_index >= c->n_sel) return set_err(c, "debug_problem: index out of range");
+    uint32_t fi = c->h_sel[sel_index];
+    uint32_t n = c->h_frame_n[fi];
+    if (n > cap_rows) return set_err(c, "debug_problem: output too small");
+    DevBuf out;
+    if (ensure(c, out, (size_t)n * 24 + 64)) return 1;
+    DebugParams p{};
+    p.rays_a = (const f4*)c->rays_a.p;
+    p.rays_b = (const f4*)c->rays_b.p;
+    p.frames = (const FrameRec*)c->frames.p;
+    p.fi = fi;
+    p.coef = (const f4*)c->coef.p;
+    p.n_knots = (int)c->n_knots;
+    p.fs = (float)c->fs;
+    p.kd = kd;
+    p.fd = fd;
+    p.P = (float*)out.p;
+    p.dP = dP ? (float*)out.p + (size_t)n * 3 : nullptr;
+    hipLaunchKernelGGL(debug_problem_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(P, out.p, (size_t)n * 12, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && dP) e = hipMemcpy(dP, (float*)out.p + (size_t)n * 3, (size_t)n * 12, hipMemcpyDeviceToHost);
+    (void)hipFree(out.p);
+    if (e != hipSuccess) return set_err(c, "debug_problem", e);
+    return 0;
+}
+
+int rship_profile_enable(rship_ctx* c, int on) {
+    if (sync_stream(c)) return 1;
+    c->prof = on != 0;
+    return 0;
+}
+
+int rship_profile_get(rship_ctx* c, int kind, uint64_t* launches, double* total_ms) {
+    if (kind < 0 || kind >= RSHIP_K_COUNT) return set_err(c, "profile: bad kind");
+    if (sync_stream(c)) return 1;
+    if (launches) *launches = c->launches[kind];
+    if (total_ms) *total_ms = c->total_ms[kind];
+    return 0;
+}
+
+int rship_profile_reset(rship_ctx* c) {
+    if (sync_stream(c)) return 1;
+    for (int i = 0; i < RSHIP_K_COUNT; ++i) { c->launches[i] = 0; c->total_ms[i] = 0; }
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,743 @@
+// sync_problem.cpp -- host side of librssync_core.so: the ISyncProblem
+// implementation that drives the gfx950 kernels through rssync_hip.h, and the
+// flat C-ABI of rssync_c.h.
+//
+// What stays on the host, and why (DESIGN.md "Host / device split"):
+//   * the gyro spline solve (O(G), sequential recurrence) and the integer-microsecond
+//     resampling of timestamped gyro data (exact integer arithmetic);
+//   * fp64 copies of the tracks, their packing into the device layout, and the split of
+//     every time into integer knot + fp32 fraction;
+//   * the optimiser control flow of Sync (backtracking, momentum, convergence counters),
+//     which consumes a handful of reduced doubles per step.
+// Everything that touches rays runs on the device; there is no CPU fallback.
+//
+// Reference (VladimirP1/rs-sync, src/) counterparts are cited per function.
+#include "../../include/rssync.h"
+#include "../../include/rssync_c.h"
+#include "../../include/rssync_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// error convention: core_support/panic.cpp:7-15
+
+struct PanicError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+int g_panic_mode = 0; // 0 = reference behaviour, 1 = throw (caught by the C-ABI)
+thread_local std::string g_last_error;
+
+[[noreturn]] void panic(const std::string& reason) {
+    if (g_panic_mode == 1) throw PanicError(reason);
+    {
+        std::ofstream out("panic.txt");
+        out << reason << std::endl;
+    }
+    std::cerr << "rssync panic: " << reason << std::endl;
+    std::exit(1);
+}
+
+bool all_finite(const double* v, size_t n) {
+    for (size_t i = 0; i < n; ++i)
+        if (!std::isfinite(v[i])) return false;
+    return true;
+}
+
+constexpr uint32_t kStreamSyncInit = 0x80000000u; // sampler stream of Sync's GuessMotion (+ call counter)
+constexpr uint32_t kStreamDebug = 0x40000000u;    // sampler streams of DebugPreSync (+ point index)
+constexpr int32_t kKnotClamp = 1 << 29;
+
+// delay (s) -> device representation: delay * fs = kd + fd, kd integer, fd in [0,1)
+struct DelaySplit {
+    int32_t kd;
+    float fd;
+};
+
+DelaySplit split_delay(double delay, double fs) {
+    double D = delay * fs;
+    if (!std::isfinite(D)) return {0, 0.f};
+    double fl = std::floor(D);
+    float fd = (float)(D - fl);
+    if (fd >= 1.0f) { fd = 0.f; fl += 1.0; }
+    if (fl > (double)kKnotClamp) fl = (double)kKnotClamp;
+    if (fl < -(double)kKnotClamp) fl = -(double)kKnotClamp;
+    return {(int32_t)fl, fd};
+}
+
+// quat.cpp:55-74 (only used by the timestamped gyro setter)
+void quat_slerp(const double* p, const double* q_in, double t, double* out) {
+    double q[4] = {q_in[0], q_in[1], q_in[2], q_in[3]};
+    double d = p[0] * q[0] + p[1] * q[1] + p[2] * q[2] + p[3] * q[3];
+    if (d < 0) {
+        for (double& v : q) v = -v;
+        d = p[0] * q[0] + p[1] * q[1] + p[2] * q[2] + p[3] * q[3];
+    }
+    const double theta = std::acos(d); // unclamped: NaN falls through to the lerp branch
+    double m1 = 1 - t, m2 = t;
+    if (theta > 1e-9) {
+        const double st = std::sin(theta);
+        m1 = std::sin((1 - t) * theta) / st;
+        m2 = std::sin(t * theta) / st;
+    }
+    for (int i = 0; i < 4; ++i) out[i] = m1 * p[i] + m2 * q[i];
+}
+
+struct HostFrame { // core_private.hpp:8-13 (FrameData), copied at SetTrackResult time
+    std::vector<double> ts_a, ts_b, rays_a, rays_b;
+};
+
+class SyncProblemHip final : public ISyncProblem {
+   public:
+    SyncProblemHip();
+    ~SyncProblemHip() override;
+
+    void SetGyroQuaternions(const double* data, size_t count, double sample_rate,
+                            double first_timestamp) override;
+    void SetGyroQuaternions(const int64_t* timestamps_us, const double* quats, size_t count) override;
+    void SetTrackResult(int64_t frame, const double* ts_a, const double* ts_b, const double* rays_a,
+                        const double* rays_b, size_t count) override;
+    std::pair<double, double> PreSync(double initial_delay, int64_t frame_begin, int64_t frame_end,
+                                      double search_step, double search_radius) override;
+    std::pair<double, double> Sync(double initial_delay, int64_t frame_begin, int64_t frame_end,
+                                   double search_center, double search_radius) override;
+    void DebugPreSync(double initial_delay, int64_t frame_begin, int64_t frame_end, double search_radius,
+                      double* delays, double* costs, int point_count) override;
+
+    // extension state (rssync_c.h)
+    uint64_t seed = 0x5EED0000ULL;
+    int max_outer = 400; // core_private.cpp:309
+    bool verbose = true;
+    rssync_reduce_fn reduce_fn = nullptr;
+    void* reduce_user = nullptr;
+    std::vector<double> trace; // 6 doubles per outer iteration of the last Sync
+
+    double sample_rate() const { return fs_; }
+    double quats_start() const { return start_; }
+    const std::vector<double>& knots() const { return knots_; }
+    rship_ctx* dev() { return dev_; }
+
+    // pieces shared by the public calls and the diagnostics
+    void ensure_device();
+    uint32_t select(int64_t begin, int64_t end_exclusive);
+    std::vector<double> sweep(const std::vector<double>& delays, uint32_t stream_base, bool panics,
+                              double* frame_costs, int32_t* best_h);
+    void init_motion(double delay);
+    void opt_motion(double delay, uint64_t* stats);
+    void loss(const std::vector<double>& delays, std::vector<double>& out_loss, std::vector<double>* out_grad);
+    void reduce(double* buf, size_t n) {
+        if (reduce_fn) reduce_fn(buf, n, reduce_user);
+    }
+    const std::vector<uint32_t>& selection() const { return sel_; }
+    int64_t table_id(uint32_t i) const { return table_ids_[i]; }
+    bool has_frame(int64_t id) const { return frames_.count(id) != 0; }
+    size_t frame_tracks(int64_t id) const { return frames_.at(id).ts_a.size(); }
+    uint32_t sync_calls = 0;
+
+   private:
+    void hip_check(int rc, const char* what) {
+        if (rc) panic(std::string("hip: ") + what + ": " + (dev_ ? rship_last_error(dev_) : "no context"));
+    }
+    void build_spline();
+    void pack_frames();
+
+    double fs_ = 0, start_ = 0;
+    std::vector<double> knots_; // 4 per sample, [w,x,y,z]
+    std::map<int64_t, HostFrame> frames_;
+    rship_ctx* dev_ = nullptr;
+    bool spline_dirty_ = true, frames_dirty_ = true;
+    std::vector<int64_t> table_ids_;
+    std::vector<uint32_t> sel_;
+};
+
+SyncProblemHip::SyncProblemHip() {
+    if (const char* s = std::getenv("RSSYNC_SEED")) seed = std::strtoull(s, nullptr, 0);
+    if (const char* s = std::getenv("RSSYNC_MAX_OUTER_ITERS")) max_outer = std::atoi(s);
+    if (const char* s = std::getenv("RSSYNC_QUIET")) verbose = !(s[0] && s[0] != '0');
+    int rc = rship_create(&dev_, -1);
+    if (rc) panic("rssync: no usable HIP device (rship_create failed with " + std::to_string(rc) +
+                  "); this library has no CPU fallback");
+}
+
+SyncProblemHip::~SyncProblemHip() { rship_destroy(dev_); }
+
+// core_private.cpp:135-140
+void SyncProblemHip::SetGyroQuaternions(const double* data, size_t count, double sample_rate,
+                                        double first_timestamp) {
+    if (count < 2) panic("set-gyro-quaternions: need at least 2 samples");
+    if (fs_ != sample_rate || start_ != first_timestamp) frames_dirty_ = true; // ray offsets depend on both
+    fs_ = sample_rate;
+    start_ = first_timestamp;
+    knots_.assign(data, data + 4 * count);
+    spline_dirty_ = true;
+}
+
+// core_private.cpp:142-190.  The grid is computed in the reference's integer types:
+// rate in micro-hertz and grid times in microseconds as uint64, first grid index by a
+// truncating division (the std::ceil at :152 is applied to an integer).
+void SyncProblemHip::SetGyroQuaternions(const int64_t* ts, const double* quats, size_t count) {
+    constexpr uint64_t kUhzInHz = 1000000ULL, kUsInSec = 1000000ULL;
+    if (count < 2) panic("set-gyro-quaternions: need at least 2 samples");
+    const uint64_t actual_sr_uhz = kUhzInHz * kUsInSec * (uint64_t)count / (uint64_t)(ts[count - 1] - ts[0]);
+    const int rounded_sr_hz = (int)(std::round((double)actual_sr_uhz / 50. / (double)kUhzInHz) * 50);
+    if (rounded_sr_hz <= 0) panic("set-gyro-quaternions: non-finite sample rate. wtf?");
+    std::vector<uint64_t> grid;
+    for (int sample = (int)((uint64_t)(ts[0] * rounded_sr_hz) / kUsInSec);
+         kUsInSec * (uint64_t)sample / (uint64_t)rounded_sr_hz < (uint64_t)ts[count - 1]; ++sample)
+        grid.push_back(kUsInSec * (uint64_t)sample / (uint64_t)rounded_sr_hz);
+    for (size_t i = 1; i < count; ++i)
+        if (ts[i - 1] > ts[i])
+            panic("set-gyro-quaternions:  timestamps out of order at pos " + std::to_string(i) + " (" +
+                  std::to_string(ts[i - 1]) + " > " + std::to_string(ts[i]) + ")");
+    if (grid.size() < 2) panic("set-gyro-quaternions: resampled grid has fewer than 2 points");
+    std::vector<double> nq(4 * grid.size());
+    for (size_t i = 0; i < grid.size(); ++i) {
+        const uint64_t t = grid[i];
+        // first sample whose (unsigned) timestamp is >= t
+        size_t idx = std::lower_bound(ts, ts + count, t, [](int64_t a, uint64_t b) { return (uint64_t)a < b; }) - ts;
+        if (idx > 0) {
+            double u = 1. * (double)(t - (uint64_t)ts[idx - 1]) / (double)(ts[idx] - ts[idx - 1]);
+            quat_slerp(quats + 4 * (idx - 1), quats + 4 * idx, u, &nq[4 * i]);
+        } else {
+            std::copy(quats, quats + 4, &nq[4 * i]);
+        }
+        if (!all_finite(&nq[4 * i], 4)) panic("set-gyro-quaternions: non-finite sample after interpolation");
+    }
+    const double new_fs = 1. * rounded_sr_hz, new_start = 1. * (double)grid[0] / (double)kUsInSec;
+    if (!std::isfinite(new_fs)) panic("set-gyro-quaternions: non-finite sample rate. wtf?");
+    if (!std::isfinite(new_start)) panic("set-gyro-quaternions: non-finite first timestamp. wtf?");
+    if (fs_ != new_fs || start_ != new_start) frames_dirty_ = true;
+    fs_ = new_fs;
+    start_ = new_start;
+    knots_.swap(nq);
+    spline_dirty_ = true;
+}
+
+// core_private.cpp:192-203; the data is copied before returning
+void SyncProblemHip::SetTrackResult(int64_t frame, const double* ts_a, const double* ts_b, const double* rays_a,
+                                    const double* rays_b, size_t count) {
+    if (!all_finite(rays_a, 3 * count)) panic("set-track-result: non-finite numbers in rays_a");
+    if (!all_finite(rays_b, 3 * count)) panic("set-track-result: non-finite numbers in rays_b");
+    if (!all_finite(ts_a, count)) panic("set-track-result: non-finite numbers in ts_a");
+    if (!all_finite(ts_b, count)) panic("set-track-result: non-finite numbers in ts_b");
+    if (count > (size_t)rship_max_tracks())
+        panic("set-track-result: " + std::to_string(count) + " tracks in one frame; this build accepts at most " +
+              std::to_string(rship_max_tracks()));
+    HostFrame& f = frames_[frame];
+    f.ts_a.assign(ts_a, ts_a + count);
+    f.ts_b.assign(ts_b, ts_b + count);
+    f.rays_a.assign(rays_a, rays_a + 3 * count);
+    f.rays_b.assign(rays_b, rays_b + 3 * count);
+    frames_dirty_ = true;
+}
+
+// Natural cubic spline on unit-spaced knots, one per quaternion component
+// (replaces minispline.cpp:3-46 / ndspline.cpp:13-19).  Interior equations
+//   c[i-1]/3 + 4 c[i]/3 + c[i+1]/3 = y[i+1] - 2 y[i] + y[i-1],  c[0] = c[n-1] = 0,
+// solved by the Thomas recurrence in fp64, then d, b and the tail coefficients the
+// reference's extrapolation uses (minispline.cpp:43-44).  The table is rounded to fp32
+// once, here: 16 floats per knot = y[4], b[4], c[4], d[4].
+void SyncProblemHip::build_spline() {
+    const size_t n = knots_.size() / 4;
+    if (n < 2) panic("sync: gyro data was not set");
+    std::vector<float> coef(n * 16);
+    std::vector<double> c(n), cp(n), y(n);
+    for (int comp = 0; comp < 4; ++comp) {
+        for (size_t i = 0; i < n; ++i) y[i] = knots_[4 * i + comp];
+        // forward sweep on rows 1..n-2 (rows 0 and n-1 pin c to zero)
+        cp[0] = 0.0;
+        c[0] = 0.0;
+        for (size_t i = 1; i + 1 < n; ++i) {
+            const double rhs = y[i + 1] - 2.0 * y[i] + y[i - 1];
+            const double denom = 4.0 / 3.0 - cp[i - 1] / 3.0;
+            cp[i] = (1.0 / 3.0) / denom;
+            c[i] = (rhs - c[i - 1] / 3.0) / denom;
+        }
+        c[n - 1] = 0.0;
+        for (size_t i = n - 1; i-- > 1;) c[i] -= cp[i] * c[i + 1];
+        double b_prev = 0, d_prev = 0;
+        for (size_t i = 0; i < n; ++i) {
+            double b, d;
+            if (i + 1 < n) {
+                d = (c[i + 1] - c[i]) / 3.0;
+                b = (y[i + 1] - y[i]) - (2.0 * c[i] + c[i + 1]) / 3.0;
+            } else {
+                d = 0.0;
+                b = 3.0 * d_prev + 2.0 * c[n - 2] + b_prev;
+            }
+            float* row = &coef[16 * i];
+            row[0 + comp] = (float)y[i];
+            row[4 + comp] = (float)b;
+            row[8 + comp] = (float)c[i];
+            row[12 + comp] = (float)d;
+            b_prev = b;
+            d_prev = d;
+        }
+    }
+    hip_check(rship_upload_spline(dev_, coef.data(), (uint32_t)n, fs_), "upload spline");
+    spline_dirty_ = false;
+}
+
+// Device layout of OptData::frame_data (core_private.hpp:21): two float4 streams
+// {ax,ay,az,ta} / {bx,by,bz,tb}, frames in ascending id order.  ta/tb carry the spline
+// parameter (ts - start) * fs (core_private.cpp:19-20 without the delay) relative to the
+// frame's integer base knot, so fp32 only ever holds a span of a few tens of knots.
+void SyncProblemHip::pack_frames() {
+    size_t total = 0;
+    for (auto& [id, f] : frames_) total += f.ts_a.size();
+    if (total > 0xffffffffull) panic("sync: more than 2^32 rays");
+    std::vector<float> a4(total * 4 + 4), b4(total * 4 + 4);
+    std::vector<rship_frame> table;
+    table.reserve(frames_.size());
+    table_ids_.clear();
+    size_t off = 0;
+    for (auto& [id, f] : frames_) {
+        const size_t n = f.ts_a.size();
+        double xmin = std::numeric_limits<double>::infinity();
+        for (size_t i = 0; i < n; ++i) {
+            xmin = std::min(xmin, (f.ts_a[i] - start_) * fs_);
+            xmin = std::min(xmin, (f.ts_b[i] - start_) * fs_);
+        }
+        double base = n ? std::floor(xmin) : 0.0;
+        if (!(base > -(double)kKnotClamp)) base = -(double)kKnotClamp;
+        if (base > (double)kKnotClamp) base = (double)kKnotClamp;
+        rship_frame rec{};
+        rec.ray_offset = (uint32_t)off;
+        rec.n_rays = (uint32_t)n;
+        rec.base_knot = (int32_t)base;
+        rec.id = id;
+        float tmin = 0.f, tmax = 0.f;
+        for (size_t i = 0; i < n; ++i) {
+            const float ta = (float)((f.ts_a[i] - start_) * fs_ - base);
+            const float tb = (float)((f.ts_b[i] - start_) * fs_ - base);
+            float* pa = &a4[4 * (off + i)];
+            float* pb = &b4[4 * (off + i)];
+            pa[0] = (float)f.rays_a[3 * i]; pa[1] = (float)f.rays_a[3 * i + 1]; pa[2] = (float)f.rays_a[3 * i + 2]; pa[3] = ta;
+            pb[0] = (float)f.rays_b[3 * i]; pb[1] = (float)f.rays_b[3 * i + 1]; pb[2] = (float)f.rays_b[3 * i + 2]; pb[3] = tb;
+            if (i == 0) { tmin = std::min(ta, tb); tmax = std::max(ta, tb); }
+            tmin = std::min(tmin, std::min(ta, tb));
+            tmax = std::max(tmax, std::max(ta, tb));
+        }
+        rec.tmin = tmin;
+        rec.tmax = tmax;
+        table.push_back(rec);
+        table_ids_.push_back(id);
+        off += n;
+    }
+    hip_check(rship_upload_frames(dev_, a4.data(), b4.data(), total, table.data(), (uint32_t)table.size()),
+              "upload frames");
+    sel_.clear();
+    frames_dirty_ = false;
+}
+
+void SyncProblemHip::ensure_device() {
+    if (knots_.size() < 8) panic("sync: gyro data was not set");
+    if (spline_dirty_) build_spline();
+    if (frames_dirty_) pack_frames();
+}
+
+// frame filters of core_private.cpp:65-68 / :218-219 / :340-343 on the sorted table
+uint32_t SyncProblemHip::select(int64_t begin, int64_t end_exclusive) {
+    sel_.clear();
+    for (uint32_t i = 0; i < table_ids_.size(); ++i)
+        if (table_ids_[i] >= begin && table_ids_[i] < end_exclusive) sel_.push_back(i);
+    for (uint32_t i : sel_)
+        if (frames_.at(table_ids_[i]).ts_a.size() < 2)
+            panic("sync: frame " + std::to_string(table_ids_[i]) + " has fewer than 2 tracks");
+    hip_check(rship_select_frames(dev_, sel_.data(), (uint32_t)sel_.size()), "select frames");
+    return (uint32_t)sel_.size();
+}
+
+static const char* presync_panic(uint32_t flags) { // core_private.cpp:76-83, in the reference's order
+    if (flags & RSHIP_BAD_P) return "pre-sync: non-finite numbers in P";
+    if (flags & RSHIP_BAD_M) return "pre-sync: non-finite numbers in M";
+    if (flags & RSHIP_BAD_R) return "pre-sync: non-finite r";
+    if (flags & RSHIP_BAD_RHO) return "pre-sync: non-finite rho";
+    return nullptr;
+}
+
+// costs of a list of candidate delays on the current selection, summed over ranks
+std::vector<double> SyncProblemHip::sweep(const std::vector<double>& delays, uint32_t stream_base, bool panics,
+                                          double* frame_costs, int32_t* best_h) {
+    const size_t n = delays.size();
+    std::vector<double> costs(n + 1, 0.0); // last slot carries the status bits through the reduction
+    uint32_t flags = 0;
+    if (!sel_.empty() && n) {
+        std::vector<int32_t> kd(n);
+        std::vector<float> fd(n);
+        for (size_t i = 0; i < n; ++i) {
+            DelaySplit s = split_delay(delays[i], fs_);
+            kd[i] = s.kd;
+            fd[i] = s.fd;
+        }
+        hip_check(rship_presync_costs(dev_, kd.data(), fd.data(), (uint32_t)n, 20 /* core_private.cpp:77 */,
+                                      stream_base, seed, costs.data(), &flags, frame_costs, best_h),
+                  "presync costs");
+    }
+    // one exchange for the whole sweep; the flag bits ride along as small integers
+    double fl[4] = {(double)((flags >> 0) & 1), (double)((flags >> 1) & 1), (double)((flags >> 2) & 1),
+                    (double)((flags >> 3) & 1)};
+    if (reduce_fn) {
+        std::vector<double> buf(costs.begin(), costs.begin() + n);
+        buf.insert(buf.end(), fl, fl + 4);
+        reduce(buf.data(), buf.size());
+        std::copy(buf.begin(), buf.begin() + n, costs.begin());
+        std::copy(buf.begin() + n, buf.end(), fl);
+    }
+    if (panics) {
+        uint32_t all = (fl[0] > 0 ? 1u : 0u) | (fl[1] > 0 ? 2u : 0u) | (fl[2] > 0 ? 4u : 0u) | (fl[3] > 0 ? 8u : 0u);
+        if (const char* msg = presync_panic(all)) panic(msg);
+    }
+    costs.resize(n);
+    return costs;
+}
+
+// core_private.cpp:205-209 -> :61-90
+std::pair<double, double> SyncProblemHip::PreSync(double initial_delay, int64_t frame_begin, int64_t frame_end,
+                                                  double search_step, double search_radius) {
+    ensure_device();
+    select(frame_begin, frame_end);
+    std::vector<double> delays; // the candidates are whatever this double loop yields (:69-70)
+    for (double delay = initial_delay - search_radius; delay < initial_delay + search_radius; delay += search_step) {
+        delays.push_back(delay);
+        if (delays.size() > 50000000) panic("pre-sync: more than 5e7 candidate delays");
+    }
+    if (delays.empty()) panic("pre-sync: empty candidate list");
+    std::vector<double> costs = sweep(delays, 0, true, nullptr, nullptr);
+    size_t best = 0; // *std::min_element over pair(cost, delay) (:89)
+    for (size_t i = 1; i < costs.size(); ++i)
+        if (std::make_pair(costs[i], delays[i]) < std::make_pair(costs[best], delays[best])) best = i;
+    return {costs[best], delays[best]};
+}
+
+// core_private.cpp:336-361
+void SyncProblemHip::DebugPreSync(double initial_delay, int64_t frame_begin, int64_t frame_end, double search_radius,
+                                  double* delays, double* costs, int point_count) {
+    ensure_device();
+    select(frame_begin, frame_end);
+    std::vector<double> d((size_t)std::max(point_count, 0));
+    for (int i = 0; i < point_count; ++i)
+        d[i] = initial_delay - search_radius + 2 * search_radius * i / (point_count - 1); // :345
+    std::vector<double> c = sweep(d, kStreamDebug, false, nullptr, nullptr);
+    for (int i = 0; i < point_count; ++i) {
+        delays[i] = d[i];
+        costs[i] = c[i];
+    }
+}
+
+void SyncProblemHip::init_motion(double delay) {
+    if (sel_.empty()) return;
+    DelaySplit s = split_delay(delay, fs_);
+    hip_check(rship_init_motion(dev_, s.kd, s.fd, 200 /* core_private.cpp:127 */, kStreamSyncInit + sync_calls, seed),
+              "init motion");
+}
+
+void SyncProblemHip::opt_motion(double delay, uint64_t* stats) {
+    if (sel_.empty()) return;
+    DelaySplit s = split_delay(delay, fs_);
+    hip_check(rship_opt_motion(dev_, s.kd, s.fd, stats), "opt motion");
+}
+
+// sum over the selection (and over ranks) of FrameState::Loss at each delay
+void SyncProblemHip::loss(const std::vector<double>& delays, std::vector<double>& out_loss,
+                          std::vector<double>* out_grad) {
+    const size_t n = delays.size();
+    std::vector<double> buf(2 * n, 0.0);
+    if (!sel_.empty() && n) {
+        std::vector<int32_t> kd(n);
+        std::vector<float> fd(n);
+        for (size_t i = 0; i < n; ++i) {
+            DelaySplit s = split_delay(delays[i], fs_);
+            kd[i] = s.kd;
+            fd[i] = s.fd;
+        }
+        hip_check(rship_loss(dev_, kd.data(), fd.data(), (uint32_t)n, buf.data(), out_grad ? buf.data() + n : nullptr),
+                  "loss");
+    }
+    reduce(buf.data(), out_grad ? 2 * n : n);
+    out_loss.assign(buf.begin(), buf.begin() + n);
+    if (out_grad) out_grad->assign(buf.begin() + n, buf.end());
+}
+
+// core_private.cpp:211-334.  Differences from the reference's schedule, none of which
+// changes a value the reference would compute differently:
+//  * d(loss)/d(delay) is the analytic derivative, not the +-1e-6 s central difference
+//    (:96-97,112); they agree to ~1e-9 relative (tests/test_oracle_math.py);
+//  * the <= 10 backtracking trials (backtrack.cpp:7-11) are evaluated in one batched
+//    launch and the first that satisfies the Armijo test is taken, which is what the
+//    sequential loop returns;
+//  * P is computed once per motion optimisation, not three times per evaluation (:94-97).
+std::pair<double, double> SyncProblemHip::Sync(double initial_delay, int64_t frame_begin, int64_t frame_end,
+                                               double search_center, double search_radius) {
+    ensure_device();
+    select(frame_begin, frame_end == std::numeric_limits<int64_t>::max() ? frame_end : frame_end + 1); // :219 inclusive
+    double d = initial_delay;
+    init_motion(d); // :218-223
+    ++sync_calls;
+    trace.clear();
+
+    const double c_armijo = 2e-4, decay = .1, t0 = 1e-3; // :226
+    const int max_bt = 10;
+    const double delay_b = .3; // :260
+    double delay_v = 0;        // :261
+    int converge_counter = 0;
+    std::vector<double> l1, g1, lt, trial(max_bt);
+    for (int it = 0; it < max_outer; ++it) { // :309
+        opt_motion(d, nullptr);              // :311
+        // do_opt_delay (:298-305) -> Backtrack::Step (backtrack.cpp:3-13)
+        const double x0 = d - delay_b * delay_v;
+        loss({x0}, l1, &g1);
+        const double v = l1[0], p = g1[0];
+        const double m = p * p;
+        double t = t0;
+        std::vector<double> ts(max_bt);
+        for (int i = 0; i < max_bt; ++i) {
+            ts[i] = t;
+            trial[i] = x0 - t * p;
+            t *= decay;
+        }
+        loss(trial, lt, nullptr);
+        int trials = max_bt;
+        for (int i = 0; i < max_bt; ++i) {
+            if (v - lt[i] >= ts[i] * c_armijo * m) {
+                t = ts[i];
+                trials = i + 1;
+                break;
+            }
+        }
+        const double step = -t * p;
+        delay_v = delay_b * delay_v + step; // :301
+        d += delay_v;                       // :302
+        const double step_size = std::fabs(step);
+        const double row[6] = {d, step, v, p, t, (double)trials};
+        trace.insert(trace.end(), row, row + 6);
+        if (step_size < 1e-4) converge_counter++; else converge_counter = 0; // :316-320
+        if (converge_counter > 5) break;                                      // :322-324
+        if (std::fabs(d - search_center) > search_radius) break;              // :326-328
+        if (verbose) std::cerr << d << " " << step_size << std::endl;         // :330
+    }
+    loss({d}, l1, nullptr); // :333
+    return {l1[0], d};
+}
+
+} // namespace
+
+// core_private.cpp:363, :365
+ISyncProblem* CreateSyncProblem() { return new SyncProblemHip(); }
+ISyncProblem::~ISyncProblem() {}
+
+// ===========================================================================
+// flat C-ABI (rssync_c.h)
+
+struct rssync_problem {
+    ISyncProblem* iface;
+    SyncProblemHip* impl;
+};
+
+namespace {
+template <typename F>
+int guarded(F&& f) {
+    try {
+        f();
+        return 0;
+    } catch (const PanicError& e) {
+        g_last_error = e.what();
+        return 1;
+    } catch (const std::exception& e) {
+        g_last_error = std::string("exception: ") + e.what();
+        return 2;
+    }
+}
+} // namespace
+
+extern "C" {
+
+rssync_problem* rssync_create(void) {
+    rssync_problem* h = nullptr;
+    int saved = g_panic_mode;
+    g_panic_mode = 1; // a missing device is reported, not fatal, on this entry point
+    int rc = guarded([&] {
+        ISyncProblem* i = CreateSyncProblem();
+        h = new rssync_problem{i, static_cast<SyncProblemHip*>(i)};
+    });
+    g_panic_mode = saved;
+    return rc ? nullptr : h;
+}
+
+void rssync_destroy(rssync_problem* p) {
+    if (!p) return;
+    delete p->iface;
+    delete p;
+}
+
+const char* rssync_last_error(void) { return g_last_error.c_str(); }
+void rssync_set_panic_mode(int mode) { g_panic_mode = mode ? 1 : 0; }
+
+int rssync_set_gyro_quaternions(rssync_problem* p, const double* data, size_t count, double sample_rate,
+                                double first_timestamp) {
+    return guarded([&] { p->iface->SetGyroQuaternions(data, count, sample_rate, first_timestamp); });
+}
+int rssync_set_gyro_quaternions_ts(rssync_problem* p, const int64_t* timestamps_us, const double* quats, size_t count) {
+    return guarded([&] { p->iface->SetGyroQuaternions(timestamps_us, quats, count); });
+}
+int rssync_set_track_result(rssync_problem* p, int64_t frame, const double* ts_a, const double* ts_b,
+                            const double* rays_a, const double* rays_b, size_t count) {
+    return guarded([&] { p->iface->SetTrackResult(frame, ts_a, ts_b, rays_a, rays_b, count); });
+}
+int rssync_pre_sync(rssync_problem* p, double initial_delay, int64_t frame_begin, int64_t frame_end, double search_step,
+                    double search_radius, double* cost, double* delay) {
+    return guarded([&] {
+        auto r = p->iface->PreSync(initial_delay, frame_begin, frame_end, search_step, search_radius);
+        *cost = r.first;
+        *delay = r.second;
+    });
+}
+int rssync_sync(rssync_problem* p, double initial_delay, int64_t frame_begin, int64_t frame_end, double search_center,
+                double search_radius, double* cost, double* delay) {
+    return guarded([&] {
+        auto r = p->iface->Sync(initial_delay, frame_begin, frame_end, search_center, search_radius);
+        *cost = r.first;
+        *delay = r.second;
+    });
+}
+int rssync_debug_pre_sync(rssync_problem* p, double initial_delay, int64_t frame_begin, int64_t frame_end,
+                          double search_radius, double* delays, double* costs, int point_count) {
+    return guarded([&] {
+        p->iface->DebugPreSync(initial_delay, frame_begin, frame_end, search_radius, delays, costs, point_count);
+    });
+}
+
+int rssync_ext_set_seed(rssync_problem* p, uint64_t seed) { p->impl->seed = seed; return 0; }
+int rssync_ext_set_max_outer_iters(rssync_problem* p, int iters) { p->impl->max_outer = iters; return 0; }
+int rssync_ext_set_verbose(rssync_problem* p, int verbose) { p->impl->verbose = verbose != 0; return 0; }
+int rssync_ext_set_stream(rssync_problem* p, void* hip_stream) {
+    return guarded([&] {
+        if (rship_set_stream(p->impl->dev(), hip_stream)) panic(std::string("hip: set stream: ") + rship_last_error(p->impl->dev()));
+    });
+}
+int rssync_ext_set_reduce_hook(rssync_problem* p, rssync_reduce_fn fn, void* user) {
+    p->impl->reduce_fn = fn;
+    p->impl->reduce_user = user;
+    return 0;
+}
+
+int rssync_ext_sample_rate(rssync_problem* p, double* sample_rate, double* quats_start, size_t* n_knots) {
+    if (sample_rate) *sample_rate = p->impl->sample_rate();
+    if (quats_start) *quats_start = p->impl->quats_start();
+    if (n_knots) *n_knots = p->impl->knots().size() / 4;
+    return 0;
+}
+int rssync_ext_gyro_knots(rssync_problem* p, double* out, size_t cap) {
+    const auto& k = p->impl->knots();
+    if (cap < k.size()) return 1;
+    std::copy(k.begin(), k.end(), out);
+    return 0;
+}
+
+int rssync_ext_presync_curve(rssync_problem* p, double initial_delay, int64_t frame_begin, int64_t frame_end,
+                             double search_step, double search_radius, double* delays, double* costs, int cap,
+                             int* n_out, double* frame_costs, int32_t* best_h, int* n_frames) {
+    return guarded([&] {
+        SyncProblemHip* s = p->impl;
+        s->ensure_device();
+        uint32_t nf = s->select(frame_begin, frame_end);
+        std::vector<double> d;
+        for (double delay = initial_delay - search_radius; delay < initial_delay + search_radius; delay += search_step) {
+            if ((int)d.size() >= cap) panic("presync_curve: candidate capacity exceeded");
+            d.push_back(delay);
+        }
+        std::vector<double> c = s->sweep(d, 0, false, frame_costs, best_h);
+        std::copy(d.begin(), d.end(), delays);
+        std::copy(c.begin(), c.end(), costs);
+        if (n_out) *n_out = (int)d.size();
+        if (n_frames) *n_frames = (int)nf;
+    });
+}
+
+int rssync_ext_problem_matrix(rssync_problem* p, int64_t frame, double delay, float* P, float* dP, size_t cap_rows,
+                              size_t* n_rows) {
+    return guarded([&] {
+        SyncProblemHip* s = p->impl;
+        s->ensure_device();
+        if (!s->has_frame(frame)) panic("problem_matrix: unknown frame");
+        s->select(frame, frame + 1);
+        DelaySplit ds = split_delay(delay, s->sample_rate());
+        if (rship_debug_problem(s->dev(), 0, ds.kd, ds.fd, P, dP, (uint32_t)cap_rows))
+            panic(std::string("hip: debug problem: ") + rship_last_error(s->dev()));
+        if (n_rows) *n_rows = s->frame_tracks(frame);
+    });
+}
+
+int rssync_ext_init_motion(rssync_problem* p, double delay, int64_t frame_begin, int64_t frame_end, double* M, double* k,
+                           int cap, int* n_frames) {
+    return guarded([&] {
+        SyncProblemHip* s = p->impl;
+        s->ensure_device();
+        s->select(frame_begin, frame_end == std::numeric_limits<int64_t>::max() ? frame_end : frame_end + 1);
+        s->init_motion(delay);
+        s->sync_calls++;
+        uint32_t n = 0;
+        if (rship_get_motion(s->dev(), M, k, (uint32_t)cap, &n)) panic(std::string("hip: get motion: ") + rship_last_error(s->dev()));
+        if (n_frames) *n_frames = (int)n;
+    });
+}
+
+int rssync_ext_opt_motion(rssync_problem* p, double delay, double* M, double* k, int cap, int* n_frames, uint64_t* iters,
+                          uint64_t* evals) {
+    return guarded([&] {
+        SyncProblemHip* s = p->impl;
+        uint64_t st[2] = {0, 0};
+        s->opt_motion(delay, st);
+        uint32_t n = 0;
+        if (rship_get_motion(s->dev(), M, k, (uint32_t)cap, &n)) panic(std::string("hip: get motion: ") + rship_last_error(s->dev()));
+        if (n_frames) *n_frames = (int)n;
+        if (iters) *iters = st[0];
+        if (evals) *evals = st[1];
+    });
+}
+
+int rssync_ext_set_motion(rssync_problem* p, const double* M, const double* k, int n_frames) {
+    return guarded([&] {
+        if (rship_set_motion(p->impl->dev(), M, k, (uint32_t)n_frames))
+            panic(std::string("hip: set motion: ") + rship_last_error(p->impl->dev()));
+    });
+}
+
+int rssync_ext_loss(rssync_problem* p, const double* delays, int n, double* loss, double* grad) {
+    return guarded([&] {
+        std::vector<double> d(delays, delays + n), l, g;
+        p->impl->loss(d, l, grad ? &g : nullptr);
+        std::copy(l.begin(), l.end(), loss);
+        if (grad) std::copy(g.begin(), g.end(), grad);
+    });
+}
+
+int rssync_ext_sync_trace(rssync_problem* p, double* trace, int cap_rows, int* n_rows) {
+    const auto& t = p->impl->trace;
+    int rows = (int)(t.size() / 6);
+    int n = std::min(rows, cap_rows);
+    std::copy(t.begin(), t.begin() + 6 * (size_t)n, trace);
+    if (n_rows) *n_rows = rows;
+    return 0;
+}
+
+int rssync_ext_profile(rssync_problem* p, int enable) { return rship_profile_enable(p->impl->dev(), enable); }
+int rssync_ext_profile_get(rssync_problem* p, int kind, uint64_t* launches, double* total_ms) {
+    return rship_profile_get(p->impl->dev(), kind, launches, total_ms);
+}
+int rssync_ext_profile_reset(rssync_problem* p) { return rship_profile_reset(p->impl->dev()); }
+
+} // extern "C"

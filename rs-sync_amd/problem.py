@@ -1,0 +1,278 @@
+"""Python mirror of the reference's ``ISyncProblem`` (src/core/public/rssync.h:9-29).
+
+Method names, argument order, units and the end-exclusive (PreSync) /
+end-inclusive (Sync) frame ranges are the reference's.  Everything is a thin
+ctypes call into ``librssync_core.so`` through the flat C-ABI declared in
+``include/rssync_c.h``; the library is required (no Python or CPU fallback).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class RsSyncError(RuntimeError):
+    """A 'panic' of the library (invalid input, device failure) in status mode."""
+
+
+def library_path():
+    return os.path.join(_HERE, "librssync_core.so")
+
+
+REDUCE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_size_t, C.c_void_p)
+
+_PD = C.POINTER(C.c_double)
+_PF = C.POINTER(C.c_float)
+_PI64 = C.POINTER(C.c_int64)
+_PI32 = C.POINTER(C.c_int32)
+_PU64 = C.POINTER(C.c_uint64)
+
+# name -> (restype, argtypes): every symbol include/rssync_c.h declares
+SIGNATURES = {
+    "rssync_create": (C.c_void_p, []),
+    "rssync_destroy": (None, [C.c_void_p]),
+    "rssync_last_error": (C.c_char_p, []),
+    "rssync_set_panic_mode": (None, [C.c_int]),
+    "rssync_set_gyro_quaternions": (C.c_int, [C.c_void_p, _PD, C.c_size_t, C.c_double, C.c_double]),
+    "rssync_set_gyro_quaternions_ts": (C.c_int, [C.c_void_p, _PI64, _PD, C.c_size_t]),
+    "rssync_set_track_result": (C.c_int, [C.c_void_p, C.c_int64, _PD, _PD, _PD, _PD, C.c_size_t]),
+    "rssync_pre_sync": (C.c_int, [C.c_void_p, C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_double, _PD, _PD]),
+    "rssync_sync": (C.c_int, [C.c_void_p, C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_double, _PD, _PD]),
+    "rssync_debug_pre_sync": (C.c_int, [C.c_void_p, C.c_double, C.c_int64, C.c_int64, C.c_double, _PD, _PD, C.c_int]),
+    "rssync_ext_set_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "rssync_ext_set_max_outer_iters": (C.c_int, [C.c_void_p, C.c_int]),
+    "rssync_ext_set_verbose": (C.c_int, [C.c_void_p, C.c_int]),
+    "rssync_ext_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rssync_ext_set_reduce_hook": (C.c_int, [C.c_void_p, REDUCE_FN, C.c_void_p]),
+    "rssync_ext_sample_rate": (C.c_int, [C.c_void_p, _PD, _PD, C.POINTER(C.c_size_t)]),
+    "rssync_ext_gyro_knots": (C.c_int, [C.c_void_p, _PD, C.c_size_t]),
+    "rssync_ext_presync_curve": (C.c_int, [C.c_void_p, C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_double,
+                                           _PD, _PD, C.c_int, C.POINTER(C.c_int), _PD, _PI32, C.POINTER(C.c_int)]),
+    "rssync_ext_problem_matrix": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, _PF, _PF, C.c_size_t,
+                                            C.POINTER(C.c_size_t)]),
+    "rssync_ext_init_motion": (C.c_int, [C.c_void_p, C.c_double, C.c_int64, C.c_int64, _PD, _PD, C.c_int,
+                                         C.POINTER(C.c_int)]),
+    "rssync_ext_opt_motion": (C.c_int, [C.c_void_p, C.c_double, _PD, _PD, C.c_int, C.POINTER(C.c_int), _PU64, _PU64]),
+    "rssync_ext_set_motion": (C.c_int, [C.c_void_p, _PD, _PD, C.c_int]),
+    "rssync_ext_loss": (C.c_int, [C.c_void_p, _PD, C.c_int, _PD, _PD]),
+    "rssync_ext_sync_trace": (C.c_int, [C.c_void_p, _PD, C.c_int, C.POINTER(C.c_int)]),
+    "rssync_ext_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "rssync_ext_profile_get": (C.c_int, [C.c_void_p, C.c_int, _PU64, _PD]),
+    "rssync_ext_profile_reset": (C.c_int, [C.c_void_p]),
+}
+
+
+def load_library():
+    """dlopen librssync_core.so and bind every C-ABI symbol; raises if it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RsSyncError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C rs-sync_amd/csrc); there is no fallback implementation")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, t=_PD):
+    return a.ctypes.data_as(t)
+
+
+class SyncProblem:
+    """``CreateSyncProblem()`` + the six ``ISyncProblem`` methods (rssync.h:9-31)."""
+
+    def __init__(self, seed=None, max_outer_iters=None, verbose=False):
+        self._lib = load_library()
+        self._lib.rssync_set_panic_mode(1)  # report panics as exceptions instead of exit(1)
+        self._h = self._lib.rssync_create()
+        if not self._h:
+            raise RsSyncError("rssync_create failed: " + self._lib.rssync_last_error().decode())
+        self._hook = None
+        self._lib.rssync_ext_set_verbose(self._h, 1 if verbose else 0)
+        if seed is not None:
+            self._lib.rssync_ext_set_seed(self._h, int(seed))
+        if max_outer_iters is not None:
+            self._lib.rssync_ext_set_max_outer_iters(self._h, int(max_outer_iters))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rssync_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise RsSyncError(self._lib.rssync_last_error().decode())
+
+    # ---- ISyncProblem -------------------------------------------------------
+    def SetGyroQuaternions(self, data, sample_rate, first_timestamp):
+        """rssync.h:13-14: `data` is (count, 4) [w,x,y,z] at a fixed rate (Hz), first sample time in s."""
+        q = _d(data).reshape(-1, 4)
+        self._check(self._lib.rssync_set_gyro_quaternions(self._h, _p(q), q.shape[0], float(sample_rate),
+                                                          float(first_timestamp)))
+
+    def SetGyroQuaternionsTimestamped(self, timestamps_us, quats):
+        """rssync.h:15-16 (the int64-timestamp overload)."""
+        ts = np.ascontiguousarray(timestamps_us, dtype=np.int64)
+        q = _d(quats).reshape(-1, 4)
+        assert ts.shape[0] == q.shape[0]
+        self._check(self._lib.rssync_set_gyro_quaternions_ts(self._h, _p(ts, _PI64), _p(q), q.shape[0]))
+
+    def SetTrackResult(self, frame, ts_a, ts_b, rays_a, rays_b):
+        """rssync.h:17-18: rays are (count, 3) unit vectors, timestamps in seconds."""
+        ta, tb, ra, rb = _d(ts_a), _d(ts_b), _d(rays_a).reshape(-1, 3), _d(rays_b).reshape(-1, 3)
+        n = ta.shape[0]
+        assert tb.shape[0] == n and ra.shape[0] == n and rb.shape[0] == n
+        self._check(self._lib.rssync_set_track_result(self._h, int(frame), _p(ta), _p(tb), _p(ra), _p(rb), n))
+
+    def PreSync(self, initial_delay, frame_begin, frame_end, search_step, search_radius):
+        """rssync.h:19-21 -> (cost, delay); frame_end exclusive."""
+        c, d = C.c_double(), C.c_double()
+        self._check(self._lib.rssync_pre_sync(self._h, initial_delay, frame_begin, frame_end, search_step,
+                                              search_radius, C.byref(c), C.byref(d)))
+        return c.value, d.value
+
+    def Sync(self, initial_delay, frame_begin, frame_end, search_center, search_radius):
+        """rssync.h:22-24 -> (cost, delay); frame_end inclusive."""
+        c, d = C.c_double(), C.c_double()
+        self._check(self._lib.rssync_sync(self._h, initial_delay, frame_begin, frame_end, search_center,
+                                          search_radius, C.byref(c), C.byref(d)))
+        return c.value, d.value
+
+    def DebugPreSync(self, initial_delay, frame_begin, frame_end, search_radius, point_count):
+        """rssync.h:26-28 -> (delays, costs)."""
+        delays = np.zeros(point_count)
+        costs = np.zeros(point_count)
+        self._check(self._lib.rssync_debug_pre_sync(self._h, initial_delay, frame_begin, frame_end, search_radius,
+                                                    _p(delays), _p(costs), point_count))
+        return delays, costs
+
+    # ---- extensions (include/rssync_c.h, rssync_ext_*) ----------------------
+    def set_seed(self, seed):
+        self._lib.rssync_ext_set_seed(self._h, int(seed))
+
+    def set_max_outer_iters(self, n):
+        self._lib.rssync_ext_set_max_outer_iters(self._h, int(n))
+
+    def set_stream(self, hip_stream_ptr):
+        self._check(self._lib.rssync_ext_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)))
+
+    def set_reduce_hook(self, fn):
+        """fn(np.ndarray float64) must sum the array in place over all ranks; None = single rank."""
+        if fn is None:
+            self._hook = None
+            self._lib.rssync_ext_set_reduce_hook(self._h, C.cast(None, REDUCE_FN), None)
+            return
+
+        def tramp(buf, n, _user):
+            arr = np.ctypeslib.as_array(buf, shape=(n,))
+            fn(arr)
+
+        self._hook = REDUCE_FN(tramp)  # keep the trampoline alive
+        self._lib.rssync_ext_set_reduce_hook(self._h, self._hook, None)
+
+    def gyro_info(self):
+        fs, st, n = C.c_double(), C.c_double(), C.c_size_t()
+        self._lib.rssync_ext_sample_rate(self._h, C.byref(fs), C.byref(st), C.byref(n))
+        return fs.value, st.value, n.value
+
+    def gyro_knots(self):
+        n = self.gyro_info()[2]
+        out = np.zeros((n, 4))
+        self._check(self._lib.rssync_ext_gyro_knots(self._h, _p(out), out.size))
+        return out
+
+    def presync_curve(self, initial_delay, frame_begin, frame_end, search_step, search_radius, per_frame=False,
+                      cap=None):
+        if cap is None:
+            cap = int(2 * search_radius / search_step) + 8
+        delays, costs = np.zeros(cap), np.zeros(cap)
+        n, nf = C.c_int(), C.c_int()
+        fc = bh = None
+        if per_frame:
+            if per_frame is True:
+                raise ValueError('per_frame must be the number of frames in the range')
+            nf_max = int(per_frame)
+            fc = np.zeros((cap, nf_max))
+            bh = np.zeros((cap, nf_max), dtype=np.int32)
+        self._check(self._lib.rssync_ext_presync_curve(
+            self._h, initial_delay, frame_begin, frame_end, search_step, search_radius, _p(delays), _p(costs), cap,
+            C.byref(n), _p(fc) if per_frame else None, _p(bh, _PI32) if per_frame else None, C.byref(nf)))
+        k = n.value
+        if per_frame:
+            f = nf.value
+            fc = fc.reshape(-1)[:k * f].reshape(k, f)
+            bh = bh.reshape(-1)[:k * f].reshape(k, f)
+            return delays[:k], costs[:k], fc, bh
+        return delays[:k], costs[:k]
+
+    def problem_matrix(self, frame, delay, n_tracks, deriv=False):
+        P = np.zeros((n_tracks, 3), dtype=np.float32)
+        dP = np.zeros((n_tracks, 3), dtype=np.float32) if deriv else None
+        n = C.c_size_t()
+        self._check(self._lib.rssync_ext_problem_matrix(self._h, int(frame), float(delay), _p(P, _PF),
+                                                        _p(dP, _PF) if deriv else None, n_tracks, C.byref(n)))
+        return (P[:n.value], dP[:n.value]) if deriv else P[:n.value]
+
+    def init_motion(self, delay, frame_begin, frame_end, cap=1 << 16):
+        M, k, n = np.zeros((cap, 3)), np.zeros(cap), C.c_int()
+        self._check(self._lib.rssync_ext_init_motion(self._h, delay, frame_begin, frame_end, _p(M), _p(k), cap,
+                                                     C.byref(n)))
+        return M[:n.value].copy(), k[:n.value].copy()
+
+    def opt_motion(self, delay, cap=1 << 16):
+        M, k, n = np.zeros((cap, 3)), np.zeros(cap), C.c_int()
+        it, ev = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.rssync_ext_opt_motion(self._h, delay, _p(M), _p(k), cap, C.byref(n), C.byref(it),
+                                                    C.byref(ev)))
+        return M[:n.value].copy(), k[:n.value].copy(), it.value, ev.value
+
+    def set_motion(self, M, k):
+        M, k = _d(M).reshape(-1, 3), _d(k)
+        self._check(self._lib.rssync_ext_set_motion(self._h, _p(M), _p(k), k.shape[0]))
+
+    def loss(self, delays, grad=False):
+        d = _d(np.atleast_1d(delays))
+        out = np.zeros(d.shape[0])
+        g = np.zeros(d.shape[0]) if grad else None
+        self._check(self._lib.rssync_ext_loss(self._h, _p(d), d.shape[0], _p(out), _p(g) if grad else None))
+        return (out, g) if grad else out
+
+    def sync_trace(self, cap=512):
+        t, n = np.zeros((cap, 6)), C.c_int()
+        self._lib.rssync_ext_sync_trace(self._h, _p(t), cap, C.byref(n))
+        return t[:min(n.value, cap)].copy()
+
+    def profile(self, enable=True):
+        self._check(self._lib.rssync_ext_profile(self._h, 1 if enable else 0))
+
+    def profile_reset(self):
+        self._check(self._lib.rssync_ext_profile_reset(self._h))
+
+    def profile_get(self):
+        names = ["lmeds", "loss", "motion", "reduce"]
+        out = {}
+        for i, nm in enumerate(names):
+            n, ms = C.c_uint64(), C.c_double()
+            self._check(self._lib.rssync_ext_profile_get(self._h, i, C.byref(n), C.byref(ms)))
+            out[nm] = (n.value, ms.value)
+        return out

@@ -1,0 +1,178 @@
+"""Deterministic synthetic inputs for the PreSync/Sync path.
+
+A rolling-shutter camera (30 fps, 11.11 ms readout) rotates with a smooth
+random angular rate and translates slowly through a static point cloud; a gyro
+samples the rotation at a fixed rate.  Orientations are taken from the same
+natural cubic spline through the gyro samples that the solver evaluates
+(core_support/minispline.cpp), so for inliers the epipolar residual is exactly
+zero at the true delay ``d_true``.
+
+Conventions follow the reference driver: gyro integration
+``q_i = normalise(quat_from_aa(w_i dt) * q_{i-1})`` (core_testcode.cpp:41-46),
+ray time ``ts = frame_time + readout * row_fraction`` (:144-145), rays are unit
+vectors in the camera frame (:147-152).  The solver de-rotates a ray with
+``R(q)^T`` (core_private.cpp:26-27), so a camera ray is ``R(q(ts + d_true))``
+applied to the world direction.
+
+numpy/scipy only; nothing here touches the oracle or the GPU.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+from scipy.interpolate import CubicSpline
+
+FPS = 30.0
+READOUT = 0.01111  # README.md:59, thesis p.28
+D_TRUE = 0.0370
+
+
+def quat_mul(p, q):
+    """Hamilton product, [w,x,y,z] (core_support/quat.cpp:33-38), vectorised over leading dims."""
+    pw, px, py, pz = p[..., 0], p[..., 1], p[..., 2], p[..., 3]
+    qw, qx, qy, qz = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    return np.stack([pw * qw - px * qx - py * qy - pz * qz,
+                     pw * qx + px * qw + py * qz - pz * qy,
+                     pw * qy - px * qz + py * qw + pz * qx,
+                     pw * qz + px * qy - py * qx + pz * qw], axis=-1)
+
+
+def quat_from_aa(aa):
+    """core_support/quat.cpp:5-17."""
+    th = np.linalg.norm(aa, axis=-1, keepdims=True)
+    half = 0.5 * th
+    k = np.where(th > 0, np.sin(half) / np.where(th > 0, th, 1.0), 0.5)
+    return np.concatenate([np.where(th > 0, np.cos(half), 1.0), aa * k], axis=-1)
+
+
+def rotate(q, v):
+    """R(q) v = vec(q (0,v) q*)."""
+    w, u = q[..., :1], q[..., 1:]
+    t = np.cross(u, v)
+    return v + 2.0 * (w * t + np.cross(u, t))
+
+
+def rotate_inv(q, v):
+    """R(q)^T v = vec(q* (0,v) q)."""
+    w, u = q[..., :1], q[..., 1:]
+    t = np.cross(u, v)
+    return v + 2.0 * (-w * t + np.cross(u, t))
+
+
+def integrate_gyro(rates, dt):
+    """q_0 = 1, q_i = normalise(quat_from_aa(w_i dt_i) q_{i-1}) as a parallel prefix product."""
+    n = rates.shape[0]
+    dq = quat_from_aa(rates * np.asarray(dt).reshape(-1, 1))
+    dq[0] = [1.0, 0.0, 0.0, 0.0]
+    q = dq.copy()
+    shift = 1
+    while shift < n:  # Hillis-Steele scan; later factors multiply on the left
+        q[shift:] = quat_mul(q[shift:], q[:-shift].copy())
+        shift *= 2
+    return q / np.linalg.norm(q, axis=1, keepdims=True)
+
+
+@dataclass
+class Gyro:
+    fs: float
+    t0: float            # time of sample 0 (s)
+    quats: np.ndarray    # (G, 4)
+    times: np.ndarray    # (G,) sample times (s); uniform unless jittered
+    spline: object       # natural cubic spline over the sample index
+
+    def orientation(self, t):
+        """unit quaternion at gyro time t: componentwise natural spline over the index, renormalised
+        (core_private.cpp:24-25)."""
+        x = (np.asarray(t) - self.t0) * self.fs
+        q = self.spline(x)
+        return q / np.linalg.norm(q, axis=-1, keepdims=True)
+
+
+def make_gyro(t_begin, t_end, fs=400.0, seed=0, margin=1.0):
+    """Gyro covering [t_begin - margin, t_end + margin] at a fixed rate."""
+    rng = np.random.default_rng(seed)
+    t0 = t_begin - margin
+    g = int(np.ceil((t_end - t_begin + 2 * margin) * fs)) + 1
+    t = t0 + np.arange(g) / fs
+    rates = np.zeros((g, 3))
+    for ax in range(3):  # three sinusoids per axis, 0.3-3 Hz, total amplitude <= 2 rad/s
+        for _ in range(3):
+            f = rng.uniform(0.3, 3.0)
+            a = rng.uniform(0.1, 2.0 / 3.0)
+            ph = rng.uniform(0, 2 * np.pi)
+            rates[:, ax] += a * np.sin(2 * np.pi * f * t + ph)
+    rates += rng.normal(0, 0.01, size=rates.shape)
+    q = integrate_gyro(rates, np.full(g, 1.0 / fs))
+    spline = CubicSpline(np.arange(g, dtype=np.float64), q, axis=0, bc_type="natural")
+    return Gyro(fs=fs, t0=t0, quats=q, times=t, spline=spline)
+
+
+def make_frames(gyro, frame_begin, frame_end, n_tracks, seed=0, d_true=D_TRUE, noise=1e-3, outliers=0.10,
+                chunk=256):
+    """Yield (frame, ts_a, ts_b, rays_a, rays_b) for frames [frame_begin, frame_end)."""
+    for f0 in range(frame_begin, frame_end, chunk):
+        f1 = min(f0 + chunk, frame_end)
+        nf = f1 - f0
+        rng = np.random.default_rng([seed, f0])
+        frames = np.arange(f0, f1)
+        ya = rng.uniform(0, 1, size=(nf, n_tracks))
+        yb = np.clip(ya + rng.normal(0, 0.03, size=ya.shape), 0.0, 0.999)
+        ts_a = frames[:, None] / FPS + READOUT * ya
+        ts_b = (frames[:, None] + 1) / FPS + READOUT * yb
+        # camera-frame ray of the current frame inside a +-55 degree cone around +z
+        cos_t = rng.uniform(np.cos(np.deg2rad(55.0)), 1.0, size=ya.shape)
+        sin_t = np.sqrt(1 - cos_t ** 2)
+        phi = rng.uniform(0, 2 * np.pi, size=ya.shape)
+        a_cam = np.stack([sin_t * np.cos(phi), sin_t * np.sin(phi), cos_t], axis=-1)
+        depth = rng.uniform(2.0, 50.0, size=ya.shape)[..., None]
+        # slowly varying translation direction, 0.05 m per frame
+        ang = 0.002 * frames + rng.uniform(0, 2 * np.pi)
+        tdir = np.stack([np.cos(ang), np.sin(ang) * np.cos(0.3 * ang), np.sin(ang) * np.sin(0.3 * ang)], axis=-1)
+        trans = 0.05 * tdir[:, None, :]
+        qa = gyro.orientation(ts_a + d_true)
+        qb = gyro.orientation(ts_b + d_true)
+        a_world = rotate_inv(qa, a_cam)
+        X = depth * a_world                       # camera centre of frame f at the origin
+        b_world = X - trans                       # seen from the next frame's centre
+        b_world /= np.linalg.norm(b_world, axis=-1, keepdims=True)
+        b_cam = rotate(qb, b_world)
+        if noise > 0:
+            b_cam = b_cam + rng.normal(0, noise, size=b_cam.shape)
+            b_cam /= np.linalg.norm(b_cam, axis=-1, keepdims=True)
+        if outliers > 0:
+            mask = rng.uniform(size=ya.shape) < outliers
+            rnd = rng.normal(size=b_cam.shape)
+            rnd /= np.linalg.norm(rnd, axis=-1, keepdims=True)
+            b_cam = np.where(mask[..., None], rnd, b_cam)
+        for i in range(nf):
+            yield int(frames[i]), ts_a[i], ts_b[i], a_cam[i], b_cam[i]
+
+
+def make_timestamped(gyro, jitter=0.2, seed=0):
+    """Variable-rate view of a gyro track for the timestamped setter: sample times jittered by
+    +-jitter of the nominal interval, quaternions taken from the smooth orientation."""
+    rng = np.random.default_rng(seed)
+    g = gyro.quats.shape[0]
+    dt = 1.0 / gyro.fs
+    t = gyro.t0 + np.arange(g) * dt + rng.uniform(-jitter, jitter, size=g) * dt * 0.5
+    t = np.sort(t)
+    t = np.clip(t, gyro.t0, gyro.t0 + (g - 1) * dt)
+    q = gyro.orientation(t)
+    ts_us = np.round(t * 1e6).astype(np.int64)
+    return ts_us, q
+
+
+def fill(problem, gyro, frame_begin, frame_end, n_tracks, seed=0, **kw):
+    """Feed one problem object (SyncProblem or the oracle mirror): same calls as the reference driver."""
+    problem.SetGyroQuaternions(gyro.quats, gyro.fs, gyro.t0)
+    for fr, ta, tb, ra, rb in make_frames(gyro, frame_begin, frame_end, n_tracks, seed=seed, **kw):
+        problem.SetTrackResult(fr, ta, tb, ra, rb)
+
+
+def config(index):
+    """The BASELINE.json configurations: frames, tracks, sweep parameters."""
+    cfgs = {
+        1: dict(frames=64, tracks=256, step=0.002, radius=0.2),
+        2: dict(frames=1024, tracks=1024, step=0.0005, radius=0.2),
+        3: dict(frames=4096, tracks=2048, step=0.0005, radius=0.2),
+    }
+    return cfgs[index]
