@@ -78,6 +78,10 @@ int rssync_ext_set_stream(rssync_problem* p, void* hip_stream);
 typedef void (*rssync_reduce_fn)(double* buf, size_t n, void* user);
 int rssync_ext_set_reduce_hook(rssync_problem* p, rssync_reduce_fn fn, void* user);
 
+/* pack the tracks and the gyro spline and copy them to HBM now (otherwise done lazily by the
+ * first PreSync/Sync/DebugPreSync after a setter) */
+int rssync_ext_upload(rssync_problem* p);
+
 /* diagnostics used by the parity tests and the benchmark */
 int rssync_ext_sample_rate(rssync_problem* p, double* sample_rate, double* quats_start,
                            size_t* n_knots);
@@ -101,7 +105,7 @@ int rssync_ext_set_motion(rssync_problem* p, const double* M, const double* k, i
 int rssync_ext_loss(rssync_problem* p, const double* delays, int n, double* loss, double* grad);
 /* trace of the last Sync: rows of {delay_after, step, loss_at_x0, grad_at_x0, t, trials} */
 int rssync_ext_sync_trace(rssync_problem* p, double* trace, int cap_rows, int* n_rows);
-/* HIP-event kernel timing: kind 0 LMedS tile, 1 loss, 2 motion, 3 reduce */
+/* HIP-event kernel timing: kind 0 LMedS tile (PreSync), 1 loss, 2 motion, 3 reduce, 4 LMedS init (Sync) */
 int rssync_ext_profile(rssync_problem* p, int enable);
 int rssync_ext_profile_get(rssync_problem* p, int kind, uint64_t* launches, double* total_ms);
 int rssync_ext_profile_reset(rssync_problem* p);

@@ -48,11 +48,12 @@ typedef struct rship_frame {
 #define RSHIP_BAD_RHO 8u
 
 /* kernel kinds for rship_profile_get */
-#define RSHIP_K_LMEDS 0  /* PreSync tile kernel (also Sync's GuessMotion/GuessK) */
+#define RSHIP_K_LMEDS 0  /* PreSync tile kernel */
 #define RSHIP_K_LOSS 1   /* residual + robust loss (+ analytic d/d-delay) */
 #define RSHIP_K_MOTION 2 /* per-frame motion L-BFGS */
 #define RSHIP_K_REDUCE 3 /* over-frames sums */
-#define RSHIP_K_COUNT 4
+#define RSHIP_K_INIT 4   /* the LMedS kernel in GuessMotion/GuessK mode (Sync start) */
+#define RSHIP_K_COUNT 5
 
 int rship_create(rship_ctx** out, int device /* -1 = current device */);
 void rship_destroy(rship_ctx* c);

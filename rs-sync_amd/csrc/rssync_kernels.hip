@@ -731,8 +731,8 @@ struct rship_ctx {
     struct Pending { int kind; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
-    uint64_t launches[RSHIP_K_COUNT] = {0, 0, 0, 0};
-    double total_ms[RSHIP_K_COUNT] = {0, 0, 0, 0};
+    uint64_t launches[RSHIP_K_COUNT] = {};
+    double total_ms[RSHIP_K_COUNT] = {};
 };
 
 namespace {
@@ -833,7 +833,7 @@ uint32_t sel_max_n(const rship_ctx* c) {
 
 template <int MODE>
 int launch_lmeds(rship_ctx* c, const LmedsParams& p, int rpt, uint32_t grid) {
-    ProfScope ps(c, RSHIP_K_LMEDS);
+    ProfScope ps(c, MODE == 1 ? RSHIP_K_INIT : RSHIP_K_LMEDS);
     switch (rpt) {
         case 1: hipLaunchKernelGGL((lmeds_kernel<1, MODE>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
         case 2: hipLaunchKernelGGL((lmeds_kernel<2, MODE>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;

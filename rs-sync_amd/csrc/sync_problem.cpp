@@ -634,6 +634,10 @@ int rssync_ext_set_reduce_hook(rssync_problem* p, rssync_reduce_fn fn, void* use
     return 0;
 }
 
+int rssync_ext_upload(rssync_problem* p) {
+    return guarded([&] { p->impl->ensure_device(); });
+}
+
 int rssync_ext_sample_rate(rssync_problem* p, double* sample_rate, double* quats_start, size_t* n_knots) {
     if (sample_rate) *sample_rate = p->impl->sample_rate();
     if (quats_start) *quats_start = p->impl->quats_start();

@@ -47,6 +47,7 @@ SIGNATURES = {
     "rssync_ext_set_verbose": (C.c_int, [C.c_void_p, C.c_int]),
     "rssync_ext_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rssync_ext_set_reduce_hook": (C.c_int, [C.c_void_p, REDUCE_FN, C.c_void_p]),
+    "rssync_ext_upload": (C.c_int, [C.c_void_p]),
     "rssync_ext_sample_rate": (C.c_int, [C.c_void_p, _PD, _PD, C.POINTER(C.c_size_t)]),
     "rssync_ext_gyro_knots": (C.c_int, [C.c_void_p, _PD, C.c_size_t]),
     "rssync_ext_presync_curve": (C.c_int, [C.c_void_p, C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_double,
@@ -190,6 +191,10 @@ class SyncProblem:
         self._hook = REDUCE_FN(tramp)  # keep the trampoline alive
         self._lib.rssync_ext_set_reduce_hook(self._h, self._hook, None)
 
+    def upload(self):
+        """Pack tracks + spline and copy them to HBM now (otherwise lazy)."""
+        self._check(self._lib.rssync_ext_upload(self._h))
+
     def gyro_info(self):
         fs, st, n = C.c_double(), C.c_double(), C.c_size_t()
         self._lib.rssync_ext_sample_rate(self._h, C.byref(fs), C.byref(st), C.byref(n))
@@ -269,7 +274,7 @@ class SyncProblem:
         self._check(self._lib.rssync_ext_profile_reset(self._h))
 
     def profile_get(self):
-        names = ["lmeds", "loss", "motion", "reduce"]
+        names = ["lmeds", "loss", "motion", "reduce", "init"]
         out = {}
         for i, nm in enumerate(names):
             n, ms = C.c_uint64(), C.c_double()

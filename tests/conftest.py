@@ -1,0 +1,61 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Everything compiled (the driver's build() step); cheap when already up to date."""
+    import __graft_entry__ as g
+    g.build()
+    return True
+
+
+@pytest.fixture(scope="session")
+def small_case(built):
+    """64 frames x 256 tracks, 400 Hz gyro (BASELINE config 1), noise + 10 % outliers."""
+    from rssync_amd import synth
+    F, N = 64, 256
+    gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=1)
+    frames = list(synth.make_frames(gyro, 0, F, N, seed=1))
+    return dict(F=F, N=N, gyro=gyro, frames=frames)
+
+
+@pytest.fixture(scope="session")
+def clean_case(built):
+    """Same shape, no noise and no outliers: the residual is exactly zero at the true delay."""
+    from rssync_amd import synth
+    F, N = 64, 256
+    gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=2)
+    frames = list(synth.make_frames(gyro, 0, F, N, seed=2, noise=0.0, outliers=0.0))
+    return dict(F=F, N=N, gyro=gyro, frames=frames)
+
+
+def fill(problem, case):
+    g = case["gyro"]
+    problem.SetGyroQuaternions(g.quats, g.fs, g.t0)
+    for fr, ta, tb, ra, rb in case["frames"]:
+        problem.SetTrackResult(fr, ta, tb, ra, rb)
+    return problem
+
+
+@pytest.fixture()
+def oracle_small(small_case):
+    from oracle.oracle import OracleProblem
+    return fill(OracleProblem(seed=123, threads=os.cpu_count() or 1, faithful=False), small_case)
+
+
+@pytest.fixture()
+def oracle_clean(clean_case):
+    from oracle.oracle import OracleProblem
+    return fill(OracleProblem(seed=123, threads=os.cpu_count() or 1, faithful=False), clean_case)

@@ -1,0 +1,113 @@
+"""CPU-side checks of the drop-in boundary: the library loads, exports every symbol the headers
+declare plus the reference's C++ symbols, and refuses loudly to run without a HIP device."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _exports(lib):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib], text=True)
+    return {line.split()[-1] for line in out.splitlines() if line.strip()}
+
+
+def _declared(header, prefix):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(%s\w+)\s*\(" % prefix, text)) - {prefix + "reduce_fn"}
+
+
+def test_library_exports_every_declared_symbol(built):
+    import rssync_amd
+    exp = _exports(rssync_amd.library_path())
+    for header, prefix in (("rssync_c.h", "rssync_"), ("rssync_hip.h", "rship_")):
+        decl = _declared(header, prefix)
+        assert len(decl) > 10
+        assert not (decl - exp), sorted(decl - exp)
+    # the ctypes table binds exactly the C-ABI the header declares
+    from rssync_amd.problem import SIGNATURES
+    assert set(SIGNATURES) == _declared("rssync_c.h", "rssync_")
+
+
+def test_reference_cxx_symbols_are_exported(built):
+    """rssync.h:31 has C++ linkage; the vtable/typeinfo of ISyncProblem live where its
+    out-of-line destructor is (core_private.cpp:363-365)."""
+    import rssync_amd
+    exp = _exports(rssync_amd.library_path())
+    for sym in ("_Z17CreateSyncProblemv", "_ZN12ISyncProblemD0Ev", "_ZN12ISyncProblemD1Ev",
+                "_ZN12ISyncProblemD2Ev", "_ZTV12ISyncProblem", "_ZTI12ISyncProblem", "_ZTS12ISyncProblem"):
+        assert sym in exp, sym
+
+
+def test_library_loads_and_binds(built):
+    import rssync_amd
+    lib = rssync_amd.load_library()
+    assert lib.rssync_last_error() is not None
+    lib.rship_max_tracks.restype = ctypes.c_int
+    assert lib.rship_max_tracks() == 2048
+
+
+CLIENT = r"""
+#include "rssync.h"
+#include <cstdio>
+#include <memory>
+#include <vector>
+int main() {
+    std::unique_ptr<ISyncProblem> sp(CreateSyncProblem());   // core_testcode.cpp:248
+    std::vector<double> q = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    sp->SetGyroQuaternions(q.data(), 3, 400.0, 0.0);
+    auto r = sp->PreSync(0.0, 0, 1, 0.01, 0.05);
+    std::printf("%g %g\n", r.first, r.second);
+    return 0;
+}
+"""
+
+
+def test_cxx_client_built_against_the_header_links_and_fails_loudly_without_a_gpu(built, tmp_path):
+    """A client written against the reference's interface compiles and links unchanged.  Without a
+    HIP device the library must not compute anything: it follows the reference's panic convention
+    (panic.txt + exit status 1, core_support/panic.cpp:7-15)."""
+    import torch
+    src = tmp_path / "client.cpp"
+    src.write_text(CLIENT)
+    exe = tmp_path / "client"
+    libdir = os.path.join(ROOT, "rs-sync_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lrssync_core", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the no-device path cannot be exercised here")
+    res = subprocess.run([str(exe)], cwd=tmp_path, capture_output=True, text=True)
+    assert res.returncode == 1
+    assert "no usable HIP device" in (tmp_path / "panic.txt").read_text()
+    assert "no CPU fallback" in res.stderr
+
+
+def test_python_mirror_fails_loudly_without_a_gpu(built):
+    import torch
+    import rssync_amd
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(rssync_amd.RsSyncError, match="no usable HIP device"):
+        rssync_amd.SyncProblem()
+
+
+def test_product_does_not_reference_the_oracle():
+    """only tests/, smoke() and bench.py's cpu_baseline may touch oracle/"""
+    pkg = os.path.join(ROOT, "rs-sync_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if "_build" in dirpath:
+            continue
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or fn == "Makefile":
+                text = open(os.path.join(dirpath, fn), errors="ignore").read()
+                for line in text.splitlines():
+                    if re.search(r"^\s*(#\s*include|import|from)\b.*oracle", line):
+                        raise AssertionError(f"{fn}: {line.strip()}")
+    import rssync_amd
+    out = subprocess.check_output(["ldd", rssync_amd.library_path()], text=True)
+    assert "oracle" not in out
