@@ -176,13 +176,32 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cores():
+    """CPU cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(gyro, frames, tracks, args):
     """The oracle (a port of the reference's CPU path, faithful evaluation schedule) timed on this
     host's cores on a bounded sample of the same workload: the first `frames` frames, all candidates."""
     from oracle.oracle import OracleProblem
     from rssync_amd import synth
 
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     o = OracleProblem(seed=0x5EED0003, max_outer_iters=args.outer_iters, threads=cores, faithful=True)
     synth.fill(o, gyro, 0, frames, tracks, seed=0x5EED0003)
     t0 = time.perf_counter()

@@ -105,6 +105,13 @@ int rship_set_motion(rship_ctx* c, const double* M, const double* k, uint32_t n)
 int rship_debug_problem(rship_ctx* c, uint32_t sel_index, int32_t kd, float fd, float* P,
                         float* dP, uint32_t cap_rows);
 
+/* the wave-level exact selection used by the LMedS kernel, on caller data (tests): for each of
+ * n_problems rows of n (<= 2048) non-negative floats, out[2i] = bit pattern of the kq-th smallest
+ * (0-based) if more than kq values lie below upper[i] (NULL = +inf), else 0xffffffff;
+ * out[2i+1] = how many lie below the bound */
+int rship_debug_select(rship_ctx* c, const float* vals, uint32_t n_problems, uint32_t n, uint32_t kq,
+                       const float* upper, uint32_t* out);
+
 /* HIP-event timing of every launch, accumulated per kernel kind */
 int rship_profile_enable(rship_ctx* c, int on);
 int rship_profile_get(rship_ctx* c, int kind, uint64_t* launches, double* total_ms);

@@ -29,7 +29,7 @@ using rs::f4;
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kWinMax = 128; // knots of the spline staged in LDS per workgroup
+constexpr int kWinMax = 64;  // knots of the spline staged in LDS per workgroup
 constexpr uint32_t kInfBits = 0x7f800000u;
 
 // ---------------------------------------------------------------------------
@@ -185,13 +185,21 @@ struct LmedsParams {
     uint32_t* flags;
 };
 
-// hypothesis direction v = safe_normalize(P[i0] x P[i1]) (core_private.cpp:45-46)
-__device__ __forceinline__ f3 hypothesis(const f4* tile, uint64_t seed, int64_t frame, uint32_t stream, uint32_t h,
+// ---- LMedS tile in LDS, struct-of-arrays: unit rows n = safe_normalize(P) and |P| ----
+struct Tile {
+    float* nx;
+    float* ny;
+    float* nz;
+    float* nrm;
+};
+
+// hypothesis direction v = safe_normalize(P[i0] x P[i1]) (core_private.cpp:45-46), P = n |P|
+__device__ __forceinline__ f3 hypothesis(const Tile& t, uint64_t seed, int64_t frame, uint32_t stream, uint32_t h,
                                          uint32_t n) {
     uint32_t i0, i1;
     rs::sample_pair(seed, frame, stream, h, n, i0, i1);
-    f4 a = tile[i0], b = tile[i1];
-    f3 v = rs::cross(f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z});
+    const float s0 = t.nrm[i0], s1 = t.nrm[i1];
+    f3 v = rs::cross(f3{t.nx[i0] * s0, t.ny[i0] * s0, t.nz[i0] * s0}, f3{t.nx[i1] * s1, t.ny[i1] * s1, t.nz[i1] * s1});
     float nn = sqrtf(rs::dot(v, v));
     if (!(nn < 1e-12f)) { // inline_utils.hpp:5-11
         float inv = 1.0f / nn;
@@ -200,19 +208,130 @@ __device__ __forceinline__ f3 hypothesis(const f4* tile, uint64_t seed, int64_t 
     return v;
 }
 
+// per-lane count of x_i < pivot over four registers.  Hand-scheduled: hipcc turns the obvious
+// `cnt += x < pivot` into a bit-packing sequence of ~5 VALU per element; this is 2 per element.
+// The compares write SGPR pairs that the add-with-carry reads as its carry-in; gfx950 needs two
+// wait states between a VALU write of an SGPR and a VALU read of it, which the interleaving
+// provides.  The pivot is passed in a VGPR so that no SGPR written just before the block is read.
+__device__ __forceinline__ void count4(uint32_t& cnt, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3,
+                                       uint32_t pivot_v) {
+    unsigned long long a, b, c;
+    asm("v_cmp_gt_u32_e64 %1, %8, %4\n\t"
+        "v_cmp_gt_u32_e64 %2, %8, %5\n\t"
+        "v_cmp_gt_u32_e64 %3, %8, %6\n\t"
+        "v_addc_co_u32_e64 %0, vcc, 0, %0, %1\n\t"
+        "v_cmp_gt_u32_e64 %1, %8, %7\n\t"
+        "v_addc_co_u32_e64 %0, vcc, 0, %0, %2\n\t"
+        "v_addc_co_u32_e64 %0, vcc, 0, %0, %3\n\t"
+        "v_addc_co_u32_e64 %0, vcc, 0, %0, %1"
+        : "+v"(cnt), "=&s"(a), "=&s"(b), "=&s"(c)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(pivot_v)
+        : "vcc");
+}
+
+// wave-wide count of r2[] < pivot (pivot uniform)
+template <int NR>
+__device__ __forceinline__ uint32_t wave_count_lt(const uint32_t (&r2)[NR], uint32_t pivot) {
+    uint32_t cnt = 0;
+    uint32_t pv = pivot;
+    asm volatile("" : "+v"(pv)); // keep the pivot in a VGPR
+#pragma unroll
+    for (int m = 0; m < NR; m += 4) count4(cnt, r2[m], r2[m + 1], r2[m + 2], r2[m + 3], pv);
+    asm volatile("s_nop 1" : "+v"(cnt)); // VALU write -> DPP read of cnt: two wait states
+    return wave_sum_u32(cnt);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_umin(uint32_t v) {
+    uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = dpp_umin<0x111, 0xf>(v);
+    v = dpp_umin<0x112, 0xf>(v);
+    v = dpp_umin<0x114, 0xf>(v);
+    v = dpp_umin<0x118, 0xf>(v);
+    v = dpp_umin<0x142, 0xa>(v);
+    v = dpp_umin<0x143, 0xc>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_fmax(float v) { // NaN-ignoring max; lanes without a source keep v
+    float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+    return fmaxf(o, v);
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = dpp_fmax<0x111, 0xf>(v);
+    v = dpp_fmax<0x112, 0xf>(v);
+    v = dpp_fmax<0x114, 0xf>(v);
+    v = dpp_fmax<0x118, 0xf>(v);
+    v = dpp_fmax<0x142, 0xa>(v);
+    v = dpp_fmax<0x143, 0xc>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Exact kq-th smallest (0-based) of the wave's r2[] bit patterns (the value std::sort would leave
+// at index kq, core_private.cpp:51-52), given an exclusive upper bound hi2 with
+// count(r2 < hi2) = c_hi > kq.  A bracket [lo2, hi2) with counts c_lo <= kq < c_hi is narrowed by
+// counting passes; pivots come from a secant step on the empirical CDF in the sqrt domain
+// (|r| is close to uniformly distributed around the lower quartile, so the CDF is nearly linear
+// there: ~8 passes instead of 31 bit-bisection passes), with bracket interpolation and plain
+// bisection of the bit pattern as fallbacks.  Ends when the bracket is one bit pattern wide or
+// holds exactly one element, which is then extracted with a min pass.
+template <int NR>
+__device__ __forceinline__ uint32_t select_kth(const uint32_t (&r2)[NR], uint32_t kq, uint32_t hi2, uint32_t c_hi) {
+    uint32_t lo2 = 0, c_lo = 0;
+    float alo = 0.f, ahi = sqrtf(__uint_as_float(hi2));
+    float a1 = 0.f, c1 = 0.f, a2 = ahi, c2 = (float)c_hi;
+    const float target = (float)kq + 0.5f;
+    for (int it = 0;; ++it) {
+        if (hi2 - lo2 == 1u) return lo2;
+        if (c_hi - c_lo == 1u) {
+            // the single element in [lo2, hi2): smallest x >= lo2; x < lo2 wraps to a huge difference
+            uint32_t mn = 0xffffffffu;
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                uint32_t d = r2[m] - lo2;
+                mn = d < mn ? d : mn;
+            }
+            return lo2 + wave_min_u32(mn);
+        }
+        uint32_t piv;
+        if (it < 24) {
+            float a3 = a2 + (target - c2) * (a2 - a1) / (c2 - c1);
+            if (!(c2 != c1 && a3 > alo && a3 < ahi))
+                a3 = alo + (target - (float)c_lo) / (float)(c_hi - c_lo) * (ahi - alo);
+            piv = __float_as_uint(a3 * a3);
+            if (!(piv > lo2 && piv < hi2)) piv = lo2 + ((hi2 - lo2) >> 1);
+        } else {
+            piv = lo2 + ((hi2 - lo2) >> 1); // guaranteed finish: <= 31 more passes
+        }
+        piv = (uint32_t)__builtin_amdgcn_readfirstlane((int)piv);
+        const uint32_t c = wave_count_lt(r2, piv);
+        a1 = a2; c1 = c2;
+        a2 = sqrtf(__uint_as_float(piv)); c2 = (float)c;
+        if (c <= kq) { lo2 = piv; c_lo = c; alo = a2; }
+        else { hi2 = piv; c_hi = c; ahi = a2; }
+    }
+}
+
 // waves per SIMD each kernel is compiled for (second __launch_bounds__ argument): the
 // LMedS tile is LDS-limited to 3 workgroups per CU at 8 rows per thread
-__host__ __device__ constexpr int lmeds_waves(int rpt) { return rpt >= 8 ? 3 : 4; }
+__host__ __device__ constexpr int lmeds_waves(int rpt) { return 4; }
 __host__ __device__ constexpr int loss_waves(int rpt, bool grad) { return (grad || rpt >= 8) ? 3 : 4; }
+
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int RPT, int MODE> // MODE 0: PreSync cost per candidate; 1: GuessMotion + GuessK
 __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsParams p) {
+    constexpr int ROWS = kBlock * RPT;
     constexpr int NR = 4 * RPT; // residual registers per lane: a wave spans the whole tile
-    __shared__ f4 s_tile[kBlock * RPT];
+    __shared__ __attribute__((aligned(16))) float s_n[4][ROWS];
     __shared__ f4 s_win[4 * kWinMax];
     __shared__ double s_red[4];
-    __shared__ uint32_t s_bestT[4];
-    __shared__ int s_bestH[4];
+    // best (quantile, hypothesis) so far, packed (bits << 32 | h): a 64-bit min is exactly
+    // "smaller quantile wins, ties go to the earlier hypothesis" (core_private.cpp:53 strict <)
+    __shared__ unsigned long long s_key;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // blocks b and b+8 share an XCD (round-robin dispatch): keep the chunks of one
@@ -226,6 +345,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     const FrameRec fr = p.frames[fi];
     const uint32_t N = fr.n;
     const uint32_t kq = N / 4; // core_private.cpp:52
+    const Tile tile{s_n[0], s_n[1], s_n[2], s_n[3]};
 
     // rays are re-read per candidate: the chunks of a frame share an XCD, so after the
     // first touch they come from that XCD's L2 (keeping them in registers costs 64 VGPRs)
@@ -255,84 +375,79 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         const int base = fr.base_knot + p.kd[c];
         const float fd = p.fd[c];
         uint32_t bad = 0;
-        // ---- stage A: P rows -> LDS tile as {Px, Py, Pz, 1/|P|} ----
+        // ---- stage A: rows of P -> LDS tile as unit rows + norms ----
 #pragma unroll 2
         for (int j = 0; j < RPT; ++j) {
             uint32_t row = j * kBlock + tid;
-            f4 t = f4{0, 0, 0, 0};
+            // rows beyond N are NaN: their residuals compare above every threshold
+            float nx = __uint_as_float(0x7fc00000u), ny = nx, nz = nx, nrm = 0.f;
             if (row < N) {
                 f3 P, dP;
                 residual_row<false>(sp, rays_a[row], rays_b[row], base, fd, P, dP);
-                if (!(finite_f(P.x) && finite_f(P.y) && finite_f(P.z))) bad |= RSHIP_BAD_P;
-                float nn = sqrtf(rs::dot(P, P));
-                float inv = (nn < 1e-12f) ? 1.f : 1.0f / nn; // safe_normalize, core_private.cpp:35-36
-                t = f4{P.x, P.y, P.z, inv};
+                const float n2 = rs::dot(P, P);
+                if (!finite_f(n2)) bad |= RSHIP_BAD_P;
+                // safe_normalize (core_private.cpp:35-36): rows with |P| < 1e-12 stay as they are
+                const bool tiny = n2 < 1e-24f;
+                const float inv = tiny ? 1.f : rs::rsqrt_fast(n2);
+                nx = P.x * inv; ny = P.y * inv; nz = P.z * inv;
+                nrm = tiny ? 1.f : n2 * inv;
             }
-            s_tile[row] = t;
+            tile.nx[row] = nx; tile.ny[row] = ny; tile.nz[row] = nz; tile.nrm[row] = nrm;
         }
+        if (tid == 0) s_key = ((unsigned long long)kInfBits << 32);
         __syncthreads();
 
-        // ---- stage C: hypotheses h = wave, wave+4, ...; wave-local best ----
-        uint32_t T = kInfBits; // best quantile so far as an ordered bit pattern (r^2 >= 0)
-        int bh = -1;
+        // ---- stage C: hypotheses h = wave, wave+4, ...; best (quantile, h) shared through LDS ----
+        const v2f* px = reinterpret_cast<const v2f*>(tile.nx);
+        const v2f* py = reinterpret_cast<const v2f*>(tile.ny);
+        const v2f* pz = reinterpret_cast<const v2f*>(tile.nz);
         for (uint32_t h = wave; h < p.n_hyp; h += 4) {
-            f3 v = hypothesis(s_tile, p.seed, fr.id, p.stream_base + c, h, N);
-            uint32_t r2[NR];
-            uint32_t cnt = 0;
+            const f3 v = hypothesis(tile, p.seed, fr.id, p.stream_base + c, h, N);
+            uint32_t r2[NR]; // register 2m, 2m+1 <-> rows 2 (64 m + lane), +1
 #pragma unroll
-            for (int m = 0; m < NR; ++m) {
-                // keep at most four 16-byte tile reads in flight: hoisting all NR of them
-                // would cost 4 VGPRs each
-                if ((m & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-                uint32_t row = m * 64 + lane;
-                f4 t = s_tile[row];
-                float r = rs::dot(f3{t.x, t.y, t.z}, v) * t.w; // core_private.cpp:48
-                uint32_t bits = (row < N) ? __float_as_uint(r * r) : kInfBits;
-                r2[m] = bits;
-                cnt += (bits < T) ? 1u : 0u;
+            for (int m = 0; m < NR / 2; ++m) {
+                if ((m & 3) == 0) __builtin_amdgcn_sched_barrier(0); // bound the LDS reads in flight
+                const int idx = m * 64 + lane;
+                const v2f r = px[idx] * v.x + py[idx] * v.y + pz[idx] * v.z; // core_private.cpp:48
+                const v2f q = r * r;                                          // :49
+                r2[2 * m] = __float_as_uint(q.x);
+                r2[2 * m + 1] = __float_as_uint(q.y);
             }
-            // med < least_med  <=>  more than kq residuals lie below least_med (core_private.cpp:51-53)
-            if (wave_sum_u32(cnt) > kq) {
-                // exact kq-th smallest by bisection over the bit pattern
-                uint32_t res = 0;
-                for (int bit = 30; bit >= 0; --bit) {
-                    uint32_t trial = res | (1u << bit);
-                    uint32_t c2 = 0;
+            // (quantile_h, h) < (T, g)  <=>  more than kq residuals lie below T (+1 ulp if g > h):
+            // med < least_med of core_private.cpp:51-53 with the reference's first-wins tie rule
+            const unsigned long long key = __hip_atomic_load(&s_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t T = (uint32_t)(key >> 32), g = (uint32_t)key;
+            uint32_t hi2 = T + ((T != kInfBits && g > h) ? 1u : 0u);
+            const uint32_t tot = wave_count_lt(r2, hi2);
+            if (tot > kq) {
+                if (hi2 == kInfBits) { // no bound yet: start the bracket at the largest residual
+                    float mx = 0.f;
 #pragma unroll
-                    for (int m = 0; m < NR; ++m) c2 += (r2[m] < trial) ? 1u : 0u;
-                    if (wave_sum_u32(c2) <= kq) res = trial;
+                    for (int m = 0; m < NR; ++m) mx = fmaxf(mx, __uint_as_float(r2[m]));
+                    mx = wave_max_f32(mx);
+                    if (finite_f(mx)) hi2 = __float_as_uint(mx) + 1u; // count(r2 < hi2) is still tot
                 }
-                T = res;
-                bh = (int)h;
+                const uint32_t kth = select_kth(r2, kq, hi2, tot);
+                if (lane == 0) atomicMin(&s_key, ((unsigned long long)kth << 32) | h);
             }
-        }
-        if (lane == 0) {
-            s_bestT[wave] = T;
-            s_bestH[wave] = bh;
         }
         __syncthreads();
-        uint32_t bT = s_bestT[0];
-        int bH = s_bestH[0];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            uint32_t t = s_bestT[w];
-            int hh = s_bestH[w];
-            if (hh >= 0 && (bH < 0 || t < bT || (t == bT && hh < bH))) {
-                bT = t;
-                bH = hh;
-            }
-        }
+        const unsigned long long best = s_key;
+        const uint32_t bT = (uint32_t)(best >> 32);
+        const int bH = (bT == kInfBits) ? -1 : (int)(uint32_t)best;
         f3 Mv = f3{0, 0, 0};
-        if (bH >= 0) Mv = hypothesis(s_tile, p.seed, fr.id, p.stream_base + c, (uint32_t)bH, N);
+        if (bH >= 0) Mv = hypothesis(tile, p.seed, fr.id, p.stream_base + c, (uint32_t)bH, N);
         if (!(finite_f(Mv.x) && finite_f(Mv.y) && finite_f(Mv.z))) bad |= RSHIP_BAD_M;
 
         // ---- stage D: k = clamp(100 / |P M|), cost = sqrt(sum sqrt(log1p(r^2))) ----
         float ss = 0.f;
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
-            f4 t = s_tile[j * kBlock + tid];
-            float pm = rs::dot(f3{t.x, t.y, t.z}, Mv);
-            ss = fmaf(pm, pm, ss);
+            const uint32_t row = j * kBlock + tid;
+            if (row < N) {
+                const float pm = tile.nrm[row] * rs::dot(f3{tile.nx[row], tile.ny[row], tile.nz[row]}, Mv);
+                ss = fmaf(pm, pm, ss);
+            }
         }
         double ss_tot = block_sum(ss, s_red);
         float kf = 100.0f / sqrtf((float)ss_tot); // core_private.cpp:79
@@ -349,12 +464,11 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
             float acc = 0.f;
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
-                uint32_t row = j * kBlock + tid;
+                const uint32_t row = j * kBlock + tid;
                 if (row < N) {
-                    f4 t = s_tile[row];
-                    float r = rs::dot(f3{t.x, t.y, t.z}, Mv) * sc;
+                    const float r = tile.nrm[row] * rs::dot(f3{tile.nx[row], tile.ny[row], tile.nz[row]}, Mv) * sc;
                     if (!finite_f(r)) bad |= RSHIP_BAD_R;
-                    float rho = log1pf(r * r); // core_private.cpp:82
+                    const float rho = log1pf(r * r); // core_private.cpp:82
                     if (!finite_f(rho)) bad |= RSHIP_BAD_RHO;
                     acc += sqrtf(rho);
                 }
@@ -366,7 +480,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
             }
         }
         if (bad) atomicOr(p.flags, bad);
-        __syncthreads(); // tile is rewritten by the next candidate
+        __syncthreads(); // tile and key are rewritten by the next candidate
     }
 }
 
@@ -697,6 +811,38 @@ __global__ __launch_bounds__(kBlock) void debug_problem_kernel(DebugParams p) {
         residual_row<true>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], fr.base_knot + p.kd, p.fd, P, dP);
         p.P[3 * row] = P.x; p.P[3 * row + 1] = P.y; p.P[3 * row + 2] = P.z;
         if (p.dP) { p.dP[3 * row] = dP.x * p.fs; p.dP[3 * row + 1] = dP.y * p.fs; p.dP[3 * row + 2] = dP.z * p.fs; }
+    }
+}
+
+// debug: the wave-level exact selection on caller-provided residuals (one wave per problem,
+// 2048 slots, NaN-padded), exactly as the LMedS kernel drives it
+__global__ __launch_bounds__(64) void debug_select_kernel(const float* __restrict__ vals, uint32_t n, uint32_t kq,
+                                                          const float* __restrict__ upper, uint32_t* out) {
+    constexpr int NR = 32;
+    const int lane = threadIdx.x;
+    const float* v = vals + (size_t)blockIdx.x * n;
+    uint32_t r2[NR];
+#pragma unroll
+    for (int m = 0; m < NR; ++m) {
+        uint32_t i = m * 64 + lane;
+        r2[m] = (i < n) ? __float_as_uint(v[i]) : 0x7fc00000u;
+    }
+    uint32_t hi2 = upper ? __float_as_uint(upper[blockIdx.x]) : kInfBits;
+    const uint32_t tot = wave_count_lt(r2, hi2);
+    uint32_t res = 0xffffffffu; // "not better than the bound"
+    if (tot > kq) {
+        if (hi2 == kInfBits) {
+            float mx = 0.f;
+#pragma unroll
+            for (int m = 0; m < NR; ++m) mx = fmaxf(mx, __uint_as_float(r2[m]));
+            mx = wave_max_f32(mx);
+            if (finite_f(mx)) hi2 = __float_as_uint(mx) + 1u;
+        }
+        res = select_kth(r2, kq, hi2, tot);
+    }
+    if (lane == 0) {
+        out[2 * blockIdx.x] = res;
+        out[2 * blockIdx.x + 1] = tot;
     }
 }
 
@@ -1194,6 +1340,28 @@ int rship_debug_problem(rship_ctx* c, uint32_t sel_index, int32_t kd, float fd, 
     if (e == hipSuccess && dP) e = hipMemcpy(dP, (float*)out.p + (size_t)n * 3, (size_t)n * 12, hipMemcpyDeviceToHost);
     (void)hipFree(out.p);
     if (e != hipSuccess) return set_err(c, "debug_problem", e);
+    return 0;
+}
+
+int rship_debug_select(rship_ctx* c, const float* vals, uint32_t n_problems, uint32_t n, uint32_t kq,
+                       const float* upper, uint32_t* out) {
+    if (n > 2048 || !n_problems) return set_err(c, "debug_select: bad sizes");
+    DevBuf dv, du, dout;
+    if (ensure(c, dv, (size_t)n_problems * n * 4) || ensure(c, dout, (size_t)n_problems * 8)) return 1;
+    if (upper && ensure(c, du, (size_t)n_problems * 4)) return 1;
+    hipError_t e = hipMemcpy(dv.p, vals, (size_t)n_problems * n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && upper) e = hipMemcpy(du.p, upper, (size_t)n_problems * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(debug_select_kernel, dim3(n_problems), dim3(64), 0, c->stream, (const float*)dv.p, n, kq,
+                           upper ? (const float*)du.p : nullptr, (uint32_t*)dout.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, dout.p, (size_t)n_problems * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(dv.p);
+    (void)hipFree(dout.p);
+    if (du.p) (void)hipFree(du.p);
+    if (e != hipSuccess) return set_err(c, "debug_select", e);
     return 0;
 }
 
