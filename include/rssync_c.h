@@ -105,6 +105,9 @@ int rssync_ext_set_motion(rssync_problem* p, const double* M, const double* k, i
 int rssync_ext_loss(rssync_problem* p, const double* delays, int n, double* loss, double* grad);
 /* trace of the last Sync: rows of {delay_after, step, loss_at_x0, grad_at_x0, t, trials} */
 int rssync_ext_sync_trace(rssync_problem* p, double* trace, int cap_rows, int* n_rows);
+/* the internal device context (rship_ctx*, include/rssync_hip.h) behind this problem, for
+ * kernel-level tests and profiling tools; owned by the problem */
+void* rssync_ext_device_context(rssync_problem* p);
 /* HIP-event kernel timing: kind 0 LMedS tile (PreSync), 1 loss, 2 motion, 3 reduce, 4 LMedS init (Sync) */
 int rssync_ext_profile(rssync_problem* p, int enable);
 int rssync_ext_profile_get(rssync_problem* p, int kind, uint64_t* launches, double* total_ms);

@@ -108,6 +108,7 @@ struct Spline {
     const f4* lds;            // [4][kWinMax]
     int n;                    // knots
     int w0, wlen;             // staged range [w0, w0 + wlen)
+    bool all_in_lds;          // the staged range covers every knot the workgroup will touch
 };
 
 __device__ __forceinline__ void stage_window(Spline& s, f4* s_win, int lo, int hi) {
@@ -115,6 +116,7 @@ __device__ __forceinline__ void stage_window(Spline& s, f4* s_win, int lo, int h
     lo = lo < 0 ? 0 : (lo > n - 1 ? n - 1 : lo);
     hi = hi < 0 ? 0 : (hi > n - 1 ? n - 1 : hi);
     int wlen = hi - lo + 1;
+    s.all_in_lds = wlen <= kWinMax;
     if (wlen > kWinMax) wlen = kWinMax;
     s.w0 = lo;
     s.wlen = wlen;
@@ -125,29 +127,34 @@ __device__ __forceinline__ void stage_window(Spline& s, f4* s_win, int lo, int h
     }
 }
 
+// LDS = true: every knot is in the staged window (workgroup-uniform fact, so the reads stay
+// ds_read_b128; a per-lane choice between the LDS and the global table would turn them into
+// flat loads).  LDS = false: wild trial delays or very fast gyros, straight from L2.
+template <bool LDS>
 __device__ __forceinline__ void fetch_coef(const Spline& s, int ci, f4& y, f4& b, f4& c, f4& d) {
-    unsigned rel = (unsigned)(ci - s.w0);
-    if (rel < (unsigned)s.wlen) {
+    if (LDS) {
+        int rel = ci - s.w0;
+        rel = rel < 0 ? 0 : (rel > s.wlen - 1 ? s.wlen - 1 : rel); // never outside the staged range
         y = s.lds[rel];
         b = s.lds[kWinMax + rel];
         c = s.lds[2 * kWinMax + rel];
         d = s.lds[3 * kWinMax + rel];
-    } else { // outside the staged window (wild trial delays, very fast gyros): L2 path
+    } else {
         const f4* p = s.g + (size_t)ci * 4;
         y = p[0]; b = p[1]; c = p[2]; d = p[3];
     }
 }
 
 // one row of P = ar x br (core_private.cpp:24-28) and, if DERIV, dP/dx (x in knots)
-template <bool DERIV>
+template <bool DERIV, bool LDS>
 __device__ __forceinline__ void residual_row(const Spline& s, f4 ra, f4 rb, int base, float fd, f3& P, f3& dP) {
     f4 y, b, c, d;
     f3 ar, br, dar, dbr;
     rs::Knot ka = rs::spline_locate(ra.w, base, fd, s.n);
-    fetch_coef(s, ka.ci, y, b, c, d);
+    fetch_coef<LDS>(s, ka.ci, y, b, c, d);
     rs::rotate_ray<DERIV>(y, b, c, d, ka, f3{ra.x, ra.y, ra.z}, ar, dar);
     rs::Knot kb = rs::spline_locate(rb.w, base, fd, s.n);
-    fetch_coef(s, kb.ci, y, b, c, d);
+    fetch_coef<LDS>(s, kb.ci, y, b, c, d);
     rs::rotate_ray<DERIV>(y, b, c, d, kb, f3{rb.x, rb.y, rb.z}, br, dbr);
     P = rs::cross(ar, br);
     if (DERIV) dP = rs::add(rs::cross(dar, br), rs::cross(ar, dbr));
@@ -185,23 +192,26 @@ struct LmedsParams {
     uint32_t* flags;
 };
 
-// ---- LMedS tile in LDS, struct-of-arrays: unit rows n = safe_normalize(P) and |P| ----
+// ---- LMedS tile in LDS, struct-of-arrays: unit rows n = safe_normalize(P).  The norms |P|
+// stay in the registers of the thread that owns the row (only stage D needs them).
 struct Tile {
     float* nx;
     float* ny;
     float* nz;
-    float* nrm;
 };
 
-// hypothesis direction v = safe_normalize(P[i0] x P[i1]) (core_private.cpp:45-46), P = n |P|
+// hypothesis direction v = safe_normalize(P[i0] x P[i1]) (core_private.cpp:45-46).  The tile
+// holds unit rows, and P[i0] x P[i1] is a positive multiple of n[i0] x n[i1], so the direction is
+// the same; the "leave it un-normalised below 1e-12" rule of safe_normalize (inline_utils.hpp:5-11)
+// is applied to |n[i0] x n[i1]| instead of |P[i0] x P[i1]| (it only fires for rows parallel to
+// within 1e-12 rad, where the hypothesis is noise either way).
 __device__ __forceinline__ f3 hypothesis(const Tile& t, uint64_t seed, int64_t frame, uint32_t stream, uint32_t h,
                                          uint32_t n) {
     uint32_t i0, i1;
     rs::sample_pair(seed, frame, stream, h, n, i0, i1);
-    const float s0 = t.nrm[i0], s1 = t.nrm[i1];
-    f3 v = rs::cross(f3{t.nx[i0] * s0, t.ny[i0] * s0, t.nz[i0] * s0}, f3{t.nx[i1] * s1, t.ny[i1] * s1, t.nz[i1] * s1});
+    f3 v = rs::cross(f3{t.nx[i0], t.ny[i0], t.nz[i0]}, f3{t.nx[i1], t.ny[i1], t.nz[i1]});
     float nn = sqrtf(rs::dot(v, v));
-    if (!(nn < 1e-12f)) { // inline_utils.hpp:5-11
+    if (!(nn < 1e-12f)) {
         float inv = 1.0f / nn;
         v = rs::scale(v, inv);
     }
@@ -315,25 +325,79 @@ __device__ __forceinline__ uint32_t select_kth(const uint32_t (&r2)[NR], uint32_
     }
 }
 
+// stage A of the LMedS kernel: this thread's rows of P for one delay, written to the LDS tile as
+// unit rows, norms kept in nrm[]; returns RSHIP_BAD_P if a row is not finite
+template <int RPT, bool LDS>
+__device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const f4* __restrict__ rays_a,
+                                               const f4* __restrict__ rays_b, uint32_t N, int base, float fd,
+                                               const Tile& tile, float (&nrm)[RPT]) {
+    uint32_t bad = 0;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        if ((j & 1) == 0) __builtin_amdgcn_sched_barrier(0); // two rows in flight, not RPT
+        const uint32_t row = j * kBlock + threadIdx.x;
+        // rows beyond N are NaN: their residuals compare above every threshold
+        float nx = __uint_as_float(0x7fc00000u), ny = nx, nz = nx;
+        nrm[j] = 0.f;
+        if (row < N) {
+            f3 P, dP;
+            residual_row<false, LDS>(sp, rays_a[row], rays_b[row], base, fd, P, dP);
+            const float n2 = rs::dot(P, P);
+            if (!finite_f(n2)) bad |= RSHIP_BAD_P;
+            // safe_normalize (core_private.cpp:35-36): rows with |P| < 1e-12 stay as they are
+            const bool tiny = n2 < 1e-24f;
+            const float inv = tiny ? 1.f : rs::rsqrt_fast(n2);
+            nx = P.x * inv; ny = P.y * inv; nz = P.z * inv;
+            nrm[j] = tiny ? 1.f : n2 * inv;
+        }
+        tile.nx[row] = nx; tile.ny[row] = ny; tile.nz[row] = nz;
+    }
+    return bad;
+}
+
 // waves per SIMD each kernel is compiled for (second __launch_bounds__ argument): the
 // LMedS tile is LDS-limited to 3 workgroups per CU at 8 rows per thread
-__host__ __device__ constexpr int lmeds_waves(int rpt) { return 4; }
+__host__ __device__ constexpr int lmeds_waves(int rpt) { return 5; }
 __host__ __device__ constexpr int loss_waves(int rpt, bool grad) { return (grad || rpt >= 8) ? 3 : 4; }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr int kHypBatch = 64; // hypothesis directions prepared per batch (one per lane of wave 0)
+
+// Pop the next index of an LDS work queue for the whole wave: lane 0 alone performs the atomic,
+// the result is broadcast.  Written as one asm statement because hipcc's structuriser turns the
+// obvious `if (lane == 0) j = atomicAdd(..); j = readfirstlane(j);` inside a loop into a per-lane
+// waterfall that re-reads the queue head for the other lanes and never terminates.
+__device__ __forceinline__ uint32_t wave_pop(uint32_t* counter) {
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)counter;
+    const uint32_t one = 1u;
+    uint32_t old;
+    unsigned long long save;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "ds_add_rtn_u32 %0, %2, %3\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "=&v"(old), "=&s"(save)
+                 : "v"(addr), "v"(one)
+                 : "memory");
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+}
 
 template <int RPT, int MODE> // MODE 0: PreSync cost per candidate; 1: GuessMotion + GuessK
 __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsParams p) {
     constexpr int ROWS = kBlock * RPT;
     constexpr int NR = 4 * RPT; // residual registers per lane: a wave spans the whole tile
-    __shared__ __attribute__((aligned(16))) float s_n[4][ROWS];
+    __shared__ __attribute__((aligned(16))) float s_n[3][ROWS];
     __shared__ f4 s_win[4 * kWinMax];
+    __shared__ f4 s_hyp[kHypBatch];
     __shared__ double s_red[4];
     // best (quantile, hypothesis) so far, packed (bits << 32 | h): a 64-bit min is exactly
     // "smaller quantile wins, ties go to the earlier hypothesis" (core_private.cpp:53 strict <)
     __shared__ unsigned long long s_key;
+    __shared__ uint32_t s_next; // hypothesis queue of the current batch
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     // blocks b and b+8 share an XCD (round-robin dispatch): keep the chunks of one
     // frame on one XCD so its rays are fetched into one L2 only
     const uint32_t per = 8u * p.n_chunks;
@@ -345,7 +409,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     const FrameRec fr = p.frames[fi];
     const uint32_t N = fr.n;
     const uint32_t kq = N / 4; // core_private.cpp:52
-    const Tile tile{s_n[0], s_n[1], s_n[2], s_n[3]};
+    const Tile tile{s_n[0], s_n[1], s_n[2]};
 
     // rays are re-read per candidate: the chunks of a frame share an XCD, so after the
     // first touch they come from that XCD's L2 (keeping them in registers costs 64 VGPRs)
@@ -371,82 +435,96 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     }
     __syncthreads();
 
+    const v2f* px = reinterpret_cast<const v2f*>(tile.nx);
+    const v2f* py = reinterpret_cast<const v2f*>(tile.ny);
+    const v2f* pz = reinterpret_cast<const v2f*>(tile.nz);
+    uint32_t prev_best = kInfBits; // winning quantile of the previous candidate of this chunk
+
     for (uint32_t c = c0; c < c1; ++c) {
         const int base = fr.base_knot + p.kd[c];
         const float fd = p.fd[c];
+        const uint32_t stream = p.stream_base + c;
         uint32_t bad = 0;
-        // ---- stage A: rows of P -> LDS tile as unit rows + norms ----
-#pragma unroll 2
-        for (int j = 0; j < RPT; ++j) {
-            uint32_t row = j * kBlock + tid;
-            // rows beyond N are NaN: their residuals compare above every threshold
-            float nx = __uint_as_float(0x7fc00000u), ny = nx, nz = nx, nrm = 0.f;
-            if (row < N) {
-                f3 P, dP;
-                residual_row<false>(sp, rays_a[row], rays_b[row], base, fd, P, dP);
-                const float n2 = rs::dot(P, P);
-                if (!finite_f(n2)) bad |= RSHIP_BAD_P;
-                // safe_normalize (core_private.cpp:35-36): rows with |P| < 1e-12 stay as they are
-                const bool tiny = n2 < 1e-24f;
-                const float inv = tiny ? 1.f : rs::rsqrt_fast(n2);
-                nx = P.x * inv; ny = P.y * inv; nz = P.z * inv;
-                nrm = tiny ? 1.f : n2 * inv;
-            }
-            tile.nx[row] = nx; tile.ny[row] = ny; tile.nz[row] = nz; tile.nrm[row] = nrm;
-        }
-        if (tid == 0) s_key = ((unsigned long long)kInfBits << 32);
-        __syncthreads();
+        // ---- stage A: rows of P -> LDS tile as unit rows; norms stay in registers ----
+        float nrm[RPT];
+        if (sp.all_in_lds) bad |= lmeds_rows<RPT, true>(sp, rays_a, rays_b, N, base, fd, tile, nrm);
+        else bad |= lmeds_rows<RPT, false>(sp, rays_a, rays_b, N, base, fd, tile, nrm);
 
-        // ---- stage C: hypotheses h = wave, wave+4, ...; best (quantile, h) shared through LDS ----
-        const v2f* px = reinterpret_cast<const v2f*>(tile.nx);
-        const v2f* py = reinterpret_cast<const v2f*>(tile.ny);
-        const v2f* pz = reinterpret_cast<const v2f*>(tile.nz);
-        for (uint32_t h = wave; h < p.n_hyp; h += 4) {
-            const f3 v = hypothesis(tile, p.seed, fr.id, p.stream_base + c, h, N);
-            uint32_t r2[NR]; // register 2m, 2m+1 <-> rows 2 (64 m + lane), +1
-#pragma unroll
-            for (int m = 0; m < NR / 2; ++m) {
-                if ((m & 3) == 0) __builtin_amdgcn_sched_barrier(0); // bound the LDS reads in flight
-                const int idx = m * 64 + lane;
-                const v2f r = px[idx] * v.x + py[idx] * v.y + pz[idx] * v.z; // core_private.cpp:48
-                const v2f q = r * r;                                          // :49
-                r2[2 * m] = __float_as_uint(q.x);
-                r2[2 * m + 1] = __float_as_uint(q.y);
-            }
-            // (quantile_h, h) < (T, g)  <=>  more than kq residuals lie below T (+1 ulp if g > h):
-            // med < least_med of core_private.cpp:51-53 with the reference's first-wins tie rule
-            const unsigned long long key = __hip_atomic_load(&s_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const uint32_t T = (uint32_t)(key >> 32), g = (uint32_t)key;
-            uint32_t hi2 = T + ((T != kInfBits && g > h) ? 1u : 0u);
-            const uint32_t tot = wave_count_lt(r2, hi2);
-            if (tot > kq) {
-                if (hi2 == kInfBits) { // no bound yet: start the bracket at the largest residual
-                    float mx = 0.f;
-#pragma unroll
-                    for (int m = 0; m < NR; ++m) mx = fmaxf(mx, __uint_as_float(r2[m]));
-                    mx = wave_max_f32(mx);
-                    if (finite_f(mx)) hi2 = __float_as_uint(mx) + 1u; // count(r2 < hi2) is still tot
+        // ---- stage C: the hypotheses.  The best quantile of the previous candidate (x4) serves as
+        // a provisional bound: a hypothesis that has <= kq residuals below it is dropped after one
+        // counting pass.  If nothing beats the bound the candidate is redone without it, so the
+        // result is the exact arg-min either way.
+        uint32_t guess = kInfBits;
+        if (prev_best < 0x7e000000u && prev_best > 0x00800000u) guess = prev_best + 0x01000000u; // x4
+        unsigned long long best;
+        for (;;) {
+            if (tid == 0) s_key = ((unsigned long long)guess << 32);
+            for (uint32_t batch = 0; batch < p.n_hyp; batch += kHypBatch) {
+                const uint32_t nb = (p.n_hyp - batch < (uint32_t)kHypBatch) ? p.n_hyp - batch : (uint32_t)kHypBatch;
+                __syncthreads(); // tile written / previous batch consumed
+                if ((uint32_t)tid < nb) {
+                    const f3 v = hypothesis(tile, p.seed, fr.id, stream, batch + tid, N);
+                    s_hyp[tid] = f4{v.x, v.y, v.z, 0.f};
                 }
-                const uint32_t kth = select_kth(r2, kq, hi2, tot);
-                if (lane == 0) atomicMin(&s_key, ((unsigned long long)kth << 32) | h);
+                if (tid == 0) s_next = 0;
+                __syncthreads();
+                for (;;) { // waves pull hypotheses from the queue: no wave idles at the barrier
+                    const uint32_t j = wave_pop(&s_next);
+                    if (j >= nb) break;
+                    const uint32_t h = batch + j;
+                    const f4 hv = s_hyp[j];
+                    uint32_t r2[NR]; // register 2m, 2m+1 <-> rows 2 (64 m + lane), +1
+#pragma unroll
+                    for (int m = 0; m < NR / 2; ++m) {
+                        if ((m & 3) == 0) __builtin_amdgcn_sched_barrier(0); // bound the LDS reads in flight
+                        const int idx = m * 64 + lane;
+                        const v2f r = px[idx] * hv.x + py[idx] * hv.y + pz[idx] * hv.z; // core_private.cpp:48
+                        const v2f q = r * r;                                             // :49
+                        r2[2 * m] = __float_as_uint(q.x);
+                        r2[2 * m + 1] = __float_as_uint(q.y);
+                    }
+                    // (quantile_h, h) < (T, g)  <=>  more than kq residuals lie below T (+1 ulp if g > h):
+                    // med < least_med of core_private.cpp:51-53 with the reference's first-wins tie rule
+                    const unsigned long long key = __hip_atomic_load(&s_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t T = (uint32_t)(key >> 32), g = (uint32_t)key;
+                    uint32_t hi2 = T + ((T != kInfBits && g > h) ? 1u : 0u);
+                    const uint32_t tot = wave_count_lt(r2, hi2);
+                    if (tot > kq) {
+                        if (hi2 == kInfBits) { // no bound yet: start the bracket at the largest residual
+                            float mx = 0.f;
+#pragma unroll
+                            for (int m = 0; m < NR; ++m) mx = fmaxf(mx, __uint_as_float(r2[m]));
+                            mx = wave_max_f32(mx);
+                            if (finite_f(mx)) hi2 = __float_as_uint(mx) + 1u; // count(r2 < hi2) is still tot
+                        }
+                        const uint32_t kth = select_kth(r2, kq, hi2, tot);
+                        if (lane == 0) atomicMin(&s_key, ((unsigned long long)kth << 32) | h);
+                    }
+                }
             }
+            __syncthreads();
+            best = s_key;
+            if (guess == kInfBits || best != ((unsigned long long)guess << 32)) break;
+            guess = kInfBits; // nothing beat the provisional bound: redo this candidate without it
+            __syncthreads();  // everyone has read s_key before it is reset
         }
-        __syncthreads();
-        const unsigned long long best = s_key;
         const uint32_t bT = (uint32_t)(best >> 32);
         const int bH = (bT == kInfBits) ? -1 : (int)(uint32_t)best;
+        prev_best = bT;
         f3 Mv = f3{0, 0, 0};
-        if (bH >= 0) Mv = hypothesis(tile, p.seed, fr.id, p.stream_base + c, (uint32_t)bH, N);
+        if (bH >= 0) Mv = hypothesis(tile, p.seed, fr.id, stream, (uint32_t)bH, N);
         if (!(finite_f(Mv.x) && finite_f(Mv.y) && finite_f(Mv.z))) bad |= RSHIP_BAD_M;
 
         // ---- stage D: k = clamp(100 / |P M|), cost = sqrt(sum sqrt(log1p(r^2))) ----
+        float pm[RPT];
         float ss = 0.f;
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const uint32_t row = j * kBlock + tid;
+            pm[j] = 0.f;
             if (row < N) {
-                const float pm = tile.nrm[row] * rs::dot(f3{tile.nx[row], tile.ny[row], tile.nz[row]}, Mv);
-                ss = fmaf(pm, pm, ss);
+                pm[j] = nrm[j] * rs::dot(f3{tile.nx[row], tile.ny[row], tile.nz[row]}, Mv);
+                ss = fmaf(pm[j], pm[j], ss);
             }
         }
         double ss_tot = block_sum(ss, s_red);
@@ -466,9 +544,9 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
             for (int j = 0; j < RPT; ++j) {
                 const uint32_t row = j * kBlock + tid;
                 if (row < N) {
-                    const float r = tile.nrm[row] * rs::dot(f3{tile.nx[row], tile.ny[row], tile.nz[row]}, Mv) * sc;
+                    const float r = pm[j] * sc;
                     if (!finite_f(r)) bad |= RSHIP_BAD_R;
-                    const float rho = log1pf(r * r); // core_private.cpp:82
+                    const float rho = rs::log1p_pos(r * r); // core_private.cpp:82
                     if (!finite_f(rho)) bad |= RSHIP_BAD_RHO;
                     acc += sqrtf(rho);
                 }
@@ -505,6 +583,29 @@ struct LossParams {
     double* part_grad; // [n_delays][n_sel] (GRAD)
 };
 
+// this thread's rows of one frame at one delay: sum of log1p(u) and of the d/d-delay terms
+template <int RPT, bool GRAD, bool LDS>
+__device__ __forceinline__ void loss_rows(const Spline& sp, const f4* __restrict__ rays_a,
+                                          const f4* __restrict__ rays_b, uint32_t N, int base, float fd, f3 Mv,
+                                          float inv_s, float& L, float& G) {
+#pragma unroll 1
+    for (int j = 0; j < RPT; ++j) {
+        const uint32_t row = j * kBlock + threadIdx.x;
+        if (row < N) {
+            f3 P, dP;
+            residual_row<GRAD, LDS>(sp, rays_a[row], rays_b[row], base, fd, P, dP);
+            const float pm = rs::dot(P, Mv);
+            const float u = pm * pm * inv_s;
+            L += rs::log1p_pos(u); // core_private.cpp:121-122
+            if (GRAD) {
+                // dL/dd = sum 1/(1+u) * (2 pm / s) * (dP/dd . M), dP/dd = fs * dP/dx
+                const float w = rs::rcp_fast(1.f + u);
+                G = fmaf(w * 2.f * pm * inv_s, rs::dot(dP, Mv), G);
+            }
+        }
+    }
+}
+
 template <int RPT, bool GRAD>
 __global__ __launch_bounds__(kBlock, loss_waves(RPT, GRAD)) void loss_kernel(LossParams p) {
     __shared__ f4 s_win[4 * kWinMax];
@@ -535,22 +636,8 @@ __global__ __launch_bounds__(kBlock, loss_waves(RPT, GRAD)) void loss_kernel(Los
         __syncthreads();
         const int base = fr.base_knot + kd;
         float L = 0.f, G = 0.f;
-#pragma unroll 1
-        for (int j = 0; j < RPT; ++j) {
-            uint32_t row = j * kBlock + tid;
-            if (row < N) {
-                f3 P, dP;
-                residual_row<GRAD>(sp, rays_a[row], rays_b[row], base, fd, P, dP);
-                float pm = rs::dot(P, Mv);
-                float u = pm * pm * inv_s;
-                L += log1pf(u); // core_private.cpp:121-122
-                if (GRAD) {
-                    // dL/dd = sum 1/(1+u) * (2 pm / s) * (dP/dd . M), dP/dd = fs * dP/dx
-                    float w = rs::rcp_fast(1.f + u);
-                    G = fmaf(w * 2.f * pm * inv_s, rs::dot(dP, Mv), G);
-                }
-            }
-        }
+        if (sp.all_in_lds) loss_rows<RPT, GRAD, true>(sp, rays_a, rays_b, N, base, fd, Mv, inv_s, L, G);
+        else loss_rows<RPT, GRAD, false>(sp, rays_a, rays_b, N, base, fd, Mv, inv_s, L, G);
         double Lw = wave_sum_f64((double)L);
         double Gw = GRAD ? wave_sum_f64((double)G) : 0.0;
         if (lane == 0) {
@@ -611,7 +698,7 @@ struct MotionEval {
             float pm = rs::dot(P[j], xv);
             float v2 = pm * pm;
             float u = v2 * inv_s;
-            L += log1pf(u);
+            L += rs::log1p_pos(u);
             float w = rs::rcp_fast(1.f + u);
             float a = w * 2.f * pm * inv_s;
             a0 = fmaf(a, P[j].x, a0);
@@ -673,7 +760,10 @@ __global__ __launch_bounds__(kBlock, 4) void opt_motion_kernel(MotionParams p) {
     for (int j = 0; j < RPT; ++j) {
         uint32_t row = j * kBlock + tid;
         f3 P = f3{0, 0, 0}, dP;
-        if (row < N) residual_row<false>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], base, p.fd, P, dP);
+        if (row < N) {
+            if (sp.all_in_lds) residual_row<false, true>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], base, p.fd, P, dP);
+            else residual_row<false, false>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], base, p.fd, P, dP);
+        }
         ev.P[j] = P; // zero rows contribute log1p(0) = 0 and no gradient
     }
 
@@ -808,7 +898,8 @@ __global__ __launch_bounds__(kBlock) void debug_problem_kernel(DebugParams p) {
     __syncthreads();
     for (uint32_t row = blockIdx.x * kBlock + threadIdx.x; row < fr.n; row += gridDim.x * kBlock) {
         f3 P, dP;
-        residual_row<true>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], fr.base_knot + p.kd, p.fd, P, dP);
+        if (sp.all_in_lds) residual_row<true, true>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], fr.base_knot + p.kd, p.fd, P, dP);
+        else residual_row<true, false>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], fr.base_knot + p.kd, p.fd, P, dP);
         p.P[3 * row] = P.x; p.P[3 * row + 1] = P.y; p.P[3 * row + 2] = P.z;
         if (p.dP) { p.dP[3 * row] = dP.x * p.fs; p.dP[3 * row + 1] = dP.y * p.fs; p.dP[3 * row + 2] = dP.z * p.fs; }
     }

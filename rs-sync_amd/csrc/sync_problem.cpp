@@ -738,6 +738,8 @@ int rssync_ext_sync_trace(rssync_problem* p, double* trace, int cap_rows, int* n
     return 0;
 }
 
+void* rssync_ext_device_context(rssync_problem* p) { return p->impl->dev(); }
+
 int rssync_ext_profile(rssync_problem* p, int enable) { return rship_profile_enable(p->impl->dev(), enable); }
 int rssync_ext_profile_get(rssync_problem* p, int kind, uint64_t* launches, double* total_ms) {
     return rship_profile_get(p->impl->dev(), kind, launches, total_ms);

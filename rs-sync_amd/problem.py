@@ -60,6 +60,7 @@ SIGNATURES = {
     "rssync_ext_set_motion": (C.c_int, [C.c_void_p, _PD, _PD, C.c_int]),
     "rssync_ext_loss": (C.c_int, [C.c_void_p, _PD, C.c_int, _PD, _PD]),
     "rssync_ext_sync_trace": (C.c_int, [C.c_void_p, _PD, C.c_int, C.POINTER(C.c_int)]),
+    "rssync_ext_device_context": (C.c_void_p, [C.c_void_p]),
     "rssync_ext_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "rssync_ext_profile_get": (C.c_int, [C.c_void_p, C.c_int, _PU64, _PD]),
     "rssync_ext_profile_reset": (C.c_int, [C.c_void_p]),
@@ -266,6 +267,10 @@ class SyncProblem:
         t, n = np.zeros((cap, 6)), C.c_int()
         self._lib.rssync_ext_sync_trace(self._h, _p(t), cap, C.byref(n))
         return t[:min(n.value, cap)].copy()
+
+    def device_context(self):
+        """rship_ctx* of this problem (include/rssync_hip.h), for kernel-level tools."""
+        return self._lib.rssync_ext_device_context(self._h)
 
     def profile(self, enable=True):
         self._check(self._lib.rssync_ext_profile(self._h, 1 if enable else 0))
