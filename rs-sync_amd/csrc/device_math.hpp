@@ -99,6 +99,16 @@ RS_HD Knot spline_locate(float t, int base, float fd, int n) {
     return k;
 }
 
+// Same as spline_locate when the caller knows (for a whole workgroup) that every parameter falls
+// strictly inside the knots, 0 <= idx <= n-2: no extrapolation branch can be taken.
+RS_HD Knot spline_locate_interior(float t, int base, float fd) {
+    float fl = floorf(t);
+    float f = (t - fl) + fd;
+    int idx = base + (int)fl;
+    if (f >= 1.f) { f -= 1.f; idx += 1; }
+    return Knot{idx, f, false};
+}
+
 // coefficient row = {y, b, c, d}, each an f4 over the quaternion components [w,x,y,z]
 RS_HD f4 horner(f4 y, f4 b, f4 c, f4 d, float h) {
     return {fmaf(fmaf(fmaf(d.x, h, c.x), h, b.x), h, y.x), fmaf(fmaf(fmaf(d.y, h, c.y), h, b.y), h, y.y),
@@ -109,13 +119,16 @@ RS_HD f4 horner_deriv(f4 b, f4 c, f4 d, float h) { // minispline.cpp:57-64
             fmaf(fmaf(3.f * d.z, h, 2.f * c.z), h, b.z), fmaf(fmaf(3.f * d.w, h, 2.f * c.w), h, b.w)};
 }
 
-// R(q)^T v for a unit quaternion q = (w, u):  v - 2w (u x v) + 2 u x (u x v)
-// == vec(conj(q) (0,v) q), i.e. quat_rotate_point(quat_conj(q), v) (quat.cpp:45-47)
-RS_HD f3 rotate_inv(f4 q, f3 v) {
+// R(q/|q|)^T v for a quaternion q = (w, u) of squared norm n2, without normalising q first:
+//   v + (2 / n2) (u x (u x v) - w (u x v))
+// == vec(conj(qn) (0,v) qn) with qn = q/|q|, i.e. quat_rotate_point(quat_conj(qn), v)
+// (quat.cpp:45-47 after arma::normalise, core_private.cpp:24-27).  n2 == 0 leaves v unchanged.
+RS_HD f3 rotate_inv(f4 q, float two_over_n2, f3 v) {
     f3 u = {q.y, q.z, q.w};
     f3 t = cross(u, v);
     f3 t2 = cross(u, t);
-    return {v.x + 2.f * (t2.x - q.x * t.x), v.y + 2.f * (t2.y - q.x * t.y), v.z + 2.f * (t2.z - q.x * t.z)};
+    return {fmaf(two_over_n2, t2.x - q.x * t.x, v.x), fmaf(two_over_n2, t2.y - q.x * t.y, v.y),
+            fmaf(two_over_n2, t2.z - q.x * t.z, v.z)};
 }
 
 // One end of a ray pair: rotated ray r = R(S(x)/|S(x)|)^T ray and, if DERIV,
@@ -125,14 +138,12 @@ RS_HD void rotate_ray(f4 y, f4 b, f4 c, f4 d, Knot kn, f3 ray, f3& r, f3& dr) {
     if (kn.quad) d = {0.f, 0.f, 0.f, 0.f};
     f4 q = horner(y, b, c, d, kn.h);
     float n2 = dot4(q, q);
-    float inv = (n2 > 0.f) ? rsqrt_fast(n2) : 1.f; // arma::normalise: divide by 1 when |q| = 0
-    f4 qn = {q.x * inv, q.y * inv, q.z * inv, q.w * inv};
-    r = rotate_inv(qn, ray);
+    float s = (n2 > 0.f) ? 2.f * rcp_fast(n2) : 0.f;
+    r = rotate_inv(q, s, ray);
     if (DERIV) {
         f4 dq = horner_deriv(b, c, d, kn.h);
         f3 u = {q.y, q.z, q.w}, du = {dq.y, dq.z, dq.w};
         f3 uxdu = cross(u, du);
-        float s = 2.f * rcp_fast(n2);
         f3 W = {s * (q.x * du.x - dq.x * u.x - uxdu.x), s * (q.x * du.y - dq.x * u.y - uxdu.y),
                 s * (q.x * du.z - dq.x * u.z - uxdu.z)};
         dr = cross(r, W);

@@ -88,10 +88,10 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 
 // workgroup sum of a per-thread fp32 partial: fp32 inside the wave, fp64 across
-// the four waves.  `slot` is a 4-double LDS scratch; two barriers.
+// the four waves.  `slot` is a 4-double LDS scratch that the caller must not reuse before another
+// barrier has passed (one barrier here).
 __device__ __forceinline__ double block_sum(float v, double* slot) {
     float w = wave_sum_f32(v);
-    __syncthreads(); // previous readers of slot are done
     if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = (double)w;
     __syncthreads();
     return slot[0] + slot[1] + slot[2] + slot[3];
@@ -108,15 +108,22 @@ struct Spline {
     const f4* lds;            // [4][kWinMax]
     int n;                    // knots
     int w0, wlen;             // staged range [w0, w0 + wlen)
-    bool all_in_lds;          // the staged range covers every knot the workgroup will touch
+    int path;                 // kPathGlobal / kPathLds / kPathInterior, uniform over the workgroup
 };
+
+// How a workgroup reads spline coefficients.  The choice is made once per workgroup from the knot
+// range it can touch, so that the hot loops carry no per-lane LDS-or-global selection (which
+// would turn ds_read_b128 into flat loads) and, in the common case, no extrapolation logic.
+constexpr int kPathGlobal = 0;   // general: any parameter (extrapolation branches included), table read from L2
+constexpr int kPathInterior = 2; // staged in LDS and strictly inside the knots (0 <= idx <= n-2)
 
 __device__ __forceinline__ void stage_window(Spline& s, f4* s_win, int lo, int hi) {
     const int n = s.n;
+    const bool interior = lo >= 0 && hi <= n - 2;
     lo = lo < 0 ? 0 : (lo > n - 1 ? n - 1 : lo);
     hi = hi < 0 ? 0 : (hi > n - 1 ? n - 1 : hi);
     int wlen = hi - lo + 1;
-    s.all_in_lds = wlen <= kWinMax;
+    s.path = (wlen <= kWinMax && interior) ? kPathInterior : kPathGlobal;
     if (wlen > kWinMax) wlen = kWinMax;
     s.w0 = lo;
     s.wlen = wlen;
@@ -127,34 +134,30 @@ __device__ __forceinline__ void stage_window(Spline& s, f4* s_win, int lo, int h
     }
 }
 
-// LDS = true: every knot is in the staged window (workgroup-uniform fact, so the reads stay
-// ds_read_b128; a per-lane choice between the LDS and the global table would turn them into
-// flat loads).  LDS = false: wild trial delays or very fast gyros, straight from L2.
-template <bool LDS>
+template <int PATH>
 __device__ __forceinline__ void fetch_coef(const Spline& s, int ci, f4& y, f4& b, f4& c, f4& d) {
-    if (LDS) {
-        int rel = ci - s.w0;
-        rel = rel < 0 ? 0 : (rel > s.wlen - 1 ? s.wlen - 1 : rel); // never outside the staged range
+    if (PATH == kPathGlobal) {
+        const f4* p = s.g + (size_t)ci * 4;
+        y = p[0]; b = p[1]; c = p[2]; d = p[3];
+    } else {
+        const int rel = ci - s.w0;
         y = s.lds[rel];
         b = s.lds[kWinMax + rel];
         c = s.lds[2 * kWinMax + rel];
         d = s.lds[3 * kWinMax + rel];
-    } else {
-        const f4* p = s.g + (size_t)ci * 4;
-        y = p[0]; b = p[1]; c = p[2]; d = p[3];
     }
 }
 
 // one row of P = ar x br (core_private.cpp:24-28) and, if DERIV, dP/dx (x in knots)
-template <bool DERIV, bool LDS>
+template <bool DERIV, int PATH>
 __device__ __forceinline__ void residual_row(const Spline& s, f4 ra, f4 rb, int base, float fd, f3& P, f3& dP) {
     f4 y, b, c, d;
     f3 ar, br, dar, dbr;
-    rs::Knot ka = rs::spline_locate(ra.w, base, fd, s.n);
-    fetch_coef<LDS>(s, ka.ci, y, b, c, d);
+    rs::Knot ka = (PATH == kPathInterior) ? rs::spline_locate_interior(ra.w, base, fd) : rs::spline_locate(ra.w, base, fd, s.n);
+    fetch_coef<PATH>(s, ka.ci, y, b, c, d);
     rs::rotate_ray<DERIV>(y, b, c, d, ka, f3{ra.x, ra.y, ra.z}, ar, dar);
-    rs::Knot kb = rs::spline_locate(rb.w, base, fd, s.n);
-    fetch_coef<LDS>(s, kb.ci, y, b, c, d);
+    rs::Knot kb = (PATH == kPathInterior) ? rs::spline_locate_interior(rb.w, base, fd) : rs::spline_locate(rb.w, base, fd, s.n);
+    fetch_coef<PATH>(s, kb.ci, y, b, c, d);
     rs::rotate_ray<DERIV>(y, b, c, d, kb, f3{rb.x, rb.y, rb.z}, br, dbr);
     P = rs::cross(ar, br);
     if (DERIV) dP = rs::add(rs::cross(dar, br), rs::cross(ar, dbr));
@@ -218,19 +221,20 @@ __device__ __forceinline__ f3 hypothesis(const Tile& t, uint64_t seed, int64_t f
     return v;
 }
 
-// per-lane count of x_i < pivot over four registers.  Hand-scheduled: hipcc turns the obvious
-// `cnt += x < pivot` into a bit-packing sequence of ~5 VALU per element; this is 2 per element.
-// The compares write SGPR pairs that the add-with-carry reads as its carry-in; gfx950 needs two
-// wait states between a VALU write of an SGPR and a VALU read of it, which the interleaving
-// provides.  The pivot is passed in a VGPR so that no SGPR written just before the block is read.
+// per-lane count of |x_i| < pivot over four registers holding fp32 residuals (the abs source
+// modifier is free).  Hand-scheduled: hipcc turns the obvious `cnt += x < pivot` into a
+// bit-packing sequence of ~5 VALU per element; this is 2 per element.  The compares write SGPR
+// pairs that the add-with-carry reads as its carry-in; gfx950 needs two wait states between a
+// VALU write of an SGPR and a VALU read of it, which the interleaving provides.  The pivot is
+// passed in a VGPR so that no SGPR written just before the block is read.  NaN never counts.
 __device__ __forceinline__ void count4(uint32_t& cnt, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3,
                                        uint32_t pivot_v) {
     unsigned long long a, b, c;
-    asm("v_cmp_gt_u32_e64 %1, %8, %4\n\t"
-        "v_cmp_gt_u32_e64 %2, %8, %5\n\t"
-        "v_cmp_gt_u32_e64 %3, %8, %6\n\t"
+    asm("v_cmp_gt_f32_e64 %1, %8, |%4|\n\t"
+        "v_cmp_gt_f32_e64 %2, %8, |%5|\n\t"
+        "v_cmp_gt_f32_e64 %3, %8, |%6|\n\t"
         "v_addc_co_u32_e64 %0, vcc, 0, %0, %1\n\t"
-        "v_cmp_gt_u32_e64 %1, %8, %7\n\t"
+        "v_cmp_gt_f32_e64 %1, %8, |%7|\n\t"
         "v_addc_co_u32_e64 %0, vcc, 0, %0, %2\n\t"
         "v_addc_co_u32_e64 %0, vcc, 0, %0, %3\n\t"
         "v_addc_co_u32_e64 %0, vcc, 0, %0, %1"
@@ -239,14 +243,14 @@ __device__ __forceinline__ void count4(uint32_t& cnt, uint32_t x0, uint32_t x1, 
         : "vcc");
 }
 
-// wave-wide count of r2[] < pivot (pivot uniform)
+// wave-wide count of |r[]| < pivot (pivot: bit pattern of a non-negative float, uniform)
 template <int NR>
-__device__ __forceinline__ uint32_t wave_count_lt(const uint32_t (&r2)[NR], uint32_t pivot) {
+__device__ __forceinline__ uint32_t wave_count_lt(const uint32_t (&r)[NR], uint32_t pivot) {
     uint32_t cnt = 0;
     uint32_t pv = pivot;
     asm volatile("" : "+v"(pv)); // keep the pivot in a VGPR
 #pragma unroll
-    for (int m = 0; m < NR; m += 4) count4(cnt, r2[m], r2[m + 1], r2[m + 2], r2[m + 3], pv);
+    for (int m = 0; m < NR; m += 4) count4(cnt, r[m], r[m + 1], r[m + 2], r[m + 3], pv);
     asm volatile("s_nop 1" : "+v"(cnt)); // VALU write -> DPP read of cnt: two wait states
     return wave_sum_u32(cnt);
 }
@@ -280,77 +284,93 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// Exact kq-th smallest (0-based) of the wave's r2[] bit patterns (the value std::sort would leave
-// at index kq, core_private.cpp:51-52), given an exclusive upper bound hi2 with
-// count(r2 < hi2) = c_hi > kq.  A bracket [lo2, hi2) with counts c_lo <= kq < c_hi is narrowed by
-// counting passes; pivots come from a secant step on the empirical CDF in the sqrt domain
-// (|r| is close to uniformly distributed around the lower quartile, so the CDF is nearly linear
-// there: ~8 passes instead of 31 bit-bisection passes), with bracket interpolation and plain
-// bisection of the bit pattern as fallbacks.  Ends when the bracket is one bit pattern wide or
-// holds exactly one element, which is then extracted with a min pass.
+// Exact kq-th smallest (0-based) of the wave's |r[]| as a bit pattern, given an exclusive upper
+// bound hi with count(|r| < hi) = c_hi > kq.  |r| orders exactly like the r^2 the reference sorts
+// (core_private.cpp:49-52), so this is the element std::sort would leave at index kq, before
+// squaring.  A bracket [lo, hi) with counts c_lo <= kq < c_hi is narrowed by counting passes;
+// pivots come from a secant step on the empirical CDF of |r| (close to uniform around the lower
+// quartile, so the CDF is nearly linear there: ~8 passes instead of 31 bit-bisection passes), with
+// bracket interpolation and plain bisection of the bit pattern as fallbacks.  Ends when the
+// bracket is one bit pattern wide or holds exactly one element, which a min pass extracts.
 template <int NR>
-__device__ __forceinline__ uint32_t select_kth(const uint32_t (&r2)[NR], uint32_t kq, uint32_t hi2, uint32_t c_hi) {
-    uint32_t lo2 = 0, c_lo = 0;
-    float alo = 0.f, ahi = sqrtf(__uint_as_float(hi2));
+__device__ __forceinline__ uint32_t select_kth(const uint32_t (&r)[NR], uint32_t kq, uint32_t hi, uint32_t c_hi) {
+    uint32_t lo = 0, c_lo = 0;
+    float alo = 0.f, ahi = __uint_as_float(hi);
     float a1 = 0.f, c1 = 0.f, a2 = ahi, c2 = (float)c_hi;
     const float target = (float)kq + 0.5f;
     for (int it = 0;; ++it) {
-        if (hi2 - lo2 == 1u) return lo2;
+        if (hi - lo == 1u) return lo;
         if (c_hi - c_lo == 1u) {
-            // the single element in [lo2, hi2): smallest x >= lo2; x < lo2 wraps to a huge difference
+            // the single element in [lo, hi): smallest |x| >= lo; |x| < lo wraps to a huge difference
             uint32_t mn = 0xffffffffu;
 #pragma unroll
             for (int m = 0; m < NR; ++m) {
-                uint32_t d = r2[m] - lo2;
+                uint32_t d = (r[m] & 0x7fffffffu) - lo;
                 mn = d < mn ? d : mn;
             }
-            return lo2 + wave_min_u32(mn);
+            return lo + wave_min_u32(mn);
         }
         uint32_t piv;
         if (it < 24) {
             float a3 = a2 + (target - c2) * (a2 - a1) / (c2 - c1);
             if (!(c2 != c1 && a3 > alo && a3 < ahi))
                 a3 = alo + (target - (float)c_lo) / (float)(c_hi - c_lo) * (ahi - alo);
-            piv = __float_as_uint(a3 * a3);
-            if (!(piv > lo2 && piv < hi2)) piv = lo2 + ((hi2 - lo2) >> 1);
+            piv = __float_as_uint(a3);
+            if (!(piv > lo && piv < hi)) piv = lo + ((hi - lo) >> 1);
         } else {
-            piv = lo2 + ((hi2 - lo2) >> 1); // guaranteed finish: <= 31 more passes
+            piv = lo + ((hi - lo) >> 1); // guaranteed finish: <= 31 more passes
         }
         piv = (uint32_t)__builtin_amdgcn_readfirstlane((int)piv);
-        const uint32_t c = wave_count_lt(r2, piv);
+        const uint32_t c = wave_count_lt(r, piv);
         a1 = a2; c1 = c2;
-        a2 = sqrtf(__uint_as_float(piv)); c2 = (float)c;
-        if (c <= kq) { lo2 = piv; c_lo = c; alo = a2; }
-        else { hi2 = piv; c_hi = c; ahi = a2; }
+        a2 = __uint_as_float(piv); c2 = (float)c;
+        if (c <= kq) { lo = piv; c_lo = c; alo = a2; }
+        else { hi = piv; c_hi = c; ahi = a2; }
     }
 }
 
 // stage A of the LMedS kernel: this thread's rows of P for one delay, written to the LDS tile as
 // unit rows, norms kept in nrm[]; returns RSHIP_BAD_P if a row is not finite
-template <int RPT, bool LDS>
+template <int PATH>
+__device__ __forceinline__ uint32_t lmeds_row(const Spline& sp, const f4* __restrict__ rays_a,
+                                              const f4* __restrict__ rays_b, uint32_t N, uint32_t row, int base, float fd,
+                                              const Tile& tile, float& nrm) {
+    uint32_t bad = 0;
+    // rows beyond N are NaN: their residuals compare above every threshold
+    float nx = __uint_as_float(0x7fc00000u), ny = nx, nz = nx;
+    nrm = 0.f;
+    if (row < N) {
+        f3 P, dP;
+        residual_row<false, PATH>(sp, rays_a[row], rays_b[row], base, fd, P, dP);
+        const float n2 = rs::dot(P, P);
+        if (!finite_f(n2)) bad = RSHIP_BAD_P;
+        // safe_normalize (core_private.cpp:35-36): rows with |P| < 1e-12 stay as they are
+        const bool tiny = n2 < 1e-24f;
+        const float inv = tiny ? 1.f : rs::rsqrt_fast(n2);
+        nx = P.x * inv; ny = P.y * inv; nz = P.z * inv;
+        nrm = tiny ? 1.f : n2 * inv;
+    }
+    tile.nx[row] = nx; tile.ny[row] = ny; tile.nz[row] = nz;
+    return bad;
+}
+
+template <int RPT>
 __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const f4* __restrict__ rays_a,
                                                const f4* __restrict__ rays_b, uint32_t N, int base, float fd,
                                                const Tile& tile, float (&nrm)[RPT]) {
     uint32_t bad = 0;
+    if (sp.path == kPathInterior) {
 #pragma unroll
-    for (int j = 0; j < RPT; ++j) {
-        if ((j & 1) == 0) __builtin_amdgcn_sched_barrier(0); // two rows in flight, not RPT
-        const uint32_t row = j * kBlock + threadIdx.x;
-        // rows beyond N are NaN: their residuals compare above every threshold
-        float nx = __uint_as_float(0x7fc00000u), ny = nx, nz = nx;
-        nrm[j] = 0.f;
-        if (row < N) {
-            f3 P, dP;
-            residual_row<false, LDS>(sp, rays_a[row], rays_b[row], base, fd, P, dP);
-            const float n2 = rs::dot(P, P);
-            if (!finite_f(n2)) bad |= RSHIP_BAD_P;
-            // safe_normalize (core_private.cpp:35-36): rows with |P| < 1e-12 stay as they are
-            const bool tiny = n2 < 1e-24f;
-            const float inv = tiny ? 1.f : rs::rsqrt_fast(n2);
-            nx = P.x * inv; ny = P.y * inv; nz = P.z * inv;
-            nrm[j] = tiny ? 1.f : n2 * inv;
+        for (int j = 0; j < RPT; ++j) {
+            bad |= lmeds_row<kPathInterior>(sp, rays_a, rays_b, N, j * kBlock + threadIdx.x, base, fd, tile, nrm[j]);
         }
-        tile.nx[row] = nx; tile.ny[row] = ny; tile.nz[row] = nz;
+    } else { // rare (ends of the gyro track, wild delays): keep the code small, not fast
+        float tmp[RPT];
+#pragma unroll 1
+        for (int j = 0; j < RPT; ++j)
+            bad |= lmeds_row<kPathGlobal>(sp, rays_a, rays_b, N, j * kBlock + threadIdx.x, base, fd, tile, tmp[j]);
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) nrm[j] = tmp[j];
     }
     return bad;
 }
@@ -391,7 +411,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     __shared__ __attribute__((aligned(16))) float s_n[3][ROWS];
     __shared__ f4 s_win[4 * kWinMax];
     __shared__ f4 s_hyp[kHypBatch];
-    __shared__ double s_red[4];
+    __shared__ double s_red[2][4];
     // best (quantile, hypothesis) so far, packed (bits << 32 | h): a 64-bit min is exactly
     // "smaller quantile wins, ties go to the earlier hypothesis" (core_private.cpp:53 strict <)
     __shared__ unsigned long long s_key;
@@ -447,8 +467,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         uint32_t bad = 0;
         // ---- stage A: rows of P -> LDS tile as unit rows; norms stay in registers ----
         float nrm[RPT];
-        if (sp.all_in_lds) bad |= lmeds_rows<RPT, true>(sp, rays_a, rays_b, N, base, fd, tile, nrm);
-        else bad |= lmeds_rows<RPT, false>(sp, rays_a, rays_b, N, base, fd, tile, nrm);
+        bad |= lmeds_rows<RPT>(sp, rays_a, rays_b, N, base, fd, tile, nrm);
 
         // ---- stage C: the hypotheses.  The best quantile of the previous candidate (x4) serves as
         // a provisional bound: a hypothesis that has <= kq residuals below it is dropped after one
@@ -473,17 +492,17 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                     if (j >= nb) break;
                     const uint32_t h = batch + j;
                     const f4 hv = s_hyp[j];
+                    // residuals r = nP v (core_private.cpp:48); |r| orders like the r^2 of :49-52
                     uint32_t r2[NR]; // register 2m, 2m+1 <-> rows 2 (64 m + lane), +1
 #pragma unroll
                     for (int m = 0; m < NR / 2; ++m) {
                         if ((m & 3) == 0) __builtin_amdgcn_sched_barrier(0); // bound the LDS reads in flight
                         const int idx = m * 64 + lane;
-                        const v2f r = px[idx] * hv.x + py[idx] * hv.y + pz[idx] * hv.z; // core_private.cpp:48
-                        const v2f q = r * r;                                             // :49
-                        r2[2 * m] = __float_as_uint(q.x);
-                        r2[2 * m + 1] = __float_as_uint(q.y);
+                        const v2f r = px[idx] * hv.x + py[idx] * hv.y + pz[idx] * hv.z;
+                        r2[2 * m] = __float_as_uint(r.x);
+                        r2[2 * m + 1] = __float_as_uint(r.y);
                     }
-                    // (quantile_h, h) < (T, g)  <=>  more than kq residuals lie below T (+1 ulp if g > h):
+                    // (quantile_h, h) < (T, g)  <=>  more than kq |residuals| lie below T (+1 ulp if g > h):
                     // med < least_med of core_private.cpp:51-53 with the reference's first-wins tie rule
                     const unsigned long long key = __hip_atomic_load(&s_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     const uint32_t T = (uint32_t)(key >> 32), g = (uint32_t)key;
@@ -493,9 +512,9 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                         if (hi2 == kInfBits) { // no bound yet: start the bracket at the largest residual
                             float mx = 0.f;
 #pragma unroll
-                            for (int m = 0; m < NR; ++m) mx = fmaxf(mx, __uint_as_float(r2[m]));
+                            for (int m = 0; m < NR; ++m) mx = fmaxf(mx, fabsf(__uint_as_float(r2[m])));
                             mx = wave_max_f32(mx);
-                            if (finite_f(mx)) hi2 = __float_as_uint(mx) + 1u; // count(r2 < hi2) is still tot
+                            if (finite_f(mx)) hi2 = __float_as_uint(mx) + 1u; // count(|r| < hi2) is still tot
                         }
                         const uint32_t kth = select_kth(r2, kq, hi2, tot);
                         if (lane == 0) atomicMin(&s_key, ((unsigned long long)kth << 32) | h);
@@ -527,7 +546,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                 ss = fmaf(pm[j], pm[j], ss);
             }
         }
-        double ss_tot = block_sum(ss, s_red);
+        double ss_tot = block_sum(ss, s_red[0]);
         float kf = 100.0f / sqrtf((float)ss_tot); // core_private.cpp:79
         kf = (kf < 10.f) ? 10.f : ((1000.f < kf) ? 1000.f : kf);
         if (MODE == 1) {
@@ -551,7 +570,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                     acc += sqrtf(rho);
                 }
             }
-            double acc_tot = block_sum(acc, s_red);
+            double acc_tot = block_sum(acc, s_red[1]);
             if (tid == 0) {
                 p.frame_cost[(size_t)c * p.n_sel + sf] = sqrt(acc_tot); // core_private.cpp:85
                 if (p.best_h) p.best_h[(size_t)c * p.n_sel + sf] = bH;
@@ -584,7 +603,7 @@ struct LossParams {
 };
 
 // this thread's rows of one frame at one delay: sum of log1p(u) and of the d/d-delay terms
-template <int RPT, bool GRAD, bool LDS>
+template <int RPT, bool GRAD, int PATH>
 __device__ __forceinline__ void loss_rows(const Spline& sp, const f4* __restrict__ rays_a,
                                           const f4* __restrict__ rays_b, uint32_t N, int base, float fd, f3 Mv,
                                           float inv_s, float& L, float& G) {
@@ -593,7 +612,7 @@ __device__ __forceinline__ void loss_rows(const Spline& sp, const f4* __restrict
         const uint32_t row = j * kBlock + threadIdx.x;
         if (row < N) {
             f3 P, dP;
-            residual_row<GRAD, LDS>(sp, rays_a[row], rays_b[row], base, fd, P, dP);
+            residual_row<GRAD, PATH>(sp, rays_a[row], rays_b[row], base, fd, P, dP);
             const float pm = rs::dot(P, Mv);
             const float u = pm * pm * inv_s;
             L += rs::log1p_pos(u); // core_private.cpp:121-122
@@ -636,8 +655,8 @@ __global__ __launch_bounds__(kBlock, loss_waves(RPT, GRAD)) void loss_kernel(Los
         __syncthreads();
         const int base = fr.base_knot + kd;
         float L = 0.f, G = 0.f;
-        if (sp.all_in_lds) loss_rows<RPT, GRAD, true>(sp, rays_a, rays_b, N, base, fd, Mv, inv_s, L, G);
-        else loss_rows<RPT, GRAD, false>(sp, rays_a, rays_b, N, base, fd, Mv, inv_s, L, G);
+        if (sp.path == kPathInterior) loss_rows<RPT, GRAD, kPathInterior>(sp, rays_a, rays_b, N, base, fd, Mv, inv_s, L, G);
+        else loss_rows<RPT, GRAD, kPathGlobal>(sp, rays_a, rays_b, N, base, fd, Mv, inv_s, L, G);
         double Lw = wave_sum_f64((double)L);
         double Gw = GRAD ? wave_sum_f64((double)G) : 0.0;
         if (lane == 0) {
@@ -761,8 +780,8 @@ __global__ __launch_bounds__(kBlock, 4) void opt_motion_kernel(MotionParams p) {
         uint32_t row = j * kBlock + tid;
         f3 P = f3{0, 0, 0}, dP;
         if (row < N) {
-            if (sp.all_in_lds) residual_row<false, true>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], base, p.fd, P, dP);
-            else residual_row<false, false>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], base, p.fd, P, dP);
+            if (sp.path == kPathInterior) residual_row<false, kPathInterior>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], base, p.fd, P, dP);
+            else residual_row<false, kPathGlobal>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], base, p.fd, P, dP);
         }
         ev.P[j] = P; // zero rows contribute log1p(0) = 0 and no gradient
     }
@@ -898,8 +917,8 @@ __global__ __launch_bounds__(kBlock) void debug_problem_kernel(DebugParams p) {
     __syncthreads();
     for (uint32_t row = blockIdx.x * kBlock + threadIdx.x; row < fr.n; row += gridDim.x * kBlock) {
         f3 P, dP;
-        if (sp.all_in_lds) residual_row<true, true>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], fr.base_knot + p.kd, p.fd, P, dP);
-        else residual_row<true, false>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], fr.base_knot + p.kd, p.fd, P, dP);
+        if (sp.path == kPathInterior) residual_row<true, kPathInterior>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], fr.base_knot + p.kd, p.fd, P, dP);
+        else residual_row<true, kPathGlobal>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], fr.base_knot + p.kd, p.fd, P, dP);
         p.P[3 * row] = P.x; p.P[3 * row + 1] = P.y; p.P[3 * row + 2] = P.z;
         if (p.dP) { p.dP[3 * row] = dP.x * p.fs; p.dP[3 * row + 1] = dP.y * p.fs; p.dP[3 * row + 2] = dP.z * p.fs; }
     }
@@ -925,7 +944,7 @@ __global__ __launch_bounds__(64) void debug_select_kernel(const float* __restric
         if (hi2 == kInfBits) {
             float mx = 0.f;
 #pragma unroll
-            for (int m = 0; m < NR; ++m) mx = fmaxf(mx, __uint_as_float(r2[m]));
+            for (int m = 0; m < NR; ++m) mx = fmaxf(mx, fabsf(__uint_as_float(r2[m])));
             mx = wave_max_f32(mx);
             if (finite_f(mx)) hi2 = __float_as_uint(mx) + 1u;
         }
