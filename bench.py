@@ -71,15 +71,9 @@ def main():
     t_gen = time.time() - t_gen
 
     if world > 1:
-        red = torch.zeros(4096, dtype=torch.float64, device="cuda")
-
-        def hook(arr):  # sum a few doubles over the ranks: RCCL all-reduce over xGMI
-            n = arr.shape[0]
-            red[:n].copy_(torch.from_numpy(arr))
-            dist.all_reduce(red[:n])
-            arr[:] = red[:n].cpu().numpy()
-
-        prob.set_reduce_hook(hook)
+        from rssync_amd.dist import make_reduce_hook
+        # the only exchange of the path: a sum of a few doubles, as an RCCL all-reduce over xGMI
+        prob.set_reduce_hook(make_reduce_hook("cuda"))
 
     t_up = time.time()
     prob.upload()  # rays + spline into HBM before the timed region

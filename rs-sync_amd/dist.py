@@ -1,0 +1,44 @@
+"""Frame-sharded multi-GPU runs: one process per GPU, ``torch.distributed`` (backend "nccl" is
+RCCL on ROCm) for the only exchange the path has -- a sum of a few doubles per step.
+
+Every rank holds its own frames in its own ``SyncProblem``; PreSync exchanges the candidate cost
+vector once, Sync exchanges {loss, d loss / d delay} and the batched line-search losses (two
+all-reduces per outer iteration).  The optimiser state is replicated: every rank sees the same
+sums and takes the same decisions, so no other traffic is needed.
+"""
+import numpy as np
+
+
+def make_reduce_hook(device=None, capacity=8192):
+    """Return fn(np.ndarray float64) that sums the array in place over all ranks.
+
+    device: torch device of the staging tensor ("cuda" for the nccl/RCCL backend, "cpu" for gloo).
+    """
+    import torch
+    import torch.distributed as dist
+
+    if device is None:
+        device = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    buf = torch.zeros(capacity, dtype=torch.float64, device=device)
+    stats = {"calls": 0, "doubles": 0}
+
+    def hook(arr):
+        n = arr.shape[0]
+        if n > capacity:
+            raise ValueError("reduce hook: buffer too small")
+        buf[:n].copy_(torch.from_numpy(arr))
+        dist.all_reduce(buf[:n])
+        arr[:] = buf[:n].cpu().numpy()
+        stats["calls"] += 1
+        stats["doubles"] += n
+
+    hook.stats = stats
+    return hook
+
+
+def shard(frame_begin, frame_end, rank, world):
+    """Contiguous block of frames [begin, end) owned by `rank`."""
+    n = frame_end - frame_begin
+    per = (n + world - 1) // world
+    b = frame_begin + rank * per
+    return min(b, frame_end), min(b + per, frame_end)

@@ -67,6 +67,15 @@ SIGNATURES = {
 }
 
 
+def bind(lib):
+    """Attach the C-ABI signatures of include/rssync_c.h to a loaded library."""
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
 def load_library():
     """dlopen librssync_core.so and bind every C-ABI symbol; raises if it is missing."""
     global _LIB
@@ -77,13 +86,8 @@ def load_library():
         raise RsSyncError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C rs-sync_amd/csrc); there is no fallback implementation")
-    lib = C.CDLL(path)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)
-        fn.restype = res
-        fn.argtypes = args
-    _LIB = lib
-    return lib
+    _LIB = bind(C.CDLL(path))
+    return _LIB
 
 
 def _d(a):
@@ -97,8 +101,10 @@ def _p(a, t=_PD):
 class SyncProblem:
     """``CreateSyncProblem()`` + the six ``ISyncProblem`` methods (rssync.h:9-31)."""
 
-    def __init__(self, seed=None, max_outer_iters=None, verbose=False):
-        self._lib = load_library()
+    def __init__(self, seed=None, max_outer_iters=None, verbose=False, _lib=None):
+        # _lib: tests pass a build of the same host code linked against a CPU test double of the
+        # device ABI (tests/cpu_device); the package itself only ever loads librssync_core.so
+        self._lib = _lib if _lib is not None else load_library()
         self._lib.rssync_set_panic_mode(1)  # report panics as exceptions instead of exit(1)
         self._h = self._lib.rssync_create()
         if not self._h:

@@ -108,24 +108,33 @@ def make_gyro(t_begin, t_end, fs=400.0, seed=0, margin=1.0):
 
 def make_frames(gyro, frame_begin, frame_end, n_tracks, seed=0, d_true=D_TRUE, noise=1e-3, outliers=0.10,
                 chunk=256):
-    """Yield (frame, ts_a, ts_b, rays_a, rays_b) for frames [frame_begin, frame_end)."""
+    """Yield (frame, ts_a, ts_b, rays_a, rays_b) for frames [frame_begin, frame_end).
+
+    Every frame draws from its own generator keyed on (seed, frame), so a shard of the range
+    (one rank of a multi-GPU run) sees exactly the frames the whole range would contain."""
     for f0 in range(frame_begin, frame_end, chunk):
         f1 = min(f0 + chunk, frame_end)
         nf = f1 - f0
-        rng = np.random.default_rng([seed, f0])
         frames = np.arange(f0, f1)
-        ya = rng.uniform(0, 1, size=(nf, n_tracks))
-        yb = np.clip(ya + rng.normal(0, 0.03, size=ya.shape), 0.0, 0.999)
+        u = np.empty((nf, 6, n_tracks))      # uniforms: ya, cos, phi, depth, outlier mask, spare
+        g = np.empty((nf, 7, n_tracks))      # normals: yb jitter, 3 noise, 3 outlier direction
+        for i, fr in enumerate(frames):
+            rng = np.random.default_rng([seed, int(fr)])
+            u[i] = rng.uniform(size=(6, n_tracks))
+            g[i] = rng.normal(size=(7, n_tracks))
+        ya = u[:, 0]
+        yb = np.clip(ya + 0.03 * g[:, 0], 0.0, 0.999)
         ts_a = frames[:, None] / FPS + READOUT * ya
         ts_b = (frames[:, None] + 1) / FPS + READOUT * yb
         # camera-frame ray of the current frame inside a +-55 degree cone around +z
-        cos_t = rng.uniform(np.cos(np.deg2rad(55.0)), 1.0, size=ya.shape)
+        c55 = np.cos(np.deg2rad(55.0))
+        cos_t = c55 + (1.0 - c55) * u[:, 1]
         sin_t = np.sqrt(1 - cos_t ** 2)
-        phi = rng.uniform(0, 2 * np.pi, size=ya.shape)
+        phi = 2 * np.pi * u[:, 2]
         a_cam = np.stack([sin_t * np.cos(phi), sin_t * np.sin(phi), cos_t], axis=-1)
-        depth = rng.uniform(2.0, 50.0, size=ya.shape)[..., None]
+        depth = (2.0 + 48.0 * u[:, 3])[..., None]
         # slowly varying translation direction, 0.05 m per frame
-        ang = 0.002 * frames + rng.uniform(0, 2 * np.pi)
+        ang = 0.002 * frames + 0.7 * seed
         tdir = np.stack([np.cos(ang), np.sin(ang) * np.cos(0.3 * ang), np.sin(ang) * np.sin(0.3 * ang)], axis=-1)
         trans = 0.05 * tdir[:, None, :]
         qa = gyro.orientation(ts_a + d_true)
@@ -136,12 +145,12 @@ def make_frames(gyro, frame_begin, frame_end, n_tracks, seed=0, d_true=D_TRUE, n
         b_world /= np.linalg.norm(b_world, axis=-1, keepdims=True)
         b_cam = rotate(qb, b_world)
         if noise > 0:
-            b_cam = b_cam + rng.normal(0, noise, size=b_cam.shape)
+            b_cam = b_cam + noise * np.moveaxis(g[:, 1:4], 1, -1)
             b_cam /= np.linalg.norm(b_cam, axis=-1, keepdims=True)
         if outliers > 0:
-            mask = rng.uniform(size=ya.shape) < outliers
-            rnd = rng.normal(size=b_cam.shape)
-            rnd /= np.linalg.norm(rnd, axis=-1, keepdims=True)
+            mask = u[:, 4] < outliers
+            rnd = np.moveaxis(g[:, 4:7], 1, -1)
+            rnd = rnd / np.linalg.norm(rnd, axis=-1, keepdims=True)
             b_cam = np.where(mask[..., None], rnd, b_cam)
         for i in range(nf):
             yield int(frames[i]), ts_a[i], ts_b[i], a_cam[i], b_cam[i]

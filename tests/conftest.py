@@ -22,6 +22,24 @@ def built():
 
 
 @pytest.fixture(scope="session")
+def hosttest_lib(built):
+    """The product's host solver (sync_problem.cpp) linked against the CPU test double of the
+    device ABI (tests/cpu_device/rship_cpu.cpp): host logic on a machine without a GPU."""
+    import ctypes
+    import subprocess
+    from rssync_amd.problem import bind
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "librssync_hosttest.so")
+    srcs = [os.path.join(ROOT, "rs-sync_amd", "csrc", "sync_problem.cpp"),
+            os.path.join(ROOT, "tests", "cpu_device", "rship_cpu.cpp")]
+    deps = srcs + [os.path.join(ROOT, "rs-sync_amd", "csrc", "device_math.hpp")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", out] + srcs)
+    return bind(ctypes.CDLL(out))
+
+
+@pytest.fixture(scope="session")
 def small_case(built):
     """64 frames x 256 tracks, 400 Hz gyro (BASELINE config 1), noise + 10 % outliers."""
     from rssync_amd import synth

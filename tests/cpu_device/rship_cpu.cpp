@@ -1,0 +1,363 @@
+// rship_cpu.cpp -- TEST DOUBLE for the device C-ABI (include/rssync_hip.h).
+//
+// The product's host solver (rs-sync_amd/csrc/sync_problem.cpp) talks to the GPU through the
+// rship_* entry points.  To exercise that host code on a machine without a GPU -- the Sync
+// control loop, frame selection, delay splitting, panics, and the multi-rank reduce hook under
+// gloo -- the tests link the SAME sync_problem.cpp against this file instead of the HIP
+// translation unit.  It evaluates the kernels' arithmetic (the shared header device_math.hpp,
+// fp32) sequentially on the CPU.  It is built only by tests/conftest.py into
+// tests/_build/librssync_hosttest.so, is never part of librssync_core.so, and nothing under
+// rs-sync_amd/ can load it.
+#include "../../include/rssync_hip.h"
+#include "../../rs-sync_amd/csrc/device_math.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using rs::f3;
+using rs::f4;
+
+struct rship_ctx {
+    std::string err;
+    std::vector<f4> coef; // 4 per knot
+    double fs = 0;
+    std::vector<f4> rays_a, rays_b;
+    std::vector<rship_frame> frames;
+    std::vector<uint32_t> sel;
+    std::vector<double> M, k; // per table frame
+};
+
+namespace {
+
+int fail(rship_ctx* c, const char* m) { c->err = m; return 1; }
+
+void row(const rship_ctx* c, const rship_frame& fr, uint32_t i, int32_t kd, float fd, f3& P, f3* dP) {
+    const int n = (int)(c->coef.size() / 4);
+    const f4 ra = c->rays_a[fr.ray_offset + i], rb = c->rays_b[fr.ray_offset + i];
+    f3 r[2], dr[2];
+    const f4 rays[2] = {ra, rb};
+    for (int s = 0; s < 2; ++s) {
+        rs::Knot kn = rs::spline_locate(rays[s].w, fr.base_knot + kd, fd, n);
+        const f4* p = &c->coef[(size_t)kn.ci * 4];
+        if (dP) rs::rotate_ray<true>(p[0], p[1], p[2], p[3], kn, f3{rays[s].x, rays[s].y, rays[s].z}, r[s], dr[s]);
+        else rs::rotate_ray<false>(p[0], p[1], p[2], p[3], kn, f3{rays[s].x, rays[s].y, rays[s].z}, r[s], dr[s]);
+    }
+    P = rs::cross(r[0], r[1]);
+    if (dP) *dP = rs::add(rs::cross(dr[0], r[1]), rs::cross(r[0], dr[1]));
+}
+
+struct Rows {
+    std::vector<f3> n;
+    std::vector<float> nrm;
+    bool bad = false;
+};
+
+Rows unit_rows(const rship_ctx* c, const rship_frame& fr, int32_t kd, float fd) {
+    Rows t;
+    t.n.resize(fr.n_rays);
+    t.nrm.resize(fr.n_rays);
+    for (uint32_t i = 0; i < fr.n_rays; ++i) {
+        f3 P;
+        row(c, fr, i, kd, fd, P, nullptr);
+        float n2 = rs::dot(P, P);
+        if (!std::isfinite(n2)) t.bad = true;
+        bool tiny = n2 < 1e-24f;
+        float inv = tiny ? 1.f : 1.0f / std::sqrt(n2);
+        t.n[i] = rs::scale(P, inv);
+        t.nrm[i] = tiny ? 1.f : n2 * inv;
+    }
+    return t;
+}
+
+f3 hypothesis(const Rows& t, uint64_t seed, int64_t frame, uint32_t stream, uint32_t h) {
+    uint32_t i0, i1;
+    rs::sample_pair(seed, frame, stream, h, (uint32_t)t.n.size(), i0, i1);
+    f3 v = rs::cross(t.n[i0], t.n[i1]);
+    float nn = std::sqrt(rs::dot(v, v));
+    if (!(nn < 1e-12f)) v = rs::scale(v, 1.0f / nn);
+    return v;
+}
+
+// LMedS arg-min over hypotheses of the lower quartile of |r| (ties: first wins)
+int lmeds(const Rows& t, uint32_t n_hyp, uint64_t seed, int64_t frame, uint32_t stream, f3& Mv) {
+    const size_t N = t.n.size(), kq = N / 4;
+    std::vector<float> a(N);
+    float best = INFINITY;
+    int bh = -1;
+    for (uint32_t h = 0; h < n_hyp; ++h) {
+        f3 v = hypothesis(t, seed, frame, stream, h);
+        for (size_t i = 0; i < N; ++i) a[i] = std::fabs(rs::dot(t.n[i], v));
+        std::nth_element(a.begin(), a.begin() + kq, a.end());
+        if (a[kq] < best) { best = a[kq]; bh = (int)h; }
+    }
+    Mv = f3{0, 0, 0};
+    if (bh >= 0) Mv = hypothesis(t, seed, frame, stream, (uint32_t)bh);
+    return bh;
+}
+
+float clampk(float k) { return (k < 10.f) ? 10.f : ((1000.f < k) ? 1000.f : k); }
+
+} // namespace
+
+extern "C" {
+
+int rship_max_tracks(void) { return 2048; }
+int rship_create(rship_ctx** out, int) { *out = new rship_ctx(); return 0; }
+void rship_destroy(rship_ctx* c) { delete c; }
+const char* rship_last_error(const rship_ctx* c) { return c->err.c_str(); }
+int rship_set_stream(rship_ctx*, void*) { return 0; }
+
+int rship_upload_spline(rship_ctx* c, const float* coef16, uint32_t n_knots, double sample_rate) {
+    c->coef.resize((size_t)n_knots * 4);
+    std::memcpy(c->coef.data(), coef16, (size_t)n_knots * 64);
+    c->fs = sample_rate;
+    return 0;
+}
+
+int rship_upload_frames(rship_ctx* c, const float* a4, const float* b4, uint64_t total, const rship_frame* table, uint32_t nf) {
+    c->rays_a.resize(total);
+    c->rays_b.resize(total);
+    if (total) {
+        std::memcpy(c->rays_a.data(), a4, total * 16);
+        std::memcpy(c->rays_b.data(), b4, total * 16);
+    }
+    c->frames.assign(table, table + nf);
+    c->M.assign((size_t)nf * 3, 0.0);
+    c->k.assign(nf, 0.0);
+    c->sel.clear();
+    return 0;
+}
+
+int rship_select_frames(rship_ctx* c, const uint32_t* idx, uint32_t n) {
+    c->sel.assign(idx, idx + n);
+    return 0;
+}
+
+int rship_presync_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand, uint32_t n_hyp,
+                        uint32_t stream_base, uint64_t seed, double* costs, uint32_t* flags, double* frame_costs,
+                        int32_t* best_h) {
+    uint32_t fl = 0;
+    for (uint32_t ci = 0; ci < n_cand; ++ci) {
+        double total = 0;
+        for (size_t s = 0; s < c->sel.size(); ++s) {
+            const rship_frame& fr = c->frames[c->sel[s]];
+            Rows t = unit_rows(c, fr, kd[ci], fd[ci]);
+            if (t.bad) fl |= RSHIP_BAD_P;
+            f3 Mv;
+            int bh = lmeds(t, n_hyp, seed, fr.id, stream_base + ci, Mv);
+            if (!(std::isfinite(Mv.x) && std::isfinite(Mv.y) && std::isfinite(Mv.z))) fl |= RSHIP_BAD_M;
+            double ss = 0;
+            std::vector<float> pm(fr.n_rays);
+            for (uint32_t i = 0; i < fr.n_rays; ++i) {
+                pm[i] = t.nrm[i] * rs::dot(t.n[i], Mv);
+                ss += (double)pm[i] * pm[i];
+            }
+            float kf = clampk(100.0f / std::sqrt((float)ss));
+            float sc = kf / std::sqrt(rs::dot(Mv, Mv));
+            double acc = 0;
+            for (uint32_t i = 0; i < fr.n_rays; ++i) {
+                float r = pm[i] * sc;
+                if (!std::isfinite(r)) fl |= RSHIP_BAD_R;
+                float rho = rs::log1p_pos(r * r);
+                if (!std::isfinite(rho)) fl |= RSHIP_BAD_RHO;
+                acc += std::sqrt(rho);
+            }
+            double cost = std::sqrt(acc);
+            total += cost;
+            if (frame_costs) frame_costs[(size_t)ci * c->sel.size() + s] = cost;
+            if (best_h) best_h[(size_t)ci * c->sel.size() + s] = bh;
+        }
+        costs[ci] = total;
+    }
+    if (flags) *flags = fl;
+    return 0;
+}
+
+int rship_init_motion(rship_ctx* c, int32_t kd, float fd, uint32_t n_hyp, uint32_t stream, uint64_t seed) {
+    for (uint32_t fi : c->sel) {
+        const rship_frame& fr = c->frames[fi];
+        Rows t = unit_rows(c, fr, kd, fd);
+        f3 Mv;
+        lmeds(t, n_hyp, seed, fr.id, stream, Mv);
+        double ss = 0;
+        for (uint32_t i = 0; i < fr.n_rays; ++i) {
+            float pm = t.nrm[i] * rs::dot(t.n[i], Mv);
+            ss += (double)pm * pm;
+        }
+        c->M[3 * fi] = Mv.x; c->M[3 * fi + 1] = Mv.y; c->M[3 * fi + 2] = Mv.z;
+        c->k[fi] = clampk(100.0f / std::sqrt((float)ss));
+    }
+    return 0;
+}
+
+// the kernel's L-BFGS (rssync_kernels.hip: opt_motion_kernel), sequential
+int rship_opt_motion(rship_ctx* c, int32_t kd, float fd, uint64_t* stats) {
+    uint64_t tot_it = 0, tot_ev = 0;
+    for (uint32_t fi : c->sel) {
+        const rship_frame& fr = c->frames[fi];
+        std::vector<f3> P(fr.n_rays);
+        for (uint32_t i = 0; i < fr.n_rays; ++i) row(c, fr, i, kd, fd, P[i], nullptr);
+        const double k2 = c->k[fi] * c->k[fi];
+        int evals = 0;
+        auto ev = [&](const double x[3], double g[3]) {
+            ++evals;
+            const double s = (x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) / k2;
+            const float inv_s = (float)(1.0 / s);
+            const f3 xv{(float)x[0], (float)x[1], (float)x[2]};
+            double L = 0, a0 = 0, a1 = 0, a2 = 0, gs = 0;
+            for (const f3& p : P) {
+                float pm = rs::dot(p, xv), v2 = pm * pm, u = v2 * inv_s;
+                L += rs::log1p_pos(u);
+                float w = 1.0f / (1.f + u), a = w * 2.f * pm * inv_s;
+                a0 += a * p.x; a1 += a * p.y; a2 += a * p.z;
+                gs += w * v2 * inv_s * inv_s;
+            }
+            const double tt = gs * 2.0 / k2;
+            g[0] = a0 - tt * x[0]; g[1] = a1 - tt * x[1]; g[2] = a2 - tt * x[2];
+            return L;
+        };
+        auto dot3 = [](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+        constexpr int NB = 10;
+        double S[NB][3], Y[NB][3], rho[NB], alpha[NB];
+        double x[3] = {c->M[3 * fi], c->M[3 * fi + 1], c->M[3 * fi + 2]}, g[3], oldx[3], oldg[3], dir[3];
+        double fval = ev(x, g);
+        int it = 0;
+        for (; it != 200; ++it) {
+            const double prev = fval;
+            if (std::sqrt(dot3(g, g)) < 1e-4 || fval != fval) break;
+            double scale;
+            if (it > 0) {
+                int pp = (it - 1) % NB;
+                double yy = dot3(Y[pp], Y[pp]);
+                scale = dot3(S[pp], Y[pp]) / ((yy >= 1e-10) ? yy : 1.0);
+            } else {
+                double gn = std::sqrt(dot3(g, g));
+                scale = (gn >= 1e-5) ? 1.0 / gn : 1.0;
+            }
+            if (scale == 0.0 || scale != scale) break;
+            for (int q = 0; q < 3; ++q) dir[q] = g[q];
+            int limit = (NB > it) ? 0 : (it - NB);
+            for (int i = it; i != limit; --i) {
+                int tp = (i + NB - 1) % NB;
+                rho[it - i] = 1.0 / dot3(Y[tp], S[tp]);
+                alpha[it - i] = rho[it - i] * dot3(S[tp], dir);
+                for (int q = 0; q < 3; ++q) dir[q] -= alpha[it - i] * Y[tp][q];
+            }
+            for (int q = 0; q < 3; ++q) dir[q] *= scale;
+            for (int i = limit; i < it; ++i) {
+                int tp = i % NB;
+                double beta = rho[it - i - 1] * dot3(Y[tp], dir);
+                for (int q = 0; q < 3; ++q) dir[q] += (alpha[it - i - 1] - beta) * S[tp][q];
+            }
+            for (int q = 0; q < 3; ++q) { dir[q] = -dir[q]; oldx[q] = x[q]; oldg[q] = g[q]; }
+            const double dg0 = dot3(g, dir);
+            if (dg0 > 0.0) break;
+            const double f0 = fval, lin = 1e-4 * dg0;
+            double step = 1.0, bestStep = 1.0, bestObj = 1.79769313486231570e308, lastStep = 1.0;
+            int trials = 0;
+            for (;;) {
+                double xn[3] = {x[0] + step * dir[0], x[1] + step * dir[1], x[2] + step * dir[2]};
+                fval = ev(xn, g);
+                lastStep = step;
+                if (fval < bestObj) { bestStep = step; bestObj = fval; }
+                ++trials;
+                double width;
+                if (fval > f0 + step * lin) width = 0.5;
+                else {
+                    double dg = dot3(g, dir);
+                    if (dg < 0.9 * dg0) width = 2.1;
+                    else if (dg > -0.9 * dg0) width = 0.5;
+                    else break;
+                }
+                if (step < 1e-20 || step > 1e20 || trials >= 50) break;
+                step *= width;
+            }
+            for (int q = 0; q < 3; ++q) x[q] += bestStep * dir[q];
+            if (bestStep != lastStep) fval = ev(x, g);
+            if (bestStep == 0.0) break;
+            if ((prev - fval) / std::fmax(std::fmax(std::fabs(prev), std::fabs(fval)), 1.0) <= 1e-15) break;
+            int op = it % NB;
+            for (int q = 0; q < 3; ++q) { S[op][q] = x[q] - oldx[q]; Y[op][q] = g[q] - oldg[q]; }
+        }
+        c->M[3 * fi] = x[0]; c->M[3 * fi + 1] = x[1]; c->M[3 * fi + 2] = x[2];
+        tot_it += (uint64_t)it;
+        tot_ev += (uint64_t)evals;
+    }
+    if (stats) { stats[0] = tot_it; stats[1] = tot_ev; }
+    return 0;
+}
+
+int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_delays, double* loss, double* grad) {
+    for (uint32_t b = 0; b < n_delays; ++b) {
+        double L = 0, G = 0;
+        for (uint32_t fi : c->sel) {
+            const rship_frame& fr = c->frames[fi];
+            const double Mx = c->M[3 * fi], My = c->M[3 * fi + 1], Mz = c->M[3 * fi + 2], kk = c->k[fi];
+            const f3 Mv{(float)Mx, (float)My, (float)Mz};
+            const float inv_s = (float)(kk * kk / (Mx * Mx + My * My + Mz * Mz));
+            double Lf = 0, Gf = 0;
+            for (uint32_t i = 0; i < fr.n_rays; ++i) {
+                f3 P, dP;
+                row(c, fr, i, kd[b], fd[b], P, grad ? &dP : nullptr);
+                float pm = rs::dot(P, Mv), u = pm * pm * inv_s;
+                Lf += rs::log1p_pos(u);
+                if (grad) Gf += (1.0f / (1.f + u)) * 2.f * pm * inv_s * rs::dot(dP, Mv);
+            }
+            L += Lf;
+            G += Gf * (double)(float)c->fs;
+        }
+        loss[b] = L;
+        if (grad) grad[b] = G;
+    }
+    return 0;
+}
+
+int rship_get_motion(rship_ctx* c, double* M, double* k, uint32_t cap, uint32_t* n) {
+    uint32_t cnt = 0;
+    for (size_t i = 0; i < c->sel.size() && cnt < cap; ++i, ++cnt) {
+        uint32_t fi = c->sel[i];
+        M[3 * cnt] = c->M[3 * fi]; M[3 * cnt + 1] = c->M[3 * fi + 1]; M[3 * cnt + 2] = c->M[3 * fi + 2];
+        k[cnt] = c->k[fi];
+    }
+    if (n) *n = cnt;
+    return 0;
+}
+
+int rship_set_motion(rship_ctx* c, const double* M, const double* k, uint32_t n) {
+    if (n != c->sel.size()) return fail(c, "set_motion: count differs from the selection");
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t fi = c->sel[i];
+        c->M[3 * fi] = M[3 * i]; c->M[3 * fi + 1] = M[3 * i + 1]; c->M[3 * fi + 2] = M[3 * i + 2];
+        c->k[fi] = k[i];
+    }
+    return 0;
+}
+
+int rship_debug_problem(rship_ctx* c, uint32_t sel_index, int32_t kd, float fd, float* P, float* dP, uint32_t cap_rows) {
+    if (sel_index >= c->sel.size()) return fail(c, "debug_problem: index out of range");
+    const rship_frame& fr = c->frames[c->sel[sel_index]];
+    if (fr.n_rays > cap_rows) return fail(c, "debug_problem: output too small");
+    for (uint32_t i = 0; i < fr.n_rays; ++i) {
+        f3 p, d;
+        row(c, fr, i, kd, fd, p, dP ? &d : nullptr);
+        P[3 * i] = p.x; P[3 * i + 1] = p.y; P[3 * i + 2] = p.z;
+        if (dP) { dP[3 * i] = d.x * (float)c->fs; dP[3 * i + 1] = d.y * (float)c->fs; dP[3 * i + 2] = d.z * (float)c->fs; }
+    }
+    return 0;
+}
+
+int rship_debug_select(rship_ctx* c, const float*, uint32_t, uint32_t, uint32_t, const float*, uint32_t*) {
+    return fail(c, "debug_select: device only");
+}
+int rship_profile_enable(rship_ctx*, int) { return 0; }
+int rship_profile_get(rship_ctx*, int, uint64_t* launches, double* total_ms) {
+    if (launches) *launches = 0;
+    if (total_ms) *total_ms = 0;
+    return 0;
+}
+int rship_profile_reset(rship_ctx*) { return 0; }
+
+} // extern "C"

@@ -1,0 +1,42 @@
+"""One rank of the world_size-2 gloo test: this rank's half of the frames in its own SyncProblem
+(host solver + CPU test double), reduce hook = torch.distributed all_reduce."""
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    import rssync_amd
+    from rssync_amd import synth
+    from rssync_amd.dist import make_reduce_hook, shard
+    from rssync_amd.problem import bind
+    lib = bind(ctypes.CDLL(os.path.join(ROOT, "tests", "_build", "librssync_hosttest.so")))
+    F, N = 16, 96
+    gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=6)
+    b, e = shard(0, F, rank, world)
+    p = rssync_amd.SyncProblem(seed=123, max_outer_iters=12, _lib=lib)
+    synth.fill(p, gyro, b, e, N, seed=6, noise=0.0, outliers=0.0)
+    hook = make_reduce_hook("cpu")
+    p.set_reduce_hook(hook)
+    c0, d0 = p.PreSync(0.0, 0, F, 0.004, 0.1)
+    n_pre = hook.stats["calls"]
+    c1, d1 = p.Sync(d0, 0, F - 1, 0.0, 0.2)
+    res = dict(rank=rank, frames=[b, e], presync=[c0, d0], sync=[c1, d1], iters=len(p.sync_trace()),
+               presync_exchanges=n_pre, sync_exchanges=hook.stats["calls"] - n_pre)
+    with open(out, "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

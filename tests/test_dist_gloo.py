@@ -1,0 +1,51 @@
+"""The N>1 path on CPU: two gloo ranks, frames sharded, the only exchange a sum of a few
+doubles.  Sharded and unsharded runs must agree (the sums differ only by fp64 association)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_equal_one(hosttest_lib, tmp_path):
+    import rssync_amd
+    from rssync_amd import synth
+    from rssync_amd.dist import shard
+    assert shard(0, 16, 0, 2) == (0, 8) and shard(0, 16, 1, 2) == (8, 16) and shard(0, 5, 3, 4) == (5, 5)
+    port = _free_port()
+    outs = [str(tmp_path / f"r{r}.json") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r), "2", str(port),
+                               outs[r]]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    res = [json.load(open(o)) for o in outs]
+    # single process, all frames, no hook
+    F, N = 16, 96
+    gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=6)
+    one = rssync_amd.SyncProblem(seed=123, max_outer_iters=12, _lib=hosttest_lib)
+    synth.fill(one, gyro, 0, F, N, seed=6, noise=0.0, outliers=0.0)
+    c0, d0 = one.PreSync(0.0, 0, F, 0.004, 0.1)
+    c1, d1 = one.Sync(d0, 0, F - 1, 0.0, 0.2)
+    assert res[0]["frames"] == [0, 8] and res[1]["frames"] == [8, 16]
+    for r in res:
+        assert r["presync"][1] == d0                       # same arg-min on every rank
+        assert r["presync"][0] == pytest.approx(c0, rel=1e-12)
+        assert r["sync"][1] == pytest.approx(d1, abs=1e-9)
+        assert r["sync"][0] == pytest.approx(c1, rel=1e-9)
+        assert r["iters"] == len(one.sync_trace())
+        assert r["presync_exchanges"] == 1                 # one all-reduce for the whole sweep
+        assert r["sync_exchanges"] == 2 * r["iters"] + 1   # <= 2 per outer iteration + final loss
+    assert res[0]["sync"] == res[1]["sync"]                # replicated optimiser state
+    assert abs(d1 - synth.D_TRUE) < 1e-4

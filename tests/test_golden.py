@@ -1,0 +1,84 @@
+"""Committed fixtures (tests/golden/oracle_small.npz, made by tests/golden/make_golden.py): the
+oracle's outputs on a stored input.  They pin oracle and HIP path against drift; the reference has
+no vectors of its own for this path (PARITY UNPINNED)."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_small.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def _fill(p, g):
+    p.SetGyroQuaternions(g["gyro_quats"], float(g["gyro_fs"]), float(g["gyro_t0"]))
+    for i, fr in enumerate(g["frame_ids"]):
+        p.SetTrackResult(int(fr), g["ts_a"][i], g["ts_b"][i], g["rays_a"][i], g["rays_b"][i])
+    return p
+
+
+def test_oracle_reproduces_the_fixture(built, gold):
+    from oracle import oracle as ora
+    from oracle.oracle import OracleProblem
+    seed = int(gold["seed"])
+    F = len(gold["frame_ids"])
+    f0 = int(gold["frame_ids"][0])
+    o = _fill(OracleProblem(seed=seed, threads=os.cpu_count() or 1, faithful=False), gold)  # schedule-independent
+    d, c, fc, bh = o.presync_curve(0.0, f0, f0 + F, 0.004, 0.1, per_frame=F)
+    np.testing.assert_array_equal(d, gold["presync_delays"])
+    np.testing.assert_array_equal(bh, gold["presync_best_h"])
+    np.testing.assert_allclose(fc, gold["presync_frame_costs"], rtol=1e-12)
+    np.testing.assert_allclose(c, gold["presync_costs"], rtol=1e-12)
+    assert o.PreSync(0.0, f0, f0 + F, 0.004, 0.1)[1] == gold["presync_result"][1]
+    dd, dc = o.DebugPreSync(0.0, f0, f0 + F, 0.1, 9)
+    np.testing.assert_allclose(dc, gold["debug_costs"], rtol=1e-12)
+    c2, d2, tr = o.sync_trace(float(gold["presync_result"][1]), f0, f0 + F - 1, 0.0, 0.1)
+    np.testing.assert_allclose(tr, gold["sync_trace"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose([c2, d2], gold["sync_result"], rtol=1e-9)
+    np.testing.assert_allclose(o.problem_matrix(33, 0.0371), gold["P_frame33"], rtol=0, atol=1e-15)
+    o2 = OracleProblem(seed=seed)
+    o2.SetGyroQuaternionsTimestamped(gold["ts_us"], gold["ts_quats"])
+    assert o2.gyro_info()[:2] == (float(gold["ts_fs"]), float(gold["ts_start"]))
+    np.testing.assert_allclose(o2.gyro_knots(), gold["ts_knots"], rtol=0, atol=1e-15)
+    cases = [(0, 0, 0, 2), (30, 5, 7, 128), (-3, ora.STREAM_SYNC_INIT, 199, 2048), (2 ** 40, ora.STREAM_DEBUG + 3, 19, 17)]
+    got = np.array([ora.sample_pair(seed, *cs) for cs in cases])
+    np.testing.assert_array_equal(got, gold["sample_pairs"])  # integer sampler: bit-exact
+
+
+def test_host_solver_against_the_fixture(hosttest_lib, gold):
+    """same fixture through the product's host code + CPU test double (fp32 arithmetic)"""
+    import rssync_amd
+    _check_product(rssync_amd.SyncProblem(seed=int(gold["seed"]), _lib=hosttest_lib), gold)
+
+
+@pytest.mark.gpu
+def test_hip_path_against_the_fixture(gold):
+    import rssync_amd
+    _check_product(rssync_amd.SyncProblem(seed=int(gold["seed"])), gold)
+
+
+def _check_product(h, gold):
+    F = len(gold["frame_ids"])
+    f0 = int(gold["frame_ids"][0])
+    _fill(h, gold)
+    d, c, fc, bh = h.presync_curve(0.0, f0, f0 + F, 0.004, 0.1, per_frame=F)
+    np.testing.assert_array_equal(d, gold["presync_delays"])      # candidate delays: bit-exact
+    same = bh == gold["presync_best_h"]
+    assert same.mean() > 0.99                                      # arg-min flips only at fp32 near-ties
+    np.testing.assert_allclose(fc[same], gold["presync_frame_costs"][same], rtol=1e-3)
+    np.testing.assert_allclose(c, gold["presync_costs"], rtol=5e-3)
+    cost, delay = h.PreSync(0.0, f0, f0 + F, 0.004, 0.1)
+    assert delay == gold["presync_result"][1]
+    P = h.problem_matrix(33, 0.0371, gold["P_frame33"].shape[0])
+    assert np.abs(P - gold["P_frame33"]).max() < 5e-7
+    dd, dc = h.DebugPreSync(0.0, f0, f0 + F, 0.1, 9)
+    np.testing.assert_array_equal(dd, gold["debug_delays"])
+    np.testing.assert_allclose(dc, gold["debug_costs"], rtol=5e-3)
+    h2 = type(h)(seed=int(gold["seed"]), _lib=h._lib)
+    h2.SetGyroQuaternionsTimestamped(gold["ts_us"], gold["ts_quats"])
+    assert h2.gyro_info()[:2] == (float(gold["ts_fs"]), float(gold["ts_start"]))
+    np.testing.assert_array_equal(h2.gyro_knots(), gold["ts_knots"])  # host-side integer grid + slerp: bit-exact

@@ -1,0 +1,218 @@
+"""The product's host solver (sync_problem.cpp: packing, delay splitting, frame selection, the
+Sync control loop, panics, the reduce hook) on a machine without a GPU, by linking it against
+the CPU test double of the device ABI (tests/cpu_device).  The arithmetic is the kernels' own
+header (device_math.hpp, fp32), so these are also CPU-side parity checks of that math against
+the fp64 oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import fill
+
+SEED = 123
+
+
+@pytest.fixture()
+def host(hosttest_lib):
+    import rssync_amd
+
+    def make(case=None, **kw):
+        p = rssync_amd.SyncProblem(seed=SEED, _lib=hosttest_lib, **kw)
+        return fill(p, case) if case is not None else p
+    return make
+
+
+@pytest.fixture(scope="module")
+def tiny_case(built):
+    from rssync_amd import synth
+    F, N = 16, 96
+    gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=5)
+    return dict(F=F, N=N, gyro=gyro, frames=list(synth.make_frames(gyro, 0, F, N, seed=5)))
+
+
+@pytest.fixture(scope="module")
+def tiny_clean(built):
+    from rssync_amd import synth
+    F, N = 16, 96
+    gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=6)
+    return dict(F=F, N=N, gyro=gyro, frames=list(synth.make_frames(gyro, 0, F, N, seed=6, noise=0.0, outliers=0.0)))
+
+
+def _oracle(case, **kw):
+    from oracle.oracle import OracleProblem
+    return fill(OracleProblem(seed=SEED, threads=os.cpu_count() or 1, faithful=False, **kw), case)
+
+
+def test_residual_rows_fp32_vs_oracle(host, tiny_case):
+    h, o = host(tiny_case), _oracle(tiny_case)
+    fs, start, n = o.gyro_info()
+    for fr, d in [(0, 0.0), (7, 0.0371), (15, -0.12), (3, -3.0), (3, n / fs + 1.0)]:  # incl. both extrapolations
+        P, dP = h.problem_matrix(fr, d, tiny_case["N"], deriv=True)
+        Po = o.problem_matrix(fr, d)
+        assert np.abs(P - Po).max() < (5e-7 if abs(d) < 1 else 2e-4)
+        if abs(d) < 1:
+            eps = 1e-6
+            dPo = (o.problem_matrix(fr, d + eps) - o.problem_matrix(fr, d - eps)) / (2 * eps)
+            assert np.abs(dP - dPo).max() < 2e-5 * max(1.0, np.abs(dPo).max())
+
+
+def test_presync_matches_oracle(host, tiny_case):
+    F = tiny_case["F"]
+    h, o = host(tiny_case), _oracle(tiny_case)
+    dh, ch, fch, bhh = h.presync_curve(0.0, 0, F, 0.004, 0.1, per_frame=F)
+    do, co, fco, bho = o.presync_curve(0.0, 0, F, 0.004, 0.1, per_frame=F)
+    np.testing.assert_array_equal(dh, do)
+    same = bhh == bho
+    assert same.mean() > 0.99
+    np.testing.assert_allclose(fch[same], fco[same], rtol=1e-3)
+    assert np.argmin(ch) == np.argmin(co)
+    assert h.PreSync(0.0, 0, F, 0.004, 0.1)[1] == o.PreSync(0.0, 0, F, 0.004, 0.1)[1]
+    d2, c2 = h.DebugPreSync(0.01, 0, 8, 0.05, 11)
+    d3, c3 = o.DebugPreSync(0.01, 0, 8, 0.05, 11)
+    np.testing.assert_array_equal(d2, d3)
+    np.testing.assert_allclose(c2, c3, rtol=5e-3)
+
+
+def test_loss_gradient_and_motion(host, tiny_case):
+    F = tiny_case["F"]
+    h, o = host(tiny_case), _oracle(tiny_case)
+    d0 = 0.036
+    M, k = h.init_motion(d0, 0, F - 1)
+    L, G = h.loss([d0, d0 + 2e-3], grad=True)
+    for j, dd in enumerate([d0, d0 + 2e-3]):
+        Lo = Gn = 0.0
+        for f in range(F):
+            l, dn, da, _ = o.loss(f, dd, M[f], k[f])
+            Lo += l
+            Gn += dn
+        assert L[j] == pytest.approx(Lo, rel=1e-6)
+        assert G[j] == pytest.approx(Gn, rel=5e-4, abs=5e-4 * abs(L[j]))
+    M2, k2, its, evs = h.opt_motion(d0)
+    assert h.loss([d0])[0] < L[0] and evs >= its >= F
+    np.testing.assert_array_equal(k2, k)
+
+
+def test_sync_control_loop_matches_oracle_on_clean_data(host, tiny_clean):
+    from rssync_amd import synth
+    F = tiny_clean["F"]
+    h, o = host(tiny_clean), _oracle(tiny_clean)
+    ch, dh = h.Sync(0.036, 0, F - 1, 0.0, 0.2)
+    co, do, tro = o.sync_trace(0.036, 0, F - 1, 0.0, 0.2)
+    trh = h.sync_trace()
+    assert abs(dh - synth.D_TRUE) < 1e-4 and abs(dh - do) < 1e-4
+    assert len(trh) == len(tro)
+    # same outer-loop decisions: accepted backtracking step and number of trials per iteration
+    np.testing.assert_array_equal(trh[:, 5], tro[:, 5])
+    np.testing.assert_allclose(trh[:, 4], tro[:, 4])
+    np.testing.assert_allclose(trh[:, 0], tro[:, 0], atol=2e-5)   # delay after each iteration
+    np.testing.assert_allclose(trh[:, 2], tro[:, 2], rtol=2e-2, atol=1e-3)  # loss at the look-ahead point
+
+
+def test_iteration_cap_window_exit_and_frame_ranges(host, tiny_case):
+    F = tiny_case["F"]
+    h = host(tiny_case, max_outer_iters=3)
+    h.Sync(0.036, 0, F - 1, 0.0, 0.2)
+    assert len(h.sync_trace()) == 3
+    h.set_max_outer_iters(400)
+    h.Sync(0.036, 0, F - 1, 0.5, 1e-3)  # centre far away: leaves the window after one step
+    assert len(h.sync_trace()) == 1
+    M, k = h.init_motion(0.03, 4, 6)     # Sync range is end-inclusive (core_private.cpp:219)
+    assert len(k) == 3
+    d, c, fc, bh = h.presync_curve(0.03, 4, 6, 0.01, 0.02, per_frame=2)  # PreSync end-exclusive (:66)
+    assert fc.shape[1] == 2
+    c0, d0 = h.PreSync(0.0, 100, 200, 0.01, 0.05)  # no frames: zero cost, first candidate
+    assert c0 == 0.0 and d0 == pytest.approx(-0.05)
+
+
+def test_reduce_hook_is_called_twice_per_outer_iteration(host, tiny_case):
+    F = tiny_case["F"]
+    h = host(tiny_case, max_outer_iters=4)
+    calls = []
+    h.set_reduce_hook(lambda a: calls.append(len(a)))
+    h.PreSync(0.0, 0, F, 0.01, 0.05)
+    assert len(calls) == 1 and calls[0] == 10 + 4      # candidate costs + 4 status flags, one exchange
+    calls.clear()
+    h.Sync(0.036, 0, F - 1, 0.0, 0.2)
+    iters = len(h.sync_trace())
+    assert len(calls) == 2 * iters + 1                  # {loss, grad}, batched line search; final loss
+    assert calls[0] == 2 and calls[1] == 10
+
+
+def test_panics_follow_the_reference_messages(host, tiny_case):
+    import rssync_amd
+    h = host()
+    fr, ta, tb, ra, rb = tiny_case["frames"][0]
+    for name, args in (("rays_a", (ta, tb, np.where(np.arange(ra.size).reshape(ra.shape) == 4, np.nan, ra), rb)),
+                       ("rays_b", (ta, tb, ra, np.where(np.arange(rb.size).reshape(rb.shape) == 4, np.inf, rb))),
+                       ("ts_a", (np.where(np.arange(ta.size) == 1, np.nan, ta), tb, ra, rb)),
+                       ("ts_b", (ta, np.where(np.arange(tb.size) == 1, -np.inf, tb), ra, rb))):
+        with pytest.raises(rssync_amd.RsSyncError, match="set-track-result: non-finite numbers in " + name):
+            h.SetTrackResult(0, *args)
+    h.SetTrackResult(0, ta, tb, ra, rb)
+    with pytest.raises(rssync_amd.RsSyncError, match="gyro data was not set"):
+        h.Sync(0.0, 0, 0, 0.0, 1.0)
+    g = tiny_case["gyro"]
+    h.SetGyroQuaternions(g.quats, g.fs, g.t0)
+    h.SetTrackResult(1, ta[:1], tb[:1], ra[:1], rb[:1])
+    with pytest.raises(rssync_amd.RsSyncError, match="fewer than 2 tracks"):
+        h.PreSync(0.0, 0, 2, 0.01, 0.05)
+    with pytest.raises(rssync_amd.RsSyncError, match="empty candidate list"):
+        h.PreSync(0.0, 0, 1, 0.01, -0.05)
+    ts = (np.arange(50) * 2500).astype(np.int64)
+    ts[10], ts[11] = ts[11], ts[10]
+    with pytest.raises(rssync_amd.RsSyncError, match="timestamps out of order at pos 11"):
+        h.SetGyroQuaternionsTimestamped(ts, np.tile([1.0, 0, 0, 0], (50, 1)))
+    with pytest.raises(rssync_amd.RsSyncError, match="tracks in one frame"):
+        n = 2049
+        h.SetTrackResult(5, np.zeros(n), np.zeros(n), np.tile([0, 0, 1.0], (n, 1)), np.tile([0, 0, 1.0], (n, 1)))
+
+
+def test_timestamped_gyro_and_gyro_replacement(host, tiny_case):
+    from rssync_amd import synth
+    from oracle.oracle import OracleProblem
+    g = synth.make_gyro(1.0, 1.0 + 20 / synth.FPS, seed=21)
+    ts_us, q = synth.make_timestamped(g, jitter=0.2, seed=4)
+    h, o = host(), OracleProblem(seed=SEED, faithful=False)
+    frames = list(synth.make_frames(g, 30, 42, 64, seed=5))
+    for p in (h, o):
+        p.SetGyroQuaternionsTimestamped(ts_us, q)
+        for fr, ta, tb, ra, rb in frames:
+            p.SetTrackResult(fr, ta, tb, ra, rb)
+    assert h.gyro_info() == o.gyro_info()
+    np.testing.assert_array_equal(h.gyro_knots(), o.gyro_knots())  # integer grid + slerp on the host
+    c1 = h.PreSync(0.0, 30, 42, 0.004, 0.06)
+    c2 = o.PreSync(0.0, 30, 42, 0.004, 0.06)
+    assert c1[1] == c2[1] and c1[0] == pytest.approx(c2[0], rel=2e-3)
+    # replace the gyro while the tracks stay (the 48-orientation sweep, core_testcode.cpp:216-224)
+    g2 = synth.make_gyro(1.0, 1.0 + 20 / synth.FPS, seed=99)
+    for p in (h, o):
+        p.SetGyroQuaternions(g2.quats, g2.fs, g2.t0)
+    w1 = h.PreSync(0.0, 30, 42, 0.004, 0.06)
+    w2 = o.PreSync(0.0, 30, 42, 0.004, 0.06)
+    assert w1[0] > c1[0] and w1[0] == pytest.approx(w2[0], rel=2e-3)
+
+
+def test_large_absolute_times_lose_no_precision(host, tiny_clean):
+    """Times reach the device as integer knot + fp32 offset, never as fp32 seconds: moving the
+    whole recording 1000 s later (fp32 resolution there: 6e-5 s) must not change the loss curve,
+    sampled here every 2 us."""
+    import rssync_amd
+    F = tiny_clean["F"]
+    g = tiny_clean["gyro"]
+    h0 = host(tiny_clean)
+    h1 = host()
+    shift = 1000.0
+    h1.SetGyroQuaternions(g.quats, g.fs, g.t0 + shift)
+    for fr, ta, tb, ra, rb in tiny_clean["frames"]:
+        h1.SetTrackResult(fr, ta + shift, tb + shift, ra, rb)
+    M, k = h0.init_motion(0.036, 0, F - 1)
+    h1.init_motion(0.036, 0, F - 1)
+    h1.set_motion(M, k)
+    d = 0.0365 + 2e-6 * np.arange(12)
+    L0, G0 = h0.loss(d, grad=True)
+    L1, G1 = h1.loss(d, grad=True)
+    np.testing.assert_allclose(L1, L0, rtol=2e-6)
+    np.testing.assert_allclose(G1, G0, rtol=1e-3, atol=1e-3 * np.abs(G0).max())
+    dd = np.diff(L0)
+    assert np.all(dd > 0) or np.all(dd < 0)  # 2 us steps are resolved monotonically
