@@ -147,7 +147,17 @@ def main():
                     "avg_launch_ms": round(avg_ms, 4), "launches": n_l,
                     "note": "equivalent bandwidth: 32 B per nominal ray-residual; the kernel reuses each ray "
                             "across the candidates of a chunk and is VALU/LDS-bound (DESIGN.md)"}
-        n_k, ms_k = prof["loss"]
+        # HBM traffic of that kernel from the PMC run committed under profiles/ (separate --pmc
+        # passes for FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+        # for gfx950); only valid for the default workload
+        if roof and (F, N, n_cand) == (4096, 2048, 800):
+            try:
+                raw = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic_raw.json")))["lmeds_kernel<8, 0>"]
+                roof["traffic"] = round((2 * raw["FETCH_SIZE"]["mean_per_launch_KiB"] +
+                                         raw["WRITE_SIZE"]["mean_per_launch_KiB"]) * 1024 / 1e9, 4)
+                roof["traffic_unit"] = "GB per launch (profiles/r1_pmc_traffic_raw.json)"
+            except Exception:
+                pass
         kernels = {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in prof.items()}
         cpu = None
         if world == 1 and args.cpu_frames > 0:
