@@ -221,38 +221,19 @@ __device__ __forceinline__ f3 hypothesis(const Tile& t, uint64_t seed, int64_t f
     return v;
 }
 
-// per-lane count of |x_i| < pivot over four registers holding fp32 residuals (the abs source
-// modifier is free).  Hand-scheduled: hipcc turns the obvious `cnt += x < pivot` into a
-// bit-packing sequence of ~5 VALU per element; this is 2 per element.  The compares write SGPR
-// pairs that the add-with-carry reads as its carry-in; gfx950 needs two wait states between a
-// VALU write of an SGPR and a VALU read of it, which the interleaving provides.  The pivot is
-// passed in a VGPR so that no SGPR written just before the block is read.  NaN never counts.
-__device__ __forceinline__ void count4(uint32_t& cnt, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3,
-                                       uint32_t pivot_v) {
-    unsigned long long a, b, c;
-    asm("v_cmp_gt_f32_e64 %1, %8, |%4|\n\t"
-        "v_cmp_gt_f32_e64 %2, %8, |%5|\n\t"
-        "v_cmp_gt_f32_e64 %3, %8, |%6|\n\t"
-        "v_addc_co_u32_e64 %0, vcc, 0, %0, %1\n\t"
-        "v_cmp_gt_f32_e64 %1, %8, |%7|\n\t"
-        "v_addc_co_u32_e64 %0, vcc, 0, %0, %2\n\t"
-        "v_addc_co_u32_e64 %0, vcc, 0, %0, %3\n\t"
-        "v_addc_co_u32_e64 %0, vcc, 0, %0, %1"
-        : "+v"(cnt), "=&s"(a), "=&s"(b), "=&s"(c)
-        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(pivot_v)
-        : "vcc");
-}
-
-// wave-wide count of |r[]| < pivot (pivot: bit pattern of a non-negative float, uniform)
+// wave-wide count of |r[]| < pivot (pivot: bit pattern of a non-negative float, uniform).
+// The kernel is bound by VALU issue (one wave64 instruction per 4 cycles per SIMD, PMC-measured),
+// while the scalar unit is mostly idle: each register costs ONE v_cmp (the abs modifier is free,
+// NaN never counts) whose 64-lane mask is counted with s_bcnt1_i32_b64 and added on the SALU.
+// The total arrives in an SGPR, so no cross-lane reduction is needed either.
 template <int NR>
 __device__ __forceinline__ uint32_t wave_count_lt(const uint32_t (&r)[NR], uint32_t pivot) {
+    const float pv = __uint_as_float(pivot);
     uint32_t cnt = 0;
-    uint32_t pv = pivot;
-    asm volatile("" : "+v"(pv)); // keep the pivot in a VGPR
 #pragma unroll
-    for (int m = 0; m < NR; m += 4) count4(cnt, r[m], r[m + 1], r[m + 2], r[m + 3], pv);
-    asm volatile("s_nop 1" : "+v"(cnt)); // VALU write -> DPP read of cnt: two wait states
-    return wave_sum_u32(cnt);
+    for (int m = 0; m < NR; ++m)
+        cnt += (uint32_t)__builtin_popcountll(__builtin_amdgcn_fcmpf(pv, fabsf(__uint_as_float(r[m])), 2 /* FCMP_OGT */));
+    return cnt;
 }
 
 template <int CTRL, int ROW_MASK>
@@ -284,6 +265,8 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 // Exact kq-th smallest (0-based) of the wave's |r[]| as a bit pattern, given an exclusive upper
 // bound hi with count(|r| < hi) = c_hi > kq.  |r| orders exactly like the r^2 the reference sorts
 // (core_private.cpp:49-52), so this is the element std::sort would leave at index kq, before
@@ -292,12 +275,12 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // quartile, so the CDF is nearly linear there: ~8 passes instead of 31 bit-bisection passes), with
 // bracket interpolation and plain bisection of the bit pattern as fallbacks.  Ends when the
 // bracket is one bit pattern wide or holds exactly one element, which a min pass extracts.
+// All bookkeeping is wave-uniform and kept on the scalar unit (bit patterns of non-negative
+// floats order like unsigned integers); only the secant formula itself runs on the VALU.
 template <int NR>
 __device__ __forceinline__ uint32_t select_kth(const uint32_t (&r)[NR], uint32_t kq, uint32_t hi, uint32_t c_hi) {
     uint32_t lo = 0, c_lo = 0;
-    float alo = 0.f, ahi = __uint_as_float(hi);
-    float a1 = 0.f, c1 = 0.f, a2 = ahi, c2 = (float)c_hi;
-    const float target = (float)kq + 0.5f;
+    uint32_t a1 = 0, c1 = 0, a2 = hi, c2 = c_hi; // the two most recent (pivot, count) points
     for (int it = 0;; ++it) {
         if (hi - lo == 1u) return lo;
         if (c_hi - c_lo == 1u) {
@@ -310,22 +293,27 @@ __device__ __forceinline__ uint32_t select_kth(const uint32_t (&r)[NR], uint32_t
             }
             return lo + wave_min_u32(mn);
         }
-        uint32_t piv;
+        uint32_t piv = 0;
         if (it < 24) {
-            float a3 = a2 + (target - c2) * (a2 - a1) / (c2 - c1);
-            if (!(c2 != c1 && a3 > alo && a3 < ahi))
-                a3 = alo + (target - (float)c_lo) / (float)(c_hi - c_lo) * (ahi - alo);
-            piv = __float_as_uint(a3);
-            if (!(piv > lo && piv < hi)) piv = lo + ((hi - lo) >> 1);
-        } else {
-            piv = lo + ((hi - lo) >> 1); // guaranteed finish: <= 31 more passes
+            if (c2 != c1) { // secant through the last two points, aimed at rank kq + 1/2
+                const float num = 0.5f * (float)(int)(2 * kq + 1 - 2 * c2);
+                const float a3 = fmaf(num * (__uint_as_float(a2) - __uint_as_float(a1)), rs::rcp_fast((float)(int)(c2 - c1)),
+                                      __uint_as_float(a2));
+                piv = uniform_u32(__float_as_uint(a3));
+            }
+            if (!(piv > lo && piv < hi)) { // interpolate inside the bracket instead
+                const float num = 0.5f * (float)(int)(2 * kq + 1 - 2 * c_lo);
+                const float a3 = fmaf(num * (__uint_as_float(hi) - __uint_as_float(lo)), rs::rcp_fast((float)(c_hi - c_lo)),
+                                      __uint_as_float(lo));
+                piv = uniform_u32(__float_as_uint(a3));
+            }
         }
-        piv = (uint32_t)__builtin_amdgcn_readfirstlane((int)piv);
+        if (!(piv > lo && piv < hi)) piv = lo + ((hi - lo) >> 1); // bit bisection: guaranteed finish
         const uint32_t c = wave_count_lt(r, piv);
         a1 = a2; c1 = c2;
-        a2 = __uint_as_float(piv); c2 = (float)c;
-        if (c <= kq) { lo = piv; c_lo = c; alo = a2; }
-        else { hi = piv; c_hi = c; ahi = a2; }
+        a2 = piv; c2 = c;
+        if (c <= kq) { lo = piv; c_lo = c; }
+        else { hi = piv; c_hi = c; }
     }
 }
 
@@ -469,12 +457,14 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         float nrm[RPT];
         bad |= lmeds_rows<RPT>(sp, rays_a, rays_b, N, base, fd, tile, nrm);
 
-        // ---- stage C: the hypotheses.  The best quantile of the previous candidate (x4) serves as
-        // a provisional bound: a hypothesis that has <= kq residuals below it is dropped after one
-        // counting pass.  If nothing beats the bound the candidate is redone without it, so the
-        // result is the exact arg-min either way.
+        // ---- stage C: the hypotheses.  The best quantile of the previous candidate (x1.25: between
+        // neighbouring candidates it moves by -20..+26 %, 1st..99th percentile) serves as a
+        // provisional bound: a hypothesis that has <= kq residuals below it is dropped after one
+        // counting pass.  If nothing beats the bound (~2 % of candidates) the candidate is redone
+        // without it, so the result is the exact arg-min either way.
         uint32_t guess = kInfBits;
-        if (prev_best < 0x7e000000u && prev_best > 0x00800000u) guess = prev_best + 0x01000000u; // x4
+        if (prev_best < 0x7e000000u && prev_best > 0x00800000u)
+            guess = uniform_u32(__float_as_uint(__uint_as_float(prev_best) * 1.25f));
         unsigned long long best;
         for (;;) {
             if (tid == 0) s_key = ((unsigned long long)guess << 32);
