@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--search-radius", type=float, default=0.2)
     ap.add_argument("--outer-iters", type=int, default=20)
     ap.add_argument("--cpu-frames", type=int, default=192, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse "
+                                                      "several ranks on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -52,10 +54,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
+    dev = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev)
+    torch.zeros(1, device="cuda")  # make this process's HIP context current on its GPU before the library opens it
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.backend)
 
     import rssync_amd
     from rssync_amd import synth
@@ -73,7 +80,7 @@ def main():
     if world > 1:
         from rssync_amd.dist import make_reduce_hook
         # the only exchange of the path: a sum of a few doubles, as an RCCL all-reduce over xGMI
-        prob.set_reduce_hook(make_reduce_hook("cuda"))
+        prob.set_reduce_hook(make_reduce_hook("cuda" if args.backend == "nccl" else "cpu"))
 
     t_up = time.time()
     prob.upload()  # rays + spline into HBM before the timed region
@@ -116,7 +123,7 @@ def main():
     prof = prob.profile_get()
     prob.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

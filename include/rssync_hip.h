@@ -91,6 +91,9 @@ int rship_init_motion(rship_ctx* c, int32_t kd, float fd, uint32_t n_hyp, uint32
  * vector at a fixed delay.  stats (optional) = {sum of iterations, sum of evaluations} */
 int rship_opt_motion(rship_ctx* c, int32_t kd, float fd, uint64_t* stats);
 
+/* the same with per-frame diagnostics: per_frame[2i] = L-BFGS iterations, [2i+1] = evaluations */
+int rship_opt_motion_detail(rship_ctx* c, int32_t kd, float fd, uint32_t* per_frame, uint32_t cap);
+
 /* sum over selected frames of FrameState::Loss at n_delays delays
  * (core_private.cpp:117-123); with grad != NULL also the analytic d/d-delay
  * that replaces the central difference at :96-97,112 */

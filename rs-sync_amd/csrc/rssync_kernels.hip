@@ -684,6 +684,7 @@ struct MotionParams {
     double* M;
     const double* k;
     unsigned long long* stats; // [0] += iterations, [1] += evaluations
+    uint32_t* per_frame;       // optional [n_sel][2]: iterations, evaluations
 };
 
 constexpr int kNB = 10; // numBasis
@@ -696,27 +697,30 @@ struct MotionEval {
     double k2;
     int evals;
 
-    // loss and dL/dM at x (core_private.cpp:99-114 in closed form)
+    // loss and dL/dM at x (core_private.cpp:99-114 in closed form).  The rows of P are fp32 data,
+    // but the objective is evaluated in fp64 (fp64 FMA issues at the fp32 rate on gfx950): with fp32
+    // terms its noise floor sits above the optimiser's stopping thresholds and frames dither through
+    // long line searches, and the slowest frame's serial chain is what the launch waits for.
     __device__ __forceinline__ double operator()(const double x[3], double g[3]) {
         const double s = (x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) / k2;
-        const float inv_s = (float)(1.0 / s);
-        const f3 xv = f3{(float)x[0], (float)x[1], (float)x[2]};
-        float L = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, gs = 0.f;
+        const double inv_s = 1.0 / s;
+        double L = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0, gs = 0.0;
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
-            float pm = rs::dot(P[j], xv);
-            float v2 = pm * pm;
-            float u = v2 * inv_s;
-            L += rs::log1p_pos(u);
-            float w = rs::rcp_fast(1.f + u);
-            float a = w * 2.f * pm * inv_s;
-            a0 = fmaf(a, P[j].x, a0);
-            a1 = fmaf(a, P[j].y, a1);
-            a2 = fmaf(a, P[j].z, a2);
-            gs = fmaf(w * v2, inv_s * inv_s, gs);
+            const double px = (double)P[j].x, py = (double)P[j].y, pz = (double)P[j].z;
+            const double pm = fma(px, x[0], fma(py, x[1], pz * x[2]));
+            const double v2 = pm * pm;
+            const double u = v2 * inv_s;
+            L += log1p(u);
+            const double w = 1.0 / (1.0 + u);
+            const double a = w * 2.0 * pm * inv_s;
+            a0 = fma(a, px, a0);
+            a1 = fma(a, py, a1);
+            a2 = fma(a, pz, a2);
+            gs = fma(w * v2, inv_s * inv_s, gs);
         }
-        double r0 = wave_sum_f64((double)L), r1 = wave_sum_f64((double)a0), r2 = wave_sum_f64((double)a1),
-               r3 = wave_sum_f64((double)a2), r4 = wave_sum_f64((double)gs);
+        double r0 = wave_sum_f64(L), r1 = wave_sum_f64(a0), r2 = wave_sum_f64(a1), r3 = wave_sum_f64(a2),
+               r4 = wave_sum_f64(gs);
         const int wave = threadIdx.x >> 6;
         if ((threadIdx.x & 63) == 0) {
             part[buf][wave][0] = r0; part[buf][wave][1] = r1; part[buf][wave][2] = r2;
@@ -863,6 +867,10 @@ __global__ __launch_bounds__(kBlock, 4) void opt_motion_kernel(MotionParams p) {
         if (p.stats) {
             atomicAdd(&p.stats[0], (unsigned long long)it);
             atomicAdd(&p.stats[1], (unsigned long long)ev.evals);
+        }
+        if (p.per_frame) {
+            p.per_frame[2 * sf] = (uint32_t)it;
+            p.per_frame[2 * sf + 1] = (uint32_t)ev.evals;
         }
     }
 }
@@ -1318,6 +1326,34 @@ int rship_init_motion(rship_ctx* c, int32_t kd, float fd, uint32_t n_hyp, uint32
     uint32_t groups = (c->n_sel + 7) / 8;
     if (launch_lmeds<1>(c, p, rpt_for(c->max_n), groups * 8)) return 1;
     return sync_stream(c);
+}
+
+int rship_opt_motion_detail(rship_ctx* c, int32_t kd, float fd, uint32_t* per_frame, uint32_t cap) {
+    if (check_ready(c)) return 1;
+    if (cap < c->n_sel) return set_err(c, "opt_motion_detail: output too small");
+    DevBuf d;
+    if (ensure(c, d, (size_t)c->n_sel * 8 + 8)) return 1;
+    MotionParams p{};
+    p.rays_a = (const f4*)c->rays_a.p;
+    p.rays_b = (const f4*)c->rays_b.p;
+    p.frames = (const FrameRec*)c->frames.p;
+    p.sel = (const uint32_t*)c->sel.p;
+    p.n_sel = c->n_sel;
+    p.coef = (const f4*)c->coef.p;
+    p.n_knots = (int)c->n_knots;
+    p.kd = kd;
+    p.fd = fd;
+    p.M = (double*)c->M.p;
+    p.k = (const double*)c->k.p;
+    p.per_frame = (uint32_t*)d.p;
+    int rc = launch_motion(c, p, rpt_for(c->max_n));
+    hipError_t e = hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    if (!rc && e == hipSuccess) e = hipMemcpy(per_frame, d.p, (size_t)c->n_sel * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d.p);
+    if (rc) return 1;
+    if (e != hipSuccess) return set_err(c, "opt_motion_detail", e);
+    return 0;
 }
 
 int rship_opt_motion(rship_ctx* c, int32_t kd, float fd, uint64_t* stats) {

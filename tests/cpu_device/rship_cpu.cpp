@@ -202,17 +202,17 @@ int rship_opt_motion(rship_ctx* c, int32_t kd, float fd, uint64_t* stats) {
         for (uint32_t i = 0; i < fr.n_rays; ++i) row(c, fr, i, kd, fd, P[i], nullptr);
         const double k2 = c->k[fi] * c->k[fi];
         int evals = 0;
-        auto ev = [&](const double x[3], double g[3]) {
+        auto ev = [&](const double x[3], double g[3]) { // fp64 on fp32 rows, like the kernel
             ++evals;
             const double s = (x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) / k2;
-            const float inv_s = (float)(1.0 / s);
-            const f3 xv{(float)x[0], (float)x[1], (float)x[2]};
+            const double inv_s = 1.0 / s;
             double L = 0, a0 = 0, a1 = 0, a2 = 0, gs = 0;
             for (const f3& p : P) {
-                float pm = rs::dot(p, xv), v2 = pm * pm, u = v2 * inv_s;
-                L += rs::log1p_pos(u);
-                float w = 1.0f / (1.f + u), a = w * 2.f * pm * inv_s;
-                a0 += a * p.x; a1 += a * p.y; a2 += a * p.z;
+                const double px = p.x, py = p.y, pz = p.z;
+                const double pm = px * x[0] + py * x[1] + pz * x[2], v2 = pm * pm, u = v2 * inv_s;
+                L += std::log1p(u);
+                const double w = 1.0 / (1.0 + u), a = w * 2.0 * pm * inv_s;
+                a0 += a * px; a1 += a * py; a2 += a * pz;
                 gs += w * v2 * inv_s * inv_s;
             }
             const double tt = gs * 2.0 / k2;
@@ -289,6 +289,8 @@ int rship_opt_motion(rship_ctx* c, int32_t kd, float fd, uint64_t* stats) {
     if (stats) { stats[0] = tot_it; stats[1] = tot_ev; }
     return 0;
 }
+
+int rship_opt_motion_detail(rship_ctx* c, int32_t, float, uint32_t*, uint32_t) { return fail(c, "opt_motion_detail: device only"); }
 
 int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_delays, double* loss, double* grad) {
     for (uint32_t b = 0; b < n_delays; ++b) {
