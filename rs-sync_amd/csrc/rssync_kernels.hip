@@ -521,7 +521,14 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         const int bH = (bT == kInfBits) ? -1 : (int)(uint32_t)best;
         prev_best = bT;
         f3 Mv = f3{0, 0, 0};
-        if (bH >= 0) Mv = hypothesis(tile, p.seed, fr.id, stream, (uint32_t)bH, N);
+        if (bH >= 0) {
+            if (p.n_hyp <= (uint32_t)kHypBatch) { // the winner's direction is still in the batch buffer
+                const f4 hv = s_hyp[bH];
+                Mv = f3{hv.x, hv.y, hv.z};
+            } else {
+                Mv = hypothesis(tile, p.seed, fr.id, stream, (uint32_t)bH, N);
+            }
+        }
         if (!(finite_f(Mv.x) && finite_f(Mv.y) && finite_f(Mv.z))) bad |= RSHIP_BAD_M;
 
         // ---- stage D: k = clamp(100 / |P M|), cost = sqrt(sum sqrt(log1p(r^2))) ----
@@ -548,18 +555,21 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
             }
         } else {
             float sc = kf / sqrtf(rs::dot(Mv, Mv)); // core_private.cpp:80
-            float acc = 0.f;
+            // a non-finite r or rho (core_private.cpp:81,83) makes the sums non-finite: NaN propagates
+            // and all terms are >= 0, so the checks are made once on the sums, not per row
+            float acc = 0.f, rsum = 0.f;
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
                 const uint32_t row = j * kBlock + tid;
                 if (row < N) {
                     const float r = pm[j] * sc;
-                    if (!finite_f(r)) bad |= RSHIP_BAD_R;
+                    rsum += fabsf(r);
                     const float rho = rs::log1p_pos(r * r); // core_private.cpp:82
-                    if (!finite_f(rho)) bad |= RSHIP_BAD_RHO;
                     acc += sqrtf(rho);
                 }
             }
+            if (!finite_f(rsum)) bad |= RSHIP_BAD_R;
+            else if (!finite_f(acc)) bad |= RSHIP_BAD_RHO;
             double acc_tot = block_sum(acc, s_red[1]);
             if (tid == 0) {
                 p.frame_cost[(size_t)c * p.n_sel + sf] = sqrt(acc_tot); // core_private.cpp:85
