@@ -376,3 +376,30 @@ def test_wave_selection_is_exact_on_adversarial_data():
                 np.testing.assert_array_equal(got[:, 1], cnt)
                 np.testing.assert_array_equal(got[:, 0], np.where(cnt > kq, want, 0xffffffff))
     lib.rship_destroy(ctx)
+
+
+def test_full_size_sync_matches_oracle():
+    """BASELINE config 3: 4096 frames x 2048 tracks, Sync capped at 20 outer iterations, noise and
+    10 % outliers, identical inputs.  North-star tolerances: returned delay within 1e-4 s of the CPU
+    solver; per-iteration loss within the stated fp32 tolerance, 2e-4 relative (measured 7e-5)."""
+    import rssync_amd
+    from rssync_amd import synth
+    from oracle.oracle import OracleProblem
+    F, N, seed = 4096, 2048, 0x5EED0003
+    g = synth.make_gyro(0, (F + 2) / synth.FPS, seed=seed)
+    h = rssync_amd.SyncProblem(seed=seed, max_outer_iters=20)
+    o = OracleProblem(seed=seed, max_outer_iters=20, threads=min(os.cpu_count() or 1, 16), faithful=False)
+    for fr in synth.make_frames(g, 0, F, N, seed=seed):
+        h.SetTrackResult(*fr)
+        o.SetTrackResult(*fr)
+    for p in (h, o):
+        p.SetGyroQuaternions(g.quats, g.fs, g.t0)
+    ch, dh = h.Sync(0.0365, 0, F - 1, 0.0, 0.2)
+    trh = h.sync_trace()
+    co, do, tro = o.sync_trace(0.0365, 0, F - 1, 0.0, 0.2)
+    assert abs(dh - do) < 1e-4
+    assert len(trh) == len(tro)
+    np.testing.assert_allclose(trh[:, 0], tro[:, 0], atol=1e-4)   # delay after every outer iteration
+    np.testing.assert_allclose(trh[:, 2], tro[:, 2], rtol=2e-4)   # loss at every outer iteration
+    assert ch == pytest.approx(co, rel=2e-4)
+    assert abs(dh - synth.D_TRUE) < 5e-4
