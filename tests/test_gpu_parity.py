@@ -403,3 +403,28 @@ def test_full_size_sync_matches_oracle():
     np.testing.assert_allclose(trh[:, 2], tro[:, 2], rtol=2e-4)   # loss at every outer iteration
     assert ch == pytest.approx(co, rel=2e-4)
     assert abs(dh - synth.D_TRUE) < 5e-4
+
+
+def test_presync_sweep_at_full_track_count():
+    """BASELINE config 2/3 sweep (radius 200 ms, step 0.5 ms = 800 candidates) at 2048 tracks per
+    frame, on a 48-frame slice the oracle can finish in seconds: the 8-rows-per-thread kernel
+    (chunks of 32 candidates, provisional bounds carried from candidate to candidate)."""
+    import rssync_amd
+    from rssync_amd import synth
+    from oracle.oracle import OracleProblem
+    F, N, seed = 48, 2048, 0x5EED0003
+    g = synth.make_gyro(0, (F + 2) / synth.FPS, seed=seed)
+    h = rssync_amd.SyncProblem(seed=seed)
+    o = OracleProblem(seed=seed, threads=min(os.cpu_count() or 1, 16), faithful=False)
+    synth.fill(h, g, 0, F, N, seed=seed)
+    synth.fill(o, g, 0, F, N, seed=seed)
+    dh, ch, fch, bhh = h.presync_curve(0.0, 0, F, 0.0005, 0.2, per_frame=F)
+    do, co, fco, bho = o.presync_curve(0.0, 0, F, 0.0005, 0.2, per_frame=F)
+    assert len(dh) == 800
+    np.testing.assert_array_equal(dh, do)
+    same = bhh == bho
+    assert same.mean() > 0.995
+    rel = np.abs(fch - fco) / fco
+    assert rel[same].max() < 1e-3 and np.median(rel[same]) < 2e-6
+    assert np.argmin(ch) == np.argmin(co)
+    np.testing.assert_allclose(ch, co, rtol=2e-3)
