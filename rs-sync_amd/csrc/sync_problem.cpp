@@ -383,9 +383,19 @@ std::vector<double> SyncProblemHip::sweep(const std::vector<double>& delays, uin
             kd[i] = s.kd;
             fd[i] = s.fd;
         }
-        hip_check(rship_presync_costs(dev_, kd.data(), fd.data(), (uint32_t)n, 20 /* core_private.cpp:77 */,
-                                      stream_base, seed, costs.data(), &flags, frame_costs, best_h),
-                  "presync costs");
+        // the device keeps a [candidates][frames] fp64 matrix: sweep very long candidate lists in
+        // slices (the sampler stream is the global candidate index, so slicing changes nothing)
+        const size_t slice = std::max<size_t>(64, (size_t)(256u << 20) / (8 * sel_.size()));
+        for (size_t b = 0; b < n; b += slice) {
+            const size_t m = std::min(slice, n - b);
+            uint32_t fl = 0;
+            hip_check(rship_presync_costs(dev_, kd.data() + b, fd.data() + b, (uint32_t)m, 20 /* core_private.cpp:77 */,
+                                          stream_base + (uint32_t)b, seed, costs.data() + b, &fl,
+                                          frame_costs ? frame_costs + b * sel_.size() : nullptr,
+                                          best_h ? best_h + b * sel_.size() : nullptr),
+                      "presync costs");
+            flags |= fl;
+        }
     }
     // one exchange for the whole sweep; the flag bits ride along as small integers
     double fl[4] = {(double)((flags >> 0) & 1), (double)((flags >> 1) & 1), (double)((flags >> 2) & 1),

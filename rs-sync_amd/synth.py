@@ -78,6 +78,7 @@ class Gyro:
     quats: np.ndarray    # (G, 4)
     times: np.ndarray    # (G,) sample times (s); uniform unless jittered
     spline: object       # natural cubic spline over the sample index
+    rates: np.ndarray = None  # (G, 3) angular rate samples the quaternions were integrated from
 
     def orientation(self, t):
         """unit quaternion at gyro time t: componentwise natural spline over the index, renormalised
@@ -103,7 +104,7 @@ def make_gyro(t_begin, t_end, fs=400.0, seed=0, margin=1.0):
     rates += rng.normal(0, 0.01, size=rates.shape)
     q = integrate_gyro(rates, np.full(g, 1.0 / fs))
     spline = CubicSpline(np.arange(g, dtype=np.float64), q, axis=0, bc_type="natural")
-    return Gyro(fs=fs, t0=t0, quats=q, times=t, spline=spline)
+    return Gyro(fs=fs, t0=t0, quats=q, times=t, spline=spline, rates=rates)
 
 
 def make_frames(gyro, frame_begin, frame_end, n_tracks, seed=0, d_true=D_TRUE, noise=1e-3, outliers=0.10,
@@ -168,6 +169,31 @@ def make_timestamped(gyro, jitter=0.2, seed=0):
     q = gyro.orientation(t)
     ts_us = np.round(t * 1e6).astype(np.int64)
     return ts_us, q
+
+
+# The 48 IMU orientations the reference's orientation-guessing block tries (core_testcode.cpp:186-190):
+# position = output axis, letter = input axis, upper case = +, lower case = - (telemetry-parser's
+# convention).  "XYZ" is the identity.
+ORIENTATIONS = (
+    "YxZ", "Xyz", "XZy", "Zxy", "zyX", "yxZ", "ZXY", "zYx", "ZYX", "yXz", "YZX", "XyZ",
+    "Yzx", "zXy", "YXz", "xyz", "yZx", "XYZ", "zxy", "xYz", "XYz", "zxY", "zXY", "xZy",
+    "zyx", "xyZ", "Yxz", "xzy", "yZX", "yzX", "ZYx", "xYZ", "zYX", "ZxY", "yzx", "xZY",
+    "Xzy", "XzY", "YzX", "Zyx", "XZY", "yxz", "xzY", "ZyX", "YXZ", "yXZ", "YZx", "ZXy")
+
+
+def orient_rates(rates, orientation):
+    """Apply a signed axis permutation to an (G, 3) rate stream."""
+    out = np.empty_like(rates)
+    for i, ch in enumerate(orientation):
+        out[:, i] = rates[:, "xyz".index(ch.lower())] * (1.0 if ch.isupper() else -1.0)
+    return out
+
+
+def gyro_for_orientation(gyro, orientation):
+    """The quaternion track a driver would hand to SetGyroQuaternions for one candidate orientation
+    (core_testcode.cpp:41-52: integrate the re-oriented rates)."""
+    r = orient_rates(gyro.rates, orientation)
+    return integrate_gyro(r, np.full(r.shape[0], 1.0 / gyro.fs))
 
 
 def fill(problem, gyro, frame_begin, frame_end, n_tracks, seed=0, **kw):

@@ -428,3 +428,36 @@ def test_presync_sweep_at_full_track_count():
     assert rel[same].max() < 1e-3 and np.median(rel[same]) < 2e-6
     assert np.argmin(ch) == np.argmin(co)
     np.testing.assert_allclose(ch, co, rtol=2e-3)
+
+
+def test_orientation_sweep_ranks_the_true_orientation_first():
+    """BASELINE config 5 in miniature: the reference's orientation-guessing loop
+    (core_testcode.cpp:216-232) -- 48 signed axis permutations of the gyro rates, SetGyroQuaternions
+    (timestamped overload) re-called on ONE problem object that keeps its tracks, PreSync each,
+    sort by cost.  The true orientation must come out on top, and costs must match the oracle."""
+    import rssync_amd
+    from rssync_amd import synth
+    from oracle.oracle import OracleProblem
+    F, N = 24, 256
+    g = synth.make_gyro(1.0, 1.0 + (F + 2) / synth.FPS, seed=77)   # t0 = 0: timestamps must be >= 0
+    frames = list(synth.make_frames(g, 30, 30 + F, N, seed=77))
+    ts_us = np.round(g.times * 1e6).astype(np.int64)
+    h = rssync_amd.SyncProblem(seed=SEED)
+    o = OracleProblem(seed=SEED, threads=min(os.cpu_count() or 1, 16), faithful=False)
+    for p in (h, o):
+        for fr in frames:
+            p.SetTrackResult(*fr)
+    results = []
+    for k, name in enumerate(synth.ORIENTATIONS):
+        q = synth.gyro_for_orientation(g, name)
+        h.SetGyroQuaternionsTimestamped(ts_us, q)
+        cost, delay = h.PreSync(0.0, 30, 30 + F, 0.004, 0.1)
+        results.append((cost, delay, name))
+        if k % 12 == 0:
+            o.SetGyroQuaternionsTimestamped(ts_us, q)
+            co, do = o.PreSync(0.0, 30, 30 + F, 0.004, 0.1)
+            assert cost == pytest.approx(co, rel=5e-3)
+    results.sort()
+    assert results[0][2] == "XYZ"
+    assert results[0][0] < 0.95 * results[1][0]
+    assert abs(results[0][1] - synth.D_TRUE) <= 0.003
