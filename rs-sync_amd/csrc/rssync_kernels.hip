@@ -564,7 +564,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                 if (row < N) {
                     const float r = pm[j] * sc;
                     rsum += fabsf(r);
-                    const float rho = rs::log1p_pos(r * r); // core_private.cpp:82
+                    const float rho = rs::log1p_pos_fast(r * r); // core_private.cpp:82
                     acc += sqrtf(rho);
                 }
             }
