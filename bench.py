@@ -156,13 +156,23 @@ def main():
                             "across the candidates of a chunk and is VALU/LDS-bound (DESIGN.md)"}
         # HBM traffic of that kernel from the PMC run committed under profiles/ (separate --pmc
         # passes for FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-        # for gfx950); only valid for the default workload
+        # for gfx950); only valid for the default workload.  The same file holds the kernel's VALU
+        # instruction count, which gives the roofline that actually bounds it (VALU issue).
+        roof_valu = None
         if roof and (F, N, n_cand) == (4096, 2048, 800):
             try:
                 raw = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic_raw.json")))["lmeds_kernel<8, 0>"]
                 roof["traffic"] = round((2 * raw["FETCH_SIZE"]["mean_per_launch_KiB"] +
                                          raw["WRITE_SIZE"]["mean_per_launch_KiB"]) * 1024 / 1e9, 4)
                 roof["traffic_unit"] = "GB per launch (profiles/r1_pmc_traffic_raw.json)"
+                insts = raw["SQ_INSTS_VALU"]["mean_per_launch"]
+                peak = 1024 * 2.4e9 / 4.43  # wave64 VALU instructions/s: tools/ubench/valu_rate.hip on MI355X
+                ach = insts / (roof["avg_launch_ms"] * 1e-3)
+                roof_valu = {"bound": "valu-issue", "kernel": "lmeds_kernel", "achieved": round(ach / 1e9, 2),
+                             "peak": round(peak / 1e9, 2), "unit": "G wave-instr/s", "frac": round(ach / peak, 4),
+                             "note": "SQ_INSTS_VALU per launch from profiles/r1_pmc_traffic_raw.json over the live "
+                                     "launch time; peak = 1024 SIMDs x 2.4 GHz / 4.43 cycles per wave64 VALU "
+                                     "instruction (measured, tools/ubench)"}
             except Exception:
                 pass
         kernels = {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in prof.items()}
@@ -177,7 +187,7 @@ def main():
             "config": {"workload": "PreSync(radius 200 ms, step 0.5 ms) + Sync(<=20 outer iters)",
                        "frames_per_gpu": F, "tracks": N, "candidates": n_cand,
                        "sync_outer_iters": iters_done, "gyro_hz": gyro.fs, "parallelism": "frames sharded x%d" % world},
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roof, "roofline_valu": roof_valu, "cpu_baseline": cpu, "kernels": kernels,
             "presync_ms_per_step": t_pre / args.steps * 1e3,
             "result": result, "host": {"gen_s": round(t_gen, 2), "pack_upload_s": round(t_up, 3)},
         }
