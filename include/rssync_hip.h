@@ -12,9 +12,11 @@
  *  - a "delay" reaches the device as  delay * sample_rate = kd + fd  with kd an
  *    int32 knot count and fd an fp32 fraction in [0,1): absolute times are
  *    never rounded to fp32;
- *  - rays live in HBM as two float4 streams per frame, {ax,ay,az,ta} and
- *    {bx,by,bz,tb}, where ta/tb are the ray's spline parameter minus the
- *    frame's integer base knot (32 B per ray pair);
+ *  - rays live in HBM as two float4 streams per frame with the two ends of a
+ *    ray pair interleaved, {ax,bx,ay,by} and {az,bz,ta,tb} (a 16-byte load
+ *    yields (a,b) component pairs in adjacent registers, which the packed
+ *    fp32 rotation consumes without moves); ta/tb are the ray's spline
+ *    parameter minus the frame's integer base knot (32 B per ray pair);
  *  - spline coefficients are 4 float4 per knot: y, b, c, d over [w,x,y,z];
  *  - every call is synchronous on return (results are in the host buffers).
  */
@@ -67,7 +69,7 @@ int rship_max_tracks(void); /* largest per-frame track count the kernels accept 
 int rship_upload_spline(rship_ctx* c, const float* coef16, uint32_t n_knots, double sample_rate);
 
 /* OptData::frame_data (core_private.hpp:21): all frames, packed */
-int rship_upload_frames(rship_ctx* c, const float* rays_a4, const float* rays_b4,
+int rship_upload_frames(rship_ctx* c, const float* rays_xy4, const float* rays_zt4,
                         uint64_t total_rays, const rship_frame* table, uint32_t n_frames);
 
 /* the frames a PreSync/Sync call works on (indices into the table; replaces the

@@ -292,7 +292,7 @@ void SyncProblemHip::build_spline() {
 }
 
 // Device layout of OptData::frame_data (core_private.hpp:21): two float4 streams
-// {ax,ay,az,ta} / {bx,by,bz,tb}, frames in ascending id order.  ta/tb carry the spline
+// {ax,bx,ay,by} / {az,bz,ta,tb}, frames in ascending id order.  ta/tb carry the spline
 // parameter (ts - start) * fs (core_private.cpp:19-20 without the delay) relative to the
 // frame's integer base knot, so fp32 only ever holds a span of a few tens of knots.
 void SyncProblemHip::pack_frames() {
@@ -325,8 +325,9 @@ void SyncProblemHip::pack_frames() {
             const float tb = (float)((f.ts_b[i] - start_) * fs_ - base);
             float* pa = &a4[4 * (off + i)];
             float* pb = &b4[4 * (off + i)];
-            pa[0] = (float)f.rays_a[3 * i]; pa[1] = (float)f.rays_a[3 * i + 1]; pa[2] = (float)f.rays_a[3 * i + 2]; pa[3] = ta;
-            pb[0] = (float)f.rays_b[3 * i]; pb[1] = (float)f.rays_b[3 * i + 1]; pb[2] = (float)f.rays_b[3 * i + 2]; pb[3] = tb;
+            // {ax,bx,ay,by} / {az,bz,ta,tb}: the two ends of the pair interleaved
+            pa[0] = (float)f.rays_a[3 * i]; pa[1] = (float)f.rays_b[3 * i]; pa[2] = (float)f.rays_a[3 * i + 1]; pa[3] = (float)f.rays_b[3 * i + 1];
+            pb[0] = (float)f.rays_a[3 * i + 2]; pb[1] = (float)f.rays_b[3 * i + 2]; pb[2] = ta; pb[3] = tb;
             if (i == 0) { tmin = std::min(ta, tb); tmax = std::max(ta, tb); }
             tmin = std::min(tmin, std::min(ta, tb));
             tmax = std::max(tmax, std::max(ta, tb));

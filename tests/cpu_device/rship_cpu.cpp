@@ -36,7 +36,8 @@ int fail(rship_ctx* c, const char* m) { c->err = m; return 1; }
 
 void row(const rship_ctx* c, const rship_frame& fr, uint32_t i, int32_t kd, float fd, f3& P, f3* dP) {
     const int n = (int)(c->coef.size() / 4);
-    const f4 ra = c->rays_a[fr.ray_offset + i], rb = c->rays_b[fr.ray_offset + i];
+    const f4 A = c->rays_a[fr.ray_offset + i], B = c->rays_b[fr.ray_offset + i]; // {ax,bx,ay,by} {az,bz,ta,tb}
+    const f4 ra{A.x, A.z, B.x, B.z}, rb{A.y, A.w, B.y, B.w};
     f3 r[2], dr[2];
     const f4 rays[2] = {ra, rb};
     for (int s = 0; s < 2; ++s) {
