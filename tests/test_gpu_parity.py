@@ -464,3 +464,41 @@ def test_orientation_sweep_ranks_the_true_orientation_first():
     assert results[0][2] == "XYZ"
     assert results[0][0] < 0.95 * results[1][0]
     assert abs(results[0][1] - synth.D_TRUE) <= 0.003
+
+
+def test_cxx_driver_through_the_vtable(tmp_path, small_case):
+    """examples/sync_driver.cpp: the reference driver's call pattern (PreSync, then four Sync calls
+    per sync point, core_testcode.cpp:303-316) through the C++ ISyncProblem surface must give the
+    same delays as the flat C-ABI does from Python."""
+    import struct
+    import subprocess
+    import rssync_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "sync_driver"
+    libdir = os.path.join(root, "rs-sync_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "sync_driver.cpp"), "-o", str(exe), "-L", libdir,
+                           "-lrssync_core", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    g = small_case["gyro"]
+    window, distance = 24, 16
+    blob = struct.pack("<qdd", g.quats.shape[0], g.fs, g.t0) + np.ascontiguousarray(g.quats).tobytes()
+    blob += struct.pack("<q", len(small_case["frames"]))
+    for fr, ta, tb, ra, rb in small_case["frames"]:
+        blob += struct.pack("<qq", fr, len(ta)) + ta.tobytes() + tb.tobytes() + np.ascontiguousarray(ra).tobytes() + \
+            np.ascontiguousarray(rb).tobytes()
+    blob += struct.pack("<qqddd", window, distance, 0.0, 2.0, 100.0)
+    inp = tmp_path / "input.bin"
+    inp.write_bytes(blob)
+    env = dict(os.environ, RSSYNC_SEED=str(SEED), RSSYNC_QUIET="1")
+    out = subprocess.run([str(exe), str(inp)], capture_output=True, text=True, env=env, cwd=tmp_path, check=True).stdout
+    got = [tuple(map(float, line.split(","))) for line in out.strip().splitlines()]
+    from conftest import fill
+    h = fill(rssync_amd.SyncProblem(seed=SEED), small_case)
+    want = []
+    for pos in range(0, small_case["F"] - window, distance):
+        d = h.PreSync(0.0, pos, pos + window, 0.002, 0.1)[1]
+        for _ in range(4):
+            d = h.Sync(d, pos, pos + window, 0.0, 0.1)[1]
+        want.append((float(pos), 1000 * d))
+    assert len(got) == len(want) >= 2
+    np.testing.assert_allclose(np.array(got), np.array(want), rtol=0, atol=1e-6)
