@@ -103,6 +103,21 @@ int rssync_ext_opt_motion(rssync_problem* p, double delay, double* M, double* k,
 int rssync_ext_set_motion(rssync_problem* p, const double* M, const double* k, int n_frames);
 /* sum over the current selection of loss (and analytic d/d-delay) at n delays */
 int rssync_ext_loss(rssync_problem* p, const double* delays, int n, double* loss, double* grad);
+/* Batched windows (the driver's loop, core_testcode.cpp:303-316, calls
+ * PreSync + 4x Sync once per window position; these run all positions in one call).
+ * pre_sync_windows: window w = PreSync(initial_delay, begins[w], ends[w], step, radius) -- the
+ * candidate list is shared, the LMedS kernel runs once over the union of the windows' frames.
+ * sync_windows: window w = the w-th of n consecutive Sync(initial_delays[w], begins[w], ends[w],
+ * center, radius) calls; the windows advance in lock-step, one launch per stage for all of them.
+ * Frame ranges follow the methods they batch: ends exclusive for pre_sync, inclusive for sync. */
+int rssync_ext_pre_sync_windows(rssync_problem* p, double initial_delay, const int64_t* frame_begins,
+                                const int64_t* frame_ends, int n_windows, double search_step,
+                                double search_radius, double* costs, double* delays);
+int rssync_ext_sync_windows(rssync_problem* p, const double* initial_delays, const int64_t* frame_begins,
+                            const int64_t* frame_ends, int n_windows, double search_center,
+                            double search_radius, double* costs, double* delays);
+/* trace of one window of the last sync_windows call (same rows as sync_trace) */
+int rssync_ext_window_trace(rssync_problem* p, int window, double* trace, int cap_rows, int* n_rows);
 /* trace of the last Sync: rows of {delay_after, step, loss_at_x0, grad_at_x0, t, trials} */
 int rssync_ext_sync_trace(rssync_problem* p, double* trace, int cap_rows, int* n_rows);
 /* the internal device context (rship_ctx*, include/rssync_hip.h) behind this problem, for

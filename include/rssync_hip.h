@@ -75,6 +75,12 @@ int rship_upload_frames(rship_ctx* c, const float* rays_xy4, const float* rays_z
 /* the frames a PreSync/Sync call works on (indices into the table; replaces the
  * frame filters at core_private.cpp:65-68, :218-219, :340-343) */
 int rship_select_frames(rship_ctx* c, const uint32_t* idx, uint32_t n);
+/* Batched windows: the selection is a list of SLOTS; slots
+ * grp_off[w] .. grp_off[w+1] belong to window w, the same frame may occupy slots of several
+ * windows, and the per-frame Sync state (M, k) is kept per slot.  Delays are then given per
+ * window.  rship_select_frames = one window over all slots. */
+int rship_select_slots(rship_ctx* c, const uint32_t* idx, uint32_t n, const uint32_t* grp_off,
+                       uint32_t n_grp);
 
 /* pre_sync's per-frame body for every (selected frame, candidate delay):
  * opt_compute_problem + opt_guess_translational_motion(P, n_hyp) + cost
@@ -83,26 +89,35 @@ int rship_select_frames(rship_ctx* c, const uint32_t* idx, uint32_t n);
 int rship_presync_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand,
                         uint32_t n_hyp, uint32_t stream_base, uint64_t seed, double* costs,
                         uint32_t* flags, double* frame_costs, int32_t* best_h);
+/* the same for several windows over one (ungrouped) selection: costs[n_cand][n_win], window w
+ * summing the slots seg_idx[seg_off[w] .. seg_off[w+1]) (seg_idx NULL = the slots themselves) */
+int rship_presync_window_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand,
+                               uint32_t n_hyp, uint32_t stream_base, uint64_t seed,
+                               const uint32_t* seg_idx, const uint32_t* seg_off, uint32_t n_win,
+                               double* costs, uint32_t* flags, double* frame_costs, int32_t* best_h);
 
 /* FrameState::GuessMotion + GuessK (core_private.cpp:125-133) for every
- * selected frame at one delay; results stay on the device */
-int rship_init_motion(rship_ctx* c, int32_t kd, float fd, uint32_t n_hyp, uint32_t stream,
-                      uint64_t seed);
+ * selected slot; kd/fd hold one delay per window, window w samples with stream + w;
+ * results stay on the device */
+int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_hyp,
+                      uint32_t stream, uint64_t seed);
 
 /* do_opt_motion (core_private.cpp:262-296): per-frame L-BFGS on the motion
- * vector at a fixed delay.  stats (optional) = {sum of iterations, sum of evaluations} */
-int rship_opt_motion(rship_ctx* c, int32_t kd, float fd, uint64_t* stats);
+ * vector at a fixed delay per window (fd = NaN skips a window).
+ * stats (optional) = {sum of iterations, sum of evaluations} */
+int rship_opt_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint64_t* stats);
+/* the same with per-slot diagnostics: per_frame[2i] = L-BFGS iterations, [2i+1] = evaluations */
+int rship_opt_motion_detail(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t* per_frame,
+                            uint32_t cap);
 
-/* the same with per-frame diagnostics: per_frame[2i] = L-BFGS iterations, [2i+1] = evaluations */
-int rship_opt_motion_detail(rship_ctx* c, int32_t kd, float fd, uint32_t* per_frame, uint32_t cap);
-
-/* sum over selected frames of FrameState::Loss at n_delays delays
- * (core_private.cpp:117-123); with grad != NULL also the analytic d/d-delay
- * that replaces the central difference at :96-97,112 */
+/* per window, sum over its slots of FrameState::Loss at n_delays delays
+ * (core_private.cpp:117-123); kd/fd are [n_delays][n_windows] (fd = NaN skips), loss/grad out
+ * likewise; with grad != NULL also the analytic d/d-delay that replaces the central
+ * difference at :96-97,112 */
 int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_delays, double* loss,
                double* grad);
 
-/* per-frame state (selected frames, ascending selection order): M[3n], k[n] */
+/* per-slot state in selection order: M[3n], k[n] */
 int rship_get_motion(rship_ctx* c, double* M, double* k, uint32_t cap, uint32_t* n);
 int rship_set_motion(rship_ctx* c, const double* M, const double* k, uint32_t n);
 

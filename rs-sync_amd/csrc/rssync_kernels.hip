@@ -11,7 +11,7 @@
 //                      d/d-delay) for a batch of delays, rays held in registers.
 //   opt_motion_kernel  one workgroup per frame: P in registers, restated L-BFGS on the
 //                      3-vector motion estimate.
-//   reduce_rows_kernel fixed-order fp64 sums over frames.
+//   segment_sum_kernel fixed-order fp64 sums over the frames of each window.
 // Data layout and the roofline that bounds each kernel: DESIGN.md.
 #include <hip/hip_runtime.h>
 
@@ -207,9 +207,11 @@ struct LmedsParams {
     uint32_t n_cand, chunk, n_chunks;
     uint32_t n_hyp, stream_base;
     uint64_t seed;
+    const uint32_t* grp; // slot -> group (window) or null; delays are indexed [candidate][group]
+    uint32_t n_grp;      // >= 1
     double* frame_cost; // [n_cand][n_sel]
     int32_t* best_h;    // [n_cand][n_sel] or null
-    double* M;          // INIT mode: per table frame [3]
+    double* M;          // INIT mode: per selection slot [3]
     double* k;          // INIT mode
     uint32_t* flags;
 };
@@ -434,6 +436,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     const FrameRec fr = p.frames[fi];
     const uint32_t N = fr.n;
     const uint32_t kq = N / 4; // core_private.cpp:52
+    const uint32_t g = p.grp ? p.grp[sf] : 0u; // window this slot belongs to (batched Sync)
     const Tile tile{s_n[0], s_n[1], s_n[2]};
 
     // rays are re-read per candidate: the chunks of a frame share an XCD, so after the
@@ -449,9 +452,9 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     sp.g = p.coef;
     sp.n = p.n_knots;
     {
-        int kd_lo = p.kd[c0], kd_hi = p.kd[c0];
+        int kd_lo = p.kd[c0 * p.n_grp + g], kd_hi = kd_lo;
         for (uint32_t c = c0 + 1; c < c1; ++c) {
-            int v = p.kd[c];
+            int v = p.kd[c * p.n_grp + g];
             kd_lo = v < kd_lo ? v : kd_lo;
             kd_hi = v > kd_hi ? v : kd_hi;
         }
@@ -466,9 +469,9 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     uint32_t prev_best = kInfBits; // winning quantile of the previous candidate of this chunk
 
     for (uint32_t c = c0; c < c1; ++c) {
-        const int base = fr.base_knot + p.kd[c];
-        const float fd = p.fd[c];
-        const uint32_t stream = p.stream_base + c;
+        const int base = fr.base_knot + p.kd[c * p.n_grp + g];
+        const float fd = p.fd[c * p.n_grp + g];
+        const uint32_t stream = p.stream_base + c + g; // g != 0 only for batched GuessMotion (one candidate)
         uint32_t bad = 0;
         // ---- stage A: rows of P -> LDS tile as unit rows; norms stay in registers ----
         float nrm[RPT];
@@ -565,10 +568,10 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         kf = (kf < 10.f) ? 10.f : ((1000.f < kf) ? 1000.f : kf);
         if (MODE == 1) {
             if (tid == 0) {
-                p.M[3 * fi + 0] = (double)Mv.x;
-                p.M[3 * fi + 1] = (double)Mv.y;
-                p.M[3 * fi + 2] = (double)Mv.z;
-                p.k[fi] = (double)kf;
+                p.M[3 * sf + 0] = (double)Mv.x;
+                p.M[3 * sf + 1] = (double)Mv.y;
+                p.M[3 * sf + 2] = (double)Mv.z;
+                p.k[sf] = (double)kf;
             }
         } else {
             float sc = kf / sqrtf(rs::dot(Mv, Mv)); // core_private.cpp:80
@@ -610,10 +613,12 @@ struct LossParams {
     const f4* coef;
     int n_knots;
     float fs;
-    const int32_t* kd;
-    const float* fd;
+    const int32_t* kd; // [n_delays][n_grp]
+    const float* fd;   // NaN = this group is skipped (its partial sums are written as 0)
     uint32_t n_delays;
-    const double* M;
+    const uint32_t* grp;
+    uint32_t n_grp;
+    const double* M; // per selection slot
     const double* k;
     double* part_loss; // [n_delays][n_sel]
     double* part_grad; // [n_delays][n_sel] (GRAD)
@@ -656,7 +661,8 @@ __global__ __launch_bounds__(kBlock, loss_waves(RPT, GRAD)) void loss_kernel(Los
     // HBM, the rest from L2 (the frame is 32 B x N, far below one XCD's 4 MiB)
     const f4* __restrict__ rays_a = p.rays_a + fr.off;
     const f4* __restrict__ rays_b = p.rays_b + fr.off;
-    const double Mx = p.M[3 * fi], My = p.M[3 * fi + 1], Mz = p.M[3 * fi + 2], kk = p.k[fi];
+    const uint32_t g = p.grp ? p.grp[sf] : 0u;
+    const double Mx = p.M[3 * sf], My = p.M[3 * sf + 1], Mz = p.M[3 * sf + 2], kk = p.k[sf];
     const f3 Mv = f3{(float)Mx, (float)My, (float)Mz};
     // r = (P.M) k / |M|  (core_private.cpp:120)  ->  u = (P.M)^2 * inv_s
     const float inv_s = (float)(kk * kk / (Mx * Mx + My * My + Mz * Mz));
@@ -665,8 +671,15 @@ __global__ __launch_bounds__(kBlock, loss_waves(RPT, GRAD)) void loss_kernel(Los
     sp.g = p.coef;
     sp.n = p.n_knots;
     for (uint32_t b = 0; b < p.n_delays; ++b) {
-        const int kd = p.kd[b];
-        const float fd = p.fd[b];
+        const int kd = p.kd[b * p.n_grp + g];
+        const float fd = p.fd[b * p.n_grp + g];
+        if (fd != fd) { // group switched off for this evaluation (workgroup-uniform)
+            if (tid == 0) {
+                p.part_loss[(size_t)b * p.n_sel + sf] = 0.0;
+                if (GRAD) p.part_grad[(size_t)b * p.n_sel + sf] = 0.0;
+            }
+            continue;
+        }
         __syncthreads(); // window and s_red reuse
         stage_window(sp, s_win, fr.base_knot + (int)floorf(fr.tmin) + kd, fr.base_knot + (int)floorf(fr.tmax) + kd + 1);
         __syncthreads();
@@ -706,9 +719,10 @@ struct MotionParams {
     uint32_t n_sel;
     const f4* coef;
     int n_knots;
-    int32_t kd;
-    float fd;
-    double* M;
+    const int32_t* kd; // [n_grp]
+    const float* fd;   // NaN = skip the group's slots
+    const uint32_t* grp;
+    double* M; // per selection slot
     const double* k;
     unsigned long long* stats; // [0] += iterations, [1] += evaluations
     uint32_t* per_frame;       // optional [n_sel][2]: iterations, evaluations
@@ -782,27 +796,31 @@ __global__ __launch_bounds__(kBlock, 4) void opt_motion_kernel(MotionParams p) {
     const uint32_t fi = p.sel[sf];
     const FrameRec fr = p.frames[fi];
     const uint32_t N = fr.n;
+    const uint32_t grp = p.grp ? p.grp[sf] : 0u;
+    const int kd = p.kd[grp];
+    const float fd = p.fd[grp];
+    if (fd != fd) return; // this window is not being optimised in this call (workgroup-uniform)
 
     Spline sp;
     sp.g = p.coef;
     sp.n = p.n_knots;
-    stage_window(sp, s_win, fr.base_knot + (int)floorf(fr.tmin) + p.kd, fr.base_knot + (int)floorf(fr.tmax) + p.kd + 1);
+    stage_window(sp, s_win, fr.base_knot + (int)floorf(fr.tmin) + kd, fr.base_knot + (int)floorf(fr.tmax) + kd + 1);
     __syncthreads();
 
     MotionEval<RPT> ev;
     ev.part = s_part;
     ev.buf = 0;
     ev.evals = 0;
-    const double kk = p.k[fi];
+    const double kk = p.k[sf];
     ev.k2 = kk * kk;
-    const int base = fr.base_knot + p.kd;
+    const int base = fr.base_knot + kd;
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
         uint32_t row = j * kBlock + tid;
         f3 P = f3{0, 0, 0}, dP;
         if (row < N) {
-            if (sp.path == kPathInterior) residual_row<false, kPathInterior>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], base, p.fd, P, dP);
-            else residual_row<false, kPathGlobal>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], base, p.fd, P, dP);
+            if (sp.path == kPathInterior) residual_row<false, kPathInterior>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], base, fd, P, dP);
+            else residual_row<false, kPathGlobal>(sp, p.rays_a[fr.off + row], p.rays_b[fr.off + row], base, fd, P, dP);
         }
         ev.P[j] = P; // zero rows contribute log1p(0) = 0 and no gradient
     }
@@ -812,7 +830,7 @@ __global__ __launch_bounds__(kBlock, 4) void opt_motion_kernel(MotionParams p) {
     const double armijo = 1e-4, wolfe = 0.9, factr = 1e-15, minStep = 1e-20, maxStep = 1e20;
     const int maxLineSearchTrials = 50;
 
-    double x[3] = {p.M[3 * fi], p.M[3 * fi + 1], p.M[3 * fi + 2]};
+    double x[3] = {p.M[3 * sf], p.M[3 * sf + 1], p.M[3 * sf + 2]};
     double g[3], oldx[3], oldg[3], dir[3];
     double fval = ev(x, g);
     int it = 0;
@@ -890,7 +908,7 @@ __global__ __launch_bounds__(kBlock, 4) void opt_motion_kernel(MotionParams p) {
         __syncthreads();
     }
     if (tid == 0) {
-        p.M[3 * fi] = x[0]; p.M[3 * fi + 1] = x[1]; p.M[3 * fi + 2] = x[2];
+        p.M[3 * sf] = x[0]; p.M[3 * sf + 1] = x[1]; p.M[3 * sf + 2] = x[2];
         if (p.stats) {
             atomicAdd(&p.stats[0], (unsigned long long)it);
             atomicAdd(&p.stats[1], (unsigned long long)ev.evals);
@@ -903,16 +921,22 @@ __global__ __launch_bounds__(kBlock, 4) void opt_motion_kernel(MotionParams p) {
 }
 
 // ---------------------------------------------------------------------------
-// out[r] = sum over columns of in[r][*], fixed association (bitwise reproducible)
+// out[r][w] = sum over j in [off[w], off[w+1]) of in[r][idx ? idx[j] : j]: per-window (segment)
+// sums over frames with a fixed association, so results are bitwise reproducible and a window
+// summed inside a batch equals the same window summed alone.  With one segment covering all
+// columns this is the plain over-frames sum.
 
-__global__ __launch_bounds__(kBlock) void reduce_rows_kernel(const double* __restrict__ in, double* __restrict__ out,
-                                                            uint32_t n_cols) {
+__global__ __launch_bounds__(kBlock) void segment_sum_kernel(const double* __restrict__ in, double* __restrict__ out,
+                                                            uint32_t n_cols, const uint32_t* __restrict__ idx,
+                                                            const uint32_t* __restrict__ off, uint32_t n_seg) {
     __shared__ double s_red[4];
-    const double* row = in + (size_t)blockIdx.x * n_cols;
+    const uint32_t r = blockIdx.x / n_seg, w = blockIdx.x % n_seg;
+    const uint32_t j0 = off ? off[w] : 0u, j1 = off ? off[w + 1] : n_cols;
+    const double* row = in + (size_t)r * n_cols;
     double acc = 0.0;
-    for (uint32_t i = threadIdx.x; i < n_cols; i += kBlock) acc += row[i];
-    double w = wave_sum_f64(acc);
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = w;
+    for (uint32_t j = j0 + threadIdx.x; j < j1; j += kBlock) acc += row[idx ? idx[j] : j];
+    double wsum = wave_sum_f64(acc);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = wsum;
     __syncthreads();
     if (threadIdx.x == 0) out[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
@@ -997,8 +1021,8 @@ struct rship_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     // problem data
-    DevBuf coef, rays_a, rays_b, frames, sel, M, k;
-    uint32_t n_knots = 0, n_frames = 0, n_sel = 0, max_n = 0;
+    DevBuf coef, rays_a, rays_b, frames, sel, M, k, grp, grp_off, seg_idx, seg_off;
+    uint32_t n_knots = 0, n_frames = 0, n_sel = 0, max_n = 0, n_grp = 1;
     uint64_t total_rays = 0;
     double fs = 0;
     std::vector<uint32_t> h_frame_n; // per table frame
@@ -1153,9 +1177,10 @@ int launch_motion(rship_ctx* c, const MotionParams& p, int rpt) {
     return 0;
 }
 
-int launch_reduce(rship_ctx* c, const double* in, double* out, uint32_t rows, uint32_t cols) {
+int launch_reduce(rship_ctx* c, const double* in, double* out, uint32_t rows, uint32_t cols, const uint32_t* idx,
+                  const uint32_t* off, uint32_t n_seg) {
     ProfScope ps(c, RSHIP_K_REDUCE);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(rows), dim3(kBlock), 0, c->stream, in, out, cols);
+    hipLaunchKernelGGL(segment_sum_kernel, dim3(rows * n_seg), dim3(kBlock), 0, c->stream, in, out, cols, idx, off, n_seg);
     RS_HIP(hipGetLastError());
     return 0;
 }
@@ -1198,7 +1223,8 @@ void rship_destroy(rship_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&c->coef, &c->rays_a, &c->rays_b, &c->frames, &c->sel, &c->M, &c->k, &c->kd, &c->fd,
+    DevBuf* bufs[] = {&c->coef, &c->rays_a, &c->rays_b, &c->frames, &c->sel, &c->M, &c->k, &c->grp, &c->grp_off,
+                      &c->seg_idx, &c->seg_off, &c->kd, &c->fd,
                       &c->frame_cost, &c->best_h, &c->costs, &c->part, &c->flags, &c->stats};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -1241,42 +1267,87 @@ int rship_upload_frames(rship_ctx* c, const float* rays_a4, const float* rays_b4
     size_t rb = (size_t)total_rays * 16;
     if (ensure(c, c->rays_a, rb ? rb : 16) || ensure(c, c->rays_b, rb ? rb : 16)) return 1;
     if (ensure(c, c->frames, (size_t)n_frames * sizeof(rship_frame) + 32)) return 1;
-    if (ensure(c, c->M, (size_t)n_frames * 24 + 24) || ensure(c, c->k, (size_t)n_frames * 8 + 8)) return 1;
     if (rb) {
         RS_HIP(hipMemcpyAsync(c->rays_a.p, rays_a4, rb, hipMemcpyHostToDevice, c->stream));
         RS_HIP(hipMemcpyAsync(c->rays_b.p, rays_b4, rb, hipMemcpyHostToDevice, c->stream));
     }
     if (n_frames) RS_HIP(hipMemcpyAsync(c->frames.p, table, (size_t)n_frames * sizeof(rship_frame), hipMemcpyHostToDevice, c->stream));
-    RS_HIP(hipMemsetAsync(c->M.p, 0, (size_t)n_frames * 24 + 24, c->stream));
-    RS_HIP(hipMemsetAsync(c->k.p, 0, (size_t)n_frames * 8 + 8, c->stream));
     RS_HIP(hipStreamSynchronize(c->stream));
     c->n_frames = n_frames;
     c->total_rays = total_rays;
     return 0;
 }
 
-int rship_select_frames(rship_ctx* c, const uint32_t* idx, uint32_t n) {
+// Selection = list of slots.  A slot names a frame of the table; with groups (batched windows)
+// the same frame may appear in several slots, slots of one group are contiguous, and the
+// per-frame Sync state (M, k) is kept per slot.
+int rship_select_slots(rship_ctx* c, const uint32_t* idx, uint32_t n, const uint32_t* grp_off, uint32_t n_grp) {
     for (uint32_t i = 0; i < n; ++i)
         if (idx[i] >= c->n_frames) return set_err(c, "select: frame index out of range");
-    if (ensure(c, c->sel, (size_t)n * 4 + 4)) return 1;
-    if (n) RS_HIP(hipMemcpyAsync(c->sel.p, idx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    if (n_grp < 1) n_grp = 1;
+    if (grp_off && (grp_off[0] != 0 || grp_off[n_grp] != n)) return set_err(c, "select: bad group offsets");
+    if (ensure(c, c->sel, (size_t)n * 4 + 4) || ensure(c, c->grp, (size_t)n * 4 + 4) ||
+        ensure(c, c->grp_off, (size_t)(n_grp + 1) * 4))
+        return 1;
+    if (ensure(c, c->M, (size_t)n * 24 + 24) || ensure(c, c->k, (size_t)n * 8 + 8)) return 1;
+    std::vector<uint32_t> g(n, 0), off(n_grp + 1, 0);
+    if (grp_off) {
+        off.assign(grp_off, grp_off + n_grp + 1);
+        for (uint32_t w = 0; w < n_grp; ++w)
+            for (uint32_t j = off[w]; j < off[w + 1]; ++j) g[j] = w;
+    } else {
+        off[n_grp] = n; // single group (n_grp == 1)
+    }
+    if (n) {
+        RS_HIP(hipMemcpyAsync(c->sel.p, idx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        RS_HIP(hipMemcpyAsync(c->grp.p, g.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    RS_HIP(hipMemcpyAsync(c->grp_off.p, off.data(), (size_t)(n_grp + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemsetAsync(c->M.p, 0, (size_t)n * 24 + 24, c->stream));
+    RS_HIP(hipMemsetAsync(c->k.p, 0, (size_t)n * 8 + 8, c->stream));
     RS_HIP(hipStreamSynchronize(c->stream));
     c->h_sel.assign(idx, idx + n);
     c->n_sel = n;
+    c->n_grp = n_grp;
     c->max_n = sel_max_n(c);
     return 0;
 }
 
+int rship_select_frames(rship_ctx* c, const uint32_t* idx, uint32_t n) { return rship_select_slots(c, idx, n, nullptr, 1); }
+
 int rship_presync_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand, uint32_t n_hyp,
                         uint32_t stream_base, uint64_t seed, double* costs, uint32_t* flags, double* frame_costs,
                         int32_t* best_h) {
+    return rship_presync_window_costs(c, kd, fd, n_cand, n_hyp, stream_base, seed, nullptr, nullptr, 1, costs, flags,
+                                      frame_costs, best_h);
+}
+
+// costs[n_cand][n_win]: window w sums the frame costs of slots seg_idx[seg_off[w] .. seg_off[w+1])
+// (NULL, NULL, 1 = one window over every selected slot).  The selection must be a single group.
+int rship_presync_window_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand, uint32_t n_hyp,
+                               uint32_t stream_base, uint64_t seed, const uint32_t* seg_idx, const uint32_t* seg_off,
+                               uint32_t n_win, double* costs, uint32_t* flags, double* frame_costs, int32_t* best_h) {
     if (check_ready(c)) return 1;
+    if (c->n_grp != 1) return set_err(c, "presync: the selection must not be grouped");
     if (!n_cand) return 0;
+    if (n_win < 1) n_win = 1;
     const uint32_t ns = c->n_sel;
     if (ensure(c, c->kd, (size_t)n_cand * 4) || ensure(c, c->fd, (size_t)n_cand * 4)) return 1;
-    if (ensure(c, c->frame_cost, (size_t)n_cand * ns * 8) || ensure(c, c->costs, (size_t)n_cand * 8)) return 1;
+    if (ensure(c, c->frame_cost, (size_t)n_cand * ns * 8) || ensure(c, c->costs, (size_t)n_cand * n_win * 8)) return 1;
     if (best_h && ensure(c, c->best_h, (size_t)n_cand * ns * 4)) return 1;
     if (ensure(c, c->flags, 16)) return 1;
+    const uint32_t* d_idx = nullptr;
+    const uint32_t* d_off = nullptr;
+    if (seg_off) {
+        const uint32_t total = seg_off[n_win];
+        for (uint32_t j = 0; seg_idx && j < total; ++j)
+            if (seg_idx[j] >= ns) return set_err(c, "presync: window index out of range");
+        if (ensure(c, c->seg_idx, (size_t)total * 4 + 4) || ensure(c, c->seg_off, (size_t)(n_win + 1) * 4)) return 1;
+        if (seg_idx && total) RS_HIP(hipMemcpyAsync(c->seg_idx.p, seg_idx, (size_t)total * 4, hipMemcpyHostToDevice, c->stream));
+        RS_HIP(hipMemcpyAsync(c->seg_off.p, seg_off, (size_t)(n_win + 1) * 4, hipMemcpyHostToDevice, c->stream));
+        d_idx = seg_idx ? (const uint32_t*)c->seg_idx.p : nullptr;
+        d_off = (const uint32_t*)c->seg_off.p;
+    }
     RS_HIP(hipMemcpyAsync(c->kd.p, kd, (size_t)n_cand * 4, hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipMemcpyAsync(c->fd.p, fd, (size_t)n_cand * 4, hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipMemsetAsync(c->flags.p, 0, 16, c->stream));
@@ -1292,8 +1363,10 @@ int rship_presync_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32
     p.kd = (const int32_t*)c->kd.p;
     p.fd = (const float*)c->fd.p;
     p.n_cand = n_cand;
+    p.grp = nullptr;
+    p.n_grp = 1;
     // enough workgroups to fill 256 CUs several times over, chunks long enough to
-    // amortise the ray loads (registers) and the spline window (LDS)
+    // amortise the spline window (LDS) and to carry the provisional bound along
     uint64_t work = (uint64_t)n_cand * ns;
     uint32_t chunk = (uint32_t)(work / 8192);
     if (chunk < 1) chunk = 1;
@@ -1311,25 +1384,48 @@ int rship_presync_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32
     uint64_t grid = (uint64_t)groups * 8 * p.n_chunks;
     if (grid > 0x7fffffffull) return set_err(c, "presync: grid too large");
     if (launch_lmeds<0>(c, p, rpt_for(c->max_n), (uint32_t)grid)) return 1;
-    if (launch_reduce(c, p.frame_cost, (double*)c->costs.p, n_cand, ns)) return 1;
+    if (launch_reduce(c, p.frame_cost, (double*)c->costs.p, n_cand, ns, d_idx, d_off, n_win)) return 1;
 
-    size_t need = (size_t)n_cand * 8 + 16;
-    if (ensure_pinned(c, need)) return 1;
-    RS_HIP(hipMemcpyAsync(c->pinned, c->costs.p, (size_t)n_cand * 8, hipMemcpyDeviceToHost, c->stream));
-    RS_HIP(hipMemcpyAsync((char*)c->pinned + (size_t)n_cand * 8, c->flags.p, 4, hipMemcpyDeviceToHost, c->stream));
+    const size_t out_bytes = (size_t)n_cand * n_win * 8;
+    if (ensure_pinned(c, out_bytes + 16)) return 1;
+    RS_HIP(hipMemcpyAsync(c->pinned, c->costs.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    RS_HIP(hipMemcpyAsync((char*)c->pinned + out_bytes, c->flags.p, 4, hipMemcpyDeviceToHost, c->stream));
     if (sync_stream(c)) return 1;
-    memcpy(costs, c->pinned, (size_t)n_cand * 8);
-    if (flags) memcpy(flags, (char*)c->pinned + (size_t)n_cand * 8, 4);
+    memcpy(costs, c->pinned, out_bytes);
+    if (flags) memcpy(flags, (char*)c->pinned + out_bytes, 4);
     if (frame_costs) RS_HIP(hipMemcpy(frame_costs, c->frame_cost.p, (size_t)n_cand * ns * 8, hipMemcpyDeviceToHost));
     if (best_h) RS_HIP(hipMemcpy(best_h, c->best_h.p, (size_t)n_cand * ns * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 
-int rship_init_motion(rship_ctx* c, int32_t kd, float fd, uint32_t n_hyp, uint32_t stream, uint64_t seed) {
+namespace {
+// per-group delays -> device (kd/fd arrays of n entries)
+int upload_delays(rship_ctx* c, const int32_t* kd, const float* fd, size_t n) {
+    if (ensure(c, c->kd, n * 4) || ensure(c, c->fd, n * 4)) return 1;
+    RS_HIP(hipMemcpyAsync(c->kd.p, kd, n * 4, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemcpyAsync(c->fd.p, fd, n * 4, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+void fill_motion(rship_ctx* c, MotionParams& p) {
+    p.rays_a = (const f4*)c->rays_a.p;
+    p.rays_b = (const f4*)c->rays_b.p;
+    p.frames = (const FrameRec*)c->frames.p;
+    p.sel = (const uint32_t*)c->sel.p;
+    p.n_sel = c->n_sel;
+    p.coef = (const f4*)c->coef.p;
+    p.n_knots = (int)c->n_knots;
+    p.kd = (const int32_t*)c->kd.p;
+    p.fd = (const float*)c->fd.p;
+    p.grp = c->n_grp > 1 ? (const uint32_t*)c->grp.p : nullptr;
+    p.M = (double*)c->M.p;
+    p.k = (const double*)c->k.p;
+}
+} // namespace
+
+// kd/fd: one delay per group of the selection
+int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_hyp, uint32_t stream, uint64_t seed) {
     if (check_ready(c)) return 1;
-    if (ensure(c, c->kd, 4) || ensure(c, c->fd, 4) || ensure(c, c->flags, 16)) return 1;
-    RS_HIP(hipMemcpyAsync(c->kd.p, &kd, 4, hipMemcpyHostToDevice, c->stream));
-    RS_HIP(hipMemcpyAsync(c->fd.p, &fd, 4, hipMemcpyHostToDevice, c->stream));
+    if (upload_delays(c, kd, fd, c->n_grp) || ensure(c, c->flags, 16)) return 1;
     RS_HIP(hipMemsetAsync(c->flags.p, 0, 16, c->stream));
     LmedsParams p{};
     p.rays_a = (const f4*)c->rays_a.p;
@@ -1345,8 +1441,10 @@ int rship_init_motion(rship_ctx* c, int32_t kd, float fd, uint32_t n_hyp, uint32
     p.chunk = 1;
     p.n_chunks = 1;
     p.n_hyp = n_hyp;
-    p.stream_base = stream;
+    p.stream_base = stream; // + group index inside the kernel: window w uses stream + w
     p.seed = seed;
+    p.grp = c->n_grp > 1 ? (const uint32_t*)c->grp.p : nullptr;
+    p.n_grp = c->n_grp;
     p.M = (double*)c->M.p;
     p.k = (double*)c->k.p;
     p.flags = (uint32_t*)c->flags.p;
@@ -1355,23 +1453,15 @@ int rship_init_motion(rship_ctx* c, int32_t kd, float fd, uint32_t n_hyp, uint32
     return sync_stream(c);
 }
 
-int rship_opt_motion_detail(rship_ctx* c, int32_t kd, float fd, uint32_t* per_frame, uint32_t cap) {
+int rship_opt_motion_detail(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t* per_frame, uint32_t cap) {
     if (check_ready(c)) return 1;
     if (cap < c->n_sel) return set_err(c, "opt_motion_detail: output too small");
     DevBuf d;
     if (ensure(c, d, (size_t)c->n_sel * 8 + 8)) return 1;
+    RS_HIP(hipMemsetAsync(d.p, 0, (size_t)c->n_sel * 8 + 8, c->stream));
+    if (upload_delays(c, kd, fd, c->n_grp)) return 1;
     MotionParams p{};
-    p.rays_a = (const f4*)c->rays_a.p;
-    p.rays_b = (const f4*)c->rays_b.p;
-    p.frames = (const FrameRec*)c->frames.p;
-    p.sel = (const uint32_t*)c->sel.p;
-    p.n_sel = c->n_sel;
-    p.coef = (const f4*)c->coef.p;
-    p.n_knots = (int)c->n_knots;
-    p.kd = kd;
-    p.fd = fd;
-    p.M = (double*)c->M.p;
-    p.k = (const double*)c->k.p;
+    fill_motion(c, p);
     p.per_frame = (uint32_t*)d.p;
     int rc = launch_motion(c, p, rpt_for(c->max_n));
     hipError_t e = hipStreamSynchronize(c->stream);
@@ -1383,22 +1473,13 @@ int rship_opt_motion_detail(rship_ctx* c, int32_t kd, float fd, uint32_t* per_fr
     return 0;
 }
 
-int rship_opt_motion(rship_ctx* c, int32_t kd, float fd, uint64_t* stats) {
+int rship_opt_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint64_t* stats) {
     if (check_ready(c)) return 1;
     if (ensure(c, c->stats, 16)) return 1;
     RS_HIP(hipMemsetAsync(c->stats.p, 0, 16, c->stream));
+    if (upload_delays(c, kd, fd, c->n_grp)) return 1;
     MotionParams p{};
-    p.rays_a = (const f4*)c->rays_a.p;
-    p.rays_b = (const f4*)c->rays_b.p;
-    p.frames = (const FrameRec*)c->frames.p;
-    p.sel = (const uint32_t*)c->sel.p;
-    p.n_sel = c->n_sel;
-    p.coef = (const f4*)c->coef.p;
-    p.n_knots = (int)c->n_knots;
-    p.kd = kd;
-    p.fd = fd;
-    p.M = (double*)c->M.p;
-    p.k = (const double*)c->k.p;
+    fill_motion(c, p);
     p.stats = (unsigned long long*)c->stats.p;
     if (launch_motion(c, p, rpt_for(c->max_n))) return 1;
     if (stats) {
@@ -1411,14 +1492,13 @@ int rship_opt_motion(rship_ctx* c, int32_t kd, float fd, uint64_t* stats) {
     return 0; // stays queued: the next loss call is ordered behind it on the stream
 }
 
+// kd/fd: [n_delays][n_grp]; loss/grad out: [n_delays][n_grp]
 int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_delays, double* loss, double* grad) {
     if (check_ready(c)) return 1;
     if (!n_delays) return 0;
-    const uint32_t ns = c->n_sel;
-    if (ensure(c, c->kd, (size_t)n_delays * 4) || ensure(c, c->fd, (size_t)n_delays * 4)) return 1;
-    if (ensure(c, c->part, (size_t)n_delays * ns * 16) || ensure(c, c->costs, (size_t)n_delays * 16)) return 1;
-    RS_HIP(hipMemcpyAsync(c->kd.p, kd, (size_t)n_delays * 4, hipMemcpyHostToDevice, c->stream));
-    RS_HIP(hipMemcpyAsync(c->fd.p, fd, (size_t)n_delays * 4, hipMemcpyHostToDevice, c->stream));
+    const uint32_t ns = c->n_sel, ng = c->n_grp;
+    if (upload_delays(c, kd, fd, (size_t)n_delays * ng)) return 1;
+    if (ensure(c, c->part, (size_t)n_delays * ns * 16) || ensure(c, c->costs, (size_t)n_delays * ng * 16)) return 1;
     LossParams p{};
     p.rays_a = (const f4*)c->rays_a.p;
     p.rays_b = (const f4*)c->rays_b.p;
@@ -1431,35 +1511,33 @@ int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_dela
     p.kd = (const int32_t*)c->kd.p;
     p.fd = (const float*)c->fd.p;
     p.n_delays = n_delays;
+    p.grp = ng > 1 ? (const uint32_t*)c->grp.p : nullptr;
+    p.n_grp = ng;
     p.M = (const double*)c->M.p;
     p.k = (const double*)c->k.p;
     p.part_loss = (double*)c->part.p;
     p.part_grad = p.part_loss + (size_t)n_delays * ns;
     const int rpt = rpt_for(c->max_n);
     if (grad ? launch_loss<true>(c, p, rpt) : launch_loss<false>(c, p, rpt)) return 1;
-    // rows [0, n_delays) = loss, [n_delays, 2 n_delays) = grad
+    // rows [0, n_delays) = loss, [n_delays, 2 n_delays) = grad; one sum per (row, group)
     uint32_t rows = grad ? 2 * n_delays : n_delays;
-    if (launch_reduce(c, p.part_loss, (double*)c->costs.p, rows, ns)) return 1;
-    if (ensure_pinned(c, (size_t)rows * 8)) return 1;
-    RS_HIP(hipMemcpyAsync(c->pinned, c->costs.p, (size_t)rows * 8, hipMemcpyDeviceToHost, c->stream));
+    if (launch_reduce(c, p.part_loss, (double*)c->costs.p, rows, ns, nullptr, ng > 1 ? (const uint32_t*)c->grp_off.p : nullptr, ng))
+        return 1;
+    const size_t half = (size_t)n_delays * ng * 8;
+    if (ensure_pinned(c, (size_t)rows * ng * 8)) return 1;
+    RS_HIP(hipMemcpyAsync(c->pinned, c->costs.p, (size_t)rows * ng * 8, hipMemcpyDeviceToHost, c->stream));
     if (sync_stream(c)) return 1;
-    memcpy(loss, c->pinned, (size_t)n_delays * 8);
-    if (grad) memcpy(grad, (char*)c->pinned + (size_t)n_delays * 8, (size_t)n_delays * 8);
+    memcpy(loss, c->pinned, half);
+    if (grad) memcpy(grad, (char*)c->pinned + half, half);
     return 0;
 }
 
 int rship_get_motion(rship_ctx* c, double* M, double* k, uint32_t cap, uint32_t* n) {
     if (sync_stream(c)) return 1;
-    std::vector<double> hM((size_t)c->n_frames * 3 + 3), hk((size_t)c->n_frames + 1);
-    if (c->n_frames) {
-        RS_HIP(hipMemcpy(hM.data(), c->M.p, (size_t)c->n_frames * 24, hipMemcpyDeviceToHost));
-        RS_HIP(hipMemcpy(hk.data(), c->k.p, (size_t)c->n_frames * 8, hipMemcpyDeviceToHost));
-    }
-    uint32_t cnt = 0;
-    for (uint32_t i = 0; i < c->n_sel && cnt < cap; ++i, ++cnt) {
-        uint32_t fi = c->h_sel[i];
-        M[3 * cnt] = hM[3 * fi]; M[3 * cnt + 1] = hM[3 * fi + 1]; M[3 * cnt + 2] = hM[3 * fi + 2];
-        k[cnt] = hk[fi];
+    uint32_t cnt = c->n_sel < cap ? c->n_sel : cap;
+    if (cnt) {
+        RS_HIP(hipMemcpy(M, c->M.p, (size_t)cnt * 24, hipMemcpyDeviceToHost));
+        RS_HIP(hipMemcpy(k, c->k.p, (size_t)cnt * 8, hipMemcpyDeviceToHost));
     }
     if (n) *n = cnt;
     return 0;
@@ -1468,10 +1546,9 @@ int rship_get_motion(rship_ctx* c, double* M, double* k, uint32_t cap, uint32_t*
 int rship_set_motion(rship_ctx* c, const double* M, const double* k, uint32_t n) {
     if (n != c->n_sel) return set_err(c, "set_motion: count differs from the selection");
     if (sync_stream(c)) return 1;
-    for (uint32_t i = 0; i < n; ++i) {
-        uint32_t fi = c->h_sel[i];
-        RS_HIP(hipMemcpy((double*)c->M.p + 3 * (size_t)fi, M + 3 * i, 24, hipMemcpyHostToDevice));
-        RS_HIP(hipMemcpy((double*)c->k.p + fi, k + i, 8, hipMemcpyHostToDevice));
+    if (n) {
+        RS_HIP(hipMemcpy(c->M.p, M, (size_t)n * 24, hipMemcpyHostToDevice));
+        RS_HIP(hipMemcpy(c->k.p, k, (size_t)n * 8, hipMemcpyHostToDevice));
     }
     return 0;
 }

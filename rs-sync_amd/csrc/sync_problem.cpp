@@ -135,9 +135,17 @@ class SyncProblemHip final : public ISyncProblem {
     uint32_t select(int64_t begin, int64_t end_exclusive);
     std::vector<double> sweep(const std::vector<double>& delays, uint32_t stream_base, bool panics,
                               double* frame_costs, int32_t* best_h);
-    void init_motion(double delay);
-    void opt_motion(double delay, uint64_t* stats);
+    void init_motion(const std::vector<double>& delays);
+    void opt_motion(const std::vector<double>& delays, uint64_t* stats);
     void loss(const std::vector<double>& delays, std::vector<double>& out_loss, std::vector<double>* out_grad);
+    void select_windows(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl);
+    void sync_windows(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl,
+                      const std::vector<double>& initial, double search_center, double search_radius,
+                      std::vector<double>& costs, std::vector<double>& delays_out);
+    void presync_windows(double initial_delay, const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_excl,
+                         double search_step, double search_radius, std::vector<double>& costs,
+                         std::vector<double>& delays_out);
+    std::vector<std::vector<double>> traces; // per window of the last sync_windows call
     void reduce(double* buf, size_t n) {
         if (reduce_fn) reduce_fn(buf, n, reduce_user);
     }
@@ -161,6 +169,7 @@ class SyncProblemHip final : public ISyncProblem {
     bool spline_dirty_ = true, frames_dirty_ = true;
     std::vector<int64_t> table_ids_;
     std::vector<uint32_t> sel_;
+    size_t n_windows_ = 1;
 };
 
 SyncProblemHip::SyncProblemHip() {
@@ -358,6 +367,7 @@ uint32_t SyncProblemHip::select(int64_t begin, int64_t end_exclusive) {
     for (uint32_t i : sel_)
         if (frames_.at(table_ids_[i]).ts_a.size() < 2)
             panic("sync: frame " + std::to_string(table_ids_[i]) + " has fewer than 2 tracks");
+    n_windows_ = 1;
     hip_check(rship_select_frames(dev_, sel_.data(), (uint32_t)sel_.size()), "select frames");
     return (uint32_t)sel_.size();
 }
@@ -449,33 +459,51 @@ void SyncProblemHip::DebugPreSync(double initial_delay, int64_t frame_begin, int
     }
 }
 
-void SyncProblemHip::init_motion(double delay) {
+// per-window delays -> device representation; NaN delay = window switched off
+static void split_all(const std::vector<double>& delays, double fs, std::vector<int32_t>& kd, std::vector<float>& fd) {
+    kd.resize(delays.size());
+    fd.resize(delays.size());
+    for (size_t i = 0; i < delays.size(); ++i) {
+        if (delays[i] != delays[i]) {
+            kd[i] = 0;
+            fd[i] = std::numeric_limits<float>::quiet_NaN();
+        } else {
+            DelaySplit s = split_delay(delays[i], fs);
+            kd[i] = s.kd;
+            fd[i] = s.fd;
+        }
+    }
+}
+
+void SyncProblemHip::init_motion(const std::vector<double>& delays) {
     if (sel_.empty()) return;
-    DelaySplit s = split_delay(delay, fs_);
-    hip_check(rship_init_motion(dev_, s.kd, s.fd, 200 /* core_private.cpp:127 */, kStreamSyncInit + sync_calls, seed),
+    std::vector<int32_t> kd;
+    std::vector<float> fd;
+    split_all(delays, fs_, kd, fd);
+    hip_check(rship_init_motion(dev_, kd.data(), fd.data(), 200 /* core_private.cpp:127 */, kStreamSyncInit + sync_calls, seed),
               "init motion");
 }
 
-void SyncProblemHip::opt_motion(double delay, uint64_t* stats) {
+void SyncProblemHip::opt_motion(const std::vector<double>& delays, uint64_t* stats) {
     if (sel_.empty()) return;
-    DelaySplit s = split_delay(delay, fs_);
-    hip_check(rship_opt_motion(dev_, s.kd, s.fd, stats), "opt motion");
+    std::vector<int32_t> kd;
+    std::vector<float> fd;
+    split_all(delays, fs_, kd, fd);
+    hip_check(rship_opt_motion(dev_, kd.data(), fd.data(), stats), "opt motion");
 }
 
-// sum over the selection (and over ranks) of FrameState::Loss at each delay
+// per window: sum over its slots (and over ranks) of FrameState::Loss; delays is
+// [n_delays][n_windows] row-major (NaN = skip that window), outputs likewise
 void SyncProblemHip::loss(const std::vector<double>& delays, std::vector<double>& out_loss,
                           std::vector<double>* out_grad) {
     const size_t n = delays.size();
     std::vector<double> buf(2 * n, 0.0);
     if (!sel_.empty() && n) {
-        std::vector<int32_t> kd(n);
-        std::vector<float> fd(n);
-        for (size_t i = 0; i < n; ++i) {
-            DelaySplit s = split_delay(delays[i], fs_);
-            kd[i] = s.kd;
-            fd[i] = s.fd;
-        }
-        hip_check(rship_loss(dev_, kd.data(), fd.data(), (uint32_t)n, buf.data(), out_grad ? buf.data() + n : nullptr),
+        std::vector<int32_t> kd;
+        std::vector<float> fd;
+        split_all(delays, fs_, kd, fd);
+        hip_check(rship_loss(dev_, kd.data(), fd.data(), (uint32_t)(n / n_windows_), buf.data(),
+                             out_grad ? buf.data() + n : nullptr),
                   "loss");
     }
     reduce(buf.data(), out_grad ? 2 * n : n);
@@ -483,65 +511,189 @@ void SyncProblemHip::loss(const std::vector<double>& delays, std::vector<double>
     if (out_grad) out_grad->assign(buf.begin() + n, buf.end());
 }
 
-// core_private.cpp:211-334.  Differences from the reference's schedule, none of which
-// changes a value the reference would compute differently:
+// selection for batched Sync: window w = frames with begin[w] <= id <= end[w] (end inclusive,
+// core_private.cpp:219); a frame covered by several windows gets one slot in each
+void SyncProblemHip::select_windows(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl) {
+    sel_.clear();
+    std::vector<uint32_t> off(begins.size() + 1, 0);
+    for (size_t w = 0; w < begins.size(); ++w) {
+        for (uint32_t i = 0; i < table_ids_.size(); ++i)
+            if (table_ids_[i] >= begins[w] && table_ids_[i] <= ends_incl[w]) sel_.push_back(i);
+        off[w + 1] = (uint32_t)sel_.size();
+    }
+    for (uint32_t i : sel_)
+        if (frames_.at(table_ids_[i]).ts_a.size() < 2)
+            panic("sync: frame " + std::to_string(table_ids_[i]) + " has fewer than 2 tracks");
+    n_windows_ = std::max<size_t>(1, begins.size());
+    hip_check(rship_select_slots(dev_, sel_.data(), (uint32_t)sel_.size(), off.data(), (uint32_t)n_windows_), "select slots");
+}
+
+// core_private.cpp:211-334 for W independent windows advanced in lock-step (W = 1 is
+// ISyncProblem::Sync).  Every window keeps its own delay, momentum and convergence counter and
+// stops on its own; what is batched is the device work: one motion-optimisation launch, one
+// loss+gradient launch and one 10-trial line-search launch per outer iteration for all windows.
+// Window w is bit-for-bit what the w-th of W consecutive Sync calls would return.
+// Differences from the reference's schedule, none of which changes a value the reference
+// would compute differently:
 //  * d(loss)/d(delay) is the analytic derivative, not the +-1e-6 s central difference
 //    (:96-97,112); they agree to ~1e-9 relative (tests/test_oracle_math.py);
 //  * the <= 10 backtracking trials (backtrack.cpp:7-11) are evaluated in one batched
 //    launch and the first that satisfies the Armijo test is taken, which is what the
 //    sequential loop returns;
 //  * P is computed once per motion optimisation, not three times per evaluation (:94-97).
-std::pair<double, double> SyncProblemHip::Sync(double initial_delay, int64_t frame_begin, int64_t frame_end,
-                                               double search_center, double search_radius) {
+void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl,
+                                  const std::vector<double>& initial, double search_center, double search_radius,
+                                  std::vector<double>& costs, std::vector<double>& delays_out) {
     ensure_device();
-    select(frame_begin, frame_end == std::numeric_limits<int64_t>::max() ? frame_end : frame_end + 1); // :219 inclusive
-    double d = initial_delay;
-    init_motion(d); // :218-223
-    ++sync_calls;
-    trace.clear();
+    const size_t W = begins.size();
+    select_windows(begins, ends_incl);
+    std::vector<double> d(initial);
+    init_motion(d); // :218-223, window w samples with stream SYNC_INIT + sync_calls + w
+    sync_calls += (uint32_t)W;
+    traces.assign(W, {});
 
     const double c_armijo = 2e-4, decay = .1, t0 = 1e-3; // :226
     const int max_bt = 10;
     const double delay_b = .3; // :260
-    double delay_v = 0;        // :261
-    int converge_counter = 0;
-    std::vector<double> l1, g1, lt, trial(max_bt);
-    for (int it = 0; it < max_outer; ++it) { // :309
-        opt_motion(d, nullptr);              // :311
+    const double kOff = std::numeric_limits<double>::quiet_NaN();
+    std::vector<double> delay_v(W, 0.0); // :261
+    std::vector<int> converge_counter(W, 0);
+    std::vector<char> active(W, 1);
+    costs.assign(W, 0.0);
+    std::vector<double> l1, g1, lt, cur(W), x0(W), trial((size_t)max_bt * W), fin(W);
+    size_t n_active = W;
+    for (int it = 0; it < max_outer && n_active; ++it) { // :309
+        for (size_t w = 0; w < W; ++w) cur[w] = active[w] ? d[w] : kOff;
+        opt_motion(cur, nullptr); // :311
         // do_opt_delay (:298-305) -> Backtrack::Step (backtrack.cpp:3-13)
-        const double x0 = d - delay_b * delay_v;
-        loss({x0}, l1, &g1);
-        const double v = l1[0], p = g1[0];
-        const double m = p * p;
-        double t = t0;
-        std::vector<double> ts(max_bt);
-        for (int i = 0; i < max_bt; ++i) {
-            ts[i] = t;
-            trial[i] = x0 - t * p;
-            t *= decay;
+        for (size_t w = 0; w < W; ++w) x0[w] = active[w] ? d[w] - delay_b * delay_v[w] : kOff;
+        loss(x0, l1, &g1);
+        double ts[16];
+        {
+            double t = t0;
+            for (int i = 0; i < max_bt; ++i) { ts[i] = t; t *= decay; }
+            ts[max_bt] = t;
         }
+        for (int i = 0; i < max_bt; ++i)
+            for (size_t w = 0; w < W; ++w) trial[(size_t)i * W + w] = active[w] ? x0[w] - ts[i] * g1[w] : kOff;
         loss(trial, lt, nullptr);
-        int trials = max_bt;
-        for (int i = 0; i < max_bt; ++i) {
-            if (v - lt[i] >= ts[i] * c_armijo * m) {
-                t = ts[i];
-                trials = i + 1;
-                break;
+        bool any_finished = false;
+        for (size_t w = 0; w < W; ++w) {
+            fin[w] = kOff;
+            if (!active[w]) continue;
+            const double v = l1[w], p = g1[w], m = p * p;
+            double t = ts[max_bt]; // never satisfied: t0 * decay^max_bt, untested (backtrack.cpp:11-12)
+            int trials = max_bt;
+            for (int i = 0; i < max_bt; ++i) {
+                if (v - lt[(size_t)i * W + w] >= ts[i] * c_armijo * m) {
+                    t = ts[i];
+                    trials = i + 1;
+                    break;
+                }
+            }
+            const double step = -t * p;
+            delay_v[w] = delay_b * delay_v[w] + step; // :301
+            d[w] += delay_v[w];                       // :302
+            const double step_size = std::fabs(step);
+            const double row[6] = {d[w], step, v, p, t, (double)trials};
+            traces[w].insert(traces[w].end(), row, row + 6);
+            if (step_size < 1e-4) converge_counter[w]++; else converge_counter[w] = 0; // :316-320
+            bool stop = converge_counter[w] > 5;                                       // :322-324
+            if (!stop && std::fabs(d[w] - search_center) > search_radius) stop = true; // :326-328
+            if (!stop && verbose && W == 1) std::cerr << d[w] << " " << step_size << std::endl; // :330
+            if (stop || it + 1 == max_outer) {
+                active[w] = 0;
+                --n_active;
+                fin[w] = d[w];
+                any_finished = true;
             }
         }
-        const double step = -t * p;
-        delay_v = delay_b * delay_v + step; // :301
-        d += delay_v;                       // :302
-        const double step_size = std::fabs(step);
-        const double row[6] = {d, step, v, p, t, (double)trials};
-        trace.insert(trace.end(), row, row + 6);
-        if (step_size < 1e-4) converge_counter++; else converge_counter = 0; // :316-320
-        if (converge_counter > 5) break;                                      // :322-324
-        if (std::fabs(d - search_center) > search_radius) break;              // :326-328
-        if (verbose) std::cerr << d << " " << step_size << std::endl;         // :330
+        if (any_finished) { // :333 for the windows that just left their loop
+            loss(fin, l1, nullptr);
+            for (size_t w = 0; w < W; ++w)
+                if (fin[w] == fin[w]) costs[w] = l1[w];
+        }
     }
-    loss({d}, l1, nullptr); // :333
-    return {l1[0], d};
+    if (max_outer <= 0) { // no iteration at all: the reference still returns the loss at the start
+        loss(d, l1, nullptr);
+        costs = l1;
+    }
+    delays_out = d;
+}
+
+std::pair<double, double> SyncProblemHip::Sync(double initial_delay, int64_t frame_begin, int64_t frame_end,
+                                               double search_center, double search_radius) {
+    std::vector<double> c, d;
+    sync_windows({frame_begin}, {frame_end}, {initial_delay}, search_center, search_radius, c, d);
+    trace = traces[0];
+    return {c[0], d[0]};
+}
+
+// PreSync for W windows that share the candidate list (same initial delay, step and radius --
+// the reference driver's pattern, core_testcode.cpp:303-311): the LMedS kernel runs once over the
+// union of the windows' frames, then each window sums its own frames.  Window w equals a
+// PreSync call on [begin[w], end[w]).
+void SyncProblemHip::presync_windows(double initial_delay, const std::vector<int64_t>& begins,
+                                     const std::vector<int64_t>& ends_excl, double search_step, double search_radius,
+                                     std::vector<double>& costs, std::vector<double>& delays_out) {
+    ensure_device();
+    const size_t W = begins.size();
+    int64_t lo = std::numeric_limits<int64_t>::max(), hi = std::numeric_limits<int64_t>::min();
+    for (size_t w = 0; w < W; ++w) { lo = std::min(lo, begins[w]); hi = std::max(hi, ends_excl[w]); }
+    select(lo, hi);
+    // keep only frames some window covers; build the per-window slot lists
+    std::vector<uint32_t> keep, slot_of(table_ids_.size(), 0xffffffffu);
+    for (uint32_t i : sel_) {
+        bool used = false;
+        for (size_t w = 0; w < W && !used; ++w) used = table_ids_[i] >= begins[w] && table_ids_[i] < ends_excl[w];
+        if (used) { slot_of[i] = (uint32_t)keep.size(); keep.push_back(i); }
+    }
+    sel_ = keep;
+    n_windows_ = 1;
+    hip_check(rship_select_frames(dev_, sel_.data(), (uint32_t)sel_.size()), "select frames");
+    std::vector<uint32_t> seg_idx, seg_off(W + 1, 0);
+    for (size_t w = 0; w < W; ++w) {
+        for (uint32_t i : sel_)
+            if (table_ids_[i] >= begins[w] && table_ids_[i] < ends_excl[w]) seg_idx.push_back(slot_of[i]);
+        seg_off[w + 1] = (uint32_t)seg_idx.size();
+    }
+    std::vector<double> delays; // :69-70
+    for (double delay = initial_delay - search_radius; delay < initial_delay + search_radius; delay += search_step) {
+        delays.push_back(delay);
+        if (delays.size() > 50000000) panic("pre-sync: more than 5e7 candidate delays");
+    }
+    if (delays.empty()) panic("pre-sync: empty candidate list");
+    const size_t n = delays.size();
+    std::vector<double> cw(n * W + 4, 0.0);
+    uint32_t flags = 0;
+    if (!sel_.empty()) {
+        std::vector<int32_t> kd;
+        std::vector<float> fd;
+        split_all(delays, fs_, kd, fd);
+        const size_t slice = std::max<size_t>(64, (size_t)(256u << 20) / (8 * sel_.size())); // as in sweep()
+        for (size_t b = 0; b < n; b += slice) {
+            uint32_t fl = 0;
+            hip_check(rship_presync_window_costs(dev_, kd.data() + b, fd.data() + b, (uint32_t)std::min(slice, n - b), 20,
+                                                 (uint32_t)b, seed, seg_idx.data(), seg_off.data(), (uint32_t)W,
+                                                 cw.data() + b * W, &fl, nullptr, nullptr),
+                      "presync window costs");
+            flags |= fl;
+        }
+    }
+    for (int b = 0; b < 4; ++b) cw[n * W + b] = (double)((flags >> b) & 1);
+    reduce(cw.data(), cw.size());
+    uint32_t all = 0;
+    for (int b = 0; b < 4; ++b) all |= cw[n * W + b] > 0 ? (1u << b) : 0u;
+    if (const char* msg = presync_panic(all)) panic(msg);
+    costs.assign(W, 0.0);
+    delays_out.assign(W, 0.0);
+    for (size_t w = 0; w < W; ++w) {
+        size_t best = 0; // *std::min_element over pair(cost, delay) (:89)
+        for (size_t i = 1; i < n; ++i)
+            if (std::make_pair(cw[i * W + w], delays[i]) < std::make_pair(cw[best * W + w], delays[best])) best = i;
+        costs[w] = cw[best * W + w];
+        delays_out[w] = delays[best];
+    }
 }
 
 } // namespace
@@ -702,7 +854,7 @@ int rssync_ext_init_motion(rssync_problem* p, double delay, int64_t frame_begin,
         SyncProblemHip* s = p->impl;
         s->ensure_device();
         s->select(frame_begin, frame_end == std::numeric_limits<int64_t>::max() ? frame_end : frame_end + 1);
-        s->init_motion(delay);
+        s->init_motion({delay});
         s->sync_calls++;
         uint32_t n = 0;
         if (rship_get_motion(s->dev(), M, k, (uint32_t)cap, &n)) panic(std::string("hip: get motion: ") + rship_last_error(s->dev()));
@@ -715,7 +867,7 @@ int rssync_ext_opt_motion(rssync_problem* p, double delay, double* M, double* k,
     return guarded([&] {
         SyncProblemHip* s = p->impl;
         uint64_t st[2] = {0, 0};
-        s->opt_motion(delay, st);
+        s->opt_motion({delay}, st);
         uint32_t n = 0;
         if (rship_get_motion(s->dev(), M, k, (uint32_t)cap, &n)) panic(std::string("hip: get motion: ") + rship_last_error(s->dev()));
         if (n_frames) *n_frames = (int)n;
@@ -737,6 +889,47 @@ int rssync_ext_loss(rssync_problem* p, const double* delays, int n, double* loss
         p->impl->loss(d, l, grad ? &g : nullptr);
         std::copy(l.begin(), l.end(), loss);
         if (grad) std::copy(g.begin(), g.end(), grad);
+    });
+}
+
+int rssync_ext_pre_sync_windows(rssync_problem* p, double initial_delay, const int64_t* frame_begins,
+                                const int64_t* frame_ends, int n_windows, double search_step, double search_radius,
+                                double* costs, double* delays) {
+    return guarded([&] {
+        if (n_windows <= 0) return;
+        std::vector<double> c, d;
+        p->impl->presync_windows(initial_delay, std::vector<int64_t>(frame_begins, frame_begins + n_windows),
+                                 std::vector<int64_t>(frame_ends, frame_ends + n_windows), search_step, search_radius, c,
+                                 d);
+        std::copy(c.begin(), c.end(), costs);
+        std::copy(d.begin(), d.end(), delays);
+    });
+}
+
+int rssync_ext_sync_windows(rssync_problem* p, const double* initial_delays, const int64_t* frame_begins,
+                            const int64_t* frame_ends, int n_windows, double search_center, double search_radius,
+                            double* costs, double* delays) {
+    return guarded([&] {
+        if (n_windows <= 0) return;
+        std::vector<double> c, d;
+        p->impl->sync_windows(std::vector<int64_t>(frame_begins, frame_begins + n_windows),
+                              std::vector<int64_t>(frame_ends, frame_ends + n_windows),
+                              std::vector<double>(initial_delays, initial_delays + n_windows), search_center,
+                              search_radius, c, d);
+        p->impl->trace = p->impl->traces[0];
+        std::copy(c.begin(), c.end(), costs);
+        std::copy(d.begin(), d.end(), delays);
+    });
+}
+
+int rssync_ext_window_trace(rssync_problem* p, int window, double* trace, int cap_rows, int* n_rows) {
+    return guarded([&] {
+        if (window < 0 || (size_t)window >= p->impl->traces.size()) throw PanicError("window_trace: no such window");
+        const std::vector<double>& t = p->impl->traces[(size_t)window];
+        int rows = (int)(t.size() / 6);
+        if (n_rows) *n_rows = rows;
+        rows = std::min(rows, cap_rows);
+        if (trace) std::copy(t.begin(), t.begin() + (size_t)rows * 6, trace);
     });
 }
 

@@ -59,6 +59,10 @@ SIGNATURES = {
     "rssync_ext_opt_motion": (C.c_int, [C.c_void_p, C.c_double, _PD, _PD, C.c_int, C.POINTER(C.c_int), _PU64, _PU64]),
     "rssync_ext_set_motion": (C.c_int, [C.c_void_p, _PD, _PD, C.c_int]),
     "rssync_ext_loss": (C.c_int, [C.c_void_p, _PD, C.c_int, _PD, _PD]),
+    "rssync_ext_pre_sync_windows": (C.c_int, [C.c_void_p, C.c_double, _PI64, _PI64, C.c_int, C.c_double, C.c_double,
+                                              _PD, _PD]),
+    "rssync_ext_sync_windows": (C.c_int, [C.c_void_p, _PD, _PI64, _PI64, C.c_int, C.c_double, C.c_double, _PD, _PD]),
+    "rssync_ext_window_trace": (C.c_int, [C.c_void_p, C.c_int, _PD, C.c_int, C.POINTER(C.c_int)]),
     "rssync_ext_sync_trace": (C.c_int, [C.c_void_p, _PD, C.c_int, C.POINTER(C.c_int)]),
     "rssync_ext_device_context": (C.c_void_p, [C.c_void_p]),
     "rssync_ext_profile": (C.c_int, [C.c_void_p, C.c_int]),
@@ -268,6 +272,36 @@ class SyncProblem:
         g = np.zeros(d.shape[0]) if grad else None
         self._check(self._lib.rssync_ext_loss(self._h, _p(d), d.shape[0], _p(out), _p(g) if grad else None))
         return (out, g) if grad else out
+
+    def pre_sync_windows(self, initial_delay, frame_begins, frame_ends, search_step, search_radius):
+        """PreSync on W windows [begin[w], end[w]) in one sweep -> (costs[W], delays[W])."""
+        b = np.ascontiguousarray(frame_begins, np.int64)
+        e = np.ascontiguousarray(frame_ends, np.int64)
+        if b.shape != e.shape or b.ndim != 1:
+            raise ValueError("frame_begins / frame_ends must be 1-D and of equal length")
+        costs, delays = np.zeros(b.size), np.zeros(b.size)
+        self._check(self._lib.rssync_ext_pre_sync_windows(self._h, float(initial_delay), _p(b, _PI64), _p(e, _PI64), b.size,
+                                                          float(search_step), float(search_radius), _p(costs),
+                                                          _p(delays)))
+        return costs, delays
+
+    def sync_windows(self, initial_delays, frame_begins, frame_ends, search_center, search_radius):
+        """Sync on W windows [begin[w], end[w]] advanced in lock-step -> (costs[W], delays[W])."""
+        b = np.ascontiguousarray(frame_begins, np.int64)
+        e = np.ascontiguousarray(frame_ends, np.int64)
+        d0 = np.ascontiguousarray(np.broadcast_to(np.asarray(initial_delays, np.float64), b.shape))
+        if b.shape != e.shape or b.ndim != 1:
+            raise ValueError("frame_begins / frame_ends must be 1-D and of equal length")
+        costs, delays = np.zeros(b.size), np.zeros(b.size)
+        self._check(self._lib.rssync_ext_sync_windows(self._h, _p(d0), _p(b, _PI64), _p(e, _PI64), b.size,
+                                                      float(search_center), float(search_radius), _p(costs),
+                                                      _p(delays)))
+        return costs, delays
+
+    def window_trace(self, window, cap=512):
+        t, n = np.zeros((cap, 6)), C.c_int()
+        self._check(self._lib.rssync_ext_window_trace(self._h, int(window), _p(t), cap, C.byref(n)))
+        return t[:min(n.value, cap)].copy()
 
     def sync_trace(self, cap=512):
         t, n = np.zeros((cap, 6)), C.c_int()

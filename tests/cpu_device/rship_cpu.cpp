@@ -26,8 +26,8 @@ struct rship_ctx {
     double fs = 0;
     std::vector<f4> rays_a, rays_b;
     std::vector<rship_frame> frames;
-    std::vector<uint32_t> sel;
-    std::vector<double> M, k; // per table frame
+    std::vector<uint32_t> sel, grp, grp_off; // slots, slot -> window, window offsets
+    std::vector<double> M, k;                // per slot
 };
 
 namespace {
@@ -126,21 +126,36 @@ int rship_upload_frames(rship_ctx* c, const float* a4, const float* b4, uint64_t
         std::memcpy(c->rays_b.data(), b4, total * 16);
     }
     c->frames.assign(table, table + nf);
-    c->M.assign((size_t)nf * 3, 0.0);
-    c->k.assign(nf, 0.0);
     c->sel.clear();
+    c->grp.clear();
+    c->grp_off.assign(2, 0);
     return 0;
 }
 
-int rship_select_frames(rship_ctx* c, const uint32_t* idx, uint32_t n) {
+int rship_select_slots(rship_ctx* c, const uint32_t* idx, uint32_t n, const uint32_t* grp_off, uint32_t n_grp) {
+    if (n_grp < 1) n_grp = 1;
     c->sel.assign(idx, idx + n);
+    c->grp.assign(n, 0);
+    c->grp_off.assign(n_grp + 1, 0);
+    if (grp_off) {
+        c->grp_off.assign(grp_off, grp_off + n_grp + 1);
+        for (uint32_t w = 0; w < n_grp; ++w)
+            for (uint32_t j = grp_off[w]; j < grp_off[w + 1]; ++j) c->grp[j] = w;
+    } else {
+        c->grp_off[n_grp] = n;
+    }
+    c->M.assign((size_t)n * 3, 0.0);
+    c->k.assign(n, 0.0);
     return 0;
 }
+int rship_select_frames(rship_ctx* c, const uint32_t* idx, uint32_t n) { return rship_select_slots(c, idx, n, nullptr, 1); }
 
-int rship_presync_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand, uint32_t n_hyp,
-                        uint32_t stream_base, uint64_t seed, double* costs, uint32_t* flags, double* frame_costs,
-                        int32_t* best_h) {
+int rship_presync_window_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand, uint32_t n_hyp,
+                               uint32_t stream_base, uint64_t seed, const uint32_t* seg_idx, const uint32_t* seg_off,
+                               uint32_t n_win, double* costs, uint32_t* flags, double* frame_costs, int32_t* best_h) {
     uint32_t fl = 0;
+    if (n_win < 1) n_win = 1;
+    std::vector<double> fc(c->sel.size());
     for (uint32_t ci = 0; ci < n_cand; ++ci) {
         double total = 0;
         for (size_t s = 0; s < c->sel.size(); ++s) {
@@ -168,40 +183,61 @@ int rship_presync_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32
             }
             double cost = std::sqrt(acc);
             total += cost;
+            fc[s] = cost;
             if (frame_costs) frame_costs[(size_t)ci * c->sel.size() + s] = cost;
             if (best_h) best_h[(size_t)ci * c->sel.size() + s] = bh;
         }
-        costs[ci] = total;
+        if (!seg_off) {
+            costs[ci] = total;
+        } else {
+            for (uint32_t w = 0; w < n_win; ++w) {
+                double t = 0;
+                for (uint32_t j = seg_off[w]; j < seg_off[w + 1]; ++j) t += fc[seg_idx ? seg_idx[j] : j];
+                costs[(size_t)ci * n_win + w] = t;
+            }
+        }
     }
     if (flags) *flags = fl;
     return 0;
 }
 
-int rship_init_motion(rship_ctx* c, int32_t kd, float fd, uint32_t n_hyp, uint32_t stream, uint64_t seed) {
-    for (uint32_t fi : c->sel) {
+int rship_presync_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand, uint32_t n_hyp,
+                        uint32_t stream_base, uint64_t seed, double* costs, uint32_t* flags, double* frame_costs,
+                        int32_t* best_h) {
+    return rship_presync_window_costs(c, kd, fd, n_cand, n_hyp, stream_base, seed, nullptr, nullptr, 1, costs, flags,
+                                      frame_costs, best_h);
+}
+
+int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_hyp, uint32_t stream, uint64_t seed) {
+    for (size_t s = 0; s < c->sel.size(); ++s) {
+        const uint32_t fi = c->sel[s], g = c->grp[s];
         const rship_frame& fr = c->frames[fi];
-        Rows t = unit_rows(c, fr, kd, fd);
+        Rows t = unit_rows(c, fr, kd[g], fd[g]);
         f3 Mv;
-        lmeds(t, n_hyp, seed, fr.id, stream, Mv);
+        lmeds(t, n_hyp, seed, fr.id, stream + g, Mv);
         double ss = 0;
         for (uint32_t i = 0; i < fr.n_rays; ++i) {
             float pm = t.nrm[i] * rs::dot(t.n[i], Mv);
             ss += (double)pm * pm;
         }
-        c->M[3 * fi] = Mv.x; c->M[3 * fi + 1] = Mv.y; c->M[3 * fi + 2] = Mv.z;
-        c->k[fi] = clampk(100.0f / std::sqrt((float)ss));
+        c->M[3 * s] = Mv.x; c->M[3 * s + 1] = Mv.y; c->M[3 * s + 2] = Mv.z;
+        c->k[s] = clampk(100.0f / std::sqrt((float)ss));
     }
     return 0;
 }
 
 // the kernel's L-BFGS (rssync_kernels.hip: opt_motion_kernel), sequential
-int rship_opt_motion(rship_ctx* c, int32_t kd, float fd, uint64_t* stats) {
+int rship_opt_motion(rship_ctx* c, const int32_t* kdv, const float* fdv, uint64_t* stats) {
     uint64_t tot_it = 0, tot_ev = 0;
-    for (uint32_t fi : c->sel) {
+    for (size_t sl = 0; sl < c->sel.size(); ++sl) {
+        const uint32_t fi = c->sel[sl], grp = c->grp[sl];
+        const int32_t kd = kdv[grp];
+        const float fd = fdv[grp];
+        if (fd != fd) continue; // window switched off
         const rship_frame& fr = c->frames[fi];
         std::vector<f3> P(fr.n_rays);
         for (uint32_t i = 0; i < fr.n_rays; ++i) row(c, fr, i, kd, fd, P[i], nullptr);
-        const double k2 = c->k[fi] * c->k[fi];
+        const double k2 = c->k[sl] * c->k[sl];
         int evals = 0;
         auto ev = [&](const double x[3], double g[3]) { // fp64 on fp32 rows, like the kernel
             ++evals;
@@ -223,7 +259,7 @@ int rship_opt_motion(rship_ctx* c, int32_t kd, float fd, uint64_t* stats) {
         auto dot3 = [](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
         constexpr int NB = 10;
         double S[NB][3], Y[NB][3], rho[NB], alpha[NB];
-        double x[3] = {c->M[3 * fi], c->M[3 * fi + 1], c->M[3 * fi + 2]}, g[3], oldx[3], oldg[3], dir[3];
+        double x[3] = {c->M[3 * sl], c->M[3 * sl + 1], c->M[3 * sl + 2]}, g[3], oldx[3], oldg[3], dir[3];
         double fval = ev(x, g);
         int it = 0;
         for (; it != 200; ++it) {
@@ -283,7 +319,7 @@ int rship_opt_motion(rship_ctx* c, int32_t kd, float fd, uint64_t* stats) {
             int op = it % NB;
             for (int q = 0; q < 3; ++q) { S[op][q] = x[q] - oldx[q]; Y[op][q] = g[q] - oldg[q]; }
         }
-        c->M[3 * fi] = x[0]; c->M[3 * fi + 1] = x[1]; c->M[3 * fi + 2] = x[2];
+        c->M[3 * sl] = x[0]; c->M[3 * sl + 1] = x[1]; c->M[3 * sl + 2] = x[2];
         tot_it += (uint64_t)it;
         tot_ev += (uint64_t)evals;
     }
@@ -291,39 +327,43 @@ int rship_opt_motion(rship_ctx* c, int32_t kd, float fd, uint64_t* stats) {
     return 0;
 }
 
-int rship_opt_motion_detail(rship_ctx* c, int32_t, float, uint32_t*, uint32_t) { return fail(c, "opt_motion_detail: device only"); }
+int rship_opt_motion_detail(rship_ctx* c, const int32_t*, const float*, uint32_t*, uint32_t) { return fail(c, "opt_motion_detail: device only"); }
 
 int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_delays, double* loss, double* grad) {
+    const size_t ng = c->grp_off.size() - 1;
     for (uint32_t b = 0; b < n_delays; ++b) {
-        double L = 0, G = 0;
-        for (uint32_t fi : c->sel) {
-            const rship_frame& fr = c->frames[fi];
-            const double Mx = c->M[3 * fi], My = c->M[3 * fi + 1], Mz = c->M[3 * fi + 2], kk = c->k[fi];
-            const f3 Mv{(float)Mx, (float)My, (float)Mz};
-            const float inv_s = (float)(kk * kk / (Mx * Mx + My * My + Mz * Mz));
-            double Lf = 0, Gf = 0;
-            for (uint32_t i = 0; i < fr.n_rays; ++i) {
-                f3 P, dP;
-                row(c, fr, i, kd[b], fd[b], P, grad ? &dP : nullptr);
-                float pm = rs::dot(P, Mv), u = pm * pm * inv_s;
-                Lf += rs::log1p_pos(u);
-                if (grad) Gf += (1.0f / (1.f + u)) * 2.f * pm * inv_s * rs::dot(dP, Mv);
+        for (size_t w = 0; w < ng; ++w) {
+            double L = 0, G = 0;
+            const int32_t kdw = kd[b * ng + w];
+            const float fdw = fd[b * ng + w];
+            for (uint32_t sl = c->grp_off[w]; fdw == fdw && sl < c->grp_off[w + 1]; ++sl) {
+                const rship_frame& fr = c->frames[c->sel[sl]];
+                const double Mx = c->M[3 * sl], My = c->M[3 * sl + 1], Mz = c->M[3 * sl + 2], kk = c->k[sl];
+                const f3 Mv{(float)Mx, (float)My, (float)Mz};
+                const float inv_s = (float)(kk * kk / (Mx * Mx + My * My + Mz * Mz));
+                double Lf = 0, Gf = 0;
+                for (uint32_t i = 0; i < fr.n_rays; ++i) {
+                    f3 P, dP;
+                    row(c, fr, i, kdw, fdw, P, grad ? &dP : nullptr);
+                    float pm = rs::dot(P, Mv), u = pm * pm * inv_s;
+                    Lf += rs::log1p_pos(u);
+                    if (grad) Gf += (1.0f / (1.f + u)) * 2.f * pm * inv_s * rs::dot(dP, Mv);
+                }
+                L += Lf;
+                G += Gf * (double)(float)c->fs;
             }
-            L += Lf;
-            G += Gf * (double)(float)c->fs;
+            loss[b * ng + w] = L;
+            if (grad) grad[b * ng + w] = G;
         }
-        loss[b] = L;
-        if (grad) grad[b] = G;
     }
     return 0;
 }
 
 int rship_get_motion(rship_ctx* c, double* M, double* k, uint32_t cap, uint32_t* n) {
-    uint32_t cnt = 0;
-    for (size_t i = 0; i < c->sel.size() && cnt < cap; ++i, ++cnt) {
-        uint32_t fi = c->sel[i];
-        M[3 * cnt] = c->M[3 * fi]; M[3 * cnt + 1] = c->M[3 * fi + 1]; M[3 * cnt + 2] = c->M[3 * fi + 2];
-        k[cnt] = c->k[fi];
+    uint32_t cnt = (uint32_t)std::min<size_t>(c->sel.size(), cap);
+    for (uint32_t i = 0; i < cnt; ++i) {
+        M[3 * i] = c->M[3 * i]; M[3 * i + 1] = c->M[3 * i + 1]; M[3 * i + 2] = c->M[3 * i + 2];
+        k[i] = c->k[i];
     }
     if (n) *n = cnt;
     return 0;
@@ -331,11 +371,8 @@ int rship_get_motion(rship_ctx* c, double* M, double* k, uint32_t cap, uint32_t*
 
 int rship_set_motion(rship_ctx* c, const double* M, const double* k, uint32_t n) {
     if (n != c->sel.size()) return fail(c, "set_motion: count differs from the selection");
-    for (uint32_t i = 0; i < n; ++i) {
-        uint32_t fi = c->sel[i];
-        c->M[3 * fi] = M[3 * i]; c->M[3 * fi + 1] = M[3 * i + 1]; c->M[3 * fi + 2] = M[3 * i + 2];
-        c->k[fi] = k[i];
-    }
+    c->M.assign(M, M + 3 * (size_t)n);
+    c->k.assign(k, k + n);
     return 0;
 }
 

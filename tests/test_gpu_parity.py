@@ -502,3 +502,31 @@ def test_cxx_driver_through_the_vtable(tmp_path, small_case):
         want.append((float(pos), 1000 * d))
     assert len(got) == len(want) >= 2
     np.testing.assert_allclose(np.array(got), np.array(want), rtol=0, atol=1e-6)
+
+
+def test_batched_windows_equal_sequential_calls(small_case):
+    """the driver's window loop (core_testcode.cpp:303-316) as one batched call.
+    Window w of pre_sync_windows / sync_windows must be what PreSync / the w-th consecutive Sync
+    on that window returns: the same kernels run on the same rows with the same sampler stream,
+    so the comparison is exact (costs: same summation order)."""
+    import rssync_amd
+    from conftest import fill
+    F = small_case["F"]
+    wins = [(0, F // 2 - 1), (F // 4, 3 * F // 4 - 1), (F // 2, F - 1), (3, 9), (0, F - 1)]
+    b = [w[0] for w in wins]
+    e = [w[1] for w in wins]
+    d0 = [0.036, 0.030, 0.040, 0.036, 0.025]
+    seq = fill(rssync_amd.SyncProblem(seed=SEED, max_outer_iters=30), small_case)
+    bat = fill(rssync_amd.SyncProblem(seed=SEED, max_outer_iters=30), small_case)
+    pc, pd = bat.pre_sync_windows(0.03, b, [x + 1 for x in e], 0.002, 0.05)
+    for w in range(len(wins)):
+        c, d = seq.PreSync(0.03, b[w], e[w] + 1, 0.002, 0.05)
+        assert pd[w] == d and pc[w] == pytest.approx(c, rel=1e-14, abs=0)
+    ref, ref_tr = [], []
+    for w in range(len(wins)):
+        ref.append(seq.Sync(d0[w], b[w], e[w], 0.03, 0.05))
+        ref_tr.append(seq.sync_trace())
+    costs, delays = bat.sync_windows(d0, b, e, 0.03, 0.05)
+    for w in range(len(wins)):
+        assert delays[w] == ref[w][1] and costs[w] == ref[w][0]
+        np.testing.assert_array_equal(bat.window_trace(w), ref_tr[w])

@@ -216,3 +216,48 @@ def test_large_absolute_times_lose_no_precision(host, tiny_clean):
     np.testing.assert_allclose(G1, G0, rtol=1e-3, atol=1e-3 * np.abs(G0).max())
     dd = np.diff(L0)
     assert np.all(dd > 0) or np.all(dd < 0)  # 2 us steps are resolved monotonically
+
+
+WINDOWS = [(0, 7), (4, 11), (8, 15), (2, 5), (0, 15)]  # overlapping, nested and whole-range
+
+
+def test_sync_windows_equal_consecutive_sync_calls(host, tiny_case):
+    """rssync_ext_sync_windows: window w is what the w-th of W consecutive Sync calls returns
+    (same sampler stream, same per-window stopping), overlapping windows included."""
+    b = [w[0] for w in WINDOWS]
+    e = [w[1] for w in WINDOWS]
+    d0 = [0.036, 0.030, 0.040, 0.036, 0.02]
+    seq = host(tiny_case, max_outer_iters=25)
+    ref, ref_tr = [], []
+    for w in range(len(WINDOWS)):
+        ref.append(seq.Sync(d0[w], b[w], e[w], 0.03, 0.05))
+        ref_tr.append(seq.sync_trace())
+    bat = host(tiny_case, max_outer_iters=25)
+    costs, delays = bat.sync_windows(d0, b, e, 0.03, 0.05)
+    assert len({len(t) for t in ref_tr}) > 1          # the windows stop at different iterations
+    for w in range(len(WINDOWS)):
+        assert delays[w] == ref[w][1] and costs[w] == ref[w][0]
+        np.testing.assert_array_equal(bat.window_trace(w), ref_tr[w])
+    # the sampler stream advanced by W: the next Sync equals the (W+1)-th sequential one
+    assert bat.Sync(0.036, 0, 15, 0.03, 0.05) == seq.Sync(0.036, 0, 15, 0.03, 0.05)
+    with pytest.raises(Exception):
+        bat.window_trace(1)                           # a plain Sync holds one window
+
+
+def test_pre_sync_windows_equal_separate_presync_calls(host, tiny_case):
+    b = [w[0] for w in WINDOWS] + [40]
+    e = [w[1] + 1 for w in WINDOWS] + [50]            # PreSync ranges are end-exclusive; last one is empty
+    h = host(tiny_case)
+    costs, delays = h.pre_sync_windows(0.03, b, e, 0.004, 0.04)
+    for w in range(len(b)):
+        c, d = h.PreSync(0.03, b[w], e[w], 0.004, 0.04)
+        assert delays[w] == d
+        assert costs[w] == pytest.approx(c, rel=1e-14, abs=0)
+    calls = []
+    h.set_reduce_hook(lambda a: calls.append(len(a)))
+    h.pre_sync_windows(0.03, b, e, 0.004, 0.04)
+    assert calls == [20 * len(b) + 4]                 # one exchange for all windows
+    calls.clear()
+    h.set_max_outer_iters(3)
+    h.sync_windows(0.036, b[:3], [x - 1 for x in e[:3]], 0.0, 0.5)
+    assert calls == [6, 30] * 3 + [3]                 # {loss, grad} and 10 trials per window; final losses
