@@ -116,7 +116,16 @@ int rssync_ext_pre_sync_windows(rssync_problem* p, double initial_delay, const i
 int rssync_ext_sync_windows(rssync_problem* p, const double* initial_delays, const int64_t* frame_begins,
                             const int64_t* frame_ends, int n_windows, double search_center,
                             double search_radius, double* costs, double* delays);
-/* trace of one window of the last sync_windows call (same rows as sync_trace) */
+/* The reference driver's whole loop over sync points (core_testcode.cpp:303-316): for each
+ * position pos: delay = initial_delay; if use_presync, delay = PreSync(delay, pos,
+ * pos + sync_window, presync_step, presync_radius).second, else the search radius is infinite;
+ * then sync_repeats (the driver: 4) times delay = Sync(delay, pos, pos + sync_window,
+ * initial_delay, radius).second.  delays[w] / costs[w] (may be NULL) are the last Sync's result
+ * for position w, identical to running that loop through the ISyncProblem methods. */
+int rssync_ext_sync_points(rssync_problem* p, const int64_t* positions, int n_points, int64_t sync_window,
+                           double initial_delay, int use_presync, double presync_step,
+                           double presync_radius, int sync_repeats, double* costs, double* delays);
+/* trace of one window of the last sync_windows / sync_points call (same rows as sync_trace) */
 int rssync_ext_window_trace(rssync_problem* p, int window, double* trace, int cap_rows, int* n_rows);
 /* trace of the last Sync: rows of {delay_after, step, loss_at_x0, grad_at_x0, t, trials} */
 int rssync_ext_sync_trace(rssync_problem* p, double* trace, int cap_rows, int* n_rows);

@@ -97,10 +97,10 @@ int rship_presync_window_costs(rship_ctx* c, const int32_t* kd, const float* fd,
                                double* costs, uint32_t* flags, double* frame_costs, int32_t* best_h);
 
 /* FrameState::GuessMotion + GuessK (core_private.cpp:125-133) for every
- * selected slot; kd/fd hold one delay per window, window w samples with stream + w;
- * results stay on the device */
+ * selected slot; kd/fd hold one delay per window, window w samples with
+ * stream + w * stream_stride; results stay on the device */
 int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_hyp,
-                      uint32_t stream, uint64_t seed);
+                      uint32_t stream, uint32_t stream_stride, uint64_t seed);
 
 /* do_opt_motion (core_private.cpp:262-296): per-frame L-BFGS on the motion
  * vector at a fixed delay per window (fd = NaN skips a window).

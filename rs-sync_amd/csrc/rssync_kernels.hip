@@ -205,7 +205,7 @@ struct LmedsParams {
     const int32_t* kd;
     const float* fd;
     uint32_t n_cand, chunk, n_chunks;
-    uint32_t n_hyp, stream_base;
+    uint32_t n_hyp, stream_base, stream_stride; // sampler stream = base + candidate + group * stride
     uint64_t seed;
     const uint32_t* grp; // slot -> group (window) or null; delays are indexed [candidate][group]
     uint32_t n_grp;      // >= 1
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     for (uint32_t c = c0; c < c1; ++c) {
         const int base = fr.base_knot + p.kd[c * p.n_grp + g];
         const float fd = p.fd[c * p.n_grp + g];
-        const uint32_t stream = p.stream_base + c + g; // g != 0 only for batched GuessMotion (one candidate)
+        const uint32_t stream = p.stream_base + c + g * p.stream_stride; // g != 0 only for batched GuessMotion
         uint32_t bad = 0;
         // ---- stage A: rows of P -> LDS tile as unit rows; norms stay in registers ----
         float nrm[RPT];
@@ -1423,7 +1423,8 @@ void fill_motion(rship_ctx* c, MotionParams& p) {
 } // namespace
 
 // kd/fd: one delay per group of the selection
-int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_hyp, uint32_t stream, uint64_t seed) {
+int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_hyp, uint32_t stream,
+                      uint32_t stream_stride, uint64_t seed) {
     if (check_ready(c)) return 1;
     if (upload_delays(c, kd, fd, c->n_grp) || ensure(c, c->flags, 16)) return 1;
     RS_HIP(hipMemsetAsync(c->flags.p, 0, 16, c->stream));
@@ -1441,7 +1442,8 @@ int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t
     p.chunk = 1;
     p.n_chunks = 1;
     p.n_hyp = n_hyp;
-    p.stream_base = stream; // + group index inside the kernel: window w uses stream + w
+    p.stream_base = stream; // window w uses stream + w * stride
+    p.stream_stride = stream_stride;
     p.seed = seed;
     p.grp = c->n_grp > 1 ? (const uint32_t*)c->grp.p : nullptr;
     p.n_grp = c->n_grp;

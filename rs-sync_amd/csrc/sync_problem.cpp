@@ -135,13 +135,16 @@ class SyncProblemHip final : public ISyncProblem {
     uint32_t select(int64_t begin, int64_t end_exclusive);
     std::vector<double> sweep(const std::vector<double>& delays, uint32_t stream_base, bool panics,
                               double* frame_costs, int32_t* best_h);
-    void init_motion(const std::vector<double>& delays);
+    void init_motion(const std::vector<double>& delays, uint32_t call_stride = 1);
     void opt_motion(const std::vector<double>& delays, uint64_t* stats);
     void loss(const std::vector<double>& delays, std::vector<double>& out_loss, std::vector<double>* out_grad);
     void select_windows(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl);
     void sync_windows(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl,
                       const std::vector<double>& initial, double search_center, double search_radius,
-                      std::vector<double>& costs, std::vector<double>& delays_out);
+                      std::vector<double>& costs, std::vector<double>& delays_out, uint32_t call_stride = 1);
+    void sync_points(const std::vector<int64_t>& positions, int64_t window, double initial_delay, bool use_presync,
+                     double presync_step, double presync_radius, int repeats, std::vector<double>& costs,
+                     std::vector<double>& delays_out);
     void presync_windows(double initial_delay, const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_excl,
                          double search_step, double search_radius, std::vector<double>& costs,
                          std::vector<double>& delays_out);
@@ -475,12 +478,13 @@ static void split_all(const std::vector<double>& delays, double fs, std::vector<
     }
 }
 
-void SyncProblemHip::init_motion(const std::vector<double>& delays) {
+void SyncProblemHip::init_motion(const std::vector<double>& delays, uint32_t call_stride) {
     if (sel_.empty()) return;
     std::vector<int32_t> kd;
     std::vector<float> fd;
     split_all(delays, fs_, kd, fd);
-    hip_check(rship_init_motion(dev_, kd.data(), fd.data(), 200 /* core_private.cpp:127 */, kStreamSyncInit + sync_calls, seed),
+    hip_check(rship_init_motion(dev_, kd.data(), fd.data(), 200 /* core_private.cpp:127 */, kStreamSyncInit + sync_calls,
+                                call_stride, seed),
               "init motion");
 }
 
@@ -543,13 +547,16 @@ void SyncProblemHip::select_windows(const std::vector<int64_t>& begins, const st
 //  * P is computed once per motion optimisation, not three times per evaluation (:94-97).
 void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl,
                                   const std::vector<double>& initial, double search_center, double search_radius,
-                                  std::vector<double>& costs, std::vector<double>& delays_out) {
+                                  std::vector<double>& costs, std::vector<double>& delays_out, uint32_t call_stride) {
     ensure_device();
     const size_t W = begins.size();
     select_windows(begins, ends_incl);
     std::vector<double> d(initial);
-    init_motion(d); // :218-223, window w samples with stream SYNC_INIT + sync_calls + w
-    sync_calls += (uint32_t)W;
+    // :218-223; window w samples with stream SYNC_INIT + sync_calls + w * call_stride.  With
+    // stride 1 the call consumes W consecutive call numbers; sync_points() interleaves
+    // several batched calls and advances the counter itself.
+    init_motion(d, call_stride);
+    if (call_stride == 1) sync_calls += (uint32_t)W;
     traces.assign(W, {});
 
     const double c_armijo = 2e-4, decay = .1, t0 = 1e-3; // :226
@@ -694,6 +701,39 @@ void SyncProblemHip::presync_windows(double initial_delay, const std::vector<int
         costs[w] = cw[best * W + w];
         delays_out[w] = delays[best];
     }
+}
+
+// The reference driver's loop over sync points (core_testcode.cpp:303-316) as batched calls:
+// for every position `pos`: delay = initial; optionally delay = PreSync(delay, pos, pos + window,
+// step, radius).second; then `repeats` (4 in the driver) times delay = Sync(delay, pos,
+// pos + window, initial, radius).second.  Position w, repeat r uses the sampler stream the
+// sequential loop would (call number w * repeats + r), so the results are those of the loop.
+void SyncProblemHip::sync_points(const std::vector<int64_t>& positions, int64_t window, double initial_delay,
+                                 bool use_presync, double presync_step, double presync_radius, int repeats,
+                                 std::vector<double>& costs, std::vector<double>& delays_out) {
+    const size_t W = positions.size();
+    std::vector<int64_t> ends(W);
+    for (size_t w = 0; w < W; ++w) ends[w] = positions[w] + window;
+    std::vector<double> d(W, initial_delay);
+    costs.assign(W, 0.0);
+    double radius = std::numeric_limits<double>::infinity(); // :307
+    if (use_presync) {                                          // :308-312
+        radius = presync_radius;
+        std::vector<double> c;
+        presync_windows(initial_delay, positions, ends, presync_step, presync_radius, c, d);
+    }
+    const uint32_t first_call = sync_calls;
+    std::vector<std::vector<double>> all(W);
+    for (int r = 0; r < repeats; ++r) { // :314 (Sync's range is end-inclusive: window + 1 frames)
+        sync_calls = first_call + (uint32_t)r;
+        std::vector<double> dn;
+        sync_windows(positions, ends, d, initial_delay, radius, costs, dn, (uint32_t)std::max(1, repeats));
+        d = dn;
+        for (size_t w = 0; w < W; ++w) all[w].insert(all[w].end(), traces[w].begin(), traces[w].end());
+    }
+    sync_calls = first_call + (uint32_t)(W * (size_t)std::max(0, repeats));
+    traces = all; // every repeat's rows, in order
+    delays_out = d;
 }
 
 } // namespace
@@ -918,6 +958,20 @@ int rssync_ext_sync_windows(rssync_problem* p, const double* initial_delays, con
                               search_radius, c, d);
         p->impl->trace = p->impl->traces[0];
         std::copy(c.begin(), c.end(), costs);
+        std::copy(d.begin(), d.end(), delays);
+    });
+}
+
+int rssync_ext_sync_points(rssync_problem* p, const int64_t* positions, int n_points, int64_t sync_window,
+                           double initial_delay, int use_presync, double presync_step, double presync_radius,
+                           int sync_repeats, double* costs, double* delays) {
+    return guarded([&] {
+        if (n_points <= 0) return;
+        std::vector<double> c, d;
+        p->impl->sync_points(std::vector<int64_t>(positions, positions + n_points), sync_window, initial_delay,
+                             use_presync != 0, presync_step, presync_radius, sync_repeats, c, d);
+        p->impl->trace = p->impl->traces[0];
+        if (costs) std::copy(c.begin(), c.end(), costs);
         std::copy(d.begin(), d.end(), delays);
     });
 }

@@ -62,6 +62,8 @@ SIGNATURES = {
     "rssync_ext_pre_sync_windows": (C.c_int, [C.c_void_p, C.c_double, _PI64, _PI64, C.c_int, C.c_double, C.c_double,
                                               _PD, _PD]),
     "rssync_ext_sync_windows": (C.c_int, [C.c_void_p, _PD, _PI64, _PI64, C.c_int, C.c_double, C.c_double, _PD, _PD]),
+    "rssync_ext_sync_points": (C.c_int, [C.c_void_p, _PI64, C.c_int, C.c_int64, C.c_double, C.c_int, C.c_double,
+                                         C.c_double, C.c_int, _PD, _PD]),
     "rssync_ext_window_trace": (C.c_int, [C.c_void_p, C.c_int, _PD, C.c_int, C.POINTER(C.c_int)]),
     "rssync_ext_sync_trace": (C.c_int, [C.c_void_p, _PD, C.c_int, C.POINTER(C.c_int)]),
     "rssync_ext_device_context": (C.c_void_p, [C.c_void_p]),
@@ -298,7 +300,22 @@ class SyncProblem:
                                                       _p(delays)))
         return costs, delays
 
-    def window_trace(self, window, cap=512):
+    def sync_points(self, positions, sync_window, initial_delay, presync_step=None, presync_radius=None, repeats=4):
+        """The reference driver's loop (core_testcode.cpp:303-316) over all sync points at once:
+        optional PreSync, then `repeats` chained Sync calls per position -> (costs[W], delays[W])."""
+        pos = np.ascontiguousarray(positions, np.int64)
+        if pos.ndim != 1:
+            raise ValueError("positions must be 1-D")
+        use = presync_step is not None and presync_radius is not None
+        costs, delays = np.zeros(pos.size), np.zeros(pos.size)
+        self._check(self._lib.rssync_ext_sync_points(self._h, _p(pos, _PI64), pos.size, int(sync_window),
+                                                     float(initial_delay), 1 if use else 0,
+                                                     float(presync_step) if use else 0.0,
+                                                     float(presync_radius) if use else 0.0, int(repeats), _p(costs),
+                                                     _p(delays)))
+        return costs, delays
+
+    def window_trace(self, window, cap=2048):
         t, n = np.zeros((cap, 6)), C.c_int()
         self._check(self._lib.rssync_ext_window_trace(self._h, int(window), _p(t), cap, C.byref(n)))
         return t[:min(n.value, cap)].copy()

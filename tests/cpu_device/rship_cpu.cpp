@@ -208,13 +208,14 @@ int rship_presync_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32
                                       frame_costs, best_h);
 }
 
-int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_hyp, uint32_t stream, uint64_t seed) {
+int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_hyp, uint32_t stream,
+                      uint32_t stream_stride, uint64_t seed) {
     for (size_t s = 0; s < c->sel.size(); ++s) {
         const uint32_t fi = c->sel[s], g = c->grp[s];
         const rship_frame& fr = c->frames[fi];
         Rows t = unit_rows(c, fr, kd[g], fd[g]);
         f3 Mv;
-        lmeds(t, n_hyp, seed, fr.id, stream + g, Mv);
+        lmeds(t, n_hyp, seed, fr.id, stream + g * stream_stride, Mv);
         double ss = 0;
         for (uint32_t i = 0; i < fr.n_rays; ++i) {
             float pm = t.nrm[i] * rs::dot(t.n[i], Mv);

@@ -530,3 +530,21 @@ def test_batched_windows_equal_sequential_calls(small_case):
     for w in range(len(wins)):
         assert delays[w] == ref[w][1] and costs[w] == ref[w][0]
         np.testing.assert_array_equal(bat.window_trace(w), ref_tr[w])
+
+
+def test_sync_points_equal_the_driver_loop(small_case):
+    """rssync_ext_sync_points == the loop at core_testcode.cpp:303-316 through PreSync/Sync."""
+    import rssync_amd
+    from conftest import fill
+    pos, window, init = [0, 10, 20, 30, 40], 20, 0.0
+    seq = fill(rssync_amd.SyncProblem(seed=SEED, max_outer_iters=40), small_case)
+    want = []
+    for p0 in pos:
+        d = seq.PreSync(init, p0, p0 + window, 0.002, 0.1)[1]
+        for _ in range(4):
+            c, d = seq.Sync(d, p0, p0 + window, init, 0.1)
+        want.append((c, d))
+    bat = fill(rssync_amd.SyncProblem(seed=SEED, max_outer_iters=40), small_case)
+    costs, delays = bat.sync_points(pos, window, init, 0.002, 0.1, repeats=4)
+    for w in range(len(pos)):
+        assert (costs[w], delays[w]) == want[w]

@@ -261,3 +261,25 @@ def test_pre_sync_windows_equal_separate_presync_calls(host, tiny_case):
     h.set_max_outer_iters(3)
     h.sync_windows(0.036, b[:3], [x - 1 for x in e[:3]], 0.0, 0.5)
     assert calls == [6, 30] * 3 + [3]                 # {loss, grad} and 10 trials per window; final losses
+
+
+def test_sync_points_equal_the_reference_driver_loop(host, tiny_case):
+    """rssync_ext_sync_points == core_testcode.cpp:303-316 run through the ISyncProblem methods."""
+    pos, window, init = [0, 3, 6, 9], 6, 0.02
+    for presync in (True, False):
+        seq = host(tiny_case, max_outer_iters=12)
+        want = []
+        for p0 in pos:
+            d, radius = init, np.inf
+            if presync:
+                radius = 0.04
+                d = seq.PreSync(d, p0, p0 + window, 0.004, radius)[1]
+            for _ in range(4):
+                c, d = seq.Sync(d, p0, p0 + window, init, radius)
+            want.append((c, d))
+        bat = host(tiny_case, max_outer_iters=12)
+        costs, delays = bat.sync_points(pos, window, init, *((0.004, 0.04) if presync else ()), repeats=4)
+        for w in range(len(pos)):
+            assert (costs[w], delays[w]) == want[w]
+        # both consumed 16 Sync call numbers
+        assert bat.Sync(0.03, 0, 15, 0.0, 0.2) == seq.Sync(0.03, 0, 15, 0.0, 0.2)
