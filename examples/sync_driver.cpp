@@ -5,12 +5,14 @@
 //   g++ -std=c++17 -Iinclude examples/sync_driver.cpp -Lrs-sync_amd -lrssync_core \
 //       -Wl,-rpath,$PWD/rs-sync_amd -Wl,-rpath,/opt/rocm/lib -o sync_driver
 //   ./sync_driver input.bin            -> prints "pos,delay_ms" per sync point, like the reference's CSV
+//   ./sync_driver input.bin batched    -> same output from ONE rssync_ext_sync_points call
 //
 // File layout (little endian): int64 n_gyro, double sample_rate, double first_timestamp,
 // n_gyro x 4 doubles [w,x,y,z]; int64 n_frames; per frame: int64 id, int64 n, ts_a[n], ts_b[n],
 // rays_a[3n], rays_b[3n] (doubles); then int64 window, int64 distance, double initial_ms,
 // double step_ms, double radius_ms.
 #include "rssync.h"
+#include "rssync_c.h"
 
 #include <cstdint>
 #include <cstdio>
@@ -47,6 +49,18 @@ int main(int argc, char** argv) {
     double initial_ms = 0, step_ms = 0, radius_ms = 0;
     rd(f, &window); rd(f, &distance); rd(f, &initial_ms); rd(f, &step_ms); rd(f, &radius_ms);
     fclose(f);
+    if (argc > 2) { // the same loop as one batched call on the object we already hold
+        std::vector<int64_t> positions;
+        for (int64_t pos = first; pos + window < last + 1; pos += distance) positions.push_back(pos);
+        std::vector<double> delays(positions.size());
+        rssync_problem* h = rssync_ext_borrow(sp.get());
+        if (!h || rssync_ext_sync_points(h, positions.data(), (int)positions.size(), window, initial_ms / 1000, 1,
+                                         step_ms / 1000., radius_ms / 1000., 4, nullptr, delays.data()))
+            return 3;
+        rssync_destroy(h); // the handle only; sp still owns the problem
+        for (size_t i = 0; i < positions.size(); ++i) std::printf("%lld,%.9f\n", (long long)positions[i], 1000 * delays[i]);
+        return 0;
+    }
     for (int64_t pos = first; pos + window < last + 1; pos += distance) { // :270-274
         const double initial = initial_ms / 1000;
         double delay = sp->PreSync(initial, pos, pos + window, step_ms / 1000., radius_ms / 1000.).second; // :310

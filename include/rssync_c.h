@@ -35,6 +35,11 @@ typedef struct rssync_problem rssync_problem;
 rssync_problem* rssync_create(void);
 /* delete through the virtual destructor (rssync.h:11) */
 void rssync_destroy(rssync_problem* p);
+/* A handle on an ISyncProblem* that CreateSyncProblem() of this library returned, for C++
+ * clients that want the rssync_ext_* entry points on the object they already hold.  The handle
+ * does not own the object: rssync_destroy() on it frees the handle only.  NULL if the pointer
+ * is not this library's. */
+rssync_problem* rssync_ext_borrow(void* isync_problem);
 const char* rssync_last_error(void);
 void rssync_set_panic_mode(int mode); /* 0 = panic.txt + exit(1); 1 = return status */
 

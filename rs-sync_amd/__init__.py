@@ -11,3 +11,4 @@ a ``SyncProblem`` needs a HIP device.
 from .problem import SyncProblem, RsSyncError, load_library, library_path  # noqa: F401
 from . import synth  # noqa: F401
 from . import dist  # noqa: F401
+from . import quality  # noqa: F401

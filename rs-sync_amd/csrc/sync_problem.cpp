@@ -748,6 +748,7 @@ ISyncProblem::~ISyncProblem() {}
 struct rssync_problem {
     ISyncProblem* iface;
     SyncProblemHip* impl;
+    bool owns = true;
 };
 
 namespace {
@@ -782,8 +783,17 @@ rssync_problem* rssync_create(void) {
 
 void rssync_destroy(rssync_problem* p) {
     if (!p) return;
-    delete p->iface;
+    if (p->owns) delete p->iface;
     delete p;
+}
+
+rssync_problem* rssync_ext_borrow(void* isync_problem) {
+    SyncProblemHip* impl = dynamic_cast<SyncProblemHip*>(static_cast<ISyncProblem*>(isync_problem));
+    if (!impl) {
+        g_last_error = "borrow: not an ISyncProblem created by this library";
+        return nullptr;
+    }
+    return new rssync_problem{impl, impl, false};
 }
 
 const char* rssync_last_error(void) { return g_last_error.c_str(); }

@@ -33,6 +33,7 @@ _PU64 = C.POINTER(C.c_uint64)
 # name -> (restype, argtypes): every symbol include/rssync_c.h declares
 SIGNATURES = {
     "rssync_create": (C.c_void_p, []),
+    "rssync_ext_borrow": (C.c_void_p, [C.c_void_p]),
     "rssync_destroy": (None, [C.c_void_p]),
     "rssync_last_error": (C.c_char_p, []),
     "rssync_set_panic_mode": (None, [C.c_int]),

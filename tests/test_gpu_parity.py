@@ -502,6 +502,10 @@ def test_cxx_driver_through_the_vtable(tmp_path, small_case):
         want.append((float(pos), 1000 * d))
     assert len(got) == len(want) >= 2
     np.testing.assert_allclose(np.array(got), np.array(want), rtol=0, atol=1e-6)
+    # the same loop as one rssync_ext_sync_points call on the borrowed object: identical text
+    out_b = subprocess.run([str(exe), str(inp), "batched"], capture_output=True, text=True, env=env, cwd=tmp_path,
+                           check=True).stdout
+    assert out_b == out
 
 
 def test_batched_windows_equal_sequential_calls(small_case):
