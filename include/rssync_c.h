@@ -108,6 +108,30 @@ int rssync_ext_opt_motion(rssync_problem* p, double delay, double* M, double* k,
 int rssync_ext_set_motion(rssync_problem* p, const double* M, const double* k, int n_frames);
 /* sum over the current selection of loss (and analytic d/d-delay) at n delays */
 int rssync_ext_loss(rssync_problem* p, const double* delays, int n, double* loss, double* grad);
+/* Upstream steps of the reference driver, moved behind the library.
+ * set_track_pixels replaces the driver's undistort + normalise + row-time loop followed by
+ * SetTrackResult (core_testcode.cpp:135-158): points_* are count x {x, y} pixel positions of the
+ * tracked points in the current / next video frame, frame_time_* those frames' times in seconds,
+ * image_rows the frame height; row time = frame_time + lens.ro * y / image_rows.  The fisheye
+ * inverse (core_testcode.cpp:63-95) runs on the device in fp64 and writes the packed ray
+ * streams directly.  A frame set this way replaces one set by rssync_set_track_result and vice
+ * versa. */
+typedef struct rssync_lens { /* core_testcode.cpp:55-61 */
+    double ro;             /* rolling-shutter readout time, seconds */
+    double fx, fy, cx, cy; /* pixels */
+    double k1, k2, k3, k4;
+} rssync_lens;
+int rssync_ext_set_track_pixels(rssync_problem* p, int64_t frame, double frame_time_a, double frame_time_b,
+                                const double* points_a, const double* points_b, size_t count,
+                                const rssync_lens* lens, double image_rows);
+/* optdata_fill_gyro (core_testcode.cpp:36-52): integrate angular rates (count x {x,y,z}, rad/s, at
+ * timestamps in seconds) to orientations and hand them to the timestamped gyro setter.
+ * orientation: telemetry-parser's three-letter axis string ("XYZ" = identity) or NULL. */
+int rssync_ext_set_gyro_rates(rssync_problem* p, const double* timestamps_s, const double* rates, size_t count,
+                              const char* orientation);
+/* the packed device ray streams of one frame ({ax,bx,ay,by} and {az,bz,ta,tb} per pair), for tests */
+int rssync_ext_frame_rays(rssync_problem* p, int64_t frame, float* a4, float* b4, size_t cap, size_t* n);
+
 /* Batched windows (the driver's loop, core_testcode.cpp:303-316, calls
  * PreSync + 4x Sync once per window position; these run all positions in one call).
  * pre_sync_windows: window w = PreSync(initial_delay, begins[w], ends[w], step, radius) -- the

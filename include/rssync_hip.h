@@ -55,7 +55,8 @@ typedef struct rship_frame {
 #define RSHIP_K_MOTION 2 /* per-frame motion L-BFGS */
 #define RSHIP_K_REDUCE 3 /* over-frames sums */
 #define RSHIP_K_INIT 4   /* the LMedS kernel in GuessMotion/GuessK mode (Sync start) */
-#define RSHIP_K_COUNT 5
+#define RSHIP_K_PIXELS 5 /* pixel -> ray + row time (rship_rays_from_pixels) */
+#define RSHIP_K_COUNT 6
 
 int rship_create(rship_ctx** out, int device /* -1 = current device */);
 void rship_destroy(rship_ctx* c);
@@ -68,7 +69,8 @@ int rship_max_tracks(void); /* largest per-frame track count the kernels accept 
  * the spline solver that replaces minispline.cpp:3-46 */
 int rship_upload_spline(rship_ctx* c, const float* coef16, uint32_t n_knots, double sample_rate);
 
-/* OptData::frame_data (core_private.hpp:21): all frames, packed */
+/* OptData::frame_data (core_private.hpp:21): all frames, packed.  Both ray pointers NULL =
+ * allocate only (every frame is then filled by rship_rays_from_pixels). */
 int rship_upload_frames(rship_ctx* c, const float* rays_xy4, const float* rays_zt4,
                         uint64_t total_rays, const rship_frame* table, uint32_t n_frames);
 
@@ -120,6 +122,25 @@ int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_dela
 /* per-slot state in selection order: M[3n], k[n] */
 int rship_get_motion(rship_ctx* c, double* M, double* k, uint32_t cap, uint32_t* n);
 int rship_set_motion(rship_ctx* c, const double* M, const double* k, uint32_t n);
+
+/* A frame given as tracked pixel positions instead of rays (the reference driver's step
+ * upstream of SetTrackResult, core_testcode.cpp:63-95,135-158). */
+typedef struct rship_pixel_frame {
+    double time_a, time_b, rows; /* times (s) of the current / next video frame; image rows */
+    double lens[9];              /* ro, fx, fy, cx, cy, k1, k2, k3, k4 */
+    double start, fs, base;      /* gyro grid (quats_start, sample_rate) and the frame's base knot */
+    uint64_t px_offset;          /* first pair of the frame in px */
+    uint32_t ray_offset, n_rays; /* where its rays live in the two float4 streams */
+} rship_pixel_frame;
+
+/* Undistort + normalise + row time + knot offset in fp64 on the device, written straight into
+ * the packed ray streams uploaded by rship_upload_frames (whose slices for these frames may hold
+ * anything).  px: 4 doubles per pair {xa, ya, xb, yb}.  *bad = number of non-finite outputs. */
+int rship_rays_from_pixels(rship_ctx* c, const double* px, uint64_t n_pairs, const rship_pixel_frame* frames,
+                           uint32_t n_frames, uint32_t* bad);
+
+/* debug: the packed float4 streams of one frame of the table */
+int rship_debug_rays(rship_ctx* c, uint32_t frame_index, float* a4, float* b4, uint32_t cap_rays);
 
 /* residual matrix P (fp32, row-major N x 3) of one selected frame at one delay (tests) */
 int rship_debug_problem(rship_ctx* c, uint32_t sel_index, int32_t kd, float fd, float* P,

@@ -63,6 +63,12 @@ def load():
     lib.ora_spline_eval.argtypes = [C.c_void_p, C.c_double, _PD]
     lib.ora_spline_deriv.argtypes = [C.c_void_p, C.c_double, _PD]
     lib.ora_quat_slerp.argtypes = [_PD, _PD, C.c_double, _PD]
+    lib.ora_undistort_point.argtypes = [_PD, C.c_double, C.c_double, _PD]
+    lib.ora_pixels_to_tracks.argtypes = [_PD, C.c_double, C.c_double, C.c_double, _PD, _PD, C.c_size_t, _PD, _PD, _PD,
+                                         _PD]
+    lib.ora_quat_from_aa.argtypes = [_PD, _PD]
+    lib.ora_integrate_gyro.argtypes = [_PD, _PD, C.c_size_t, _PD, C.POINTER(C.c_int64)]
+    lib.ora_orient_rates.argtypes = [_PD, C.c_size_t, C.c_char_p, _PD]
     lib.ora_compute_problem.argtypes = [C.c_void_p, C.c_int64, C.c_double, _PD]
     lib.ora_sample_pair.argtypes = [C.c_uint64, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -103,6 +109,43 @@ def quat_slerp(p, q, t):
     out = np.zeros(4)
     lib.ora_quat_slerp(_p(_d(p)), _p(_d(q)), float(t), _p(out))
     return out
+
+
+def undistort_point(lens, px, py):
+    """core_testcode.cpp:63-95; lens = (ro, fx, fy, cx, cy, k1, k2, k3, k4)"""
+    out = np.zeros(2)
+    load().ora_undistort_point(_p(_d(lens)), float(px), float(py), _p(out))
+    return out
+
+
+def pixels_to_tracks(lens, time_a, time_b, rows, points_a, points_b):
+    """core_testcode.cpp:135-152 -> (ts_a, ts_b, rays_a, rays_b) as SetTrackResult takes them"""
+    a, b = _d(points_a), _d(points_b)
+    n = a.shape[0]
+    ts_a, ts_b, ra, rb = np.zeros(n), np.zeros(n), np.zeros((n, 3)), np.zeros((n, 3))
+    load().ora_pixels_to_tracks(_p(_d(lens)), float(time_a), float(time_b), float(rows), _p(a), _p(b), n, _p(ts_a),
+                                _p(ts_b), _p(ra), _p(rb))
+    return ts_a, ts_b, ra, rb
+
+
+def quat_from_aa(aa):
+    out = np.zeros(4)
+    load().ora_quat_from_aa(_p(_d(aa)), _p(out))
+    return out
+
+
+def integrate_gyro(timestamps_s, rates, orientation=None):
+    """core_testcode.cpp:36-51 -> (quats (n, 4), timestamps_us int64)"""
+    t, r = _d(timestamps_s), _d(rates)
+    n = r.shape[0]
+    if orientation is not None:
+        o = np.zeros_like(r)
+        if load().ora_orient_rates(_p(r), n, orientation.encode(), _p(o)):
+            raise ValueError("bad orientation string")
+        r = o
+    q, us = np.zeros((n, 4)), np.zeros(n, np.int64)
+    load().ora_integrate_gyro(_p(t), _p(r), n, _p(q), us.ctypes.data_as(C.POINTER(C.c_int64)))
+    return q, us
 
 
 class OracleProblem:

@@ -121,6 +121,22 @@ int ora_sync_trace(ora_problem* p, double initial_delay, int64_t frame_begin,
 /* per-frame state after the last Sync: M[3*i..], k[i] in ascending frame-id order */
 int ora_sync_state(const ora_problem* p, double* M, double* k, int cap, int* n_frames);
 
+/* ---- driver steps upstream of the ISyncProblem calls (rssync_oracle_driver.c) ---- */
+typedef struct ora_lens { /* core_testcode.cpp:55-61 */
+    double ro, fx, fy, cx, cy, k1, k2, k3, k4;
+} ora_lens;
+/* core_testcode.cpp:63-95 */
+void ora_undistort_point(const ora_lens* lens, double px, double py, double out[2]);
+/* core_testcode.cpp:135-152: px_* = n x {x, y}; outputs as SetTrackResult takes them */
+void ora_pixels_to_tracks(const ora_lens* lens, double time_a, double time_b, double rows, const double* px_a,
+                          const double* px_b, size_t n, double* ts_a, double* ts_b, double* rays_a, double* rays_b);
+/* quat.cpp:5-17 */
+void ora_quat_from_aa(const double aa[3], double out[4]);
+/* core_testcode.cpp:36-51: rates n x 3 rad/s, timestamps seconds -> quats n x 4, int64 microseconds */
+void ora_integrate_gyro(const double* timestamps_s, const double* rates, size_t n, double* quats, int64_t* ts_us);
+/* telemetry-parser orientation string ("XYZ" = identity); 0 on success */
+int ora_orient_rates(const double* rates, size_t n, const char* orientation, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,7 @@
 
 #include "../../include/rssync_hip.h"
 #include "device_math.hpp"
+#include "lens_math.hpp"
 
 using rs::f3;
 using rs::f4;
@@ -973,6 +974,40 @@ __global__ __launch_bounds__(kBlock) void debug_problem_kernel(DebugParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// pixel -> ray (core_testcode.cpp:63-95,135-158).  One thread per tracked
+// pair, fp64 (the reference's arithmetic; gfx950 issues fp64 FMA at the fp32 rate), results
+// rounded once to the packed fp32 layout.  HBM: 32 B read + 32 B written per pair.
+struct PixelParams {
+    const double* px;
+    const rship_pixel_frame* frames;
+    f4* rays_a;
+    f4* rays_b;
+    uint32_t* bad;
+};
+
+__global__ __launch_bounds__(kBlock) void rays_from_pixels_kernel(PixelParams p) {
+    const rship_pixel_frame& fr = p.frames[blockIdx.x];
+    const uint32_t row = blockIdx.y * kBlock + threadIdx.x;
+    if (row >= fr.n_rays) return;
+    const double2* src = (const double2*)(p.px + 4 * (fr.px_offset + row));
+    const double2 a = src[0], b = src[1];
+    rs::Lens lens{fr.lens[0], fr.lens[1], fr.lens[2], fr.lens[3], fr.lens[4], fr.lens[5], fr.lens[6], fr.lens[7], fr.lens[8]};
+    double ra[3], rb[3], tsa, tsb;
+    rs::pixel_to_ray(lens, a.x, a.y, fr.time_a, fr.rows, ra, &tsa);
+    rs::pixel_to_ray(lens, b.x, b.y, fr.time_b, fr.rows, rb, &tsb);
+    const float ta = (float)rs::knot_offset(tsa, fr.start, fr.fs, fr.base);
+    const float tb = (float)rs::knot_offset(tsb, fr.start, fr.fs, fr.base);
+    f4 o0, o1;
+    o0.x = (float)ra[0]; o0.y = (float)rb[0]; o0.z = (float)ra[1]; o0.w = (float)rb[1];
+    o1.x = (float)ra[2]; o1.y = (float)rb[2]; o1.z = ta; o1.w = tb;
+    const bool ok = finite_f(o0.x) && finite_f(o0.y) && finite_f(o0.z) && finite_f(o0.w) && finite_f(o1.x) &&
+                    finite_f(o1.y) && finite_f(o1.z) && finite_f(o1.w);
+    if (!ok) atomicAdd(p.bad, 1u);
+    p.rays_a[fr.ray_offset + row] = o0;
+    p.rays_b[fr.ray_offset + row] = o1;
+}
+
 // debug: the wave-level exact selection on caller-provided residuals (one wave per problem,
 // 2048 slots, NaN-padded), exactly as the LMedS kernel drives it
 __global__ __launch_bounds__(64) void debug_select_kernel(const float* __restrict__ vals, uint32_t n, uint32_t kq,
@@ -1267,7 +1302,7 @@ int rship_upload_frames(rship_ctx* c, const float* rays_a4, const float* rays_b4
     size_t rb = (size_t)total_rays * 16;
     if (ensure(c, c->rays_a, rb ? rb : 16) || ensure(c, c->rays_b, rb ? rb : 16)) return 1;
     if (ensure(c, c->frames, (size_t)n_frames * sizeof(rship_frame) + 32)) return 1;
-    if (rb) {
+    if (rb && rays_a4 && rays_b4) { // null: the caller fills the streams on the device (rship_rays_from_pixels)
         RS_HIP(hipMemcpyAsync(c->rays_a.p, rays_a4, rb, hipMemcpyHostToDevice, c->stream));
         RS_HIP(hipMemcpyAsync(c->rays_b.p, rays_b4, rb, hipMemcpyHostToDevice, c->stream));
     }
@@ -1552,6 +1587,57 @@ int rship_set_motion(rship_ctx* c, const double* M, const double* k, uint32_t n)
         RS_HIP(hipMemcpy(c->M.p, M, (size_t)n * 24, hipMemcpyHostToDevice));
         RS_HIP(hipMemcpy(c->k.p, k, (size_t)n * 8, hipMemcpyHostToDevice));
     }
+    return 0;
+}
+
+int rship_rays_from_pixels(rship_ctx* c, const double* px, uint64_t n_pairs, const rship_pixel_frame* frames,
+                           uint32_t n_frames, uint32_t* bad) {
+    if (bad) *bad = 0;
+    if (!n_frames) return 0;
+    uint32_t max_n = 0;
+    for (uint32_t i = 0; i < n_frames; ++i) {
+        const rship_pixel_frame& f = frames[i];
+        if (f.px_offset + f.n_rays > n_pairs) return set_err(c, "rays_from_pixels: frame exceeds the pixel buffer");
+        if ((uint64_t)f.ray_offset + f.n_rays > c->total_rays) return set_err(c, "rays_from_pixels: frame exceeds the ray buffer");
+        max_n = std::max(max_n, f.n_rays);
+    }
+    if (!max_n) return 0;
+    DevBuf dpx, dfr, dbad;
+    if (ensure(c, dpx, (size_t)n_pairs * 32 + 32) || ensure(c, dfr, (size_t)n_frames * sizeof(rship_pixel_frame)) ||
+        ensure(c, dbad, 16))
+        return 1;
+    hipError_t e = hipMemcpyAsync(dpx.p, px, (size_t)n_pairs * 32, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dfr.p, frames, (size_t)n_frames * sizeof(rship_pixel_frame), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(dbad.p, 0, 16, c->stream);
+    if (e == hipSuccess) {
+        PixelParams p{(const double*)dpx.p, (const rship_pixel_frame*)dfr.p, (f4*)c->rays_a.p, (f4*)c->rays_b.p, (uint32_t*)dbad.p};
+        {
+            ProfScope ps(c, RSHIP_K_PIXELS);
+            hipLaunchKernelGGL(rays_from_pixels_kernel, dim3(n_frames, (max_n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, p);
+        }
+        e = hipGetLastError();
+    }
+    uint32_t nb = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&nb, dbad.p, 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    (void)hipFree(dpx.p);
+    (void)hipFree(dfr.p);
+    (void)hipFree(dbad.p);
+    if (e != hipSuccess) return set_err(c, "rays_from_pixels", e);
+    if (bad) *bad = nb;
+    return 0;
+}
+
+int rship_debug_rays(rship_ctx* c, uint32_t frame_index, float* a4, float* b4, uint32_t cap_rays) {
+    if (frame_index >= c->n_frames) return set_err(c, "debug_rays: index out of range");
+    rship_frame rec;
+    hipError_t e = hipMemcpy(&rec, (const rship_frame*)c->frames.p + frame_index, sizeof(rec), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return set_err(c, "debug_rays", e);
+    if (rec.n_rays > cap_rays) return set_err(c, "debug_rays: output too small");
+    e = hipMemcpy(a4, (const f4*)c->rays_a.p + rec.ray_offset, (size_t)rec.n_rays * 16, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(b4, (const f4*)c->rays_b.p + rec.ray_offset, (size_t)rec.n_rays * 16, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return set_err(c, "debug_rays", e);
     return 0;
 }
 

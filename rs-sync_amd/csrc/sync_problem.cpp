@@ -17,6 +17,7 @@
 #include "../../include/rssync_hip.h"
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -98,6 +99,12 @@ void quat_slerp(const double* p, const double* q_in, double t, double* out) {
 
 struct HostFrame { // core_private.hpp:8-13 (FrameData), copied at SetTrackResult time
     std::vector<double> ts_a, ts_b, rays_a, rays_b;
+    // frames given as tracked pixels (rssync_ext_set_track_pixels): rays_* stay empty, the device
+    // produces them from px = {xa, ya, xb, yb} per pair; ts_* are kept for the frame table
+    bool from_pixels = false;
+    std::vector<double> px;
+    double time_a = 0, time_b = 0, rows = 0;
+    double lens[9] = {};
 };
 
 class SyncProblemHip final : public ISyncProblem {
@@ -117,7 +124,10 @@ class SyncProblemHip final : public ISyncProblem {
     void DebugPreSync(double initial_delay, int64_t frame_begin, int64_t frame_end, double search_radius,
                       double* delays, double* costs, int point_count) override;
 
-    // extension state (rssync_c.h)
+    // extension entry points (rssync_c.h)
+    void SetTrackPixels(int64_t frame, double time_a, double time_b, const double* px_a, const double* px_b,
+                        size_t count, const double lens[9], double image_rows);
+    void SetGyroRates(const double* timestamps_s, const double* rates, size_t count, const char* orientation);
     uint64_t seed = 0x5EED0000ULL;
     int max_outer = 400; // core_private.cpp:309
     bool verbose = true;
@@ -154,6 +164,7 @@ class SyncProblemHip final : public ISyncProblem {
     }
     const std::vector<uint32_t>& selection() const { return sel_; }
     int64_t table_id(uint32_t i) const { return table_ids_[i]; }
+    size_t table_size() const { return table_ids_.size(); }
     bool has_frame(int64_t id) const { return frames_.count(id) != 0; }
     size_t frame_tracks(int64_t id) const { return frames_.at(id).ts_a.size(); }
     uint32_t sync_calls = 0;
@@ -249,11 +260,90 @@ void SyncProblemHip::SetTrackResult(int64_t frame, const double* ts_a, const dou
         panic("set-track-result: " + std::to_string(count) + " tracks in one frame; this build accepts at most " +
               std::to_string(rship_max_tracks()));
     HostFrame& f = frames_[frame];
+    f = HostFrame{};
     f.ts_a.assign(ts_a, ts_a + count);
     f.ts_b.assign(ts_b, ts_b + count);
     f.rays_a.assign(rays_a, rays_a + 3 * count);
     f.rays_b.assign(rays_b, rays_b + 3 * count);
     frames_dirty_ = true;
+}
+
+// The reference driver's per-frame step before SetTrackResult (core_testcode.cpp:135-158) with the
+// arithmetic moved to the device: the host keeps the pixels and the row times (:144-145, needed for
+// the frame table), rays_from_pixels_kernel undistorts and normalises into the packed streams.
+void SyncProblemHip::SetTrackPixels(int64_t frame, double time_a, double time_b, const double* px_a,
+                                    const double* px_b, size_t count, const double lens[9], double image_rows) {
+    if (!all_finite(px_a, 2 * count)) panic("set-track-pixels: non-finite numbers in points_a");
+    if (!all_finite(px_b, 2 * count)) panic("set-track-pixels: non-finite numbers in points_b");
+    if (!all_finite(lens, 9) || !std::isfinite(time_a) || !std::isfinite(time_b) || !std::isfinite(image_rows) ||
+        image_rows == 0)
+        panic("set-track-pixels: non-finite lens or frame parameters");
+    if (count > (size_t)rship_max_tracks())
+        panic("set-track-result: " + std::to_string(count) + " tracks in one frame; this build accepts at most " +
+              std::to_string(rship_max_tracks()));
+    HostFrame& f = frames_[frame];
+    f = HostFrame{};
+    f.from_pixels = true;
+    f.time_a = time_a;
+    f.time_b = time_b;
+    f.rows = image_rows;
+    std::copy(lens, lens + 9, f.lens);
+    f.px.resize(4 * count);
+    f.ts_a.resize(count);
+    f.ts_b.resize(count);
+    for (size_t i = 0; i < count; ++i) {
+        f.px[4 * i] = px_a[2 * i]; f.px[4 * i + 1] = px_a[2 * i + 1];
+        f.px[4 * i + 2] = px_b[2 * i]; f.px[4 * i + 3] = px_b[2 * i + 1];
+        f.ts_a[i] = time_a + lens[0] * (px_a[2 * i + 1] / image_rows); // :144
+        f.ts_b[i] = time_b + lens[0] * (px_b[2 * i + 1] / image_rows); // :145
+    }
+    frames_dirty_ = true;
+}
+
+// optdata_fill_gyro (core_testcode.cpp:36-52): q_0 = identity, q_i = normalise(dq_i * q_{i-1}) with
+// dq_i the rotation by rate_i over (t_i - t_{i-1}) (quat.cpp:5-17), timestamps truncated to whole
+// microseconds, then the timestamped setter.  `orientation` is telemetry-parser's three-letter
+// string (position = output axis, letter = input axis, upper case +, lower case -) or NULL.
+void SyncProblemHip::SetGyroRates(const double* ts, const double* rates, size_t count, const char* orientation) {
+    if (count < 2) panic("set-gyro-rates: need at least 2 samples");
+    if (!all_finite(ts, count) || !all_finite(rates, 3 * count)) panic("set-gyro-rates: non-finite numbers");
+    int axis[3] = {0, 1, 2};
+    double sign[3] = {1, 1, 1};
+    if (orientation) {
+        if (std::strlen(orientation) != 3) panic("set-gyro-rates: orientation must have 3 letters");
+        for (int c = 0; c < 3; ++c) {
+            const char lo = (char)std::tolower((unsigned char)orientation[c]);
+            if (lo < 'x' || lo > 'z') panic("set-gyro-rates: orientation letters are x, y, z");
+            axis[c] = lo - 'x';
+            sign[c] = orientation[c] == lo ? -1.0 : 1.0;
+        }
+    }
+    std::vector<double> q(4 * count);
+    std::vector<int64_t> us(count);
+    q[0] = 1; q[1] = q[2] = q[3] = 0;
+    for (size_t i = 1; i < count; ++i) {
+        const double dt = ts[i] - ts[i - 1];
+        const double w[3] = {rates[3 * i + axis[0]] * sign[0] * dt, rates[3 * i + axis[1]] * sign[1] * dt,
+                             rates[3 * i + axis[2]] * sign[2] * dt};
+        const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+        double d[4];
+        if (th2 > 0.) {
+            const double th = std::sqrt(th2), half = th * 0.5, kk = std::sin(half) / th;
+            d[0] = std::cos(half); d[1] = w[0] * kk; d[2] = w[1] * kk; d[3] = w[2] * kk;
+        } else {
+            d[0] = 1.; d[1] = w[0] * 0.5; d[2] = w[1] * 0.5; d[3] = w[2] * 0.5;
+        }
+        const double* p = &q[4 * (i - 1)];
+        double o[4] = {d[0] * p[0] - d[1] * p[1] - d[2] * p[2] - d[3] * p[3],
+                       d[0] * p[1] + d[1] * p[0] + d[2] * p[3] - d[3] * p[2],
+                       d[0] * p[2] - d[1] * p[3] + d[2] * p[0] + d[3] * p[1],
+                       d[0] * p[3] + d[1] * p[2] - d[2] * p[1] + d[3] * p[0]};
+        double nn = std::sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+        if (nn == 0) nn = 1;
+        for (int c = 0; c < 4; ++c) q[4 * i + c] = o[c] / nn;
+    }
+    for (size_t i = 0; i < count; ++i) us[i] = (int64_t)(ts[i] * 1000000); // :48-50
+    SetGyroQuaternions(us.data(), q.data(), count);
 }
 
 // Natural cubic spline on unit-spaced knots, one per quaternion component
@@ -311,8 +401,12 @@ void SyncProblemHip::pack_frames() {
     size_t total = 0;
     for (auto& [id, f] : frames_) total += f.ts_a.size();
     if (total > 0xffffffffull) panic("sync: more than 2^32 rays");
-    std::vector<float> a4(total * 4 + 4), b4(total * 4 + 4);
+    size_t ray_frames = 0;
+    for (auto& [id, f] : frames_) ray_frames += f.from_pixels ? 0 : 1;
+    std::vector<float> a4(ray_frames ? total * 4 + 4 : 4), b4(ray_frames ? total * 4 + 4 : 4);
     std::vector<rship_frame> table;
+    std::vector<rship_pixel_frame> pframes;
+    std::vector<double> px;
     table.reserve(frames_.size());
     table_ids_.clear();
     size_t off = 0;
@@ -335,14 +429,31 @@ void SyncProblemHip::pack_frames() {
         for (size_t i = 0; i < n; ++i) {
             const float ta = (float)((f.ts_a[i] - start_) * fs_ - base);
             const float tb = (float)((f.ts_b[i] - start_) * fs_ - base);
-            float* pa = &a4[4 * (off + i)];
-            float* pb = &b4[4 * (off + i)];
-            // {ax,bx,ay,by} / {az,bz,ta,tb}: the two ends of the pair interleaved
-            pa[0] = (float)f.rays_a[3 * i]; pa[1] = (float)f.rays_b[3 * i]; pa[2] = (float)f.rays_a[3 * i + 1]; pa[3] = (float)f.rays_b[3 * i + 1];
-            pb[0] = (float)f.rays_a[3 * i + 2]; pb[1] = (float)f.rays_b[3 * i + 2]; pb[2] = ta; pb[3] = tb;
+            if (!f.from_pixels) {
+                float* pa = &a4[4 * (off + i)];
+                float* pb = &b4[4 * (off + i)];
+                // {ax,bx,ay,by} / {az,bz,ta,tb}: the two ends of the pair interleaved
+                pa[0] = (float)f.rays_a[3 * i]; pa[1] = (float)f.rays_b[3 * i]; pa[2] = (float)f.rays_a[3 * i + 1]; pa[3] = (float)f.rays_b[3 * i + 1];
+                pb[0] = (float)f.rays_a[3 * i + 2]; pb[1] = (float)f.rays_b[3 * i + 2]; pb[2] = ta; pb[3] = tb;
+            }
             if (i == 0) { tmin = std::min(ta, tb); tmax = std::max(ta, tb); }
             tmin = std::min(tmin, std::min(ta, tb));
             tmax = std::max(tmax, std::max(ta, tb));
+        }
+        if (f.from_pixels && n) {
+            // the device recomputes ta/tb from the pixels with the same fp64 operations; one ulp
+            // of slack on the bounds costs nothing and makes the window independent of that
+            tmin = std::nextafterf(tmin, -std::numeric_limits<float>::infinity());
+            tmax = std::nextafterf(tmax, std::numeric_limits<float>::infinity());
+            rship_pixel_frame pf{};
+            pf.time_a = f.time_a; pf.time_b = f.time_b; pf.rows = f.rows;
+            std::copy(f.lens, f.lens + 9, pf.lens);
+            pf.start = start_; pf.fs = fs_; pf.base = base;
+            pf.px_offset = px.size() / 4;
+            pf.ray_offset = (uint32_t)off;
+            pf.n_rays = (uint32_t)n;
+            px.insert(px.end(), f.px.begin(), f.px.end());
+            pframes.push_back(pf);
         }
         rec.tmin = tmin;
         rec.tmax = tmax;
@@ -350,8 +461,17 @@ void SyncProblemHip::pack_frames() {
         table_ids_.push_back(id);
         off += n;
     }
-    hip_check(rship_upload_frames(dev_, a4.data(), b4.data(), total, table.data(), (uint32_t)table.size()),
+    // frames given as pixels are filled in on the device: if all are, nothing is copied
+    const bool any_rays = pframes.size() < table.size();
+    hip_check(rship_upload_frames(dev_, any_rays ? a4.data() : nullptr, any_rays ? b4.data() : nullptr, total,
+                                  table.data(), (uint32_t)table.size()),
               "upload frames");
+    if (!pframes.empty()) {
+        uint32_t bad = 0;
+        hip_check(rship_rays_from_pixels(dev_, px.data(), px.size() / 4, pframes.data(), (uint32_t)pframes.size(), &bad),
+                  "rays from pixels");
+        if (bad) panic("set-track-result: non-finite numbers in rays (" + std::to_string(bad) + " tracks; lens parameters?)");
+    }
     sel_.clear();
     frames_dirty_ = false;
 }
@@ -969,6 +1089,37 @@ int rssync_ext_sync_windows(rssync_problem* p, const double* initial_delays, con
         p->impl->trace = p->impl->traces[0];
         std::copy(c.begin(), c.end(), costs);
         std::copy(d.begin(), d.end(), delays);
+    });
+}
+
+int rssync_ext_set_track_pixels(rssync_problem* p, int64_t frame, double frame_time_a, double frame_time_b,
+                                const double* points_a, const double* points_b, size_t count, const rssync_lens* lens,
+                                double image_rows) {
+    return guarded([&] {
+        if (!lens) panic("set-track-pixels: no lens");
+        const double l[9] = {lens->ro, lens->fx, lens->fy, lens->cx, lens->cy, lens->k1, lens->k2, lens->k3, lens->k4};
+        p->impl->SetTrackPixels(frame, frame_time_a, frame_time_b, points_a, points_b, count, l, image_rows);
+    });
+}
+
+int rssync_ext_set_gyro_rates(rssync_problem* p, const double* timestamps_s, const double* rates, size_t count,
+                              const char* orientation) {
+    return guarded([&] { p->impl->SetGyroRates(timestamps_s, rates, count, orientation); });
+}
+
+int rssync_ext_frame_rays(rssync_problem* p, int64_t frame, float* a4, float* b4, size_t cap, size_t* n) {
+    return guarded([&] {
+        SyncProblemHip* s = p->impl;
+        s->ensure_device();
+        for (uint32_t i = 0;; ++i) {
+            if (i >= s->table_size()) panic("frame_rays: no such frame");
+            if (s->table_id(i) != frame) continue;
+            const size_t cnt = s->frame_tracks(frame);
+            if (n) *n = cnt;
+            if (cnt > cap) panic("frame_rays: output too small");
+            if (rship_debug_rays(s->dev(), i, a4, b4, (uint32_t)cap)) panic(std::string("hip: debug rays: ") + rship_last_error(s->dev()));
+            return;
+        }
     });
 }
 

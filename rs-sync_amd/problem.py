@@ -60,6 +60,11 @@ SIGNATURES = {
     "rssync_ext_opt_motion": (C.c_int, [C.c_void_p, C.c_double, _PD, _PD, C.c_int, C.POINTER(C.c_int), _PU64, _PU64]),
     "rssync_ext_set_motion": (C.c_int, [C.c_void_p, _PD, _PD, C.c_int]),
     "rssync_ext_loss": (C.c_int, [C.c_void_p, _PD, C.c_int, _PD, _PD]),
+    "rssync_ext_set_track_pixels": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, _PD, _PD, C.c_size_t,
+                                              C.c_void_p, C.c_double]),
+    "rssync_ext_set_gyro_rates": (C.c_int, [C.c_void_p, _PD, _PD, C.c_size_t, C.c_char_p]),
+    "rssync_ext_frame_rays": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
+                                        C.POINTER(C.c_size_t)]),
     "rssync_ext_pre_sync_windows": (C.c_int, [C.c_void_p, C.c_double, _PI64, _PI64, C.c_int, C.c_double, C.c_double,
                                               _PD, _PD]),
     "rssync_ext_sync_windows": (C.c_int, [C.c_void_p, _PD, _PI64, _PI64, C.c_int, C.c_double, C.c_double, _PD, _PD]),
@@ -276,6 +281,38 @@ class SyncProblem:
         self._check(self._lib.rssync_ext_loss(self._h, _p(d), d.shape[0], _p(out), _p(g) if grad else None))
         return (out, g) if grad else out
 
+    def set_track_pixels(self, frame, frame_time_a, frame_time_b, points_a, points_b, lens, image_rows):
+        """Tracked pixel positions (n x 2 each) of one frame pair; undistortion, normalisation and
+        row times (core_testcode.cpp:135-158) happen on the device.  lens = (ro, fx, fy, cx, cy,
+        k1, k2, k3, k4)."""
+        a = np.ascontiguousarray(points_a, np.float64)
+        b = np.ascontiguousarray(points_b, np.float64)
+        if a.ndim != 2 or a.shape[1] != 2 or a.shape != b.shape:
+            raise ValueError("points_a / points_b must both be (n, 2)")
+        L = np.ascontiguousarray(lens, np.float64)
+        if L.shape != (9,):
+            raise ValueError("lens = (ro, fx, fy, cx, cy, k1, k2, k3, k4)")
+        self._check(self._lib.rssync_ext_set_track_pixels(self._h, int(frame), float(frame_time_a),
+                                                          float(frame_time_b), _p(a), _p(b), a.shape[0],
+                                                          L.ctypes.data, float(image_rows)))
+
+    def set_gyro_rates(self, timestamps_s, rates, orientation=None):
+        """Angular rates (n x 3, rad/s) at timestamps (s): integrated as the reference driver does
+        (core_testcode.cpp:36-52) and passed to the timestamped gyro setter."""
+        t = np.ascontiguousarray(timestamps_s, np.float64)
+        r = np.ascontiguousarray(rates, np.float64)
+        if r.ndim != 2 or r.shape[1] != 3 or t.shape != (r.shape[0],):
+            raise ValueError("rates must be (n, 3) and timestamps (n,)")
+        self._check(self._lib.rssync_ext_set_gyro_rates(self._h, _p(t), _p(r), r.shape[0],
+                                                        orientation.encode() if orientation else None))
+
+    def frame_rays(self, frame, cap=2048):
+        """The packed device streams of one frame: ({ax,bx,ay,by}, {az,bz,ta,tb}) as (n, 4) float32."""
+        a4, b4, n = np.zeros((cap, 4), np.float32), np.zeros((cap, 4), np.float32), C.c_size_t()
+        self._check(self._lib.rssync_ext_frame_rays(self._h, int(frame), a4.ctypes.data, b4.ctypes.data, cap,
+                                                    C.byref(n)))
+        return a4[:n.value].copy(), b4[:n.value].copy()
+
     def pre_sync_windows(self, initial_delay, frame_begins, frame_ends, search_step, search_radius):
         """PreSync on W windows [begin[w], end[w]) in one sweep -> (costs[W], delays[W])."""
         b = np.ascontiguousarray(frame_begins, np.int64)
@@ -337,7 +374,7 @@ class SyncProblem:
         self._check(self._lib.rssync_ext_profile_reset(self._h))
 
     def profile_get(self):
-        names = ["lmeds", "loss", "motion", "reduce", "init"]
+        names = ["lmeds", "loss", "motion", "reduce", "init", "pixels"]
         out = {}
         for i, nm in enumerate(names):
             n, ms = C.c_uint64(), C.c_double()

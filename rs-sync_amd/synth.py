@@ -199,6 +199,86 @@ def gyro_for_orientation(gyro, orientation):
     return integrate_gyro(r, np.full(r.shape[0], 1.0 / gyro.fs))
 
 
+# A GoPro-like fisheye preset in the reference's Lens fields (core_testcode.cpp:55-61):
+# (ro, fx, fy, cx, cy, k1, k2, k3, k4) for a 2704 x 1520 image.
+LENS = (READOUT, 1180.0, 1180.0, 1352.0, 760.0, 0.05, 0.01, -0.005, 0.001)
+IMAGE_ROWS, IMAGE_COLS = 1520, 2704
+
+
+def fisheye_distort(theta, lens):
+    """theta_d = theta + k1 theta^3 + k2 theta^5 + k3 theta^7 + k4 theta^9 (the forward model whose
+    inverse core_testcode.cpp:63-95 computes)."""
+    _, _, _, _, _, k1, k2, k3, k4 = lens
+    t2 = theta * theta
+    return theta * (1 + t2 * (k1 + t2 * (k2 + t2 * (k3 + t2 * k4))))
+
+
+def fisheye_undistort_angle(theta_d, lens, iters=40):
+    """Accurate inverse of fisheye_distort on (0, pi/2) (plain Newton with the true derivative)."""
+    _, _, _, _, _, k1, k2, k3, k4 = lens
+    th = np.array(theta_d, dtype=np.float64, copy=True)
+    for _ in range(iters):
+        t2 = th * th
+        f = th * (1 + t2 * (k1 + t2 * (k2 + t2 * (k3 + t2 * k4)))) - theta_d
+        df = 1 + t2 * (3 * k1 + t2 * (5 * k2 + t2 * (7 * k3 + t2 * 9 * k4)))
+        th = np.clip(th - f / df, 1e-12, np.pi / 2 - 1e-9)
+    return th
+
+
+def project(ray_cam, lens):
+    """camera-frame direction(s) (..., 3) with z > 0 -> distorted pixel position(s) (..., 2)"""
+    _, fx, fy, cx, cy = lens[:5]
+    r = np.linalg.norm(ray_cam[..., :2], axis=-1)
+    theta = np.arctan2(r, ray_cam[..., 2])
+    scale = np.where(r > 0, fisheye_distort(theta, lens) / np.where(r > 0, r, 1.0), 0.0)
+    return np.stack([fx * scale * ray_cam[..., 0] + cx, fy * scale * ray_cam[..., 1] + cy], axis=-1)
+
+
+def unproject(px, lens):
+    """distorted pixel position(s) (..., 2) -> unit camera-frame direction(s) (..., 3)"""
+    _, fx, fy, cx, cy = lens[:5]
+    x_ = (px[..., 0] - cx) / fx
+    y_ = (px[..., 1] - cy) / fy
+    td = np.hypot(x_, y_)
+    th = fisheye_undistort_angle(np.maximum(td, 1e-300), lens)
+    s = np.where(td > 0, np.sin(th) / np.where(td > 0, td, 1.0), 0.0)
+    return np.stack([s * x_, s * y_, np.cos(th)], axis=-1)
+
+
+def make_pixel_frames(gyro, frame_begin, frame_end, n_tracks, seed=0, d_true=D_TRUE, noise_px=0.3, outliers=0.10,
+                      lens=LENS, rows=IMAGE_ROWS, cols=IMAGE_COLS):
+    """Yield (frame, time_a, time_b, points_a, points_b): what the reference driver has after
+    optical flow and before undistortion (core_testcode.cpp:123-133) -- tracked pixel positions in
+    the current and the next video frame.  The row a point lies on sets its capture time
+    (frame_time + ro * y / rows, :144-145); the scene is the one make_frames uses."""
+    ro = lens[0]
+    for fr in range(frame_begin, frame_end):
+        rng = np.random.default_rng([seed, int(fr), 7])
+        u = rng.uniform(size=(5, n_tracks))
+        g = rng.normal(size=(2, n_tracks))
+        t_a, t_b = fr / FPS, (fr + 1) / FPS
+        pa = np.stack([0.05 * cols + 0.9 * cols * u[0], 0.05 * rows + 0.9 * rows * u[1]], axis=-1)
+        a_cam = unproject(pa, lens)
+        ts_a = t_a + ro * (pa[:, 1] / rows)
+        qa = gyro.orientation(ts_a + d_true)
+        depth = (2.0 + 48.0 * u[2])[:, None]
+        ang = 0.002 * fr + 0.7 * seed
+        tdir = np.array([np.cos(ang), np.sin(ang) * np.cos(0.3 * ang), np.sin(ang) * np.sin(0.3 * ang)])
+        b_world = depth * rotate_inv(qa, a_cam) - 0.05 * tdir
+        b_world /= np.linalg.norm(b_world, axis=-1, keepdims=True)
+        pb = pa.copy()
+        for _ in range(4):  # the row of the point in the next frame sets the time it is seen at
+            ts_b = t_b + ro * (pb[:, 1] / rows)
+            pb = project(rotate(gyro.orientation(ts_b + d_true), b_world), lens)
+        if noise_px > 0:
+            pb = pb + noise_px * g.T
+        if outliers > 0:
+            mask = u[3] < outliers
+            rnd = np.stack([cols * u[4], rows * rng.uniform(size=n_tracks)], axis=-1)
+            pb = np.where(mask[:, None], rnd, pb)
+        yield int(fr), t_a, t_b, pa, pb
+
+
 def fill(problem, gyro, frame_begin, frame_end, n_tracks, seed=0, **kw):
     """Feed one problem object (SyncProblem or the oracle mirror): same calls as the reference driver."""
     problem.SetGyroQuaternions(gyro.quats, gyro.fs, gyro.t0)

@@ -10,6 +10,7 @@
 // rs-sync_amd/ can load it.
 #include "../../include/rssync_hip.h"
 #include "../../rs-sync_amd/csrc/device_math.hpp"
+#include "../../rs-sync_amd/csrc/lens_math.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -121,7 +122,7 @@ int rship_upload_spline(rship_ctx* c, const float* coef16, uint32_t n_knots, dou
 int rship_upload_frames(rship_ctx* c, const float* a4, const float* b4, uint64_t total, const rship_frame* table, uint32_t nf) {
     c->rays_a.resize(total);
     c->rays_b.resize(total);
-    if (total) {
+    if (total && a4 && b4) {
         std::memcpy(c->rays_a.data(), a4, total * 16);
         std::memcpy(c->rays_b.data(), b4, total * 16);
     }
@@ -129,6 +130,44 @@ int rship_upload_frames(rship_ctx* c, const float* a4, const float* b4, uint64_t
     c->sel.clear();
     c->grp.clear();
     c->grp_off.assign(2, 0);
+    return 0;
+}
+
+// rays_from_pixels_kernel, one pair at a time (same header, same operations)
+int rship_rays_from_pixels(rship_ctx* c, const double* px, uint64_t n_pairs, const rship_pixel_frame* frames,
+                           uint32_t n_frames, uint32_t* bad) {
+    uint32_t nb = 0;
+    for (uint32_t fi = 0; fi < n_frames; ++fi) {
+        const rship_pixel_frame& fr = frames[fi];
+        if (fr.px_offset + fr.n_rays > n_pairs || (uint64_t)fr.ray_offset + fr.n_rays > c->rays_a.size())
+            return fail(c, "rays_from_pixels: frame exceeds a buffer");
+        const rs::Lens lens{fr.lens[0], fr.lens[1], fr.lens[2], fr.lens[3], fr.lens[4], fr.lens[5], fr.lens[6], fr.lens[7], fr.lens[8]};
+        for (uint32_t i = 0; i < fr.n_rays; ++i) {
+            const double* q = px + 4 * (fr.px_offset + i);
+            double ra[3], rb[3], tsa, tsb;
+            rs::pixel_to_ray(lens, q[0], q[1], fr.time_a, fr.rows, ra, &tsa);
+            rs::pixel_to_ray(lens, q[2], q[3], fr.time_b, fr.rows, rb, &tsb);
+            const f4 o0{(float)ra[0], (float)rb[0], (float)ra[1], (float)rb[1]};
+            const f4 o1{(float)ra[2], (float)rb[2], (float)rs::knot_offset(tsa, fr.start, fr.fs, fr.base),
+                        (float)rs::knot_offset(tsb, fr.start, fr.fs, fr.base)};
+            const float v[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+            bool ok = true;
+            for (float x : v) ok = ok && std::isfinite(x);
+            nb += ok ? 0u : 1u;
+            c->rays_a[fr.ray_offset + i] = o0;
+            c->rays_b[fr.ray_offset + i] = o1;
+        }
+    }
+    if (bad) *bad = nb;
+    return 0;
+}
+
+int rship_debug_rays(rship_ctx* c, uint32_t frame_index, float* a4, float* b4, uint32_t cap) {
+    if (frame_index >= c->frames.size()) return fail(c, "debug_rays: index out of range");
+    const rship_frame& fr = c->frames[frame_index];
+    if (fr.n_rays > cap) return fail(c, "debug_rays: output too small");
+    std::memcpy(a4, c->rays_a.data() + fr.ray_offset, (size_t)fr.n_rays * 16);
+    std::memcpy(b4, c->rays_b.data() + fr.ray_offset, (size_t)fr.n_rays * 16);
     return 0;
 }
 
