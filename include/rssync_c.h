@@ -129,6 +129,14 @@ int rssync_ext_set_track_pixels(rssync_problem* p, int64_t frame, double frame_t
  * orientation: telemetry-parser's three-letter axis string ("XYZ" = identity) or NULL. */
 int rssync_ext_set_gyro_rates(rssync_problem* p, const double* timestamps_s, const double* rates, size_t count,
                               const char* orientation);
+/* The driver's orientation-guessing sweep (core_testcode.cpp:186-224): for each orientation
+ * string, set_gyro_rates(orientation) then PreSync(initial_delay, frame_begin, frame_end, step,
+ * radius); costs[i] / delays[i] are that PreSync's result.  Host preparation of orientation i+1
+ * overlaps the GPU sweep of orientation i.  The last orientation stays installed. */
+int rssync_ext_orientation_sweep(rssync_problem* p, const double* timestamps_s, const double* rates, size_t count,
+                                 const char* const* orientations, int n_orientations, double initial_delay,
+                                 int64_t frame_begin, int64_t frame_end, double search_step, double search_radius,
+                                 double* costs, double* delays);
 /* the packed device ray streams of one frame ({ax,bx,ay,by} and {az,bz,ta,tb} per pair), for tests */
 int rssync_ext_frame_rays(rssync_problem* p, int64_t frame, float* a4, float* b4, size_t cap, size_t* n);
 

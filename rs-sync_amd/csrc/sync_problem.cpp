@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <limits>
 #include <map>
@@ -128,6 +129,9 @@ class SyncProblemHip final : public ISyncProblem {
     void SetTrackPixels(int64_t frame, double time_a, double time_b, const double* px_a, const double* px_b,
                         size_t count, const double lens[9], double image_rows);
     void SetGyroRates(const double* timestamps_s, const double* rates, size_t count, const char* orientation);
+    void orientation_sweep(const double* timestamps_s, const double* rates, size_t count,
+                           const std::vector<std::string>& orientations, double initial_delay, int64_t frame_begin,
+                           int64_t frame_end, double search_step, double search_radius, double* costs, double* delays);
     uint64_t seed = 0x5EED0000ULL;
     int max_outer = 400; // core_private.cpp:309
     bool verbose = true;
@@ -175,6 +179,7 @@ class SyncProblemHip final : public ISyncProblem {
     }
     void build_spline();
     void pack_frames();
+    void install_gyro(struct GyroGrid&& g, std::vector<float>* coef);
 
     double fs_ = 0, start_ = 0;
     std::vector<double> knots_; // 4 per sample, [w,x,y,z]
@@ -211,7 +216,14 @@ void SyncProblemHip::SetGyroQuaternions(const double* data, size_t count, double
 // core_private.cpp:142-190.  The grid is computed in the reference's integer types:
 // rate in micro-hertz and grid times in microseconds as uint64, first grid index by a
 // truncating division (the std::ceil at :152 is applied to an integer).
-void SyncProblemHip::SetGyroQuaternions(const int64_t* ts, const double* quats, size_t count) {
+static std::vector<float> spline_table(const std::vector<double>& knots);
+
+struct GyroGrid {
+    double fs = 0, start = 0;
+    std::vector<double> knots; // 4 per sample
+};
+
+static GyroGrid resample_timestamped(const int64_t* ts, const double* quats, size_t count) {
     constexpr uint64_t kUhzInHz = 1000000ULL, kUsInSec = 1000000ULL;
     if (count < 2) panic("set-gyro-quaternions: need at least 2 samples");
     const uint64_t actual_sr_uhz = kUhzInHz * kUsInSec * (uint64_t)count / (uint64_t)(ts[count - 1] - ts[0]);
@@ -226,7 +238,9 @@ void SyncProblemHip::SetGyroQuaternions(const int64_t* ts, const double* quats, 
             panic("set-gyro-quaternions:  timestamps out of order at pos " + std::to_string(i) + " (" +
                   std::to_string(ts[i - 1]) + " > " + std::to_string(ts[i]) + ")");
     if (grid.size() < 2) panic("set-gyro-quaternions: resampled grid has fewer than 2 points");
-    std::vector<double> nq(4 * grid.size());
+    GyroGrid out;
+    std::vector<double>& nq = out.knots;
+    nq.resize(4 * grid.size());
     for (size_t i = 0; i < grid.size(); ++i) {
         const uint64_t t = grid[i];
         // first sample whose (unsigned) timestamp is >= t
@@ -239,14 +253,28 @@ void SyncProblemHip::SetGyroQuaternions(const int64_t* ts, const double* quats, 
         }
         if (!all_finite(&nq[4 * i], 4)) panic("set-gyro-quaternions: non-finite sample after interpolation");
     }
-    const double new_fs = 1. * rounded_sr_hz, new_start = 1. * (double)grid[0] / (double)kUsInSec;
-    if (!std::isfinite(new_fs)) panic("set-gyro-quaternions: non-finite sample rate. wtf?");
-    if (!std::isfinite(new_start)) panic("set-gyro-quaternions: non-finite first timestamp. wtf?");
-    if (fs_ != new_fs || start_ != new_start) frames_dirty_ = true;
-    fs_ = new_fs;
-    start_ = new_start;
-    knots_.swap(nq);
+    out.fs = 1. * rounded_sr_hz;
+    out.start = 1. * (double)grid[0] / (double)kUsInSec;
+    if (!std::isfinite(out.fs)) panic("set-gyro-quaternions: non-finite sample rate. wtf?");
+    if (!std::isfinite(out.start)) panic("set-gyro-quaternions: non-finite first timestamp. wtf?");
+    return out;
+}
+
+void SyncProblemHip::SetGyroQuaternions(const int64_t* ts, const double* quats, size_t count) {
+    install_gyro(resample_timestamped(ts, quats, count), nullptr);
+}
+
+void SyncProblemHip::install_gyro(GyroGrid&& g, std::vector<float>* coef) {
+    if (fs_ != g.fs || start_ != g.start) frames_dirty_ = true;
+    fs_ = g.fs;
+    start_ = g.start;
+    knots_.swap(g.knots);
     spline_dirty_ = true;
+    if (coef) { // table already built (orientation sweep worker): upload it now
+        if (knots_.size() / 4 * 16 != coef->size()) panic("install-gyro: table size mismatch");
+        hip_check(rship_upload_spline(dev_, coef->data(), (uint32_t)(knots_.size() / 4), fs_), "upload spline");
+        spline_dirty_ = false;
+    }
 }
 
 // core_private.cpp:192-203; the data is copied before returning
@@ -304,7 +332,7 @@ void SyncProblemHip::SetTrackPixels(int64_t frame, double time_a, double time_b,
 // dq_i the rotation by rate_i over (t_i - t_{i-1}) (quat.cpp:5-17), timestamps truncated to whole
 // microseconds, then the timestamped setter.  `orientation` is telemetry-parser's three-letter
 // string (position = output axis, letter = input axis, upper case +, lower case -) or NULL.
-void SyncProblemHip::SetGyroRates(const double* ts, const double* rates, size_t count, const char* orientation) {
+static GyroGrid integrate_rates(const double* ts, const double* rates, size_t count, const char* orientation) {
     if (count < 2) panic("set-gyro-rates: need at least 2 samples");
     if (!all_finite(ts, count) || !all_finite(rates, 3 * count)) panic("set-gyro-rates: non-finite numbers");
     int axis[3] = {0, 1, 2};
@@ -343,7 +371,41 @@ void SyncProblemHip::SetGyroRates(const double* ts, const double* rates, size_t 
         for (int c = 0; c < 4; ++c) q[4 * i + c] = o[c] / nn;
     }
     for (size_t i = 0; i < count; ++i) us[i] = (int64_t)(ts[i] * 1000000); // :48-50
-    SetGyroQuaternions(us.data(), q.data(), count);
+    return resample_timestamped(us.data(), q.data(), count);
+}
+
+void SyncProblemHip::SetGyroRates(const double* ts, const double* rates, size_t count, const char* orientation) {
+    install_gyro(integrate_rates(ts, rates, count, orientation), nullptr);
+}
+
+// The orientation-guessing block of the reference driver (core_testcode.cpp:186-224): for each
+// candidate IMU orientation re-integrate the rates, replace the gyro (tracks stay) and PreSync;
+// the caller ranks the costs.  Integration, resampling and the spline solve of orientation i+1
+// run on a host thread while the GPU sweeps orientation i.  The last orientation stays installed.
+void SyncProblemHip::orientation_sweep(const double* ts, const double* rates, size_t count,
+                                       const std::vector<std::string>& orientations, double initial_delay,
+                                       int64_t frame_begin, int64_t frame_end, double search_step,
+                                       double search_radius, double* costs, double* delays) {
+    struct Prepared {
+        GyroGrid grid;
+        std::vector<float> coef;
+    };
+    auto prepare = [=](std::string o) {
+        Prepared p;
+        p.grid = integrate_rates(ts, rates, count, o.c_str());
+        p.coef = spline_table(p.grid.knots);
+        return p;
+    };
+    if (orientations.empty()) return;
+    std::future<Prepared> next = std::async(std::launch::async, prepare, orientations[0]);
+    for (size_t i = 0; i < orientations.size(); ++i) {
+        Prepared cur = next.get();
+        if (i + 1 < orientations.size()) next = std::async(std::launch::async, prepare, orientations[i + 1]);
+        install_gyro(std::move(cur.grid), &cur.coef);
+        const std::pair<double, double> r = PreSync(initial_delay, frame_begin, frame_end, search_step, search_radius);
+        costs[i] = r.first;
+        delays[i] = r.second;
+    }
 }
 
 // Natural cubic spline on unit-spaced knots, one per quaternion component
@@ -352,13 +414,13 @@ void SyncProblemHip::SetGyroRates(const double* ts, const double* rates, size_t 
 // solved by the Thomas recurrence in fp64, then d, b and the tail coefficients the
 // reference's extrapolation uses (minispline.cpp:43-44).  The table is rounded to fp32
 // once, here: 16 floats per knot = y[4], b[4], c[4], d[4].
-void SyncProblemHip::build_spline() {
-    const size_t n = knots_.size() / 4;
+static std::vector<float> spline_table(const std::vector<double>& knots) {
+    const size_t n = knots.size() / 4;
     if (n < 2) panic("sync: gyro data was not set");
     std::vector<float> coef(n * 16);
     std::vector<double> c(n), cp(n), y(n);
     for (int comp = 0; comp < 4; ++comp) {
-        for (size_t i = 0; i < n; ++i) y[i] = knots_[4 * i + comp];
+        for (size_t i = 0; i < n; ++i) y[i] = knots[4 * i + comp];
         // forward sweep on rows 1..n-2 (rows 0 and n-1 pin c to zero)
         cp[0] = 0.0;
         c[0] = 0.0;
@@ -389,7 +451,12 @@ void SyncProblemHip::build_spline() {
             d_prev = d;
         }
     }
-    hip_check(rship_upload_spline(dev_, coef.data(), (uint32_t)n, fs_), "upload spline");
+    return coef;
+}
+
+void SyncProblemHip::build_spline() {
+    std::vector<float> coef = spline_table(knots_);
+    hip_check(rship_upload_spline(dev_, coef.data(), (uint32_t)(knots_.size() / 4), fs_), "upload spline");
     spline_dirty_ = false;
 }
 
@@ -1105,6 +1172,18 @@ int rssync_ext_set_track_pixels(rssync_problem* p, int64_t frame, double frame_t
 int rssync_ext_set_gyro_rates(rssync_problem* p, const double* timestamps_s, const double* rates, size_t count,
                               const char* orientation) {
     return guarded([&] { p->impl->SetGyroRates(timestamps_s, rates, count, orientation); });
+}
+
+int rssync_ext_orientation_sweep(rssync_problem* p, const double* timestamps_s, const double* rates, size_t count,
+                                 const char* const* orientations, int n_orientations, double initial_delay,
+                                 int64_t frame_begin, int64_t frame_end, double search_step, double search_radius,
+                                 double* costs, double* delays) {
+    return guarded([&] {
+        std::vector<std::string> o;
+        for (int i = 0; i < n_orientations; ++i) o.emplace_back(orientations[i] ? orientations[i] : "XYZ");
+        p->impl->orientation_sweep(timestamps_s, rates, count, o, initial_delay, frame_begin, frame_end, search_step,
+                                   search_radius, costs, delays);
+    });
 }
 
 int rssync_ext_frame_rays(rssync_problem* p, int64_t frame, float* a4, float* b4, size_t cap, size_t* n) {

@@ -63,6 +63,8 @@ SIGNATURES = {
     "rssync_ext_set_track_pixels": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, _PD, _PD, C.c_size_t,
                                               C.c_void_p, C.c_double]),
     "rssync_ext_set_gyro_rates": (C.c_int, [C.c_void_p, _PD, _PD, C.c_size_t, C.c_char_p]),
+    "rssync_ext_orientation_sweep": (C.c_int, [C.c_void_p, _PD, _PD, C.c_size_t, C.POINTER(C.c_char_p), C.c_int,
+                                               C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_double, _PD, _PD]),
     "rssync_ext_frame_rays": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
                                         C.POINTER(C.c_size_t)]),
     "rssync_ext_pre_sync_windows": (C.c_int, [C.c_void_p, C.c_double, _PI64, _PI64, C.c_int, C.c_double, C.c_double,
@@ -305,6 +307,22 @@ class SyncProblem:
             raise ValueError("rates must be (n, 3) and timestamps (n,)")
         self._check(self._lib.rssync_ext_set_gyro_rates(self._h, _p(t), _p(r), r.shape[0],
                                                         orientation.encode() if orientation else None))
+
+    def orientation_sweep(self, timestamps_s, rates, orientations, initial_delay, frame_begin, frame_end,
+                          search_step, search_radius):
+        """core_testcode.cpp:186-224: PreSync under every candidate IMU orientation ->
+        (costs[n], delays[n]); the true orientation has the lowest cost."""
+        t = np.ascontiguousarray(timestamps_s, np.float64)
+        r = np.ascontiguousarray(rates, np.float64)
+        if r.ndim != 2 or r.shape[1] != 3 or t.shape != (r.shape[0],):
+            raise ValueError("rates must be (n, 3) and timestamps (n,)")
+        names = (C.c_char_p * len(orientations))(*[o.encode() for o in orientations])
+        costs, delays = np.zeros(len(orientations)), np.zeros(len(orientations))
+        self._check(self._lib.rssync_ext_orientation_sweep(self._h, _p(t), _p(r), r.shape[0], names,
+                                                           len(orientations), float(initial_delay), int(frame_begin),
+                                                           int(frame_end), float(search_step), float(search_radius),
+                                                           _p(costs), _p(delays)))
+        return costs, delays
 
     def frame_rays(self, frame, cap=2048):
         """The packed device streams of one frame: ({ax,bx,ay,by}, {az,bz,ta,tb}) as (n, 4) float32."""

@@ -133,3 +133,40 @@ def test_pixels_end_to_end_recover_the_true_delay(built):
     ch, dh = h.Sync(dh, 0, F - 1, 0.0, 0.2)
     co, do = o.Sync(do, 0, F - 1, 0.0, 0.2)
     assert abs(dh - synth.D_TRUE) < 1e-4 and abs(dh - do) < 1e-4
+
+
+def _check_orientation_sweep(make, F, N, margin, tol=0.004):
+    """rssync_ext_orientation_sweep == set_gyro_rates + PreSync per orientation (exactly), and the
+    orientation the rays were generated with has the lowest cost (core_testcode.cpp:186-232)."""
+    from rssync_amd import synth
+    g = synth.make_gyro(1.0, 1.0 + (F + 2) / synth.FPS, seed=77)   # t0 = 0: timestamps must be >= 0
+    frames = list(synth.make_frames(g, 30, 30 + F, N, seed=77))
+    names = list(synth.ORIENTATIONS[:9]) + ["XYZ"]
+    seq, bat = make(), make()
+    for p in (seq, bat):
+        for fr in frames:
+            p.SetTrackResult(*fr)
+    want = []
+    for name in names:
+        seq.set_gyro_rates(g.times, g.rates, name)
+        want.append(seq.PreSync(0.0, 30, 30 + F, 0.004, 0.1))
+    costs, delays = bat.orientation_sweep(g.times, g.rates, names, 0.0, 30, 30 + F, 0.004, 0.1)
+    for i in range(len(names)):
+        assert (costs[i], delays[i]) == want[i]
+    order = np.argsort(costs)
+    assert names[order[0]] == "XYZ" and costs[order[0]] < margin * costs[order[1]]
+    assert abs(delays[order[0]] - synth.D_TRUE) <= tol                  # grid step 4 ms
+    np.testing.assert_array_equal(bat.gyro_knots(), seq.gyro_knots())   # the last orientation stays installed
+    with pytest.raises(Exception, match="orientation"):
+        bat.orientation_sweep(g.times, g.rates, ["XYZ", "abc"], 0.0, 30, 30 + F, 0.004, 0.1)
+
+
+def test_orientation_sweep_on_the_host_solver(hosttest_lib, built):
+    import rssync_amd
+    _check_orientation_sweep(lambda: rssync_amd.SyncProblem(seed=SEED, _lib=hosttest_lib), 10, 64, 0.97, tol=0.0081)
+
+
+@pytest.mark.gpu
+def test_orientation_sweep_on_the_device(built):
+    import rssync_amd
+    _check_orientation_sweep(lambda: rssync_amd.SyncProblem(seed=SEED), 24, 256, 0.95)
