@@ -151,25 +151,46 @@ __device__ __forceinline__ void fetch_coef(const Spline& s, int ci, f4& y, f4& b
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// Knot index and in-knot fraction for the PreSync sweep's interior path: x = t + fd directly.
+// t >= 0 (offsets are relative to the frame's base knot) and 0 <= fd < 1, so truncation is floor
+// and v_fract is exact.  Compared with spline_locate_interior (fraction of t first, then + fd, then
+// wrap) this rounds the sum at the magnitude of t (< 64 knots): 4e-6 knots = 10 ns of delay at
+// 400 Hz, far below the sweep's grid -- and it is 4 VALU instead of 9 per ray.  Sync keeps the
+// precise form (its line search compares losses at delays a few ns apart).
+__device__ __forceinline__ rs::Knot locate_sweep(float t, int base, float fd) {
+    const float x = t + fd;
+    return rs::Knot{base + (int)x, __builtin_amdgcn_fractf(x), false};
+}
+
 // one row of P = ar x br (core_private.cpp:24-28) and, if DERIV, dP/dx (x in knots).
 // A = {ax,bx,ay,by}, B = {az,bz,ta,tb} as stored in HBM.
-template <bool DERIV, int PATH>
+template <bool DERIV, int PATH, bool SWEEP = false>
 __device__ __forceinline__ void residual_row(const Spline& s, f4 A, f4 B, int base, float fd, f3& P, f3& dP) {
     f4 ya, ba, ca, da, yb, bb, cb, db;
-    rs::Knot ka = (PATH == kPathInterior) ? rs::spline_locate_interior(B.z, base, fd) : rs::spline_locate(B.z, base, fd, s.n);
+    rs::Knot ka = (PATH == kPathInterior) ? (SWEEP ? locate_sweep(B.z, base, fd) : rs::spline_locate_interior(B.z, base, fd))
+                                          : rs::spline_locate(B.z, base, fd, s.n);
     fetch_coef<PATH>(s, ka.ci, ya, ba, ca, da);
-    rs::Knot kb = (PATH == kPathInterior) ? rs::spline_locate_interior(B.w, base, fd) : rs::spline_locate(B.w, base, fd, s.n);
+    rs::Knot kb = (PATH == kPathInterior) ? (SWEEP ? locate_sweep(B.w, base, fd) : rs::spline_locate_interior(B.w, base, fd))
+                                          : rs::spline_locate(B.w, base, fd, s.n);
     fetch_coef<PATH>(s, kb.ci, yb, bb, cb, db);
     if (!DERIV && PATH == kPathInterior) {
-        // hot path: Horner per end in scalar form, then both rotations at once in packed fp32
-        // (lane halves = the two ends of the pair; the interleaved ray layout and the Horner
-        // results land in adjacent registers, so no moves are needed): 56 VALU instead of 84
-        const f4 qa = rs::horner(ya, ba, ca, da, ka.h), qb = rs::horner(yb, bb, cb, db, kb.h);
-        const v2f qw = {qa.x, qb.x}, qx = {qa.y, qb.y}, qy = {qa.z, qb.z}, qz = {qa.w, qb.w};
+        // hot path, all in packed fp32.  Horner per end on the component pairs (w,x), (y,z) exactly as
+        // ds_read_b128 delivers them (same fma chain per component as rs::horner, so the values are
+        // bit-identical), four v_pk_mov to regroup by component across the two ends, then both
+        // rotations at once (lane halves = the two ends of the pair; the interleaved ray layout puts
+        // the ray components in adjacent registers already).
+        const v2f ha = {ka.h, ka.h}, hb = {kb.h, kb.h};
+        const v2f a01 = ((v2f{da.x, da.y} * ha + v2f{ca.x, ca.y}) * ha + v2f{ba.x, ba.y}) * ha + v2f{ya.x, ya.y};
+        const v2f a23 = ((v2f{da.z, da.w} * ha + v2f{ca.z, ca.w}) * ha + v2f{ba.z, ba.w}) * ha + v2f{ya.z, ya.w};
+        const v2f b01 = ((v2f{db.x, db.y} * hb + v2f{cb.x, cb.y}) * hb + v2f{bb.x, bb.y}) * hb + v2f{yb.x, yb.y};
+        const v2f b23 = ((v2f{db.z, db.w} * hb + v2f{cb.z, cb.w}) * hb + v2f{bb.z, bb.w}) * hb + v2f{yb.z, yb.w};
+        const v2f qw = __builtin_shufflevector(a01, b01, 0, 2), qx = __builtin_shufflevector(a01, b01, 1, 3);
+        const v2f qy = __builtin_shufflevector(a23, b23, 0, 2), qz = __builtin_shufflevector(a23, b23, 1, 3);
         const v2f vx = {A.x, A.y}, vy = {A.z, A.w}, vz = {B.x, B.y};
         const v2f n2 = qw * qw + qx * qx + qy * qy + qz * qz;
-        // R(q/|q|)^T v = v + (2/|q|^2) (u x (u x v) - w (u x v)), u = (qx,qy,qz)  (rs::rotate_inv)
-        const v2f sc = {n2.x > 0.f ? 2.f * rs::rcp_fast(n2.x) : 0.f, n2.y > 0.f ? 2.f * rs::rcp_fast(n2.y) : 0.f};
+        // R(q/|q|)^T v = v + (2/|q|^2) (u x (u x v) - w (u x v)), u = (qx,qy,qz)  (rs::rotate_inv);
+        // |q|^2 = 0 leaves v unchanged (u = 0 times a large finite factor)
+        const v2f sc = {2.f * rs::rcp_fast(fmaxf(n2.x, 1e-30f)), 2.f * rs::rcp_fast(fmaxf(n2.y, 1e-30f))};
         const v2f tx = qy * vz - qz * vy, ty = qz * vx - qx * vz, tz = qx * vy - qy * vx;
         const v2f ux = qy * tz - qz * ty, uy = qz * tx - qx * tz, uz = qx * ty - qy * tx;
         const v2f rx = vx + sc * (ux - qw * tx), ry = vy + sc * (uy - qw * ty), rz = vz + sc * (uz - qw * tz);
@@ -340,31 +361,29 @@ __device__ __forceinline__ uint32_t select_kth(const uint32_t (&r)[NR], uint32_t
 }
 
 // stage A of the LMedS kernel: this thread's rows of P for one delay, written to the LDS tile as
-// unit rows, norms kept in nrm[]; returns RSHIP_BAD_P if a row is not finite
-template <int PATH>
+// unit rows, norms kept in nrm[]; returns RSHIP_BAD_P if a row is not finite.  Rows >= N are not
+// touched: the kernel fills them with NaN once (their residuals compare above every threshold).
+template <int PATH, bool SWEEP>
 __device__ __forceinline__ uint32_t lmeds_row(const Spline& sp, const f4* __restrict__ rays_a,
                                               const f4* __restrict__ rays_b, uint32_t N, uint32_t row, int base, float fd,
                                               const Tile& tile, float& nrm) {
     uint32_t bad = 0;
-    // rows beyond N are NaN: their residuals compare above every threshold
-    float nx = __uint_as_float(0x7fc00000u), ny = nx, nz = nx;
     nrm = 0.f;
     if (row < N) {
         f3 P, dP;
-        residual_row<false, PATH>(sp, rays_a[row], rays_b[row], base, fd, P, dP);
+        residual_row<false, PATH, SWEEP>(sp, rays_a[row], rays_b[row], base, fd, P, dP);
         const float n2 = rs::dot(P, P);
         if (!finite_f(n2)) bad = RSHIP_BAD_P;
         // safe_normalize (core_private.cpp:35-36): rows with |P| < 1e-12 stay as they are
         const bool tiny = n2 < 1e-24f;
         const float inv = tiny ? 1.f : rs::rsqrt_fast(n2);
-        nx = P.x * inv; ny = P.y * inv; nz = P.z * inv;
+        tile.nx[row] = P.x * inv; tile.ny[row] = P.y * inv; tile.nz[row] = P.z * inv;
         nrm = tiny ? 1.f : n2 * inv;
     }
-    tile.nx[row] = nx; tile.ny[row] = ny; tile.nz[row] = nz;
     return bad;
 }
 
-template <int RPT>
+template <int RPT, bool SWEEP>
 __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const f4* __restrict__ rays_a,
                                                const f4* __restrict__ rays_b, uint32_t N, int base, float fd,
                                                const Tile& tile, float (&nrm)[RPT]) {
@@ -372,13 +391,13 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const f4* __res
     if (sp.path == kPathInterior) {
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
-            bad |= lmeds_row<kPathInterior>(sp, rays_a, rays_b, N, j * kBlock + threadIdx.x, base, fd, tile, nrm[j]);
+            bad |= lmeds_row<kPathInterior, SWEEP>(sp, rays_a, rays_b, N, j * kBlock + threadIdx.x, base, fd, tile, nrm[j]);
         }
     } else { // rare (ends of the gyro track, wild delays): keep the code small, not fast
         float tmp[RPT];
 #pragma unroll 1
         for (int j = 0; j < RPT; ++j)
-            bad |= lmeds_row<kPathGlobal>(sp, rays_a, rays_b, N, j * kBlock + threadIdx.x, base, fd, tile, tmp[j]);
+            bad |= lmeds_row<kPathGlobal, false>(sp, rays_a, rays_b, N, j * kBlock + threadIdx.x, base, fd, tile, tmp[j]);
 #pragma unroll
         for (int j = 0; j < RPT; ++j) nrm[j] = tmp[j];
     }
@@ -462,11 +481,16 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         stage_window(sp, s_win, fr.base_knot + (int)floorf(fr.tmin) + kd_lo,
                      fr.base_knot + (int)floorf(fr.tmax) + kd_hi + 1);
     }
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) { // rows beyond N: NaN once, never rewritten
+        const uint32_t row = j * kBlock + tid;
+        if (row >= N) s_n[0][row] = s_n[1][row] = s_n[2][row] = __uint_as_float(0x7fc00000u);
+    }
     __syncthreads();
 
-    const v2f* px = reinterpret_cast<const v2f*>(tile.nx);
-    const v2f* py = reinterpret_cast<const v2f*>(tile.ny);
-    const v2f* pz = reinterpret_cast<const v2f*>(tile.nz);
+    const f4* p4x = reinterpret_cast<const f4*>(tile.nx);
+    const f4* p4y = reinterpret_cast<const f4*>(tile.ny);
+    const f4* p4z = reinterpret_cast<const f4*>(tile.nz);
     uint32_t prev_best = kInfBits; // winning quantile of the previous candidate of this chunk
 
     for (uint32_t c = c0; c < c1; ++c) {
@@ -476,7 +500,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         uint32_t bad = 0;
         // ---- stage A: rows of P -> LDS tile as unit rows; norms stay in registers ----
         float nrm[RPT];
-        bad |= lmeds_rows<RPT>(sp, rays_a, rays_b, N, base, fd, tile, nrm);
+        bad |= lmeds_rows<RPT, MODE == 0>(sp, rays_a, rays_b, N, base, fd, tile, nrm);
 
         // ---- stage C: the hypotheses.  The best quantile of the previous candidate (x1.25: between
         // neighbouring candidates it moves by -20..+26 %, 1st..99th percentile) serves as a
@@ -504,14 +528,19 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                     const uint32_t h = batch + j;
                     const f4 hv = s_hyp[j];
                     // residuals r = nP v (core_private.cpp:48); |r| orders like the r^2 of :49-52
-                    uint32_t r2[NR]; // register 2m, 2m+1 <-> rows 2 (64 m + lane), +1
+                    uint32_t r2[NR]; // registers 4m..4m+3 <-> rows 4 (64 m + lane) .. +3
 #pragma unroll
-                    for (int m = 0; m < NR / 2; ++m) {
-                        if ((m & 3) == 0) __builtin_amdgcn_sched_barrier(0); // bound the LDS reads in flight
+                    for (int m = 0; m < NR / 4; ++m) {
+                        if ((m & 1) == 0) __builtin_amdgcn_sched_barrier(0); // bound the LDS reads in flight
                         const int idx = m * 64 + lane;
-                        const v2f r = px[idx] * hv.x + py[idx] * hv.y + pz[idx] * hv.z;
-                        r2[2 * m] = __float_as_uint(r.x);
-                        r2[2 * m + 1] = __float_as_uint(r.y);
+                        // ds_read_b128 per array: full LDS rate (ds_read2_b64 pairs run at half of it)
+                        const f4 x = p4x[idx], y = p4y[idx], z = p4z[idx];
+                        const v2f r01 = v2f{x.x, x.y} * hv.x + v2f{y.x, y.y} * hv.y + v2f{z.x, z.y} * hv.z;
+                        const v2f r23 = v2f{x.z, x.w} * hv.x + v2f{y.z, y.w} * hv.y + v2f{z.z, z.w} * hv.z;
+                        r2[4 * m] = __float_as_uint(r01.x);
+                        r2[4 * m + 1] = __float_as_uint(r01.y);
+                        r2[4 * m + 2] = __float_as_uint(r23.x);
+                        r2[4 * m + 3] = __float_as_uint(r23.y);
                     }
                     // (quantile_h, h) < (T, g)  <=>  more than kq |residuals| lie below T (+1 ulp if g > h):
                     // med < least_med of core_private.cpp:51-53 with the reference's first-wins tie rule
