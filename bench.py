@@ -161,16 +161,16 @@ def main():
         roof_valu = None
         if roof and (F, N, n_cand) == (4096, 2048, 800):
             try:
-                raw = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic_raw.json")))["lmeds_kernel<8, 0>"]
+                raw = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")))["lmeds_kernel<8, 0>"]
                 roof["traffic"] = round((2 * raw["FETCH_SIZE"]["mean_per_launch_KiB"] +
                                          raw["WRITE_SIZE"]["mean_per_launch_KiB"]) * 1024 / 1e9, 4)
-                roof["traffic_unit"] = "GB per launch (profiles/r1_pmc_traffic_raw.json)"
+                roof["traffic_unit"] = "GB per launch (profiles/r1_pmc_summary.json)"
                 insts = raw["SQ_INSTS_VALU"]["mean_per_launch"]
                 peak = 1024 * 2.4e9 / 4.43  # wave64 VALU instructions/s: tools/ubench/valu_rate.hip on MI355X
                 ach = insts / (roof["avg_launch_ms"] * 1e-3)
                 roof_valu = {"bound": "valu-issue", "kernel": "lmeds_kernel", "achieved": round(ach / 1e9, 2),
                              "peak": round(peak / 1e9, 2), "unit": "G wave-instr/s", "frac": round(ach / peak, 4),
-                             "note": "SQ_INSTS_VALU per launch from profiles/r1_pmc_traffic_raw.json over the live "
+                             "note": "SQ_INSTS_VALU per launch from profiles/r1_pmc_summary.json over the live "
                                      "launch time; peak = 1024 SIMDs x 2.4 GHz / 4.43 cycles per wave64 VALU "
                                      "instruction (measured, tools/ubench)"}
             except Exception:
