@@ -175,4 +175,53 @@ RS_HD float log1p_pos_fast(float u) {
 }
 RS_HD float loss_term(float pm, float inv_s) { return log1p_pos(pm * pm * inv_s); }
 
+// fp64 log1p(u) and 1/(1+u) for u >= 0 in one go, for the motion optimiser's objective and
+// gradient (core_private.cpp:99-114 in closed form).  libm's log1p plus an IEEE division are
+// ~150 instructions per row on the device; this is ~50 and accurate to a few ulp:
+//   w = 1 + u (its rounding error wl is carried to first order),  w = 2^e m,  m in [sqrt(1/2), sqrt(2)),
+//   log(m) = 2 atanh(s),  s = (m - 1)/(m + 1),  |s| <= 0.1716  (odd series in s up to s^19),
+//   log1p(u) = e ln2 + log(m) + wl / w.
+// Both 1/(m+1) and 1/m (hence 1/w) come from ONE reciprocal of m (m + 1), refined by two
+// Newton steps from the hardware seed.
+RS_HD double log1p_rcp_f64(double u, double* rc) {
+    const double w = 1.0 + u;
+    const double wl = u - (w - 1.0);
+#if defined(__HIP_DEVICE_COMPILE__)
+    double m = __builtin_amdgcn_frexp_mant(w); // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(w);
+#else
+    int e;
+    double m = frexp(w, &e);
+#endif
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double m1 = m + 1.0;
+    const double p = m * m1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double ip = __builtin_amdgcn_rcp(p);
+#else
+    double ip = (double)(1.0f / (float)p); // a seed of comparable quality to the hardware's
+#endif
+    ip = fma(fma(-p, ip, 1.0), ip, ip);
+    ip = fma(fma(-p, ip, 1.0), ip, ip);
+    const double inv_m = ip * m1, inv_m1 = ip * m;
+    const double sft = (m - 1.0) * inv_m1;
+    const double z = sft * sft;
+    double q = 1.0 / 19.0;
+    q = fma(q, z, 1.0 / 17.0);
+    q = fma(q, z, 1.0 / 15.0);
+    q = fma(q, z, 1.0 / 13.0);
+    q = fma(q, z, 1.0 / 11.0);
+    q = fma(q, z, 1.0 / 9.0);
+    q = fma(q, z, 1.0 / 7.0);
+    q = fma(q, z, 1.0 / 5.0);
+    q = fma(q, z, 1.0 / 3.0);
+    const double logm = fma(sft + sft, q * z, sft + sft);
+    const double r = ldexp(inv_m, -e); // 1 / w
+    *rc = r;
+    const double ed = (double)e;
+    return fma(ed, 6.93147180369123816490e-01, logm + fma(ed, 1.90821492927058770002e-10, wl * r));
+}
+
 } // namespace rs

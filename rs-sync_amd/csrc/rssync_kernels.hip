@@ -782,8 +782,8 @@ struct MotionEval {
             const double pm = fma(px, x[0], fma(py, x[1], pz * x[2]));
             const double v2 = pm * pm;
             const double u = v2 * inv_s;
-            L += log1p(u);
-            const double w = 1.0 / (1.0 + u);
+            double w; // 1 / (1 + u)
+            L += rs::log1p_rcp_f64(u, &w);
             const double a = w * 2.0 * pm * inv_s;
             a0 = fma(a, px, a0);
             a1 = fma(a, py, a1);

@@ -287,8 +287,9 @@ int rship_opt_motion(rship_ctx* c, const int32_t* kdv, const float* fdv, uint64_
             for (const f3& p : P) {
                 const double px = p.x, py = p.y, pz = p.z;
                 const double pm = px * x[0] + py * x[1] + pz * x[2], v2 = pm * pm, u = v2 * inv_s;
-                L += std::log1p(u);
-                const double w = 1.0 / (1.0 + u), a = w * 2.0 * pm * inv_s;
+                double w; // 1 / (1 + u), from the kernel's own fp64 routine
+                L += rs::log1p_rcp_f64(u, &w);
+                const double a = w * 2.0 * pm * inv_s;
                 a0 += a * px; a1 += a * py; a2 += a * pz;
                 gs += w * v2 * inv_s * inv_s;
             }
