@@ -176,7 +176,7 @@ __device__ __forceinline__ void residual_row(const Spline& s, f4 A, f4 B, int ba
     if (!DERIV && PATH == kPathInterior) {
         // hot path, all in packed fp32.  Horner per end on the component pairs (w,x), (y,z) exactly as
         // ds_read_b128 delivers them (same fma chain per component as rs::horner, so the values are
-        // bit-identical), four v_pk_mov to regroup by component across the two ends, then both
+        // bit-identical), eight moves to regroup by component across the two ends, then both
         // rotations at once (lane halves = the two ends of the pair; the interleaved ray layout puts
         // the ray components in adjacent registers already).
         const v2f ha = {ka.h, ka.h}, hb = {kb.h, kb.h};
@@ -184,6 +184,8 @@ __device__ __forceinline__ void residual_row(const Spline& s, f4 A, f4 B, int ba
         const v2f a23 = ((v2f{da.z, da.w} * ha + v2f{ca.z, ca.w}) * ha + v2f{ba.z, ba.w}) * ha + v2f{ya.z, ya.w};
         const v2f b01 = ((v2f{db.x, db.y} * hb + v2f{cb.x, cb.y}) * hb + v2f{bb.x, bb.y}) * hb + v2f{yb.x, yb.y};
         const v2f b23 = ((v2f{db.z, db.w} * hb + v2f{cb.z, cb.w}) * hb + v2f{bb.z, bb.w}) * hb + v2f{yb.z, yb.w};
+        // (eight v_mov_b32; the four v_pk_mov_b32 that would do the same made the kernel 17 % SLOWER
+        // on gfx950 -- measured, tools/ubench/pk_mov.hip documents the operand selection)
         const v2f qw = __builtin_shufflevector(a01, b01, 0, 2), qx = __builtin_shufflevector(a01, b01, 1, 3);
         const v2f qy = __builtin_shufflevector(a23, b23, 0, 2), qz = __builtin_shufflevector(a23, b23, 1, 3);
         const v2f vx = {A.x, A.y}, vy = {A.z, A.w}, vz = {B.x, B.y};
@@ -582,16 +584,16 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         if (!(finite_f(Mv.x) && finite_f(Mv.y) && finite_f(Mv.z))) bad |= RSHIP_BAD_M;
 
         // ---- stage D: k = clamp(100 / |P M|), cost = sqrt(sum sqrt(log1p(r^2))) ----
+        // Branch-free over the rows: a row beyond N has nrm = 0 but a NaN tile entry, so its
+        // product is replaced by 0 with one select; zeros then contribute nothing below.
         float pm[RPT];
         float ss = 0.f;
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const uint32_t row = j * kBlock + tid;
-            pm[j] = 0.f;
-            if (row < N) {
-                pm[j] = nrm[j] * rs::dot(f3{tile.nx[row], tile.ny[row], tile.nz[row]}, Mv);
-                ss = fmaf(pm[j], pm[j], ss);
-            }
+            const float v = nrm[j] * rs::dot(f3{tile.nx[row], tile.ny[row], tile.nz[row]}, Mv);
+            pm[j] = row < N ? v : 0.f;
+            ss = fmaf(pm[j], pm[j], ss);
         }
         double ss_tot = block_sum(ss, s_red[0]);
         float kf = 100.0f / sqrtf((float)ss_tot); // core_private.cpp:79
@@ -610,13 +612,12 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
             float acc = 0.f, rsum = 0.f;
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
-                const uint32_t row = j * kBlock + tid;
-                if (row < N) {
-                    const float r = pm[j] * sc;
-                    rsum += fabsf(r);
-                    const float rho = rs::log1p_pos_fast(r * r); // core_private.cpp:82
-                    acc += sqrtf(rho);
-                }
+                const float r = pm[j] * sc;
+                rsum += fabsf(r);
+                const float rho = rs::log1p_pos_fast(r * r); // core_private.cpp:82
+                // v_sqrt_f32 directly (1 ulp): libm's sqrtf adds range scaling for denormal inputs,
+                // whose square roots (< 1e-19) cannot change a sum of O(1) terms in fp32
+                acc += __builtin_amdgcn_sqrtf(rho);
             }
             if (!finite_f(rsum)) bad |= RSHIP_BAD_R;
             else if (!finite_f(acc)) bad |= RSHIP_BAD_RHO;
