@@ -1,0 +1,43 @@
+"""Single-rank RCCL run on the GPU box: the product library on cuda:0 with the reduce hook of
+bench.py's N>1 path (torch.distributed backend "nccl" = RCCL, staging tensor on the device).
+With one rank the all-reduce is the identity, so the results must equal a run without a hook."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    port, out = int(sys.argv[1]), sys.argv[2]
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    import rssync_amd
+    from rssync_amd import synth
+    from rssync_amd.dist import make_reduce_hook
+    F, N = 32, 128
+    gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=6)
+    res = {}
+    for name in ("plain", "rccl"):
+        p = rssync_amd.SyncProblem(seed=123, max_outer_iters=12)
+        synth.fill(p, gyro, 0, F, N, seed=6)
+        if name == "rccl":
+            hook = make_reduce_hook()          # picks the device from the backend
+            p.set_reduce_hook(hook)
+        c0, d0 = p.PreSync(0.0, 0, F, 0.004, 0.1)
+        c1, d1 = p.Sync(d0, 0, F - 1, 0.0, 0.2)
+        res[name] = [c0, d0, c1, d1, len(p.sync_trace())]
+    res["exchanges"] = hook.stats["calls"]
+    res["backend"] = dist.get_backend()
+    with open(out, "w") as f:
+        json.dump(res, f)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

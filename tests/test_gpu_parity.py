@@ -552,3 +552,24 @@ def test_sync_points_equal_the_driver_loop(small_case):
     costs, delays = bat.sync_points(pos, window, init, 0.002, 0.1, repeats=4)
     for w in range(len(pos)):
         assert (costs[w], delays[w]) == want[w]
+
+
+def test_rccl_reduce_hook_on_the_device(tmp_path):
+    """bench.py's multi-GPU exchange (torch.distributed "nccl" = RCCL, device staging tensor) with
+    one rank on this box: same results as without a hook, 1 + 2 per outer iteration + 1 exchanges."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "rccl.json"
+    subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_worker.py"), str(port), str(out)], check=True,
+                   timeout=300)
+    r = json.load(open(out))
+    assert r["backend"] == "nccl"
+    assert r["plain"] == r["rccl"]
+    assert r["exchanges"] == 1 + 2 * r["rccl"][4] + 1
