@@ -411,6 +411,7 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const f4* __res
 __host__ __device__ constexpr int lmeds_waves(int rpt) { return 5; }
 __host__ __device__ constexpr int loss_waves(int rpt, bool grad) { return (grad || rpt >= 8) ? 3 : 4; }
 
+constexpr int kMaxChunk = 32; // candidates per workgroup (rship: chunk <= kMaxChunk)
 constexpr int kHypBatch = 64; // hypothesis directions prepared per batch (one per lane of wave 0)
 
 // Pop the next index of an LDS work queue for the whole wave: lane 0 alone performs the atomic,
@@ -470,6 +471,14 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     const uint32_t c1 = (c0 + p.chunk < p.n_cand) ? c0 + p.chunk : p.n_cand;
     if (c0 >= c1) return;
 
+    // the chunk's delays, staged once: a scalar load per candidate would put an L2 round trip at
+    // the head of every stage A
+    __shared__ int s_kd[kMaxChunk];
+    __shared__ float s_fd[kMaxChunk];
+    if ((uint32_t)tid < c1 - c0) {
+        s_kd[tid] = p.kd[(c0 + tid) * p.n_grp + g];
+        s_fd[tid] = p.fd[(c0 + tid) * p.n_grp + g];
+    }
     Spline sp;
     sp.g = p.coef;
     sp.n = p.n_knots;
@@ -496,8 +505,8 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     uint32_t prev_best = kInfBits; // winning quantile of the previous candidate of this chunk
 
     for (uint32_t c = c0; c < c1; ++c) {
-        const int base = fr.base_knot + p.kd[c * p.n_grp + g];
-        const float fd = p.fd[c * p.n_grp + g];
+        const int base = fr.base_knot + s_kd[c - c0];
+        const float fd = s_fd[c - c0];
         const uint32_t stream = p.stream_base + c + g * p.stream_stride; // g != 0 only for batched GuessMotion
         uint32_t bad = 0;
         // ---- stage A: rows of P -> LDS tile as unit rows; norms stay in registers ----
@@ -596,7 +605,8 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
             ss = fmaf(pm[j], pm[j], ss);
         }
         double ss_tot = block_sum(ss, s_red[0]);
-        float kf = 100.0f / sqrtf((float)ss_tot); // core_private.cpp:79
+        // core_private.cpp:79, 100 / ||P M|| as 100 * rsq (v_rsq_f32, 1 ulp); ss = 0 gives +inf -> clamp
+        float kf = 100.0f * rs::rsqrt_fast((float)ss_tot);
         kf = (kf < 10.f) ? 10.f : ((1000.f < kf) ? 1000.f : kf);
         if (MODE == 1) {
             if (tid == 0) {
@@ -606,7 +616,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                 p.k[sf] = (double)kf;
             }
         } else {
-            float sc = kf / sqrtf(rs::dot(Mv, Mv)); // core_private.cpp:80
+            float sc = kf * rs::rsqrt_fast(rs::dot(Mv, Mv)); // core_private.cpp:80
             // a non-finite r or rho (core_private.cpp:81,83) makes the sums non-finite: NaN propagates
             // and all terms are >= 0, so the checks are made once on the sums, not per row
             float acc = 0.f, rsum = 0.f;
@@ -628,7 +638,10 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
             }
         }
         if (bad) atomicOr(p.flags, bad);
-        __syncthreads(); // tile and key are rewritten by the next candidate
+        // No barrier here.  What the next candidate overwrites before its first barrier is (a) this
+        // thread's own tile rows and (b) s_key, by thread 0: every reader of s_key reads it before
+        // the workgroup sum barrier of stage D, which thread 0 has passed by then.  s_hyp, s_next
+        // and the sum slots are rewritten only after further barriers of the next candidate.
     }
 }
 
@@ -1435,7 +1448,7 @@ int rship_presync_window_costs(rship_ctx* c, const int32_t* kd, const float* fd,
     uint64_t work = (uint64_t)n_cand * ns;
     uint32_t chunk = (uint32_t)(work / 8192);
     if (chunk < 1) chunk = 1;
-    if (chunk > 32) chunk = 32;
+    if (chunk > (uint32_t)kMaxChunk) chunk = kMaxChunk;
     if (chunk > n_cand) chunk = n_cand;
     p.chunk = chunk;
     p.n_chunks = (n_cand + chunk - 1) / chunk;
