@@ -1,7 +1,7 @@
 """Full-size (BASELINE config 3) Sync: HIP path vs oracle on identical inputs."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import rssync_amd
 from rssync_amd import synth
 from oracle.oracle import OracleProblem

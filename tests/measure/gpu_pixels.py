@@ -2,7 +2,7 @@
 and the host route it replaces (CPU undistort -> SetTrackResult -> host packing).  GPU box."""
 import os, sys, time, json
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import rssync_amd
 from rssync_amd import synth
 from oracle import oracle

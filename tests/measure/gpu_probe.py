@@ -5,7 +5,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import rssync_amd  # noqa: E402
 from rssync_amd import synth  # noqa: E402
 from oracle.oracle import OracleProblem  # noqa: E402

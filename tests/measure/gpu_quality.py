@@ -2,7 +2,7 @@
 fit, RMSE (python/plot_sync.py) -- for the HIP library and, on the same inputs, the CPU oracle."""
 import os, sys, json, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import rssync_amd
 from rssync_amd import synth, quality
 from oracle.oracle import OracleProblem
