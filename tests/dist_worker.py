@@ -30,8 +30,15 @@ def main():
     c0, d0 = p.PreSync(0.0, 0, F, 0.004, 0.1)
     n_pre = hook.stats["calls"]
     c1, d1 = p.Sync(d0, 0, F - 1, 0.0, 0.2)
-    res = dict(rank=rank, frames=[b, e], presync=[c0, d0], sync=[c1, d1], iters=len(p.sync_trace()),
-               presync_exchanges=n_pre, sync_exchanges=hook.stats["calls"] - n_pre)
+    n_sync = hook.stats["calls"] - n_pre
+    iters = len(p.sync_trace())
+    # the batched driver loop on sharded frames: windows straddle the two ranks' blocks
+    pos = [0, 3, 6, 9]
+    costs, delays = p.sync_points(pos, 6, 0.02, 0.004, 0.04, repeats=2)
+    res = dict(rank=rank, frames=[b, e], presync=[c0, d0], sync=[c1, d1], iters=iters,
+               presync_exchanges=n_pre, sync_exchanges=n_sync,
+               points=[list(map(float, costs)), list(map(float, delays))],
+               points_iters=[len(p.window_trace(w)) for w in range(len(pos))])
     with open(out, "w") as f:
         json.dump(res, f)
     dist.barrier()

@@ -38,14 +38,23 @@ def test_two_ranks_equal_one(hosttest_lib, tmp_path):
     synth.fill(one, gyro, 0, F, N, seed=6, noise=0.0, outliers=0.0)
     c0, d0 = one.PreSync(0.0, 0, F, 0.004, 0.1)
     c1, d1 = one.Sync(d0, 0, F - 1, 0.0, 0.2)
+    n_iters = len(one.sync_trace())
     assert res[0]["frames"] == [0, 8] and res[1]["frames"] == [8, 16]
     for r in res:
         assert r["presync"][1] == d0                       # same arg-min on every rank
         assert r["presync"][0] == pytest.approx(c0, rel=1e-12)
         assert r["sync"][1] == pytest.approx(d1, abs=1e-9)
         assert r["sync"][0] == pytest.approx(c1, rel=1e-9)
-        assert r["iters"] == len(one.sync_trace())
+        assert r["iters"] == n_iters
         assert r["presync_exchanges"] == 1                 # one all-reduce for the whole sweep
         assert r["sync_exchanges"] == 2 * r["iters"] + 1   # <= 2 per outer iteration + final loss
     assert res[0]["sync"] == res[1]["sync"]                # replicated optimiser state
     assert abs(d1 - synth.D_TRUE) < 1e-4
+    # sync points on sharded frames == unsharded (windows cross the shard boundary at frame 8)
+    costs, delays = one.sync_points([0, 3, 6, 9], 6, 0.02, 0.004, 0.04, repeats=2)
+    iters = [len(one.window_trace(w)) for w in range(4)]
+    for r in res:
+        assert r["points_iters"] == iters
+        assert r["points"][1] == pytest.approx(list(delays), abs=1e-9)
+        assert r["points"][0] == pytest.approx(list(costs), rel=1e-9)
+    assert res[0]["points"] == res[1]["points"]
