@@ -573,3 +573,28 @@ def test_rccl_reduce_hook_on_the_device(tmp_path):
     assert r["backend"] == "nccl"
     assert r["plain"] == r["rccl"]
     assert r["exchanges"] == 1 + 2 * r["rccl"][4] + 1
+
+
+def test_high_rate_gyro_uses_the_general_spline_path():
+    """A 3.2 kHz gyro: one frame spans ~140 knots, more than the LDS window (64), so every kernel
+    takes the general path (table from L2, per-lane branch logic).  Same checks as at 400 Hz."""
+    import rssync_amd
+    from rssync_amd import synth
+    from oracle.oracle import OracleProblem
+    F, N = 24, 200
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, fs=3200.0, seed=21)
+    frames = list(synth.make_frames(g, 0, F, N, seed=21, noise=0.0, outliers=0.0))
+    h = rssync_amd.SyncProblem(seed=SEED)
+    o = OracleProblem(seed=SEED, threads=min(os.cpu_count() or 1, 16), faithful=False)
+    for p in (h, o):
+        p.SetGyroQuaternions(g.quats, g.fs, g.t0)
+        for fr in frames:
+            p.SetTrackResult(*fr)
+    Ph = h.problem_matrix(5, 0.0371, N)
+    assert np.abs(Ph - o.problem_matrix(5, 0.0371)).max() < 5e-7
+    ch, dh = h.PreSync(0.0, 0, F, 0.002, 0.1)
+    co, do = o.PreSync(0.0, 0, F, 0.002, 0.1)
+    assert dh == do and ch == pytest.approx(co, rel=5e-3)    # noise-free: see __graft_entry__.smoke
+    c2h, d2h = h.Sync(dh, 0, F - 1, 0.0, 0.1)
+    c2o, d2o = o.Sync(do, 0, F - 1, 0.0, 0.1)
+    assert abs(d2h - d2o) < 1e-4 and abs(d2h - synth.D_TRUE) < 1e-4
