@@ -191,6 +191,9 @@ def main():
             "presync_ms_per_step": t_pre / args.steps * 1e3,
             "result": result, "host": {"gen_s": round(t_gen, 2), "pack_upload_s": round(t_up, 3)},
         }
+        if cpu:
+            # reported for context only: the roofline fraction, not this ratio, says how good the kernels are
+            out["gpu_over_cpu"] = round(value / world / cpu["value"], 1)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
