@@ -1263,6 +1263,22 @@ int launch_reduce(rship_ctx* c, const double* in, double* out, uint32_t rows, ui
     return 0;
 }
 
+// Every entry point works on the context's device, whatever the calling thread's current device
+// is (a host with several GPUs in one process), and leaves the caller's choice as it found it.
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(const rship_ctx* c) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != c->device) (void)hipSetDevice(c->device);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 int check_ready(rship_ctx* c) {
     if (!c->n_knots) return set_err(c, "no gyro spline uploaded");
     if (!c->n_frames) return set_err(c, "no frames uploaded");
@@ -1298,6 +1314,7 @@ int rship_create(rship_ctx** out, int device) {
 
 void rship_destroy(rship_ctx* c) {
     if (!c) return;
+    DeviceGuard dev_guard(c);
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
@@ -1314,12 +1331,14 @@ void rship_destroy(rship_ctx* c) {
 const char* rship_last_error(const rship_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 int rship_set_stream(rship_ctx* c, void* hip_stream) {
+    DeviceGuard dev_guard(c);
     RS_HIP(hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return 0;
 }
 
 int rship_upload_spline(rship_ctx* c, const float* coef16, uint32_t n_knots, double sample_rate) {
+    DeviceGuard dev_guard(c);
     if (n_knots < 2) return set_err(c, "spline: need >= 2 knots");
     size_t bytes = (size_t)n_knots * 64;
     if (ensure(c, c->coef, bytes)) return 1;
@@ -1332,6 +1351,7 @@ int rship_upload_spline(rship_ctx* c, const float* coef16, uint32_t n_knots, dou
 
 int rship_upload_frames(rship_ctx* c, const float* rays_a4, const float* rays_b4, uint64_t total_rays,
                         const rship_frame* table, uint32_t n_frames) {
+    DeviceGuard dev_guard(c);
     c->n_frames = 0;
     c->n_sel = 0;
     c->h_sel.clear();
@@ -1360,6 +1380,7 @@ int rship_upload_frames(rship_ctx* c, const float* rays_a4, const float* rays_b4
 // the same frame may appear in several slots, slots of one group are contiguous, and the
 // per-frame Sync state (M, k) is kept per slot.
 int rship_select_slots(rship_ctx* c, const uint32_t* idx, uint32_t n, const uint32_t* grp_off, uint32_t n_grp) {
+    DeviceGuard dev_guard(c);
     for (uint32_t i = 0; i < n; ++i)
         if (idx[i] >= c->n_frames) return set_err(c, "select: frame index out of range");
     if (n_grp < 1) n_grp = 1;
@@ -1405,6 +1426,7 @@ int rship_presync_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32
 int rship_presync_window_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand, uint32_t n_hyp,
                                uint32_t stream_base, uint64_t seed, const uint32_t* seg_idx, const uint32_t* seg_off,
                                uint32_t n_win, double* costs, uint32_t* flags, double* frame_costs, int32_t* best_h) {
+    DeviceGuard dev_guard(c);
     if (check_ready(c)) return 1;
     if (c->n_grp != 1) return set_err(c, "presync: the selection must not be grouped");
     if (!n_cand) return 0;
@@ -1503,6 +1525,7 @@ void fill_motion(rship_ctx* c, MotionParams& p) {
 // kd/fd: one delay per group of the selection
 int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_hyp, uint32_t stream,
                       uint32_t stream_stride, uint64_t seed) {
+    DeviceGuard dev_guard(c);
     if (check_ready(c)) return 1;
     if (upload_delays(c, kd, fd, c->n_grp) || ensure(c, c->flags, 16)) return 1;
     RS_HIP(hipMemsetAsync(c->flags.p, 0, 16, c->stream));
@@ -1534,6 +1557,7 @@ int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t
 }
 
 int rship_opt_motion_detail(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t* per_frame, uint32_t cap) {
+    DeviceGuard dev_guard(c);
     if (check_ready(c)) return 1;
     if (cap < c->n_sel) return set_err(c, "opt_motion_detail: output too small");
     DevBuf d;
@@ -1554,6 +1578,7 @@ int rship_opt_motion_detail(rship_ctx* c, const int32_t* kd, const float* fd, ui
 }
 
 int rship_opt_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint64_t* stats) {
+    DeviceGuard dev_guard(c);
     if (check_ready(c)) return 1;
     if (ensure(c, c->stats, 16)) return 1;
     RS_HIP(hipMemsetAsync(c->stats.p, 0, 16, c->stream));
@@ -1574,6 +1599,7 @@ int rship_opt_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint64_t*
 
 // kd/fd: [n_delays][n_grp]; loss/grad out: [n_delays][n_grp]
 int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_delays, double* loss, double* grad) {
+    DeviceGuard dev_guard(c);
     if (check_ready(c)) return 1;
     if (!n_delays) return 0;
     const uint32_t ns = c->n_sel, ng = c->n_grp;
@@ -1613,6 +1639,7 @@ int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_dela
 }
 
 int rship_get_motion(rship_ctx* c, double* M, double* k, uint32_t cap, uint32_t* n) {
+    DeviceGuard dev_guard(c);
     if (sync_stream(c)) return 1;
     uint32_t cnt = c->n_sel < cap ? c->n_sel : cap;
     if (cnt) {
@@ -1624,6 +1651,7 @@ int rship_get_motion(rship_ctx* c, double* M, double* k, uint32_t cap, uint32_t*
 }
 
 int rship_set_motion(rship_ctx* c, const double* M, const double* k, uint32_t n) {
+    DeviceGuard dev_guard(c);
     if (n != c->n_sel) return set_err(c, "set_motion: count differs from the selection");
     if (sync_stream(c)) return 1;
     if (n) {
@@ -1635,6 +1663,7 @@ int rship_set_motion(rship_ctx* c, const double* M, const double* k, uint32_t n)
 
 int rship_rays_from_pixels(rship_ctx* c, const double* px, uint64_t n_pairs, const rship_pixel_frame* frames,
                            uint32_t n_frames, uint32_t* bad) {
+    DeviceGuard dev_guard(c);
     if (bad) *bad = 0;
     if (!n_frames) return 0;
     uint32_t max_n = 0;
@@ -1673,6 +1702,7 @@ int rship_rays_from_pixels(rship_ctx* c, const double* px, uint64_t n_pairs, con
 }
 
 int rship_debug_rays(rship_ctx* c, uint32_t frame_index, float* a4, float* b4, uint32_t cap_rays) {
+    DeviceGuard dev_guard(c);
     if (frame_index >= c->n_frames) return set_err(c, "debug_rays: index out of range");
     rship_frame rec;
     hipError_t e = hipMemcpy(&rec, (const rship_frame*)c->frames.p + frame_index, sizeof(rec), hipMemcpyDeviceToHost);
@@ -1685,6 +1715,7 @@ int rship_debug_rays(rship_ctx* c, uint32_t frame_index, float* a4, float* b4, u
 }
 
 int rship_debug_problem(rship_ctx* c, uint32_t sel_index, int32_t kd, float fd, float* P, float* dP, uint32_t cap_rows) {
+    DeviceGuard dev_guard(c);
     if (check_ready(c)) return 1;
     if (sel_index >= c->n_sel) return set_err(c, "debug_problem: index out of range");
     uint32_t fi = c->h_sel[sel_index];
@@ -1716,6 +1747,7 @@ int rship_debug_problem(rship_ctx* c, uint32_t sel_index, int32_t kd, float fd, 
 
 int rship_debug_select(rship_ctx* c, const float* vals, uint32_t n_problems, uint32_t n, uint32_t kq,
                        const float* upper, uint32_t* out) {
+    DeviceGuard dev_guard(c);
     if (n > 2048 || !n_problems) return set_err(c, "debug_select: bad sizes");
     DevBuf dv, du, dout;
     if (ensure(c, dv, (size_t)n_problems * n * 4) || ensure(c, dout, (size_t)n_problems * 8)) return 1;
