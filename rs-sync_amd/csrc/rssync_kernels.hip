@@ -1092,6 +1092,15 @@ struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
 };
+// a device allocation that lives for one call (freed on every return path)
+struct TempBuf : DevBuf {
+    TempBuf() = default;
+    TempBuf(const TempBuf&) = delete;
+    TempBuf& operator=(const TempBuf&) = delete;
+    ~TempBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
 
 struct rship_ctx {
     int device = 0;
@@ -1560,7 +1569,7 @@ int rship_opt_motion_detail(rship_ctx* c, const int32_t* kd, const float* fd, ui
     DeviceGuard dev_guard(c);
     if (check_ready(c)) return 1;
     if (cap < c->n_sel) return set_err(c, "opt_motion_detail: output too small");
-    DevBuf d;
+    TempBuf d;
     if (ensure(c, d, (size_t)c->n_sel * 8 + 8)) return 1;
     RS_HIP(hipMemsetAsync(d.p, 0, (size_t)c->n_sel * 8 + 8, c->stream));
     if (upload_delays(c, kd, fd, c->n_grp)) return 1;
@@ -1571,7 +1580,6 @@ int rship_opt_motion_detail(rship_ctx* c, const int32_t* kd, const float* fd, ui
     hipError_t e = hipStreamSynchronize(c->stream);
     prof_collect(c);
     if (!rc && e == hipSuccess) e = hipMemcpy(per_frame, d.p, (size_t)c->n_sel * 8, hipMemcpyDeviceToHost);
-    (void)hipFree(d.p);
     if (rc) return 1;
     if (e != hipSuccess) return set_err(c, "opt_motion_detail", e);
     return 0;
@@ -1674,7 +1682,7 @@ int rship_rays_from_pixels(rship_ctx* c, const double* px, uint64_t n_pairs, con
         max_n = std::max(max_n, f.n_rays);
     }
     if (!max_n) return 0;
-    DevBuf dpx, dfr, dbad;
+    TempBuf dpx, dfr, dbad;
     if (ensure(c, dpx, (size_t)n_pairs * 32 + 32) || ensure(c, dfr, (size_t)n_frames * sizeof(rship_pixel_frame)) ||
         ensure(c, dbad, 16))
         return 1;
@@ -1693,9 +1701,6 @@ int rship_rays_from_pixels(rship_ctx* c, const double* px, uint64_t n_pairs, con
     if (e == hipSuccess) e = hipMemcpyAsync(&nb, dbad.p, 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     prof_collect(c);
-    (void)hipFree(dpx.p);
-    (void)hipFree(dfr.p);
-    (void)hipFree(dbad.p);
     if (e != hipSuccess) return set_err(c, "rays_from_pixels", e);
     if (bad) *bad = nb;
     return 0;
@@ -1721,7 +1726,7 @@ int rship_debug_problem(rship_ctx* c, uint32_t sel_index, int32_t kd, float fd, 
     uint32_t fi = c->h_sel[sel_index];
     uint32_t n = c->h_frame_n[fi];
     if (n > cap_rows) return set_err(c, "debug_problem: output too small");
-    DevBuf out;
+    TempBuf out;
     if (ensure(c, out, (size_t)n * 24 + 64)) return 1;
     DebugParams p{};
     p.rays_a = (const f4*)c->rays_a.p;
@@ -1740,7 +1745,6 @@ int rship_debug_problem(rship_ctx* c, uint32_t sel_index, int32_t kd, float fd, 
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(P, out.p, (size_t)n * 12, hipMemcpyDeviceToHost);
     if (e == hipSuccess && dP) e = hipMemcpy(dP, (float*)out.p + (size_t)n * 3, (size_t)n * 12, hipMemcpyDeviceToHost);
-    (void)hipFree(out.p);
     if (e != hipSuccess) return set_err(c, "debug_problem", e);
     return 0;
 }
@@ -1749,7 +1753,7 @@ int rship_debug_select(rship_ctx* c, const float* vals, uint32_t n_problems, uin
                        const float* upper, uint32_t* out) {
     DeviceGuard dev_guard(c);
     if (n > 2048 || !n_problems) return set_err(c, "debug_select: bad sizes");
-    DevBuf dv, du, dout;
+    TempBuf dv, du, dout;
     if (ensure(c, dv, (size_t)n_problems * n * 4) || ensure(c, dout, (size_t)n_problems * 8)) return 1;
     if (upper && ensure(c, du, (size_t)n_problems * 4)) return 1;
     hipError_t e = hipMemcpy(dv.p, vals, (size_t)n_problems * n * 4, hipMemcpyHostToDevice);
@@ -1761,9 +1765,6 @@ int rship_debug_select(rship_ctx* c, const float* vals, uint32_t n_problems, uin
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(out, dout.p, (size_t)n_problems * 8, hipMemcpyDeviceToHost);
-    (void)hipFree(dv.p);
-    (void)hipFree(dout.p);
-    if (du.p) (void)hipFree(du.p);
     if (e != hipSuccess) return set_err(c, "debug_select", e);
     return 0;
 }

@@ -145,3 +145,37 @@ int main() {
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", str(exe), str(src)])
     worst, worst_rc = map(float, subprocess.check_output([str(exe)], text=True).split())
     assert worst < 1e-15 and worst_rc < 5e-16
+
+
+def test_c_headers_are_valid_c99(tmp_path):
+    """include/rssync_c.h and include/rssync_hip.h are consumed by C hosts (cgo, JNI glue): they
+    must compile as plain C99, and a C client must link against the library."""
+    import rssync_amd
+    src = tmp_path / "client.c"
+    src.write_text(r'''
+#include "rssync_c.h"
+#include "rssync_hip.h"
+#include <stdio.h>
+int main(void) {
+    rssync_set_panic_mode(1);
+    rssync_problem* p = rssync_create();          /* NULL here: no GPU, no CPU fallback */
+    rssync_lens lens = {0.011, 1000, 1000, 500, 400, 0, 0, 0, 0};
+    (void)lens;
+    printf("%s|%d\n", p ? "created" : rssync_last_error(), rship_max_tracks());
+    rssync_destroy(p);
+    return 0;
+}
+''')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+    libdir = os.path.dirname(rssync_amd.library_path())
+    exe = tmp_path / "client"
+    subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lrssync_core",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    import torch
+    out = subprocess.run([str(exe)], capture_output=True, text=True, cwd=tmp_path)
+    assert out.returncode == 0
+    msg, tracks = out.stdout.strip().rsplit("|", 1)
+    assert tracks == "2048"
+    if not torch.cuda.is_available():
+        assert "no usable HIP device" in msg and "no CPU fallback" in msg
