@@ -1114,8 +1114,10 @@ struct rship_ctx {
     double fs = 0;
     std::vector<uint32_t> h_frame_n; // per table frame
     std::vector<uint32_t> h_sel;
+    std::vector<uint32_t> h_delays; // staging of upload_delays
+    const float* d_fd = nullptr;    // device address of the fd half of the last upload
     // scratch
-    DevBuf kd, fd, frame_cost, best_h, costs, part, flags, stats;
+    DevBuf kd, frame_cost, best_h, costs, part, flags, stats;
     void* pinned = nullptr;
     size_t pinned_cap = 0;
     // profiling
@@ -1288,6 +1290,17 @@ struct DeviceGuard {
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
+// kd[n] then fd[n] in one device buffer, staged through the host so that it is ONE copy per call
+// (the Sync loop uploads delays three times per outer iteration; API calls are what it waits for)
+int upload_delays(rship_ctx* c, const int32_t* kd, const float* fd, size_t n) {
+    if (ensure(c, c->kd, n * 8)) return 1;
+    c->h_delays.resize(2 * n);
+    memcpy(c->h_delays.data(), kd, n * 4);
+    memcpy(c->h_delays.data() + n, fd, n * 4);
+    RS_HIP(hipMemcpyAsync(c->kd.p, c->h_delays.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+    c->d_fd = (const float*)((const int32_t*)c->kd.p + n);
+    return 0;
+}
 int check_ready(rship_ctx* c) {
     if (!c->n_knots) return set_err(c, "no gyro spline uploaded");
     if (!c->n_frames) return set_err(c, "no frames uploaded");
@@ -1328,7 +1341,7 @@ void rship_destroy(rship_ctx* c) {
     prof_collect(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->coef, &c->rays_a, &c->rays_b, &c->frames, &c->sel, &c->M, &c->k, &c->grp, &c->grp_off,
-                      &c->seg_idx, &c->seg_off, &c->kd, &c->fd,
+                      &c->seg_idx, &c->seg_off, &c->kd,
                       &c->frame_cost, &c->best_h, &c->costs, &c->part, &c->flags, &c->stats};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -1441,7 +1454,6 @@ int rship_presync_window_costs(rship_ctx* c, const int32_t* kd, const float* fd,
     if (!n_cand) return 0;
     if (n_win < 1) n_win = 1;
     const uint32_t ns = c->n_sel;
-    if (ensure(c, c->kd, (size_t)n_cand * 4) || ensure(c, c->fd, (size_t)n_cand * 4)) return 1;
     if (ensure(c, c->frame_cost, (size_t)n_cand * ns * 8) || ensure(c, c->costs, (size_t)n_cand * n_win * 8)) return 1;
     if (best_h && ensure(c, c->best_h, (size_t)n_cand * ns * 4)) return 1;
     if (ensure(c, c->flags, 16)) return 1;
@@ -1457,8 +1469,7 @@ int rship_presync_window_costs(rship_ctx* c, const int32_t* kd, const float* fd,
         d_idx = seg_idx ? (const uint32_t*)c->seg_idx.p : nullptr;
         d_off = (const uint32_t*)c->seg_off.p;
     }
-    RS_HIP(hipMemcpyAsync(c->kd.p, kd, (size_t)n_cand * 4, hipMemcpyHostToDevice, c->stream));
-    RS_HIP(hipMemcpyAsync(c->fd.p, fd, (size_t)n_cand * 4, hipMemcpyHostToDevice, c->stream));
+    if (upload_delays(c, kd, fd, n_cand)) return 1;
     RS_HIP(hipMemsetAsync(c->flags.p, 0, 16, c->stream));
 
     LmedsParams p{};
@@ -1470,7 +1481,7 @@ int rship_presync_window_costs(rship_ctx* c, const int32_t* kd, const float* fd,
     p.coef = (const f4*)c->coef.p;
     p.n_knots = (int)c->n_knots;
     p.kd = (const int32_t*)c->kd.p;
-    p.fd = (const float*)c->fd.p;
+    p.fd = c->d_fd;
     p.n_cand = n_cand;
     p.grp = nullptr;
     p.n_grp = 1;
@@ -1509,12 +1520,6 @@ int rship_presync_window_costs(rship_ctx* c, const int32_t* kd, const float* fd,
 
 namespace {
 // per-group delays -> device (kd/fd arrays of n entries)
-int upload_delays(rship_ctx* c, const int32_t* kd, const float* fd, size_t n) {
-    if (ensure(c, c->kd, n * 4) || ensure(c, c->fd, n * 4)) return 1;
-    RS_HIP(hipMemcpyAsync(c->kd.p, kd, n * 4, hipMemcpyHostToDevice, c->stream));
-    RS_HIP(hipMemcpyAsync(c->fd.p, fd, n * 4, hipMemcpyHostToDevice, c->stream));
-    return 0;
-}
 void fill_motion(rship_ctx* c, MotionParams& p) {
     p.rays_a = (const f4*)c->rays_a.p;
     p.rays_b = (const f4*)c->rays_b.p;
@@ -1524,7 +1529,7 @@ void fill_motion(rship_ctx* c, MotionParams& p) {
     p.coef = (const f4*)c->coef.p;
     p.n_knots = (int)c->n_knots;
     p.kd = (const int32_t*)c->kd.p;
-    p.fd = (const float*)c->fd.p;
+    p.fd = c->d_fd;
     p.grp = c->n_grp > 1 ? (const uint32_t*)c->grp.p : nullptr;
     p.M = (double*)c->M.p;
     p.k = (const double*)c->k.p;
@@ -1547,7 +1552,7 @@ int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t
     p.coef = (const f4*)c->coef.p;
     p.n_knots = (int)c->n_knots;
     p.kd = (const int32_t*)c->kd.p;
-    p.fd = (const float*)c->fd.p;
+    p.fd = c->d_fd;
     p.n_cand = 1;
     p.chunk = 1;
     p.n_chunks = 1;
@@ -1588,12 +1593,14 @@ int rship_opt_motion_detail(rship_ctx* c, const int32_t* kd, const float* fd, ui
 int rship_opt_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint64_t* stats) {
     DeviceGuard dev_guard(c);
     if (check_ready(c)) return 1;
-    if (ensure(c, c->stats, 16)) return 1;
-    RS_HIP(hipMemsetAsync(c->stats.p, 0, 16, c->stream));
+    if (stats) {
+        if (ensure(c, c->stats, 16)) return 1;
+        RS_HIP(hipMemsetAsync(c->stats.p, 0, 16, c->stream));
+    }
     if (upload_delays(c, kd, fd, c->n_grp)) return 1;
     MotionParams p{};
     fill_motion(c, p);
-    p.stats = (unsigned long long*)c->stats.p;
+    p.stats = stats ? (unsigned long long*)c->stats.p : nullptr;
     if (launch_motion(c, p, rpt_for(c->max_n))) return 1;
     if (stats) {
         if (ensure_pinned(c, 16)) return 1;
@@ -1612,7 +1619,7 @@ int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_dela
     if (!n_delays) return 0;
     const uint32_t ns = c->n_sel, ng = c->n_grp;
     if (upload_delays(c, kd, fd, (size_t)n_delays * ng)) return 1;
-    if (ensure(c, c->part, (size_t)n_delays * ns * 16) || ensure(c, c->costs, (size_t)n_delays * ng * 16)) return 1;
+    if (ensure(c, c->part, (size_t)n_delays * ns * 16)) return 1;
     LossParams p{};
     p.rays_a = (const f4*)c->rays_a.p;
     p.rays_b = (const f4*)c->rays_b.p;
@@ -1623,7 +1630,7 @@ int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_dela
     p.n_knots = (int)c->n_knots;
     p.fs = (float)c->fs;
     p.kd = (const int32_t*)c->kd.p;
-    p.fd = (const float*)c->fd.p;
+    p.fd = c->d_fd;
     p.n_delays = n_delays;
     p.grp = ng > 1 ? (const uint32_t*)c->grp.p : nullptr;
     p.n_grp = ng;
@@ -1635,11 +1642,14 @@ int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_dela
     if (grad ? launch_loss<true>(c, p, rpt) : launch_loss<false>(c, p, rpt)) return 1;
     // rows [0, n_delays) = loss, [n_delays, 2 n_delays) = grad; one sum per (row, group)
     uint32_t rows = grad ? 2 * n_delays : n_delays;
-    if (launch_reduce(c, p.part_loss, (double*)c->costs.p, rows, ns, nullptr, ng > 1 ? (const uint32_t*)c->grp_off.p : nullptr, ng))
-        return 1;
+    // the few sums go straight into pinned host memory (visible once the stream has drained):
+    // one API call less per evaluation than a device buffer + copy
     const size_t half = (size_t)n_delays * ng * 8;
     if (ensure_pinned(c, (size_t)rows * ng * 8)) return 1;
-    RS_HIP(hipMemcpyAsync(c->pinned, c->costs.p, (size_t)rows * ng * 8, hipMemcpyDeviceToHost, c->stream));
+    void* d_out = nullptr;
+    RS_HIP(hipHostGetDevicePointer(&d_out, c->pinned, 0));
+    if (launch_reduce(c, p.part_loss, (double*)d_out, rows, ns, nullptr, ng > 1 ? (const uint32_t*)c->grp_off.p : nullptr, ng))
+        return 1;
     if (sync_stream(c)) return 1;
     memcpy(loss, c->pinned, half);
     if (grad) memcpy(grad, (char*)c->pinned + half, half);
