@@ -669,6 +669,22 @@ struct LossParams {
 };
 
 // this thread's rows of one frame at one delay: sum of log1p(u) and of the d/d-delay terms
+template <bool GRAD, int PATH>
+__device__ __forceinline__ void loss_row(const Spline& sp, f4 A, f4 B, int base, float fd, f3 Mv, float inv_s, float& L,
+                                         float& G) {
+    f3 P, dP;
+    residual_row<GRAD, PATH>(sp, A, B, base, fd, P, dP);
+    const float pm = rs::dot(P, Mv);
+    const float u = pm * pm * inv_s;
+    L += rs::log1p_pos(u); // core_private.cpp:121-122
+    if (GRAD) {
+        // dL/dd = sum 1/(1+u) * (2 pm / s) * (dP/dd . M), dP/dd = fs * dP/dx
+        const float w = rs::rcp_fast(1.f + u);
+        G = fmaf(w * 2.f * pm * inv_s, rs::dot(dP, Mv), G);
+    }
+}
+
+// this thread's rows of one frame at one delay, rays read from memory (single-delay launches)
 template <int RPT, bool GRAD, int PATH>
 __device__ __forceinline__ void loss_rows(const Spline& sp, const f4* __restrict__ rays_a,
                                           const f4* __restrict__ rays_b, uint32_t N, int base, float fd, f3 Mv,
@@ -676,18 +692,18 @@ __device__ __forceinline__ void loss_rows(const Spline& sp, const f4* __restrict
 #pragma unroll 1
     for (int j = 0; j < RPT; ++j) {
         const uint32_t row = j * kBlock + threadIdx.x;
-        if (row < N) {
-            f3 P, dP;
-            residual_row<GRAD, PATH>(sp, rays_a[row], rays_b[row], base, fd, P, dP);
-            const float pm = rs::dot(P, Mv);
-            const float u = pm * pm * inv_s;
-            L += rs::log1p_pos(u); // core_private.cpp:121-122
-            if (GRAD) {
-                // dL/dd = sum 1/(1+u) * (2 pm / s) * (dP/dd . M), dP/dd = fs * dP/dx
-                const float w = rs::rcp_fast(1.f + u);
-                G = fmaf(w * 2.f * pm * inv_s, rs::dot(dP, Mv), G);
-            }
-        }
+        if (row < N) loss_row<GRAD, PATH>(sp, rays_a[row], rays_b[row], base, fd, Mv, inv_s, L, G);
+    }
+}
+
+// the same with the rays already in registers (batches of delays: the line search's ten trials)
+template <int RPT, bool GRAD, int PATH>
+__device__ __forceinline__ void loss_rows_cached(const Spline& sp, const f4 (&ra)[RPT], const f4 (&rb)[RPT], uint32_t N,
+                                                 int base, float fd, f3 Mv, float inv_s, float& L, float& G) {
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        const uint32_t row = j * kBlock + threadIdx.x;
+        if (row < N) loss_row<GRAD, PATH>(sp, ra[j], rb[j], base, fd, Mv, inv_s, L, G);
     }
 }
 
@@ -701,10 +717,21 @@ __global__ __launch_bounds__(kBlock, loss_waves(RPT, GRAD)) void loss_kernel(Los
     const FrameRec fr = p.frames[fi];
     const uint32_t N = fr.n;
 
-    // each delay of the batch re-reads the frame's rays; only the first read comes from
-    // HBM, the rest from L2 (the frame is 32 B x N, far below one XCD's 4 MiB)
     const f4* __restrict__ rays_a = p.rays_a + fr.off;
     const f4* __restrict__ rays_b = p.rays_b + fr.off;
+    // A batch of delays (no gradient: the ten backtracking trials) keeps this thread's rays in
+    // registers, 8 floats per row: re-reading the frame per delay made that launch bound by the
+    // L2/Infinity-Cache side (2.4 GB for 268 MB of rays), not by its arithmetic.
+    constexpr bool kCache = !GRAD;
+    f4 ra[kCache ? RPT : 1], rb[kCache ? RPT : 1];
+    if (kCache) {
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const uint32_t row = j * kBlock + tid;
+            ra[j] = row < N ? rays_a[row] : f4{0.f, 0.f, 0.f, 0.f};
+            rb[j] = row < N ? rays_b[row] : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     const uint32_t g = p.grp ? p.grp[sf] : 0u;
     const double Mx = p.M[3 * sf], My = p.M[3 * sf + 1], Mz = p.M[3 * sf + 2], kk = p.k[sf];
     const f3 Mv = f3{(float)Mx, (float)My, (float)Mz};
@@ -729,8 +756,13 @@ __global__ __launch_bounds__(kBlock, loss_waves(RPT, GRAD)) void loss_kernel(Los
         __syncthreads();
         const int base = fr.base_knot + kd;
         float L = 0.f, G = 0.f;
-        if (sp.path == kPathInterior) loss_rows<RPT, GRAD, kPathInterior>(sp, rays_a, rays_b, N, base, fd, Mv, inv_s, L, G);
-        else loss_rows<RPT, GRAD, kPathGlobal>(sp, rays_a, rays_b, N, base, fd, Mv, inv_s, L, G);
+        if (kCache) {
+            if (sp.path == kPathInterior) loss_rows_cached<kCache ? RPT : 1, GRAD, kPathInterior>(sp, ra, rb, N, base, fd, Mv, inv_s, L, G);
+            else loss_rows_cached<kCache ? RPT : 1, GRAD, kPathGlobal>(sp, ra, rb, N, base, fd, Mv, inv_s, L, G);
+        } else {
+            if (sp.path == kPathInterior) loss_rows<RPT, GRAD, kPathInterior>(sp, rays_a, rays_b, N, base, fd, Mv, inv_s, L, G);
+            else loss_rows<RPT, GRAD, kPathGlobal>(sp, rays_a, rays_b, N, base, fd, Mv, inv_s, L, G);
+        }
         double Lw = wave_sum_f64((double)L);
         double Gw = GRAD ? wave_sum_f64((double)G) : 0.0;
         if (lane == 0) {
