@@ -1,6 +1,6 @@
 // device_math.hpp -- per-ray arithmetic of the rs-sync hot path in fp32.
 //
-// These are the functions the gfx950 kernels inline (rssync_kernels.hip).  They
+// These are the functions the gfx950 kernels inline (kernels/*.hpp).  They
 // are marked RS_HD so that tests/ can also compile them with g++ and compare
 // them with the fp64 oracle on the CPU before anything is launched on a GPU;
 // the product only ever runs them on the device.

@@ -1,0 +1,194 @@
+// common.hpp -- launch constants, wave/workgroup reductions, the LDS spline window, one row of the residual matrix
+// Part of the single HIP translation unit rssync_kernels.hip (included there, in order).
+#pragma once
+
+namespace {
+
+
+constexpr int kBlock = 256;
+constexpr int kWinMax = 64;  // knots of the spline staged in LDS per workgroup
+constexpr uint32_t kInfBits = 0x7f800000u;
+
+// ---------------------------------------------------------------------------
+// wave64 / workgroup reductions.  DPP row shifts + row broadcasts (gfx9 forms):
+// after the six steps lane 63 holds the wave total.
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
+    int v = (int)x;
+    v += dpp_i<0x111, 0xf>(v); // row_shr:1
+    v += dpp_i<0x112, 0xf>(v); // row_shr:2
+    v += dpp_i<0x114, 0xf>(v); // row_shr:4
+    v += dpp_i<0x118, 0xf>(v); // row_shr:8
+    v += dpp_i<0x142, 0xa>(v); // row_bcast:15 -> rows 1,3
+    v += dpp_i<0x143, 0xc>(v); // row_bcast:31 -> rows 2,3
+    return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v += dpp_f<0x111, 0xf>(v);
+    v += dpp_f<0x112, 0xf>(v);
+    v += dpp_f<0x114, 0xf>(v);
+    v += dpp_f<0x118, 0xf>(v);
+    v += dpp_f<0x142, 0xa>(v);
+    v += dpp_f<0x143, 0xc>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_d<0x111, 0xf>(v);
+    v += dpp_d<0x112, 0xf>(v);
+    v += dpp_d<0x114, 0xf>(v);
+    v += dpp_d<0x118, 0xf>(v);
+    v += dpp_d<0x142, 0xa>(v);
+    v += dpp_d<0x143, 0xc>(v);
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// workgroup sum of a per-thread fp32 partial: fp32 inside the wave, fp64 across
+// the four waves.  `slot` is a 4-double LDS scratch that the caller must not reuse before another
+// barrier has passed (one barrier here).
+__device__ __forceinline__ double block_sum(float v, double* slot) {
+    float w = wave_sum_f32(v);
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = (double)w;
+    __syncthreads();
+    return slot[0] + slot[1] + slot[2] + slot[3];
+}
+
+__device__ __forceinline__ bool finite_f(float x) { return (__float_as_uint(x) & kInfBits) != kInfBits; }
+
+// ---------------------------------------------------------------------------
+// spline window in LDS: SoA by coefficient kind so that neighbouring knots
+// fall into different banks (ds_read_b128 of kind k, knot j at (k*kWinMax + j) * 16 B).
+
+struct Spline {
+    const f4* __restrict__ g; // global table, 4 f4 per knot
+    const f4* lds;            // [4][kWinMax]
+    int n;                    // knots
+    int w0, wlen;             // staged range [w0, w0 + wlen)
+    int path;                 // kPathGlobal / kPathLds / kPathInterior, uniform over the workgroup
+};
+
+// How a workgroup reads spline coefficients.  The choice is made once per workgroup from the knot
+// range it can touch, so that the hot loops carry no per-lane LDS-or-global selection (which
+// would turn ds_read_b128 into flat loads) and, in the common case, no extrapolation logic.
+constexpr int kPathGlobal = 0;   // general: any parameter (extrapolation branches included), table read from L2
+constexpr int kPathInterior = 2; // staged in LDS and strictly inside the knots (0 <= idx <= n-2)
+
+__device__ __forceinline__ void stage_window(Spline& s, f4* s_win, int lo, int hi) {
+    const int n = s.n;
+    const bool interior = lo >= 0 && hi <= n - 2;
+    lo = lo < 0 ? 0 : (lo > n - 1 ? n - 1 : lo);
+    hi = hi < 0 ? 0 : (hi > n - 1 ? n - 1 : hi);
+    int wlen = hi - lo + 1;
+    s.path = (wlen <= kWinMax && interior) ? kPathInterior : kPathGlobal;
+    if (wlen > kWinMax) wlen = kWinMax;
+    s.w0 = lo;
+    s.wlen = wlen;
+    s.lds = s_win;
+    for (int e = threadIdx.x; e < wlen * 4; e += kBlock) {
+        int knot = e >> 2, kind = e & 3;
+        s_win[kind * kWinMax + knot] = s.g[(size_t)(lo + knot) * 4 + kind];
+    }
+}
+
+template <int PATH>
+__device__ __forceinline__ void fetch_coef(const Spline& s, int ci, f4& y, f4& b, f4& c, f4& d) {
+    if (PATH == kPathGlobal) {
+        const f4* p = s.g + (size_t)ci * 4;
+        y = p[0]; b = p[1]; c = p[2]; d = p[3];
+    } else {
+        const int rel = ci - s.w0;
+        y = s.lds[rel];
+        b = s.lds[kWinMax + rel];
+        c = s.lds[2 * kWinMax + rel];
+        d = s.lds[3 * kWinMax + rel];
+    }
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Knot index and in-knot fraction for the PreSync sweep's interior path: x = t + fd directly.
+// t >= 0 (offsets are relative to the frame's base knot) and 0 <= fd < 1, so truncation is floor
+// and v_fract is exact.  Compared with spline_locate_interior (fraction of t first, then + fd, then
+// wrap) this rounds the sum at the magnitude of t (< 64 knots): 4e-6 knots = 10 ns of delay at
+// 400 Hz, far below the sweep's grid -- and it is 4 VALU instead of 9 per ray.  Sync keeps the
+// precise form (its line search compares losses at delays a few ns apart).
+__device__ __forceinline__ rs::Knot locate_sweep(float t, int base, float fd) {
+    const float x = t + fd;
+    return rs::Knot{base + (int)x, __builtin_amdgcn_fractf(x), false};
+}
+
+// one row of P = ar x br (core_private.cpp:24-28) and, if DERIV, dP/dx (x in knots).
+// A = {ax,bx,ay,by}, B = {az,bz,ta,tb} as stored in HBM.
+template <bool DERIV, int PATH, bool SWEEP = false>
+__device__ __forceinline__ void residual_row(const Spline& s, f4 A, f4 B, int base, float fd, f3& P, f3& dP) {
+    f4 ya, ba, ca, da, yb, bb, cb, db;
+    rs::Knot ka = (PATH == kPathInterior) ? (SWEEP ? locate_sweep(B.z, base, fd) : rs::spline_locate_interior(B.z, base, fd))
+                                          : rs::spline_locate(B.z, base, fd, s.n);
+    fetch_coef<PATH>(s, ka.ci, ya, ba, ca, da);
+    rs::Knot kb = (PATH == kPathInterior) ? (SWEEP ? locate_sweep(B.w, base, fd) : rs::spline_locate_interior(B.w, base, fd))
+                                          : rs::spline_locate(B.w, base, fd, s.n);
+    fetch_coef<PATH>(s, kb.ci, yb, bb, cb, db);
+    if (!DERIV && PATH == kPathInterior) {
+        // hot path, all in packed fp32.  Horner per end on the component pairs (w,x), (y,z) exactly as
+        // ds_read_b128 delivers them (same fma chain per component as rs::horner, so the values are
+        // bit-identical), eight moves to regroup by component across the two ends, then both
+        // rotations at once (lane halves = the two ends of the pair; the interleaved ray layout puts
+        // the ray components in adjacent registers already).
+        const v2f ha = {ka.h, ka.h}, hb = {kb.h, kb.h};
+        const v2f a01 = ((v2f{da.x, da.y} * ha + v2f{ca.x, ca.y}) * ha + v2f{ba.x, ba.y}) * ha + v2f{ya.x, ya.y};
+        const v2f a23 = ((v2f{da.z, da.w} * ha + v2f{ca.z, ca.w}) * ha + v2f{ba.z, ba.w}) * ha + v2f{ya.z, ya.w};
+        const v2f b01 = ((v2f{db.x, db.y} * hb + v2f{cb.x, cb.y}) * hb + v2f{bb.x, bb.y}) * hb + v2f{yb.x, yb.y};
+        const v2f b23 = ((v2f{db.z, db.w} * hb + v2f{cb.z, cb.w}) * hb + v2f{bb.z, bb.w}) * hb + v2f{yb.z, yb.w};
+        // (eight v_mov_b32; the four v_pk_mov_b32 that would do the same made the kernel 17 % SLOWER
+        // on gfx950 -- measured, tools/ubench/pk_mov.hip documents the operand selection)
+        const v2f qw = __builtin_shufflevector(a01, b01, 0, 2), qx = __builtin_shufflevector(a01, b01, 1, 3);
+        const v2f qy = __builtin_shufflevector(a23, b23, 0, 2), qz = __builtin_shufflevector(a23, b23, 1, 3);
+        const v2f vx = {A.x, A.y}, vy = {A.z, A.w}, vz = {B.x, B.y};
+        const v2f n2 = qw * qw + qx * qx + qy * qy + qz * qz;
+        // R(q/|q|)^T v = v + (2/|q|^2) (u x (u x v) - w (u x v)), u = (qx,qy,qz)  (rs::rotate_inv);
+        // |q|^2 = 0 leaves v unchanged (u = 0 times a large finite factor)
+        const v2f sc = {2.f * rs::rcp_fast(fmaxf(n2.x, 1e-30f)), 2.f * rs::rcp_fast(fmaxf(n2.y, 1e-30f))};
+        const v2f tx = qy * vz - qz * vy, ty = qz * vx - qx * vz, tz = qx * vy - qy * vx;
+        const v2f ux = qy * tz - qz * ty, uy = qz * tx - qx * tz, uz = qx * ty - qy * tx;
+        const v2f rx = vx + sc * (ux - qw * tx), ry = vy + sc * (uy - qw * ty), rz = vz + sc * (uz - qw * tz);
+        P = f3{ry.x * rz.y - rz.x * ry.y, rz.x * rx.y - rx.x * rz.y, rx.x * ry.y - ry.x * rx.y}; // ar x br
+    } else {
+        f3 ar, br, dar, dbr;
+        rs::rotate_ray<DERIV>(ya, ba, ca, da, ka, f3{A.x, A.z, B.x}, ar, dar);
+        rs::rotate_ray<DERIV>(yb, bb, cb, db, kb, f3{A.y, A.w, B.y}, br, dbr);
+        P = rs::cross(ar, br);
+        if (DERIV) dP = rs::add(rs::cross(dar, br), rs::cross(ar, dbr));
+    }
+}
+
+struct FrameRec { // == rship_frame
+    uint32_t off, n;
+    int32_t base_knot;
+    float tmin, tmax;
+    uint32_t reserved;
+    int64_t id;
+};
+static_assert(sizeof(FrameRec) == sizeof(rship_frame), "frame record layout");
+
+} // namespace

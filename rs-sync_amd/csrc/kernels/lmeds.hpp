@@ -1,0 +1,437 @@
+// lmeds.hpp -- K2: the LMedS tile kernel (PreSync sweep; GuessMotion/GuessK in INIT mode)
+// Part of the single HIP translation unit rssync_kernels.hip (included there, in order).
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// K2: LMedS tile kernel
+
+struct LmedsParams {
+    const f4* rays_a;
+    const f4* rays_b;
+    const FrameRec* frames;
+    const uint32_t* sel;
+    uint32_t n_sel;
+    const f4* coef;
+    int n_knots;
+    const int32_t* kd;
+    const float* fd;
+    uint32_t n_cand, chunk, n_chunks;
+    uint32_t n_hyp, stream_base, stream_stride; // sampler stream = base + candidate + group * stride
+    uint64_t seed;
+    const uint32_t* grp; // slot -> group (window) or null; delays are indexed [candidate][group]
+    uint32_t n_grp;      // >= 1
+    double* frame_cost; // [n_cand][n_sel]
+    int32_t* best_h;    // [n_cand][n_sel] or null
+    double* M;          // INIT mode: per selection slot [3]
+    double* k;          // INIT mode
+    uint32_t* flags;
+};
+
+// ---- LMedS tile in LDS, struct-of-arrays: unit rows n = safe_normalize(P).  The norms |P|
+// stay in the registers of the thread that owns the row (only stage D needs them).
+struct Tile {
+    float* nx;
+    float* ny;
+    float* nz;
+};
+
+// hypothesis direction v = safe_normalize(P[i0] x P[i1]) (core_private.cpp:45-46).  The tile
+// holds unit rows, and P[i0] x P[i1] is a positive multiple of n[i0] x n[i1], so the direction is
+// the same; the "leave it un-normalised below 1e-12" rule of safe_normalize (inline_utils.hpp:5-11)
+// is applied to |n[i0] x n[i1]| instead of |P[i0] x P[i1]| (it only fires for rows parallel to
+// within 1e-12 rad, where the hypothesis is noise either way).
+__device__ __forceinline__ f3 hypothesis(const Tile& t, uint64_t seed, int64_t frame, uint32_t stream, uint32_t h,
+                                         uint32_t n) {
+    uint32_t i0, i1;
+    rs::sample_pair(seed, frame, stream, h, n, i0, i1);
+    f3 v = rs::cross(f3{t.nx[i0], t.ny[i0], t.nz[i0]}, f3{t.nx[i1], t.ny[i1], t.nz[i1]});
+    float nn = sqrtf(rs::dot(v, v));
+    if (!(nn < 1e-12f)) {
+        float inv = 1.0f / nn;
+        v = rs::scale(v, inv);
+    }
+    return v;
+}
+
+// wave-wide count of |r[]| < pivot (pivot: bit pattern of a non-negative float, uniform).
+// The kernel is bound by VALU issue (one wave64 instruction per 4 cycles per SIMD, PMC-measured),
+// while the scalar unit is mostly idle: each register costs ONE v_cmp (the abs modifier is free,
+// NaN never counts) whose 64-lane mask is counted with s_bcnt1_i32_b64 and added on the SALU.
+// The total arrives in an SGPR, so no cross-lane reduction is needed either.
+template <int NR>
+__device__ __forceinline__ uint32_t wave_count_lt(const uint32_t (&r)[NR], uint32_t pivot) {
+    const float pv = __uint_as_float(pivot);
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int m = 0; m < NR; ++m)
+        cnt += (uint32_t)__builtin_popcountll(__builtin_amdgcn_fcmpf(pv, fabsf(__uint_as_float(r[m])), 2 /* FCMP_OGT */));
+    return cnt;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_umin(uint32_t v) {
+    uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = dpp_umin<0x111, 0xf>(v);
+    v = dpp_umin<0x112, 0xf>(v);
+    v = dpp_umin<0x114, 0xf>(v);
+    v = dpp_umin<0x118, 0xf>(v);
+    v = dpp_umin<0x142, 0xa>(v);
+    v = dpp_umin<0x143, 0xc>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_fmax(float v) { // NaN-ignoring max; lanes without a source keep v
+    float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+    return fmaxf(o, v);
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = dpp_fmax<0x111, 0xf>(v);
+    v = dpp_fmax<0x112, 0xf>(v);
+    v = dpp_fmax<0x114, 0xf>(v);
+    v = dpp_fmax<0x118, 0xf>(v);
+    v = dpp_fmax<0x142, 0xa>(v);
+    v = dpp_fmax<0x143, 0xc>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// Exact kq-th smallest (0-based) of the wave's |r[]| as a bit pattern, given an exclusive upper
+// bound hi with count(|r| < hi) = c_hi > kq.  |r| orders exactly like the r^2 the reference sorts
+// (core_private.cpp:49-52), so this is the element std::sort would leave at index kq, before
+// squaring.  A bracket [lo, hi) with counts c_lo <= kq < c_hi is narrowed by counting passes;
+// pivots come from a secant step on the empirical CDF of |r| (close to uniform around the lower
+// quartile, so the CDF is nearly linear there: ~8 passes instead of 31 bit-bisection passes), with
+// bracket interpolation and plain bisection of the bit pattern as fallbacks.  Ends when the
+// bracket is one bit pattern wide or holds exactly one element, which a min pass extracts.
+// All bookkeeping is wave-uniform and kept on the scalar unit (bit patterns of non-negative
+// floats order like unsigned integers); only the secant formula itself runs on the VALU.
+template <int NR>
+__device__ __forceinline__ uint32_t select_kth(const uint32_t (&r)[NR], uint32_t kq, uint32_t hi, uint32_t c_hi) {
+    uint32_t lo = 0, c_lo = 0;
+    uint32_t a1 = 0, c1 = 0, a2 = hi, c2 = c_hi; // the two most recent (pivot, count) points
+    for (int it = 0;; ++it) {
+        if (hi - lo == 1u) return lo;
+        if (c_hi - c_lo == 1u) {
+            // the single element in [lo, hi): smallest |x| >= lo; |x| < lo wraps to a huge difference
+            uint32_t mn = 0xffffffffu;
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                uint32_t d = (r[m] & 0x7fffffffu) - lo;
+                mn = d < mn ? d : mn;
+            }
+            return lo + wave_min_u32(mn);
+        }
+        uint32_t piv = 0;
+        if (it < 24) {
+            if (c2 != c1) { // secant through the last two points, aimed at rank kq + 1/2
+                const float num = 0.5f * (float)(int)(2 * kq + 1 - 2 * c2);
+                const float a3 = fmaf(num * (__uint_as_float(a2) - __uint_as_float(a1)), rs::rcp_fast((float)(int)(c2 - c1)),
+                                      __uint_as_float(a2));
+                piv = uniform_u32(__float_as_uint(a3));
+            }
+            if (!(piv > lo && piv < hi)) { // interpolate inside the bracket instead
+                const float num = 0.5f * (float)(int)(2 * kq + 1 - 2 * c_lo);
+                const float a3 = fmaf(num * (__uint_as_float(hi) - __uint_as_float(lo)), rs::rcp_fast((float)(c_hi - c_lo)),
+                                      __uint_as_float(lo));
+                piv = uniform_u32(__float_as_uint(a3));
+            }
+        }
+        if (!(piv > lo && piv < hi)) piv = lo + ((hi - lo) >> 1); // bit bisection: guaranteed finish
+        const uint32_t c = wave_count_lt(r, piv);
+        a1 = a2; c1 = c2;
+        a2 = piv; c2 = c;
+        if (c <= kq) { lo = piv; c_lo = c; }
+        else { hi = piv; c_hi = c; }
+    }
+}
+
+// stage A of the LMedS kernel: this thread's rows of P for one delay, written to the LDS tile as
+// unit rows, norms kept in nrm[]; returns RSHIP_BAD_P if a row is not finite.  Rows >= N are not
+// touched: the kernel fills them with NaN once (their residuals compare above every threshold).
+template <int PATH, bool SWEEP>
+__device__ __forceinline__ uint32_t lmeds_row(const Spline& sp, const f4* __restrict__ rays_a,
+                                              const f4* __restrict__ rays_b, uint32_t N, uint32_t row, int base, float fd,
+                                              const Tile& tile, float& nrm) {
+    uint32_t bad = 0;
+    nrm = 0.f;
+    if (row < N) {
+        f3 P, dP;
+        residual_row<false, PATH, SWEEP>(sp, rays_a[row], rays_b[row], base, fd, P, dP);
+        const float n2 = rs::dot(P, P);
+        if (!finite_f(n2)) bad = RSHIP_BAD_P;
+        // safe_normalize (core_private.cpp:35-36): rows with |P| < 1e-12 stay as they are
+        const bool tiny = n2 < 1e-24f;
+        const float inv = tiny ? 1.f : rs::rsqrt_fast(n2);
+        tile.nx[row] = P.x * inv; tile.ny[row] = P.y * inv; tile.nz[row] = P.z * inv;
+        nrm = tiny ? 1.f : n2 * inv;
+    }
+    return bad;
+}
+
+template <int RPT, bool SWEEP>
+__device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const f4* __restrict__ rays_a,
+                                               const f4* __restrict__ rays_b, uint32_t N, int base, float fd,
+                                               const Tile& tile, float (&nrm)[RPT]) {
+    uint32_t bad = 0;
+    if (sp.path == kPathInterior) {
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            bad |= lmeds_row<kPathInterior, SWEEP>(sp, rays_a, rays_b, N, j * kBlock + threadIdx.x, base, fd, tile, nrm[j]);
+        }
+    } else { // rare (ends of the gyro track, wild delays): keep the code small, not fast
+        float tmp[RPT];
+#pragma unroll 1
+        for (int j = 0; j < RPT; ++j)
+            bad |= lmeds_row<kPathGlobal, false>(sp, rays_a, rays_b, N, j * kBlock + threadIdx.x, base, fd, tile, tmp[j]);
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) nrm[j] = tmp[j];
+    }
+    return bad;
+}
+
+// waves per SIMD each kernel is compiled for (second __launch_bounds__ argument): the
+// LMedS tile is LDS-limited to 3 workgroups per CU at 8 rows per thread
+__host__ __device__ constexpr int lmeds_waves(int rpt) { return 5; }
+__host__ __device__ constexpr int loss_waves(int rpt, bool grad) { return (grad || rpt >= 8) ? 3 : 4; }
+
+constexpr int kMaxChunk = 32; // candidates per workgroup (rship: chunk <= kMaxChunk)
+constexpr int kHypBatch = 64; // hypothesis directions prepared per batch (one per lane of wave 0)
+
+// Pop the next index of an LDS work queue for the whole wave: lane 0 alone performs the atomic,
+// the result is broadcast.  Written as one asm statement because hipcc's structuriser turns the
+// obvious `if (lane == 0) j = atomicAdd(..); j = readfirstlane(j);` inside a loop into a per-lane
+// waterfall that re-reads the queue head for the other lanes and never terminates.
+__device__ __forceinline__ uint32_t wave_pop(uint32_t* counter) {
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)counter;
+    const uint32_t one = 1u;
+    uint32_t old;
+    unsigned long long save;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "ds_add_rtn_u32 %0, %2, %3\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "=&v"(old), "=&s"(save)
+                 : "v"(addr), "v"(one)
+                 : "memory");
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+}
+
+template <int RPT, int MODE> // MODE 0: PreSync cost per candidate; 1: GuessMotion + GuessK
+__global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsParams p) {
+    constexpr int ROWS = kBlock * RPT;
+    constexpr int NR = 4 * RPT; // residual registers per lane: a wave spans the whole tile
+    __shared__ __attribute__((aligned(16))) float s_n[3][ROWS];
+    __shared__ f4 s_win[4 * kWinMax];
+    __shared__ f4 s_hyp[kHypBatch];
+    __shared__ double s_red[2][4];
+    // best (quantile, hypothesis) so far, packed (bits << 32 | h): a 64-bit min is exactly
+    // "smaller quantile wins, ties go to the earlier hypothesis" (core_private.cpp:53 strict <)
+    __shared__ unsigned long long s_key;
+    __shared__ uint32_t s_next; // hypothesis queue of the current batch
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    // blocks b and b+8 share an XCD (round-robin dispatch): keep the chunks of one
+    // frame on one XCD so its rays are fetched into one L2 only
+    const uint32_t per = 8u * p.n_chunks;
+    const uint32_t grp = blockIdx.x / per, within = blockIdx.x % per;
+    const uint32_t sf = grp * 8u + (within & 7u);
+    const uint32_t chunk = within >> 3;
+    if (sf >= p.n_sel) return;
+    const uint32_t fi = p.sel[sf];
+    const FrameRec fr = p.frames[fi];
+    const uint32_t N = fr.n;
+    const uint32_t kq = N / 4; // core_private.cpp:52
+    const uint32_t g = p.grp ? p.grp[sf] : 0u; // window this slot belongs to (batched Sync)
+    const Tile tile{s_n[0], s_n[1], s_n[2]};
+
+    // rays are re-read per candidate: the chunks of a frame share an XCD, so after the
+    // first touch they come from that XCD's L2 (keeping them in registers costs 64 VGPRs)
+    const f4* __restrict__ rays_a = p.rays_a + fr.off;
+    const f4* __restrict__ rays_b = p.rays_b + fr.off;
+
+    const uint32_t c0 = chunk * p.chunk;
+    const uint32_t c1 = (c0 + p.chunk < p.n_cand) ? c0 + p.chunk : p.n_cand;
+    if (c0 >= c1) return;
+
+    // the chunk's delays, staged once: a scalar load per candidate would put an L2 round trip at
+    // the head of every stage A
+    __shared__ int s_kd[kMaxChunk];
+    __shared__ float s_fd[kMaxChunk];
+    if ((uint32_t)tid < c1 - c0) {
+        s_kd[tid] = p.kd[(c0 + tid) * p.n_grp + g];
+        s_fd[tid] = p.fd[(c0 + tid) * p.n_grp + g];
+    }
+    Spline sp;
+    sp.g = p.coef;
+    sp.n = p.n_knots;
+    {
+        int kd_lo = p.kd[c0 * p.n_grp + g], kd_hi = kd_lo;
+        for (uint32_t c = c0 + 1; c < c1; ++c) {
+            int v = p.kd[c * p.n_grp + g];
+            kd_lo = v < kd_lo ? v : kd_lo;
+            kd_hi = v > kd_hi ? v : kd_hi;
+        }
+        stage_window(sp, s_win, fr.base_knot + (int)floorf(fr.tmin) + kd_lo,
+                     fr.base_knot + (int)floorf(fr.tmax) + kd_hi + 1);
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) { // rows beyond N: NaN once, never rewritten
+        const uint32_t row = j * kBlock + tid;
+        if (row >= N) s_n[0][row] = s_n[1][row] = s_n[2][row] = __uint_as_float(0x7fc00000u);
+    }
+    __syncthreads();
+
+    const f4* p4x = reinterpret_cast<const f4*>(tile.nx);
+    const f4* p4y = reinterpret_cast<const f4*>(tile.ny);
+    const f4* p4z = reinterpret_cast<const f4*>(tile.nz);
+    uint32_t prev_best = kInfBits; // winning quantile of the previous candidate of this chunk
+
+    for (uint32_t c = c0; c < c1; ++c) {
+        const int base = fr.base_knot + s_kd[c - c0];
+        const float fd = s_fd[c - c0];
+        const uint32_t stream = p.stream_base + c + g * p.stream_stride; // g != 0 only for batched GuessMotion
+        uint32_t bad = 0;
+        // ---- stage A: rows of P -> LDS tile as unit rows; norms stay in registers ----
+        float nrm[RPT];
+        bad |= lmeds_rows<RPT, MODE == 0>(sp, rays_a, rays_b, N, base, fd, tile, nrm);
+
+        // ---- stage C: the hypotheses.  The best quantile of the previous candidate (x1.25: between
+        // neighbouring candidates it moves by -20..+26 %, 1st..99th percentile) serves as a
+        // provisional bound: a hypothesis that has <= kq residuals below it is dropped after one
+        // counting pass.  If nothing beats the bound (~2 % of candidates) the candidate is redone
+        // without it, so the result is the exact arg-min either way.
+        uint32_t guess = kInfBits;
+        if (prev_best < 0x7e000000u && prev_best > 0x00800000u)
+            guess = uniform_u32(__float_as_uint(__uint_as_float(prev_best) * 1.25f));
+        unsigned long long best;
+        for (;;) {
+            if (tid == 0) s_key = ((unsigned long long)guess << 32);
+            for (uint32_t batch = 0; batch < p.n_hyp; batch += kHypBatch) {
+                const uint32_t nb = (p.n_hyp - batch < (uint32_t)kHypBatch) ? p.n_hyp - batch : (uint32_t)kHypBatch;
+                __syncthreads(); // tile written / previous batch consumed
+                if ((uint32_t)tid < nb) {
+                    const f3 v = hypothesis(tile, p.seed, fr.id, stream, batch + tid, N);
+                    s_hyp[tid] = f4{v.x, v.y, v.z, 0.f};
+                }
+                if (tid == 0) s_next = 0;
+                __syncthreads();
+                for (;;) { // waves pull hypotheses from the queue: no wave idles at the barrier
+                    const uint32_t j = wave_pop(&s_next);
+                    if (j >= nb) break;
+                    const uint32_t h = batch + j;
+                    const f4 hv = s_hyp[j];
+                    // residuals r = nP v (core_private.cpp:48); |r| orders like the r^2 of :49-52
+                    uint32_t r2[NR]; // registers 4m..4m+3 <-> rows 4 (64 m + lane) .. +3
+#pragma unroll
+                    for (int m = 0; m < NR / 4; ++m) {
+                        if ((m & 1) == 0) __builtin_amdgcn_sched_barrier(0); // bound the LDS reads in flight
+                        const int idx = m * 64 + lane;
+                        // ds_read_b128 per array: full LDS rate (ds_read2_b64 pairs run at half of it)
+                        const f4 x = p4x[idx], y = p4y[idx], z = p4z[idx];
+                        const v2f r01 = v2f{x.x, x.y} * hv.x + v2f{y.x, y.y} * hv.y + v2f{z.x, z.y} * hv.z;
+                        const v2f r23 = v2f{x.z, x.w} * hv.x + v2f{y.z, y.w} * hv.y + v2f{z.z, z.w} * hv.z;
+                        r2[4 * m] = __float_as_uint(r01.x);
+                        r2[4 * m + 1] = __float_as_uint(r01.y);
+                        r2[4 * m + 2] = __float_as_uint(r23.x);
+                        r2[4 * m + 3] = __float_as_uint(r23.y);
+                    }
+                    // (quantile_h, h) < (T, g)  <=>  more than kq |residuals| lie below T (+1 ulp if g > h):
+                    // med < least_med of core_private.cpp:51-53 with the reference's first-wins tie rule
+                    const unsigned long long key = __hip_atomic_load(&s_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t T = (uint32_t)(key >> 32), g = (uint32_t)key;
+                    uint32_t hi2 = T + ((T != kInfBits && g > h) ? 1u : 0u);
+                    const uint32_t tot = wave_count_lt(r2, hi2);
+                    if (tot > kq) {
+                        if (hi2 == kInfBits) { // no bound yet: start the bracket at the largest residual
+                            float mx = 0.f;
+#pragma unroll
+                            for (int m = 0; m < NR; ++m) mx = fmaxf(mx, fabsf(__uint_as_float(r2[m])));
+                            mx = wave_max_f32(mx);
+                            if (finite_f(mx)) hi2 = __float_as_uint(mx) + 1u; // count(|r| < hi2) is still tot
+                        }
+                        const uint32_t kth = select_kth(r2, kq, hi2, tot);
+                        if (lane == 0) atomicMin(&s_key, ((unsigned long long)kth << 32) | h);
+                    }
+                }
+            }
+            __syncthreads();
+            best = s_key;
+            if (guess == kInfBits || best != ((unsigned long long)guess << 32)) break;
+            guess = kInfBits; // nothing beat the provisional bound: redo this candidate without it
+            __syncthreads();  // everyone has read s_key before it is reset
+        }
+        const uint32_t bT = (uint32_t)(best >> 32);
+        const int bH = (bT == kInfBits) ? -1 : (int)(uint32_t)best;
+        prev_best = bT;
+        f3 Mv = f3{0, 0, 0};
+        if (bH >= 0) {
+            if (p.n_hyp <= (uint32_t)kHypBatch) { // the winner's direction is still in the batch buffer
+                const f4 hv = s_hyp[bH];
+                Mv = f3{hv.x, hv.y, hv.z};
+            } else {
+                Mv = hypothesis(tile, p.seed, fr.id, stream, (uint32_t)bH, N);
+            }
+        }
+        if (!(finite_f(Mv.x) && finite_f(Mv.y) && finite_f(Mv.z))) bad |= RSHIP_BAD_M;
+
+        // ---- stage D: k = clamp(100 / |P M|), cost = sqrt(sum sqrt(log1p(r^2))) ----
+        // Branch-free over the rows: a row beyond N has nrm = 0 but a NaN tile entry, so its
+        // product is replaced by 0 with one select; zeros then contribute nothing below.
+        float pm[RPT];
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const uint32_t row = j * kBlock + tid;
+            const float v = nrm[j] * rs::dot(f3{tile.nx[row], tile.ny[row], tile.nz[row]}, Mv);
+            pm[j] = row < N ? v : 0.f;
+            ss = fmaf(pm[j], pm[j], ss);
+        }
+        double ss_tot = block_sum(ss, s_red[0]);
+        // core_private.cpp:79, 100 / ||P M|| as 100 * rsq (v_rsq_f32, 1 ulp); ss = 0 gives +inf -> clamp
+        float kf = 100.0f * rs::rsqrt_fast((float)ss_tot);
+        kf = (kf < 10.f) ? 10.f : ((1000.f < kf) ? 1000.f : kf);
+        if (MODE == 1) {
+            if (tid == 0) {
+                p.M[3 * sf + 0] = (double)Mv.x;
+                p.M[3 * sf + 1] = (double)Mv.y;
+                p.M[3 * sf + 2] = (double)Mv.z;
+                p.k[sf] = (double)kf;
+            }
+        } else {
+            float sc = kf * rs::rsqrt_fast(rs::dot(Mv, Mv)); // core_private.cpp:80
+            // a non-finite r or rho (core_private.cpp:81,83) makes the sums non-finite: NaN propagates
+            // and all terms are >= 0, so the checks are made once on the sums, not per row
+            float acc = 0.f, rsum = 0.f;
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                const float r = pm[j] * sc;
+                rsum += fabsf(r);
+                const float rho = rs::log1p_pos_fast(r * r); // core_private.cpp:82
+                // v_sqrt_f32 directly (1 ulp): libm's sqrtf adds range scaling for denormal inputs,
+                // whose square roots (< 1e-19) cannot change a sum of O(1) terms in fp32
+                acc += __builtin_amdgcn_sqrtf(rho);
+            }
+            if (!finite_f(rsum)) bad |= RSHIP_BAD_R;
+            else if (!finite_f(acc)) bad |= RSHIP_BAD_RHO;
+            double acc_tot = block_sum(acc, s_red[1]);
+            if (tid == 0) {
+                p.frame_cost[(size_t)c * p.n_sel + sf] = sqrt(acc_tot); // core_private.cpp:85
+                if (p.best_h) p.best_h[(size_t)c * p.n_sel + sf] = bH;
+            }
+        }
+        if (bad) atomicOr(p.flags, bad);
+        // No barrier here.  What the next candidate overwrites before its first barrier is (a) this
+        // thread's own tile rows and (b) s_key, by thread 0: every reader of s_key reads it before
+        // the workgroup sum barrier of stage D, which thread 0 has passed by then.  s_hyp, s_next
+        // and the sum slots are rewritten only after further barriers of the next candidate.
+    }
+}
+
+} // namespace

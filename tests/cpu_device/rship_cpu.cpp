@@ -266,7 +266,7 @@ int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t
     return 0;
 }
 
-// the kernel's L-BFGS (rssync_kernels.hip: opt_motion_kernel), sequential
+// the kernel's L-BFGS (kernels/motion.hpp: opt_motion_kernel), sequential
 int rship_opt_motion(rship_ctx* c, const int32_t* kdv, const float* fdv, uint64_t* stats) {
     uint64_t tot_it = 0, tot_ev = 0;
     for (size_t sl = 0; sl < c->sel.size(); ++sl) {
