@@ -6,7 +6,8 @@ namespace {
 
 
 constexpr int kBlock = 256;
-constexpr int kWinMax = 64;  // knots of the spline staged in LDS per workgroup
+constexpr int kWinMax = 80;  // knots of the spline staged in LDS per workgroup (5 KB; with the LMedS tile
+                             // a workgroup stays at 31.3 KB, five per CU)
 constexpr uint32_t kInfBits = 0x7f800000u;
 
 // ---------------------------------------------------------------------------

@@ -63,6 +63,7 @@ struct rship_ctx {
     uint32_t n_knots = 0, n_frames = 0, n_sel = 0, max_n = 0, n_grp = 1;
     uint64_t total_rays = 0;
     double fs = 0;
+    float max_span = 0.f; // widest frame, in knots (frame table)
     std::vector<uint32_t> h_frame_n; // per table frame
     std::vector<uint32_t> h_sel;
     std::vector<uint32_t> h_delays; // staging of upload_delays
@@ -329,11 +330,14 @@ int rship_upload_frames(rship_ctx* c, const float* rays_a4, const float* rays_b4
     c->n_sel = 0;
     c->h_sel.clear();
     c->h_frame_n.assign(n_frames, 0);
+    c->max_span = 0.f;
     for (uint32_t i = 0; i < n_frames; ++i) {
         if ((uint64_t)table[i].ray_offset + table[i].n_rays > total_rays) return set_err(c, "frame table exceeds ray buffer");
         if (table[i].n_rays > (uint32_t)rship_max_tracks())
             return set_err(c, "frame has more tracks than the kernels accept (" + std::to_string(rship_max_tracks()) + ")");
         c->h_frame_n[i] = table[i].n_rays;
+        const float span = floorf(table[i].tmax) - floorf(table[i].tmin) + 2.f; // knots a frame touches at one delay
+        if (table[i].n_rays && span > c->max_span) c->max_span = span;
     }
     size_t rb = (size_t)total_rays * 16;
     if (ensure(c, c->rays_a, rb ? rb : 16) || ensure(c, c->rays_b, rb ? rb : 16)) return 1;
@@ -443,6 +447,16 @@ int rship_presync_window_costs(rship_ctx* c, const int32_t* kd, const float* fd,
     if (chunk < 1) chunk = 1;
     if (chunk > (uint32_t)kMaxChunk) chunk = kMaxChunk;
     if (chunk > n_cand) chunk = n_cand;
+    if (n_cand > 1) {
+        // keep the chunk's delays inside what the LDS spline window can hold next to the widest
+        // frame (higher gyro rates: a frame pair spans more knots), as long as chunks stay useful
+        const double step = ((double)kd[n_cand - 1] + fd[n_cand - 1] - (double)kd[0] - fd[0]) / (double)(n_cand - 1);
+        const double room = (double)kWinMax - c->max_span - 1.0;
+        if (step > 0 && room > 0) {
+            const uint32_t fit = (uint32_t)(room / step);
+            if (fit >= 4 && fit < chunk) chunk = fit;
+        }
+    }
     p.chunk = chunk;
     p.n_chunks = (n_cand + chunk - 1) / chunk;
     p.n_hyp = n_hyp;
