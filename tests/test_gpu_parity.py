@@ -598,3 +598,40 @@ def test_high_rate_gyro_uses_the_general_spline_path():
     c2h, d2h = h.Sync(dh, 0, F - 1, 0.0, 0.1)
     c2o, d2o = o.Sync(do, 0, F - 1, 0.0, 0.1)
     assert abs(d2h - d2o) < 1e-4 and abs(d2h - synth.D_TRUE) < 1e-4
+
+
+def test_create_use_destroy_does_not_leak_device_memory(small_case):
+    """100 problems created, used (PreSync, Sync, batched windows, pixel frames) and destroyed:
+    free HBM returns to where it was (a long-running host must not creep)."""
+    import ctypes
+    import gc
+    import rssync_amd
+    from rssync_amd import synth
+    from conftest import fill
+    F = 16
+    case = dict(small_case, frames=small_case["frames"][:F])
+    rssync_amd.load_library()                      # pulls in the HIP runtime the library uses
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        assert hip.hipDeviceSynchronize() == 0
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
+    def once():
+        p = fill(rssync_amd.SyncProblem(seed=SEED, max_outer_iters=3), case)
+        p.PreSync(0.0, 0, F, 0.01, 0.05)
+        p.Sync(0.03, 0, F - 1, 0.0, 0.2)
+        p.sync_points([0, 4], 8, 0.03, 0.01, 0.05, repeats=1)
+        pa = np.array([[500.0, 400.0], [900.0, 700.0], [1500.0, 300.0]])
+        p.set_track_pixels(99, 3.3, 3.3333, pa, pa + 1.0, synth.LENS, synth.IMAGE_ROWS)
+        p.upload()
+        del p
+        gc.collect()
+    once()
+    free0 = free_bytes()
+    for _ in range(100):
+        once()
+    free1 = free_bytes()
+    assert free0 - free1 < 32 << 20, (free0, free1)
