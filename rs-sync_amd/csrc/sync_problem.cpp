@@ -27,8 +27,10 @@
 #include <iostream>
 #include <limits>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -465,72 +467,101 @@ void SyncProblemHip::build_spline() {
 // parameter (ts - start) * fs (core_private.cpp:19-20 without the delay) relative to the
 // frame's integer base knot, so fp32 only ever holds a span of a few tens of knots.
 void SyncProblemHip::pack_frames() {
-    size_t total = 0;
-    for (auto& [id, f] : frames_) total += f.ts_a.size();
-    if (total > 0xffffffffull) panic("sync: more than 2^32 rays");
-    size_t ray_frames = 0;
-    for (auto& [id, f] : frames_) ray_frames += f.from_pixels ? 0 : 1;
-    std::vector<float> a4(ray_frames ? total * 4 + 4 : 4), b4(ray_frames ? total * 4 + 4 : 4);
-    std::vector<rship_frame> table;
-    std::vector<rship_pixel_frame> pframes;
-    std::vector<double> px;
-    table.reserve(frames_.size());
-    table_ids_.clear();
-    size_t off = 0;
+    // pass 1 (serial, O(frames)): where every frame goes
+    struct Slot {
+        int64_t id;
+        const HostFrame* f;
+        size_t off, px_off;
+        int pix; // index into the pixel-frame list, or -1
+    };
+    std::vector<Slot> slots;
+    slots.reserve(frames_.size());
+    size_t total = 0, px_pairs = 0, n_pix = 0;
     for (auto& [id, f] : frames_) {
-        const size_t n = f.ts_a.size();
-        double xmin = std::numeric_limits<double>::infinity();
-        for (size_t i = 0; i < n; ++i) {
-            xmin = std::min(xmin, (f.ts_a[i] - start_) * fs_);
-            xmin = std::min(xmin, (f.ts_b[i] - start_) * fs_);
-        }
-        double base = n ? std::floor(xmin) : 0.0;
-        if (!(base > -(double)kKnotClamp)) base = -(double)kKnotClamp;
-        if (base > (double)kKnotClamp) base = (double)kKnotClamp;
-        rship_frame rec{};
-        rec.ray_offset = (uint32_t)off;
-        rec.n_rays = (uint32_t)n;
-        rec.base_knot = (int32_t)base;
-        rec.id = id;
-        float tmin = 0.f, tmax = 0.f;
-        for (size_t i = 0; i < n; ++i) {
-            const float ta = (float)((f.ts_a[i] - start_) * fs_ - base);
-            const float tb = (float)((f.ts_b[i] - start_) * fs_ - base);
-            if (!f.from_pixels) {
-                float* pa = &a4[4 * (off + i)];
-                float* pb = &b4[4 * (off + i)];
-                // {ax,bx,ay,by} / {az,bz,ta,tb}: the two ends of the pair interleaved
-                pa[0] = (float)f.rays_a[3 * i]; pa[1] = (float)f.rays_b[3 * i]; pa[2] = (float)f.rays_a[3 * i + 1]; pa[3] = (float)f.rays_b[3 * i + 1];
-                pb[0] = (float)f.rays_a[3 * i + 2]; pb[1] = (float)f.rays_b[3 * i + 2]; pb[2] = ta; pb[3] = tb;
+        slots.push_back({id, &f, total, px_pairs, f.from_pixels && !f.ts_a.empty() ? (int)n_pix : -1});
+        total += f.ts_a.size();
+        if (f.from_pixels && !f.ts_a.empty()) { px_pairs += f.ts_a.size(); ++n_pix; }
+    }
+    if (total > 0xffffffffull) panic("sync: more than 2^32 rays");
+    const bool any_rays = n_pix < slots.size();
+    // uninitialised on purpose: every ray-frame slice is written below, pixel-frame slices on the device
+    std::unique_ptr<float[]> a4(new float[any_rays ? total * 4 + 4 : 4]), b4(new float[any_rays ? total * 4 + 4 : 4]);
+    std::vector<rship_frame> table(slots.size());
+    std::vector<rship_pixel_frame> pframes(n_pix);
+    std::vector<double> px(px_pairs * 4);
+    table_ids_.resize(slots.size());
+
+    // pass 2: frames are independent -- packed by a few host threads (268 MB at BASELINE size)
+    const double start = start_, fs = fs_;
+    auto pack_range = [&](size_t lo, size_t hi) {
+        for (size_t s = lo; s < hi; ++s) {
+            const Slot& sl = slots[s];
+            const HostFrame& f = *sl.f;
+            const size_t n = f.ts_a.size(), off = sl.off;
+            double xmin = std::numeric_limits<double>::infinity();
+            for (size_t i = 0; i < n; ++i) {
+                xmin = std::min(xmin, (f.ts_a[i] - start) * fs);
+                xmin = std::min(xmin, (f.ts_b[i] - start) * fs);
             }
-            if (i == 0) { tmin = std::min(ta, tb); tmax = std::max(ta, tb); }
-            tmin = std::min(tmin, std::min(ta, tb));
-            tmax = std::max(tmax, std::max(ta, tb));
+            double base = n ? std::floor(xmin) : 0.0;
+            if (!(base > -(double)kKnotClamp)) base = -(double)kKnotClamp;
+            if (base > (double)kKnotClamp) base = (double)kKnotClamp;
+            rship_frame rec{};
+            rec.ray_offset = (uint32_t)off;
+            rec.n_rays = (uint32_t)n;
+            rec.base_knot = (int32_t)base;
+            rec.id = sl.id;
+            float tmin = 0.f, tmax = 0.f;
+            for (size_t i = 0; i < n; ++i) {
+                const float ta = (float)((f.ts_a[i] - start) * fs - base);
+                const float tb = (float)((f.ts_b[i] - start) * fs - base);
+                if (!f.from_pixels) {
+                    float* pa = &a4[4 * (off + i)];
+                    float* pb = &b4[4 * (off + i)];
+                    // {ax,bx,ay,by} / {az,bz,ta,tb}: the two ends of the pair interleaved
+                    pa[0] = (float)f.rays_a[3 * i]; pa[1] = (float)f.rays_b[3 * i]; pa[2] = (float)f.rays_a[3 * i + 1]; pa[3] = (float)f.rays_b[3 * i + 1];
+                    pb[0] = (float)f.rays_a[3 * i + 2]; pb[1] = (float)f.rays_b[3 * i + 2]; pb[2] = ta; pb[3] = tb;
+                }
+                if (i == 0) { tmin = std::min(ta, tb); tmax = std::max(ta, tb); }
+                tmin = std::min(tmin, std::min(ta, tb));
+                tmax = std::max(tmax, std::max(ta, tb));
+            }
+            if (sl.pix >= 0) {
+                // the device recomputes ta/tb from the pixels with the same fp64 operations; one ulp
+                // of slack on the bounds costs nothing and makes the window independent of that
+                tmin = std::nextafterf(tmin, -std::numeric_limits<float>::infinity());
+                tmax = std::nextafterf(tmax, std::numeric_limits<float>::infinity());
+                rship_pixel_frame pf{};
+                pf.time_a = f.time_a; pf.time_b = f.time_b; pf.rows = f.rows;
+                std::copy(f.lens, f.lens + 9, pf.lens);
+                pf.start = start; pf.fs = fs; pf.base = base;
+                pf.px_offset = sl.px_off;
+                pf.ray_offset = (uint32_t)off;
+                pf.n_rays = (uint32_t)n;
+                std::copy(f.px.begin(), f.px.end(), px.begin() + 4 * sl.px_off);
+                pframes[(size_t)sl.pix] = pf;
+            }
+            rec.tmin = tmin;
+            rec.tmax = tmax;
+            table[s] = rec;
+            table_ids_[s] = sl.id;
         }
-        if (f.from_pixels && n) {
-            // the device recomputes ta/tb from the pixels with the same fp64 operations; one ulp
-            // of slack on the bounds costs nothing and makes the window independent of that
-            tmin = std::nextafterf(tmin, -std::numeric_limits<float>::infinity());
-            tmax = std::nextafterf(tmax, std::numeric_limits<float>::infinity());
-            rship_pixel_frame pf{};
-            pf.time_a = f.time_a; pf.time_b = f.time_b; pf.rows = f.rows;
-            std::copy(f.lens, f.lens + 9, pf.lens);
-            pf.start = start_; pf.fs = fs_; pf.base = base;
-            pf.px_offset = px.size() / 4;
-            pf.ray_offset = (uint32_t)off;
-            pf.n_rays = (uint32_t)n;
-            px.insert(px.end(), f.px.begin(), f.px.end());
-            pframes.push_back(pf);
+    };
+    const size_t hw = std::max<size_t>(1, std::min<size_t>(16, std::thread::hardware_concurrency()));
+    const size_t n_thr = total < (1u << 18) ? 1 : std::min(hw, slots.size());
+    if (n_thr <= 1) {
+        pack_range(0, slots.size());
+    } else {
+        std::vector<std::thread> pool;
+        const size_t per = (slots.size() + n_thr - 1) / n_thr;
+        for (size_t t = 0; t < n_thr; ++t) {
+            const size_t lo = t * per, hi = std::min(slots.size(), lo + per);
+            if (lo < hi) pool.emplace_back(pack_range, lo, hi);
         }
-        rec.tmin = tmin;
-        rec.tmax = tmax;
-        table.push_back(rec);
-        table_ids_.push_back(id);
-        off += n;
+        for (auto& th : pool) th.join();
     }
     // frames given as pixels are filled in on the device: if all are, nothing is copied
-    const bool any_rays = pframes.size() < table.size();
-    hip_check(rship_upload_frames(dev_, any_rays ? a4.data() : nullptr, any_rays ? b4.data() : nullptr, total,
+    hip_check(rship_upload_frames(dev_, any_rays ? a4.get() : nullptr, any_rays ? b4.get() : nullptr, total,
                                   table.data(), (uint32_t)table.size()),
               "upload frames");
     if (!pframes.empty()) {
