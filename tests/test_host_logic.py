@@ -283,3 +283,32 @@ def test_sync_points_equal_the_reference_driver_loop(host, tiny_case):
             assert (costs[w], delays[w]) == want[w]
         # both consumed 16 Sync call numbers
         assert bat.Sync(0.03, 0, 15, 0.0, 0.2) == seq.Sync(0.03, 0, 15, 0.0, 0.2)
+
+
+def test_random_window_sets_batched_equal_sequential(host, tiny_case):
+    """property: for ANY set of windows (overlapping, nested, empty, out of range, repeated) the
+    batched calls return what the sequential method calls return"""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    F = tiny_case["F"]
+    window = st.tuples(st.integers(-2, F + 1), st.integers(0, 9)).map(lambda t: (t[0], t[0] + t[1]))
+
+    @settings(max_examples=12, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(st.lists(window, min_size=1, max_size=5), st.floats(0.02, 0.05))
+    def check(wins, d0):
+        b = [w[0] for w in wins]
+        e = [w[1] for w in wins]
+        seq = host(tiny_case, max_outer_iters=4)
+        bat = host(tiny_case, max_outer_iters=4)
+        try:
+            want = [seq.Sync(d0, b[w], e[w], 0.03, 0.05) for w in range(len(wins))]
+        except Exception as ex:          # a window with a <2-track frame would panic in both
+            with pytest.raises(type(ex)):
+                bat.sync_windows(d0, b, e, 0.03, 0.05)
+            return
+        costs, delays = bat.sync_windows(d0, b, e, 0.03, 0.05)
+        assert [(c, d) for c, d in zip(costs, delays)] == want
+        pc, pd = bat.pre_sync_windows(0.03, b, [x + 1 for x in e], 0.01, 0.03)
+        for w in range(len(wins)):
+            c, d = seq.PreSync(0.03, b[w], e[w] + 1, 0.01, 0.03)
+            assert pd[w] == d and pc[w] == pytest.approx(c, rel=1e-14, abs=0)
+    check()
