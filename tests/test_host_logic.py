@@ -312,3 +312,24 @@ def test_random_window_sets_batched_equal_sequential(host, tiny_case):
             c, d = seq.PreSync(0.03, b[w], e[w] + 1, 0.01, 0.03)
             assert pd[w] == d and pc[w] == pytest.approx(c, rel=1e-14, abs=0)
     check()
+
+
+def test_host_solver_is_clean_under_asan_ubsan(built, tmp_path):
+    """sync_problem.cpp + the CPU test double compiled with -fsanitize=address,undefined and driven
+    through every entry point (tests/asan_driver.py): no report.  (Sanitizers run on the CPU build
+    only; the GPU pool has no ASan.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = tmp_path / "librssync_hosttest_asan.so"
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                           "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-o", str(lib),
+                           os.path.join(root, "rs-sync_amd", "csrc", "sync_problem.cpp"),
+                           os.path.join(root, "tests", "cpu_device", "rship_cpu.cpp")])
+    asan = subprocess.check_output(["g++", "-print-file-name=libasan.so"], text=True).strip()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "asan_driver.py"), str(lib)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("done"), r.stderr[-2000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-2000:]
