@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--search-radius", type=float, default=0.2)
     ap.add_argument("--outer-iters", type=int, default=20)
     ap.add_argument("--cpu-frames", type=int, default=192, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "native"],
+                    help="multi-GPU sum: torch.distributed all_reduce through a Python hook (default), or the "
+                         "library's own RCCL communicator (rssync_ext_rccl_init; nccl backend only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse "
                                                       "several ranks on one GPU)")
     args = ap.parse_args()
@@ -78,9 +81,12 @@ def main():
     t_gen = time.time() - t_gen
 
     if world > 1:
-        from rssync_amd.dist import make_reduce_hook
+        from rssync_amd.dist import make_reduce_hook, use_native_rccl
         # the only exchange of the path: a sum of a few doubles, as an RCCL all-reduce over xGMI
-        prob.set_reduce_hook(make_reduce_hook("cuda" if args.backend == "nccl" else "cpu"))
+        if args.exchange == "native" and args.backend == "nccl":
+            use_native_rccl(prob)
+        else:
+            prob.set_reduce_hook(make_reduce_hook("cuda" if args.backend == "nccl" else "cpu"))
 
     t_up = time.time()
     prob.upload()  # rays + spline into HBM before the timed region

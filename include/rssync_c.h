@@ -83,6 +83,12 @@ int rssync_ext_set_stream(rssync_problem* p, void* hip_stream);
 typedef void (*rssync_reduce_fn)(double* buf, size_t n, void* user);
 int rssync_ext_set_reduce_hook(rssync_problem* p, rssync_reduce_fn fn, void* user);
 
+/* Native exchange instead of a reduce hook: the library keeps its own RCCL communicator (one rank
+ * per process, librccl opened at run time).  Rank 0 calls rccl_unique_id (128 bytes), the host
+ * hands the bytes to every rank by whatever means it has, every rank calls rccl_init; from then on
+ * the sums of PreSync / Sync are all-reduced with ncclAllReduce on the problem's stream. */
+int rssync_ext_rccl_unique_id(rssync_problem* p, void* id128);
+int rssync_ext_rccl_init(rssync_problem* p, const void* id128, int rank, int world_size);
 /* pack the tracks and the gyro spline and copy them to HBM now (otherwise done lazily by the
  * first PreSync/Sync/DebugPreSync after a setter) */
 int rssync_ext_upload(rssync_problem* p);

@@ -139,6 +139,14 @@ typedef struct rship_pixel_frame {
 int rship_rays_from_pixels(rship_ctx* c, const double* px, uint64_t n_pairs, const rship_pixel_frame* frames,
                            uint32_t n_frames, uint32_t* bad);
 
+/* Native exchange for frame-sharded multi-GPU runs: an RCCL communicator owned by the context
+ * (librccl is opened with dlopen on first use: no link-time dependency), one rank per process.
+ * unique_id: rank 0 fills 128 bytes, the host distributes them (MPI, torch.distributed, a file...),
+ * every rank then calls init.  allreduce sums n doubles in place over all ranks (host buffer). */
+int rship_rccl_unique_id(rship_ctx* c, void* id128);
+int rship_rccl_init(rship_ctx* c, const void* id128, int rank, int world);
+int rship_rccl_allreduce(rship_ctx* c, double* buf, uint64_t n);
+
 /* debug: the packed float4 streams of one frame of the table */
 int rship_debug_rays(rship_ctx* c, uint32_t frame_index, float* a4, float* b4, uint32_t cap_rays);
 

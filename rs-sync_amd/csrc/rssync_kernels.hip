@@ -17,6 +17,8 @@
 // device context and the launchers.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -64,6 +66,10 @@ struct rship_ctx {
     uint64_t total_rays = 0;
     double fs = 0;
     float max_span = 0.f; // widest frame, in knots (frame table)
+    // native exchange (RCCL through dlopen)
+    void* rccl_lib = nullptr;
+    void* rccl_comm = nullptr;
+    DevBuf rccl_buf;
     std::vector<uint32_t> h_frame_n; // per table frame
     std::vector<uint32_t> h_sel;
     std::vector<uint32_t> h_delays; // staging of upload_delays
@@ -262,6 +268,33 @@ int check_ready(rship_ctx* c) {
 
 } // namespace
 
+// ---- native exchange: RCCL, resolved at run time -----------------------------------------
+// The four entry points used, with the signatures of <rccl/rccl.h> (ncclResult_t is an int enum,
+// ncclUniqueId a 128-byte struct passed by value, ncclDouble = 8, ncclSum = 0).
+namespace {
+struct RcclId { char bytes[128]; };
+using rccl_get_id_fn = int (*)(RcclId*);
+using rccl_init_fn = int (*)(void**, int, RcclId, int);
+using rccl_allreduce_fn = int (*)(const void*, void*, size_t, int, int, void*, hipStream_t);
+using rccl_destroy_fn = int (*)(void*);
+
+void* rccl_sym(rship_ctx* c, const char* name) {
+    if (!c->rccl_lib) {
+        for (const char* lib : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            c->rccl_lib = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+            if (c->rccl_lib) break;
+        }
+        if (!c->rccl_lib) {
+            set_err(c, std::string("rccl: cannot open librccl: ") + dlerror());
+            return nullptr;
+        }
+    }
+    void* f = dlsym(c->rccl_lib, name);
+    if (!f) set_err(c, std::string("rccl: missing symbol ") + name);
+    return f;
+}
+} // namespace
+
 extern "C" {
 
 int rship_max_tracks(void) { return kMaxRpt * kBlock; }
@@ -291,6 +324,10 @@ void rship_destroy(rship_ctx* c) {
     DeviceGuard dev_guard(c);
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
+    if (c->rccl_comm) {
+        if (auto destroy = (rccl_destroy_fn)rccl_sym(c, "ncclCommDestroy")) (void)destroy(c->rccl_comm);
+    }
+    if (c->rccl_buf.p) (void)hipFree(c->rccl_buf.p);
     for (auto e : c->pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->coef, &c->rays_a, &c->rays_b, &c->frames, &c->sel, &c->M, &c->k, &c->grp, &c->grp_off,
                       &c->seg_idx, &c->seg_off, &c->kd,
@@ -678,6 +715,47 @@ int rship_rays_from_pixels(rship_ctx* c, const double* px, uint64_t n_pairs, con
     prof_collect(c);
     if (e != hipSuccess) return set_err(c, "rays_from_pixels", e);
     if (bad) *bad = nb;
+    return 0;
+}
+
+int rship_rccl_unique_id(rship_ctx* c, void* id128) {
+    auto get = (rccl_get_id_fn)rccl_sym(c, "ncclGetUniqueId");
+    if (!get) return 1;
+    RcclId id;
+    const int rc = get(&id);
+    if (rc) return set_err(c, "rccl: ncclGetUniqueId failed (" + std::to_string(rc) + ")");
+    memcpy(id128, id.bytes, sizeof(id.bytes));
+    return 0;
+}
+
+int rship_rccl_init(rship_ctx* c, const void* id128, int rank, int world) {
+    DeviceGuard dev_guard(c);
+    if (c->rccl_comm) return set_err(c, "rccl: already initialised");
+    if (world < 1 || rank < 0 || rank >= world) return set_err(c, "rccl: bad rank / world size");
+    auto init = (rccl_init_fn)rccl_sym(c, "ncclCommInitRank");
+    if (!init || !rccl_sym(c, "ncclAllReduce")) return 1;
+    RcclId id;
+    memcpy(id.bytes, id128, sizeof(id.bytes));
+    const int rc = init(&c->rccl_comm, world, id, rank);
+    if (rc) {
+        c->rccl_comm = nullptr;
+        return set_err(c, "rccl: ncclCommInitRank failed (" + std::to_string(rc) + ")");
+    }
+    return 0;
+}
+
+int rship_rccl_allreduce(rship_ctx* c, double* buf, uint64_t n) {
+    DeviceGuard dev_guard(c);
+    if (!c->rccl_comm) return set_err(c, "rccl: not initialised");
+    if (!n) return 0;
+    auto allreduce = (rccl_allreduce_fn)rccl_sym(c, "ncclAllReduce");
+    if (!allreduce) return 1;
+    if (ensure(c, c->rccl_buf, (size_t)n * 8)) return 1;
+    RS_HIP(hipMemcpyAsync(c->rccl_buf.p, buf, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    const int rc = allreduce(c->rccl_buf.p, c->rccl_buf.p, (size_t)n, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->rccl_comm, c->stream);
+    if (rc) return set_err(c, "rccl: ncclAllReduce failed (" + std::to_string(rc) + ")");
+    RS_HIP(hipMemcpyAsync(buf, c->rccl_buf.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    RS_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
 

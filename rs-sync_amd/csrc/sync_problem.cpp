@@ -165,8 +165,11 @@ class SyncProblemHip final : public ISyncProblem {
                          double search_step, double search_radius, std::vector<double>& costs,
                          std::vector<double>& delays_out);
     std::vector<std::vector<double>> traces; // per window of the last sync_windows call
+    bool native_exchange = false; // RCCL communicator inside the device context (rssync_ext_rccl_init)
+    bool distributed() const { return native_exchange || reduce_fn; }
     void reduce(double* buf, size_t n) {
-        if (reduce_fn) reduce_fn(buf, n, reduce_user);
+        if (native_exchange) hip_check(rship_rccl_allreduce(dev_, buf, n), "rccl all-reduce");
+        else if (reduce_fn) reduce_fn(buf, n, reduce_user);
     }
     const std::vector<uint32_t>& selection() const { return sel_; }
     int64_t table_id(uint32_t i) const { return table_ids_[i]; }
@@ -632,7 +635,7 @@ std::vector<double> SyncProblemHip::sweep(const std::vector<double>& delays, uin
     // one exchange for the whole sweep; the flag bits ride along as small integers
     double fl[4] = {(double)((flags >> 0) & 1), (double)((flags >> 1) & 1), (double)((flags >> 2) & 1),
                     (double)((flags >> 3) & 1)};
-    if (reduce_fn) {
+    if (distributed()) {
         std::vector<double> buf(costs.begin(), costs.begin() + n);
         buf.insert(buf.end(), fl, fl + 4);
         reduce(buf.data(), buf.size());
@@ -1063,6 +1066,19 @@ int rssync_ext_set_reduce_hook(rssync_problem* p, rssync_reduce_fn fn, void* use
     p->impl->reduce_fn = fn;
     p->impl->reduce_user = user;
     return 0;
+}
+
+int rssync_ext_rccl_unique_id(rssync_problem* p, void* id128) {
+    return guarded([&] {
+        if (rship_rccl_unique_id(p->impl->dev(), id128)) panic(std::string("hip: ") + rship_last_error(p->impl->dev()));
+    });
+}
+
+int rssync_ext_rccl_init(rssync_problem* p, const void* id128, int rank, int world_size) {
+    return guarded([&] {
+        if (rship_rccl_init(p->impl->dev(), id128, rank, world_size)) panic(std::string("hip: ") + rship_last_error(p->impl->dev()));
+        p->impl->native_exchange = true;
+    });
 }
 
 int rssync_ext_upload(rssync_problem* p) {

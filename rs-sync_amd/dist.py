@@ -36,6 +36,17 @@ def make_reduce_hook(device=None, capacity=8192):
     return hook
 
 
+def use_native_rccl(problem):
+    """Give `problem` its own RCCL communicator (no Python in the exchange): rank 0's unique id is
+    broadcast through the already initialised torch.distributed group, then every rank joins."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ids = [problem.rccl_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    problem.rccl_init(ids[0], rank, world)
+
+
 def shard(frame_begin, frame_end, rank, world):
     """Contiguous block of frames [begin, end) owned by `rank`."""
     n = frame_end - frame_begin

@@ -48,6 +48,8 @@ SIGNATURES = {
     "rssync_ext_set_verbose": (C.c_int, [C.c_void_p, C.c_int]),
     "rssync_ext_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rssync_ext_set_reduce_hook": (C.c_int, [C.c_void_p, REDUCE_FN, C.c_void_p]),
+    "rssync_ext_rccl_unique_id": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rssync_ext_rccl_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rssync_ext_upload": (C.c_int, [C.c_void_p]),
     "rssync_ext_sample_rate": (C.c_int, [C.c_void_p, _PD, _PD, C.POINTER(C.c_size_t)]),
     "rssync_ext_gyro_knots": (C.c_int, [C.c_void_p, _PD, C.c_size_t]),
@@ -211,6 +213,19 @@ class SyncProblem:
 
         self._hook = REDUCE_FN(tramp)  # keep the trampoline alive
         self._lib.rssync_ext_set_reduce_hook(self._h, self._hook, None)
+
+    def rccl_unique_id(self):
+        """128 opaque bytes from ncclGetUniqueId (call on rank 0, hand them to every rank)."""
+        buf = C.create_string_buffer(128)
+        self._check(self._lib.rssync_ext_rccl_unique_id(self._h, buf))
+        return buf.raw
+
+    def rccl_init(self, unique_id, rank, world_size):
+        """Join the library's own RCCL communicator; replaces the reduce hook."""
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of rccl_unique_id()")
+        self._check(self._lib.rssync_ext_rccl_init(self._h, C.create_string_buffer(unique_id, 128), int(rank),
+                                                   int(world_size)))
 
     def upload(self):
         """Pack tracks + spline and copy them to HBM now (otherwise lazy)."""

@@ -162,6 +162,11 @@ int rship_rays_from_pixels(rship_ctx* c, const double* px, uint64_t n_pairs, con
     return 0;
 }
 
+// the native exchange needs a GPU and librccl: not part of the test double
+int rship_rccl_unique_id(rship_ctx* c, void*) { return fail(c, "rccl: device only"); }
+int rship_rccl_init(rship_ctx* c, const void*, int, int) { return fail(c, "rccl: device only"); }
+int rship_rccl_allreduce(rship_ctx* c, double*, uint64_t) { return fail(c, "rccl: device only"); }
+
 int rship_debug_rays(rship_ctx* c, uint32_t frame_index, float* a4, float* b4, uint32_t cap) {
     if (frame_index >= c->frames.size()) return fail(c, "debug_rays: index out of range");
     const rship_frame& fr = c->frames[frame_index];

@@ -19,16 +19,18 @@ def main():
                             device_id=torch.device("cuda", 0))
     import rssync_amd
     from rssync_amd import synth
-    from rssync_amd.dist import make_reduce_hook
+    from rssync_amd.dist import make_reduce_hook, use_native_rccl
     F, N = 32, 128
     gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=6)
     res = {}
-    for name in ("plain", "rccl"):
+    for name in ("plain", "rccl", "native"):
         p = rssync_amd.SyncProblem(seed=123, max_outer_iters=12)
         synth.fill(p, gyro, 0, F, N, seed=6)
         if name == "rccl":
             hook = make_reduce_hook()          # picks the device from the backend
             p.set_reduce_hook(hook)
+        if name == "native":                   # the library's own communicator, id broadcast by torch
+            use_native_rccl(p)
         c0, d0 = p.PreSync(0.0, 0, F, 0.004, 0.1)
         c1, d1 = p.Sync(d0, 0, F - 1, 0.0, 0.2)
         res[name] = [c0, d0, c1, d1, len(p.sync_trace())]

@@ -571,7 +571,7 @@ def test_rccl_reduce_hook_on_the_device(tmp_path):
                    timeout=300)
     r = json.load(open(out))
     assert r["backend"] == "nccl"
-    assert r["plain"] == r["rccl"]
+    assert r["plain"] == r["rccl"] == r["native"]
     assert r["exchanges"] == 1 + 2 * r["rccl"][4] + 1
 
 
@@ -635,3 +635,24 @@ def test_create_use_destroy_does_not_leak_device_memory(small_case):
         once()
     free1 = free_bytes()
     assert free0 - free1 < 32 << 20, (free0, free1)
+
+
+def test_native_rccl_exchange_single_rank(small_case):
+    """rssync_ext_rccl_unique_id / _init: the library's own RCCL communicator (librccl opened at
+    run time) with one rank: the all-reduce is the identity, so results equal a hook-free run, and
+    the exchange really goes through ncclAllReduce (a second init is refused)."""
+    import rssync_amd
+    from conftest import fill
+    F = 24
+    case = dict(small_case, frames=small_case["frames"][:F])
+    plain = fill(rssync_amd.SyncProblem(seed=SEED, max_outer_iters=10), case)
+    nat = fill(rssync_amd.SyncProblem(seed=SEED, max_outer_iters=10), case)
+    uid = nat.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    nat.rccl_init(uid, 0, 1)
+    with pytest.raises(rssync_amd.RsSyncError, match="already initialised"):
+        nat.rccl_init(uid, 0, 1)
+    assert nat.PreSync(0.0, 0, F, 0.004, 0.1) == plain.PreSync(0.0, 0, F, 0.004, 0.1)
+    assert nat.Sync(0.036, 0, F - 1, 0.0, 0.2) == plain.Sync(0.036, 0, F - 1, 0.0, 0.2)
+    got = nat.sync_points([0, 8], 10, 0.03, 0.004, 0.05, repeats=2)[1].tolist()
+    assert got == plain.sync_points([0, 8], 10, 0.03, 0.004, 0.05, repeats=2)[1].tolist()
