@@ -170,3 +170,29 @@ def test_orientation_sweep_on_the_host_solver(hosttest_lib, built):
 def test_orientation_sweep_on_the_device(built):
     import rssync_amd
     _check_orientation_sweep(lambda: rssync_amd.SyncProblem(seed=SEED), 24, 256, 0.95)
+
+
+def test_a_frame_can_switch_between_rays_and_pixels(hosttest_lib, built):
+    """SetTrackResult on a frame that was given as pixels (and the reverse) replaces it completely
+    (core_private.cpp:194: re-setting a frame overwrites it)."""
+    import rssync_amd
+    from oracle import oracle
+    from rssync_amd import synth
+    gyro, frames = _scene(F=6, N=40)
+    p = rssync_amd.SyncProblem(seed=SEED, _lib=hosttest_lib)
+    p.SetGyroQuaternions(gyro.quats, gyro.fs, gyro.t0)
+    for fr, ta, tb, pa, pb in frames:
+        p.set_track_pixels(fr, ta, tb, pa, pb, synth.LENS, synth.IMAGE_ROWS)
+    base = p.PreSync(0.0, 0, 6, 0.004, 0.05)
+    fr, ta, tb, pa, pb = frames[2]
+    tracks = oracle.pixels_to_tracks(synth.LENS, ta, tb, synth.IMAGE_ROWS, pa, pb)
+    p.SetTrackResult(fr, *tracks)                      # same content, now as rays
+    a_rays = p.frame_rays(fr)
+    again = p.PreSync(0.0, 0, 6, 0.004, 0.05)
+    assert again[1] == base[1] and again[0] == pytest.approx(base[0], rel=1e-6)
+    p.SetTrackResult(fr, *[x[:10] for x in tracks])    # fewer tracks: the old ones are gone
+    assert p.frame_rays(fr)[0].shape == (10, 4)
+    p.set_track_pixels(fr, ta, tb, pa, pb, synth.LENS, synth.IMAGE_ROWS)   # and back to pixels
+    a_pix = p.frame_rays(fr)
+    assert a_pix[0].shape == (40, 4) and np.abs(a_pix[0] - a_rays[0]).max() <= 1.2e-7
+    assert p.PreSync(0.0, 0, 6, 0.004, 0.05) == base
