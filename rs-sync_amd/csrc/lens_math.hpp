@@ -2,7 +2,8 @@
 //
 // The step upstream of SetTrackResult in the reference driver:
 //   undistort_point   src/core_testcode.cpp:63-95  (Newton inverse of the 4-coefficient fisheye
-//                     polynomial, 9 iterations from pi/4, halving back into (0, pi/2))
+//                     polynomial, 9 iterations from pi/4, halving back into (0, pi/2); written
+//                     here in Horner form, see the function)
 //   row_time          :144-145  ts = frame_time + readout * (pixel_y / image_rows)
 //   unit_ray          :147-152  normalise([x_u, y_u, 1])
 // RS_HD like device_math.hpp: the kernel (rays_from_pixels_kernel) inlines these, the CPU test
@@ -28,43 +29,38 @@ struct Lens { // core_testcode.cpp:55-61
     double k1, k2, k3, k4; // fisheye polynomial
 };
 
+// Inverse of the fisheye model  rd = th * (1 + k1 th^2 + k2 th^4 + k3 th^6 + k4 th^8)  by the
+// reference's fixed schedule (core_testcode.cpp:63-95): nine Newton steps from pi/4, each step
+// pulled back towards the previous iterate by halving while it lies outside (0, pi/2).  Both
+// polynomials are evaluated by Horner's rule in q = th^2 (the reference expands the powers
+// th^2 .. th^9 one by one; the two forms agree to a few fp64 ulps, far below the fp32 result).
+// The slope polynomial keeps the reference's coefficient 8 on k4 (:80; the exact derivative has
+// 9): it changes the path of the iteration, not its fixed point.
 RS_LHD void undistort_point(const Lens& lens, double px, double py, double* ux, double* uy) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
-    const double kHalfPi = 3.14159265358979323846 / 2., kQuarterPi = 3.14159265358979323846 / 4.;
-    if (sqrt(px * px + py * py) < 1e-8) { // :64 (the norm of the PIXEL position, as written)
-        *ux = 0;
-        *uy = 0;
-        return;
+    const double kPi = 3.14159265358979323846;
+    *ux = 0;
+    *uy = 0;
+    if (sqrt(px * px + py * py) < 1e-8) return; // :64 tests the PIXEL position, not the centred one
+    const double xn = (px - lens.cx) / lens.fx, yn = (py - lens.cy) / lens.fy;
+    const double rd = sqrt(xn * xn + yn * yn); // distorted angle the model must reproduce
+    double th = kPi / 4.;
+    for (int step = 0; step < 9; ++step) {
+        const double q = th * th;
+        const double model = th * (1. + q * (lens.k1 + q * (lens.k2 + q * (lens.k3 + q * lens.k4))));
+        const double slope = 1. + q * (3. * lens.k1 + q * (5. * lens.k2 + q * (7. * lens.k3 + q * (8. * lens.k4))));
+        double next = th - (model - rd) / slope;
+        // the midpoints approach th, which lies inside the interval, and reach it exactly after at
+        // most ~1100 halvings of a finite fp64 distance: the bound only guarantees that a wave leaves
+        for (int guard = 0; guard < 1200 && (next <= 0. || next >= kPi / 2.); ++guard) next = 0.5 * (next + th);
+        th = next;
     }
-    const double x_ = (px - lens.cx) / lens.fx;
-    const double y_ = (py - lens.cy) / lens.fy;
-    const double theta_ = sqrt(x_ * x_ + y_ * y_);
-    double theta = kQuarterPi;
-    for (int i = 0; i < 9; ++i) { // :73
-        const double theta2 = theta * theta, theta3 = theta2 * theta, theta4 = theta2 * theta2,
-                     theta5 = theta2 * theta3, theta6 = theta3 * theta3, theta7 = theta3 * theta4,
-                     theta8 = theta4 * theta4, theta9 = theta4 * theta5;
-        const double cur_theta_ = theta + lens.k1 * theta3 + lens.k2 * theta5 + lens.k3 * theta7 + lens.k4 * theta9;
-        // the factor on k4 is 8 in the reference (:80), not 9; kept: it only slows the iteration
-        const double cur_dTheta_ = 1 + 3 * lens.k1 * theta2 + 5 * lens.k2 * theta4 + 7 * lens.k3 * theta6 +
-                                   8 * lens.k4 * theta8;
-        const double error = cur_theta_ - theta_;
-        const double dthetaDtheta_ = 1. / cur_dTheta_;
-        double new_theta = theta - error * dthetaDtheta_;
-        // :85-87 `while`: the midpoint sequence reaches theta (inside the interval) exactly after
-        // at most ~1100 halvings of a finite fp64 distance, so the bound never binds -- it is
-        // there so that a device wave always leaves the loop.
-        for (int guard = 0; guard < 1200 && (new_theta >= kHalfPi || new_theta <= 0.); ++guard)
-            new_theta = (new_theta + theta) / 2.;
-        theta = new_theta;
-    }
-    const double r = tan(theta);
-    const double inv_cos_theta = 1. / cos(theta);
-    const double s = (theta_ < 1e-9) ? inv_cos_theta : r / theta_;
-    *ux = x_ * s;
-    *uy = y_ * s;
+    // (x, y) scaled from distorted radius rd to tan(th); at the image centre the ratio is taken as 1 / cos (:91-93)
+    const double gain = (rd < 1e-9) ? 1. / cos(th) : tan(th) / rd;
+    *ux = xn * gain;
+    *uy = yn * gain;
 }
 
 // one end of a track: pixel -> unit ray (:147-152) and absolute row time (:144-145)

@@ -1,0 +1,156 @@
+"""HIP path vs the oracle at 256 < tracks <= 1024 per frame (BASELINE config 2's 1024-track shape).
+
+The kernels are instantiated per rows-per-thread (rssync_kernels.hip:rpt_for): 1 row for <= 256
+tracks, 2 for <= 512, 4 for <= 1024, 8 for <= 2048.  tests/test_gpu_parity.py covers <1> and <8>;
+these cases dispatch lmeds/loss/opt_motion <2> and <4>, including ragged tails (N not a multiple of
+256: NaN-padded tile rows, partially filled last row tile).  Reference: core_private.cpp:15-32
+(P), :34-59 + :61-90 (PreSync), :92-133 (loss, init), :211-334 (Sync).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 123
+THREADS = min(os.cpu_count() or 1, 16)
+
+
+def _pair(F, N, seed, noise=1e-3, outliers=0.10, **kw):
+    import rssync_amd
+    from rssync_amd import synth
+    from oracle.oracle import OracleProblem
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=seed)
+    h = rssync_amd.SyncProblem(seed=SEED, **kw)
+    o = OracleProblem(seed=SEED, threads=THREADS, faithful=False, **kw)
+    synth.fill(h, g, 0, F, N, seed=seed, noise=noise, outliers=outliers)
+    synth.fill(o, g, 0, F, N, seed=seed, noise=noise, outliers=outliers)
+    return h, o
+
+
+@pytest.mark.parametrize("N", [257, 512, 600, 1024])
+def test_residual_matrix_mid_sizes(N):
+    """problem_matrix at N = 257 / 512 (two rows per thread) and 600 / 1024 (four)"""
+    h, o = _pair(6, N, seed=50 + N)
+    for frame, delay in [(0, 0.0), (3, 0.0371), (5, -0.15)]:
+        Ph, dPh = h.problem_matrix(frame, delay, N, deriv=True)
+        Po = o.problem_matrix(frame, delay)
+        assert Ph.shape == (N, 3)
+        assert np.abs(Ph - Po).max() < 5e-7     # P = ar x br of unit vectors: a few fp32 ulps of 1
+        eps = 1e-6
+        dPo = (o.problem_matrix(frame, delay + eps) - o.problem_matrix(frame, delay - eps)) / (2 * eps)
+        assert np.abs(dPh - dPo).max() < 2e-5 * max(1.0, np.abs(dPo).max())
+
+
+@pytest.mark.parametrize("N,F", [(1024, 32), (600, 24), (300, 24), (512, 16)])
+def test_presync_sweep_mid_sizes(N, F):
+    """BASELINE config 2's sweep (radius 200 ms, step 0.5 ms = 800 candidates) on a slice the oracle
+    finishes in seconds: arg-min, per-(frame, candidate) winning hypothesis, frame costs."""
+    h, o = _pair(F, N, seed=0x5EED0002)
+    dh, ch, fch, bhh = h.presync_curve(0.0, 0, F, 0.0005, 0.2, per_frame=F)
+    do, co, fco, bho = o.presync_curve(0.0, 0, F, 0.0005, 0.2, per_frame=F)
+    assert len(dh) == 800
+    np.testing.assert_array_equal(dh, do)            # candidate delays: bit-exact (core_private.cpp:69-70)
+    same = bhh == bho
+    assert same.mean() > 0.995                       # the arg-min over 20 quantiles flips only at fp32 near-ties
+    rel = np.abs(fch - fco) / fco
+    assert rel[same].max() < 1e-3 and np.median(rel[same]) < 2e-6
+    assert np.argmin(ch) == np.argmin(co)
+    np.testing.assert_allclose(ch, co, rtol=2e-3)
+    c1, d1 = h.PreSync(0.0, 0, F, 0.0005, 0.2)
+    c2, d2 = o.PreSync(0.0, 0, F, 0.0005, 0.2)
+    assert d1 == d2 and c1 == pytest.approx(c2, rel=1e-3)
+
+
+@pytest.mark.parametrize("N", [512, 1024])
+def test_lmeds_selection_is_exact_mid_sizes(N):
+    """the winning hypothesis is the arg-min of the EXACT lower quartile of the device's own fp32
+    residuals (select_kth with NR = 8 / 16 registers per lane)"""
+    from oracle import oracle as ora
+    F = 8
+    h, _ = _pair(F, N, seed=77)
+    dh, ch, fch, bhh = h.presync_curve(0.0, 0, F, 0.02, 0.1, per_frame=F)
+    mismatches = 0
+    for ci in (0, 4, 9):
+        for fr in (0, 3, 7):
+            P = h.problem_matrix(fr, dh[ci], N).astype(np.float64)
+            nrm = np.linalg.norm(P, axis=1)
+            meds = []
+            for hyp in range(20):
+                i0, i1 = ora.sample_pair(SEED, fr, ci, hyp, N)
+                v = np.cross(P[i0], P[i1])
+                v /= np.linalg.norm(v)
+                meds.append(np.sort(((P @ v) / nrm) ** 2)[N // 4])
+            order = np.argsort(meds)
+            if int(order[0]) != int(bhh[ci, fr]):
+                assert (meds[order[1]] - meds[order[0]]) / meds[order[0]] < 1e-4  # a genuine near-tie
+                mismatches += 1
+    assert mismatches <= 1
+
+
+@pytest.mark.parametrize("N", [300, 512, 600, 1024])
+def test_init_loss_gradient_mid_sizes(N):
+    """GuessMotion/GuessK (200 hypotheses), Loss and the analytic d/d-delay at mid sizes"""
+    from oracle import oracle as ora
+    F, d0 = 12, 0.036
+    h, o = _pair(F, N, seed=31 + N)
+    Mh, kh = h.init_motion(d0, 0, F - 1)
+    agree = 0
+    for f in range(F):
+        Mo, bh, med = o.guess_motion(f, d0, 200, ora.STREAM_SYNC_INIT + 0)
+        if np.abs(Mh[f] - Mo).max() < 5e-4:
+            agree += 1
+            P = o.problem_matrix(f, d0)
+            assert kh[f] == pytest.approx(np.clip(100 / np.linalg.norm(P @ Mo), 10, 1000), rel=2e-3)
+    assert agree >= F - 1
+    delays = [d0, d0 + 1e-3, 0.0, -0.17]
+    Lh, Gh = h.loss(delays, grad=True)
+    for j, dd in enumerate(delays):
+        L = Gn = 0.0
+        for f in range(F):
+            l, dn, da, _ = o.loss(f, dd, Mh[f], kh[f])
+            L += l
+            Gn += dn                                  # the reference's central difference (:96-97,112)
+        assert Lh[j] == pytest.approx(L, rel=1e-6)    # fp32 terms, fp64 accumulation
+        assert Gh[j] == pytest.approx(Gn, rel=2e-4, abs=2e-4 * abs(Lh[j]))
+    np.testing.assert_allclose(h.loss(delays), Lh, rtol=1e-6)   # batched no-gradient path (rays in registers)
+
+
+@pytest.mark.parametrize("N", [600, 1024])
+def test_sync_on_clean_data_mid_sizes(N):
+    """Sync at N = 600 and 1024 on noise-free data: within 1e-4 s of the oracle and of the truth
+    (north star), same number of outer iterations."""
+    from rssync_amd import synth
+    F = 32
+    h, o = _pair(F, N, seed=9, noise=0.0, outliers=0.0)
+    ch, dh = h.PreSync(0.0, 0, F, 0.002, 0.1)
+    co, do = o.PreSync(0.0, 0, F, 0.002, 0.1)
+    assert dh == do
+    c1, d1 = h.Sync(dh, 0, F - 1, 0.0, 0.1)
+    c2, d2, tro = o.sync_trace(do, 0, F - 1, 0.0, 0.1)
+    trh = h.sync_trace()
+    assert abs(d1 - synth.D_TRUE) < 1e-4
+    assert abs(d1 - d2) < 1e-4
+    assert abs(len(trh) - len(tro)) <= 2
+
+
+@pytest.mark.parametrize("N", [512, 1024])
+def test_motion_optimiser_mid_sizes(N):
+    """opt_motion_kernel<2>/<4> from identical starts: the loss goes down, k is untouched, and most
+    frames land on the oracle's optimum"""
+    F, d0 = 16, 0.036
+    h, o = _pair(F, N, seed=5 + N)
+    Mh, kh = h.init_motion(d0, 0, F - 1)
+    L0 = h.loss([d0])[0]
+    M2, k2, its, evs = h.opt_motion(d0)
+    L1 = h.loss([d0])[0]
+    assert L1 < L0 and 1 <= its / F <= 200 and evs >= its
+    np.testing.assert_array_equal(k2, kh)
+    same = 0
+    for f in range(F):
+        Mo, it, ev, fl = o.lbfgs_motion(f, d0, Mh[f], kh[f])
+        lh = o.loss(f, d0, M2[f], k2[f])[0]
+        if abs(lh - fl) <= 1e-5 * fl:
+            same += 1
+    assert same >= 0.7 * F
