@@ -79,8 +79,11 @@ int rssync_ext_set_stream(rssync_problem* p, void* hip_stream);
 /* Multi-GPU: frames are sharded over ranks (one process per GPU); the only
  * exchange on the path is a sum of a few doubles (PreSync: the candidate cost
  * vector; Sync: loss/gradient and the line-search losses).  The hook must sum
- * buf[0..n) in place over all ranks (e.g. an RCCL all-reduce).  NULL = single rank. */
-typedef void (*rssync_reduce_fn)(double* buf, size_t n, void* user);
+ * buf[0..n) in place over all ranks (e.g. an RCCL all-reduce) and return 0; any other return value
+ * is a failed exchange and panics ("reduce hook failed"): a rank that carried on with its local
+ * sums would take different decisions from the others.  n is not bounded by the library (batched
+ * sync points exchange candidates x windows doubles).  NULL = single rank. */
+typedef int (*rssync_reduce_fn)(double* buf, size_t n, void* user);
 int rssync_ext_set_reduce_hook(rssync_problem* p, rssync_reduce_fn fn, void* user);
 
 /* Native exchange instead of a reduce hook: the library keeps its own RCCL communicator (one rank

@@ -169,7 +169,11 @@ class SyncProblemHip final : public ISyncProblem {
     bool distributed() const { return native_exchange || reduce_fn; }
     void reduce(double* buf, size_t n) {
         if (native_exchange) hip_check(rship_rccl_allreduce(dev_, buf, n), "rccl all-reduce");
-        else if (reduce_fn) reduce_fn(buf, n, reduce_user);
+        else if (reduce_fn) {
+            const int rc = reduce_fn(buf, n, reduce_user);
+            if (rc) panic("reduce hook failed (status " + std::to_string(rc) + "): the exchange of " + std::to_string(n) +
+                          " doubles did not complete");
+        }
     }
     const std::vector<uint32_t>& selection() const { return sel_; }
     int64_t table_id(uint32_t i) const { return table_ids_[i]; }

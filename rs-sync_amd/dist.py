@@ -19,13 +19,15 @@ def make_reduce_hook(device=None, capacity=8192):
 
     if device is None:
         device = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    buf = torch.zeros(capacity, dtype=torch.float64, device=device)
+    state = {"buf": torch.zeros(capacity, dtype=torch.float64, device=device)}
     stats = {"calls": 0, "doubles": 0}
 
     def hook(arr):
         n = arr.shape[0]
-        if n > capacity:
-            raise ValueError("reduce hook: buffer too small")
+        if n > state["buf"].shape[0]:
+            # batched sync points exchange candidates x windows doubles (98 x 800 = 78 k): grow, never refuse
+            state["buf"] = torch.zeros(max(n, 2 * state["buf"].shape[0]), dtype=torch.float64, device=device)
+        buf = state["buf"]
         buf[:n].copy_(torch.from_numpy(arr))
         dist.all_reduce(buf[:n])
         arr[:] = buf[:n].cpu().numpy()

@@ -22,7 +22,7 @@ def library_path():
     return os.path.join(_HERE, "librssync_core.so")
 
 
-REDUCE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_size_t, C.c_void_p)
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_size_t, C.c_void_p)
 
 _PD = C.POINTER(C.c_double)
 _PF = C.POINTER(C.c_float)
@@ -126,6 +126,7 @@ class SyncProblem:
         if not self._h:
             raise RsSyncError("rssync_create failed: " + self._lib.rssync_last_error().decode())
         self._hook = None
+        self._hook_error = None
         self._lib.rssync_ext_set_verbose(self._h, 1 if verbose else 0)
         if seed is not None:
             self._lib.rssync_ext_set_seed(self._h, int(seed))
@@ -145,7 +146,11 @@ class SyncProblem:
 
     def _check(self, rc):
         if rc:
-            raise RsSyncError(self._lib.rssync_last_error().decode())
+            err = RsSyncError(self._lib.rssync_last_error().decode())
+            cause, self._hook_error = self._hook_error, None
+            if cause is not None:
+                raise err from cause  # the exception a Python reduce hook raised
+            raise err
 
     # ---- ISyncProblem -------------------------------------------------------
     def SetGyroQuaternions(self, data, sample_rate, first_timestamp):
@@ -208,8 +213,15 @@ class SyncProblem:
             return
 
         def tramp(buf, n, _user):
-            arr = np.ctypeslib.as_array(buf, shape=(n,))
-            fn(arr)
+            # ctypes swallows exceptions raised inside a callback: report them as a status instead,
+            # which the library turns into a panic (a skipped all-reduce must never go unnoticed)
+            try:
+                arr = np.ctypeslib.as_array(buf, shape=(n,))
+                fn(arr)
+                return 0
+            except BaseException as exc:  # noqa: BLE001
+                self._hook_error = exc
+                return 1
 
         self._hook = REDUCE_FN(tramp)  # keep the trampoline alive
         self._lib.rssync_ext_set_reduce_hook(self._h, self._hook, None)

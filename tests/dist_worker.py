@@ -35,7 +35,12 @@ def main():
     # the batched driver loop on sharded frames: windows straddle the two ranks' blocks
     pos = [0, 3, 6, 9]
     costs, delays = p.sync_points(pos, 6, 0.02, 0.004, 0.04, repeats=2)
-    res = dict(rank=rank, frames=[b, e], presync=[c0, d0], sync=[c1, d1], iters=iters,
+    # an exchange larger than the hook's initial staging buffer (8192 doubles): 2100 candidates x 4 windows
+    n_before = hook.stats["calls"]
+    wc, wd = p.pre_sync_windows(0.02, [0, 3, 6, 9], [6, 9, 12, 15], 0.0001, 0.105)
+    big = dict(costs=list(map(float, wc)), delays=list(map(float, wd)), calls=hook.stats["calls"] - n_before,
+               doubles=hook.stats["doubles"])
+    res = dict(rank=rank, big=big, frames=[b, e], presync=[c0, d0], sync=[c1, d1], iters=iters,
                presync_exchanges=n_pre, sync_exchanges=n_sync,
                points=[list(map(float, costs)), list(map(float, delays))],
                points_iters=[len(p.window_trace(w)) for w in range(len(pos))])

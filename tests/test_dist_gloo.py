@@ -58,3 +58,12 @@ def test_two_ranks_equal_one(hosttest_lib, tmp_path):
         assert r["points"][1] == pytest.approx(list(delays), abs=1e-9)
         assert r["points"][0] == pytest.approx(list(costs), rel=1e-9)
     assert res[0]["points"] == res[1]["points"]
+    # one exchange of 2100 candidates x 4 windows + 4 flags = 8404 doubles: more than the hook's initial
+    # 8192-double staging buffer, which must grow (a refused or skipped all-reduce would leave the ranks
+    # with different sums)
+    wc, wd = one.pre_sync_windows(0.02, [0, 3, 6, 9], [6, 9, 12, 15], 0.0001, 0.105)
+    for r in res:
+        assert r["big"]["calls"] == 1
+        assert r["big"]["delays"] == list(wd)
+        assert r["big"]["costs"] == pytest.approx(list(wc), rel=1e-12)
+    assert res[0]["big"]["costs"] == res[1]["big"]["costs"]

@@ -139,6 +139,25 @@ def test_reduce_hook_is_called_twice_per_outer_iteration(host, tiny_case):
     assert calls[0] == 2 and calls[1] == 10
 
 
+def test_a_failing_reduce_hook_is_a_panic_not_a_silent_skip(host, tiny_case):
+    """an exception inside the Python hook (ctypes would swallow it) or a non-zero status from a C hook
+    must stop the call: a rank that continued with rank-local sums would diverge from the others"""
+    import rssync_amd
+    F = tiny_case["F"]
+    h = host(tiny_case, max_outer_iters=2)
+
+    def broken(arr):
+        raise ValueError("staging buffer too small")
+
+    h.set_reduce_hook(broken)
+    with pytest.raises(rssync_amd.RsSyncError, match="reduce hook failed") as ei:
+        h.PreSync(0.0, 0, F, 0.01, 0.05)
+    assert isinstance(ei.value.__cause__, ValueError)
+    h.set_reduce_hook(None)
+    c, d = h.PreSync(0.0, 0, F, 0.01, 0.05)
+    assert np.isfinite(c)
+
+
 def test_panics_follow_the_reference_messages(host, tiny_case):
     import rssync_amd
     h = host()
