@@ -73,6 +73,12 @@ int rssync_ext_set_seed(rssync_problem* p, uint64_t seed);
 int rssync_ext_set_max_outer_iters(rssync_problem* p, int iters);
 /* 0 silences the "delay step" progress lines Sync writes to stderr (core_private.cpp:330; env RSSYNC_QUIET=1) */
 int rssync_ext_set_verbose(rssync_problem* p, int verbose);
+/* The per-frame motion optimiser restates ens::L_BFGS (core_private.cpp:264-294; third party, unpinned).
+ * When a line search's best step is not its last, 0 (default) keeps value and gradient as the last trial
+ * left them while the iterate moves to the best step (the published LineSearch); 1 re-evaluates there. */
+int rssync_ext_set_lbfgs_reeval(rssync_problem* p, int reeval);
+/* line searches of the last rssync_ext_opt_motion call whose best step was not the last one tried */
+int rssync_ext_lbfgs_best_not_last(rssync_problem* p, uint64_t* count);
 /* run the kernels on a caller-owned hipStream_t (NULL = internal stream) */
 int rssync_ext_set_stream(rssync_problem* p, void* hip_stream);
 

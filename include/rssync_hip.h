@@ -64,6 +64,11 @@ const char* rship_last_error(const rship_ctx* c);
 /* launch on a caller-owned hipStream_t (NULL = the context's own stream) */
 int rship_set_stream(rship_ctx* c, void* hip_stream);
 int rship_max_tracks(void); /* largest per-frame track count the kernels accept */
+/* Behaviour switches.  RSHIP_OPT_LBFGS_REEVAL: what the restated ens::L_BFGS does when a line search's
+ * best step is not its last -- 0 (default): iterate at the best step, value and gradient as the last
+ * trial left them (the published LineSearch); 1: evaluate once more at the best step. */
+#define RSHIP_OPT_LBFGS_REEVAL 1
+int rship_set_option(rship_ctx* c, int option, int value);
 
 /* OptData::quats (core_private.hpp:18): coefficient table built on the host by
  * the spline solver that replaces minispline.cpp:3-46 */
@@ -106,7 +111,7 @@ int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t
 
 /* do_opt_motion (core_private.cpp:262-296): per-frame L-BFGS on the motion
  * vector at a fixed delay per window (fd = NaN skips a window).
- * stats (optional) = {sum of iterations, sum of evaluations} */
+ * stats (optional) = {sum of iterations, sum of evaluations, line searches whose best step was not the last} */
 int rship_opt_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint64_t* stats);
 /* the same with per-slot diagnostics: per_frame[2i] = L-BFGS iterations, [2i+1] = evaluations */
 int rship_opt_motion_detail(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t* per_frame,

@@ -53,6 +53,9 @@ def load():
     lib.ora_set_max_outer_iters.argtypes = [C.c_void_p, C.c_int]
     lib.ora_set_faithful.argtypes = [C.c_void_p, C.c_int]
     lib.ora_set_verbose.argtypes = [C.c_void_p, C.c_int]
+    lib.ora_set_lbfgs_reeval.argtypes = [C.c_void_p, C.c_int]
+    lib.ora_lbfgs_best_not_last.argtypes = [C.c_void_p]
+    lib.ora_lbfgs_best_not_last.restype = C.c_long
     lib.ora_gyro_knots.argtypes = [C.c_void_p, _PD]
     lib.ora_set_gyro_quaternions.argtypes = [C.c_void_p, _PD, C.c_size_t, C.c_double, C.c_double]
     lib.ora_set_gyro_quaternions_ts.argtypes = [C.c_void_p, C.POINTER(C.c_int64), _PD, C.c_size_t]
@@ -149,7 +152,7 @@ def integrate_gyro(timestamps_s, rates, orientation=None):
 
 
 class OracleProblem:
-    def __init__(self, seed=None, max_outer_iters=None, threads=1, faithful=True, verbose=False):
+    def __init__(self, seed=None, max_outer_iters=None, threads=1, faithful=True, verbose=False, lbfgs_reeval=False):
         self._lib = load()
         self._h = self._lib.ora_create()
         if seed is not None:
@@ -159,6 +162,11 @@ class OracleProblem:
         self._lib.ora_set_threads(self._h, int(threads))
         self._lib.ora_set_faithful(self._h, 1 if faithful else 0)
         self._lib.ora_set_verbose(self._h, 1 if verbose else 0)
+        self._lib.ora_set_lbfgs_reeval(self._h, 1 if lbfgs_reeval else 0)
+
+    def lbfgs_best_not_last(self):
+        """line searches so far whose best step was not the last one tried"""
+        return int(self._lib.ora_lbfgs_best_not_last(self._h))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -38,7 +38,8 @@ struct ora_problem {
     frame_t* frames; /* ascending id */
     size_t nframes, cap;
     uint64_t seed;
-    int nthreads, max_outer, faithful, verbose;
+    int nthreads, max_outer, faithful, verbose, lbfgs_reeval;
+    long lbfgs_best_not_last; /* line searches whose best step was not the last one tried */
     uint32_t sync_calls;
     /* frames selected by the last Sync (indices into frames) */
     size_t* sel;
@@ -84,6 +85,8 @@ void ora_set_threads(ora_problem* p, int n) { p->nthreads = n < 1 ? 1 : n; }
 void ora_set_max_outer_iters(ora_problem* p, int it) { p->max_outer = it; }
 void ora_set_faithful(ora_problem* p, int f) { p->faithful = f; }
 void ora_set_verbose(ora_problem* p, int v) { p->verbose = v; }
+void ora_set_lbfgs_reeval(ora_problem* p, int v) { p->lbfgs_reeval = v; }
+long ora_lbfgs_best_not_last(const ora_problem* p) { return p->lbfgs_best_not_last; }
 double ora_sample_rate(const ora_problem* p) { return p->sample_rate; }
 double ora_quats_start(const ora_problem* p) { return p->quats_start; }
 size_t ora_gyro_count(const ora_problem* p) { return p->gyro_n; }
@@ -829,9 +832,13 @@ int ora_loss(const ora_problem* p, int64_t frame, double delay, const double M[3
  * ensmallen 2.x (lbfgs_impl.hpp): two-loop recursion, scaling 1/|g| on the
  * first iteration and s.y / y.y afterwards, backtracking/expanding line
  * search (x0.5 on Armijo failure or strong-Wolfe overshoot, x2.1 on curvature
- * failure) that moves to the best-objective step.  One stated choice: when
- * the best step is not the last step evaluated, value and gradient are
- * re-evaluated at the best step so that (x, f, g) stay consistent. */
+ * failure) that moves to the best-objective step.
+ * When the best step is not the last one evaluated, the published LineSearch moves the ITERATE to
+ * the best step but leaves functionValue and gradient as the LAST trial computed them; the
+ * progress test, UpdateBasisSet (y = gradient - oldGradient) and the next search direction then
+ * use that value and gradient.  That is the default here (lbfgs_reeval = 0).  ora_set_lbfgs_reeval(1)
+ * selects the self-consistent variant instead (one more evaluation at the best step), which round
+ * 1 used; tests/measure/ counts how often the two differ and what it does to Sync's delay. */
 
 typedef struct {
     const ora_problem* p;
@@ -927,7 +934,11 @@ static double lbfgs_minimise(motion_obj* o, double x[3], int* iters_out) {
             step *= width;
         }
         for (int c = 0; c < 3; ++c) x[c] += bestStep * dir[c];
-        if (bestStep != lastStep) fval = motion_eval(o, x, g); /* stated choice, see above */
+        if (bestStep != lastStep) {
+            __atomic_fetch_add(&((ora_problem*)o->p)->lbfgs_best_not_last, 1L, __ATOMIC_RELAXED);
+            if (o->p->lbfgs_reeval) fval = motion_eval(o, x, g); /* variant: keep (x, f, g) consistent */
+            /* default: f and g stay those of the last trial, as the published LineSearch leaves them */
+        }
         if (bestStep == 0.0) break;
         double denom = fmax(fmax(fabs(prev), fabs(fval)), 1.0);
         if ((prev - fval) / denom <= factr) break;

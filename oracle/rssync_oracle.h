@@ -53,6 +53,10 @@ void ora_set_threads(ora_problem* p, int nthreads);      /* frames-parallel pool
 void ora_set_max_outer_iters(ora_problem* p, int iters); /* reference: 400 */
 void ora_set_faithful(ora_problem* p, int faithful);     /* 1 = reference evaluation schedule */
 void ora_set_verbose(ora_problem* p, int verbose);       /* 1 = print "delay step" like the reference */
+/* L-BFGS line search whose best step is not its last: 0 (default) = value and gradient stay those of the
+ * last trial, as ensmallen's LineSearch leaves them; 1 = re-evaluate at the best step */
+void ora_set_lbfgs_reeval(ora_problem* p, int reeval);
+long ora_lbfgs_best_not_last(const ora_problem* p);      /* how many line searches ended that way so far */
 
 /* core_private.cpp:135-140 */
 int ora_set_gyro_quaternions(ora_problem* p, const double* data, size_t count,

@@ -7,9 +7,12 @@ namespace {
 // ---------------------------------------------------------------------------
 // K3: per-frame L-BFGS on the motion vector, P resident in registers.
 // Restates ens::L_BFGS as called at core_private.cpp:264-294 (MaxIterations 200,
-// MinGradientNorm 1e-4, library defaults otherwise); the algorithm and the one
-// stated choice (re-evaluate at the best step when it is not the last one tried)
-// are those of oracle/rssync_oracle.c:lbfgs_minimise.  Control flow is uniform:
+// MinGradientNorm 1e-4, library defaults otherwise) from the published ensmallen 2.x
+// algorithm (lbfgs_impl.hpp; the dependency is unpinned and not under the reference tree).
+// When a line search's best step is not its last, the published LineSearch moves the iterate
+// to the best step and leaves value and gradient as the last trial computed them; that is the
+// default (MotionParams::reeval = 0).  reeval = 1 evaluates once more at the best step so that
+// (x, f, g) stay consistent (round 1's choice; kept for comparison).  Control flow is uniform:
 // every thread runs the same fp64 scalar logic on the same reduced sums.
 
 struct MotionParams {
@@ -25,7 +28,8 @@ struct MotionParams {
     const uint32_t* grp;
     double* M; // per selection slot
     const double* k;
-    unsigned long long* stats; // [0] += iterations, [1] += evaluations
+    unsigned long long* stats; // [0] += iterations, [1] += evaluations, [2] += line searches with best != last step
+    int reeval;                // see the header comment
     uint32_t* per_frame;       // optional [n_sel][2]: iterations, evaluations
 };
 
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(kBlock, 4) void opt_motion_kernel(MotionParams p) {
     double x[3] = {p.M[3 * sf], p.M[3 * sf + 1], p.M[3 * sf + 2]};
     double g[3], oldx[3], oldg[3], dir[3];
     double fval = ev(x, g);
-    int it = 0;
+    int it = 0, best_not_last = 0;
     for (; it != maxIterations; ++it) {
         const double prev = fval;
         if (sqrt(dot3d(g, g)) < minGradientNorm) break;
@@ -197,7 +201,10 @@ __global__ __launch_bounds__(kBlock, 4) void opt_motion_kernel(MotionParams p) {
             step *= width;
         }
         x[0] += bestStep * dir[0]; x[1] += bestStep * dir[1]; x[2] += bestStep * dir[2];
-        if (bestStep != lastStep) fval = ev(x, g);
+        if (bestStep != lastStep) {
+            ++best_not_last;
+            if (p.reeval) fval = ev(x, g);
+        }
         if (bestStep == 0.0) break;
         const double denom = fmax(fmax(fabs(prev), fabs(fval)), 1.0);
         if ((prev - fval) / denom <= factr) break;
@@ -213,6 +220,7 @@ __global__ __launch_bounds__(kBlock, 4) void opt_motion_kernel(MotionParams p) {
         if (p.stats) {
             atomicAdd(&p.stats[0], (unsigned long long)it);
             atomicAdd(&p.stats[1], (unsigned long long)ev.evals);
+            atomicAdd(&p.stats[2], (unsigned long long)best_not_last);
         }
         if (p.per_frame) {
             p.per_frame[2 * sf] = (uint32_t)it;

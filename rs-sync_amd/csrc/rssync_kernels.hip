@@ -65,6 +65,7 @@ struct rship_ctx {
     uint32_t n_knots = 0, n_frames = 0, n_sel = 0, max_n = 0, n_grp = 1;
     uint64_t total_rays = 0;
     double fs = 0;
+    int lbfgs_reeval = 0; // RSHIP_OPT_LBFGS_REEVAL
     float max_span = 0.f; // widest frame, in knots (frame table)
     // native exchange (RCCL through dlopen)
     void* rccl_lib = nullptr;
@@ -341,6 +342,13 @@ void rship_destroy(rship_ctx* c) {
 
 const char* rship_last_error(const rship_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
+int rship_set_option(rship_ctx* c, int option, int value) {
+    switch (option) {
+        case RSHIP_OPT_LBFGS_REEVAL: c->lbfgs_reeval = value != 0; return 0;
+        default: return set_err(c, "set_option: unknown option");
+    }
+}
+
 int rship_set_stream(rship_ctx* c, void* hip_stream) {
     DeviceGuard dev_guard(c);
     RS_HIP(hipStreamSynchronize(c->stream));
@@ -535,6 +543,7 @@ void fill_motion(rship_ctx* c, MotionParams& p) {
     p.grp = c->n_grp > 1 ? (const uint32_t*)c->grp.p : nullptr;
     p.M = (double*)c->M.p;
     p.k = (const double*)c->k.p;
+    p.reeval = c->lbfgs_reeval;
 }
 } // namespace
 
@@ -596,8 +605,8 @@ int rship_opt_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint64_t*
     DeviceGuard dev_guard(c);
     if (check_ready(c)) return 1;
     if (stats) {
-        if (ensure(c, c->stats, 16)) return 1;
-        RS_HIP(hipMemsetAsync(c->stats.p, 0, 16, c->stream));
+        if (ensure(c, c->stats, 32)) return 1;
+        RS_HIP(hipMemsetAsync(c->stats.p, 0, 32, c->stream));
     }
     if (upload_delays(c, kd, fd, c->n_grp)) return 1;
     MotionParams p{};
@@ -605,10 +614,10 @@ int rship_opt_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint64_t*
     p.stats = stats ? (unsigned long long*)c->stats.p : nullptr;
     if (launch_motion(c, p, rpt_for(c->max_n))) return 1;
     if (stats) {
-        if (ensure_pinned(c, 16)) return 1;
-        RS_HIP(hipMemcpyAsync(c->pinned, c->stats.p, 16, hipMemcpyDeviceToHost, c->stream));
+        if (ensure_pinned(c, 32)) return 1;
+        RS_HIP(hipMemcpyAsync(c->pinned, c->stats.p, 24, hipMemcpyDeviceToHost, c->stream));
         if (sync_stream(c)) return 1;
-        memcpy(stats, c->pinned, 16);
+        memcpy(stats, c->pinned, 24);
         return 0;
     }
     return 0; // stays queued: the next loss call is ordered behind it on the stream

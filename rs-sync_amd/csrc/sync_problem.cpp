@@ -181,6 +181,7 @@ class SyncProblemHip final : public ISyncProblem {
     bool has_frame(int64_t id) const { return frames_.count(id) != 0; }
     size_t frame_tracks(int64_t id) const { return frames_.at(id).ts_a.size(); }
     uint32_t sync_calls = 0;
+    uint64_t last_best_not_last = 0; // of the last rssync_ext_opt_motion call
 
    private:
     void hip_check(int rc, const char* what) {
@@ -1061,6 +1062,16 @@ int rssync_debug_pre_sync(rssync_problem* p, double initial_delay, int64_t frame
 int rssync_ext_set_seed(rssync_problem* p, uint64_t seed) { p->impl->seed = seed; return 0; }
 int rssync_ext_set_max_outer_iters(rssync_problem* p, int iters) { p->impl->max_outer = iters; return 0; }
 int rssync_ext_set_verbose(rssync_problem* p, int verbose) { p->impl->verbose = verbose != 0; return 0; }
+int rssync_ext_set_lbfgs_reeval(rssync_problem* p, int reeval) {
+    return guarded([&] {
+        if (rship_set_option(p->impl->dev(), RSHIP_OPT_LBFGS_REEVAL, reeval))
+            panic(std::string("hip: set option: ") + rship_last_error(p->impl->dev()));
+    });
+}
+int rssync_ext_lbfgs_best_not_last(rssync_problem* p, uint64_t* count) {
+    *count = p->impl->last_best_not_last;
+    return 0;
+}
 int rssync_ext_set_stream(rssync_problem* p, void* hip_stream) {
     return guarded([&] {
         if (rship_set_stream(p->impl->dev(), hip_stream)) panic(std::string("hip: set stream: ") + rship_last_error(p->impl->dev()));
@@ -1154,13 +1165,14 @@ int rssync_ext_opt_motion(rssync_problem* p, double delay, double* M, double* k,
                           uint64_t* evals) {
     return guarded([&] {
         SyncProblemHip* s = p->impl;
-        uint64_t st[2] = {0, 0};
+        uint64_t st[3] = {0, 0, 0};
         s->opt_motion({delay}, st);
         uint32_t n = 0;
         if (rship_get_motion(s->dev(), M, k, (uint32_t)cap, &n)) panic(std::string("hip: get motion: ") + rship_last_error(s->dev()));
         if (n_frames) *n_frames = (int)n;
         if (iters) *iters = st[0];
         if (evals) *evals = st[1];
+        s->last_best_not_last = st[2];
     });
 }
 

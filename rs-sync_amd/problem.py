@@ -46,6 +46,8 @@ SIGNATURES = {
     "rssync_ext_set_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
     "rssync_ext_set_max_outer_iters": (C.c_int, [C.c_void_p, C.c_int]),
     "rssync_ext_set_verbose": (C.c_int, [C.c_void_p, C.c_int]),
+    "rssync_ext_set_lbfgs_reeval": (C.c_int, [C.c_void_p, C.c_int]),
+    "rssync_ext_lbfgs_best_not_last": (C.c_int, [C.c_void_p, _PU64]),
     "rssync_ext_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rssync_ext_set_reduce_hook": (C.c_int, [C.c_void_p, REDUCE_FN, C.c_void_p]),
     "rssync_ext_rccl_unique_id": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -201,6 +203,16 @@ class SyncProblem:
 
     def set_max_outer_iters(self, n):
         self._lib.rssync_ext_set_max_outer_iters(self._h, int(n))
+
+    def set_lbfgs_reeval(self, reeval):
+        """False (default): a line search whose best step is not its last leaves value and gradient as
+        the last trial computed them (published ens::L_BFGS); True: re-evaluate at the best step."""
+        self._check(self._lib.rssync_ext_set_lbfgs_reeval(self._h, 1 if reeval else 0))
+
+    def lbfgs_best_not_last(self):
+        n = C.c_uint64()
+        self._lib.rssync_ext_lbfgs_best_not_last(self._h, C.byref(n))
+        return n.value
 
     def set_stream(self, hip_stream_ptr):
         self._check(self._lib.rssync_ext_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)))

@@ -29,6 +29,7 @@ struct rship_ctx {
     std::vector<rship_frame> frames;
     std::vector<uint32_t> sel, grp, grp_off; // slots, slot -> window, window offsets
     std::vector<double> M, k;                // per slot
+    int lbfgs_reeval = 0;
 };
 
 namespace {
@@ -111,6 +112,11 @@ int rship_create(rship_ctx** out, int) { *out = new rship_ctx(); return 0; }
 void rship_destroy(rship_ctx* c) { delete c; }
 const char* rship_last_error(const rship_ctx* c) { return c->err.c_str(); }
 int rship_set_stream(rship_ctx*, void*) { return 0; }
+int rship_set_option(rship_ctx* c, int option, int value) {
+    if (option != RSHIP_OPT_LBFGS_REEVAL) return fail(c, "set_option: unknown option");
+    c->lbfgs_reeval = value != 0;
+    return 0;
+}
 
 int rship_upload_spline(rship_ctx* c, const float* coef16, uint32_t n_knots, double sample_rate) {
     c->coef.resize((size_t)n_knots * 4);
@@ -273,7 +279,7 @@ int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t
 
 // the kernel's L-BFGS (kernels/motion.hpp: opt_motion_kernel), sequential
 int rship_opt_motion(rship_ctx* c, const int32_t* kdv, const float* fdv, uint64_t* stats) {
-    uint64_t tot_it = 0, tot_ev = 0;
+    uint64_t tot_it = 0, tot_ev = 0, tot_bnl = 0;
     for (size_t sl = 0; sl < c->sel.size(); ++sl) {
         const uint32_t fi = c->sel[sl], grp = c->grp[sl];
         const int32_t kd = kdv[grp];
@@ -359,7 +365,10 @@ int rship_opt_motion(rship_ctx* c, const int32_t* kdv, const float* fdv, uint64_
                 step *= width;
             }
             for (int q = 0; q < 3; ++q) x[q] += bestStep * dir[q];
-            if (bestStep != lastStep) fval = ev(x, g);
+            if (bestStep != lastStep) {
+                ++tot_bnl;
+                if (c->lbfgs_reeval) fval = ev(x, g);
+            }
             if (bestStep == 0.0) break;
             if ((prev - fval) / std::fmax(std::fmax(std::fabs(prev), std::fabs(fval)), 1.0) <= 1e-15) break;
             int op = it % NB;
@@ -369,7 +378,7 @@ int rship_opt_motion(rship_ctx* c, const int32_t* kdv, const float* fdv, uint64_
         tot_it += (uint64_t)it;
         tot_ev += (uint64_t)evals;
     }
-    if (stats) { stats[0] = tot_it; stats[1] = tot_ev; }
+    if (stats) { stats[0] = tot_it; stats[1] = tot_ev; stats[2] = tot_bnl; }
     return 0;
 }
 

@@ -177,7 +177,7 @@ def test_analytic_delay_derivative_equals_the_reference_central_difference(oracl
             assert da == pytest.approx(dn, rel=2e-7, abs=1e-5)  # h = 1e-6 central difference: O(h^2)
 
 
-def _lbfgs_python(P, k, x):
+def _lbfgs_python(P, k, x, reeval=False):
     """Independent transcription of the restated ens::L_BFGS (same constants and branches)."""
     def ev(x):
         s = (x @ x) / (k * k)
@@ -236,7 +236,7 @@ def _lbfgs_python(P, k, x):
                 break
             step *= width
         x = x + best * dirn
-        if best != last:
+        if best != last and reeval:   # published LineSearch: value and gradient stay those of the last trial
             fv, g = ev(x)
             evals += 1
         if best == 0:
@@ -250,18 +250,26 @@ def _lbfgs_python(P, k, x):
     return x, it, evals, fv
 
 
+@pytest.mark.parametrize("reeval", [False, True])
 @pytest.mark.parametrize("frame", [0, 3, 4, 5, 21])
-def test_lbfgs_follows_the_python_transcription(oracle_small, frame):
+def test_lbfgs_follows_the_python_transcription(small_case, frame, reeval):
+    from conftest import fill
+    o = fill(OracleProblem(seed=123, threads=1, faithful=False, lbfgs_reeval=reeval), small_case)
     d = 0.036
-    M, _, _ = oracle_small.guess_motion(frame, d, 200, ora.STREAM_SYNC_INIT)
-    P = oracle_small.problem_matrix(frame, d)
+    M, _, _ = o.guess_motion(frame, d, 200, ora.STREAM_SYNC_INIT)
+    P = o.problem_matrix(frame, d)
     k = float(np.clip(100 / np.linalg.norm(P @ M), 10, 1000))
-    Mo, it, ev, fl = oracle_small.lbfgs_motion(frame, d, M, k)
-    Mp, itp, evp, flp = _lbfgs_python(P, k, M.copy())
+    Mo, it, ev, fl = o.lbfgs_motion(frame, d, M, k)
+    Mp, itp, evp, flp = _lbfgs_python(P, k, M.copy(), reeval=reeval)
     assert (it, ev) == (itp, evp)
-    np.testing.assert_allclose(Mo, Mp, rtol=1e-6, atol=1e-9)  # numpy sums pairwise, the C code in order
+    # numpy sums pairwise, the C code in order.  The loss does not depend on |M| (core_private.cpp:120
+    # divides by it), so the length of the iterate is a free gauge that the optimiser lets drift: the
+    # direction is what is determined
+    np.testing.assert_allclose(Mo / np.linalg.norm(Mo), Mp / np.linalg.norm(Mp), rtol=0, atol=2e-6)
+    assert np.linalg.norm(Mo) == pytest.approx(np.linalg.norm(Mp), rel=2e-3)
     assert fl == pytest.approx(flp, rel=1e-9)
-    assert fl <= oracle_small.loss(frame, d, M, k)[0] + 1e-9  # never worse than the start
+    # the returned value is the last trial's in the published form; the iterate itself never ends worse than the start
+    assert o.loss(frame, d, Mo, k)[0] <= o.loss(frame, d, M, k)[0] + 1e-9
 
 
 def test_presync_minimum_is_the_grid_point_nearest_the_true_delay(oracle_clean, clean_case):
