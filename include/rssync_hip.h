@@ -10,8 +10,8 @@
  *
  * Conventions
  *  - a "delay" reaches the device as  delay * sample_rate = kd + fd  with kd an
- *    int32 knot count and fd an fp32 fraction in [0,1): absolute times are
- *    never rounded to fp32;
+ *    int32 knot count and fd a fraction in [0,1) (fp32 for the PreSync sweep, fp64 for the Sync
+ *    kernels): absolute times are never rounded to fp32;
  *  - rays live in HBM as two float4 streams per frame with the two ends of a
  *    ray pair interleaved, {ax,bx,ay,by} and {az,bz,ta,tb} (a 16-byte load
  *    yields (a,b) component pairs in adjacent registers, which the packed
@@ -32,14 +32,15 @@ extern "C" {
 
 typedef struct rship_ctx rship_ctx;
 
-/* one record of the device frame table (32 bytes) */
+/* one record of the device frame table (48 bytes) */
 typedef struct rship_frame {
-    uint32_t ray_offset; /* first ray of the frame in the two float4 streams */
+    uint32_t ray_offset; /* first ray of the frame in the packed streams */
     uint32_t n_rays;
     int32_t base_knot; /* floor(min over rays of (ts - start) * fs) */
-    float tmin, tmax;  /* min / max of the per-ray offsets ta, tb */
+    float tmin, tmax;  /* min / max of the per-ray offsets ta, tb as the fp32 streams hold them */
     uint32_t reserved;
-    int64_t id; /* caller's frame number (keys the hypothesis sampler) */
+    int64_t id;            /* caller's frame number (keys the hypothesis sampler) */
+    double tmin64, tmax64; /* the same bounds as the fp64 streams hold them */
 } rship_frame;
 
 /* status bits reported by the LMedS kernel; the host turns them into the
@@ -55,7 +56,7 @@ typedef struct rship_frame {
 #define RSHIP_K_MOTION 2 /* per-frame motion L-BFGS */
 #define RSHIP_K_REDUCE 3 /* over-frames sums */
 #define RSHIP_K_INIT 4   /* the LMedS kernel in GuessMotion/GuessK mode (Sync start) */
-#define RSHIP_K_PIXELS 5 /* pixel -> ray + row time (rship_rays_from_pixels) */
+#define RSHIP_K_PIXELS 5 /* packing kernels: raw records (rays or pixels) -> packed fp32 + fp64 streams */
 #define RSHIP_K_COUNT 6
 
 int rship_create(rship_ctx** out, int device /* -1 = current device */);
@@ -70,14 +71,42 @@ int rship_max_tracks(void); /* largest per-frame track count the kernels accept 
 #define RSHIP_OPT_LBFGS_REEVAL 1
 int rship_set_option(rship_ctx* c, int option, int value);
 
-/* OptData::quats (core_private.hpp:18): coefficient table built on the host by
- * the spline solver that replaces minispline.cpp:3-46 */
-int rship_upload_spline(rship_ctx* c, const float* coef16, uint32_t n_knots, double sample_rate);
+/* OptData::quats (core_private.hpp:18): coefficient table built on the host in fp64 by the spline
+ * solver that replaces minispline.cpp:3-46: 16 doubles per knot = y[4], b[4], c[4], d[4] over
+ * [w,x,y,z].  The device keeps it in fp64 (Sync kernels) and rounds it once to fp32 (PreSync). */
+int rship_upload_spline(rship_ctx* c, const double* coef16, uint32_t n_knots, double sample_rate);
 
-/* OptData::frame_data (core_private.hpp:21): all frames, packed.  Both ray pointers NULL =
- * allocate only (every frame is then filled by rship_rays_from_pixels). */
-int rship_upload_frames(rship_ctx* c, const float* rays_xy4, const float* rays_zt4,
-                        uint64_t total_rays, const rship_frame* table, uint32_t n_frames);
+/* OptData::frame_data (core_private.hpp:21).  Track data travels in three steps:
+ *  1. SetTrackResult copies the caller's arrays into a host staging arena obtained from
+ *     rship_host_alloc (pinned memory: the copy the reference's contract requires,
+ *     core_private.cpp:192-203) as one record per frame,
+ *         rays:   ts_a[n], ts_b[n], rays_a[3n], rays_b[3n]        (8n doubles)
+ *         pixels: {xa, ya, xb, yb}[n]                             (4n doubles);
+ *  2. rship_upload_raw copies a range of the arena to the same offsets of the context's raw
+ *     buffer, asynchronously on the context's copy stream (it may be called while the caller is
+ *     still feeding frames);
+ *  3. rship_pack_frames runs the packing kernels: raw records -> the packed fp32 streams the
+ *     PreSync kernel reads ({ax,bx,ay,by} / {az,bz,ta,tb}, 32 B per ray pair) and the fp64 streams
+ *     the Sync kernels read ({ax,bx} {ay,by} {az,bz} {ta,tb} as double2, 64 B per ray pair), with
+ *     ta/tb = (ts - start) * fs - base_knot evaluated in fp64 on the device.  Nothing is packed on
+ *     the host and nothing but the raw records crosses PCIe. */
+void* rship_host_alloc(size_t bytes); /* pinned where a HIP device exists; NULL on failure */
+void rship_host_free(void* p);
+int rship_upload_raw(rship_ctx* c, const double* host, uint64_t arena_offset, uint64_t n_doubles);
+
+typedef struct rship_pack_frame {
+    uint64_t raw_offset;         /* arena offset (doubles) of the frame's record */
+    uint32_t ray_offset, n_rays; /* where its rays go in the packed streams */
+    double base;                 /* base knot, as the frame table has it */
+    uint32_t is_pixels, reserved;
+    double time_a, time_b, rows; /* pixels only: frame times (s), image rows */
+    double lens[9];              /* pixels only: ro, fx, fy, cx, cy, k1, k2, k3, k4 */
+} rship_pack_frame;
+/* (Re)build the packed streams of ALL frames: table[i] / pack[i] describe frame i, frames in
+ * ascending id order.  *bad = number of rays with a non-finite packed value (pixel frames: the
+ * reference checks the rays it is handed, core_private.cpp:199-200). */
+int rship_pack_frames(rship_ctx* c, const rship_frame* table, const rship_pack_frame* pack, uint32_t n_frames,
+                      uint64_t total_rays, double start, double fs, uint32_t* bad);
 
 /* the frames a PreSync/Sync call works on (indices into the table; replaces the
  * frame filters at core_private.cpp:65-68, :218-219, :340-343) */
@@ -128,21 +157,9 @@ int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_dela
 int rship_get_motion(rship_ctx* c, double* M, double* k, uint32_t cap, uint32_t* n);
 int rship_set_motion(rship_ctx* c, const double* M, const double* k, uint32_t n);
 
-/* A frame given as tracked pixel positions instead of rays (the reference driver's step
- * upstream of SetTrackResult, core_testcode.cpp:63-95,135-158). */
-typedef struct rship_pixel_frame {
-    double time_a, time_b, rows; /* times (s) of the current / next video frame; image rows */
-    double lens[9];              /* ro, fx, fy, cx, cy, k1, k2, k3, k4 */
-    double start, fs, base;      /* gyro grid (quats_start, sample_rate) and the frame's base knot */
-    uint64_t px_offset;          /* first pair of the frame in px */
-    uint32_t ray_offset, n_rays; /* where its rays live in the two float4 streams */
-} rship_pixel_frame;
-
-/* Undistort + normalise + row time + knot offset in fp64 on the device, written straight into
- * the packed ray streams uploaded by rship_upload_frames (whose slices for these frames may hold
- * anything).  px: 4 doubles per pair {xa, ya, xb, yb}.  *bad = number of non-finite outputs. */
-int rship_rays_from_pixels(rship_ctx* c, const double* px, uint64_t n_pairs, const rship_pixel_frame* frames,
-                           uint32_t n_frames, uint32_t* bad);
+/* Frames given as tracked pixel positions instead of rays (the reference driver's step upstream of
+ * SetTrackResult, core_testcode.cpp:63-95,135-158) are rship_pack_frame records with is_pixels = 1:
+ * undistortion, normalisation, row time and knot offset run in fp64 inside the packing kernel. */
 
 /* Native exchange for frame-sharded multi-GPU runs: an RCCL communicator owned by the context
  * (librccl is opened with dlopen on first use: no link-time dependency), one rank per process.

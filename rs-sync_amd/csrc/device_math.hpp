@@ -40,16 +40,30 @@ RS_HD float rsqrt_fast(float x) {
 #endif
 }
 
-struct f3 { float x, y, z; };
-struct alignas(16) f4 { float x, y, z, w; };
+// 3- and 4-vectors over fp32 (PreSync kernel) and fp64 (Sync kernels; the reference's arithmetic is
+// IEEE double throughout, core_private.cpp).  Everything below is written once for both.
+template <typename T> struct v3 { T x, y, z; };
+template <typename T> struct alignas(16) v4 { T x, y, z, w; };
+using f3 = v3<float>;
+using f4 = v4<float>;
+using d3 = v3<double>;
+using d4 = v4<double>;
 
-RS_HD f3 cross(f3 a, f3 b) {
+RS_HD float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
+RS_HD double fma_t(double a, double b, double c) { return fma(a, b, c); }
+RS_HD float floor_t(float x) { return floorf(x); }
+RS_HD double floor_t(double x) { return floor(x); }
+// 2 / n2 for the rotation: the hardware reciprocal in fp32 (about 1 ulp), a true division in fp64
+RS_HD float two_over(float n2) { return 2.f * rcp_fast(n2); }
+RS_HD double two_over(double n2) { return 2.0 / n2; }
+
+template <typename T> RS_HD v3<T> cross(v3<T> a, v3<T> b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-RS_HD float dot(f3 a, f3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
-RS_HD float dot4(f4 a, f4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
-RS_HD f3 scale(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
-RS_HD f3 add(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename T> RS_HD T dot(v3<T> a, v3<T> b) { return fma_t(a.x, b.x, fma_t(a.y, b.y, a.z * b.z)); }
+template <typename T> RS_HD T dot4(v4<T> a, v4<T> b) { return fma_t(a.x, b.x, fma_t(a.y, b.y, fma_t(a.z, b.z, a.w * b.w))); }
+template <typename T> RS_HD v3<T> scale(v3<T> a, T s) { return {a.x * s, a.y * s, a.z * s}; }
+template <typename T> RS_HD v3<T> add(v3<T> a, v3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 
 // ---- hypothesis sampler, identical integer arithmetic to oracle/ora_sample_pair ----
 RS_HD uint64_t sm64(uint64_t z) {
@@ -71,28 +85,31 @@ RS_HD void sample_pair(uint64_t seed, int64_t frame, uint32_t stream, uint32_t h
 
 // ---- spline ----
 // A spline parameter is carried as  x = idx + f  with an integer knot idx and
-// a fraction f in [0,1): the host splits (ts - start) * fs into a per-frame
-// integer base knot plus a per-ray fp32 offset t, and delay * fs into an
-// integer kd plus a fraction fd, so no absolute time is ever rounded to fp32.
-struct Knot {
+// a fraction f in [0,1): the frame table holds an integer base knot, every ray its offset t from
+// it ((ts - start) * fs - base), and delay * fs is split into an integer kd plus a fraction fd,
+// so no absolute time is ever rounded to the working precision.
+template <typename T>
+struct KnotT {
     int ci;    // coefficient row to use, always in [0, n-1]
-    float h;   // local parameter
+    T h;       // local parameter
     bool quad; // true on the two extrapolation branches (cubic term dropped)
 };
+using Knot = KnotT<float>;
 
-RS_HD Knot spline_locate(float t, int base, float fd, int n) {
-    float fl = floorf(t);
-    float f = (t - fl) + fd;
+template <typename T>
+RS_HD KnotT<T> spline_locate(T t, int base, T fd, int n) {
+    T fl = floor_t(t);
+    T f = (t - fl) + fd;
     int idx = base + (int)fl;
-    if (f >= 1.f) { f -= 1.f; idx += 1; }
-    Knot k;
+    if (f >= (T)1) { f -= (T)1; idx += 1; }
+    KnotT<T> k;
     if (idx < 0) { // minispline.cpp:52  x < idx(=0): quadratic from knot 0, h = x
-        k.ci = 0; k.h = (float)idx + f; k.quad = true;
-    } else if (idx > n - 1 || (idx == n - 1 && f > 0.f)) {
+        k.ci = 0; k.h = (T)idx + f; k.quad = true;
+    } else if (idx > n - 1 || (idx == n - 1 && f > (T)0)) {
         // minispline.cpp:53  x > n-1: quadratic from the last knot; idx is clamped to n,
         // so h = x - (n-1) inside the last interval and x - n beyond it (reference quirk)
         int idc = idx < n ? idx : n;
-        k.ci = n - 1; k.h = (float)(idx - idc) + f; k.quad = true;
+        k.ci = n - 1; k.h = (T)(idx - idc) + f; k.quad = true;
     } else { // minispline.cpp:54
         k.ci = idx; k.h = f; k.quad = false;
     }
@@ -101,51 +118,55 @@ RS_HD Knot spline_locate(float t, int base, float fd, int n) {
 
 // Same as spline_locate when the caller knows (for a whole workgroup) that every parameter falls
 // strictly inside the knots, 0 <= idx <= n-2: no extrapolation branch can be taken.
-RS_HD Knot spline_locate_interior(float t, int base, float fd) {
-    float fl = floorf(t);
-    float f = (t - fl) + fd;
+template <typename T>
+RS_HD KnotT<T> spline_locate_interior(T t, int base, T fd) {
+    T fl = floor_t(t);
+    T f = (t - fl) + fd;
     int idx = base + (int)fl;
-    if (f >= 1.f) { f -= 1.f; idx += 1; }
-    return Knot{idx, f, false};
+    if (f >= (T)1) { f -= (T)1; idx += 1; }
+    return KnotT<T>{idx, f, false};
 }
 
-// coefficient row = {y, b, c, d}, each an f4 over the quaternion components [w,x,y,z]
-RS_HD f4 horner(f4 y, f4 b, f4 c, f4 d, float h) {
-    return {fmaf(fmaf(fmaf(d.x, h, c.x), h, b.x), h, y.x), fmaf(fmaf(fmaf(d.y, h, c.y), h, b.y), h, y.y),
-            fmaf(fmaf(fmaf(d.z, h, c.z), h, b.z), h, y.z), fmaf(fmaf(fmaf(d.w, h, c.w), h, b.w), h, y.w)};
+// coefficient row = {y, b, c, d}, each a 4-vector over the quaternion components [w,x,y,z]
+template <typename T>
+RS_HD v4<T> horner(v4<T> y, v4<T> b, v4<T> c, v4<T> d, T h) {
+    return {fma_t(fma_t(fma_t(d.x, h, c.x), h, b.x), h, y.x), fma_t(fma_t(fma_t(d.y, h, c.y), h, b.y), h, y.y),
+            fma_t(fma_t(fma_t(d.z, h, c.z), h, b.z), h, y.z), fma_t(fma_t(fma_t(d.w, h, c.w), h, b.w), h, y.w)};
 }
-RS_HD f4 horner_deriv(f4 b, f4 c, f4 d, float h) { // minispline.cpp:57-64
-    return {fmaf(fmaf(3.f * d.x, h, 2.f * c.x), h, b.x), fmaf(fmaf(3.f * d.y, h, 2.f * c.y), h, b.y),
-            fmaf(fmaf(3.f * d.z, h, 2.f * c.z), h, b.z), fmaf(fmaf(3.f * d.w, h, 2.f * c.w), h, b.w)};
+template <typename T>
+RS_HD v4<T> horner_deriv(v4<T> b, v4<T> c, v4<T> d, T h) { // minispline.cpp:57-64
+    return {fma_t(fma_t((T)3 * d.x, h, (T)2 * c.x), h, b.x), fma_t(fma_t((T)3 * d.y, h, (T)2 * c.y), h, b.y),
+            fma_t(fma_t((T)3 * d.z, h, (T)2 * c.z), h, b.z), fma_t(fma_t((T)3 * d.w, h, (T)2 * c.w), h, b.w)};
 }
 
 // R(q/|q|)^T v for a quaternion q = (w, u) of squared norm n2, without normalising q first:
 //   v + (2 / n2) (u x (u x v) - w (u x v))
 // == vec(conj(qn) (0,v) qn) with qn = q/|q|, i.e. quat_rotate_point(quat_conj(qn), v)
 // (quat.cpp:45-47 after arma::normalise, core_private.cpp:24-27).  n2 == 0 leaves v unchanged.
-RS_HD f3 rotate_inv(f4 q, float two_over_n2, f3 v) {
-    f3 u = {q.y, q.z, q.w};
-    f3 t = cross(u, v);
-    f3 t2 = cross(u, t);
-    return {fmaf(two_over_n2, t2.x - q.x * t.x, v.x), fmaf(two_over_n2, t2.y - q.x * t.y, v.y),
-            fmaf(two_over_n2, t2.z - q.x * t.z, v.z)};
+template <typename T>
+RS_HD v3<T> rotate_inv(v4<T> q, T two_over_n2, v3<T> v) {
+    v3<T> u = {q.y, q.z, q.w};
+    v3<T> t = cross(u, v);
+    v3<T> t2 = cross(u, t);
+    return {fma_t(two_over_n2, t2.x - q.x * t.x, v.x), fma_t(two_over_n2, t2.y - q.x * t.y, v.y),
+            fma_t(two_over_n2, t2.z - q.x * t.z, v.z)};
 }
 
 // One end of a ray pair: rotated ray r = R(S(x)/|S(x)|)^T ray and, if DERIV,
 // dr/dx = r x W with W = vec(2 conj(S) S' / |S|^2) (ndspline.cpp:45-49).
-template <bool DERIV>
-RS_HD void rotate_ray(f4 y, f4 b, f4 c, f4 d, Knot kn, f3 ray, f3& r, f3& dr) {
-    if (kn.quad) d = {0.f, 0.f, 0.f, 0.f};
-    f4 q = horner(y, b, c, d, kn.h);
-    float n2 = dot4(q, q);
-    float s = (n2 > 0.f) ? 2.f * rcp_fast(n2) : 0.f;
+template <bool DERIV, typename T>
+RS_HD void rotate_ray(v4<T> y, v4<T> b, v4<T> c, v4<T> d, KnotT<T> kn, v3<T> ray, v3<T>& r, v3<T>& dr) {
+    if (kn.quad) d = {(T)0, (T)0, (T)0, (T)0};
+    v4<T> q = horner(y, b, c, d, kn.h);
+    T n2 = dot4(q, q);
+    T s = (n2 > (T)0) ? two_over(n2) : (T)0;
     r = rotate_inv(q, s, ray);
     if (DERIV) {
-        f4 dq = horner_deriv(b, c, d, kn.h);
-        f3 u = {q.y, q.z, q.w}, du = {dq.y, dq.z, dq.w};
-        f3 uxdu = cross(u, du);
-        f3 W = {s * (q.x * du.x - dq.x * u.x - uxdu.x), s * (q.x * du.y - dq.x * u.y - uxdu.y),
-                s * (q.x * du.z - dq.x * u.z - uxdu.z)};
+        v4<T> dq = horner_deriv(b, c, d, kn.h);
+        v3<T> u = {q.y, q.z, q.w}, du = {dq.y, dq.z, dq.w};
+        v3<T> uxdu = cross(u, du);
+        v3<T> W = {s * (q.x * du.x - dq.x * u.x - uxdu.x), s * (q.x * du.y - dq.x * u.y - uxdu.y),
+                   s * (q.x * du.z - dq.x * u.z - uxdu.z)};
         dr = cross(r, W);
     }
 }

@@ -189,6 +189,7 @@ struct FrameRec { // == rship_frame
     float tmin, tmax;
     uint32_t reserved;
     int64_t id;
+    double tmin64, tmax64;
 };
 static_assert(sizeof(FrameRec) == sizeof(rship_frame), "frame record layout");
 

@@ -1,4 +1,4 @@
-// support.hpp -- segment sums, pixels -> rays, debug kernels
+// support.hpp -- segment sums, packing kernels (raw records -> packed streams), debug kernels
 // Part of the single HIP translation unit rssync_kernels.hip (included there, in order).
 #pragma once
 
@@ -58,37 +58,61 @@ __global__ __launch_bounds__(kBlock) void debug_problem_kernel(DebugParams p) {
 }
 
 // ---------------------------------------------------------------------------
-// pixel -> ray (core_testcode.cpp:63-95,135-158).  One thread per tracked
-// pair, fp64 (the reference's arithmetic; gfx950 issues fp64 FMA at the fp32 rate), results
-// rounded once to the packed fp32 layout.  HBM: 32 B read + 32 B written per pair.
-struct PixelParams {
-    const double* px;
-    const rship_pixel_frame* frames;
+// Packing kernels: raw records (what SetTrackResult / set_track_pixels staged, fp64) -> the packed
+// streams.  One thread per ray pair; the spline parameter offset (ts - start) * fs - base is
+// evaluated in fp64 here (core_private.cpp:19-20 without the delay, relative to the frame's base
+// knot), written as fp64 for the Sync kernels and rounded once to fp32 for the PreSync kernel.
+// Pixel frames run the driver's undistortion first (core_testcode.cpp:63-95,
+// 135-158; fp64 = the reference's arithmetic).  HBM: 64 B read + 96 B written per pair.
+struct PackParams {
+    const double* raw;
+    const rship_pack_frame* frames;
     f4* rays_a;
     f4* rays_b;
+    double2* q0; // {ax,bx}
+    double2* q1; // {ay,by}
+    double2* q2; // {az,bz}
+    double2* q3; // {ta,tb}
+    double start, fs;
     uint32_t* bad;
 };
 
-__global__ __launch_bounds__(kBlock) void rays_from_pixels_kernel(PixelParams p) {
-    const rship_pixel_frame& fr = p.frames[blockIdx.x];
-    const uint32_t row = blockIdx.y * kBlock + threadIdx.x;
-    if (row >= fr.n_rays) return;
-    const double2* src = (const double2*)(p.px + 4 * (fr.px_offset + row));
-    const double2 a = src[0], b = src[1];
-    rs::Lens lens{fr.lens[0], fr.lens[1], fr.lens[2], fr.lens[3], fr.lens[4], fr.lens[5], fr.lens[6], fr.lens[7], fr.lens[8]};
-    double ra[3], rb[3], tsa, tsb;
-    rs::pixel_to_ray(lens, a.x, a.y, fr.time_a, fr.rows, ra, &tsa);
-    rs::pixel_to_ray(lens, b.x, b.y, fr.time_b, fr.rows, rb, &tsb);
-    const float ta = (float)rs::knot_offset(tsa, fr.start, fr.fs, fr.base);
-    const float tb = (float)rs::knot_offset(tsb, fr.start, fr.fs, fr.base);
-    f4 o0, o1;
-    o0.x = (float)ra[0]; o0.y = (float)rb[0]; o0.z = (float)ra[1]; o0.w = (float)rb[1];
-    o1.x = (float)ra[2]; o1.y = (float)rb[2]; o1.z = ta; o1.w = tb;
-    const bool ok = finite_f(o0.x) && finite_f(o0.y) && finite_f(o0.z) && finite_f(o0.w) && finite_f(o1.x) &&
-                    finite_f(o1.y) && finite_f(o1.z) && finite_f(o1.w);
-    if (!ok) atomicAdd(p.bad, 1u);
-    p.rays_a[fr.ray_offset + row] = o0;
-    p.rays_b[fr.ray_offset + row] = o1;
+__global__ __launch_bounds__(kBlock) void pack_frames_kernel(PackParams p) {
+    const rship_pack_frame& fr = p.frames[blockIdx.x];
+    const uint32_t n = fr.n_rays;
+    for (uint32_t row = blockIdx.y * kBlock + threadIdx.x; row < n; row += gridDim.y * kBlock) {
+        double ra[3], rb[3], tsa, tsb;
+        const double* rec = p.raw + fr.raw_offset;
+        if (fr.is_pixels) {
+            const double2* src = (const double2*)(rec + 4 * (size_t)row);
+            const double2 a = src[0], b = src[1];
+            const rs::Lens lens{fr.lens[0], fr.lens[1], fr.lens[2], fr.lens[3], fr.lens[4], fr.lens[5], fr.lens[6], fr.lens[7], fr.lens[8]};
+            rs::pixel_to_ray(lens, a.x, a.y, fr.time_a, fr.rows, ra, &tsa);
+            rs::pixel_to_ray(lens, b.x, b.y, fr.time_b, fr.rows, rb, &tsb);
+        } else {
+            tsa = rec[row];
+            tsb = rec[(size_t)n + row];
+            const double* pa = rec + 2 * (size_t)n + 3 * (size_t)row;
+            const double* pb = rec + 5 * (size_t)n + 3 * (size_t)row;
+            ra[0] = pa[0]; ra[1] = pa[1]; ra[2] = pa[2];
+            rb[0] = pb[0]; rb[1] = pb[1]; rb[2] = pb[2];
+        }
+        const double ta = rs::knot_offset(tsa, p.start, p.fs, fr.base);
+        const double tb = rs::knot_offset(tsb, p.start, p.fs, fr.base);
+        f4 o0, o1;
+        o0.x = (float)ra[0]; o0.y = (float)rb[0]; o0.z = (float)ra[1]; o0.w = (float)rb[1];
+        o1.x = (float)ra[2]; o1.y = (float)rb[2]; o1.z = (float)ta; o1.w = (float)tb;
+        const bool ok = finite_f(o0.x) && finite_f(o0.y) && finite_f(o0.z) && finite_f(o0.w) && finite_f(o1.x) &&
+                        finite_f(o1.y) && finite_f(o1.z) && finite_f(o1.w);
+        if (!ok) atomicAdd(p.bad, 1u);
+        const size_t o = (size_t)fr.ray_offset + row;
+        p.rays_a[o] = o0;
+        p.rays_b[o] = o1;
+        p.q0[o] = double2{ra[0], rb[0]};
+        p.q1[o] = double2{ra[1], rb[1]};
+        p.q2[o] = double2{ra[2], rb[2]};
+        p.q3[o] = double2{ta, tb};
+    }
 }
 
 // debug: the wave-level exact selection on caller-provided residuals (one wave per problem,

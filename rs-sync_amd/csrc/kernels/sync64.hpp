@@ -1,0 +1,493 @@
+// sync64.hpp -- the Sync kernels in fp64: K1 (residual + robust loss + analytic d/d-delay, also the
+// no-translation variant) and K3 (per-frame motion L-BFGS, with GuessMotion/GuessK finished in fp64).
+// Part of the single HIP translation unit rssync_kernels.hip (included there, in order).
+//
+// Why fp64: the reference's arithmetic is IEEE double throughout (core_private.cpp), and Sync is a
+// chaotic iteration on data with outliers -- the per-frame L-BFGS takes unit-length first steps on a
+// non-convex loss, so a 1e-7 perturbation of one residual row (fp32 rounding of a ray, of a spline
+// coefficient, or of one product) sends some frames into another basin and moves the returned delay
+// by tenths of a millisecond.  With fp64 inputs (the raw records are packed into fp64 streams, the
+// spline table stays fp64) and fp64 arithmetic the device follows the CPU solver to ~1e-12 per
+// evaluation.  gfx950 issues fp64 FMA at half the fp32 rate; Sync is ~10 % of a PreSync + Sync step.
+#pragma once
+
+namespace {
+
+using rs::d3;
+using rs::d4;
+
+// ---------------------------------------------------------------------------
+// fp64 spline window in LDS: [kind][knot] of d4 (32 B), 10 KB at kWinMax = 80 knots
+
+struct Spline64 {
+    const d4* __restrict__ g; // global table, 4 d4 per knot
+    const d4* lds;            // [4][kWinMax]
+    int n;
+    int w0, wlen;
+    int path; // kPathGlobal / kPathInterior, uniform over the workgroup
+};
+
+__device__ __forceinline__ void stage_window64(Spline64& s, d4* s_win, int lo, int hi) {
+    const int n = s.n;
+    const bool interior = lo >= 0 && hi <= n - 2;
+    lo = lo < 0 ? 0 : (lo > n - 1 ? n - 1 : lo);
+    hi = hi < 0 ? 0 : (hi > n - 1 ? n - 1 : hi);
+    int wlen = hi - lo + 1;
+    s.path = (wlen <= kWinMax && interior) ? kPathInterior : kPathGlobal;
+    if (wlen > kWinMax) wlen = kWinMax;
+    s.w0 = lo;
+    s.wlen = wlen;
+    s.lds = s_win;
+    for (int e = threadIdx.x; e < wlen * 4; e += blockDim.x) {
+        int knot = e >> 2, kind = e & 3;
+        s_win[kind * kWinMax + knot] = s.g[(size_t)(lo + knot) * 4 + kind];
+    }
+}
+
+template <int PATH>
+__device__ __forceinline__ void fetch_coef64(const Spline64& s, int ci, d4& y, d4& b, d4& c, d4& d) {
+    if (PATH == kPathGlobal) {
+        const d4* p = s.g + (size_t)ci * 4;
+        y = p[0]; b = p[1]; c = p[2]; d = p[3];
+    } else {
+        const int rel = ci - s.w0;
+        y = s.lds[rel];
+        b = s.lds[kWinMax + rel];
+        c = s.lds[2 * kWinMax + rel];
+        d = s.lds[3 * kWinMax + rel];
+    }
+}
+
+// the four fp64 streams of the frames: {ax,bx} {ay,by} {az,bz} {ta,tb}
+struct Rays64 {
+    const double2* __restrict__ q0;
+    const double2* __restrict__ q1;
+    const double2* __restrict__ q2;
+    const double2* __restrict__ q3;
+};
+
+// one row of P = ar x br (core_private.cpp:24-28) and, if DERIV, dP/dx (x in knots), in fp64
+template <bool DERIV, int PATH>
+__device__ __forceinline__ void residual_row64(const Spline64& s, const Rays64& r, size_t idx, int base, double fd, d3& P,
+                                               d3& dP) {
+    const double2 X = r.q0[idx], Y = r.q1[idx], Z = r.q2[idx], T = r.q3[idx];
+    d4 ya, ba, ca, da, yb, bb, cb, db;
+    const rs::KnotT<double> ka = (PATH == kPathInterior) ? rs::spline_locate_interior(T.x, base, fd)
+                                                         : rs::spline_locate(T.x, base, fd, s.n);
+    fetch_coef64<PATH>(s, ka.ci, ya, ba, ca, da);
+    const rs::KnotT<double> kb = (PATH == kPathInterior) ? rs::spline_locate_interior(T.y, base, fd)
+                                                         : rs::spline_locate(T.y, base, fd, s.n);
+    fetch_coef64<PATH>(s, kb.ci, yb, bb, cb, db);
+    d3 ar, br, dar, dbr;
+    rs::rotate_ray<DERIV>(ya, ba, ca, da, ka, d3{X.x, Y.x, Z.x}, ar, dar);
+    rs::rotate_ray<DERIV>(yb, bb, cb, db, kb, d3{X.y, Y.y, Z.y}, br, dbr);
+    P = rs::cross(ar, br);
+    if (DERIV) dP = rs::add(rs::cross(dar, br), rs::cross(ar, dbr));
+}
+
+template <bool DERIV>
+__device__ __forceinline__ void residual_row64(const Spline64& s, const Rays64& r, size_t idx, int base, double fd, d3& P,
+                                               d3& dP) {
+    if (s.path == kPathInterior) residual_row64<DERIV, kPathInterior>(s, r, idx, base, fd, P, dP);
+    else residual_row64<DERIV, kPathGlobal>(s, r, idx, base, fd, P, dP);
+}
+
+__device__ __forceinline__ void frame_window64(Spline64& sp, d4* s_win, const FrameRec& fr, int kd) {
+    stage_window64(sp, s_win, fr.base_knot + (int)floor(fr.tmin64) + kd, fr.base_knot + (int)floor(fr.tmax64) + kd + 1);
+}
+
+// ---------------------------------------------------------------------------
+// K1: per slot, FrameState::Loss at a batch of delays (core_private.cpp:117-123):
+//   r = (P M) k / |M|,  loss = sum log1p(r^2)
+// and with GRAD the analytic d/d-delay that replaces the central difference of :96-97,112
+//   dL/dd = sum 1/(1+u) (2 pm / s) (dP/dd . M),  u = pm^2 / s,  s = |M|^2 / k^2.
+// SIMPLE = the thesis' no-translation variant (section 2.11 eq. (12)): u = k^2 |P|^2, no M.
+// One workgroup per slot; rows are re-read per delay (the frame's 128 KB stay in L2).
+
+struct Loss64Params {
+    Rays64 rays;
+    const FrameRec* frames;
+    const uint32_t* sel;
+    uint32_t n_sel;
+    const d4* coef;
+    int n_knots;
+    double fs;
+    const int32_t* kd; // [n_delays][n_grp]
+    const double* fd;  // NaN = this group is skipped (its partial sums are written as 0)
+    uint32_t n_delays;
+    const uint32_t* grp;
+    uint32_t n_grp;
+    const double* M; // per selection slot
+    const double* k;
+    double* part_loss; // [n_delays][n_sel]
+    double* part_grad; // [n_delays][n_sel] (GRAD)
+};
+
+template <int RPT, bool GRAD, bool SIMPLE>
+__global__ __launch_bounds__(kBlock, 4) void loss64_kernel(Loss64Params p) {
+    __shared__ d4 s_win[4 * kWinMax];
+    __shared__ double s_red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t sf = blockIdx.x;
+    const uint32_t fi = p.sel[sf];
+    const FrameRec fr = p.frames[fi];
+    const uint32_t N = fr.n;
+    const uint32_t g = p.grp ? p.grp[sf] : 0u;
+    const double Mx = SIMPLE ? 0.0 : p.M[3 * sf], My = SIMPLE ? 0.0 : p.M[3 * sf + 1], Mz = SIMPLE ? 0.0 : p.M[3 * sf + 2];
+    const double kk = p.k[sf];
+    const d3 Mv = d3{Mx, My, Mz};
+    // r = (P.M) k / |M|  (core_private.cpp:120)  ->  u = (P.M)^2 * inv_s;  SIMPLE: u = |P|^2 k^2
+    const double inv_s = SIMPLE ? kk * kk : kk * kk / (Mx * Mx + My * My + Mz * Mz);
+
+    Spline64 sp;
+    sp.g = p.coef;
+    sp.n = p.n_knots;
+    for (uint32_t b = 0; b < p.n_delays; ++b) {
+        const int kd = p.kd[b * p.n_grp + g];
+        const double fd = p.fd[b * p.n_grp + g];
+        if (fd != fd) { // group switched off for this evaluation (workgroup-uniform)
+            if (tid == 0) {
+                p.part_loss[(size_t)b * p.n_sel + sf] = 0.0;
+                if (GRAD) p.part_grad[(size_t)b * p.n_sel + sf] = 0.0;
+            }
+            continue;
+        }
+        __syncthreads(); // window and s_red reuse
+        frame_window64(sp, s_win, fr, kd);
+        __syncthreads();
+        const int base = fr.base_knot + kd;
+        double L = 0.0, G = 0.0;
+#pragma unroll 1
+        for (int j = 0; j < RPT; ++j) {
+            const uint32_t row = j * kBlock + tid;
+            if (row < N) {
+                d3 P, dP;
+                residual_row64<GRAD>(sp, p.rays, (size_t)fr.off + row, base, fd, P, dP);
+                double w;
+                if (SIMPLE) {
+                    const double u = rs::dot(P, P) * inv_s;
+                    L += rs::log1p_rcp_f64(u, &w);
+                    if (GRAD) G = fma(w * 2.0 * inv_s, rs::dot(P, dP), G);
+                } else {
+                    const double pm = rs::dot(P, Mv);
+                    const double u = pm * pm * inv_s;
+                    L += rs::log1p_rcp_f64(u, &w); // core_private.cpp:121-122
+                    if (GRAD) G = fma(w * 2.0 * pm * inv_s, rs::dot(dP, Mv), G);
+                }
+            }
+        }
+        const double Lw = wave_sum_f64(L);
+        const double Gw = GRAD ? wave_sum_f64(G) : 0.0;
+        if (lane == 0) {
+            s_red[0][wave] = Lw;
+            s_red[1][wave] = Gw;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            p.part_loss[(size_t)b * p.n_sel + sf] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+            if (GRAD)
+                p.part_grad[(size_t)b * p.n_sel + sf] = (s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3]) * p.fs;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3: per-slot L-BFGS on the motion vector, P resident in registers in fp64.
+// Restates ens::L_BFGS as called at core_private.cpp:264-294 (MaxIterations 200,
+// MinGradientNorm 1e-4, library defaults otherwise) from the published ensmallen 2.x
+// algorithm (lbfgs_impl.hpp; the dependency is unpinned and not under the reference tree).
+// When a line search's best step is not its last, the published LineSearch moves the iterate
+// to the best step and leaves value and gradient as the last trial computed them; that is the
+// default (reeval = 0).  reeval = 1 evaluates once more at the best step so that
+// (x, f, g) stay consistent (round 1's choice; kept for comparison).  Control flow is uniform:
+// every thread runs the same fp64 scalar logic on the same reduced sums.
+//
+// The kernel also FINISHES FrameState::GuessMotion / GuessK (core_private.cpp:125-133) in fp64:
+// the LMedS search over 200 hypotheses runs in the fp32 tile kernel and leaves only the index of
+// the winning hypothesis per slot (init_h); here the winning pair of rows is recomputed in fp64,
+// M = safe_normalize(P[i0] x P[i1]) (core_private.cpp:45-46) and k = clamp(100 / |P M|, 10, 1000).
+
+struct Motion64Params {
+    Rays64 rays;
+    const FrameRec* frames;
+    const uint32_t* sel;
+    uint32_t n_sel;
+    const d4* coef;
+    int n_knots;
+    const int32_t* kd; // [n_grp]
+    const double* fd;  // NaN = skip the group's slots
+    const uint32_t* grp;
+    double* M; // per selection slot
+    double* k;
+    unsigned long long* stats; // [0] += iterations, [1] += evaluations, [2] += line searches with best != last step
+    uint32_t* per_frame;       // optional [n_sel][2]: iterations, evaluations
+    int reeval;
+    int max_iters; // 200 (core_private.cpp:265); 0 = finish the initialisation only
+    // pending initialisation (GuessMotion finish): winning hypothesis per slot, INT_MIN = none pending
+    int32_t* init_h;
+    uint64_t seed;
+    uint32_t stream_base, stream_stride; // sampler stream = base + group * stride
+    int simple_k; // 1: k = clamp(100 / sqrt(sum |P_j|^2)) only (no-translation variant), no M, no optimisation
+};
+
+constexpr int kInitNone = (int)0x80000000;
+
+template <int RPT>
+struct MotionEval64 {
+    d3 P[RPT];
+    double (*part)[4][5]; // [2][4][5] LDS, double-buffered
+    int buf;
+    double k2;
+    int evals;
+
+    // loss and dL/dM at x (core_private.cpp:99-114 in closed form)
+    __device__ __forceinline__ double operator()(const double x[3], double g[3]) {
+        const double s = (x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) / k2;
+        const double inv_s = 1.0 / s;
+        double L = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0, gs = 0.0;
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const double px = P[j].x, py = P[j].y, pz = P[j].z;
+            const double pm = fma(px, x[0], fma(py, x[1], pz * x[2]));
+            const double v2 = pm * pm;
+            const double u = v2 * inv_s;
+            double w; // 1 / (1 + u)
+            L += rs::log1p_rcp_f64(u, &w);
+            const double a = w * 2.0 * pm * inv_s;
+            a0 = fma(a, px, a0);
+            a1 = fma(a, py, a1);
+            a2 = fma(a, pz, a2);
+            gs = fma(w * v2, inv_s * inv_s, gs);
+        }
+        double r0 = wave_sum_f64(L), r1 = wave_sum_f64(a0), r2 = wave_sum_f64(a1), r3 = wave_sum_f64(a2),
+               r4 = wave_sum_f64(gs);
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+            part[buf][wave][0] = r0; part[buf][wave][1] = r1; part[buf][wave][2] = r2;
+            part[buf][wave][3] = r3; part[buf][wave][4] = r4;
+        }
+        __syncthreads();
+        double t[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) t[q] = part[buf][0][q] + part[buf][1][q] + part[buf][2][q] + part[buf][3][q];
+        buf ^= 1;
+        ++evals;
+        const double tt = t[4] * 2.0 / k2;
+        g[0] = t[1] - tt * x[0];
+        g[1] = t[2] - tt * x[1];
+        g[2] = t[3] - tt * x[2];
+        return t[0];
+    }
+};
+
+__device__ __forceinline__ double dot3d(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+__device__ __forceinline__ double clamp_k(double k) { return (k < 10.0) ? 10.0 : ((1000.0 < k) ? 1000.0 : k); } // inline_utils.hpp:50
+
+template <int RPT>
+__global__ __launch_bounds__(kBlock, 3) void opt_motion64_kernel(Motion64Params p) {
+    __shared__ d4 s_win[4 * kWinMax];
+    __shared__ double s_part[2][4][5];
+    __shared__ double s_S[kNB][3], s_Y[kNB][3];
+    // two-loop scratch: every thread writes the same values and reads them back itself;
+    // the barrier inside each evaluation separates one iteration's use from the next
+    __shared__ double s_rho[kNB], s_alpha[kNB];
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x;
+    const uint32_t sf = blockIdx.x;
+    const uint32_t fi = p.sel[sf];
+    const FrameRec fr = p.frames[fi];
+    const uint32_t N = fr.n;
+    const uint32_t grp = p.grp ? p.grp[sf] : 0u;
+    const int kd = p.kd[grp];
+    const double fd = p.fd[grp];
+    if (fd != fd) return; // this window is not being optimised in this call (workgroup-uniform)
+
+    Spline64 sp;
+    sp.g = p.coef;
+    sp.n = p.n_knots;
+    frame_window64(sp, s_win, fr, kd);
+    __syncthreads();
+
+    MotionEval64<RPT> ev;
+    ev.part = s_part;
+    ev.buf = 0;
+    ev.evals = 0;
+    const int base = fr.base_knot + kd;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        const uint32_t row = j * kBlock + tid;
+        d3 P = d3{0, 0, 0}, dP;
+        if (row < N) residual_row64<false>(sp, p.rays, (size_t)fr.off + row, base, fd, P, dP);
+        ev.P[j] = P; // zero rows contribute log1p(0) = 0 and no gradient
+    }
+
+    double x[3];
+    double kk;
+    const int pend = p.init_h ? p.init_h[sf] : kInitNone;
+    if (p.simple_k || pend != kInitNone) {
+        // GuessMotion's winner recomputed in fp64, then GuessK (core_private.cpp:125-133)
+        d3 Mv = d3{0, 0, 0};
+        if (!p.simple_k && pend >= 0) {
+            uint32_t i0, i1;
+            rs::sample_pair(p.seed, fr.id, p.stream_base + grp * p.stream_stride, (uint32_t)pend, N, i0, i1);
+            d3 P0, P1, dP;
+            residual_row64<false>(sp, p.rays, (size_t)fr.off + i0, base, fd, P0, dP);
+            residual_row64<false>(sp, p.rays, (size_t)fr.off + i1, base, fd, P1, dP);
+            Mv = rs::cross(P0, P1);
+            const double nn = sqrt(rs::dot(Mv, Mv));
+            if (!(nn < 1e-12)) Mv = rs::scale(Mv, 1.0 / nn); // safe_normalize, inline_utils.hpp:5-11
+        }
+        double ss = 0.0;
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const double pm = p.simple_k ? sqrt(rs::dot(ev.P[j], ev.P[j])) : rs::dot(ev.P[j], Mv);
+            ss = fma(pm, pm, ss);
+        }
+        const double sw = wave_sum_f64(ss);
+        if ((tid & 63) == 0) s_red[tid >> 6] = sw;
+        __syncthreads();
+        const double tot = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        kk = clamp_k(100.0 / sqrt(tot)); // :132; tot = 0 gives +inf -> 1000
+        x[0] = Mv.x; x[1] = Mv.y; x[2] = Mv.z;
+        if (tid == 0) {
+            if (!p.simple_k) { p.M[3 * sf] = x[0]; p.M[3 * sf + 1] = x[1]; p.M[3 * sf + 2] = x[2]; }
+            p.k[sf] = kk;
+            if (p.init_h) p.init_h[sf] = kInitNone;
+        }
+    } else {
+        x[0] = p.M[3 * sf]; x[1] = p.M[3 * sf + 1]; x[2] = p.M[3 * sf + 2];
+        kk = p.k[sf];
+    }
+    if (p.max_iters <= 0 || p.simple_k) return;
+    ev.k2 = kk * kk;
+
+    const int maxIterations = p.max_iters; // core_private.cpp:265
+    const double minGradientNorm = 1e-4;   // core_private.cpp:266
+    const double armijo = 1e-4, wolfe = 0.9, factr = 1e-15, minStep = 1e-20, maxStep = 1e20;
+    const int maxLineSearchTrials = 50;
+
+    double g[3], oldx[3], oldg[3], dir[3];
+    double fval = ev(x, g);
+    int it = 0, best_not_last = 0;
+    for (; it != maxIterations; ++it) {
+        const double prev = fval;
+        if (sqrt(dot3d(g, g)) < minGradientNorm) break;
+        if (fval != fval) break;
+        double scale;
+        if (it > 0) {
+            const int pp = (it - 1) % kNB;
+            const double yy = dot3d(s_Y[pp], s_Y[pp]);
+            scale = dot3d(s_S[pp], s_Y[pp]) / ((yy >= 1e-10) ? yy : 1.0);
+        } else {
+            const double gn = sqrt(dot3d(g, g));
+            scale = (gn >= 1e-5) ? 1.0 / gn : 1.0;
+        }
+        if (scale == 0.0 || scale != scale) break;
+        // two-loop recursion
+        dir[0] = g[0]; dir[1] = g[1]; dir[2] = g[2];
+        const int limit = (kNB > it) ? 0 : (it - kNB);
+#pragma unroll 1
+        for (int i = it; i != limit; --i) {
+            const int tp = (i + (kNB - 1)) % kNB;
+            const double r = 1.0 / dot3d(s_Y[tp], s_S[tp]);
+            const double al = r * dot3d(s_S[tp], dir);
+            s_rho[it - i] = r; // it - i in [0, kNB)
+            s_alpha[it - i] = al;
+            dir[0] -= al * s_Y[tp][0]; dir[1] -= al * s_Y[tp][1]; dir[2] -= al * s_Y[tp][2];
+        }
+        dir[0] *= scale; dir[1] *= scale; dir[2] *= scale;
+#pragma unroll 1
+        for (int i = limit; i < it; ++i) {
+            const int tp = i % kNB;
+            const double beta = s_rho[it - i - 1] * dot3d(s_Y[tp], dir);
+            const double cf = s_alpha[it - i - 1] - beta;
+            dir[0] += cf * s_S[tp][0]; dir[1] += cf * s_S[tp][1]; dir[2] += cf * s_S[tp][2];
+        }
+        dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2];
+        oldx[0] = x[0]; oldx[1] = x[1]; oldx[2] = x[2];
+        oldg[0] = g[0]; oldg[1] = g[1]; oldg[2] = g[2];
+        // line search
+        const double dg0 = dot3d(g, dir);
+        if (dg0 > 0.0) break;
+        const double f0 = fval, lin = armijo * dg0;
+        double step = 1.0, bestStep = 1.0, bestObj = 1.79769313486231570e308, lastStep = 1.0;
+        int trials = 0;
+        for (;;) {
+            double xn[3] = {x[0] + step * dir[0], x[1] + step * dir[1], x[2] + step * dir[2]};
+            fval = ev(xn, g);
+            lastStep = step;
+            if (fval < bestObj) { bestStep = step; bestObj = fval; }
+            ++trials;
+            double width;
+            if (fval > f0 + step * lin) {
+                width = 0.5;
+            } else {
+                const double dg = dot3d(g, dir);
+                if (dg < wolfe * dg0) width = 2.1;
+                else if (dg > -wolfe * dg0) width = 0.5;
+                else break;
+            }
+            if (step < minStep || step > maxStep || trials >= maxLineSearchTrials) break;
+            step *= width;
+        }
+        x[0] += bestStep * dir[0]; x[1] += bestStep * dir[1]; x[2] += bestStep * dir[2];
+        if (bestStep != lastStep) {
+            ++best_not_last;
+            if (p.reeval) fval = ev(x, g);
+        }
+        if (bestStep == 0.0) break;
+        const double denom = fmax(fmax(fabs(prev), fabs(fval)), 1.0);
+        if ((prev - fval) / denom <= factr) break;
+        const int op = it % kNB;
+        __syncthreads(); // every thread has finished reading the history for this iteration
+        if (tid == 0) {
+            for (int c = 0; c < 3; ++c) { s_S[op][c] = x[c] - oldx[c]; s_Y[op][c] = g[c] - oldg[c]; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        p.M[3 * sf] = x[0]; p.M[3 * sf + 1] = x[1]; p.M[3 * sf + 2] = x[2];
+        if (p.stats) {
+            atomicAdd(&p.stats[0], (unsigned long long)it);
+            atomicAdd(&p.stats[1], (unsigned long long)ev.evals);
+            atomicAdd(&p.stats[2], (unsigned long long)best_not_last);
+        }
+        if (p.per_frame) {
+            p.per_frame[2 * sf] = (uint32_t)it;
+            p.per_frame[2 * sf + 1] = (uint32_t)ev.evals;
+        }
+    }
+}
+
+// debug: fp64 P (and dP/dd) rows of one frame, as the Sync kernels compute them
+struct Debug64Params {
+    Rays64 rays;
+    const FrameRec* frames;
+    uint32_t fi;
+    const d4* coef;
+    int n_knots;
+    double fs;
+    int32_t kd;
+    double fd;
+    double* P;
+    double* dP;
+};
+
+__global__ __launch_bounds__(kBlock) void debug_problem64_kernel(Debug64Params p) {
+    __shared__ d4 s_win[4 * kWinMax];
+    const FrameRec fr = p.frames[p.fi];
+    Spline64 sp;
+    sp.g = p.coef;
+    sp.n = p.n_knots;
+    frame_window64(sp, s_win, fr, p.kd);
+    __syncthreads();
+    for (uint32_t row = blockIdx.x * kBlock + threadIdx.x; row < fr.n; row += gridDim.x * kBlock) {
+        d3 P, dP;
+        residual_row64<true>(sp, p.rays, (size_t)fr.off + row, fr.base_knot + p.kd, p.fd, P, dP);
+        p.P[3 * row] = P.x; p.P[3 * row + 1] = P.y; p.P[3 * row + 2] = P.z;
+        if (p.dP) { p.dP[3 * row] = dP.x * p.fs; p.dP[3 * row + 1] = dP.y * p.fs; p.dP[3 * row + 2] = dP.z * p.fs; }
+    }
+}
+
+} // namespace

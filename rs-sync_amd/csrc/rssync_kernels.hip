@@ -59,9 +59,11 @@ struct rship_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr; // raw-record uploads, overlapping the caller's SetTrackResult loop
+    hipEvent_t copy_done = nullptr;
     std::string err;
     // problem data
-    DevBuf coef, rays_a, rays_b, frames, sel, M, k, grp, grp_off, seg_idx, seg_off;
+    DevBuf coef, coef64, raw, rays_a, rays_b, rays64, frames, sel, M, k, grp, grp_off, seg_idx, seg_off;
     uint32_t n_knots = 0, n_frames = 0, n_sel = 0, max_n = 0, n_grp = 1;
     uint64_t total_rays = 0;
     double fs = 0;
@@ -300,6 +302,19 @@ extern "C" {
 
 int rship_max_tracks(void) { return kMaxRpt * kBlock; }
 
+// Staging memory for the host solver: pinned, so that rship_upload_raw is a true asynchronous DMA
+// at PCIe rate (a pageable source is staged through a bounce buffer at ~1 GB/s: round 1's 0.24 s
+// for 268 MB).  Falls back to pageable memory if the runtime refuses to pin.
+void* rship_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess && p) return p;
+    (void)hipGetLastError();
+    return nullptr;
+}
+void rship_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int rship_create(rship_ctx** out, int device) {
     *out = nullptr;
     int ndev = 0;
@@ -314,6 +329,8 @@ int rship_create(rship_ctx** out, int device) {
         (void)hipGetDevice(&c->device);
     }
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming);
     if (e != hipSuccess) { delete c; return 4; }
     c->stream = c->own_stream;
     *out = c;
@@ -330,12 +347,15 @@ void rship_destroy(rship_ctx* c) {
     }
     if (c->rccl_buf.p) (void)hipFree(c->rccl_buf.p);
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&c->coef, &c->rays_a, &c->rays_b, &c->frames, &c->sel, &c->M, &c->k, &c->grp, &c->grp_off,
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    DevBuf* bufs[] = {&c->coef, &c->coef64, &c->raw, &c->rays_a, &c->rays_b, &c->rays64, &c->frames, &c->sel, &c->M, &c->k, &c->grp, &c->grp_off,
                       &c->seg_idx, &c->seg_off, &c->kd,
                       &c->frame_cost, &c->best_h, &c->costs, &c->part, &c->flags, &c->stats};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->copy_done) (void)hipEventDestroy(c->copy_done);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -356,45 +376,113 @@ int rship_set_stream(rship_ctx* c, void* hip_stream) {
     return 0;
 }
 
-int rship_upload_spline(rship_ctx* c, const float* coef16, uint32_t n_knots, double sample_rate) {
+int rship_upload_spline(rship_ctx* c, const double* coef16, uint32_t n_knots, double sample_rate) {
     DeviceGuard dev_guard(c);
     if (n_knots < 2) return set_err(c, "spline: need >= 2 knots");
-    size_t bytes = (size_t)n_knots * 64;
-    if (ensure(c, c->coef, bytes)) return 1;
-    RS_HIP(hipMemcpyAsync(c->coef.p, coef16, bytes, hipMemcpyHostToDevice, c->stream));
+    const size_t n = (size_t)n_knots * 16;
+    if (ensure(c, c->coef64, n * 8) || ensure(c, c->coef, n * 4)) return 1;
+    std::vector<float> f32(n); // rounded once, here (the PreSync kernel's table)
+    for (size_t i = 0; i < n; ++i) f32[i] = (float)coef16[i];
+    RS_HIP(hipMemcpyAsync(c->coef64.p, coef16, n * 8, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemcpyAsync(c->coef.p, f32.data(), n * 4, hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipStreamSynchronize(c->stream));
     c->n_knots = n_knots;
     c->fs = sample_rate;
     return 0;
 }
 
-int rship_upload_frames(rship_ctx* c, const float* rays_a4, const float* rays_b4, uint64_t total_rays,
-                        const rship_frame* table, uint32_t n_frames) {
+int rship_upload_raw(rship_ctx* c, const double* host, uint64_t arena_offset, uint64_t n_doubles) {
     DeviceGuard dev_guard(c);
+    if (!n_doubles) return 0;
+    const size_t need = (size_t)(arena_offset + n_doubles) * 8;
+    if (need > c->raw.cap) {
+        // grow geometrically, keeping what is there (earlier uploads may still be in flight)
+        RS_HIP(hipStreamSynchronize(c->copy_stream));
+        DevBuf bigger;
+        size_t want = c->raw.cap * 2 > need ? c->raw.cap * 2 : need;
+        want += want / 8 + 4096;
+        RS_HIP(hipMalloc(&bigger.p, want));
+        bigger.cap = want;
+        if (c->raw.p) {
+            hipError_t e = hipMemcpy(bigger.p, c->raw.p, c->raw.cap, hipMemcpyDeviceToDevice);
+            if (e != hipSuccess) { (void)hipFree(bigger.p); return set_err(c, "upload_raw: grow", e); }
+            // a packing kernel reading the old buffer may still be queued on the compute stream
+            RS_HIP(hipStreamSynchronize(c->stream));
+            RS_HIP(hipFree(c->raw.p));
+        }
+        c->raw = bigger;
+    }
+    RS_HIP(hipMemcpyAsync((double*)c->raw.p + arena_offset, host, (size_t)n_doubles * 8, hipMemcpyHostToDevice, c->copy_stream));
+    return 0;
+}
+
+int rship_pack_frames(rship_ctx* c, const rship_frame* table, const rship_pack_frame* pack, uint32_t n_frames,
+                      uint64_t total_rays, double start, double fs, uint32_t* bad) {
+    DeviceGuard dev_guard(c);
+    if (bad) *bad = 0;
     c->n_frames = 0;
     c->n_sel = 0;
     c->h_sel.clear();
     c->h_frame_n.assign(n_frames, 0);
     c->max_span = 0.f;
+    uint32_t max_n = 0;
     for (uint32_t i = 0; i < n_frames; ++i) {
         if ((uint64_t)table[i].ray_offset + table[i].n_rays > total_rays) return set_err(c, "frame table exceeds ray buffer");
+        if (table[i].n_rays != pack[i].n_rays || table[i].ray_offset != pack[i].ray_offset)
+            return set_err(c, "pack list does not match the frame table");
+        const uint64_t rec = (uint64_t)pack[i].n_rays * (pack[i].is_pixels ? 4 : 8);
+        if ((pack[i].raw_offset + rec) * 8 > c->raw.cap && rec) return set_err(c, "pack: record outside the uploaded raw data");
         if (table[i].n_rays > (uint32_t)rship_max_tracks())
             return set_err(c, "frame has more tracks than the kernels accept (" + std::to_string(rship_max_tracks()) + ")");
         c->h_frame_n[i] = table[i].n_rays;
+        max_n = std::max(max_n, table[i].n_rays);
         const float span = floorf(table[i].tmax) - floorf(table[i].tmin) + 2.f; // knots a frame touches at one delay
         if (table[i].n_rays && span > c->max_span) c->max_span = span;
     }
-    size_t rb = (size_t)total_rays * 16;
-    if (ensure(c, c->rays_a, rb ? rb : 16) || ensure(c, c->rays_b, rb ? rb : 16)) return 1;
-    if (ensure(c, c->frames, (size_t)n_frames * sizeof(rship_frame) + 32)) return 1;
-    if (rb && rays_a4 && rays_b4) { // null: the caller fills the streams on the device (rship_rays_from_pixels)
-        RS_HIP(hipMemcpyAsync(c->rays_a.p, rays_a4, rb, hipMemcpyHostToDevice, c->stream));
-        RS_HIP(hipMemcpyAsync(c->rays_b.p, rays_b4, rb, hipMemcpyHostToDevice, c->stream));
-    }
-    if (n_frames) RS_HIP(hipMemcpyAsync(c->frames.p, table, (size_t)n_frames * sizeof(rship_frame), hipMemcpyHostToDevice, c->stream));
-    RS_HIP(hipStreamSynchronize(c->stream));
-    c->n_frames = n_frames;
+    const size_t tr = (size_t)total_rays;
+    if (ensure(c, c->rays_a, tr ? tr * 16 : 16) || ensure(c, c->rays_b, tr ? tr * 16 : 16) ||
+        ensure(c, c->rays64, tr ? tr * 64 : 64))
+        return 1;
+    if (ensure(c, c->frames, (size_t)n_frames * sizeof(rship_frame) + 64)) return 1;
     c->total_rays = total_rays;
+    if (n_frames) RS_HIP(hipMemcpyAsync(c->frames.p, table, (size_t)n_frames * sizeof(rship_frame), hipMemcpyHostToDevice, c->stream));
+    uint32_t nb = 0;
+    if (n_frames && max_n) {
+        TempBuf dpk, dbad;
+        if (ensure(c, dpk, (size_t)n_frames * sizeof(rship_pack_frame)) || ensure(c, dbad, 16)) return 1;
+        hipError_t e = hipMemcpyAsync(dpk.p, pack, (size_t)n_frames * sizeof(rship_pack_frame), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(dbad.p, 0, 16, c->stream);
+        // every raw upload issued so far must have landed before the kernel reads the records
+        if (e == hipSuccess) e = hipEventRecord(c->copy_done, c->copy_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->copy_done, 0);
+        if (e == hipSuccess) {
+            PackParams p{};
+            p.raw = (const double*)c->raw.p;
+            p.frames = (const rship_pack_frame*)dpk.p;
+            p.rays_a = (f4*)c->rays_a.p;
+            p.rays_b = (f4*)c->rays_b.p;
+            p.q0 = (double2*)c->rays64.p;
+            p.q1 = p.q0 + tr;
+            p.q2 = p.q1 + tr;
+            p.q3 = p.q2 + tr;
+            p.start = start;
+            p.fs = fs;
+            p.bad = (uint32_t*)dbad.p;
+            {
+                ProfScope ps(c, RSHIP_K_PIXELS);
+                hipLaunchKernelGGL(pack_frames_kernel, dim3(n_frames, (max_n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, p);
+            }
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&nb, dbad.p, 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        prof_collect(c);
+        if (e != hipSuccess) return set_err(c, "pack_frames", e);
+    } else {
+        RS_HIP(hipStreamSynchronize(c->stream));
+    }
+    if (bad) *bad = nb;
+    c->n_frames = n_frames;
     return 0;
 }
 
@@ -687,43 +775,6 @@ int rship_set_motion(rship_ctx* c, const double* M, const double* k, uint32_t n)
         RS_HIP(hipMemcpy(c->M.p, M, (size_t)n * 24, hipMemcpyHostToDevice));
         RS_HIP(hipMemcpy(c->k.p, k, (size_t)n * 8, hipMemcpyHostToDevice));
     }
-    return 0;
-}
-
-int rship_rays_from_pixels(rship_ctx* c, const double* px, uint64_t n_pairs, const rship_pixel_frame* frames,
-                           uint32_t n_frames, uint32_t* bad) {
-    DeviceGuard dev_guard(c);
-    if (bad) *bad = 0;
-    if (!n_frames) return 0;
-    uint32_t max_n = 0;
-    for (uint32_t i = 0; i < n_frames; ++i) {
-        const rship_pixel_frame& f = frames[i];
-        if (f.px_offset + f.n_rays > n_pairs) return set_err(c, "rays_from_pixels: frame exceeds the pixel buffer");
-        if ((uint64_t)f.ray_offset + f.n_rays > c->total_rays) return set_err(c, "rays_from_pixels: frame exceeds the ray buffer");
-        max_n = std::max(max_n, f.n_rays);
-    }
-    if (!max_n) return 0;
-    TempBuf dpx, dfr, dbad;
-    if (ensure(c, dpx, (size_t)n_pairs * 32 + 32) || ensure(c, dfr, (size_t)n_frames * sizeof(rship_pixel_frame)) ||
-        ensure(c, dbad, 16))
-        return 1;
-    hipError_t e = hipMemcpyAsync(dpx.p, px, (size_t)n_pairs * 32, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dfr.p, frames, (size_t)n_frames * sizeof(rship_pixel_frame), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(dbad.p, 0, 16, c->stream);
-    if (e == hipSuccess) {
-        PixelParams p{(const double*)dpx.p, (const rship_pixel_frame*)dfr.p, (f4*)c->rays_a.p, (f4*)c->rays_b.p, (uint32_t*)dbad.p};
-        {
-            ProfScope ps(c, RSHIP_K_PIXELS);
-            hipLaunchKernelGGL(rays_from_pixels_kernel, dim3(n_frames, (max_n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, p);
-        }
-        e = hipGetLastError();
-    }
-    uint32_t nb = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&nb, dbad.p, 4, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    prof_collect(c);
-    if (e != hipSuccess) return set_err(c, "rays_from_pixels", e);
-    if (bad) *bad = nb;
     return 0;
 }
 

@@ -100,12 +100,63 @@ void quat_slerp(const double* p, const double* q_in, double t, double* out) {
     for (int i = 0; i < 4; ++i) out[i] = m1 * p[i] + m2 * q[i];
 }
 
-struct HostFrame { // core_private.hpp:8-13 (FrameData), copied at SetTrackResult time
-    std::vector<double> ts_a, ts_b, rays_a, rays_b;
-    // frames given as tracked pixels (rssync_ext_set_track_pixels): rays_* stay empty, the device
-    // produces them from px = {xa, ya, xb, yb} per pair; ts_* are kept for the frame table
+// Host staging of the track data (core_private.hpp:8-13 FrameData; "copy at call time" is the
+// contract of core_private.cpp:192-203): one record per frame in a chunked arena of pinned memory,
+// addressed by a single running offset in doubles.  The device keeps a raw buffer with the same
+// offsets (rship_upload_raw); records are never moved, a frame that is set again gets a new record
+// and the old one is dead space until the problem is destroyed.
+class Arena {
+   public:
+    ~Arena() {
+        for (auto& s : slabs_) {
+            if (s.pinned) rship_host_free(s.p);
+            else std::free(s.p);
+        }
+    }
+    // space for n doubles that does not straddle a slab; returns its arena offset
+    uint64_t alloc(uint64_t n, double** out) {
+        if (slabs_.empty() || slabs_.back().used + n > slabs_.back().cap) {
+            Slab s;
+            s.base = size(); // offsets stay dense: the unused tail of the previous slab has none
+            s.cap = std::max<uint64_t>(n, kSlabDoubles);
+            s.p = (double*)rship_host_alloc((size_t)s.cap * 8);
+            s.pinned = s.p != nullptr;
+            if (!s.p) s.p = (double*)std::malloc((size_t)s.cap * 8); // the runtime refused to pin
+            if (!s.p) return UINT64_MAX;
+            slabs_.push_back(s);
+        }
+        Slab& s = slabs_.back();
+        *out = s.p + s.used;
+        const uint64_t off = s.base + s.used;
+        s.used += n;
+        return off;
+    }
+    uint64_t size() const { return slabs_.empty() ? 0 : slabs_.back().base + slabs_.back().used; }
+    // contiguous host ranges covering arena offsets [lo, hi): fn(host pointer, arena offset, count)
+    template <typename F>
+    void ranges(uint64_t lo, uint64_t hi, F&& fn) const {
+        for (const Slab& s : slabs_) {
+            const uint64_t a = std::max(lo, s.base), b = std::min(hi, s.base + s.used);
+            if (a < b) fn(s.p + (a - s.base), a, b - a);
+        }
+    }
+
+   private:
+    static constexpr uint64_t kSlabDoubles = (64u << 20) / 8; // 64 MB slabs
+    struct Slab {
+        double* p = nullptr;
+        uint64_t base = 0, cap = 0, used = 0;
+        bool pinned = false;
+    };
+    std::vector<Slab> slabs_;
+};
+
+struct HostFrame {
+    uint64_t raw_off = 0; // arena offset of the record: rays = ts_a[n] ts_b[n] rays_a[3n] rays_b[3n]; pixels = {xa,ya,xb,yb}[n]
+    uint32_t n = 0;
+    double ts_min = 0, ts_max = 0; // over ts_a and ts_b: all the frame table needs from the data
+    // frames given as tracked pixels (rssync_ext_set_track_pixels): the packing kernel undistorts
     bool from_pixels = false;
-    std::vector<double> px;
     double time_a = 0, time_b = 0, rows = 0;
     double lens[9] = {};
 };
@@ -179,7 +230,7 @@ class SyncProblemHip final : public ISyncProblem {
     int64_t table_id(uint32_t i) const { return table_ids_[i]; }
     size_t table_size() const { return table_ids_.size(); }
     bool has_frame(int64_t id) const { return frames_.count(id) != 0; }
-    size_t frame_tracks(int64_t id) const { return frames_.at(id).ts_a.size(); }
+    size_t frame_tracks(int64_t id) const { return frames_.at(id).n; }
     uint32_t sync_calls = 0;
     uint64_t last_best_not_last = 0; // of the last rssync_ext_opt_motion call
 
@@ -189,7 +240,11 @@ class SyncProblemHip final : public ISyncProblem {
     }
     void build_spline();
     void pack_frames();
-    void install_gyro(struct GyroGrid&& g, std::vector<float>* coef);
+    void install_gyro(struct GyroGrid&& g, std::vector<double>* coef);
+    double* stage_record(int64_t frame, uint64_t n_doubles, HostFrame& f);
+    void upload_new_records();
+    Arena arena_;
+    uint64_t uploaded_ = 0; // arena offsets below this are on the device
 
     double fs_ = 0, start_ = 0;
     std::vector<double> knots_; // 4 per sample, [w,x,y,z]
@@ -226,7 +281,7 @@ void SyncProblemHip::SetGyroQuaternions(const double* data, size_t count, double
 // core_private.cpp:142-190.  The grid is computed in the reference's integer types:
 // rate in micro-hertz and grid times in microseconds as uint64, first grid index by a
 // truncating division (the std::ceil at :152 is applied to an integer).
-static std::vector<float> spline_table(const std::vector<double>& knots);
+static std::vector<double> spline_table(const std::vector<double>& knots);
 
 struct GyroGrid {
     double fs = 0, start = 0;
@@ -274,7 +329,7 @@ void SyncProblemHip::SetGyroQuaternions(const int64_t* ts, const double* quats, 
     install_gyro(resample_timestamped(ts, quats, count), nullptr);
 }
 
-void SyncProblemHip::install_gyro(GyroGrid&& g, std::vector<float>* coef) {
+void SyncProblemHip::install_gyro(GyroGrid&& g, std::vector<double>* coef) {
     if (fs_ != g.fs || start_ != g.start) frames_dirty_ = true;
     fs_ = g.fs;
     start_ = g.start;
@@ -287,6 +342,27 @@ void SyncProblemHip::install_gyro(GyroGrid&& g, std::vector<float>* coef) {
     }
 }
 
+// a new record for `frame` in the staging arena (replaces any earlier one)
+double* SyncProblemHip::stage_record(int64_t frame, uint64_t n_doubles, HostFrame& f) {
+    double* dst = nullptr;
+    f.raw_off = arena_.alloc(n_doubles ? n_doubles : 1, &dst);
+    if (f.raw_off == UINT64_MAX) panic("set-track-result: out of host memory");
+    (void)frame;
+    return dst;
+}
+
+// Hand everything staged since the last call to the device, asynchronously: the DMA overlaps the
+// caller's loop over frames (the reference driver tracks one frame pair at a time,
+// core_testcode.cpp:135-158) and has usually finished by the time PreSync/Sync is called.
+void SyncProblemHip::upload_new_records() {
+    const uint64_t end = arena_.size();
+    if (end <= uploaded_) return;
+    arena_.ranges(uploaded_, end, [&](const double* host, uint64_t off, uint64_t cnt) {
+        hip_check(rship_upload_raw(dev_, host, off, cnt), "upload tracks");
+    });
+    uploaded_ = end;
+}
+
 // core_private.cpp:192-203; the data is copied before returning
 void SyncProblemHip::SetTrackResult(int64_t frame, const double* ts_a, const double* ts_b, const double* rays_a,
                                     const double* rays_b, size_t count) {
@@ -297,18 +373,28 @@ void SyncProblemHip::SetTrackResult(int64_t frame, const double* ts_a, const dou
     if (count > (size_t)rship_max_tracks())
         panic("set-track-result: " + std::to_string(count) + " tracks in one frame; this build accepts at most " +
               std::to_string(rship_max_tracks()));
-    HostFrame& f = frames_[frame];
-    f = HostFrame{};
-    f.ts_a.assign(ts_a, ts_a + count);
-    f.ts_b.assign(ts_b, ts_b + count);
-    f.rays_a.assign(rays_a, rays_a + 3 * count);
-    f.rays_b.assign(rays_b, rays_b + 3 * count);
+    HostFrame f;
+    f.n = (uint32_t)count;
+    double* rec = stage_record(frame, 8 * (uint64_t)count, f);
+    std::memcpy(rec, ts_a, count * 8);
+    std::memcpy(rec + count, ts_b, count * 8);
+    std::memcpy(rec + 2 * count, rays_a, 3 * count * 8);
+    std::memcpy(rec + 5 * count, rays_b, 3 * count * 8);
+    if (count) {
+        f.ts_min = f.ts_max = ts_a[0];
+        for (size_t i = 0; i < count; ++i) {
+            f.ts_min = std::min(f.ts_min, std::min(ts_a[i], ts_b[i]));
+            f.ts_max = std::max(f.ts_max, std::max(ts_a[i], ts_b[i]));
+        }
+    }
+    frames_[frame] = f;
     frames_dirty_ = true;
+    upload_new_records();
 }
 
 // The reference driver's per-frame step before SetTrackResult (core_testcode.cpp:135-158) with the
-// arithmetic moved to the device: the host keeps the pixels and the row times (:144-145, needed for
-// the frame table), rays_from_pixels_kernel undistorts and normalises into the packed streams.
+// arithmetic moved to the device: the host stages the pixels and keeps the range of the row times
+// (:144-145, needed for the frame table); the packing kernel undistorts and normalises.
 void SyncProblemHip::SetTrackPixels(int64_t frame, double time_a, double time_b, const double* px_a,
                                     const double* px_b, size_t count, const double lens[9], double image_rows) {
     if (!all_finite(px_a, 2 * count)) panic("set-track-pixels: non-finite numbers in points_a");
@@ -319,23 +405,26 @@ void SyncProblemHip::SetTrackPixels(int64_t frame, double time_a, double time_b,
     if (count > (size_t)rship_max_tracks())
         panic("set-track-result: " + std::to_string(count) + " tracks in one frame; this build accepts at most " +
               std::to_string(rship_max_tracks()));
-    HostFrame& f = frames_[frame];
-    f = HostFrame{};
+    HostFrame f;
+    f.n = (uint32_t)count;
     f.from_pixels = true;
     f.time_a = time_a;
     f.time_b = time_b;
     f.rows = image_rows;
     std::copy(lens, lens + 9, f.lens);
-    f.px.resize(4 * count);
-    f.ts_a.resize(count);
-    f.ts_b.resize(count);
+    double* rec = stage_record(frame, 4 * (uint64_t)count, f);
     for (size_t i = 0; i < count; ++i) {
-        f.px[4 * i] = px_a[2 * i]; f.px[4 * i + 1] = px_a[2 * i + 1];
-        f.px[4 * i + 2] = px_b[2 * i]; f.px[4 * i + 3] = px_b[2 * i + 1];
-        f.ts_a[i] = time_a + lens[0] * (px_a[2 * i + 1] / image_rows); // :144
-        f.ts_b[i] = time_b + lens[0] * (px_b[2 * i + 1] / image_rows); // :145
+        rec[4 * i] = px_a[2 * i]; rec[4 * i + 1] = px_a[2 * i + 1];
+        rec[4 * i + 2] = px_b[2 * i]; rec[4 * i + 3] = px_b[2 * i + 1];
+        const double tsa = time_a + lens[0] * (px_a[2 * i + 1] / image_rows); // :144
+        const double tsb = time_b + lens[0] * (px_b[2 * i + 1] / image_rows); // :145
+        if (i == 0) f.ts_min = f.ts_max = tsa;
+        f.ts_min = std::min(f.ts_min, std::min(tsa, tsb));
+        f.ts_max = std::max(f.ts_max, std::max(tsa, tsb));
     }
+    frames_[frame] = f;
     frames_dirty_ = true;
+    upload_new_records();
 }
 
 // optdata_fill_gyro (core_testcode.cpp:36-52): q_0 = identity, q_i = normalise(dq_i * q_{i-1}) with
@@ -398,7 +487,7 @@ void SyncProblemHip::orientation_sweep(const double* ts, const double* rates, si
                                        double search_radius, double* costs, double* delays) {
     struct Prepared {
         GyroGrid grid;
-        std::vector<float> coef;
+        std::vector<double> coef;
     };
     auto prepare = [=](std::string o) {
         Prepared p;
@@ -422,12 +511,12 @@ void SyncProblemHip::orientation_sweep(const double* ts, const double* rates, si
 // (replaces minispline.cpp:3-46 / ndspline.cpp:13-19).  Interior equations
 //   c[i-1]/3 + 4 c[i]/3 + c[i+1]/3 = y[i+1] - 2 y[i] + y[i-1],  c[0] = c[n-1] = 0,
 // solved by the Thomas recurrence in fp64, then d, b and the tail coefficients the
-// reference's extrapolation uses (minispline.cpp:43-44).  The table is rounded to fp32
-// once, here: 16 floats per knot = y[4], b[4], c[4], d[4].
-static std::vector<float> spline_table(const std::vector<double>& knots) {
+// reference's extrapolation uses (minispline.cpp:43-44).  16 doubles per knot = y[4], b[4],
+// c[4], d[4]; the device keeps the table in fp64 and rounds a copy to fp32 for the PreSync kernel.
+static std::vector<double> spline_table(const std::vector<double>& knots) {
     const size_t n = knots.size() / 4;
     if (n < 2) panic("sync: gyro data was not set");
-    std::vector<float> coef(n * 16);
+    std::vector<double> coef(n * 16);
     std::vector<double> c(n), cp(n), y(n);
     for (int comp = 0; comp < 4; ++comp) {
         for (size_t i = 0; i < n; ++i) y[i] = knots[4 * i + comp];
@@ -452,11 +541,11 @@ static std::vector<float> spline_table(const std::vector<double>& knots) {
                 d = 0.0;
                 b = 3.0 * d_prev + 2.0 * c[n - 2] + b_prev;
             }
-            float* row = &coef[16 * i];
-            row[0 + comp] = (float)y[i];
-            row[4 + comp] = (float)b;
-            row[8 + comp] = (float)c[i];
-            row[12 + comp] = (float)d;
+            double* row = &coef[16 * i];
+            row[0 + comp] = y[i];
+            row[4 + comp] = b;
+            row[8 + comp] = c[i];
+            row[12 + comp] = d;
             b_prev = b;
             d_prev = d;
         }
@@ -465,119 +554,67 @@ static std::vector<float> spline_table(const std::vector<double>& knots) {
 }
 
 void SyncProblemHip::build_spline() {
-    std::vector<float> coef = spline_table(knots_);
+    std::vector<double> coef = spline_table(knots_);
     hip_check(rship_upload_spline(dev_, coef.data(), (uint32_t)(knots_.size() / 4), fs_), "upload spline");
     spline_dirty_ = false;
 }
 
-// Device layout of OptData::frame_data (core_private.hpp:21): two float4 streams
-// {ax,bx,ay,by} / {az,bz,ta,tb}, frames in ascending id order.  ta/tb carry the spline
-// parameter (ts - start) * fs (core_private.cpp:19-20 without the delay) relative to the
-// frame's integer base knot, so fp32 only ever holds a span of a few tens of knots.
+// Device layout of OptData::frame_data (core_private.hpp:21): frames in ascending id order; per
+// ray pair the fp32 streams {ax,bx,ay,by} / {az,bz,ta,tb} (PreSync) and the fp64 streams
+// {ax,bx} {ay,by} {az,bz} {ta,tb} (Sync).  ta/tb carry the spline parameter (ts - start) * fs
+// (core_private.cpp:19-20 without the delay) relative to the frame's integer base knot, so fp32
+// only ever holds a span of a few tens of knots.  The host's part is O(frames): the table (base
+// knot and parameter range of every frame, from the time range noted at SetTrackResult) and the
+// list of raw records; the streams themselves are written by the packing kernel.
 void SyncProblemHip::pack_frames() {
-    // pass 1 (serial, O(frames)): where every frame goes
-    struct Slot {
-        int64_t id;
-        const HostFrame* f;
-        size_t off, px_off;
-        int pix; // index into the pixel-frame list, or -1
-    };
-    std::vector<Slot> slots;
-    slots.reserve(frames_.size());
-    size_t total = 0, px_pairs = 0, n_pix = 0;
+    const size_t nf = frames_.size();
+    std::vector<rship_frame> table(nf);
+    std::vector<rship_pack_frame> pack(nf);
+    table_ids_.resize(nf);
+    size_t total = 0, s = 0;
     for (auto& [id, f] : frames_) {
-        slots.push_back({id, &f, total, px_pairs, f.from_pixels && !f.ts_a.empty() ? (int)n_pix : -1});
-        total += f.ts_a.size();
-        if (f.from_pixels && !f.ts_a.empty()) { px_pairs += f.ts_a.size(); ++n_pix; }
+        const size_t n = f.n;
+        // (ts - start) * fs is monotonic in ts: its range comes from the range of ts
+        const double xmin = (f.ts_min - start_) * fs_, xmax = (f.ts_max - start_) * fs_;
+        double base = n ? std::floor(xmin) : 0.0;
+        if (!(base > -(double)kKnotClamp)) base = -(double)kKnotClamp;
+        if (base > (double)kKnotClamp) base = (double)kKnotClamp;
+        rship_frame rec{};
+        rec.ray_offset = (uint32_t)total;
+        rec.n_rays = (uint32_t)n;
+        rec.base_knot = (int32_t)base;
+        rec.id = id;
+        rec.tmin64 = n ? xmin - base : 0.0;
+        rec.tmax64 = n ? xmax - base : 0.0;
+        rec.tmin = (float)rec.tmin64;
+        rec.tmax = (float)rec.tmax64;
+        if (f.from_pixels) {
+            // the device recomputes the row times from the pixels with the same fp64 operations; one
+            // ulp of slack on the bounds costs nothing and makes the window independent of that
+            rec.tmin = std::nextafterf(rec.tmin, -std::numeric_limits<float>::infinity());
+            rec.tmax = std::nextafterf(rec.tmax, std::numeric_limits<float>::infinity());
+            rec.tmin64 = std::nextafter(rec.tmin64, -std::numeric_limits<double>::infinity());
+            rec.tmax64 = std::nextafter(rec.tmax64, std::numeric_limits<double>::infinity());
+        }
+        rship_pack_frame pf{};
+        pf.raw_offset = f.raw_off;
+        pf.ray_offset = rec.ray_offset;
+        pf.n_rays = rec.n_rays;
+        pf.base = base;
+        pf.is_pixels = f.from_pixels ? 1u : 0u;
+        pf.time_a = f.time_a; pf.time_b = f.time_b; pf.rows = f.rows;
+        std::copy(f.lens, f.lens + 9, pf.lens);
+        table[s] = rec;
+        pack[s] = pf;
+        table_ids_[s] = id;
+        total += n;
+        ++s;
     }
     if (total > 0xffffffffull) panic("sync: more than 2^32 rays");
-    const bool any_rays = n_pix < slots.size();
-    // uninitialised on purpose: every ray-frame slice is written below, pixel-frame slices on the device
-    std::unique_ptr<float[]> a4(new float[any_rays ? total * 4 + 4 : 4]), b4(new float[any_rays ? total * 4 + 4 : 4]);
-    std::vector<rship_frame> table(slots.size());
-    std::vector<rship_pixel_frame> pframes(n_pix);
-    std::vector<double> px(px_pairs * 4);
-    table_ids_.resize(slots.size());
-
-    // pass 2: frames are independent -- packed by a few host threads (268 MB at BASELINE size)
-    const double start = start_, fs = fs_;
-    auto pack_range = [&](size_t lo, size_t hi) {
-        for (size_t s = lo; s < hi; ++s) {
-            const Slot& sl = slots[s];
-            const HostFrame& f = *sl.f;
-            const size_t n = f.ts_a.size(), off = sl.off;
-            double xmin = std::numeric_limits<double>::infinity();
-            for (size_t i = 0; i < n; ++i) {
-                xmin = std::min(xmin, (f.ts_a[i] - start) * fs);
-                xmin = std::min(xmin, (f.ts_b[i] - start) * fs);
-            }
-            double base = n ? std::floor(xmin) : 0.0;
-            if (!(base > -(double)kKnotClamp)) base = -(double)kKnotClamp;
-            if (base > (double)kKnotClamp) base = (double)kKnotClamp;
-            rship_frame rec{};
-            rec.ray_offset = (uint32_t)off;
-            rec.n_rays = (uint32_t)n;
-            rec.base_knot = (int32_t)base;
-            rec.id = sl.id;
-            float tmin = 0.f, tmax = 0.f;
-            for (size_t i = 0; i < n; ++i) {
-                const float ta = (float)((f.ts_a[i] - start) * fs - base);
-                const float tb = (float)((f.ts_b[i] - start) * fs - base);
-                if (!f.from_pixels) {
-                    float* pa = &a4[4 * (off + i)];
-                    float* pb = &b4[4 * (off + i)];
-                    // {ax,bx,ay,by} / {az,bz,ta,tb}: the two ends of the pair interleaved
-                    pa[0] = (float)f.rays_a[3 * i]; pa[1] = (float)f.rays_b[3 * i]; pa[2] = (float)f.rays_a[3 * i + 1]; pa[3] = (float)f.rays_b[3 * i + 1];
-                    pb[0] = (float)f.rays_a[3 * i + 2]; pb[1] = (float)f.rays_b[3 * i + 2]; pb[2] = ta; pb[3] = tb;
-                }
-                if (i == 0) { tmin = std::min(ta, tb); tmax = std::max(ta, tb); }
-                tmin = std::min(tmin, std::min(ta, tb));
-                tmax = std::max(tmax, std::max(ta, tb));
-            }
-            if (sl.pix >= 0) {
-                // the device recomputes ta/tb from the pixels with the same fp64 operations; one ulp
-                // of slack on the bounds costs nothing and makes the window independent of that
-                tmin = std::nextafterf(tmin, -std::numeric_limits<float>::infinity());
-                tmax = std::nextafterf(tmax, std::numeric_limits<float>::infinity());
-                rship_pixel_frame pf{};
-                pf.time_a = f.time_a; pf.time_b = f.time_b; pf.rows = f.rows;
-                std::copy(f.lens, f.lens + 9, pf.lens);
-                pf.start = start; pf.fs = fs; pf.base = base;
-                pf.px_offset = sl.px_off;
-                pf.ray_offset = (uint32_t)off;
-                pf.n_rays = (uint32_t)n;
-                std::copy(f.px.begin(), f.px.end(), px.begin() + 4 * sl.px_off);
-                pframes[(size_t)sl.pix] = pf;
-            }
-            rec.tmin = tmin;
-            rec.tmax = tmax;
-            table[s] = rec;
-            table_ids_[s] = sl.id;
-        }
-    };
-    const size_t hw = std::max<size_t>(1, std::min<size_t>(16, std::thread::hardware_concurrency()));
-    const size_t n_thr = total < (1u << 18) ? 1 : std::min(hw, slots.size());
-    if (n_thr <= 1) {
-        pack_range(0, slots.size());
-    } else {
-        std::vector<std::thread> pool;
-        const size_t per = (slots.size() + n_thr - 1) / n_thr;
-        for (size_t t = 0; t < n_thr; ++t) {
-            const size_t lo = t * per, hi = std::min(slots.size(), lo + per);
-            if (lo < hi) pool.emplace_back(pack_range, lo, hi);
-        }
-        for (auto& th : pool) th.join();
-    }
-    // frames given as pixels are filled in on the device: if all are, nothing is copied
-    hip_check(rship_upload_frames(dev_, any_rays ? a4.get() : nullptr, any_rays ? b4.get() : nullptr, total,
-                                  table.data(), (uint32_t)table.size()),
-              "upload frames");
-    if (!pframes.empty()) {
-        uint32_t bad = 0;
-        hip_check(rship_rays_from_pixels(dev_, px.data(), px.size() / 4, pframes.data(), (uint32_t)pframes.size(), &bad),
-                  "rays from pixels");
-        if (bad) panic("set-track-result: non-finite numbers in rays (" + std::to_string(bad) + " tracks; lens parameters?)");
-    }
+    upload_new_records();
+    uint32_t bad = 0;
+    hip_check(rship_pack_frames(dev_, table.data(), pack.data(), (uint32_t)nf, total, start_, fs_, &bad), "pack frames");
+    if (bad) panic("set-track-result: non-finite numbers in rays (" + std::to_string(bad) + " tracks; lens parameters?)");
     sel_.clear();
     frames_dirty_ = false;
 }
@@ -594,7 +631,7 @@ uint32_t SyncProblemHip::select(int64_t begin, int64_t end_exclusive) {
     for (uint32_t i = 0; i < table_ids_.size(); ++i)
         if (table_ids_[i] >= begin && table_ids_[i] < end_exclusive) sel_.push_back(i);
     for (uint32_t i : sel_)
-        if (frames_.at(table_ids_[i]).ts_a.size() < 2)
+        if (frames_.at(table_ids_[i]).n < 2)
             panic("sync: frame " + std::to_string(table_ids_[i]) + " has fewer than 2 tracks");
     n_windows_ = 1;
     hip_check(rship_select_frames(dev_, sel_.data(), (uint32_t)sel_.size()), "select frames");
@@ -752,7 +789,7 @@ void SyncProblemHip::select_windows(const std::vector<int64_t>& begins, const st
         off[w + 1] = (uint32_t)sel_.size();
     }
     for (uint32_t i : sel_)
-        if (frames_.at(table_ids_[i]).ts_a.size() < 2)
+        if (frames_.at(table_ids_[i]).n < 2)
             panic("sync: frame " + std::to_string(table_ids_[i]) + " has fewer than 2 tracks");
     n_windows_ = std::max<size_t>(1, begins.size());
     hip_check(rship_select_slots(dev_, sel_.data(), (uint32_t)sel_.size(), off.data(), (uint32_t)n_windows_), "select slots");

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -23,9 +24,12 @@ using rs::f4;
 
 struct rship_ctx {
     std::string err;
-    std::vector<f4> coef; // 4 per knot
+    std::vector<f4> coef; // 4 per knot (fp32, PreSync)
+    std::vector<double> coef64; // 16 per knot (Sync)
     double fs = 0;
+    std::vector<double> raw;    // mirror of the host staging arena
     std::vector<f4> rays_a, rays_b;
+    std::vector<double> q[4];   // fp64 streams {ax,bx} {ay,by} {az,bz} {ta,tb}, 2 doubles per ray each
     std::vector<rship_frame> frames;
     std::vector<uint32_t> sel, grp, grp_off; // slots, slot -> window, window offsets
     std::vector<double> M, k;                // per slot
@@ -118,50 +122,67 @@ int rship_set_option(rship_ctx* c, int option, int value) {
     return 0;
 }
 
-int rship_upload_spline(rship_ctx* c, const float* coef16, uint32_t n_knots, double sample_rate) {
+int rship_upload_spline(rship_ctx* c, const double* coef16, uint32_t n_knots, double sample_rate) {
+    c->coef64.assign(coef16, coef16 + (size_t)n_knots * 16);
     c->coef.resize((size_t)n_knots * 4);
-    std::memcpy(c->coef.data(), coef16, (size_t)n_knots * 64);
+    float* f = reinterpret_cast<float*>(c->coef.data());
+    for (size_t i = 0; i < (size_t)n_knots * 16; ++i) f[i] = (float)coef16[i];
     c->fs = sample_rate;
     return 0;
 }
 
-int rship_upload_frames(rship_ctx* c, const float* a4, const float* b4, uint64_t total, const rship_frame* table, uint32_t nf) {
-    c->rays_a.resize(total);
-    c->rays_b.resize(total);
-    if (total && a4 && b4) {
-        std::memcpy(c->rays_a.data(), a4, total * 16);
-        std::memcpy(c->rays_b.data(), b4, total * 16);
-    }
+void* rship_host_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
+void rship_host_free(void* p) { std::free(p); }
+
+int rship_upload_raw(rship_ctx* c, const double* host, uint64_t arena_offset, uint64_t n_doubles) {
+    if (c->raw.size() < arena_offset + n_doubles) c->raw.resize(arena_offset + n_doubles);
+    std::memcpy(c->raw.data() + arena_offset, host, (size_t)n_doubles * 8);
+    return 0;
+}
+
+// pack_frames_kernel, one pair at a time (same headers, same operations)
+int rship_pack_frames(rship_ctx* c, const rship_frame* table, const rship_pack_frame* pack, uint32_t nf, uint64_t total,
+                      double start, double fs, uint32_t* bad) {
+    c->rays_a.assign(total, f4{0, 0, 0, 0});
+    c->rays_b.assign(total, f4{0, 0, 0, 0});
+    for (auto& q : c->q) q.assign(2 * total, 0.0);
     c->frames.assign(table, table + nf);
     c->sel.clear();
     c->grp.clear();
     c->grp_off.assign(2, 0);
-    return 0;
-}
-
-// rays_from_pixels_kernel, one pair at a time (same header, same operations)
-int rship_rays_from_pixels(rship_ctx* c, const double* px, uint64_t n_pairs, const rship_pixel_frame* frames,
-                           uint32_t n_frames, uint32_t* bad) {
     uint32_t nb = 0;
-    for (uint32_t fi = 0; fi < n_frames; ++fi) {
-        const rship_pixel_frame& fr = frames[fi];
-        if (fr.px_offset + fr.n_rays > n_pairs || (uint64_t)fr.ray_offset + fr.n_rays > c->rays_a.size())
-            return fail(c, "rays_from_pixels: frame exceeds a buffer");
+    for (uint32_t fi = 0; fi < nf; ++fi) {
+        const rship_pack_frame& fr = pack[fi];
+        const uint64_t rec_len = (uint64_t)fr.n_rays * (fr.is_pixels ? 4 : 8);
+        if (fr.raw_offset + rec_len > c->raw.size() || (uint64_t)fr.ray_offset + fr.n_rays > total)
+            return fail(c, "pack: record outside a buffer");
+        const double* rec = c->raw.data() + fr.raw_offset;
+        const uint32_t n = fr.n_rays;
         const rs::Lens lens{fr.lens[0], fr.lens[1], fr.lens[2], fr.lens[3], fr.lens[4], fr.lens[5], fr.lens[6], fr.lens[7], fr.lens[8]};
-        for (uint32_t i = 0; i < fr.n_rays; ++i) {
-            const double* q = px + 4 * (fr.px_offset + i);
+        for (uint32_t i = 0; i < n; ++i) {
             double ra[3], rb[3], tsa, tsb;
-            rs::pixel_to_ray(lens, q[0], q[1], fr.time_a, fr.rows, ra, &tsa);
-            rs::pixel_to_ray(lens, q[2], q[3], fr.time_b, fr.rows, rb, &tsb);
+            if (fr.is_pixels) {
+                const double* q = rec + 4 * (size_t)i;
+                rs::pixel_to_ray(lens, q[0], q[1], fr.time_a, fr.rows, ra, &tsa);
+                rs::pixel_to_ray(lens, q[2], q[3], fr.time_b, fr.rows, rb, &tsb);
+            } else {
+                tsa = rec[i];
+                tsb = rec[(size_t)n + i];
+                for (int k = 0; k < 3; ++k) { ra[k] = rec[2 * (size_t)n + 3 * (size_t)i + k]; rb[k] = rec[5 * (size_t)n + 3 * (size_t)i + k]; }
+            }
+            const double ta = rs::knot_offset(tsa, start, fs, fr.base), tb = rs::knot_offset(tsb, start, fs, fr.base);
             const f4 o0{(float)ra[0], (float)rb[0], (float)ra[1], (float)rb[1]};
-            const f4 o1{(float)ra[2], (float)rb[2], (float)rs::knot_offset(tsa, fr.start, fr.fs, fr.base),
-                        (float)rs::knot_offset(tsb, fr.start, fr.fs, fr.base)};
+            const f4 o1{(float)ra[2], (float)rb[2], (float)ta, (float)tb};
             const float v[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
             bool ok = true;
             for (float x : v) ok = ok && std::isfinite(x);
             nb += ok ? 0u : 1u;
-            c->rays_a[fr.ray_offset + i] = o0;
-            c->rays_b[fr.ray_offset + i] = o1;
+            const size_t o = (size_t)fr.ray_offset + i;
+            c->rays_a[o] = o0;
+            c->rays_b[o] = o1;
+            for (int k = 0; k < 3; ++k) { c->q[k][2 * o] = ra[k]; c->q[k][2 * o + 1] = rb[k]; }
+            c->q[3][2 * o] = ta;
+            c->q[3][2 * o + 1] = tb;
         }
     }
     if (bad) *bad = nb;
