@@ -123,6 +123,24 @@ int rssync_ext_opt_motion(rssync_problem* p, double delay, double* M, double* k,
 int rssync_ext_set_motion(rssync_problem* p, const double* M, const double* k, int n_frames);
 /* sum over the current selection of loss (and analytic d/d-delay) at n delays */
 int rssync_ext_loss(rssync_problem* p, const double* delays, int n, double* loss, double* grad);
+/* "Simplified" mode of the thesis (section 2.11 eq. (12), p.26): translation neglected, loss
+ * sum over frames and tracks of log1p((k |h_j|)^2) with h_j = the j-th row of the residual matrix P
+ * (core_private.cpp:28).  The optimisation is one-dimensional: Sync's outer loop (core_private.cpp:298-331:
+ * backtracking step with momentum, the same stopping rules) without GuessMotion and without the per-frame
+ * motion optimisation; k per frame is GuessK's rule (:130-133, inline_utils.hpp:50) applied to the row norms,
+ * clamp(100 / sqrt(sum_j |h_j|^2), 10, 1000), at the initial delay.  The reference snapshot has no code for this
+ * mode; the thesis describes it.  frame_end inclusive, as Sync. */
+int rssync_ext_sync_simplified(rssync_problem* p, double initial_delay, int64_t frame_begin, int64_t frame_end,
+                               double search_center, double search_radius, double* cost, double* delay);
+/* its pieces, for the parity tests: k per frame at `delay` (selects [frame_begin, frame_end]), then the loss
+ * and its analytic d/d-delay on that selection */
+int rssync_ext_init_k_simplified(rssync_problem* p, double delay, int64_t frame_begin, int64_t frame_end, double* k,
+                                 int cap, int* n_frames);
+int rssync_ext_loss_simplified(rssync_problem* p, const double* delays, int n, double* loss, double* grad);
+/* the residual matrix as the Sync kernels compute it (fp64; rssync_ext_problem_matrix: fp32, PreSync) */
+int rssync_ext_problem_matrix64(rssync_problem* p, int64_t frame, double delay, double* P, double* dP, size_t cap_rows,
+                                size_t* n_rows);
+
 /* Upstream steps of the reference driver, moved behind the library.
  * set_track_pixels replaces the driver's undistort + normalise + row-time loop followed by
  * SetTrackResult (core_testcode.cpp:135-158): points_* are count x {x, y} pixel positions of the

@@ -132,26 +132,34 @@ int rship_presync_window_costs(rship_ctx* c, const int32_t* kd, const float* fd,
                                const uint32_t* seg_idx, const uint32_t* seg_off, uint32_t n_win,
                                double* costs, uint32_t* flags, double* frame_costs, int32_t* best_h);
 
-/* FrameState::GuessMotion + GuessK (core_private.cpp:125-133) for every
- * selected slot; kd/fd hold one delay per window, window w samples with
- * stream + w * stream_stride; results stay on the device */
+/* FrameState::GuessMotion (core_private.cpp:125-128): the 200-hypothesis LMedS search for every selected
+ * slot, in the fp32 tile kernel; kd/fd hold one delay per window (fp32 split), window w samples with
+ * stream + w * stream_stride.  Only the winning hypothesis index per slot is kept (on the device); the
+ * next rship_opt_motion -- or rship_finish_init -- recomputes the winning pair of rows in fp64,
+ * M = safe_normalize(P[i0] x P[i1]), and GuessK (:130-133) k = clamp(100 / |P M|, 10, 1000).  Asynchronous. */
 int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_hyp,
                       uint32_t stream, uint32_t stream_stride, uint64_t seed);
+/* finish a pending rship_init_motion at the same delays (fp64 split) without optimising */
+int rship_finish_init(rship_ctx* c, const int32_t* kd, const double* fd);
+/* no-translation variant (thesis section 2.11 eq. (12)): k = clamp(100 / sqrt(sum_j |P_j|^2), 10, 1000) per slot */
+int rship_init_k_simple(rship_ctx* c, const int32_t* kd, const double* fd);
 
 /* do_opt_motion (core_private.cpp:262-296): per-frame L-BFGS on the motion
- * vector at a fixed delay per window (fd = NaN skips a window).
+ * vector at a fixed delay per window (fd = NaN skips a window), in fp64.
  * stats (optional) = {sum of iterations, sum of evaluations, line searches whose best step was not the last} */
-int rship_opt_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint64_t* stats);
+int rship_opt_motion(rship_ctx* c, const int32_t* kd, const double* fd, uint64_t* stats);
 /* the same with per-slot diagnostics: per_frame[2i] = L-BFGS iterations, [2i+1] = evaluations */
-int rship_opt_motion_detail(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t* per_frame,
+int rship_opt_motion_detail(rship_ctx* c, const int32_t* kd, const double* fd, uint32_t* per_frame,
                             uint32_t cap);
 
 /* per window, sum over its slots of FrameState::Loss at n_delays delays
- * (core_private.cpp:117-123); kd/fd are [n_delays][n_windows] (fd = NaN skips), loss/grad out
+ * (core_private.cpp:117-123), in fp64; kd/fd are [n_delays][n_windows] (fd = NaN skips), loss/grad out
  * likewise; with grad != NULL also the analytic d/d-delay that replaces the central
- * difference at :96-97,112 */
-int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_delays, double* loss,
-               double* grad);
+ * difference at :96-97,112.  flags: RSHIP_LOSS_SIMPLIFIED = the no-translation loss
+ * sum_j log1p((k |P_j|)^2) (thesis section 2.11 eq. (12)) instead. */
+#define RSHIP_LOSS_SIMPLIFIED 1u
+int rship_loss(rship_ctx* c, const int32_t* kd, const double* fd, uint32_t n_delays, double* loss,
+               double* grad, uint32_t flags);
 
 /* per-slot state in selection order: M[3n], k[n] */
 int rship_get_motion(rship_ctx* c, double* M, double* k, uint32_t cap, uint32_t* n);
@@ -172,9 +180,12 @@ int rship_rccl_allreduce(rship_ctx* c, double* buf, uint64_t n);
 /* debug: the packed float4 streams of one frame of the table */
 int rship_debug_rays(rship_ctx* c, uint32_t frame_index, float* a4, float* b4, uint32_t cap_rays);
 
-/* residual matrix P (fp32, row-major N x 3) of one selected frame at one delay (tests) */
+/* residual matrix P (fp32, row-major N x 3) of one selected frame at one delay, as the PreSync
+ * kernel computes it (tests); _64: as the Sync kernels compute it, in fp64 */
 int rship_debug_problem(rship_ctx* c, uint32_t sel_index, int32_t kd, float fd, float* P,
                         float* dP, uint32_t cap_rows);
+int rship_debug_problem64(rship_ctx* c, uint32_t sel_index, int32_t kd, double fd, double* P,
+                          double* dP, uint32_t cap_rows);
 
 /* the wave-level exact selection used by the LMedS kernel, on caller data (tests): for each of
  * n_problems rows of n (<= 2048) non-negative floats, out[2i] = bit pattern of the kq-th smallest

@@ -84,6 +84,8 @@ def load():
     lib.ora_sync_trace.argtypes = [C.c_void_p, C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_double, _PD, _PD,
                                    _PD, C.c_int, _PI]
     lib.ora_sync_state.argtypes = [C.c_void_p, _PD, _PD, C.c_int, _PI]
+    lib.ora_sync_simplified_trace.argtypes = lib.ora_sync_trace.argtypes
+    lib.ora_loss_simplified.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_double, _PD, _PD, _PD]
     _LIB = lib
     return lib
 
@@ -300,6 +302,21 @@ class OracleProblem:
         self._check(self._lib.ora_sync_trace(self._h, initial_delay, frame_begin, frame_end, search_center,
                                              search_radius, C.byref(c), C.byref(d), _p(tr), cap, C.byref(n)))
         return c.value, d.value, tr[:min(n.value, cap)].copy()
+
+    def sync_simplified_trace(self, initial_delay, frame_begin, frame_end, search_center, search_radius, cap=512):
+        """Sync in the thesis' simplified (no-translation) mode -> (cost, delay, trace)"""
+        c, d, n = C.c_double(), C.c_double(), C.c_int()
+        tr = np.zeros((cap, 6))
+        self._check(self._lib.ora_sync_simplified_trace(self._h, initial_delay, frame_begin, frame_end, search_center,
+                                                        search_radius, C.byref(c), C.byref(d), _p(tr), cap, C.byref(n)))
+        return c.value, d.value, tr[:min(n.value, cap)].copy()
+
+    def loss_simplified(self, frame, delay_k, delay):
+        """one frame: (k chosen at delay_k, loss at delay, central-difference d loss / d delay)"""
+        k, L, g = C.c_double(), C.c_double(), C.c_double()
+        self._check(self._lib.ora_loss_simplified(self._h, int(frame), float(delay_k), float(delay), C.byref(k),
+                                                  C.byref(L), C.byref(g)))
+        return k.value, L.value, g.value
 
     def sync_state(self, cap=1 << 16):
         M, k, n = np.zeros((cap, 3)), np.zeros(cap), C.c_int()

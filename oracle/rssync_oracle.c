@@ -765,6 +765,17 @@ static double loss_from_P(const double* P, size_t n, const double M[3], double k
     return acc;
 }
 
+/* The thesis' no-translation variant (thesis-text.pdf section 2.11 eq. (12), printed p.26; no code in the
+ * reference snapshot): L = sum_j log(1 + (k |h_j|)^2) with h_j the j-th row of P (core_private.cpp:28). */
+static double loss_simple_from_P(const double* P, size_t n, double k) {
+    double acc = 0;
+    for (size_t i = 0; i < n; ++i) {
+        double r2 = (P[3 * i] * P[3 * i] + P[3 * i + 1] * P[3 * i + 1] + P[3 * i + 2] * P[3 * i + 2]) * k * k;
+        acc += log1p(r2);
+    }
+    return acc;
+}
+
 /* :99-110,114 given P: loss through the v1..v8 chain and dL/dM in closed form.
  * With pm = P M, s = |M|^2 / k^2, u = pm^2 / s:
  *   dL/dM = sum_i 1/(1+u_i) * [ (2 pm_i / s) P_i - (pm_i^2 / s^2) (2 M / k^2) ]
@@ -975,6 +986,7 @@ typedef struct {
     double* out_loss;
     double* out_grad;
     int with_grad;
+    int simplified; /* thesis section 2.11: no motion estimate, loss_simple_from_P */
 } sync_ctx;
 
 /* :218-223: GuessMotion (200 hypotheses) then GuessK at the initial delay */
@@ -984,6 +996,14 @@ static void sync_init_fn(void* vctx, size_t i) {
     size_t n = f->n;
     double* buf = (double*)malloc(7 * n * sizeof(double));
     compute_problem(c->p, f, c->delay, buf);
+    if (c->simplified) {
+        /* GuessK's rule (:130-133, inline_utils.hpp:50) with |h_j| in place of h_j . v: k = gamma / |x|_2 */
+        double ss = 0;
+        for (size_t j = 0; j < n; ++j) ss += buf[3 * j] * buf[3 * j] + buf[3 * j + 1] * buf[3 * j + 1] + buf[3 * j + 2] * buf[3 * j + 2];
+        f->k = clamp_k(1 / sqrt(ss) * 1e2);
+        free(buf);
+        return;
+    }
     guess_motion(buf, n, 200, c->p->seed, f->id, c->stream, buf + 3 * n, buf + 6 * n, f->M, NULL, NULL); /* :125-128 */
     if (c->p->faithful) compute_problem(c->p, f, c->delay, buf); /* :131 recomputes P */
     double ss = 0;
@@ -1001,6 +1021,19 @@ static void sync_loss_fn(void* vctx, size_t i) {
     frame_t* f = &c->p->frames[c->p->sel[i]];
     size_t n = f->n;
     double* P = (double*)malloc(3 * n * sizeof(double));
+    if (c->simplified) { /* the same schedule (central difference of :96-97,112) on the simplified loss */
+        if (c->with_grad) {
+            compute_problem(c->p, f, c->delay - kNumericDiffStep, P);
+            double ll = loss_simple_from_P(P, n, f->k);
+            compute_problem(c->p, f, c->delay + kNumericDiffStep, P);
+            double lr = loss_simple_from_P(P, n, f->k);
+            c->out_grad[i] = (lr - ll) / 2 / kNumericDiffStep;
+        }
+        compute_problem(c->p, f, c->delay, P);
+        c->out_loss[i] = loss_simple_from_P(P, n, f->k);
+        free(P);
+        return;
+    }
     if (c->with_grad) {
         compute_problem(c->p, f, c->delay - kNumericDiffStep, P);
         double ll = loss_from_P(P, n, f->M, f->k);
@@ -1035,9 +1068,9 @@ static double sum_in_order(const double* v, size_t n) {
     return s;
 }
 
-int ora_sync_trace(ora_problem* p, double initial_delay, int64_t frame_begin,
-                   int64_t frame_end, double search_center, double search_radius, double* cost,
-                   double* delay_out, double* trace, int cap, int* n_rows) {
+static int sync_trace_impl(ora_problem* p, int simplified, double initial_delay, int64_t frame_begin,
+                           int64_t frame_end, double search_center, double search_radius, double* cost,
+                           double* delay_out, double* trace, int cap, int* n_rows) {
     /* :218-219 end INCLUSIVE */
     select_frames(p, frame_begin, frame_end == INT64_MAX ? INT64_MAX : frame_end + 1);
     if (check_tracks(p)) return 1;
@@ -1045,8 +1078,8 @@ int ora_sync_trace(ora_problem* p, double initial_delay, int64_t frame_begin,
     double* fl = (double*)malloc((nf ? nf : 1) * sizeof(double));
     double* fg = (double*)malloc((nf ? nf : 1) * sizeof(double));
     double d = initial_delay;
-    sync_ctx ctx = {p, d, ORA_STREAM_SYNC_INIT + p->sync_calls, fl, fg, 0};
-    p->sync_calls++;
+    sync_ctx ctx = {p, d, ORA_STREAM_SYNC_INIT + p->sync_calls, fl, fg, 0, simplified};
+    if (!simplified) p->sync_calls++;
     parallel_for(p->nthreads, nf, sync_init_fn, &ctx);
 
     const double c_armijo = 2e-4, decay = .1, t0 = 1e-3; /* :226 */
@@ -1056,7 +1089,7 @@ int ora_sync_trace(ora_problem* p, double initial_delay, int64_t frame_begin,
     int converge_counter = 0, rows = 0;
     for (int it = 0; it < p->max_outer; ++it) { /* :309 */
         ctx.delay = d;
-        parallel_for(p->nthreads, nf, sync_motion_fn, &ctx); /* :311 */
+        if (!simplified) parallel_for(p->nthreads, nf, sync_motion_fn, &ctx); /* :311 */
         /* :298-305 do_opt_delay -> Backtrack::Step (backtrack.cpp:3-13) */
         double x0 = d - delay_b * delay_v;
         ctx.delay = x0; ctx.with_grad = 1;
@@ -1093,6 +1126,45 @@ int ora_sync_trace(ora_problem* p, double initial_delay, int64_t frame_begin,
     *delay_out = d;
     if (n_rows) *n_rows = rows;
     free(fl); free(fg);
+    return 0;
+}
+
+int ora_sync_trace(ora_problem* p, double initial_delay, int64_t frame_begin,
+                   int64_t frame_end, double search_center, double search_radius, double* cost,
+                   double* delay_out, double* trace, int cap, int* n_rows) {
+    return sync_trace_impl(p, 0, initial_delay, frame_begin, frame_end, search_center, search_radius, cost, delay_out,
+                           trace, cap, n_rows);
+}
+
+/* Sync of the thesis' simplified mode (section 2.11): the outer loop of core_private.cpp:298-331 on the
+ * no-translation loss; no GuessMotion, no per-frame motion optimisation, k from the row norms. */
+int ora_sync_simplified_trace(ora_problem* p, double initial_delay, int64_t frame_begin,
+                              int64_t frame_end, double search_center, double search_radius, double* cost,
+                              double* delay_out, double* trace, int cap, int* n_rows) {
+    return sync_trace_impl(p, 1, initial_delay, frame_begin, frame_end, search_center, search_radius, cost, delay_out,
+                           trace, cap, n_rows);
+}
+
+/* one frame of the simplified mode: k at delay_k, then loss and its central-difference d/d-delay at delay */
+int ora_loss_simplified(const ora_problem* p, int64_t frame, double delay_k, double delay, double* k_out, double* loss,
+                        double* dd_numeric) {
+    frame_t* f = find_frame(p, frame);
+    if (!f) return 1;
+    size_t n = f->n;
+    double* P = (double*)malloc(3 * n * sizeof(double));
+    compute_problem(p, f, delay_k, P);
+    double ss = 0;
+    for (size_t j = 0; j < 3 * n; ++j) ss += P[j] * P[j];
+    const double k = clamp_k(1 / sqrt(ss) * 1e2);
+    compute_problem(p, f, delay - kNumericDiffStep, P);
+    double ll = loss_simple_from_P(P, n, k);
+    compute_problem(p, f, delay + kNumericDiffStep, P);
+    double lr = loss_simple_from_P(P, n, k);
+    compute_problem(p, f, delay, P);
+    *loss = loss_simple_from_P(P, n, k);
+    *dd_numeric = (lr - ll) / 2 / kNumericDiffStep;
+    *k_out = k;
+    free(P);
     return 0;
 }
 

@@ -124,6 +124,14 @@ int ora_sync_trace(ora_problem* p, double initial_delay, int64_t frame_begin,
                    double* delay, double* trace, int cap, int* n_rows);
 /* per-frame state after the last Sync: M[3*i..], k[i] in ascending frame-id order */
 int ora_sync_state(const ora_problem* p, double* M, double* k, int cap, int* n_frames);
+/* The thesis' simplified mode (thesis-text.pdf section 2.11 eq. (12), printed p.26; the reference snapshot has
+ * no code for it): loss sum_j log1p((k |h_j|)^2) with h_j the rows of P, k per frame = clamp(100 / |x|_2, 10,
+ * 1000) over x_j = |h_j| (GuessK's rule, core_private.cpp:130-133), Sync's outer loop (:298-331) unchanged. */
+int ora_sync_simplified_trace(ora_problem* p, double initial_delay, int64_t frame_begin,
+                              int64_t frame_end, double search_center, double search_radius, double* cost,
+                              double* delay_out, double* trace, int cap, int* n_rows);
+int ora_loss_simplified(const ora_problem* p, int64_t frame, double delay_k, double delay, double* k_out, double* loss,
+                        double* dd_numeric);
 
 /* ---- driver steps upstream of the ISyncProblem calls (rssync_oracle_driver.c) ---- */
 typedef struct ora_lens { /* core_testcode.cpp:55-61 */

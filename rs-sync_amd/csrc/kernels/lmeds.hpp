@@ -23,9 +23,8 @@ struct LmedsParams {
     const uint32_t* grp; // slot -> group (window) or null; delays are indexed [candidate][group]
     uint32_t n_grp;      // >= 1
     double* frame_cost; // [n_cand][n_sel]
-    int32_t* best_h;    // [n_cand][n_sel] or null
-    double* M;          // INIT mode: per selection slot [3]
-    double* k;          // INIT mode
+    int32_t* best_h;    // [n_cand][n_sel] or null; INIT mode: [n_sel], the winning hypothesis per slot (-1 = none),
+                        // from which opt_motion64_kernel recomputes M and k in fp64
     uint32_t* flags;
 };
 
@@ -223,7 +222,7 @@ __device__ __forceinline__ uint32_t wave_pop(uint32_t* counter) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
 }
 
-template <int RPT, int MODE> // MODE 0: PreSync cost per candidate; 1: GuessMotion + GuessK
+template <int RPT, int MODE> // MODE 0: PreSync cost per candidate; 1: GuessMotion's hypothesis search (Sync start)
 __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsParams p) {
     constexpr int ROWS = kBlock * RPT;
     constexpr int NR = 4 * RPT; // residual registers per lane: a wave spans the whole tile
@@ -380,6 +379,10 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
             }
         }
         if (!(finite_f(Mv.x) && finite_f(Mv.y) && finite_f(Mv.z))) bad |= RSHIP_BAD_M;
+        if (MODE == 1) { // GuessMotion: only the winner's index leaves this kernel (one candidate per workgroup)
+            if (tid == 0) p.best_h[sf] = bH;
+            continue;
+        }
 
         // ---- stage D: k = clamp(100 / |P M|), cost = sqrt(sum sqrt(log1p(r^2))) ----
         // Branch-free over the rows: a row beyond N has nrm = 0 but a NaN tile entry, so its
@@ -397,14 +400,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         // core_private.cpp:79, 100 / ||P M|| as 100 * rsq (v_rsq_f32, 1 ulp); ss = 0 gives +inf -> clamp
         float kf = 100.0f * rs::rsqrt_fast((float)ss_tot);
         kf = (kf < 10.f) ? 10.f : ((1000.f < kf) ? 1000.f : kf);
-        if (MODE == 1) {
-            if (tid == 0) {
-                p.M[3 * sf + 0] = (double)Mv.x;
-                p.M[3 * sf + 1] = (double)Mv.y;
-                p.M[3 * sf + 2] = (double)Mv.z;
-                p.k[sf] = (double)kf;
-            }
-        } else {
+        {
             float sc = kf * rs::rsqrt_fast(rs::dot(Mv, Mv)); // core_private.cpp:80
             // a non-finite r or rho (core_private.cpp:81,83) makes the sums non-finite: NaN propagates
             // and all terms are >= 0, so the checks are made once on the sums, not per row

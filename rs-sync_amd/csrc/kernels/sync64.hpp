@@ -231,6 +231,7 @@ struct Motion64Params {
 };
 
 constexpr int kInitNone = (int)0x80000000;
+constexpr int kNB = 10; // numBasis (ens::L_BFGS default)
 
 template <int RPT>
 struct MotionEval64 {

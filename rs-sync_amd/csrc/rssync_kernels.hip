@@ -7,10 +7,11 @@
 //                      matrix P into an LDS tile, LMedS hypothesis search with an exact
 //                      lower-quartile selection, robust PreSync cost.  The same kernel
 //                      in INIT mode is Sync's GuessMotion/GuessK.
-//   loss_kernel        one workgroup per frame: residual + robust loss (+ analytic
-//                      d/d-delay) for a batch of delays, rays held in registers.
-//   opt_motion_kernel  one workgroup per frame: P in registers, restated L-BFGS on the
-//                      3-vector motion estimate.
+//   loss64_kernel      one workgroup per frame: residual + robust loss (+ analytic
+//                      d/d-delay) for a batch of delays, fp64 (the reference's arithmetic).
+//   opt_motion64_kernel one workgroup per frame: P in registers (fp64), restated L-BFGS on the
+//                      3-vector motion estimate; also finishes GuessMotion/GuessK in fp64.
+//   pack_frames_kernel raw track records -> packed fp32 + fp64 streams.
 //   segment_sum_kernel fixed-order fp64 sums over the frames of each window.
 // Data layout and the roofline that bounds each kernel: DESIGN.md.
 // The kernels live in kernels/*.hpp (one header each, included below); this file holds the
@@ -34,9 +35,8 @@ using rs::f4;
 // the kernels, one header per kernel, all in this translation unit
 #include "kernels/common.hpp"
 #include "kernels/lmeds.hpp"
-#include "kernels/loss.hpp"
-#include "kernels/motion.hpp"
 #include "kernels/support.hpp"
+#include "kernels/sync64.hpp"
 
 // ===========================================================================
 // host side of the C-ABI
@@ -63,7 +63,11 @@ struct rship_ctx {
     hipEvent_t copy_done = nullptr;
     std::string err;
     // problem data
-    DevBuf coef, coef64, raw, rays_a, rays_b, rays64, frames, sel, M, k, grp, grp_off, seg_idx, seg_off;
+    DevBuf coef, coef64, raw, rays_a, rays_b, rays64, frames, sel, M, k, grp, grp_off, seg_idx, seg_off, init_h;
+    // GuessMotion's hypothesis search has run and left winners in init_h: the next motion launch finishes it
+    bool init_pending = false;
+    uint64_t init_seed = 0;
+    uint32_t init_stream = 0, init_stride = 0;
     uint32_t n_knots = 0, n_frames = 0, n_sel = 0, max_n = 0, n_grp = 1;
     uint64_t total_rays = 0;
     double fs = 0;
@@ -75,8 +79,10 @@ struct rship_ctx {
     DevBuf rccl_buf;
     std::vector<uint32_t> h_frame_n; // per table frame
     std::vector<uint32_t> h_sel;
-    std::vector<uint32_t> h_delays; // staging of upload_delays
+    std::vector<uint32_t> h_delays, h_delays64; // staging of upload_delays / upload_delays64
     const float* d_fd = nullptr;    // device address of the fd half of the last upload
+    DevBuf kd64;                    // kd[n] (int32) then fd[n] (double) for the fp64 kernels
+    const double* d_fd64 = nullptr;
     // scratch
     DevBuf kd, frame_cost, best_h, costs, part, flags, stats;
     void* pinned = nullptr;
@@ -200,27 +206,27 @@ int launch_lmeds(rship_ctx* c, const LmedsParams& p, int rpt, uint32_t grid) {
     return 0;
 }
 
-template <bool GRAD>
-int launch_loss(rship_ctx* c, const LossParams& p, int rpt) {
+template <bool GRAD, bool SIMPLE>
+int launch_loss64(rship_ctx* c, const Loss64Params& p, int rpt) {
     ProfScope ps(c, RSHIP_K_LOSS);
     switch (rpt) {
-        case 1: hipLaunchKernelGGL((loss_kernel<1, GRAD>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
-        case 2: hipLaunchKernelGGL((loss_kernel<2, GRAD>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
-        case 4: hipLaunchKernelGGL((loss_kernel<4, GRAD>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
-        case 8: hipLaunchKernelGGL((loss_kernel<8, GRAD>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        case 1: hipLaunchKernelGGL((loss64_kernel<1, GRAD, SIMPLE>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        case 2: hipLaunchKernelGGL((loss64_kernel<2, GRAD, SIMPLE>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        case 4: hipLaunchKernelGGL((loss64_kernel<4, GRAD, SIMPLE>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        case 8: hipLaunchKernelGGL((loss64_kernel<8, GRAD, SIMPLE>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
         default: return set_err(c, "loss: unsupported rows-per-thread");
     }
     RS_HIP(hipGetLastError());
     return 0;
 }
 
-int launch_motion(rship_ctx* c, const MotionParams& p, int rpt) {
+int launch_motion64(rship_ctx* c, const Motion64Params& p, int rpt) {
     ProfScope ps(c, RSHIP_K_MOTION);
     switch (rpt) {
-        case 1: hipLaunchKernelGGL((opt_motion_kernel<1>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
-        case 2: hipLaunchKernelGGL((opt_motion_kernel<2>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
-        case 4: hipLaunchKernelGGL((opt_motion_kernel<4>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
-        case 8: hipLaunchKernelGGL((opt_motion_kernel<8>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        case 1: hipLaunchKernelGGL((opt_motion64_kernel<1>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        case 2: hipLaunchKernelGGL((opt_motion64_kernel<2>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        case 4: hipLaunchKernelGGL((opt_motion64_kernel<4>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        case 8: hipLaunchKernelGGL((opt_motion64_kernel<8>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
         default: return set_err(c, "motion: unsupported rows-per-thread");
     }
     RS_HIP(hipGetLastError());
@@ -261,6 +267,22 @@ int upload_delays(rship_ctx* c, const int32_t* kd, const float* fd, size_t n) {
     RS_HIP(hipMemcpyAsync(c->kd.p, c->h_delays.data(), n * 8, hipMemcpyHostToDevice, c->stream));
     c->d_fd = (const float*)((const int32_t*)c->kd.p + n);
     return 0;
+}
+// the same for the fp64 kernels: kd[n] (int32), padded to 8 bytes, then fd[n] (double)
+int upload_delays64(rship_ctx* c, const int32_t* kd, const double* fd, size_t n) {
+    const size_t pad = (n + 1) / 2 * 2; // int32 slots before the doubles
+    if (ensure(c, c->kd64, pad * 4 + n * 8)) return 1;
+    c->h_delays64.resize(pad + 2 * n);
+    memcpy(c->h_delays64.data(), kd, n * 4);
+    memcpy(c->h_delays64.data() + pad, fd, n * 8);
+    RS_HIP(hipMemcpyAsync(c->kd64.p, c->h_delays64.data(), pad * 4 + n * 8, hipMemcpyHostToDevice, c->stream));
+    c->d_fd64 = (const double*)((const int32_t*)c->kd64.p + pad);
+    return 0;
+}
+Rays64 rays64_of(const rship_ctx* c) {
+    const double2* q0 = (const double2*)c->rays64.p;
+    const size_t tr = (size_t)c->total_rays;
+    return Rays64{q0, q0 + tr, q0 + 2 * tr, q0 + 3 * tr};
 }
 int check_ready(rship_ctx* c) {
     if (!c->n_knots) return set_err(c, "no gyro spline uploaded");
@@ -349,7 +371,7 @@ void rship_destroy(rship_ctx* c) {
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     DevBuf* bufs[] = {&c->coef, &c->coef64, &c->raw, &c->rays_a, &c->rays_b, &c->rays64, &c->frames, &c->sel, &c->M, &c->k, &c->grp, &c->grp_off,
-                      &c->seg_idx, &c->seg_off, &c->kd,
+                      &c->seg_idx, &c->seg_off, &c->kd, &c->kd64, &c->init_h,
                       &c->frame_cost, &c->best_h, &c->costs, &c->part, &c->flags, &c->stats};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -498,7 +520,8 @@ int rship_select_slots(rship_ctx* c, const uint32_t* idx, uint32_t n, const uint
     if (ensure(c, c->sel, (size_t)n * 4 + 4) || ensure(c, c->grp, (size_t)n * 4 + 4) ||
         ensure(c, c->grp_off, (size_t)(n_grp + 1) * 4))
         return 1;
-    if (ensure(c, c->M, (size_t)n * 24 + 24) || ensure(c, c->k, (size_t)n * 8 + 8)) return 1;
+    if (ensure(c, c->M, (size_t)n * 24 + 24) || ensure(c, c->k, (size_t)n * 8 + 8) || ensure(c, c->init_h, (size_t)n * 4 + 4)) return 1;
+    c->init_pending = false;
     std::vector<uint32_t> g(n, 0), off(n_grp + 1, 0);
     if (grp_off) {
         off.assign(grp_off, grp_off + n_grp + 1);
@@ -514,6 +537,7 @@ int rship_select_slots(rship_ctx* c, const uint32_t* idx, uint32_t n, const uint
     RS_HIP(hipMemcpyAsync(c->grp_off.p, off.data(), (size_t)(n_grp + 1) * 4, hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipMemsetAsync(c->M.p, 0, (size_t)n * 24 + 24, c->stream));
     RS_HIP(hipMemsetAsync(c->k.p, 0, (size_t)n * 8 + 8, c->stream));
+    RS_HIP(hipMemsetD32Async((hipDeviceptr_t)c->init_h.p, kInitNone, (size_t)n + 1, c->stream));
     RS_HIP(hipStreamSynchronize(c->stream));
     c->h_sel.assign(idx, idx + n);
     c->n_sel = n;
@@ -617,25 +641,31 @@ int rship_presync_window_costs(rship_ctx* c, const int32_t* kd, const float* fd,
 }
 
 namespace {
-// per-group delays -> device (kd/fd arrays of n entries)
-void fill_motion(rship_ctx* c, MotionParams& p) {
-    p.rays_a = (const f4*)c->rays_a.p;
-    p.rays_b = (const f4*)c->rays_b.p;
+void fill_motion(rship_ctx* c, Motion64Params& p) {
+    p.rays = rays64_of(c);
     p.frames = (const FrameRec*)c->frames.p;
     p.sel = (const uint32_t*)c->sel.p;
     p.n_sel = c->n_sel;
-    p.coef = (const f4*)c->coef.p;
+    p.coef = (const d4*)c->coef64.p;
     p.n_knots = (int)c->n_knots;
-    p.kd = (const int32_t*)c->kd.p;
-    p.fd = c->d_fd;
+    p.kd = (const int32_t*)c->kd64.p;
+    p.fd = c->d_fd64;
     p.grp = c->n_grp > 1 ? (const uint32_t*)c->grp.p : nullptr;
     p.M = (double*)c->M.p;
-    p.k = (const double*)c->k.p;
+    p.k = (double*)c->k.p;
     p.reeval = c->lbfgs_reeval;
+    p.max_iters = 200; // core_private.cpp:265
+    p.init_h = (int32_t*)c->init_h.p; // per slot: kInitNone unless GuessMotion's search has left a winner to finish
+    p.seed = c->init_seed;
+    p.stream_base = c->init_stream;
+    p.stream_stride = c->init_stride;
+    p.simple_k = 0;
 }
 } // namespace
 
-// kd/fd: one delay per group of the selection
+// FrameState::GuessMotion's hypothesis search (core_private.cpp:125-128 -> :34-59, 200 hypotheses) in the
+// fp32 tile kernel at one delay per group (kd/fd); the winners stay on the device and the next
+// rship_opt_motion / rship_finish_init turns them into M and k in fp64.  Asynchronous.
 int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_hyp, uint32_t stream,
                       uint32_t stream_stride, uint64_t seed) {
     DeviceGuard dev_guard(c);
@@ -661,26 +691,58 @@ int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t
     p.seed = seed;
     p.grp = c->n_grp > 1 ? (const uint32_t*)c->grp.p : nullptr;
     p.n_grp = c->n_grp;
-    p.M = (double*)c->M.p;
-    p.k = (double*)c->k.p;
+    p.best_h = (int32_t*)c->init_h.p;
     p.flags = (uint32_t*)c->flags.p;
     uint32_t groups = (c->n_sel + 7) / 8;
     if (launch_lmeds<1>(c, p, rpt_for(c->max_n), groups * 8)) return 1;
+    c->init_pending = true;
+    c->init_seed = seed;
+    c->init_stream = stream;
+    c->init_stride = stream_stride;
+    return 0;
+}
+
+// GuessMotion's winners -> M, and GuessK (core_private.cpp:130-133), in fp64, without optimising
+int rship_finish_init(rship_ctx* c, const int32_t* kd, const double* fd) {
+    DeviceGuard dev_guard(c);
+    if (check_ready(c)) return 1;
+    if (!c->init_pending) return 0;
+    if (upload_delays64(c, kd, fd, c->n_grp)) return 1;
+    Motion64Params p{};
+    fill_motion(c, p);
+    p.max_iters = 0;
+    if (launch_motion64(c, p, rpt_for(c->max_n))) return 1;
+    c->init_pending = false;
     return sync_stream(c);
 }
 
-int rship_opt_motion_detail(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t* per_frame, uint32_t cap) {
+// the no-translation variant's hyper-parameter: k = clamp(100 / sqrt(sum_j |P_j|^2), 10, 1000) per slot
+// (GuessK, core_private.cpp:130-133, with |h_j| in place of v.h_j: thesis section 2.11 eq. (12))
+int rship_init_k_simple(rship_ctx* c, const int32_t* kd, const double* fd) {
+    DeviceGuard dev_guard(c);
+    if (check_ready(c)) return 1;
+    if (upload_delays64(c, kd, fd, c->n_grp)) return 1;
+    Motion64Params p{};
+    fill_motion(c, p);
+    p.init_h = nullptr;
+    p.simple_k = 1;
+    if (launch_motion64(c, p, rpt_for(c->max_n))) return 1;
+    return sync_stream(c);
+}
+
+int rship_opt_motion_detail(rship_ctx* c, const int32_t* kd, const double* fd, uint32_t* per_frame, uint32_t cap) {
     DeviceGuard dev_guard(c);
     if (check_ready(c)) return 1;
     if (cap < c->n_sel) return set_err(c, "opt_motion_detail: output too small");
     TempBuf d;
     if (ensure(c, d, (size_t)c->n_sel * 8 + 8)) return 1;
     RS_HIP(hipMemsetAsync(d.p, 0, (size_t)c->n_sel * 8 + 8, c->stream));
-    if (upload_delays(c, kd, fd, c->n_grp)) return 1;
-    MotionParams p{};
+    if (upload_delays64(c, kd, fd, c->n_grp)) return 1;
+    Motion64Params p{};
     fill_motion(c, p);
     p.per_frame = (uint32_t*)d.p;
-    int rc = launch_motion(c, p, rpt_for(c->max_n));
+    int rc = launch_motion64(c, p, rpt_for(c->max_n));
+    c->init_pending = false;
     hipError_t e = hipStreamSynchronize(c->stream);
     prof_collect(c);
     if (!rc && e == hipSuccess) e = hipMemcpy(per_frame, d.p, (size_t)c->n_sel * 8, hipMemcpyDeviceToHost);
@@ -689,18 +751,19 @@ int rship_opt_motion_detail(rship_ctx* c, const int32_t* kd, const float* fd, ui
     return 0;
 }
 
-int rship_opt_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint64_t* stats) {
+int rship_opt_motion(rship_ctx* c, const int32_t* kd, const double* fd, uint64_t* stats) {
     DeviceGuard dev_guard(c);
     if (check_ready(c)) return 1;
     if (stats) {
         if (ensure(c, c->stats, 32)) return 1;
         RS_HIP(hipMemsetAsync(c->stats.p, 0, 32, c->stream));
     }
-    if (upload_delays(c, kd, fd, c->n_grp)) return 1;
-    MotionParams p{};
+    if (upload_delays64(c, kd, fd, c->n_grp)) return 1;
+    Motion64Params p{};
     fill_motion(c, p);
     p.stats = stats ? (unsigned long long*)c->stats.p : nullptr;
-    if (launch_motion(c, p, rpt_for(c->max_n))) return 1;
+    if (launch_motion64(c, p, rpt_for(c->max_n))) return 1;
+    c->init_pending = false;
     if (stats) {
         if (ensure_pinned(c, 32)) return 1;
         RS_HIP(hipMemcpyAsync(c->pinned, c->stats.p, 24, hipMemcpyDeviceToHost, c->stream));
@@ -712,24 +775,26 @@ int rship_opt_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint64_t*
 }
 
 // kd/fd: [n_delays][n_grp]; loss/grad out: [n_delays][n_grp]
-int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_delays, double* loss, double* grad) {
+int rship_loss(rship_ctx* c, const int32_t* kd, const double* fd, uint32_t n_delays, double* loss, double* grad,
+               uint32_t flags) {
     DeviceGuard dev_guard(c);
     if (check_ready(c)) return 1;
     if (!n_delays) return 0;
+    const bool simple = (flags & RSHIP_LOSS_SIMPLIFIED) != 0;
+    if (c->init_pending && !simple) return set_err(c, "loss: the motion initialisation has not been finished");
     const uint32_t ns = c->n_sel, ng = c->n_grp;
-    if (upload_delays(c, kd, fd, (size_t)n_delays * ng)) return 1;
+    if (upload_delays64(c, kd, fd, (size_t)n_delays * ng)) return 1;
     if (ensure(c, c->part, (size_t)n_delays * ns * 16)) return 1;
-    LossParams p{};
-    p.rays_a = (const f4*)c->rays_a.p;
-    p.rays_b = (const f4*)c->rays_b.p;
+    Loss64Params p{};
+    p.rays = rays64_of(c);
     p.frames = (const FrameRec*)c->frames.p;
     p.sel = (const uint32_t*)c->sel.p;
     p.n_sel = ns;
-    p.coef = (const f4*)c->coef.p;
+    p.coef = (const d4*)c->coef64.p;
     p.n_knots = (int)c->n_knots;
-    p.fs = (float)c->fs;
-    p.kd = (const int32_t*)c->kd.p;
-    p.fd = c->d_fd;
+    p.fs = c->fs;
+    p.kd = (const int32_t*)c->kd64.p;
+    p.fd = c->d_fd64;
     p.n_delays = n_delays;
     p.grp = ng > 1 ? (const uint32_t*)c->grp.p : nullptr;
     p.n_grp = ng;
@@ -738,7 +803,10 @@ int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_dela
     p.part_loss = (double*)c->part.p;
     p.part_grad = p.part_loss + (size_t)n_delays * ns;
     const int rpt = rpt_for(c->max_n);
-    if (grad ? launch_loss<true>(c, p, rpt) : launch_loss<false>(c, p, rpt)) return 1;
+    int rc;
+    if (simple) rc = grad ? launch_loss64<true, true>(c, p, rpt) : launch_loss64<false, true>(c, p, rpt);
+    else rc = grad ? launch_loss64<true, false>(c, p, rpt) : launch_loss64<false, false>(c, p, rpt);
+    if (rc) return 1;
     // rows [0, n_delays) = loss, [n_delays, 2 n_delays) = grad; one sum per (row, group)
     uint32_t rows = grad ? 2 * n_delays : n_delays;
     // the few sums go straight into pinned host memory (visible once the stream has drained):
@@ -859,6 +927,35 @@ int rship_debug_problem(rship_ctx* c, uint32_t sel_index, int32_t kd, float fd, 
     if (e == hipSuccess) e = hipMemcpy(P, out.p, (size_t)n * 12, hipMemcpyDeviceToHost);
     if (e == hipSuccess && dP) e = hipMemcpy(dP, (float*)out.p + (size_t)n * 3, (size_t)n * 12, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return set_err(c, "debug_problem", e);
+    return 0;
+}
+
+int rship_debug_problem64(rship_ctx* c, uint32_t sel_index, int32_t kd, double fd, double* P, double* dP, uint32_t cap_rows) {
+    DeviceGuard dev_guard(c);
+    if (check_ready(c)) return 1;
+    if (sel_index >= c->n_sel) return set_err(c, "debug_problem: index out of range");
+    uint32_t fi = c->h_sel[sel_index];
+    uint32_t n = c->h_frame_n[fi];
+    if (n > cap_rows) return set_err(c, "debug_problem: output too small");
+    TempBuf out;
+    if (ensure(c, out, (size_t)n * 48 + 64)) return 1;
+    Debug64Params p{};
+    p.rays = rays64_of(c);
+    p.frames = (const FrameRec*)c->frames.p;
+    p.fi = fi;
+    p.coef = (const d4*)c->coef64.p;
+    p.n_knots = (int)c->n_knots;
+    p.fs = c->fs;
+    p.kd = kd;
+    p.fd = fd;
+    p.P = (double*)out.p;
+    p.dP = dP ? (double*)out.p + (size_t)n * 3 : nullptr;
+    hipLaunchKernelGGL(debug_problem64_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(P, out.p, (size_t)n * 24, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && dP) e = hipMemcpy(dP, (double*)out.p + (size_t)n * 3, (size_t)n * 24, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return set_err(c, "debug_problem64", e);
     return 0;
 }
 

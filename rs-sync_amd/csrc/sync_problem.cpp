@@ -82,6 +82,21 @@ DelaySplit split_delay(double delay, double fs) {
     return {(int32_t)fl, fd};
 }
 
+// the same split for the fp64 kernels: the fraction keeps full precision (D - floor(D) is exact)
+struct DelaySplit64 {
+    int32_t kd;
+    double fd;
+};
+
+DelaySplit64 split_delay64(double delay, double fs) {
+    double D = delay * fs;
+    if (!std::isfinite(D)) return {0, 0.0};
+    double fl = std::floor(D);
+    if (fl > (double)kKnotClamp) return {kKnotClamp, 0.0};
+    if (fl < -(double)kKnotClamp) return {-kKnotClamp, 0.0};
+    return {(int32_t)fl, D - fl};
+}
+
 // quat.cpp:55-74 (only used by the timestamped gyro setter)
 void quat_slerp(const double* p, const double* q_in, double t, double* out) {
     double q[4] = {q_in[0], q_in[1], q_in[2], q_in[3]};
@@ -204,11 +219,15 @@ class SyncProblemHip final : public ISyncProblem {
                               double* frame_costs, int32_t* best_h);
     void init_motion(const std::vector<double>& delays, uint32_t call_stride = 1);
     void opt_motion(const std::vector<double>& delays, uint64_t* stats);
-    void loss(const std::vector<double>& delays, std::vector<double>& out_loss, std::vector<double>* out_grad);
+    void finish_init(const std::vector<double>& delays);
+    void init_k_simple(const std::vector<double>& delays);
+    void loss(const std::vector<double>& delays, std::vector<double>& out_loss, std::vector<double>* out_grad,
+              bool simplified = false);
     void select_windows(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl);
     void sync_windows(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl,
                       const std::vector<double>& initial, double search_center, double search_radius,
-                      std::vector<double>& costs, std::vector<double>& delays_out, uint32_t call_stride = 1);
+                      std::vector<double>& costs, std::vector<double>& delays_out, uint32_t call_stride = 1,
+                      bool simplified = false);
     void sync_points(const std::vector<int64_t>& positions, int64_t window, double initial_delay, bool use_presync,
                      double presync_step, double presync_radius, int repeats, std::vector<double>& costs,
                      std::vector<double>& delays_out);
@@ -725,6 +744,21 @@ void SyncProblemHip::DebugPreSync(double initial_delay, int64_t frame_begin, int
     }
 }
 
+static void split_all64(const std::vector<double>& delays, double fs, std::vector<int32_t>& kd, std::vector<double>& fd) {
+    kd.resize(delays.size());
+    fd.resize(delays.size());
+    for (size_t i = 0; i < delays.size(); ++i) {
+        if (delays[i] != delays[i]) {
+            kd[i] = 0;
+            fd[i] = std::numeric_limits<double>::quiet_NaN();
+        } else {
+            DelaySplit64 s = split_delay64(delays[i], fs);
+            kd[i] = s.kd;
+            fd[i] = s.fd;
+        }
+    }
+}
+
 // per-window delays -> device representation; NaN delay = window switched off
 static void split_all(const std::vector<double>& delays, double fs, std::vector<int32_t>& kd, std::vector<float>& fd) {
     kd.resize(delays.size());
@@ -754,23 +788,40 @@ void SyncProblemHip::init_motion(const std::vector<double>& delays, uint32_t cal
 void SyncProblemHip::opt_motion(const std::vector<double>& delays, uint64_t* stats) {
     if (sel_.empty()) return;
     std::vector<int32_t> kd;
-    std::vector<float> fd;
-    split_all(delays, fs_, kd, fd);
+    std::vector<double> fd;
+    split_all64(delays, fs_, kd, fd);
     hip_check(rship_opt_motion(dev_, kd.data(), fd.data(), stats), "opt motion");
+}
+
+// M and k of GuessMotion/GuessK in fp64 from the winners of init_motion (same delays), without optimising
+void SyncProblemHip::finish_init(const std::vector<double>& delays) {
+    if (sel_.empty()) return;
+    std::vector<int32_t> kd;
+    std::vector<double> fd;
+    split_all64(delays, fs_, kd, fd);
+    hip_check(rship_finish_init(dev_, kd.data(), fd.data()), "finish init");
+}
+
+void SyncProblemHip::init_k_simple(const std::vector<double>& delays) {
+    if (sel_.empty()) return;
+    std::vector<int32_t> kd;
+    std::vector<double> fd;
+    split_all64(delays, fs_, kd, fd);
+    hip_check(rship_init_k_simple(dev_, kd.data(), fd.data()), "init k (simplified)");
 }
 
 // per window: sum over its slots (and over ranks) of FrameState::Loss; delays is
 // [n_delays][n_windows] row-major (NaN = skip that window), outputs likewise
 void SyncProblemHip::loss(const std::vector<double>& delays, std::vector<double>& out_loss,
-                          std::vector<double>* out_grad) {
+                          std::vector<double>* out_grad, bool simplified) {
     const size_t n = delays.size();
     std::vector<double> buf(2 * n, 0.0);
     if (!sel_.empty() && n) {
         std::vector<int32_t> kd;
-        std::vector<float> fd;
-        split_all(delays, fs_, kd, fd);
+        std::vector<double> fd;
+        split_all64(delays, fs_, kd, fd);
         hip_check(rship_loss(dev_, kd.data(), fd.data(), (uint32_t)(n / n_windows_), buf.data(),
-                             out_grad ? buf.data() + n : nullptr),
+                             out_grad ? buf.data() + n : nullptr, simplified ? RSHIP_LOSS_SIMPLIFIED : 0u),
                   "loss");
     }
     reduce(buf.data(), out_grad ? 2 * n : n);
@@ -804,13 +855,14 @@ void SyncProblemHip::select_windows(const std::vector<int64_t>& begins, const st
 // would compute differently:
 //  * d(loss)/d(delay) is the analytic derivative, not the +-1e-6 s central difference
 //    (:96-97,112); they agree to ~1e-9 relative (tests/test_oracle_math.py);
-//  * the <= 10 backtracking trials (backtrack.cpp:7-11) are evaluated in one batched
-//    launch and the first that satisfies the Armijo test is taken, which is what the
+//  * the <= 10 backtracking trials (backtrack.cpp:7-11) are evaluated in batched launches of
+//    five and the first that satisfies the Armijo test is taken, which is what the
 //    sequential loop returns;
 //  * P is computed once per motion optimisation, not three times per evaluation (:94-97).
 void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl,
                                   const std::vector<double>& initial, double search_center, double search_radius,
-                                  std::vector<double>& costs, std::vector<double>& delays_out, uint32_t call_stride) {
+                                  std::vector<double>& costs, std::vector<double>& delays_out, uint32_t call_stride,
+                                  bool simplified) {
     ensure_device();
     const size_t W = begins.size();
     select_windows(begins, ends_incl);
@@ -818,49 +870,69 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
     // :218-223; window w samples with stream SYNC_INIT + sync_calls + w * call_stride.  With
     // stride 1 the call consumes W consecutive call numbers; sync_points() interleaves
     // several batched calls and advances the counter itself.
-    init_motion(d, call_stride);
-    if (call_stride == 1) sync_calls += (uint32_t)W;
+    if (simplified) {
+        init_k_simple(d); // no v_i to guess or optimise (thesis section 2.11): only the hyper-parameter
+    } else {
+        init_motion(d, call_stride);
+        if (call_stride == 1) sync_calls += (uint32_t)W;
+    }
     traces.assign(W, {});
 
     const double c_armijo = 2e-4, decay = .1, t0 = 1e-3; // :226
-    const int max_bt = 10;
+    const int max_bt = 10, half_bt = 5;
     const double delay_b = .3; // :260
     const double kOff = std::numeric_limits<double>::quiet_NaN();
     std::vector<double> delay_v(W, 0.0); // :261
     std::vector<int> converge_counter(W, 0);
     std::vector<char> active(W, 1);
     costs.assign(W, 0.0);
-    std::vector<double> l1, g1, lt, cur(W), x0(W), trial((size_t)max_bt * W), fin(W);
+    std::vector<double> l1, g1, lt, lt2, cur(W), x0(W), trial((size_t)half_bt * W);
+    double ts[16];
+    {
+        double t = t0;
+        for (int i = 0; i < max_bt; ++i) { ts[i] = t; t *= decay; }
+        ts[max_bt] = t;
+    }
     size_t n_active = W;
     for (int it = 0; it < max_outer && n_active; ++it) { // :309
         for (size_t w = 0; w < W; ++w) cur[w] = active[w] ? d[w] : kOff;
-        opt_motion(cur, nullptr); // :311
+        if (!simplified) opt_motion(cur, nullptr); // :311
         // do_opt_delay (:298-305) -> Backtrack::Step (backtrack.cpp:3-13)
         for (size_t w = 0; w < W; ++w) x0[w] = active[w] ? d[w] - delay_b * delay_v[w] : kOff;
-        loss(x0, l1, &g1);
-        double ts[16];
-        {
-            double t = t0;
-            for (int i = 0; i < max_bt; ++i) { ts[i] = t; t *= decay; }
-            ts[max_bt] = t;
-        }
-        for (int i = 0; i < max_bt; ++i)
-            for (size_t w = 0; w < W; ++w) trial[(size_t)i * W + w] = active[w] ? x0[w] - ts[i] * g1[w] : kOff;
-        loss(trial, lt, nullptr);
-        bool any_finished = false;
-        for (size_t w = 0; w < W; ++w) {
-            fin[w] = kOff;
-            if (!active[w]) continue;
-            const double v = l1[w], p = g1[w], m = p * p;
-            double t = ts[max_bt]; // never satisfied: t0 * decay^max_bt, untested (backtrack.cpp:11-12)
-            int trials = max_bt;
-            for (int i = 0; i < max_bt; ++i) {
-                if (v - lt[(size_t)i * W + w] >= ts[i] * c_armijo * m) {
-                    t = ts[i];
-                    trials = i + 1;
-                    break;
+        loss(x0, l1, &g1, simplified);
+        // The <= 10 backtracking trials (backtrack.cpp:7-11) are evaluated five at a time in one
+        // batched launch; the first that satisfies the Armijo test is taken, which is what the
+        // sequential loop returns.  The second five are only evaluated for windows whose first five
+        // all failed (steps of 1e-3 .. 1e-7 times the gradient: rare).
+        std::vector<int> hit(W, -1); // index of the first successful trial
+        for (int half = 0; half < 2; ++half) {
+            bool need = false;
+            for (size_t w = 0; w < W; ++w) {
+                const bool want = active[w] && hit[w] < 0;
+                need = need || want;
+                for (int i = 0; i < half_bt; ++i)
+                    trial[(size_t)i * W + w] = want ? x0[w] - ts[half * half_bt + i] * g1[w] : kOff;
+            }
+            if (!need) break;
+            loss(trial, lt, nullptr, simplified);
+            for (size_t w = 0; w < W; ++w) {
+                if (!active[w] || hit[w] >= 0) continue;
+                const double m = g1[w] * g1[w];
+                for (int i = 0; i < half_bt; ++i) {
+                    const int gi = half * half_bt + i;
+                    if (l1[w] - lt[(size_t)i * W + w] >= ts[gi] * c_armijo * m) {
+                        hit[w] = gi;
+                        break;
+                    }
                 }
             }
+        }
+        for (size_t w = 0; w < W; ++w) {
+            if (!active[w]) continue;
+            const double v = l1[w], p = g1[w];
+            // never satisfied: t0 * decay^max_bt, untested (backtrack.cpp:11-12)
+            const double t = hit[w] >= 0 ? ts[hit[w]] : ts[max_bt];
+            const int trials = hit[w] >= 0 ? hit[w] + 1 : max_bt;
             const double step = -t * p;
             delay_v[w] = delay_b * delay_v[w] + step; // :301
             d[w] += delay_v[w];                       // :302
@@ -874,20 +946,15 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
             if (stop || it + 1 == max_outer) {
                 active[w] = 0;
                 --n_active;
-                fin[w] = d[w];
-                any_finished = true;
             }
         }
-        if (any_finished) { // :333 for the windows that just left their loop
-            loss(fin, l1, nullptr);
-            for (size_t w = 0; w < W; ++w)
-                if (fin[w] == fin[w]) costs[w] = l1[w];
-        }
     }
-    if (max_outer <= 0) { // no iteration at all: the reference still returns the loss at the start
-        loss(d, l1, nullptr);
-        costs = l1;
-    }
+    // :333, the loss at the returned delay.  A window's motion estimates are frozen once it has left
+    // its loop (the motion launch skips it), so one evaluation after the last window has finished gives
+    // every window the value it would have got at the moment it stopped.
+    if (!simplified && max_outer <= 0) finish_init(d); // no iteration at all: GuessMotion/GuessK only
+    loss(d, l1, nullptr, simplified);
+    costs = l1;
     delays_out = d;
 }
 
@@ -1191,6 +1258,7 @@ int rssync_ext_init_motion(rssync_problem* p, double delay, int64_t frame_begin,
         s->ensure_device();
         s->select(frame_begin, frame_end == std::numeric_limits<int64_t>::max() ? frame_end : frame_end + 1);
         s->init_motion({delay});
+        s->finish_init({delay});
         s->sync_calls++;
         uint32_t n = 0;
         if (rship_get_motion(s->dev(), M, k, (uint32_t)cap, &n)) panic(std::string("hip: get motion: ") + rship_last_error(s->dev()));
@@ -1256,6 +1324,56 @@ int rssync_ext_sync_windows(rssync_problem* p, const double* initial_delays, con
         p->impl->trace = p->impl->traces[0];
         std::copy(c.begin(), c.end(), costs);
         std::copy(d.begin(), d.end(), delays);
+    });
+}
+
+// Sync without translation (thesis section 2.11 eq. (12)): loss sum_j log1p((k |P_j|)^2), k per frame from
+// GuessK with |P_j| in place of P_j . v, no motion estimate, otherwise core_private.cpp:211-334.
+int rssync_ext_sync_simplified(rssync_problem* p, double initial_delay, int64_t frame_begin, int64_t frame_end,
+                               double search_center, double search_radius, double* cost, double* delay) {
+    return guarded([&] {
+        std::vector<double> c, d;
+        p->impl->sync_windows({frame_begin}, {frame_end}, {initial_delay}, search_center, search_radius, c, d, 1, true);
+        p->impl->trace = p->impl->traces[0];
+        *cost = c[0];
+        *delay = d[0];
+    });
+}
+
+int rssync_ext_init_k_simplified(rssync_problem* p, double delay, int64_t frame_begin, int64_t frame_end, double* k,
+                                 int cap, int* n_frames) {
+    return guarded([&] {
+        SyncProblemHip* s = p->impl;
+        s->ensure_device();
+        s->select(frame_begin, frame_end == std::numeric_limits<int64_t>::max() ? frame_end : frame_end + 1);
+        s->init_k_simple({delay});
+        std::vector<double> M((size_t)std::max(cap, 0) * 3);
+        uint32_t n = 0;
+        if (rship_get_motion(s->dev(), M.data(), k, (uint32_t)cap, &n)) panic(std::string("hip: get motion: ") + rship_last_error(s->dev()));
+        if (n_frames) *n_frames = (int)n;
+    });
+}
+
+int rssync_ext_loss_simplified(rssync_problem* p, const double* delays, int n, double* loss, double* grad) {
+    return guarded([&] {
+        std::vector<double> d(delays, delays + n), l, g;
+        p->impl->loss(d, l, grad ? &g : nullptr, true);
+        std::copy(l.begin(), l.end(), loss);
+        if (grad) std::copy(g.begin(), g.end(), grad);
+    });
+}
+
+int rssync_ext_problem_matrix64(rssync_problem* p, int64_t frame, double delay, double* P, double* dP, size_t cap_rows,
+                                size_t* n_rows) {
+    return guarded([&] {
+        SyncProblemHip* s = p->impl;
+        s->ensure_device();
+        if (!s->has_frame(frame)) panic("problem_matrix: unknown frame");
+        s->select(frame, frame + 1);
+        DelaySplit64 ds = split_delay64(delay, s->sample_rate());
+        if (rship_debug_problem64(s->dev(), 0, ds.kd, ds.fd, P, dP, (uint32_t)cap_rows))
+            panic(std::string("hip: debug problem: ") + rship_last_error(s->dev()));
+        if (n_rows) *n_rows = s->frame_tracks(frame);
     });
 }
 

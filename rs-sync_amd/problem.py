@@ -64,6 +64,12 @@ SIGNATURES = {
     "rssync_ext_opt_motion": (C.c_int, [C.c_void_p, C.c_double, _PD, _PD, C.c_int, C.POINTER(C.c_int), _PU64, _PU64]),
     "rssync_ext_set_motion": (C.c_int, [C.c_void_p, _PD, _PD, C.c_int]),
     "rssync_ext_loss": (C.c_int, [C.c_void_p, _PD, C.c_int, _PD, _PD]),
+    "rssync_ext_sync_simplified": (C.c_int, [C.c_void_p, C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_double, _PD, _PD]),
+    "rssync_ext_init_k_simplified": (C.c_int, [C.c_void_p, C.c_double, C.c_int64, C.c_int64, _PD, C.c_int,
+                                               C.POINTER(C.c_int)]),
+    "rssync_ext_loss_simplified": (C.c_int, [C.c_void_p, _PD, C.c_int, _PD, _PD]),
+    "rssync_ext_problem_matrix64": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, _PD, _PD, C.c_size_t,
+                                              C.POINTER(C.c_size_t)]),
     "rssync_ext_set_track_pixels": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, _PD, _PD, C.c_size_t,
                                               C.c_void_p, C.c_double]),
     "rssync_ext_set_gyro_rates": (C.c_int, [C.c_void_p, _PD, _PD, C.c_size_t, C.c_char_p]),
@@ -297,6 +303,34 @@ class SyncProblem:
         self._check(self._lib.rssync_ext_problem_matrix(self._h, int(frame), float(delay), _p(P, _PF),
                                                         _p(dP, _PF) if deriv else None, n_tracks, C.byref(n)))
         return (P[:n.value], dP[:n.value]) if deriv else P[:n.value]
+
+    def problem_matrix64(self, frame, delay, n_tracks, deriv=False):
+        """P (and dP/d-delay) as the Sync kernels compute it, fp64"""
+        P = np.zeros((n_tracks, 3))
+        dP = np.zeros((n_tracks, 3)) if deriv else None
+        n = C.c_size_t()
+        self._check(self._lib.rssync_ext_problem_matrix64(self._h, int(frame), float(delay), _p(P),
+                                                          _p(dP) if deriv else None, n_tracks, C.byref(n)))
+        return (P[:n.value], dP[:n.value]) if deriv else P[:n.value]
+
+    def SyncSimplified(self, initial_delay, frame_begin, frame_end, search_center, search_radius):
+        """Sync with translation neglected (thesis section 2.11 eq. (12)) -> (cost, delay); frame_end inclusive."""
+        c, d = C.c_double(), C.c_double()
+        self._check(self._lib.rssync_ext_sync_simplified(self._h, initial_delay, frame_begin, frame_end, search_center,
+                                                         search_radius, C.byref(c), C.byref(d)))
+        return c.value, d.value
+
+    def init_k_simplified(self, delay, frame_begin, frame_end, cap=1 << 16):
+        k, n = np.zeros(cap), C.c_int()
+        self._check(self._lib.rssync_ext_init_k_simplified(self._h, delay, frame_begin, frame_end, _p(k), cap, C.byref(n)))
+        return k[:n.value].copy()
+
+    def loss_simplified(self, delays, grad=False):
+        d = _d(np.atleast_1d(delays))
+        out = np.zeros(d.shape[0])
+        g = np.zeros(d.shape[0]) if grad else None
+        self._check(self._lib.rssync_ext_loss_simplified(self._h, _p(d), d.shape[0], _p(out), _p(g) if grad else None))
+        return (out, g) if grad else out
 
     def init_motion(self, delay, frame_begin, frame_end, cap=1 << 16):
         M, k, n = np.zeros((cap, 3)), np.zeros(cap), C.c_int()

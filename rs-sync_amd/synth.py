@@ -108,11 +108,12 @@ def make_gyro(t_begin, t_end, fs=400.0, seed=0, margin=1.0):
 
 
 def make_frames(gyro, frame_begin, frame_end, n_tracks, seed=0, d_true=D_TRUE, noise=1e-3, outliers=0.10,
-                chunk=256, drift=0.0):
+                chunk=256, drift=0.0, translation=0.05):
     """Yield (frame, ts_a, ts_b, rays_a, rays_b) for frames [frame_begin, frame_end).
 
     `drift` (seconds of delay per second of video) makes the true delay `d_true + drift * t`:
     the clock-drift scenario the reference's CSV + python/plot_sync.py evaluate.
+    `translation` is the camera's displacement per frame in metres (scene depth 2-50 m).
 
     Every frame draws from its own generator keyed on (seed, frame), so a shard of the range
     (one rank of a multi-GPU run) sees exactly the frames the whole range would contain."""
@@ -140,7 +141,7 @@ def make_frames(gyro, frame_begin, frame_end, n_tracks, seed=0, d_true=D_TRUE, n
         # slowly varying translation direction, 0.05 m per frame
         ang = 0.002 * frames + 0.7 * seed
         tdir = np.stack([np.cos(ang), np.sin(ang) * np.cos(0.3 * ang), np.sin(ang) * np.sin(0.3 * ang)], axis=-1)
-        trans = 0.05 * tdir[:, None, :]
+        trans = translation * tdir[:, None, :]  # metres per frame; 0 = pure rotation (the thesis' simplified mode)
         qa = gyro.orientation(ts_a + d_true + drift * ts_a)
         qb = gyro.orientation(ts_b + d_true + drift * ts_b)
         a_world = rotate_inv(qa, a_cam)

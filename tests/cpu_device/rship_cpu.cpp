@@ -19,8 +19,12 @@
 #include <string>
 #include <vector>
 
+using rs::d3;
+using rs::d4;
 using rs::f3;
 using rs::f4;
+
+static const int32_t kNone = (int32_t)0x80000000;
 
 struct rship_ctx {
     std::string err;
@@ -34,6 +38,9 @@ struct rship_ctx {
     std::vector<uint32_t> sel, grp, grp_off; // slots, slot -> window, window offsets
     std::vector<double> M, k;                // per slot
     int lbfgs_reeval = 0;
+    std::vector<int32_t> init_h; // per slot: winning hypothesis of a pending GuessMotion, or kNone
+    uint64_t init_seed = 0;
+    uint32_t init_stream = 0, init_stride = 0;
 };
 
 namespace {
@@ -51,6 +58,25 @@ void row(const rship_ctx* c, const rship_frame& fr, uint32_t i, int32_t kd, floa
         const f4* p = &c->coef[(size_t)kn.ci * 4];
         if (dP) rs::rotate_ray<true>(p[0], p[1], p[2], p[3], kn, f3{rays[s].x, rays[s].y, rays[s].z}, r[s], dr[s]);
         else rs::rotate_ray<false>(p[0], p[1], p[2], p[3], kn, f3{rays[s].x, rays[s].y, rays[s].z}, r[s], dr[s]);
+    }
+    P = rs::cross(r[0], r[1]);
+    if (dP) *dP = rs::add(rs::cross(dr[0], r[1]), rs::cross(r[0], dr[1]));
+}
+
+// one row of P in fp64 from the fp64 streams and the fp64 spline table (kernels/sync64.hpp: residual_row64)
+void row64(const rship_ctx* c, const rship_frame& fr, uint32_t i, int32_t kd, double fd, d3& P, d3* dP) {
+    const int n = (int)(c->coef64.size() / 16);
+    const size_t o = (size_t)fr.ray_offset + i;
+    const d3 ra{c->q[0][2 * o], c->q[1][2 * o], c->q[2][2 * o]}, rb{c->q[0][2 * o + 1], c->q[1][2 * o + 1], c->q[2][2 * o + 1]};
+    const double t[2] = {c->q[3][2 * o], c->q[3][2 * o + 1]};
+    const d3 rays[2] = {ra, rb};
+    d3 r[2], dr[2];
+    for (int s = 0; s < 2; ++s) {
+        rs::KnotT<double> kn = rs::spline_locate(t[s], fr.base_knot + kd, fd, n);
+        const double* p = &c->coef64[(size_t)kn.ci * 16];
+        const d4 y{p[0], p[1], p[2], p[3]}, b{p[4], p[5], p[6], p[7]}, cc{p[8], p[9], p[10], p[11]}, d{p[12], p[13], p[14], p[15]};
+        if (dP) rs::rotate_ray<true>(y, b, cc, d, kn, rays[s], r[s], dr[s]);
+        else rs::rotate_ray<false>(y, b, cc, d, kn, rays[s], r[s], dr[s]);
     }
     P = rs::cross(r[0], r[1]);
     if (dP) *dP = rs::add(rs::cross(dr[0], r[1]), rs::cross(r[0], dr[1]));
@@ -217,6 +243,7 @@ int rship_select_slots(rship_ctx* c, const uint32_t* idx, uint32_t n, const uint
     }
     c->M.assign((size_t)n * 3, 0.0);
     c->k.assign(n, 0.0);
+    c->init_h.assign(n, kNone);
     return 0;
 }
 int rship_select_frames(rship_ctx* c, const uint32_t* idx, uint32_t n) { return rship_select_slots(c, idx, n, nullptr, 1); }
@@ -281,42 +308,68 @@ int rship_presync_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32
 
 int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_hyp, uint32_t stream,
                       uint32_t stream_stride, uint64_t seed) {
+    c->init_h.assign(c->sel.size(), kNone);
     for (size_t s = 0; s < c->sel.size(); ++s) {
         const uint32_t fi = c->sel[s], g = c->grp[s];
         const rship_frame& fr = c->frames[fi];
         Rows t = unit_rows(c, fr, kd[g], fd[g]);
         f3 Mv;
-        lmeds(t, n_hyp, seed, fr.id, stream + g * stream_stride, Mv);
-        double ss = 0;
-        for (uint32_t i = 0; i < fr.n_rays; ++i) {
-            float pm = t.nrm[i] * rs::dot(t.n[i], Mv);
-            ss += (double)pm * pm;
-        }
-        c->M[3 * s] = Mv.x; c->M[3 * s + 1] = Mv.y; c->M[3 * s + 2] = Mv.z;
-        c->k[s] = clampk(100.0f / std::sqrt((float)ss));
+        c->init_h[s] = lmeds(t, n_hyp, seed, fr.id, stream + g * stream_stride, Mv);
     }
+    c->init_seed = seed;
+    c->init_stream = stream;
+    c->init_stride = stream_stride;
     return 0;
 }
 
-// the kernel's L-BFGS (kernels/motion.hpp: opt_motion_kernel), sequential
-int rship_opt_motion(rship_ctx* c, const int32_t* kdv, const float* fdv, uint64_t* stats) {
+namespace {
+double clampk64(double k) { return (k < 10.0) ? 10.0 : ((1000.0 < k) ? 1000.0 : k); }
+
+// opt_motion64_kernel's prologue: GuessMotion's winner -> M in fp64, GuessK; returns the fp64 rows
+void finish_slot(rship_ctx* c, size_t sl, int32_t kd, double fd, bool simple_k, std::vector<d3>& P) {
+    const uint32_t fi = c->sel[sl], grp = c->grp[sl];
+    const rship_frame& fr = c->frames[fi];
+    P.resize(fr.n_rays);
+    for (uint32_t i = 0; i < fr.n_rays; ++i) row64(c, fr, i, kd, fd, P[i], nullptr);
+    const int32_t pend = sl < c->init_h.size() ? c->init_h[sl] : kNone;
+    if (!simple_k && pend == kNone) return;
+    d3 Mv{0, 0, 0};
+    if (!simple_k && pend >= 0) {
+        uint32_t i0, i1;
+        rs::sample_pair(c->init_seed, fr.id, c->init_stream + grp * c->init_stride, (uint32_t)pend, fr.n_rays, i0, i1);
+        Mv = rs::cross(P[i0], P[i1]);
+        const double nn = std::sqrt(rs::dot(Mv, Mv));
+        if (!(nn < 1e-12)) Mv = rs::scale(Mv, 1.0 / nn);
+    }
+    double ss = 0;
+    for (const d3& p : P) {
+        const double pm = simple_k ? std::sqrt(rs::dot(p, p)) : rs::dot(p, Mv);
+        ss += pm * pm;
+    }
+    if (!simple_k) { c->M[3 * sl] = Mv.x; c->M[3 * sl + 1] = Mv.y; c->M[3 * sl + 2] = Mv.z; }
+    c->k[sl] = clampk64(100.0 / std::sqrt(ss));
+    if (sl < c->init_h.size()) c->init_h[sl] = kNone;
+}
+
+// the kernel's L-BFGS (kernels/sync64.hpp: opt_motion64_kernel), sequential
+void motion_pass(rship_ctx* c, const int32_t* kdv, const double* fdv, int max_iters, bool simple_k, uint64_t* stats) {
     uint64_t tot_it = 0, tot_ev = 0, tot_bnl = 0;
     for (size_t sl = 0; sl < c->sel.size(); ++sl) {
-        const uint32_t fi = c->sel[sl], grp = c->grp[sl];
+        const uint32_t grp = c->grp[sl];
         const int32_t kd = kdv[grp];
-        const float fd = fdv[grp];
+        const double fd = fdv[grp];
         if (fd != fd) continue; // window switched off
-        const rship_frame& fr = c->frames[fi];
-        std::vector<f3> P(fr.n_rays);
-        for (uint32_t i = 0; i < fr.n_rays; ++i) row(c, fr, i, kd, fd, P[i], nullptr);
+        std::vector<d3> P;
+        finish_slot(c, sl, kd, fd, simple_k, P);
+        if (max_iters <= 0 || simple_k) continue;
         const double k2 = c->k[sl] * c->k[sl];
         int evals = 0;
-        auto ev = [&](const double x[3], double g[3]) { // fp64 on fp32 rows, like the kernel
+        auto ev = [&](const double x[3], double g[3]) {
             ++evals;
             const double s = (x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) / k2;
             const double inv_s = 1.0 / s;
             double L = 0, a0 = 0, a1 = 0, a2 = 0, gs = 0;
-            for (const f3& p : P) {
+            for (const d3& p : P) {
                 const double px = p.x, py = p.y, pz = p.z;
                 const double pm = px * x[0] + py * x[1] + pz * x[2], v2 = pm * pm, u = v2 * inv_s;
                 double w; // 1 / (1 + u), from the kernel's own fp64 routine
@@ -335,7 +388,7 @@ int rship_opt_motion(rship_ctx* c, const int32_t* kdv, const float* fdv, uint64_
         double x[3] = {c->M[3 * sl], c->M[3 * sl + 1], c->M[3 * sl + 2]}, g[3], oldx[3], oldg[3], dir[3];
         double fval = ev(x, g);
         int it = 0;
-        for (; it != 200; ++it) {
+        for (; it != max_iters; ++it) {
             const double prev = fval;
             if (std::sqrt(dot3(g, g)) < 1e-4 || fval != fval) break;
             double scale;
@@ -400,33 +453,54 @@ int rship_opt_motion(rship_ctx* c, const int32_t* kdv, const float* fdv, uint64_
         tot_ev += (uint64_t)evals;
     }
     if (stats) { stats[0] = tot_it; stats[1] = tot_ev; stats[2] = tot_bnl; }
+}
+} // namespace
+
+int rship_opt_motion(rship_ctx* c, const int32_t* kd, const double* fd, uint64_t* stats) {
+    motion_pass(c, kd, fd, 200, false, stats);
+    return 0;
+}
+int rship_finish_init(rship_ctx* c, const int32_t* kd, const double* fd) {
+    motion_pass(c, kd, fd, 0, false, nullptr);
+    return 0;
+}
+int rship_init_k_simple(rship_ctx* c, const int32_t* kd, const double* fd) {
+    motion_pass(c, kd, fd, 0, true, nullptr);
     return 0;
 }
 
-int rship_opt_motion_detail(rship_ctx* c, const int32_t*, const float*, uint32_t*, uint32_t) { return fail(c, "opt_motion_detail: device only"); }
+int rship_opt_motion_detail(rship_ctx* c, const int32_t*, const double*, uint32_t*, uint32_t) { return fail(c, "opt_motion_detail: device only"); }
 
-int rship_loss(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_delays, double* loss, double* grad) {
+int rship_loss(rship_ctx* c, const int32_t* kd, const double* fd, uint32_t n_delays, double* loss, double* grad,
+               uint32_t flags) {
+    const bool simple = (flags & RSHIP_LOSS_SIMPLIFIED) != 0;
     const size_t ng = c->grp_off.size() - 1;
     for (uint32_t b = 0; b < n_delays; ++b) {
         for (size_t w = 0; w < ng; ++w) {
             double L = 0, G = 0;
             const int32_t kdw = kd[b * ng + w];
-            const float fdw = fd[b * ng + w];
+            const double fdw = fd[b * ng + w];
             for (uint32_t sl = c->grp_off[w]; fdw == fdw && sl < c->grp_off[w + 1]; ++sl) {
                 const rship_frame& fr = c->frames[c->sel[sl]];
                 const double Mx = c->M[3 * sl], My = c->M[3 * sl + 1], Mz = c->M[3 * sl + 2], kk = c->k[sl];
-                const f3 Mv{(float)Mx, (float)My, (float)Mz};
-                const float inv_s = (float)(kk * kk / (Mx * Mx + My * My + Mz * Mz));
+                const d3 Mv{Mx, My, Mz};
+                const double inv_s = simple ? kk * kk : kk * kk / (Mx * Mx + My * My + Mz * Mz);
                 double Lf = 0, Gf = 0;
                 for (uint32_t i = 0; i < fr.n_rays; ++i) {
-                    f3 P, dP;
-                    row(c, fr, i, kdw, fdw, P, grad ? &dP : nullptr);
-                    float pm = rs::dot(P, Mv), u = pm * pm * inv_s;
-                    Lf += rs::log1p_pos(u);
-                    if (grad) Gf += (1.0f / (1.f + u)) * 2.f * pm * inv_s * rs::dot(dP, Mv);
+                    d3 P, dP;
+                    row64(c, fr, i, kdw, fdw, P, grad ? &dP : nullptr);
+                    double wgt;
+                    if (simple) {
+                        Lf += rs::log1p_rcp_f64(rs::dot(P, P) * inv_s, &wgt);
+                        if (grad) Gf += wgt * 2.0 * inv_s * rs::dot(P, dP);
+                    } else {
+                        const double pm = rs::dot(P, Mv), u = pm * pm * inv_s;
+                        Lf += rs::log1p_rcp_f64(u, &wgt);
+                        if (grad) Gf += wgt * 2.0 * pm * inv_s * rs::dot(dP, Mv);
+                    }
                 }
                 L += Lf;
-                G += Gf * (double)(float)c->fs;
+                G += Gf * c->fs;
             }
             loss[b * ng + w] = L;
             if (grad) grad[b * ng + w] = G;
@@ -461,6 +535,19 @@ int rship_debug_problem(rship_ctx* c, uint32_t sel_index, int32_t kd, float fd, 
         row(c, fr, i, kd, fd, p, dP ? &d : nullptr);
         P[3 * i] = p.x; P[3 * i + 1] = p.y; P[3 * i + 2] = p.z;
         if (dP) { dP[3 * i] = d.x * (float)c->fs; dP[3 * i + 1] = d.y * (float)c->fs; dP[3 * i + 2] = d.z * (float)c->fs; }
+    }
+    return 0;
+}
+
+int rship_debug_problem64(rship_ctx* c, uint32_t sel_index, int32_t kd, double fd, double* P, double* dP, uint32_t cap_rows) {
+    if (sel_index >= c->sel.size()) return fail(c, "debug_problem: index out of range");
+    const rship_frame& fr = c->frames[c->sel[sel_index]];
+    if (fr.n_rays > cap_rows) return fail(c, "debug_problem: output too small");
+    for (uint32_t i = 0; i < fr.n_rays; ++i) {
+        d3 p, d;
+        row64(c, fr, i, kd, fd, p, dP ? &d : nullptr);
+        P[3 * i] = p.x; P[3 * i + 1] = p.y; P[3 * i + 2] = p.z;
+        if (dP) { dP[3 * i] = d.x * c->fs; dP[3 * i + 1] = d.y * c->fs; dP[3 * i + 2] = d.z * c->fs; }
     }
     return 0;
 }
