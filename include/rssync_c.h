@@ -79,7 +79,15 @@ int rssync_ext_set_verbose(rssync_problem* p, int verbose);
 int rssync_ext_set_lbfgs_reeval(rssync_problem* p, int reeval);
 /* line searches of the last rssync_ext_opt_motion call whose best step was not the last one tried */
 int rssync_ext_lbfgs_best_not_last(rssync_problem* p, uint64_t* count);
-/* run the kernels on a caller-owned hipStream_t (NULL = internal stream) */
+/* ONE object, several GPUs (the reference parallelises over frames inside the object, core_private.cpp:73,231,
+ * 245,263): the frames are spread over the listed devices of this process in contiguous blocks, every
+ * PreSync/Sync launches on all of them and adds their partial sums on the host (a few kB) in an order that
+ * does not depend on the device count -- results are bit-identical to the single-GPU run.  Also settable
+ * without touching the client: environment RSSYNC_GPUS = "4" (devices 0..3) or "0,2,5".  Default: the
+ * calling thread's current device.  May be called at any time; the data is uploaded again when next needed. */
+int rssync_ext_set_devices(rssync_problem* p, const int* device_ids, int n_devices);
+int rssync_ext_device_count(rssync_problem* p);
+/* run the kernels on a caller-owned hipStream_t (NULL = internal stream); single-GPU objects only */
 int rssync_ext_set_stream(rssync_problem* p, void* hip_stream);
 
 /* Multi-GPU: frames are sharded over ranks (one process per GPU); the only

@@ -118,19 +118,25 @@ int rship_select_frames(rship_ctx* c, const uint32_t* idx, uint32_t n);
 int rship_select_slots(rship_ctx* c, const uint32_t* idx, uint32_t n, const uint32_t* grp_off,
                        uint32_t n_grp);
 
-/* pre_sync's per-frame body for every (selected frame, candidate delay):
+/* Sums over frames (the mutex-guarded accumulations of core_private.cpp:84-85, :235-237, :248-249) follow a
+ * PLAN: window w = chunks win_chunk_off[w] .. [w+1]; chunk c = plan positions chunk_off[c] .. [c+1]; position
+ * j = slot plan_idx[j] (NULL: j itself).  A chunk is summed sequentially, a window is the sequential sum of
+ * its chunks.  The host puts into one chunk the slots of a window whose frame-table index lies in the same
+ * block of 64 and splits frames over devices at multiples of 64: the chunk sums of several devices, added in
+ * order, then equal the single-device window sums bit for bit. */
+int rship_set_plan(rship_ctx* c, const uint32_t* plan_idx, uint32_t plan_len, const uint32_t* chunk_off,
+                   uint32_t n_chunks, const uint32_t* win_chunk_off, uint32_t n_win);
+
+/* pre_sync's per-frame body for every (selected slot, candidate delay):
  * opt_compute_problem + opt_guess_translational_motion(P, n_hyp) + cost
- * (core_private.cpp:75-85).  costs[n_cand] = sum over selected frames.
- * Optional debug outputs (may be NULL): frame_costs / best_h [n_cand][n_sel]. */
-int rship_presync_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand,
-                        uint32_t n_hyp, uint32_t stream_base, uint64_t seed, double* costs,
-                        uint32_t* flags, double* frame_costs, int32_t* best_h);
-/* the same for several windows over one (ungrouped) selection: costs[n_cand][n_win], window w
- * summing the slots seg_idx[seg_off[w] .. seg_off[w+1]) (seg_idx NULL = the slots themselves) */
-int rship_presync_window_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand,
-                               uint32_t n_hyp, uint32_t stream_base, uint64_t seed,
-                               const uint32_t* seg_idx, const uint32_t* seg_off, uint32_t n_win,
-                               double* costs, uint32_t* flags, double* frame_costs, int32_t* best_h);
+ * (core_private.cpp:75-85), then the sums of the plan.  enqueue returns at once (several devices work
+ * concurrently); collect waits: win_costs[n_cand][n_win], chunk_costs[n_cand][n_chunks] (either may be
+ * NULL), status bits, and the debug matrices frame_costs / best_h [n_cand][n_sel] if asked for. */
+int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand,
+                          uint32_t n_hyp, uint32_t stream_base, uint64_t seed, int want_frame_costs,
+                          int want_best_h);
+int rship_presync_collect(rship_ctx* c, uint32_t n_cand, double* win_costs, double* chunk_costs,
+                          uint32_t* flags, double* frame_costs, int32_t* best_h);
 
 /* FrameState::GuessMotion (core_private.cpp:125-128): the 200-hypothesis LMedS search for every selected
  * slot, in the fp32 tile kernel; kd/fd hold one delay per window (fp32 split), window w samples with
@@ -152,14 +158,17 @@ int rship_opt_motion(rship_ctx* c, const int32_t* kd, const double* fd, uint64_t
 int rship_opt_motion_detail(rship_ctx* c, const int32_t* kd, const double* fd, uint32_t* per_frame,
                             uint32_t cap);
 
-/* per window, sum over its slots of FrameState::Loss at n_delays delays
- * (core_private.cpp:117-123), in fp64; kd/fd are [n_delays][n_windows] (fd = NaN skips), loss/grad out
- * likewise; with grad != NULL also the analytic d/d-delay that replaces the central
- * difference at :96-97,112.  flags: RSHIP_LOSS_SIMPLIFIED = the no-translation loss
- * sum_j log1p((k |P_j|)^2) (thesis section 2.11 eq. (12)) instead. */
+/* FrameState::Loss (core_private.cpp:117-123) of every selected slot at n_delays delays, in fp64, summed
+ * under the plan (for Sync the plan's windows are the selection's groups); kd/fd are
+ * [n_delays][n_groups] (fd = NaN skips a group); with want_grad also the analytic d/d-delay that replaces
+ * the central difference at :96-97,112.  flags: RSHIP_LOSS_SIMPLIFIED = the no-translation loss
+ * sum_j log1p((k |P_j|)^2) (thesis section 2.11 eq. (12)) instead.  collect: [n_delays][n_win] window sums
+ * and [n_delays][n_chunks] chunk sums; any pointer may be NULL. */
 #define RSHIP_LOSS_SIMPLIFIED 1u
-int rship_loss(rship_ctx* c, const int32_t* kd, const double* fd, uint32_t n_delays, double* loss,
-               double* grad, uint32_t flags);
+int rship_loss_enqueue(rship_ctx* c, const int32_t* kd, const double* fd, uint32_t n_delays, int want_grad,
+                       uint32_t flags);
+int rship_loss_collect(rship_ctx* c, uint32_t n_delays, double* win_loss, double* win_grad,
+                       double* chunk_loss, double* chunk_grad);
 
 /* per-slot state in selection order: M[3n], k[n] */
 int rship_get_motion(rship_ctx* c, double* M, double* k, uint32_t cap, uint32_t* n);

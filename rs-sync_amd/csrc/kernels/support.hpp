@@ -5,24 +5,37 @@
 namespace {
 
 // ---------------------------------------------------------------------------
-// out[r][w] = sum over j in [off[w], off[w+1]) of in[r][idx ? idx[j] : j]: per-window (segment)
-// sums over frames with a fixed association, so results are bitwise reproducible and a window
-// summed inside a batch equals the same window summed alone.  With one segment covering all
-// columns this is the plain over-frames sum.
-
-__global__ __launch_bounds__(kBlock) void segment_sum_kernel(const double* __restrict__ in, double* __restrict__ out,
-                                                            uint32_t n_cols, const uint32_t* __restrict__ idx,
-                                                            const uint32_t* __restrict__ off, uint32_t n_seg) {
-    __shared__ double s_red[4];
-    const uint32_t r = blockIdx.x / n_seg, w = blockIdx.x % n_seg;
-    const uint32_t j0 = off ? off[w] : 0u, j1 = off ? off[w + 1] : n_cols;
+// Sums over the frames of a window, in ONE association that does not depend on how many devices
+// share the frames: slots are grouped into CHUNKS (the slots of the window whose frame-table index
+// falls into the same block of 64; the host builds the plan), a chunk is summed sequentially in
+// slot order, and a window is the sequential sum of its chunks in order.  A device that holds only
+// part of a window contributes its chunk sums, and whoever adds the chunks in order -- this kernel
+// on a single device, the host across several -- gets bit-identical totals.
+//   in[r][slot]                 per-slot values of row r (a candidate delay, a line-search trial)
+//   idx[j]                      slot of plan position j (NULL = j itself)
+//   chunk_off[c] .. [c+1]       plan positions of chunk c
+//   win_chunk_off[w] .. [w+1]   chunks of window w
+//   chunk_out[r][c], win_out[r][w]
+__global__ __launch_bounds__(kBlock) void plan_sum_kernel(const double* __restrict__ in, uint32_t n_cols,
+                                                         const uint32_t* __restrict__ idx,
+                                                         const uint32_t* __restrict__ chunk_off, uint32_t n_chunks,
+                                                         const uint32_t* __restrict__ win_chunk_off, uint32_t n_win,
+                                                         double* __restrict__ chunk_out, double* __restrict__ win_out) {
+    const uint32_t r = blockIdx.x / n_win, w = blockIdx.x % n_win;
+    const uint32_t c0 = win_chunk_off[w], c1 = win_chunk_off[w + 1];
     const double* row = in + (size_t)r * n_cols;
-    double acc = 0.0;
-    for (uint32_t j = j0 + threadIdx.x; j < j1; j += kBlock) acc += row[idx ? idx[j] : j];
-    double wsum = wave_sum_f64(acc);
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = wsum;
-    __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    double* cout = chunk_out + (size_t)r * n_chunks;
+    for (uint32_t c = c0 + threadIdx.x; c < c1; c += kBlock) {
+        double acc = 0.0;
+        for (uint32_t j = chunk_off[c]; j < chunk_off[c + 1]; ++j) acc += row[idx ? idx[j] : j];
+        cout[c] = acc;
+    }
+    __syncthreads(); // the chunk sums of this block are visible to its thread 0
+    if (threadIdx.x == 0) {
+        double acc = 0.0;
+        for (uint32_t c = c0; c < c1; ++c) acc += cout[c];
+        win_out[blockIdx.x] = acc;
+    }
 }
 
 // debug: P (and dP/dd) rows of one frame

@@ -12,7 +12,8 @@
 //   opt_motion64_kernel one workgroup per frame: P in registers (fp64), restated L-BFGS on the
 //                      3-vector motion estimate; also finishes GuessMotion/GuessK in fp64.
 //   pack_frames_kernel raw track records -> packed fp32 + fp64 streams.
-//   segment_sum_kernel fixed-order fp64 sums over the frames of each window.
+//   plan_sum_kernel    sums over the frames of each window in an association that does not
+//                      depend on the number of devices sharing the frames.
 // Data layout and the roofline that bounds each kernel: DESIGN.md.
 // The kernels live in kernels/*.hpp (one header each, included below); this file holds the
 // device context and the launchers.
@@ -63,7 +64,13 @@ struct rship_ctx {
     hipEvent_t copy_done = nullptr;
     std::string err;
     // problem data
-    DevBuf coef, coef64, raw, rays_a, rays_b, rays64, frames, sel, M, k, grp, grp_off, seg_idx, seg_off, init_h;
+    DevBuf coef, coef64, raw, rays_a, rays_b, rays64, frames, sel, M, k, grp, grp_off, init_h;
+    // reduction plan (rship_set_plan): windows -> chunks -> slots
+    DevBuf plan_idx, plan_chunk_off, plan_win_off, chunk_out, win_out;
+    bool plan_has_idx = false;
+    uint32_t plan_chunks = 0, plan_wins = 0, plan_len = 0;
+    // what the last *_enqueue left for its *_collect
+    struct Pend { uint32_t rows = 0; bool grad = false, frame_costs = false, best_h = false; size_t off_chunk = 0, off_flags = 0; } pend;
     // GuessMotion's hypothesis search has run and left winners in init_h: the next motion launch finishes it
     bool init_pending = false;
     uint64_t init_seed = 0;
@@ -233,11 +240,28 @@ int launch_motion64(rship_ctx* c, const Motion64Params& p, int rpt) {
     return 0;
 }
 
-int launch_reduce(rship_ctx* c, const double* in, double* out, uint32_t rows, uint32_t cols, const uint32_t* idx,
-                  const uint32_t* off, uint32_t n_seg) {
+// rows x (chunk sums, window sums) of in[rows][cols] under the current plan, into c->chunk_out / c->win_out
+int launch_plan_sum(rship_ctx* c, const double* in, uint32_t rows, uint32_t cols) {
+    if (!c->plan_wins) return set_err(c, "no reduction plan set");
+    if (ensure(c, c->chunk_out, (size_t)rows * (c->plan_chunks + 1) * 8) || ensure(c, c->win_out, (size_t)rows * c->plan_wins * 8))
+        return 1;
     ProfScope ps(c, RSHIP_K_REDUCE);
-    hipLaunchKernelGGL(segment_sum_kernel, dim3(rows * n_seg), dim3(kBlock), 0, c->stream, in, out, cols, idx, off, n_seg);
+    hipLaunchKernelGGL(plan_sum_kernel, dim3(rows * c->plan_wins), dim3(kBlock), 0, c->stream, in, cols,
+                       c->plan_has_idx ? (const uint32_t*)c->plan_idx.p : nullptr, (const uint32_t*)c->plan_chunk_off.p,
+                       c->plan_chunks, (const uint32_t*)c->plan_win_off.p, c->plan_wins, (double*)c->chunk_out.p,
+                       (double*)c->win_out.p);
     RS_HIP(hipGetLastError());
+    return 0;
+}
+
+// queue the copy of the last plan sum (rows x windows, then rows x chunks) into pinned memory at `at`
+int queue_sums_to_host(rship_ctx* c, uint32_t rows, size_t at, size_t* off_chunk, size_t* end) {
+    const size_t wb = (size_t)rows * c->plan_wins * 8, cb = (size_t)rows * c->plan_chunks * 8;
+    if (ensure_pinned(c, at + wb + cb + 64)) return 1;
+    RS_HIP(hipMemcpyAsync((char*)c->pinned + at, c->win_out.p, wb, hipMemcpyDeviceToHost, c->stream));
+    if (cb) RS_HIP(hipMemcpyAsync((char*)c->pinned + at + wb, c->chunk_out.p, cb, hipMemcpyDeviceToHost, c->stream));
+    *off_chunk = at + wb;
+    *end = at + wb + cb;
     return 0;
 }
 
@@ -371,7 +395,7 @@ void rship_destroy(rship_ctx* c) {
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     DevBuf* bufs[] = {&c->coef, &c->coef64, &c->raw, &c->rays_a, &c->rays_b, &c->rays64, &c->frames, &c->sel, &c->M, &c->k, &c->grp, &c->grp_off,
-                      &c->seg_idx, &c->seg_off, &c->kd, &c->kd64, &c->init_h,
+                      &c->plan_idx, &c->plan_chunk_off, &c->plan_win_off, &c->chunk_out, &c->win_out, &c->kd, &c->kd64, &c->init_h,
                       &c->frame_cost, &c->best_h, &c->costs, &c->part, &c->flags, &c->stats};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -548,39 +572,46 @@ int rship_select_slots(rship_ctx* c, const uint32_t* idx, uint32_t n, const uint
 
 int rship_select_frames(rship_ctx* c, const uint32_t* idx, uint32_t n) { return rship_select_slots(c, idx, n, nullptr, 1); }
 
-int rship_presync_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand, uint32_t n_hyp,
-                        uint32_t stream_base, uint64_t seed, double* costs, uint32_t* flags, double* frame_costs,
-                        int32_t* best_h) {
-    return rship_presync_window_costs(c, kd, fd, n_cand, n_hyp, stream_base, seed, nullptr, nullptr, 1, costs, flags,
-                                      frame_costs, best_h);
+// The plan of the sums that follow: window w = chunks win_chunk_off[w] .. [w+1]; chunk c = plan positions
+// chunk_off[c] .. [c+1]; position j = slot plan_idx[j] (NULL: j itself).  Chunks hold the slots of a window whose
+// frame-table index falls into the same block of 64 (the host builds them that way).
+int rship_set_plan(rship_ctx* c, const uint32_t* plan_idx, uint32_t plan_len, const uint32_t* chunk_off, uint32_t n_chunks,
+                   const uint32_t* win_chunk_off, uint32_t n_win) {
+    DeviceGuard dev_guard(c);
+    if (n_win < 1) return set_err(c, "plan: no window");
+    if (win_chunk_off[0] != 0 || win_chunk_off[n_win] != n_chunks) return set_err(c, "plan: bad window offsets");
+    if (n_chunks && (chunk_off[0] != 0 || chunk_off[n_chunks] != plan_len)) return set_err(c, "plan: bad chunk offsets");
+    for (uint32_t j = 0; plan_idx && j < plan_len; ++j)
+        if (plan_idx[j] >= c->n_sel) return set_err(c, "plan: slot out of range");
+    if (!plan_idx && plan_len > c->n_sel) return set_err(c, "plan: slot out of range");
+    if (ensure(c, c->plan_idx, (size_t)plan_len * 4 + 4) || ensure(c, c->plan_chunk_off, (size_t)(n_chunks + 1) * 4) ||
+        ensure(c, c->plan_win_off, (size_t)(n_win + 1) * 4))
+        return 1;
+    if (plan_idx && plan_len) RS_HIP(hipMemcpyAsync(c->plan_idx.p, plan_idx, (size_t)plan_len * 4, hipMemcpyHostToDevice, c->stream));
+    const uint32_t zero = 0;
+    RS_HIP(hipMemcpyAsync(c->plan_chunk_off.p, n_chunks ? chunk_off : &zero, (size_t)(n_chunks + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemcpyAsync(c->plan_win_off.p, win_chunk_off, (size_t)(n_win + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipStreamSynchronize(c->stream));
+    c->plan_has_idx = plan_idx != nullptr;
+    c->plan_chunks = n_chunks;
+    c->plan_wins = n_win;
+    c->plan_len = plan_len;
+    return 0;
 }
 
-// costs[n_cand][n_win]: window w sums the frame costs of slots seg_idx[seg_off[w] .. seg_off[w+1])
-// (NULL, NULL, 1 = one window over every selected slot).  The selection must be a single group.
-int rship_presync_window_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand, uint32_t n_hyp,
-                               uint32_t stream_base, uint64_t seed, const uint32_t* seg_idx, const uint32_t* seg_off,
-                               uint32_t n_win, double* costs, uint32_t* flags, double* frame_costs, int32_t* best_h) {
+// pre_sync's per-frame body (core_private.cpp:75-85) for every (selected slot, candidate delay), then the
+// sums of the current plan.  Asynchronous: rship_presync_collect waits and hands the results over.
+int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand, uint32_t n_hyp,
+                          uint32_t stream_base, uint64_t seed, int want_frame_costs, int want_best_h) {
     DeviceGuard dev_guard(c);
-    if (check_ready(c)) return 1;
+    c->pend = rship_ctx::Pend{};
+    if (!c->n_knots) return set_err(c, "no gyro spline uploaded");
     if (c->n_grp != 1) return set_err(c, "presync: the selection must not be grouped");
-    if (!n_cand) return 0;
-    if (n_win < 1) n_win = 1;
     const uint32_t ns = c->n_sel;
-    if (ensure(c, c->frame_cost, (size_t)n_cand * ns * 8) || ensure(c, c->costs, (size_t)n_cand * n_win * 8)) return 1;
-    if (best_h && ensure(c, c->best_h, (size_t)n_cand * ns * 4)) return 1;
+    if (!n_cand || !ns) return 0; // nothing on this device: collect reports zeros
+    if (ensure(c, c->frame_cost, (size_t)n_cand * ns * 8)) return 1;
+    if (want_best_h && ensure(c, c->best_h, (size_t)n_cand * ns * 4)) return 1;
     if (ensure(c, c->flags, 16)) return 1;
-    const uint32_t* d_idx = nullptr;
-    const uint32_t* d_off = nullptr;
-    if (seg_off) {
-        const uint32_t total = seg_off[n_win];
-        for (uint32_t j = 0; seg_idx && j < total; ++j)
-            if (seg_idx[j] >= ns) return set_err(c, "presync: window index out of range");
-        if (ensure(c, c->seg_idx, (size_t)total * 4 + 4) || ensure(c, c->seg_off, (size_t)(n_win + 1) * 4)) return 1;
-        if (seg_idx && total) RS_HIP(hipMemcpyAsync(c->seg_idx.p, seg_idx, (size_t)total * 4, hipMemcpyHostToDevice, c->stream));
-        RS_HIP(hipMemcpyAsync(c->seg_off.p, seg_off, (size_t)(n_win + 1) * 4, hipMemcpyHostToDevice, c->stream));
-        d_idx = seg_idx ? (const uint32_t*)c->seg_idx.p : nullptr;
-        d_off = (const uint32_t*)c->seg_off.p;
-    }
     if (upload_delays(c, kd, fd, n_cand)) return 1;
     RS_HIP(hipMemsetAsync(c->flags.p, 0, 16, c->stream));
 
@@ -620,23 +651,43 @@ int rship_presync_window_costs(rship_ctx* c, const int32_t* kd, const float* fd,
     p.stream_base = stream_base;
     p.seed = seed;
     p.frame_cost = (double*)c->frame_cost.p;
-    p.best_h = best_h ? (int32_t*)c->best_h.p : nullptr;
+    p.best_h = want_best_h ? (int32_t*)c->best_h.p : nullptr;
     p.flags = (uint32_t*)c->flags.p;
     uint32_t groups = (ns + 7) / 8;
     uint64_t grid = (uint64_t)groups * 8 * p.n_chunks;
     if (grid > 0x7fffffffull) return set_err(c, "presync: grid too large");
     if (launch_lmeds<0>(c, p, rpt_for(c->max_n), (uint32_t)grid)) return 1;
-    if (launch_reduce(c, p.frame_cost, (double*)c->costs.p, n_cand, ns, d_idx, d_off, n_win)) return 1;
+    if (launch_plan_sum(c, p.frame_cost, n_cand, ns)) return 1;
+    size_t end = 0;
+    if (queue_sums_to_host(c, n_cand, 0, &c->pend.off_chunk, &end)) return 1;
+    c->pend.off_flags = end;
+    RS_HIP(hipMemcpyAsync((char*)c->pinned + end, c->flags.p, 4, hipMemcpyDeviceToHost, c->stream));
+    c->pend.rows = n_cand;
+    c->pend.frame_costs = want_frame_costs != 0;
+    c->pend.best_h = want_best_h != 0;
+    return 0;
+}
 
-    const size_t out_bytes = (size_t)n_cand * n_win * 8;
-    if (ensure_pinned(c, out_bytes + 16)) return 1;
-    RS_HIP(hipMemcpyAsync(c->pinned, c->costs.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
-    RS_HIP(hipMemcpyAsync((char*)c->pinned + out_bytes, c->flags.p, 4, hipMemcpyDeviceToHost, c->stream));
+// win_costs[n_cand][n_win], chunk_costs[n_cand][n_chunks] (either may be NULL); debug outputs
+// frame_costs / best_h [n_cand][n_sel] if they were asked for at enqueue time
+int rship_presync_collect(rship_ctx* c, uint32_t n_cand, double* win_costs, double* chunk_costs, uint32_t* flags,
+                          double* frame_costs, int32_t* best_h) {
+    DeviceGuard dev_guard(c);
+    if (flags) *flags = 0;
+    if (!c->pend.rows) { // nothing was launched (no candidates or no slots on this device)
+        if (win_costs) memset(win_costs, 0, (size_t)n_cand * (c->plan_wins ? c->plan_wins : 1) * 8);
+        if (chunk_costs) memset(chunk_costs, 0, (size_t)n_cand * c->plan_chunks * 8);
+        return 0;
+    }
+    if (n_cand != c->pend.rows) return set_err(c, "presync_collect: candidate count differs from the enqueue");
     if (sync_stream(c)) return 1;
-    memcpy(costs, c->pinned, out_bytes);
-    if (flags) memcpy(flags, (char*)c->pinned + out_bytes, 4);
+    const uint32_t ns = c->n_sel;
+    if (win_costs) memcpy(win_costs, c->pinned, (size_t)n_cand * c->plan_wins * 8);
+    if (chunk_costs) memcpy(chunk_costs, (char*)c->pinned + c->pend.off_chunk, (size_t)n_cand * c->plan_chunks * 8);
+    if (flags) memcpy(flags, (char*)c->pinned + c->pend.off_flags, 4);
     if (frame_costs) RS_HIP(hipMemcpy(frame_costs, c->frame_cost.p, (size_t)n_cand * ns * 8, hipMemcpyDeviceToHost));
-    if (best_h) RS_HIP(hipMemcpy(best_h, c->best_h.p, (size_t)n_cand * ns * 4, hipMemcpyDeviceToHost));
+    if (best_h && c->pend.best_h) RS_HIP(hipMemcpy(best_h, c->best_h.p, (size_t)n_cand * ns * 4, hipMemcpyDeviceToHost));
+    c->pend.rows = 0;
     return 0;
 }
 
@@ -774,15 +825,16 @@ int rship_opt_motion(rship_ctx* c, const int32_t* kd, const double* fd, uint64_t
     return 0; // stays queued: the next loss call is ordered behind it on the stream
 }
 
-// kd/fd: [n_delays][n_grp]; loss/grad out: [n_delays][n_grp]
-int rship_loss(rship_ctx* c, const int32_t* kd, const double* fd, uint32_t n_delays, double* loss, double* grad,
-               uint32_t flags) {
+// kd/fd: [n_delays][n_grp] (one delay per group of the selection, fd = NaN skips a group).  The per-slot
+// losses are summed under the current plan (for Sync: plan windows = groups).  Asynchronous.
+int rship_loss_enqueue(rship_ctx* c, const int32_t* kd, const double* fd, uint32_t n_delays, int want_grad, uint32_t flags) {
     DeviceGuard dev_guard(c);
-    if (check_ready(c)) return 1;
-    if (!n_delays) return 0;
+    c->pend = rship_ctx::Pend{};
+    if (!c->n_knots) return set_err(c, "no gyro spline uploaded");
+    const uint32_t ns = c->n_sel, ng = c->n_grp;
+    if (!n_delays || !ns) return 0;
     const bool simple = (flags & RSHIP_LOSS_SIMPLIFIED) != 0;
     if (c->init_pending && !simple) return set_err(c, "loss: the motion initialisation has not been finished");
-    const uint32_t ns = c->n_sel, ng = c->n_grp;
     if (upload_delays64(c, kd, fd, (size_t)n_delays * ng)) return 1;
     if (ensure(c, c->part, (size_t)n_delays * ns * 16)) return 1;
     Loss64Params p{};
@@ -804,22 +856,39 @@ int rship_loss(rship_ctx* c, const int32_t* kd, const double* fd, uint32_t n_del
     p.part_grad = p.part_loss + (size_t)n_delays * ns;
     const int rpt = rpt_for(c->max_n);
     int rc;
-    if (simple) rc = grad ? launch_loss64<true, true>(c, p, rpt) : launch_loss64<false, true>(c, p, rpt);
-    else rc = grad ? launch_loss64<true, false>(c, p, rpt) : launch_loss64<false, false>(c, p, rpt);
+    if (simple) rc = want_grad ? launch_loss64<true, true>(c, p, rpt) : launch_loss64<false, true>(c, p, rpt);
+    else rc = want_grad ? launch_loss64<true, false>(c, p, rpt) : launch_loss64<false, false>(c, p, rpt);
     if (rc) return 1;
-    // rows [0, n_delays) = loss, [n_delays, 2 n_delays) = grad; one sum per (row, group)
-    uint32_t rows = grad ? 2 * n_delays : n_delays;
-    // the few sums go straight into pinned host memory (visible once the stream has drained):
-    // one API call less per evaluation than a device buffer + copy
-    const size_t half = (size_t)n_delays * ng * 8;
-    if (ensure_pinned(c, (size_t)rows * ng * 8)) return 1;
-    void* d_out = nullptr;
-    RS_HIP(hipHostGetDevicePointer(&d_out, c->pinned, 0));
-    if (launch_reduce(c, p.part_loss, (double*)d_out, rows, ns, nullptr, ng > 1 ? (const uint32_t*)c->grp_off.p : nullptr, ng))
-        return 1;
+    // rows [0, n_delays) = loss, [n_delays, 2 n_delays) = d loss / d delay
+    const uint32_t rows = want_grad ? 2 * n_delays : n_delays;
+    if (launch_plan_sum(c, p.part_loss, rows, ns)) return 1;
+    size_t end = 0;
+    if (queue_sums_to_host(c, rows, 0, &c->pend.off_chunk, &end)) return 1;
+    c->pend.rows = rows;
+    c->pend.grad = want_grad != 0;
+    return 0;
+}
+
+// win_loss / win_grad [n_delays][n_win], chunk_loss / chunk_grad [n_delays][n_chunks]; any may be NULL
+int rship_loss_collect(rship_ctx* c, uint32_t n_delays, double* win_loss, double* win_grad, double* chunk_loss,
+                       double* chunk_grad) {
+    DeviceGuard dev_guard(c);
+    const size_t wn = (size_t)n_delays * (c->plan_wins ? c->plan_wins : 1), cn = (size_t)n_delays * c->plan_chunks;
+    if (!c->pend.rows) {
+        if (win_loss) memset(win_loss, 0, wn * 8);
+        if (win_grad) memset(win_grad, 0, wn * 8);
+        if (chunk_loss) memset(chunk_loss, 0, cn * 8);
+        if (chunk_grad) memset(chunk_grad, 0, cn * 8);
+        return 0;
+    }
+    if (n_delays * (c->pend.grad ? 2u : 1u) != c->pend.rows) return set_err(c, "loss_collect: row count differs from the enqueue");
     if (sync_stream(c)) return 1;
-    memcpy(loss, c->pinned, half);
-    if (grad) memcpy(grad, (char*)c->pinned + half, half);
+    const char* base = (const char*)c->pinned;
+    if (win_loss) memcpy(win_loss, base, wn * 8);
+    if (win_grad && c->pend.grad) memcpy(win_grad, base + wn * 8, wn * 8);
+    if (chunk_loss) memcpy(chunk_loss, base + c->pend.off_chunk, cn * 8);
+    if (chunk_grad && c->pend.grad) memcpy(chunk_grad, base + c->pend.off_chunk + cn * 8, cn * 8);
+    c->pend.rows = 0;
     return 0;
 }
 

@@ -210,13 +210,26 @@ class SyncProblemHip final : public ISyncProblem {
     double sample_rate() const { return fs_; }
     double quats_start() const { return start_; }
     const std::vector<double>& knots() const { return knots_; }
-    rship_ctx* dev() { return dev_; }
+    rship_ctx* dev() { return shards_[0].ctx; }
+    size_t n_devices() const { return shards_.size(); }
+    void set_devices(const std::vector<int>& ids);
+    void set_option(int option, int value);
+    void profile_enable(int on);
+    void profile_get(int kind, uint64_t* launches, double* total_ms);
+    void profile_reset();
+    // per-slot state in the GLOBAL slot order (window-major, frames ascending), gathered over the devices
+    uint32_t get_motion(double* M, double* k, uint32_t cap);
+    void set_motion(const double* M, const double* k, uint32_t n);
+    void debug_problem(int64_t frame, double delay, float* P, float* dP, double* P64, double* dP64, size_t cap_rows);
+    void debug_rays(int64_t frame, float* a4, float* b4, size_t cap);
 
     // pieces shared by the public calls and the diagnostics
     void ensure_device();
     uint32_t select(int64_t begin, int64_t end_exclusive);
     std::vector<double> sweep(const std::vector<double>& delays, uint32_t stream_base, bool panics,
                               double* frame_costs, int32_t* best_h);
+    void sweep_windows(const std::vector<double>& delays, uint32_t stream_base, double* out, uint32_t* flags_out,
+                       double* frame_costs, int32_t* best_h);
     void init_motion(const std::vector<double>& delays, uint32_t call_stride = 1);
     void opt_motion(const std::vector<double>& delays, uint64_t* stats);
     void finish_init(const std::vector<double>& delays);
@@ -238,7 +251,7 @@ class SyncProblemHip final : public ISyncProblem {
     bool native_exchange = false; // RCCL communicator inside the device context (rssync_ext_rccl_init)
     bool distributed() const { return native_exchange || reduce_fn; }
     void reduce(double* buf, size_t n) {
-        if (native_exchange) hip_check(rship_rccl_allreduce(dev_, buf, n), "rccl all-reduce");
+        if (native_exchange) hip_check(shards_[0], rship_rccl_allreduce(shards_[0].ctx, buf, n), "rccl all-reduce");
         else if (reduce_fn) {
             const int rc = reduce_fn(buf, n, reduce_user);
             if (rc) panic("reduce hook failed (status " + std::to_string(rc) + "): the exchange of " + std::to_string(n) +
@@ -254,9 +267,33 @@ class SyncProblemHip final : public ISyncProblem {
     uint64_t last_best_not_last = 0; // of the last rssync_ext_opt_motion call
 
    private:
-    void hip_check(int rc, const char* what) {
-        if (rc) panic(std::string("hip: ") + what + ": " + (dev_ ? rship_last_error(dev_) : "no context"));
+    // One device context per GPU this object drives (core_private.cpp:73,231,245,263 parallelise over
+    // frames inside ONE object; here the frames of a shard live on one GPU).  Shards own contiguous
+    // ranges of the sorted frame table, split at multiples of kChunk frames.
+    struct Shard {
+        rship_ctx* ctx = nullptr;
+        int device = -1;
+        uint32_t t0 = 0, t1 = 0;             // frame-table range [t0, t1)
+        uint64_t raw_lo = 0;                 // arena offset of this device's raw offset 0
+        std::vector<uint32_t> sel;           // local table indices of the current selection, in slot order
+        std::vector<uint32_t> slot_global;   // global slot of each local slot
+        uint32_t n_chunks = 0;               // current plan
+        std::vector<uint32_t> win_chunk_off; // [windows + 1]
+    };
+    static constexpr uint32_t kChunk = 64;
+    void hip_check(const Shard& sh, int rc, const char* what) {
+        if (rc) panic(std::string("hip: ") + what + ": " + (sh.ctx ? rship_last_error(sh.ctx) : "no context") +
+                      (shards_.size() > 1 ? " (device " + std::to_string(sh.device) + ")" : std::string()));
     }
+    void create_shards(const std::vector<int>& ids);
+    void destroy_shards();
+    // slots (table indices, window-major; off = window offsets or empty for one ungrouped window) -> per-shard
+    // selections; plan windows = the given lists of slot positions (plan_off/plan_pos) or, if empty, the groups
+    void apply_selection(const std::vector<uint32_t>& slots, const std::vector<uint32_t>& grp_off,
+                         const std::vector<uint32_t>* plan_pos, const std::vector<uint32_t>* plan_off);
+    // rows x windows sums from every shard's last enqueue: collect(shard, win_out, chunk_out)
+    template <typename Collect>
+    void combine(size_t rows, size_t n_win, Collect&& collect, double* out);
     void build_spline();
     void pack_frames();
     void install_gyro(struct GyroGrid&& g, std::vector<double>* coef);
@@ -268,7 +305,8 @@ class SyncProblemHip final : public ISyncProblem {
     double fs_ = 0, start_ = 0;
     std::vector<double> knots_; // 4 per sample, [w,x,y,z]
     std::map<int64_t, HostFrame> frames_;
-    rship_ctx* dev_ = nullptr;
+    std::vector<Shard> shards_;
+    size_t plan_windows_ = 1;
     bool spline_dirty_ = true, frames_dirty_ = true;
     std::vector<int64_t> table_ids_;
     std::vector<uint32_t> sel_;
@@ -279,12 +317,83 @@ SyncProblemHip::SyncProblemHip() {
     if (const char* s = std::getenv("RSSYNC_SEED")) seed = std::strtoull(s, nullptr, 0);
     if (const char* s = std::getenv("RSSYNC_MAX_OUTER_ITERS")) max_outer = std::atoi(s);
     if (const char* s = std::getenv("RSSYNC_QUIET")) verbose = !(s[0] && s[0] != '0');
-    int rc = rship_create(&dev_, -1);
-    if (rc) panic("rssync: no usable HIP device (rship_create failed with " + std::to_string(rc) +
-                  "); this library has no CPU fallback");
+    // RSSYNC_GPUS: how many GPUs this object spreads its frames over ("4" = devices 0..3) or which
+    // ("0,2,5"); default: the calling thread's current device only
+    std::vector<int> ids;
+    if (const char* s = std::getenv("RSSYNC_GPUS")) {
+        std::string v(s);
+        if (v.find(',') == std::string::npos) {
+            const int n = std::atoi(v.c_str());
+            for (int i = 0; i < n; ++i) ids.push_back(i);
+        } else {
+            size_t pos = 0;
+            while (pos <= v.size()) {
+                size_t q = v.find(',', pos);
+                if (q == std::string::npos) q = v.size();
+                if (q > pos) ids.push_back(std::atoi(v.substr(pos, q - pos).c_str()));
+                pos = q + 1;
+            }
+        }
+    }
+    if (ids.empty()) ids.push_back(-1);
+    create_shards(ids);
 }
 
-SyncProblemHip::~SyncProblemHip() { rship_destroy(dev_); }
+SyncProblemHip::~SyncProblemHip() { destroy_shards(); }
+
+void SyncProblemHip::create_shards(const std::vector<int>& ids) {
+    for (int id : ids) {
+        Shard sh;
+        sh.device = id;
+        int rc = rship_create(&sh.ctx, id);
+        if (rc) {
+            destroy_shards();
+            panic("rssync: no usable HIP device (rship_create(" + std::to_string(id) + ") failed with " +
+                  std::to_string(rc) + "); this library has no CPU fallback");
+        }
+        shards_.push_back(sh);
+    }
+}
+
+void SyncProblemHip::destroy_shards() {
+    for (Shard& sh : shards_) rship_destroy(sh.ctx);
+    shards_.clear();
+}
+
+// the GPUs this object drives (before or after the data has been set: it is uploaded again)
+void SyncProblemHip::set_devices(const std::vector<int>& ids) {
+    if (ids.empty()) panic("set-devices: empty device list");
+    if (native_exchange) panic("set-devices: not after rccl_init");
+    destroy_shards();
+    create_shards(ids);
+    uploaded_ = 0;
+    spline_dirty_ = true;
+    frames_dirty_ = true;
+    sel_.clear();
+}
+
+void SyncProblemHip::set_option(int option, int value) {
+    for (Shard& sh : shards_) hip_check(sh, rship_set_option(sh.ctx, option, value), "set option");
+}
+void SyncProblemHip::profile_enable(int on) {
+    for (Shard& sh : shards_) hip_check(sh, rship_profile_enable(sh.ctx, on), "profile");
+}
+void SyncProblemHip::profile_reset() {
+    for (Shard& sh : shards_) hip_check(sh, rship_profile_reset(sh.ctx), "profile");
+}
+void SyncProblemHip::profile_get(int kind, uint64_t* launches, double* total_ms) {
+    uint64_t n = 0;
+    double ms = 0;
+    for (Shard& sh : shards_) {
+        uint64_t a = 0;
+        double b = 0;
+        hip_check(sh, rship_profile_get(sh.ctx, kind, &a, &b), "profile");
+        n += a;
+        ms += b;
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+}
 
 // core_private.cpp:135-140
 void SyncProblemHip::SetGyroQuaternions(const double* data, size_t count, double sample_rate,
@@ -356,7 +465,8 @@ void SyncProblemHip::install_gyro(GyroGrid&& g, std::vector<double>* coef) {
     spline_dirty_ = true;
     if (coef) { // table already built (orientation sweep worker): upload it now
         if (knots_.size() / 4 * 16 != coef->size()) panic("install-gyro: table size mismatch");
-        hip_check(rship_upload_spline(dev_, coef->data(), (uint32_t)(knots_.size() / 4), fs_), "upload spline");
+        for (Shard& sh : shards_)
+            hip_check(sh, rship_upload_spline(sh.ctx, coef->data(), (uint32_t)(knots_.size() / 4), fs_), "upload spline");
         spline_dirty_ = false;
     }
 }
@@ -374,10 +484,11 @@ double* SyncProblemHip::stage_record(int64_t frame, uint64_t n_doubles, HostFram
 // caller's loop over frames (the reference driver tracks one frame pair at a time,
 // core_testcode.cpp:135-158) and has usually finished by the time PreSync/Sync is called.
 void SyncProblemHip::upload_new_records() {
+    if (shards_.size() != 1) return; // several devices: who owns a frame is only known once all frames are (pack_frames)
     const uint64_t end = arena_.size();
     if (end <= uploaded_) return;
     arena_.ranges(uploaded_, end, [&](const double* host, uint64_t off, uint64_t cnt) {
-        hip_check(rship_upload_raw(dev_, host, off, cnt), "upload tracks");
+        hip_check(shards_[0], rship_upload_raw(shards_[0].ctx, host, off, cnt), "upload tracks");
     });
     uploaded_ = end;
 }
@@ -574,7 +685,8 @@ static std::vector<double> spline_table(const std::vector<double>& knots) {
 
 void SyncProblemHip::build_spline() {
     std::vector<double> coef = spline_table(knots_);
-    hip_check(rship_upload_spline(dev_, coef.data(), (uint32_t)(knots_.size() / 4), fs_), "upload spline");
+    for (Shard& sh : shards_)
+        hip_check(sh, rship_upload_spline(sh.ctx, coef.data(), (uint32_t)(knots_.size() / 4), fs_), "upload spline");
     spline_dirty_ = false;
 }
 
@@ -589,8 +701,9 @@ void SyncProblemHip::pack_frames() {
     const size_t nf = frames_.size();
     std::vector<rship_frame> table(nf);
     std::vector<rship_pack_frame> pack(nf);
+    std::vector<uint64_t> cum(nf + 1, 0); // rays before frame i
     table_ids_.resize(nf);
-    size_t total = 0, s = 0;
+    size_t s = 0;
     for (auto& [id, f] : frames_) {
         const size_t n = f.n;
         // (ts - start) * fs is monotonic in ts: its range comes from the range of ts
@@ -599,7 +712,6 @@ void SyncProblemHip::pack_frames() {
         if (!(base > -(double)kKnotClamp)) base = -(double)kKnotClamp;
         if (base > (double)kKnotClamp) base = (double)kKnotClamp;
         rship_frame rec{};
-        rec.ray_offset = (uint32_t)total;
         rec.n_rays = (uint32_t)n;
         rec.base_knot = (int32_t)base;
         rec.id = id;
@@ -617,7 +729,6 @@ void SyncProblemHip::pack_frames() {
         }
         rship_pack_frame pf{};
         pf.raw_offset = f.raw_off;
-        pf.ray_offset = rec.ray_offset;
         pf.n_rays = rec.n_rays;
         pf.base = base;
         pf.is_pixels = f.from_pixels ? 1u : 0u;
@@ -626,22 +737,214 @@ void SyncProblemHip::pack_frames() {
         table[s] = rec;
         pack[s] = pf;
         table_ids_[s] = id;
-        total += n;
+        cum[s + 1] = cum[s] + n;
         ++s;
     }
-    if (total > 0xffffffffull) panic("sync: more than 2^32 rays");
-    upload_new_records();
+    // Contiguous blocks of the sorted frame list per device, balanced by ray count, cut at multiples of
+    // kChunk frames (the sums over frames are defined on those blocks: DESIGN.md "Sums").
+    const size_t S = shards_.size();
+    std::vector<uint32_t> cut(S + 1, 0);
+    cut[S] = (uint32_t)nf;
+    for (size_t d = 1; d < S; ++d) {
+        const double target = (double)cum[nf] * (double)d / (double)S;
+        uint32_t best = cut[d - 1];
+        double best_err = std::numeric_limits<double>::infinity();
+        for (uint32_t i = cut[d - 1]; i <= nf; i += kChunk - (i % kChunk)) {
+            const double err = std::fabs((double)cum[i] - target);
+            if (err < best_err) { best_err = err; best = i; }
+            if ((double)cum[i] > target) break;
+        }
+        cut[d] = best;
+    }
+    if (S == 1) upload_new_records();
     uint32_t bad = 0;
-    hip_check(rship_pack_frames(dev_, table.data(), pack.data(), (uint32_t)nf, total, start_, fs_, &bad), "pack frames");
+    for (size_t d = 0; d < S; ++d) {
+        Shard& sh = shards_[d];
+        sh.t0 = cut[d];
+        sh.t1 = cut[d + 1];
+        sh.sel.clear();
+        sh.slot_global.clear();
+        const uint32_t n = sh.t1 - sh.t0;
+        if ((cum[sh.t1] - cum[sh.t0]) > 0xffffffffull) panic("sync: more than 2^32 rays on one device");
+        sh.raw_lo = 0;
+        if (S > 1) {
+            // this device's records, as few copies as the arena layout allows
+            std::vector<std::pair<uint64_t, uint64_t>> rng;
+            for (uint32_t i = sh.t0; i < sh.t1; ++i) {
+                const uint64_t len = (uint64_t)pack[i].n_rays * (pack[i].is_pixels ? 4 : 8);
+                if (len) rng.emplace_back(pack[i].raw_offset, pack[i].raw_offset + len);
+            }
+            std::sort(rng.begin(), rng.end());
+            sh.raw_lo = rng.empty() ? 0 : rng.front().first;
+            for (size_t i = 0; i < rng.size();) {
+                uint64_t lo = rng[i].first, hi = rng[i].second;
+                size_t j = i + 1;
+                while (j < rng.size() && rng[j].first <= hi) { hi = std::max(hi, rng[j].second); ++j; }
+                arena_.ranges(lo, hi, [&](const double* host, uint64_t off, uint64_t cnt) {
+                    hip_check(sh, rship_upload_raw(sh.ctx, host, off - sh.raw_lo, cnt), "upload tracks");
+                });
+                i = j;
+            }
+        }
+        for (uint32_t i = sh.t0; i < sh.t1; ++i) {
+            table[i].ray_offset = pack[i].ray_offset = (uint32_t)(cum[i] - cum[sh.t0]);
+            pack[i].raw_offset -= sh.raw_lo;
+        }
+        uint32_t b = 0;
+        hip_check(sh, rship_pack_frames(sh.ctx, table.data() + sh.t0, pack.data() + sh.t0, n, cum[sh.t1] - cum[sh.t0], start_,
+                                        fs_, &b),
+                  "pack frames");
+        bad += b;
+    }
     if (bad) panic("set-track-result: non-finite numbers in rays (" + std::to_string(bad) + " tracks; lens parameters?)");
     sel_.clear();
     frames_dirty_ = false;
+}
+
+// Hand a selection to the devices.  `slots` are frame-table indices in slot order (window-major,
+// ascending within a window); grp_off has the window offsets of a grouped selection (batched Sync:
+// per-window delays and per-slot state) or is empty.  The plan of the sums is, by default, one window
+// per group; plan_pos / plan_off give other windows as lists of slot positions (batched PreSync:
+// windows may overlap).  Every shard gets its part, in the same order, and its own plan; chunk
+// boundaries are multiples of kChunk in the frame table, which shard boundaries are as well.
+void SyncProblemHip::apply_selection(const std::vector<uint32_t>& slots, const std::vector<uint32_t>& grp_off,
+                                     const std::vector<uint32_t>* plan_pos, const std::vector<uint32_t>* plan_off) {
+    const bool grouped = !grp_off.empty();
+    const size_t n_grp = grouped ? grp_off.size() - 1 : 1;
+    std::vector<uint32_t> def_off;
+    if (!grouped) def_off = {0u, (uint32_t)slots.size()};
+    const std::vector<uint32_t>& goff = grouped ? grp_off : def_off;
+    const size_t n_win = plan_off ? plan_off->size() - 1 : n_grp;
+    plan_windows_ = n_win;
+    for (Shard& sh : shards_) {
+        sh.sel.clear();
+        sh.slot_global.clear();
+        std::vector<uint32_t> loff(n_grp + 1, 0), local_of(slots.size(), 0xffffffffu);
+        for (size_t w = 0; w < n_grp; ++w) {
+            for (uint32_t j = goff[w]; j < goff[w + 1]; ++j) {
+                if (slots[j] < sh.t0 || slots[j] >= sh.t1) continue;
+                local_of[j] = (uint32_t)sh.sel.size();
+                sh.sel.push_back(slots[j] - sh.t0);
+                sh.slot_global.push_back(j);
+            }
+            loff[w + 1] = (uint32_t)sh.sel.size();
+        }
+        hip_check(sh, rship_select_slots(sh.ctx, sh.sel.data(), (uint32_t)sh.sel.size(), grouped ? loff.data() : nullptr,
+                                         (uint32_t)n_grp),
+                  "select slots");
+        // plan: windows -> chunks (same block of kChunk table indices) -> local slot positions
+        std::vector<uint32_t> pidx, coff{0u};
+        sh.win_chunk_off.assign(1, 0u);
+        for (size_t w = 0; w < n_win; ++w) {
+            const uint32_t j0 = plan_off ? (*plan_off)[w] : goff[w], j1 = plan_off ? (*plan_off)[w + 1] : goff[w + 1];
+            uint32_t cur_block = 0xffffffffu;
+            for (uint32_t j = j0; j < j1; ++j) {
+                const uint32_t pos = plan_pos ? (*plan_pos)[j] : j; // position in `slots`
+                if (local_of[pos] == 0xffffffffu) continue;
+                const uint32_t block = slots[pos] / kChunk;
+                if (block != cur_block) {
+                    if (cur_block != 0xffffffffu) coff.push_back((uint32_t)pidx.size());
+                    cur_block = block;
+                }
+                pidx.push_back(local_of[pos]);
+            }
+            if (cur_block != 0xffffffffu) coff.push_back((uint32_t)pidx.size());
+            sh.win_chunk_off.push_back((uint32_t)coff.size() - 1);
+        }
+        sh.n_chunks = (uint32_t)coff.size() - 1;
+        hip_check(sh, rship_set_plan(sh.ctx, pidx.data(), (uint32_t)pidx.size(), coff.data(), sh.n_chunks, sh.win_chunk_off.data(),
+                                     (uint32_t)n_win),
+                  "set plan");
+    }
+}
+
+// Sums of every shard's last enqueue, rows x windows.  One device: its window sums.  Several: every
+// window is the sequential sum of its chunks, devices in frame order -- the association the single
+// device uses (plan_sum_kernel), so the totals do not depend on the number of devices.
+template <typename Collect>
+void SyncProblemHip::combine(size_t rows, size_t n_win, Collect&& collect, double* out) {
+    if (shards_.size() == 1) {
+        collect(shards_[0], out, (double*)nullptr);
+        return;
+    }
+    std::fill(out, out + rows * n_win, 0.0);
+    std::vector<double> chunk;
+    for (Shard& sh : shards_) {
+        chunk.assign(rows * (size_t)sh.n_chunks + 1, 0.0);
+        collect(sh, (double*)nullptr, chunk.data());
+        for (size_t r = 0; r < rows; ++r)
+            for (size_t w = 0; w < n_win; ++w) {
+                double acc = out[r * n_win + w];
+                for (uint32_t c = sh.win_chunk_off[w]; c < sh.win_chunk_off[w + 1]; ++c) acc += chunk[r * sh.n_chunks + c];
+                out[r * n_win + w] = acc;
+            }
+    }
 }
 
 void SyncProblemHip::ensure_device() {
     if (knots_.size() < 8) panic("sync: gyro data was not set");
     if (spline_dirty_) build_spline();
     if (frames_dirty_) pack_frames();
+}
+
+uint32_t SyncProblemHip::get_motion(double* M, double* k, uint32_t cap) {
+    std::vector<double> lm, lk;
+    for (Shard& sh : shards_) {
+        const size_t nl = sh.sel.size();
+        lm.assign(nl * 3 + 3, 0.0);
+        lk.assign(nl + 1, 0.0);
+        uint32_t got = 0;
+        if (nl) hip_check(sh, rship_get_motion(sh.ctx, lm.data(), lk.data(), (uint32_t)nl, &got), "get motion");
+        for (size_t j = 0; j < got; ++j) {
+            const uint32_t gslot = sh.slot_global[j];
+            if (gslot >= cap) continue;
+            M[3 * gslot] = lm[3 * j]; M[3 * gslot + 1] = lm[3 * j + 1]; M[3 * gslot + 2] = lm[3 * j + 2];
+            k[gslot] = lk[j];
+        }
+    }
+    return (uint32_t)std::min<size_t>(sel_.size(), cap);
+}
+
+void SyncProblemHip::set_motion(const double* M, const double* k, uint32_t n) {
+    if (n != sel_.size()) panic("set_motion: count differs from the selection");
+    std::vector<double> lm, lk;
+    for (Shard& sh : shards_) {
+        const size_t nl = sh.sel.size();
+        if (!nl) continue;
+        lm.resize(nl * 3);
+        lk.resize(nl);
+        for (size_t j = 0; j < nl; ++j) {
+            const uint32_t gslot = sh.slot_global[j];
+            lm[3 * j] = M[3 * gslot]; lm[3 * j + 1] = M[3 * gslot + 1]; lm[3 * j + 2] = M[3 * gslot + 2];
+            lk[j] = k[gslot];
+        }
+        hip_check(sh, rship_set_motion(sh.ctx, lm.data(), lk.data(), (uint32_t)nl), "set motion");
+    }
+}
+
+// one frame's residual matrix as the PreSync kernel (fp32) or the Sync kernels (fp64) compute it
+void SyncProblemHip::debug_problem(int64_t frame, double delay, float* P, float* dP, double* P64, double* dP64, size_t cap_rows) {
+    select(frame, frame + 1);
+    for (Shard& sh : shards_) {
+        if (sh.sel.empty()) continue;
+        if (P64) {
+            DelaySplit64 ds = split_delay64(delay, fs_);
+            hip_check(sh, rship_debug_problem64(sh.ctx, 0, ds.kd, ds.fd, P64, dP64, (uint32_t)cap_rows), "debug problem");
+        } else {
+            DelaySplit ds = split_delay(delay, fs_);
+            hip_check(sh, rship_debug_problem(sh.ctx, 0, ds.kd, ds.fd, P, dP, (uint32_t)cap_rows), "debug problem");
+        }
+    }
+}
+
+void SyncProblemHip::debug_rays(int64_t frame, float* a4, float* b4, size_t cap) {
+    for (uint32_t i = 0; i < table_ids_.size(); ++i) {
+        if (table_ids_[i] != frame) continue;
+        for (Shard& sh : shards_)
+            if (i >= sh.t0 && i < sh.t1) hip_check(sh, rship_debug_rays(sh.ctx, i - sh.t0, a4, b4, (uint32_t)cap), "debug rays");
+        return;
+    }
+    panic("frame_rays: no such frame");
 }
 
 // frame filters of core_private.cpp:65-68 / :218-219 / :340-343 on the sorted table
@@ -653,7 +956,7 @@ uint32_t SyncProblemHip::select(int64_t begin, int64_t end_exclusive) {
         if (frames_.at(table_ids_[i]).n < 2)
             panic("sync: frame " + std::to_string(table_ids_[i]) + " has fewer than 2 tracks");
     n_windows_ = 1;
-    hip_check(rship_select_frames(dev_, sel_.data(), (uint32_t)sel_.size()), "select frames");
+    apply_selection(sel_, {}, nullptr, nullptr);
     return (uint32_t)sel_.size();
 }
 
@@ -665,34 +968,59 @@ static const char* presync_panic(uint32_t flags) { // core_private.cpp:76-83, in
     return nullptr;
 }
 
-// costs of a list of candidate delays on the current selection, summed over ranks
-std::vector<double> SyncProblemHip::sweep(const std::vector<double>& delays, uint32_t stream_base, bool panics,
-                                          double* frame_costs, int32_t* best_h) {
-    const size_t n = delays.size();
-    std::vector<double> costs(n + 1, 0.0); // last slot carries the status bits through the reduction
+// costs[candidate][window] of a list of candidate delays under the current selection and plan, summed over
+// this object's devices (not yet over ranks); per-slot debug matrices in global slot order if asked for
+void SyncProblemHip::sweep_windows(const std::vector<double>& delays, uint32_t stream_base, double* out, uint32_t* flags_out,
+                                   double* frame_costs, int32_t* best_h) {
+    const size_t n = delays.size(), W = plan_windows_, ns = sel_.size();
+    std::fill(out, out + n * W, 0.0);
     uint32_t flags = 0;
-    if (!sel_.empty() && n) {
+    if (ns && n) {
         std::vector<int32_t> kd(n);
         std::vector<float> fd(n);
         for (size_t i = 0; i < n; ++i) {
-            DelaySplit s = split_delay(delays[i], fs_);
-            kd[i] = s.kd;
-            fd[i] = s.fd;
+            DelaySplit sp = split_delay(delays[i], fs_);
+            kd[i] = sp.kd;
+            fd[i] = sp.fd;
         }
-        // the device keeps a [candidates][frames] fp64 matrix: sweep very long candidate lists in
+        // the devices keep a [candidates][frames] fp64 matrix: sweep very long candidate lists in
         // slices (the sampler stream is the global candidate index, so slicing changes nothing)
-        const size_t slice = std::max<size_t>(64, (size_t)(256u << 20) / (8 * sel_.size()));
+        const size_t slice = std::max<size_t>(64, (size_t)(256u << 20) / (8 * ns));
+        std::vector<double> fc;
+        std::vector<int32_t> bh;
         for (size_t b = 0; b < n; b += slice) {
             const size_t m = std::min(slice, n - b);
-            uint32_t fl = 0;
-            hip_check(rship_presync_costs(dev_, kd.data() + b, fd.data() + b, (uint32_t)m, 20 /* core_private.cpp:77 */,
-                                          stream_base + (uint32_t)b, seed, costs.data() + b, &fl,
-                                          frame_costs ? frame_costs + b * sel_.size() : nullptr,
-                                          best_h ? best_h + b * sel_.size() : nullptr),
-                      "presync costs");
-            flags |= fl;
+            for (Shard& sh : shards_) // every device starts its part ...
+                hip_check(sh, rship_presync_enqueue(sh.ctx, kd.data() + b, fd.data() + b, (uint32_t)m, 20 /* core_private.cpp:77 */,
+                                                    stream_base + (uint32_t)b, seed, frame_costs != nullptr, best_h != nullptr),
+                          "presync");
+            combine(m, W, [&](Shard& sh, double* win, double* chunk) { // ... and is waited for in turn
+                uint32_t fl = 0;
+                const size_t nl = sh.sel.size();
+                if (frame_costs) fc.assign(m * nl + 1, 0.0);
+                if (best_h) bh.assign(m * nl + 1, 0);
+                hip_check(sh, rship_presync_collect(sh.ctx, (uint32_t)m, win, chunk, &fl, frame_costs ? fc.data() : nullptr,
+                                                    best_h ? bh.data() : nullptr),
+                          "presync");
+                flags |= fl;
+                for (size_t r = 0; r < m && (frame_costs || best_h); ++r)
+                    for (size_t j = 0; j < nl; ++j) {
+                        if (frame_costs) frame_costs[(b + r) * ns + sh.slot_global[j]] = fc[r * nl + j];
+                        if (best_h) best_h[(b + r) * ns + sh.slot_global[j]] = bh[r * nl + j];
+                    }
+            }, out + b * W);
         }
     }
+    *flags_out = flags;
+}
+
+// costs of a list of candidate delays on the current (single-window) selection, summed over ranks
+std::vector<double> SyncProblemHip::sweep(const std::vector<double>& delays, uint32_t stream_base, bool panics,
+                                          double* frame_costs, int32_t* best_h) {
+    const size_t n = delays.size();
+    std::vector<double> costs(n + 1, 0.0);
+    uint32_t flags = 0;
+    sweep_windows(delays, stream_base, costs.data(), &flags, frame_costs, best_h);
     // one exchange for the whole sweep; the flag bits ride along as small integers
     double fl[4] = {(double)((flags >> 0) & 1), (double)((flags >> 1) & 1), (double)((flags >> 2) & 1),
                     (double)((flags >> 3) & 1)};
@@ -776,53 +1104,75 @@ static void split_all(const std::vector<double>& delays, double fs, std::vector<
 }
 
 void SyncProblemHip::init_motion(const std::vector<double>& delays, uint32_t call_stride) {
-    if (sel_.empty()) return;
     std::vector<int32_t> kd;
     std::vector<float> fd;
     split_all(delays, fs_, kd, fd);
-    hip_check(rship_init_motion(dev_, kd.data(), fd.data(), 200 /* core_private.cpp:127 */, kStreamSyncInit + sync_calls,
-                                call_stride, seed),
-              "init motion");
+    for (Shard& sh : shards_)
+        if (!sh.sel.empty())
+            hip_check(sh, rship_init_motion(sh.ctx, kd.data(), fd.data(), 200 /* core_private.cpp:127 */,
+                                            kStreamSyncInit + sync_calls, call_stride, seed),
+                      "init motion");
 }
 
 void SyncProblemHip::opt_motion(const std::vector<double>& delays, uint64_t* stats) {
-    if (sel_.empty()) return;
     std::vector<int32_t> kd;
     std::vector<double> fd;
     split_all64(delays, fs_, kd, fd);
-    hip_check(rship_opt_motion(dev_, kd.data(), fd.data(), stats), "opt motion");
+    if (stats) stats[0] = stats[1] = stats[2] = 0;
+    for (Shard& sh : shards_) {
+        if (sh.sel.empty()) continue;
+        uint64_t st[3] = {0, 0, 0};
+        hip_check(sh, rship_opt_motion(sh.ctx, kd.data(), fd.data(), stats ? st : nullptr), "opt motion");
+        if (stats) { stats[0] += st[0]; stats[1] += st[1]; stats[2] += st[2]; }
+    }
 }
 
 // M and k of GuessMotion/GuessK in fp64 from the winners of init_motion (same delays), without optimising
 void SyncProblemHip::finish_init(const std::vector<double>& delays) {
-    if (sel_.empty()) return;
     std::vector<int32_t> kd;
     std::vector<double> fd;
     split_all64(delays, fs_, kd, fd);
-    hip_check(rship_finish_init(dev_, kd.data(), fd.data()), "finish init");
+    for (Shard& sh : shards_)
+        if (!sh.sel.empty()) hip_check(sh, rship_finish_init(sh.ctx, kd.data(), fd.data()), "finish init");
 }
 
 void SyncProblemHip::init_k_simple(const std::vector<double>& delays) {
-    if (sel_.empty()) return;
     std::vector<int32_t> kd;
     std::vector<double> fd;
     split_all64(delays, fs_, kd, fd);
-    hip_check(rship_init_k_simple(dev_, kd.data(), fd.data()), "init k (simplified)");
+    for (Shard& sh : shards_)
+        if (!sh.sel.empty()) hip_check(sh, rship_init_k_simple(sh.ctx, kd.data(), fd.data()), "init k (simplified)");
 }
 
-// per window: sum over its slots (and over ranks) of FrameState::Loss; delays is
+// per window: sum over its slots (over this object's devices and over ranks) of FrameState::Loss; delays is
 // [n_delays][n_windows] row-major (NaN = skip that window), outputs likewise
 void SyncProblemHip::loss(const std::vector<double>& delays, std::vector<double>& out_loss,
                           std::vector<double>* out_grad, bool simplified) {
-    const size_t n = delays.size();
+    const size_t n = delays.size(), W = n_windows_, nd = n / W;
     std::vector<double> buf(2 * n, 0.0);
     if (!sel_.empty() && n) {
         std::vector<int32_t> kd;
         std::vector<double> fd;
         split_all64(delays, fs_, kd, fd);
-        hip_check(rship_loss(dev_, kd.data(), fd.data(), (uint32_t)(n / n_windows_), buf.data(),
-                             out_grad ? buf.data() + n : nullptr, simplified ? RSHIP_LOSS_SIMPLIFIED : 0u),
-                  "loss");
+        for (Shard& sh : shards_)
+            hip_check(sh, rship_loss_enqueue(sh.ctx, kd.data(), fd.data(), (uint32_t)nd, out_grad != nullptr,
+                                             simplified ? RSHIP_LOSS_SIMPLIFIED : 0u),
+                      "loss");
+        // rows: the nd losses, then (with a gradient) the nd derivatives
+        const size_t rows = out_grad ? 2 * nd : nd;
+        std::vector<double> win(rows * W), cw, cg;
+        combine(rows, W, [&](Shard& sh, double* w_out, double* c_out) {
+            if (w_out) {
+                hip_check(sh, rship_loss_collect(sh.ctx, (uint32_t)nd, w_out, out_grad ? w_out + nd * W : nullptr, nullptr, nullptr),
+                          "loss");
+            } else {
+                hip_check(sh, rship_loss_collect(sh.ctx, (uint32_t)nd, nullptr, nullptr, c_out,
+                                                 out_grad ? c_out + nd * (size_t)sh.n_chunks : nullptr),
+                          "loss");
+            }
+        }, win.data());
+        std::copy(win.begin(), win.begin() + n, buf.begin());
+        if (out_grad) std::copy(win.begin() + n, win.end(), buf.begin() + n);
     }
     reduce(buf.data(), out_grad ? 2 * n : n);
     out_loss.assign(buf.begin(), buf.begin() + n);
@@ -843,7 +1193,8 @@ void SyncProblemHip::select_windows(const std::vector<int64_t>& begins, const st
         if (frames_.at(table_ids_[i]).n < 2)
             panic("sync: frame " + std::to_string(table_ids_[i]) + " has fewer than 2 tracks");
     n_windows_ = std::max<size_t>(1, begins.size());
-    hip_check(rship_select_slots(dev_, sel_.data(), (uint32_t)sel_.size(), off.data(), (uint32_t)n_windows_), "select slots");
+    if (begins.empty()) off.assign(2, 0u);
+    apply_selection(sel_, off, nullptr, nullptr);
 }
 
 // core_private.cpp:211-334 for W independent windows advanced in lock-step (W = 1 is
@@ -987,13 +1338,13 @@ void SyncProblemHip::presync_windows(double initial_delay, const std::vector<int
     }
     sel_ = keep;
     n_windows_ = 1;
-    hip_check(rship_select_frames(dev_, sel_.data(), (uint32_t)sel_.size()), "select frames");
     std::vector<uint32_t> seg_idx, seg_off(W + 1, 0);
     for (size_t w = 0; w < W; ++w) {
         for (uint32_t i : sel_)
             if (table_ids_[i] >= begins[w] && table_ids_[i] < ends_excl[w]) seg_idx.push_back(slot_of[i]);
         seg_off[w + 1] = (uint32_t)seg_idx.size();
     }
+    apply_selection(sel_, {}, &seg_idx, &seg_off); // one ungrouped selection, W (possibly overlapping) windows to sum
     std::vector<double> delays; // :69-70
     for (double delay = initial_delay - search_radius; delay < initial_delay + search_radius; delay += search_step) {
         delays.push_back(delay);
@@ -1003,20 +1354,7 @@ void SyncProblemHip::presync_windows(double initial_delay, const std::vector<int
     const size_t n = delays.size();
     std::vector<double> cw(n * W + 4, 0.0);
     uint32_t flags = 0;
-    if (!sel_.empty()) {
-        std::vector<int32_t> kd;
-        std::vector<float> fd;
-        split_all(delays, fs_, kd, fd);
-        const size_t slice = std::max<size_t>(64, (size_t)(256u << 20) / (8 * sel_.size())); // as in sweep()
-        for (size_t b = 0; b < n; b += slice) {
-            uint32_t fl = 0;
-            hip_check(rship_presync_window_costs(dev_, kd.data() + b, fd.data() + b, (uint32_t)std::min(slice, n - b), 20,
-                                                 (uint32_t)b, seed, seg_idx.data(), seg_off.data(), (uint32_t)W,
-                                                 cw.data() + b * W, &fl, nullptr, nullptr),
-                      "presync window costs");
-            flags |= fl;
-        }
-    }
+    sweep_windows(delays, 0, cw.data(), &flags, nullptr, nullptr);
     for (int b = 0; b < 4; ++b) cw[n * W + b] = (double)((flags >> b) & 1);
     reduce(cw.data(), cw.size());
     uint32_t all = 0;
@@ -1168,8 +1506,7 @@ int rssync_ext_set_max_outer_iters(rssync_problem* p, int iters) { p->impl->max_
 int rssync_ext_set_verbose(rssync_problem* p, int verbose) { p->impl->verbose = verbose != 0; return 0; }
 int rssync_ext_set_lbfgs_reeval(rssync_problem* p, int reeval) {
     return guarded([&] {
-        if (rship_set_option(p->impl->dev(), RSHIP_OPT_LBFGS_REEVAL, reeval))
-            panic(std::string("hip: set option: ") + rship_last_error(p->impl->dev()));
+        p->impl->set_option(RSHIP_OPT_LBFGS_REEVAL, reeval);
     });
 }
 int rssync_ext_lbfgs_best_not_last(rssync_problem* p, uint64_t* count) {
@@ -1178,6 +1515,7 @@ int rssync_ext_lbfgs_best_not_last(rssync_problem* p, uint64_t* count) {
 }
 int rssync_ext_set_stream(rssync_problem* p, void* hip_stream) {
     return guarded([&] {
+        if (p->impl->n_devices() != 1) panic("set-stream: this object drives several GPUs; each keeps its own stream");
         if (rship_set_stream(p->impl->dev(), hip_stream)) panic(std::string("hip: set stream: ") + rship_last_error(p->impl->dev()));
     });
 }
@@ -1244,9 +1582,7 @@ int rssync_ext_problem_matrix(rssync_problem* p, int64_t frame, double delay, fl
         s->ensure_device();
         if (!s->has_frame(frame)) panic("problem_matrix: unknown frame");
         s->select(frame, frame + 1);
-        DelaySplit ds = split_delay(delay, s->sample_rate());
-        if (rship_debug_problem(s->dev(), 0, ds.kd, ds.fd, P, dP, (uint32_t)cap_rows))
-            panic(std::string("hip: debug problem: ") + rship_last_error(s->dev()));
+        s->debug_problem(frame, delay, P, dP, nullptr, nullptr, cap_rows);
         if (n_rows) *n_rows = s->frame_tracks(frame);
     });
 }
@@ -1260,8 +1596,7 @@ int rssync_ext_init_motion(rssync_problem* p, double delay, int64_t frame_begin,
         s->init_motion({delay});
         s->finish_init({delay});
         s->sync_calls++;
-        uint32_t n = 0;
-        if (rship_get_motion(s->dev(), M, k, (uint32_t)cap, &n)) panic(std::string("hip: get motion: ") + rship_last_error(s->dev()));
+        const uint32_t n = s->get_motion(M, k, (uint32_t)cap);
         if (n_frames) *n_frames = (int)n;
     });
 }
@@ -1272,8 +1607,7 @@ int rssync_ext_opt_motion(rssync_problem* p, double delay, double* M, double* k,
         SyncProblemHip* s = p->impl;
         uint64_t st[3] = {0, 0, 0};
         s->opt_motion({delay}, st);
-        uint32_t n = 0;
-        if (rship_get_motion(s->dev(), M, k, (uint32_t)cap, &n)) panic(std::string("hip: get motion: ") + rship_last_error(s->dev()));
+        const uint32_t n = s->get_motion(M, k, (uint32_t)cap);
         if (n_frames) *n_frames = (int)n;
         if (iters) *iters = st[0];
         if (evals) *evals = st[1];
@@ -1283,8 +1617,7 @@ int rssync_ext_opt_motion(rssync_problem* p, double delay, double* M, double* k,
 
 int rssync_ext_set_motion(rssync_problem* p, const double* M, const double* k, int n_frames) {
     return guarded([&] {
-        if (rship_set_motion(p->impl->dev(), M, k, (uint32_t)n_frames))
-            panic(std::string("hip: set motion: ") + rship_last_error(p->impl->dev()));
+        p->impl->set_motion(M, k, (uint32_t)n_frames);
     });
 }
 
@@ -1347,9 +1680,8 @@ int rssync_ext_init_k_simplified(rssync_problem* p, double delay, int64_t frame_
         s->ensure_device();
         s->select(frame_begin, frame_end == std::numeric_limits<int64_t>::max() ? frame_end : frame_end + 1);
         s->init_k_simple({delay});
-        std::vector<double> M((size_t)std::max(cap, 0) * 3);
-        uint32_t n = 0;
-        if (rship_get_motion(s->dev(), M.data(), k, (uint32_t)cap, &n)) panic(std::string("hip: get motion: ") + rship_last_error(s->dev()));
+        std::vector<double> M((size_t)std::max(cap, 0) * 3 + 3);
+        const uint32_t n = s->get_motion(M.data(), k, (uint32_t)cap);
         if (n_frames) *n_frames = (int)n;
     });
 }
@@ -1370,9 +1702,7 @@ int rssync_ext_problem_matrix64(rssync_problem* p, int64_t frame, double delay, 
         s->ensure_device();
         if (!s->has_frame(frame)) panic("problem_matrix: unknown frame");
         s->select(frame, frame + 1);
-        DelaySplit64 ds = split_delay64(delay, s->sample_rate());
-        if (rship_debug_problem64(s->dev(), 0, ds.kd, ds.fd, P, dP, (uint32_t)cap_rows))
-            panic(std::string("hip: debug problem: ") + rship_last_error(s->dev()));
+        s->debug_problem(frame, delay, nullptr, nullptr, P, dP, cap_rows);
         if (n_rows) *n_rows = s->frame_tracks(frame);
     });
 }
@@ -1414,7 +1744,7 @@ int rssync_ext_frame_rays(rssync_problem* p, int64_t frame, float* a4, float* b4
             const size_t cnt = s->frame_tracks(frame);
             if (n) *n = cnt;
             if (cnt > cap) panic("frame_rays: output too small");
-            if (rship_debug_rays(s->dev(), i, a4, b4, (uint32_t)cap)) panic(std::string("hip: debug rays: ") + rship_last_error(s->dev()));
+            s->debug_rays(frame, a4, b4, cap);
             return;
         }
     });
@@ -1456,10 +1786,17 @@ int rssync_ext_sync_trace(rssync_problem* p, double* trace, int cap_rows, int* n
 
 void* rssync_ext_device_context(rssync_problem* p) { return p->impl->dev(); }
 
-int rssync_ext_profile(rssync_problem* p, int enable) { return rship_profile_enable(p->impl->dev(), enable); }
+int rssync_ext_profile(rssync_problem* p, int enable) { return guarded([&] { p->impl->profile_enable(enable); }); }
 int rssync_ext_profile_get(rssync_problem* p, int kind, uint64_t* launches, double* total_ms) {
-    return rship_profile_get(p->impl->dev(), kind, launches, total_ms);
+    return guarded([&] { p->impl->profile_get(kind, launches, total_ms); });
 }
-int rssync_ext_profile_reset(rssync_problem* p) { return rship_profile_reset(p->impl->dev()); }
+int rssync_ext_profile_reset(rssync_problem* p) { return guarded([&] { p->impl->profile_reset(); }); }
+
+// Spread this object's frames over several GPUs of the process (device ordinals; the same ordinal may be
+// listed more than once).  Frames are re-uploaded by the next call that needs them.
+int rssync_ext_set_devices(rssync_problem* p, const int* device_ids, int n_devices) {
+    return guarded([&] { p->impl->set_devices(std::vector<int>(device_ids, device_ids + std::max(n_devices, 0))); });
+}
+int rssync_ext_device_count(rssync_problem* p) { return (int)p->impl->n_devices(); }
 
 } // extern "C"

@@ -49,6 +49,8 @@ SIGNATURES = {
     "rssync_ext_set_lbfgs_reeval": (C.c_int, [C.c_void_p, C.c_int]),
     "rssync_ext_lbfgs_best_not_last": (C.c_int, [C.c_void_p, _PU64]),
     "rssync_ext_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rssync_ext_set_devices": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
+    "rssync_ext_device_count": (C.c_int, [C.c_void_p]),
     "rssync_ext_set_reduce_hook": (C.c_int, [C.c_void_p, REDUCE_FN, C.c_void_p]),
     "rssync_ext_rccl_unique_id": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rssync_ext_rccl_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -219,6 +221,14 @@ class SyncProblem:
         n = C.c_uint64()
         self._lib.rssync_ext_lbfgs_best_not_last(self._h, C.byref(n))
         return n.value
+
+    def set_devices(self, device_ids):
+        """Spread this object's frames over several GPUs of the process (list of device ordinals)."""
+        ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        self._check(self._lib.rssync_ext_set_devices(self._h, ids, len(device_ids)))
+
+    def device_count(self):
+        return int(self._lib.rssync_ext_device_count(self._h))
 
     def set_stream(self, hip_stream_ptr):
         self._check(self._lib.rssync_ext_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)))

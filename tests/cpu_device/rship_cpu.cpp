@@ -38,6 +38,13 @@ struct rship_ctx {
     std::vector<uint32_t> sel, grp, grp_off; // slots, slot -> window, window offsets
     std::vector<double> M, k;                // per slot
     int lbfgs_reeval = 0;
+    // reduction plan and the results of the last *_enqueue
+    std::vector<uint32_t> plan_idx, plan_chunk_off, plan_win_off;
+    bool plan_has_idx = false;
+    std::vector<double> win_out, chunk_out, frame_cost;
+    std::vector<int32_t> best_h;
+    uint32_t pend_rows = 0, pend_flags = 0;
+    bool pend_grad = false;
     std::vector<int32_t> init_h; // per slot: winning hypothesis of a pending GuessMotion, or kNone
     uint64_t init_seed = 0;
     uint32_t init_stream = 0, init_stride = 0;
@@ -138,7 +145,7 @@ float clampk(float k) { return (k < 10.f) ? 10.f : ((1000.f < k) ? 1000.f : k); 
 extern "C" {
 
 int rship_max_tracks(void) { return 2048; }
-int rship_create(rship_ctx** out, int) { *out = new rship_ctx(); return 0; }
+int rship_create(rship_ctx** out, int) { *out = new rship_ctx(); return 0; } // any device ordinal: a fake device
 void rship_destroy(rship_ctx* c) { delete c; }
 const char* rship_last_error(const rship_ctx* c) { return c->err.c_str(); }
 int rship_set_stream(rship_ctx*, void*) { return 0; }
@@ -248,15 +255,49 @@ int rship_select_slots(rship_ctx* c, const uint32_t* idx, uint32_t n, const uint
 }
 int rship_select_frames(rship_ctx* c, const uint32_t* idx, uint32_t n) { return rship_select_slots(c, idx, n, nullptr, 1); }
 
-int rship_presync_window_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand, uint32_t n_hyp,
-                               uint32_t stream_base, uint64_t seed, const uint32_t* seg_idx, const uint32_t* seg_off,
-                               uint32_t n_win, double* costs, uint32_t* flags, double* frame_costs, int32_t* best_h) {
+int rship_set_plan(rship_ctx* c, const uint32_t* plan_idx, uint32_t plan_len, const uint32_t* chunk_off, uint32_t n_chunks,
+                   const uint32_t* win_chunk_off, uint32_t n_win) {
+    if (n_win < 1 || win_chunk_off[0] != 0 || win_chunk_off[n_win] != n_chunks) return fail(c, "plan: bad window offsets");
+    if (n_chunks && (chunk_off[0] != 0 || chunk_off[n_chunks] != plan_len)) return fail(c, "plan: bad chunk offsets");
+    c->plan_has_idx = plan_idx != nullptr;
+    c->plan_idx.assign(plan_idx ? plan_idx : chunk_off, plan_idx ? plan_idx + plan_len : chunk_off);
+    if (n_chunks) c->plan_chunk_off.assign(chunk_off, chunk_off + n_chunks + 1);
+    else c->plan_chunk_off.assign(1, 0u);
+    c->plan_win_off.assign(win_chunk_off, win_chunk_off + n_win + 1);
+    return 0;
+}
+
+namespace {
+// plan_sum_kernel: chunks summed sequentially, windows = sequential sum of their chunks
+void plan_sum(rship_ctx* c, const std::vector<double>& in, uint32_t rows, size_t cols) {
+    const size_t nc = c->plan_chunk_off.size() - 1, nw = c->plan_win_off.size() - 1;
+    c->chunk_out.assign((size_t)rows * nc + 1, 0.0);
+    c->win_out.assign((size_t)rows * nw + 1, 0.0);
+    for (uint32_t r = 0; r < rows; ++r)
+        for (size_t w = 0; w < nw; ++w) {
+            double tot = 0.0;
+            for (uint32_t ch = c->plan_win_off[w]; ch < c->plan_win_off[w + 1]; ++ch) {
+                double acc = 0.0;
+                for (uint32_t j = c->plan_chunk_off[ch]; j < c->plan_chunk_off[ch + 1]; ++j)
+                    acc += in[(size_t)r * cols + (c->plan_has_idx ? c->plan_idx[j] : j)];
+                c->chunk_out[(size_t)r * nc + ch] = acc;
+                tot += acc;
+            }
+            c->win_out[(size_t)r * nw + w] = tot;
+        }
+}
+} // namespace
+
+int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand, uint32_t n_hyp,
+                          uint32_t stream_base, uint64_t seed, int, int) {
     uint32_t fl = 0;
-    if (n_win < 1) n_win = 1;
-    std::vector<double> fc(c->sel.size());
+    c->pend_rows = 0;
+    const size_t ns = c->sel.size();
+    if (!n_cand || !ns) return 0;
+    c->frame_cost.assign((size_t)n_cand * ns, 0.0);
+    c->best_h.assign((size_t)n_cand * ns, 0);
     for (uint32_t ci = 0; ci < n_cand; ++ci) {
-        double total = 0;
-        for (size_t s = 0; s < c->sel.size(); ++s) {
+        for (size_t s = 0; s < ns; ++s) {
             const rship_frame& fr = c->frames[c->sel[s]];
             Rows t = unit_rows(c, fr, kd[ci], fd[ci]);
             if (t.bad) fl |= RSHIP_BAD_P;
@@ -279,31 +320,32 @@ int rship_presync_window_costs(rship_ctx* c, const int32_t* kd, const float* fd,
                 if (!std::isfinite(rho)) fl |= RSHIP_BAD_RHO;
                 acc += std::sqrt(rho);
             }
-            double cost = std::sqrt(acc);
-            total += cost;
-            fc[s] = cost;
-            if (frame_costs) frame_costs[(size_t)ci * c->sel.size() + s] = cost;
-            if (best_h) best_h[(size_t)ci * c->sel.size() + s] = bh;
-        }
-        if (!seg_off) {
-            costs[ci] = total;
-        } else {
-            for (uint32_t w = 0; w < n_win; ++w) {
-                double t = 0;
-                for (uint32_t j = seg_off[w]; j < seg_off[w + 1]; ++j) t += fc[seg_idx ? seg_idx[j] : j];
-                costs[(size_t)ci * n_win + w] = t;
-            }
+            c->frame_cost[(size_t)ci * ns + s] = std::sqrt(acc);
+            c->best_h[(size_t)ci * ns + s] = bh;
         }
     }
-    if (flags) *flags = fl;
+    plan_sum(c, c->frame_cost, n_cand, ns);
+    c->pend_rows = n_cand;
+    c->pend_flags = fl;
     return 0;
 }
 
-int rship_presync_costs(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand, uint32_t n_hyp,
-                        uint32_t stream_base, uint64_t seed, double* costs, uint32_t* flags, double* frame_costs,
-                        int32_t* best_h) {
-    return rship_presync_window_costs(c, kd, fd, n_cand, n_hyp, stream_base, seed, nullptr, nullptr, 1, costs, flags,
-                                      frame_costs, best_h);
+int rship_presync_collect(rship_ctx* c, uint32_t n_cand, double* win_costs, double* chunk_costs, uint32_t* flags,
+                          double* frame_costs, int32_t* best_h) {
+    const size_t nc = c->plan_chunk_off.size() - 1, nw = c->plan_win_off.size() - 1, ns = c->sel.size();
+    if (flags) *flags = 0;
+    if (!c->pend_rows) {
+        if (win_costs) std::fill(win_costs, win_costs + (size_t)n_cand * nw, 0.0);
+        if (chunk_costs) std::fill(chunk_costs, chunk_costs + (size_t)n_cand * nc, 0.0);
+        return 0;
+    }
+    if (win_costs) std::copy(c->win_out.begin(), c->win_out.begin() + (size_t)n_cand * nw, win_costs);
+    if (chunk_costs) std::copy(c->chunk_out.begin(), c->chunk_out.begin() + (size_t)n_cand * nc, chunk_costs);
+    if (flags) *flags = c->pend_flags;
+    if (frame_costs) std::copy(c->frame_cost.begin(), c->frame_cost.begin() + (size_t)n_cand * ns, frame_costs);
+    if (best_h) std::copy(c->best_h.begin(), c->best_h.begin() + (size_t)n_cand * ns, best_h);
+    c->pend_rows = 0;
+    return 0;
 }
 
 int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_hyp, uint32_t stream,
@@ -471,13 +513,15 @@ int rship_init_k_simple(rship_ctx* c, const int32_t* kd, const double* fd) {
 
 int rship_opt_motion_detail(rship_ctx* c, const int32_t*, const double*, uint32_t*, uint32_t) { return fail(c, "opt_motion_detail: device only"); }
 
-int rship_loss(rship_ctx* c, const int32_t* kd, const double* fd, uint32_t n_delays, double* loss, double* grad,
-               uint32_t flags) {
+int rship_loss_enqueue(rship_ctx* c, const int32_t* kd, const double* fd, uint32_t n_delays, int want_grad, uint32_t flags) {
     const bool simple = (flags & RSHIP_LOSS_SIMPLIFIED) != 0;
-    const size_t ng = c->grp_off.size() - 1;
+    const size_t ng = c->grp_off.size() - 1, ns = c->sel.size();
+    c->pend_rows = 0;
+    if (!n_delays || !ns) return 0;
+    const uint32_t rows = want_grad ? 2 * n_delays : n_delays;
+    std::vector<double> part((size_t)rows * ns, 0.0); // [loss rows][grad rows] x slots, like the kernel
     for (uint32_t b = 0; b < n_delays; ++b) {
         for (size_t w = 0; w < ng; ++w) {
-            double L = 0, G = 0;
             const int32_t kdw = kd[b * ng + w];
             const double fdw = fd[b * ng + w];
             for (uint32_t sl = c->grp_off[w]; fdw == fdw && sl < c->grp_off[w + 1]; ++sl) {
@@ -488,24 +532,44 @@ int rship_loss(rship_ctx* c, const int32_t* kd, const double* fd, uint32_t n_del
                 double Lf = 0, Gf = 0;
                 for (uint32_t i = 0; i < fr.n_rays; ++i) {
                     d3 P, dP;
-                    row64(c, fr, i, kdw, fdw, P, grad ? &dP : nullptr);
+                    row64(c, fr, i, kdw, fdw, P, want_grad ? &dP : nullptr);
                     double wgt;
                     if (simple) {
                         Lf += rs::log1p_rcp_f64(rs::dot(P, P) * inv_s, &wgt);
-                        if (grad) Gf += wgt * 2.0 * inv_s * rs::dot(P, dP);
+                        if (want_grad) Gf += wgt * 2.0 * inv_s * rs::dot(P, dP);
                     } else {
                         const double pm = rs::dot(P, Mv), u = pm * pm * inv_s;
                         Lf += rs::log1p_rcp_f64(u, &wgt);
-                        if (grad) Gf += wgt * 2.0 * pm * inv_s * rs::dot(dP, Mv);
+                        if (want_grad) Gf += wgt * 2.0 * pm * inv_s * rs::dot(dP, Mv);
                     }
                 }
-                L += Lf;
-                G += Gf * c->fs;
+                part[(size_t)b * ns + sl] = Lf;
+                if (want_grad) part[(size_t)(n_delays + b) * ns + sl] = Gf * c->fs;
             }
-            loss[b * ng + w] = L;
-            if (grad) grad[b * ng + w] = G;
         }
     }
+    plan_sum(c, part, rows, ns);
+    c->pend_rows = rows;
+    c->pend_grad = want_grad != 0;
+    return 0;
+}
+
+int rship_loss_collect(rship_ctx* c, uint32_t n_delays, double* win_loss, double* win_grad, double* chunk_loss,
+                       double* chunk_grad) {
+    const size_t nc = c->plan_chunk_off.size() - 1, nw = c->plan_win_off.size() - 1;
+    const size_t wn = (size_t)n_delays * nw, cn = (size_t)n_delays * nc;
+    if (!c->pend_rows) {
+        if (win_loss) std::fill(win_loss, win_loss + wn, 0.0);
+        if (win_grad) std::fill(win_grad, win_grad + wn, 0.0);
+        if (chunk_loss) std::fill(chunk_loss, chunk_loss + cn, 0.0);
+        if (chunk_grad) std::fill(chunk_grad, chunk_grad + cn, 0.0);
+        return 0;
+    }
+    if (win_loss) std::copy(c->win_out.begin(), c->win_out.begin() + wn, win_loss);
+    if (win_grad && c->pend_grad) std::copy(c->win_out.begin() + wn, c->win_out.begin() + 2 * wn, win_grad);
+    if (chunk_loss) std::copy(c->chunk_out.begin(), c->chunk_out.begin() + cn, chunk_loss);
+    if (chunk_grad && c->pend_grad) std::copy(c->chunk_out.begin() + cn, c->chunk_out.begin() + 2 * cn, chunk_grad);
+    c->pend_rows = 0;
     return 0;
 }
 

@@ -1,5 +1,11 @@
 """The thesis' accuracy metric on a synthetic clock-drift scenario: delays at sync points, line
-fit, RMSE (python/plot_sync.py) -- for the HIP library and, on the same inputs, the CPU oracle."""
+fit, RMSE (python/plot_sync.py) -- for the HIP library and, on the same inputs, the CPU oracle.
+
+Also separates what the device adds from what the algorithm does to itself on noisy data:
+ * first_sync: ONE Sync call per sync point from the oracle's PreSync result -- device vs oracle;
+ * chain: the driver's PreSync + 4 chained Sync calls (core_testcode.cpp:303-316) -- device vs oracle;
+ * oracle_self: the oracle's own chain started 1e-9 s away from its PreSync result vs its unperturbed
+   chain: the sensitivity of the reference algorithm to a perturbation far below any tolerance."""
 import os, sys, json, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -14,6 +20,7 @@ NOISE = float(os.environ.get("NOISE", 1e-3)); OUTL = float(os.environ.get("OUTLI
 g = synth.make_gyro(0, (F + 2) / synth.FPS, seed=SEED)
 frames = list(synth.make_frames(g, 0, F, N, seed=SEED, drift=DRIFT, noise=NOISE, outliers=OUTL))
 pos = quality.sync_points_auto(0, F, WINDOW, DIST)
+threads = os.cpu_count() or 1
 
 
 def fill(p):
@@ -23,23 +30,43 @@ def fill(p):
     return p
 
 
+def oracle_chain(eps=0.0):
+    o = fill(OracleProblem(seed=SEED, threads=threads, faithful=False))
+    out, pre = [], []
+    for p0 in pos:
+        d = o.PreSync(0.0, p0, p0 + WINDOW, 0.001, 0.1)[1]
+        pre.append(d)
+        d += eps
+        for _ in range(4):
+            d = o.Sync(d, p0, p0 + WINDOW, 0.0, 0.1)[1]
+        out.append(d)
+    return np.array(out), np.array(pre)
+
+
 h = fill(rssync_amd.SyncProblem(seed=SEED))
 t = time.perf_counter(); _, dh = h.sync_points(pos, WINDOW, 0.0, 0.001, 0.1); th = time.perf_counter() - t
-o = fill(OracleProblem(seed=SEED, threads=os.cpu_count() or 1, faithful=False))
-t = time.perf_counter()
-do = []
-for p0 in pos:
-    d = o.PreSync(0.0, p0, p0 + WINDOW, 0.001, 0.1)[1]
-    for _ in range(4):
-        d = o.Sync(d, p0, p0 + WINDOW, 0.0, 0.1)[1]
-    do.append(d)
-to = time.perf_counter() - t
-do = np.array(do)
+t = time.perf_counter(); do, pre_o = oracle_chain(); to = time.perf_counter() - t
+do_eps, _ = oracle_chain(1e-9)
+
+# one Sync call per sync point, both sides from the oracle's PreSync delay, fresh objects (call counter 0)
+h1 = fill(rssync_amd.SyncProblem(seed=SEED))
+o1 = fill(OracleProblem(seed=SEED, threads=threads, faithful=False))
+first = []
+for p0, d0 in zip(pos, pre_o):
+    first.append(h1.Sync(float(d0), p0, p0 + WINDOW, 0.0, 0.1)[1] - o1.Sync(float(d0), p0, p0 + WINDOW, 0.0, 0.1)[1])
+first = np.array(first)
+
 mid = (np.array(pos) + WINDOW / 2) / synth.FPS
 truth = synth.D_TRUE + DRIFT * mid
 sh, ih, rh = quality.linear_fit_rmse(pos, 1e3 * dh)
 so, io, ro = quality.linear_fit_rmse(pos, 1e3 * do)
 print(json.dumps({"frames": F, "tracks": N, "window": WINDOW, "positions": len(pos), "drift_ms_per_frame": 1e3 * DRIFT / synth.FPS,
+                  "noise_rad": NOISE, "outliers": OUTL,
                   "hip": {"slope": sh, "intercept": ih, "rmse_ms": rh, "max_err_vs_truth_ms": float(1e3 * np.abs(dh - truth).max()), "s": round(th, 3)},
                   "oracle": {"slope": so, "intercept": io, "rmse_ms": ro, "max_err_vs_truth_ms": float(1e3 * np.abs(do - truth).max()), "s": round(to, 3)},
-                  "max_abs_hip_minus_oracle_ms": float(1e3 * np.abs(dh - do).max())}))
+                  "first_sync_max_abs_hip_minus_oracle_ms": float(1e3 * np.abs(first).max()),
+                  "first_sync_median_abs_hip_minus_oracle_ms": float(1e3 * np.median(np.abs(first))),
+                  "chain_max_abs_hip_minus_oracle_ms": float(1e3 * np.abs(dh - do).max()),
+                  "chain_median_abs_hip_minus_oracle_ms": float(1e3 * np.median(np.abs(dh - do))),
+                  "oracle_self_max_abs_ms_after_1e-9_s_perturbation": float(1e3 * np.abs(do_eps - do).max()),
+                  "oracle_self_median_abs_ms_after_1e-9_s_perturbation": float(1e3 * np.median(np.abs(do_eps - do)))}))

@@ -78,6 +78,16 @@ def _check_product(h, gold):
     dd, dc = h.DebugPreSync(0.0, f0, f0 + F, 0.1, 9)
     np.testing.assert_array_equal(dd, gold["debug_delays"])
     np.testing.assert_allclose(dc, gold["debug_costs"], rtol=5e-3)
+    # Sync from the stored PreSync result against the stored trace (24 x 128, noise + outliers): the fp64
+    # Sync path follows the CPU solver within the north-star 1e-4 s at every outer iteration
+    c2, d2 = h.Sync(float(gold["presync_result"][1]), f0, f0 + F - 1, 0.0, 0.1)
+    tr = h.sync_trace()
+    assert abs(d2 - gold["sync_result"][1]) < 1e-4
+    assert c2 == pytest.approx(gold["sync_result"][0], rel=2e-3)
+    assert abs(len(tr) - len(gold["sync_trace"])) <= 2
+    n = min(len(tr), len(gold["sync_trace"]))
+    np.testing.assert_allclose(tr[:n, 0], gold["sync_trace"][:n, 0], atol=1e-4)
+    np.testing.assert_allclose(tr[:n, 2], gold["sync_trace"][:n, 2], rtol=2e-3)
     h2 = type(h)(seed=int(gold["seed"]), _lib=h._lib)
     h2.SetGyroQuaternionsTimestamped(gold["ts_us"], gold["ts_quats"])
     assert h2.gyro_info()[:2] == (float(gold["ts_fs"]), float(gold["ts_start"]))

@@ -118,30 +118,50 @@ def test_init_motion_matches_oracle(ora_small, small_case):
         Mo, bh, med = ora_small.guess_motion(f, d0, 200, ora.STREAM_SYNC_INIT + 0)
         # same winning pair of rows -> same direction up to the fp32 error of the rows themselves
         # (P = ar x br cancels to ~1e-2, so ~1e-5 relative per row)
-        if np.abs(Mh[f] - Mo).max() < 5e-4:
+        # the search over the 200 hypotheses runs in fp32 (it may flip at a near-tie of two quantiles);
+        # the winner's direction and k are then recomputed in fp64 from the fp64 rows
+        if np.abs(Mh[f] - Mo).max() < 1e-12:
             agree += 1
             P = ora_small.problem_matrix(f, d0)
             ko = np.clip(100 / np.linalg.norm(P @ Mo), 10, 1000)
-            assert kh[f] == pytest.approx(ko, rel=2e-3)
-    assert agree >= F - 2
+            assert kh[f] == pytest.approx(ko, rel=1e-12)
+    assert agree >= F - 1
 
 
 def test_loss_and_analytic_gradient(hip_small, ora_small, small_case):
+    """Sync's objective runs in fp64 on the device (fp64 rays, fp64 spline): the loss agrees with the
+    CPU solver to 1e-12, the analytic d/d-delay with the oracle's analytic one to 1e-10 and with the
+    reference's +-1e-6 s central difference (core_private.cpp:96-97,112) to that difference's own error"""
     F = small_case["F"]
     d0 = 0.036
     Mh, kh = hip_small.init_motion(d0, 0, F - 1)
     delays = [d0, d0 + 1e-3, 0.0, -0.17]
     Lh, Gh = hip_small.loss(delays, grad=True)
     for j, dd in enumerate(delays):
-        L = Gn = 0.0
+        L = Gn = Ga = 0.0
         for f in range(F):
             l, dn, da, _ = ora_small.loss(f, dd, Mh[f], kh[f])
             L += l
-            Gn += dn  # the reference's central difference (core_private.cpp:96-97,112)
-        assert Lh[j] == pytest.approx(L, rel=1e-6)  # fp32 terms, fp64 accumulation
-        assert Gh[j] == pytest.approx(Gn, rel=2e-4, abs=2e-4 * abs(Lh[j]))
-    # loss-only path gives the same numbers
-    np.testing.assert_allclose(hip_small.loss(delays), Lh, rtol=1e-6)  # packed (loss) vs scalar (gradient) rotation
+            Gn += dn
+            Ga += da
+        assert Lh[j] == pytest.approx(L, rel=1e-12)
+        assert Gh[j] == pytest.approx(Ga, rel=1e-10, abs=1e-10 * abs(Lh[j]))
+        assert Gh[j] == pytest.approx(Gn, rel=2e-6, abs=2e-6 * abs(Lh[j]))
+    # loss-only launches give the same numbers
+    np.testing.assert_allclose(hip_small.loss(delays), Lh, rtol=1e-14)
+
+
+def test_fp64_residual_matrix_matches_the_cpu_solver(hip_small, ora_small, small_case):
+    """the rows the Sync kernels work on (fp64 streams packed on the device from the raw records)"""
+    N = small_case["N"]
+    fs, start, n = ora_small.gyro_info()
+    for frame, delay in [(0, 0.0), (3, 0.0371), (63, -0.15), (5, -5.0), (5, n / fs + 3.0)]:
+        P, dP = hip_small.problem_matrix64(frame, delay, N, deriv=True)
+        Po = ora_small.problem_matrix(frame, delay)
+        assert np.abs(P - Po).max() < 1e-13 * max(1.0, np.abs(Po).max())
+        eps = 1e-6
+        dPo = (ora_small.problem_matrix(frame, delay + eps) - ora_small.problem_matrix(frame, delay - eps)) / (2 * eps)
+        assert np.abs(dP - dPo).max() < 1e-6 * max(1.0, np.abs(dPo).max())
 
 
 def test_motion_optimiser_against_oracle_from_identical_starts(ora_small, small_case):
@@ -160,15 +180,17 @@ def test_motion_optimiser_against_oracle_from_identical_starts(ora_small, small_
     Lo_sum = 0.0
     for f in range(F):
         Mo, it, ev, fl = ora_small.lbfgs_motion(f, d0, Mh[f], kh[f])
-        Lo_sum += fl
+        lo = ora_small.loss(f, d0, Mo, kh[f])[0]
+        Lo_sum += lo
         lh = ora_small.loss(f, d0, M2[f], k2[f])[0]
-        if abs(lh - fl) <= 1e-5 * fl:
+        # the loss does not depend on |M| (core_private.cpp:120): compare directions and losses
+        if np.abs(M2[f] / np.linalg.norm(M2[f]) - Mo / np.linalg.norm(Mo)).max() < 1e-6 and abs(lh - lo) <= 1e-9 * lo:
             same += 1
-    # per-frame trajectories coincide for most frames; a 1e-7 perturbation sends the rest into a
-    # different basin of the non-convex loss (the fp64 oracle does the same when its own start is
-    # rounded to fp32, see test below)
-    assert same >= 0.7 * F
-    assert L1 == pytest.approx(Lo_sum, rel=1e-2)
+    # fp64 rows, fp64 objective: the per-frame trajectories follow the CPU solver's; what is left is
+    # the order of the sums (wave reductions vs a sequential loop), which the optimiser can amplify on
+    # a frame whose line search sits at a branch
+    assert same >= 0.95 * F
+    assert L1 == pytest.approx(Lo_sum, rel=1e-6)
 
 
 def test_sync_on_clean_data_recovers_truth_and_oracle(clean_case):
@@ -190,27 +212,25 @@ def test_sync_on_clean_data_recovers_truth_and_oracle(clean_case):
     assert tr.shape[1] == 6 and 6 <= len(tr) <= 400
 
 
-def test_sync_on_noisy_data_is_as_close_to_oracle_as_oracle_is_to_itself(small_case):
-    """With 10 % outliers the optimiser is chaotic: rounding the oracle's OWN inputs to fp32 moves
-    its answer by about as much as the device's answer differs.  Assert the device is within 3x of
-    that intrinsic sensitivity (and within 1 ms in absolute terms)."""
+def test_sync_on_noisy_data_matches_the_cpu_solver(small_case):
+    """Noise 1e-3 rad + 10 % outliers (BASELINE config 1): one Sync call from the same start stays
+    within the north-star 1e-4 s of the CPU solver, outer iteration by outer iteration.  (Round 1 ran
+    Sync in fp32 and was 1e-3 s away here: the optimiser amplifies a 1e-7 perturbation.)"""
     import rssync_amd
     from oracle.oracle import OracleProblem
     from conftest import fill
     F = small_case["F"]
     h = fill(rssync_amd.SyncProblem(seed=SEED), small_case)
     o = fill(OracleProblem(seed=SEED, threads=os.cpu_count() or 1, faithful=False), small_case)
-    o32 = OracleProblem(seed=SEED, threads=os.cpu_count() or 1, faithful=False)
-    g = small_case["gyro"]
-    o32.SetGyroQuaternions(g.quats.astype(np.float32), g.fs, g.t0)
-    for fr, ta, tb, ra, rb in small_case["frames"]:
-        o32.SetTrackResult(fr, ta, tb, ra.astype(np.float32), rb.astype(np.float32))
     ch, dh = h.Sync(0.036, 0, F - 1, 0.0, 0.2)
-    co, do = o.Sync(0.036, 0, F - 1, 0.0, 0.2)
-    c3, d3 = o32.Sync(0.036, 0, F - 1, 0.0, 0.2)
-    intrinsic = max(abs(d3 - do), 1e-4)
-    assert abs(dh - do) < max(3 * intrinsic, 1e-3)
-    assert ch == pytest.approx(co, rel=5e-2)
+    co, do, tro = o.sync_trace(0.036, 0, F - 1, 0.0, 0.2)
+    trh = h.sync_trace()
+    assert abs(dh - do) < 1e-4
+    n = min(len(trh), len(tro))
+    assert abs(len(trh) - len(tro)) <= 2
+    np.testing.assert_allclose(trh[:n, 0], tro[:n, 0], atol=1e-4)   # delay after every outer iteration
+    np.testing.assert_allclose(trh[:n, 2], tro[:n, 2], rtol=2e-3)   # loss at every outer iteration
+    assert ch == pytest.approx(co, rel=2e-3)
 
 
 def test_debug_presync_and_frame_ranges(hip_small, ora_small):
@@ -506,6 +526,11 @@ def test_cxx_driver_through_the_vtable(tmp_path, small_case):
     out_b = subprocess.run([str(exe), str(inp), "batched"], capture_output=True, text=True, env=env, cwd=tmp_path,
                            check=True).stdout
     assert out_b == out
+    # ONE object on several GPUs with no source change: RSSYNC_GPUS makes CreateSyncProblem() spread its frames
+    # over the listed devices (here two contexts on the one GPU of the box); the text must not change
+    out_m = subprocess.run([str(exe), str(inp)], capture_output=True, text=True, env=dict(env, RSSYNC_GPUS="0,0"),
+                           cwd=tmp_path, check=True).stdout
+    assert out_m == out
 
 
 def test_batched_windows_equal_sequential_calls(small_case):

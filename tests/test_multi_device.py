@@ -1,0 +1,101 @@
+"""One object, several GPUs (rssync_ext_set_devices / RSSYNC_GPUS): the frames are spread over the devices in
+contiguous blocks cut at multiples of 64 frames, every device works on its block, and the host adds chunk
+sums in frame order -- the association the single-device kernel uses.  Results must therefore be
+BIT-IDENTICAL to the single-device run, whatever the device count (the reference parallelises over
+frames inside one object, core_private.cpp:73,231,245,263).
+
+CPU: the product's host solver on the test double with several fake devices.  GPU: several contexts on
+the one device of the test box (the driver's multi-GPU node is not available to these tests)."""
+import os
+
+import numpy as np
+import pytest
+
+F, N = 200, 40
+
+
+def _case():
+    from rssync_amd import synth
+    gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=11)
+    frames = list(synth.make_frames(gyro, 0, F, N, seed=11))
+    # ragged: a few frames with other track counts, sparse ids at the end
+    out = []
+    for fr, ta, tb, ra, rb in frames:
+        n = N if fr % 7 else max(2, N - fr % 13)
+        out.append((fr if fr < F - 10 else fr + 1000, ta[:n], tb[:n], ra[:n], rb[:n]))
+    return gyro, out
+
+
+def _fill(p, case):
+    g, frames = case
+    p.SetGyroQuaternions(g.quats, g.fs, g.t0)
+    for fr in frames:
+        p.SetTrackResult(*fr)
+    return p
+
+
+def _run(p):
+    res = {}
+    res["presync"] = p.PreSync(0.0, 0, 5000, 0.004, 0.06)
+    d, c, fc, bh = p.presync_curve(0.0, 10, 150, 0.01, 0.05, per_frame=140)
+    res["curve"] = (c.tolist(), fc.tolist(), bh.tolist())
+    res["sync"] = p.Sync(res["presync"][1], 0, 5000, 0.0, 0.2)
+    res["trace"] = p.sync_trace().tolist()
+    M, k = p.init_motion(0.036, 30, 170)
+    res["init"] = (M.tolist(), k.tolist())
+    M2, k2, its, evs = p.opt_motion(0.036)
+    res["opt"] = (M2.tolist(), k2.tolist(), its, evs)
+    res["loss"] = [x.tolist() for x in p.loss([0.036, 0.03, -0.1], grad=True)]
+    res["windows"] = [x.tolist() for x in p.pre_sync_windows(0.03, [0, 50, 60, 120], [70, 130, 64, 1300], 0.004, 0.04)]
+    res["points"] = [x.tolist() for x in p.sync_points([0, 40, 100, 130], 60, 0.03, 0.004, 0.04, repeats=2)]
+    res["point_traces"] = [p.window_trace(w).tolist() for w in range(4)]
+    res["simplified"] = p.SyncSimplified(0.036, 20, 180, 0.0, 0.2)
+    res["debug"] = [x.tolist() for x in p.DebugPreSync(0.02, 60, 70, 0.03, 7)]
+    res["P"] = p.problem_matrix64(130, 0.0371, N).tolist()
+    return res
+
+
+def _check(one, many):
+    assert one.keys() == many.keys()
+    for key in one:
+        assert one[key] == many[key], key   # exact equality, floats included
+
+
+def test_frames_sharded_over_fake_devices_equal_one_device(hosttest_lib):
+    import rssync_amd
+    case = _case()
+    one = _run(_fill(rssync_amd.SyncProblem(seed=5, max_outer_iters=12, _lib=hosttest_lib), case))
+    for ids in ([0, 1], [0, 1, 2], [3, 3, 3, 3, 3]):
+        p = rssync_amd.SyncProblem(seed=5, max_outer_iters=12, _lib=hosttest_lib)
+        p.set_devices(ids)
+        assert p.device_count() == len(ids)
+        _check(one, _run(_fill(p, case)))
+    # devices changed after the data was set: everything is uploaded again
+    p = _fill(rssync_amd.SyncProblem(seed=5, max_outer_iters=12, _lib=hosttest_lib), case)
+    a = p.PreSync(0.0, 0, 5000, 0.004, 0.06)
+    p.set_devices([0, 1])
+    assert p.PreSync(0.0, 0, 5000, 0.004, 0.06) == a
+
+
+def test_environment_variable_selects_the_devices(hosttest_lib, monkeypatch):
+    import rssync_amd
+    monkeypatch.setenv("RSSYNC_GPUS", "3")
+    assert rssync_amd.SyncProblem(_lib=hosttest_lib).device_count() == 3
+    monkeypatch.setenv("RSSYNC_GPUS", "0,0")
+    assert rssync_amd.SyncProblem(_lib=hosttest_lib).device_count() == 2
+    monkeypatch.delenv("RSSYNC_GPUS")
+    assert rssync_amd.SyncProblem(_lib=hosttest_lib).device_count() == 1
+
+
+@pytest.mark.gpu
+def test_several_contexts_on_the_gpu_equal_one(tmp_path):
+    """the same on the device: two and three contexts (streams, buffers, kernels of their own) on the one GPU
+    of the test box, frames split between them; and the C++ client of examples/sync_driver.cpp with
+    RSSYNC_GPUS set, no source change"""
+    import rssync_amd
+    case = _case()
+    one = _run(_fill(rssync_amd.SyncProblem(seed=5, max_outer_iters=12), case))
+    for ids in ([0, 0], [0, 0, 0]):
+        p = rssync_amd.SyncProblem(seed=5, max_outer_iters=12)
+        p.set_devices(ids)
+        _check(one, _run(_fill(p, case)))
