@@ -69,6 +69,10 @@ int rship_max_tracks(void); /* largest per-frame track count the kernels accept 
  * best step is not its last -- 0 (default): iterate at the best step, value and gradient as the last
  * trial left them (the published LineSearch); 1: evaluate once more at the best step. */
 #define RSHIP_OPT_LBFGS_REEVAL 1
+/* RSHIP_OPT_TRACKS_HINT: the largest per-frame track count of the WHOLE problem (all devices).  Kernels whose
+ * workgroup shape fixes the order of a frame's sums pick the shape from it, so that a frame gets the same sums
+ * on any device and in any selection. */
+#define RSHIP_OPT_TRACKS_HINT 2
 int rship_set_option(rship_ctx* c, int option, int value);
 
 /* OptData::quats (core_private.hpp:18): coefficient table built on the host in fp64 by the spline

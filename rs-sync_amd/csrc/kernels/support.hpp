@@ -16,7 +16,7 @@ namespace {
 //   chunk_off[c] .. [c+1]       plan positions of chunk c
 //   win_chunk_off[w] .. [w+1]   chunks of window w
 //   chunk_out[r][c], win_out[r][w]
-__global__ __launch_bounds__(kBlock) void plan_sum_kernel(const double* __restrict__ in, uint32_t n_cols,
+__global__ __launch_bounds__(64) void plan_sum_kernel(const double* __restrict__ in, uint32_t n_cols,
                                                          const uint32_t* __restrict__ idx,
                                                          const uint32_t* __restrict__ chunk_off, uint32_t n_chunks,
                                                          const uint32_t* __restrict__ win_chunk_off, uint32_t n_win,
@@ -25,9 +25,18 @@ __global__ __launch_bounds__(kBlock) void plan_sum_kernel(const double* __restri
     const uint32_t c0 = win_chunk_off[w], c1 = win_chunk_off[w + 1];
     const double* row = in + (size_t)r * n_cols;
     double* cout = chunk_out + (size_t)r * n_chunks;
-    for (uint32_t c = c0 + threadIdx.x; c < c1; c += kBlock) {
+    for (uint32_t c = c0 + threadIdx.x; c < c1; c += blockDim.x) {
         double acc = 0.0;
-        for (uint32_t j = chunk_off[c]; j < chunk_off[c + 1]; ++j) acc += row[idx ? idx[j] : j];
+        uint32_t j = chunk_off[c];
+        const uint32_t j1 = chunk_off[c + 1];
+        for (; j + 8 <= j1; j += 8) { // eight loads in flight, the additions still in slot order
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = row[idx ? idx[j + q] : j + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += v[q];
+        }
+        for (; j < j1; ++j) acc += row[idx ? idx[j] : j];
         cout[c] = acc;
     }
     __syncthreads(); // the chunk sums of this block are visible to its thread 0

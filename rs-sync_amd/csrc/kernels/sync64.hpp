@@ -68,9 +68,8 @@ struct Rays64 {
 
 // one row of P = ar x br (core_private.cpp:24-28) and, if DERIV, dP/dx (x in knots), in fp64
 template <bool DERIV, int PATH>
-__device__ __forceinline__ void residual_row64(const Spline64& s, const Rays64& r, size_t idx, int base, double fd, d3& P,
-                                               d3& dP) {
-    const double2 X = r.q0[idx], Y = r.q1[idx], Z = r.q2[idx], T = r.q3[idx];
+__device__ __forceinline__ void residual_row64(const Spline64& s, double2 X, double2 Y, double2 Z, double2 T, int base, double fd,
+                                               d3& P, d3& dP) {
     d4 ya, ba, ca, da, yb, bb, cb, db;
     const rs::KnotT<double> ka = (PATH == kPathInterior) ? rs::spline_locate_interior(T.x, base, fd)
                                                          : rs::spline_locate(T.x, base, fd, s.n);
@@ -86,10 +85,15 @@ __device__ __forceinline__ void residual_row64(const Spline64& s, const Rays64& 
 }
 
 template <bool DERIV>
+__device__ __forceinline__ void residual_row64(const Spline64& s, double2 X, double2 Y, double2 Z, double2 T, int base, double fd,
+                                               d3& P, d3& dP) {
+    if (s.path == kPathInterior) residual_row64<DERIV, kPathInterior>(s, X, Y, Z, T, base, fd, P, dP);
+    else residual_row64<DERIV, kPathGlobal>(s, X, Y, Z, T, base, fd, P, dP);
+}
+template <bool DERIV>
 __device__ __forceinline__ void residual_row64(const Spline64& s, const Rays64& r, size_t idx, int base, double fd, d3& P,
                                                d3& dP) {
-    if (s.path == kPathInterior) residual_row64<DERIV, kPathInterior>(s, r, idx, base, fd, P, dP);
-    else residual_row64<DERIV, kPathGlobal>(s, r, idx, base, fd, P, dP);
+    residual_row64<DERIV>(s, r.q0[idx], r.q1[idx], r.q2[idx], r.q3[idx], base, fd, P, dP);
 }
 
 __device__ __forceinline__ void frame_window64(Spline64& sp, d4* s_win, const FrameRec& fr, int kd) {
@@ -123,10 +127,17 @@ struct Loss64Params {
     double* part_grad; // [n_delays][n_sel] (GRAD)
 };
 
+// delays evaluated per pass over the rows: every ray pair is read once for kLossBatch delays (their spline
+// windows sit side by side in LDS, 10 KB each).  The line search's trials are far apart in time (steps of
+// 1e-3 .. 1e-12 times the gradient), so the windows cannot be shared; the rays can.  A pass per delay made
+// this kernel HBM/L2-bound (64 B per ray pair per delay: 6.5 TB/s effective at 4096 x 2048).
+constexpr int kLossBatch = 5;
+
 template <int RPT, bool GRAD, bool SIMPLE>
-__global__ __launch_bounds__(kBlock, 4) void loss64_kernel(Loss64Params p) {
-    __shared__ d4 s_win[4 * kWinMax];
-    __shared__ double s_red[2][4];
+__global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
+    constexpr int NB = GRAD ? 1 : kLossBatch;
+    __shared__ d4 s_win[NB][4 * kWinMax];
+    __shared__ double s_red[NB][2][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t sf = blockIdx.x;
     const uint32_t fi = p.sel[sf];
@@ -139,54 +150,71 @@ __global__ __launch_bounds__(kBlock, 4) void loss64_kernel(Loss64Params p) {
     // r = (P.M) k / |M|  (core_private.cpp:120)  ->  u = (P.M)^2 * inv_s;  SIMPLE: u = |P|^2 k^2
     const double inv_s = SIMPLE ? kk * kk : kk * kk / (Mx * Mx + My * My + Mz * Mz);
 
-    Spline64 sp;
-    sp.g = p.coef;
-    sp.n = p.n_knots;
-    for (uint32_t b = 0; b < p.n_delays; ++b) {
-        const int kd = p.kd[b * p.n_grp + g];
-        const double fd = p.fd[b * p.n_grp + g];
-        if (fd != fd) { // group switched off for this evaluation (workgroup-uniform)
-            if (tid == 0) {
-                p.part_loss[(size_t)b * p.n_sel + sf] = 0.0;
-                if (GRAD) p.part_grad[(size_t)b * p.n_sel + sf] = 0.0;
-            }
-            continue;
+    for (uint32_t b0 = 0; b0 < p.n_delays; b0 += NB) {
+        Spline64 sp[NB];
+        int base[NB];
+        double fdv[NB];
+        bool on[NB];
+        __syncthreads(); // windows and s_red of the previous group are free
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const uint32_t b = b0 + q;
+            on[q] = b < p.n_delays;
+            const int kd = on[q] ? p.kd[b * p.n_grp + g] : 0;
+            fdv[q] = on[q] ? p.fd[b * p.n_grp + g] : 0.0;
+            if (fdv[q] != fdv[q]) on[q] = false; // group switched off for this evaluation (workgroup-uniform)
+            sp[q].g = p.coef;
+            sp[q].n = p.n_knots;
+            base[q] = fr.base_knot + kd;
+            if (on[q]) frame_window64(sp[q], s_win[q], fr, kd);
         }
-        __syncthreads(); // window and s_red reuse
-        frame_window64(sp, s_win, fr, kd);
         __syncthreads();
-        const int base = fr.base_knot + kd;
-        double L = 0.0, G = 0.0;
+        double L[NB], G[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) L[q] = G[q] = 0.0;
 #pragma unroll 1
         for (int j = 0; j < RPT; ++j) {
             const uint32_t row = j * kBlock + tid;
             if (row < N) {
-                d3 P, dP;
-                residual_row64<GRAD>(sp, p.rays, (size_t)fr.off + row, base, fd, P, dP);
-                double w;
-                if (SIMPLE) {
-                    const double u = rs::dot(P, P) * inv_s;
-                    L += rs::log1p_rcp_f64(u, &w);
-                    if (GRAD) G = fma(w * 2.0 * inv_s, rs::dot(P, dP), G);
-                } else {
-                    const double pm = rs::dot(P, Mv);
-                    const double u = pm * pm * inv_s;
-                    L += rs::log1p_rcp_f64(u, &w); // core_private.cpp:121-122
-                    if (GRAD) G = fma(w * 2.0 * pm * inv_s, rs::dot(dP, Mv), G);
+                const size_t idx = (size_t)fr.off + row;
+                const double2 X = p.rays.q0[idx], Y = p.rays.q1[idx], Z = p.rays.q2[idx], T = p.rays.q3[idx];
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    if (!on[q]) continue;
+                    d3 P, dP;
+                    residual_row64<GRAD>(sp[q], X, Y, Z, T, base[q], fdv[q], P, dP);
+                    double w;
+                    if (SIMPLE) {
+                        const double u = rs::dot(P, P) * inv_s;
+                        L[q] += rs::log1p_rcp_f64(u, &w);
+                        if (GRAD) G[q] = fma(w * 2.0 * inv_s, rs::dot(P, dP), G[q]);
+                    } else {
+                        const double pm = rs::dot(P, Mv);
+                        const double u = pm * pm * inv_s;
+                        L[q] += rs::log1p_rcp_f64(u, &w); // core_private.cpp:121-122
+                        if (GRAD) G[q] = fma(w * 2.0 * pm * inv_s, rs::dot(dP, Mv), G[q]);
+                    }
                 }
             }
         }
-        const double Lw = wave_sum_f64(L);
-        const double Gw = GRAD ? wave_sum_f64(G) : 0.0;
-        if (lane == 0) {
-            s_red[0][wave] = Lw;
-            s_red[1][wave] = Gw;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const double Lw = wave_sum_f64(L[q]);
+            const double Gw = GRAD ? wave_sum_f64(G[q]) : 0.0;
+            if (lane == 0) {
+                s_red[q][0][wave] = Lw;
+                s_red[q][1][wave] = Gw;
+            }
         }
         __syncthreads();
-        if (tid == 0) {
-            p.part_loss[(size_t)b * p.n_sel + sf] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+        if (tid < NB && b0 + tid < p.n_delays) {
+            const uint32_t b = b0 + tid;
+            const double fdb = p.fd[b * p.n_grp + g];
+            const bool live = fdb == fdb;
+            p.part_loss[(size_t)b * p.n_sel + sf] = live ? s_red[tid][0][0] + s_red[tid][0][1] + s_red[tid][0][2] + s_red[tid][0][3] : 0.0;
             if (GRAD)
-                p.part_grad[(size_t)b * p.n_sel + sf] = (s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3]) * p.fs;
+                p.part_grad[(size_t)b * p.n_sel + sf] =
+                    live ? (s_red[tid][1][0] + s_red[tid][1][1] + s_red[tid][1][2] + s_red[tid][1][3]) * p.fs : 0.0;
         }
     }
 }
@@ -233,10 +261,11 @@ struct Motion64Params {
 constexpr int kInitNone = (int)0x80000000;
 constexpr int kNB = 10; // numBasis (ens::L_BFGS default)
 
-template <int RPT>
+// NW = waves per workgroup (4 in the product: measured fastest, see launch_motion64)
+template <int RPT, int NW>
 struct MotionEval64 {
     d3 P[RPT];
-    double (*part)[4][5]; // [2][4][5] LDS, double-buffered
+    double (*part)[NW][5]; // [2][NW][5] LDS, double-buffered
     int buf;
     double k2;
     int evals;
@@ -270,7 +299,12 @@ struct MotionEval64 {
         __syncthreads();
         double t[5];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) t[q] = part[buf][0][q] + part[buf][1][q] + part[buf][2][q] + part[buf][3][q];
+        for (int q = 0; q < 5; ++q) {
+            double acc = part[buf][0][q];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) acc += part[buf][w][q];
+            t[q] = acc;
+        }
         buf ^= 1;
         ++evals;
         const double tt = t[4] * 2.0 / k2;
@@ -285,15 +319,16 @@ __device__ __forceinline__ double dot3d(const double* a, const double* b) { retu
 
 __device__ __forceinline__ double clamp_k(double k) { return (k < 10.0) ? 10.0 : ((1000.0 < k) ? 1000.0 : k); } // inline_utils.hpp:50
 
-template <int RPT>
-__global__ __launch_bounds__(kBlock, 3) void opt_motion64_kernel(Motion64Params p) {
+template <int RPT, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (NW == 1 ? (RPT >= 8 ? 3 : 4) : 2)) void opt_motion64_kernel(Motion64Params p) {
+    constexpr int kThreads = 64 * NW;
     __shared__ d4 s_win[4 * kWinMax];
-    __shared__ double s_part[2][4][5];
+    __shared__ double s_part[2][NW][5];
     __shared__ double s_S[kNB][3], s_Y[kNB][3];
     // two-loop scratch: every thread writes the same values and reads them back itself;
     // the barrier inside each evaluation separates one iteration's use from the next
     __shared__ double s_rho[kNB], s_alpha[kNB];
-    __shared__ double s_red[4];
+    __shared__ double s_red[NW];
     const int tid = threadIdx.x;
     const uint32_t sf = blockIdx.x;
     const uint32_t fi = p.sel[sf];
@@ -310,14 +345,14 @@ __global__ __launch_bounds__(kBlock, 3) void opt_motion64_kernel(Motion64Params 
     frame_window64(sp, s_win, fr, kd);
     __syncthreads();
 
-    MotionEval64<RPT> ev;
+    MotionEval64<RPT, NW> ev;
     ev.part = s_part;
     ev.buf = 0;
     ev.evals = 0;
     const int base = fr.base_knot + kd;
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
-        const uint32_t row = j * kBlock + tid;
+        const uint32_t row = j * kThreads + tid;
         d3 P = d3{0, 0, 0}, dP;
         if (row < N) residual_row64<false>(sp, p.rays, (size_t)fr.off + row, base, fd, P, dP);
         ev.P[j] = P; // zero rows contribute log1p(0) = 0 and no gradient
@@ -348,7 +383,9 @@ __global__ __launch_bounds__(kBlock, 3) void opt_motion64_kernel(Motion64Params 
         const double sw = wave_sum_f64(ss);
         if ((tid & 63) == 0) s_red[tid >> 6] = sw;
         __syncthreads();
-        const double tot = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        double tot = s_red[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) tot += s_red[w];
         kk = clamp_k(100.0 / sqrt(tot)); // :132; tot = 0 gives +inf -> 1000
         x[0] = Mv.x; x[1] = Mv.y; x[2] = Mv.z;
         if (tid == 0) {

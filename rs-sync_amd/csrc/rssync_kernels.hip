@@ -22,6 +22,7 @@
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -79,6 +80,7 @@ struct rship_ctx {
     uint64_t total_rays = 0;
     double fs = 0;
     int lbfgs_reeval = 0; // RSHIP_OPT_LBFGS_REEVAL
+    uint32_t tracks_hint = 0; // RSHIP_OPT_TRACKS_HINT
     float max_span = 0.f; // widest frame, in knots (frame table)
     // native exchange (RCCL through dlopen)
     void* rccl_lib = nullptr;
@@ -227,15 +229,26 @@ int launch_loss64(rship_ctx* c, const Loss64Params& p, int rpt) {
     return 0;
 }
 
-int launch_motion64(rship_ctx* c, const Motion64Params& p, int rpt) {
+// The workgroup shape of the motion kernel follows the LARGEST frame of the whole problem (all devices:
+// RSHIP_OPT_TRACKS_HINT), not of the selection at hand: the shape fixes the order in which a frame's row
+// terms are added, and a frame must get the same sums whichever selection or device it is part of.
+int launch_motion64(rship_ctx* c, const Motion64Params& p) {
     ProfScope ps(c, RSHIP_K_MOTION);
-    switch (rpt) {
-        case 1: hipLaunchKernelGGL((opt_motion64_kernel<1>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
-        case 2: hipLaunchKernelGGL((opt_motion64_kernel<2>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
-        case 4: hipLaunchKernelGGL((opt_motion64_kernel<4>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
-        case 8: hipLaunchKernelGGL((opt_motion64_kernel<8>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
-        default: return set_err(c, "motion: unsupported rows-per-thread");
-    }
+    const uint32_t n = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
+    // One wave per frame up to 512 tracks: the evaluations of a frame are dominated by their fixed part (five
+    // wave reductions, the uniform L-BFGS bookkeeping) which every wave of a workgroup repeats, and a one-wave
+    // frame needs no LDS exchange or barrier at all -- the reference's own workload (~130 tracks) ran 3x as
+    // many frames per CU this way.  Above that, four waves: with 8 / 16 waves (4 / 2 rows per thread at 2048
+    // tracks) the launch took 7.8 / 12.4 ms per bench step instead of 4.75, and with two waves 5.15: the kernel is
+    // bound by the work per evaluation, not by its slowest frame.
+    if (n <= 64) hipLaunchKernelGGL((opt_motion64_kernel<1, 1>), dim3(p.n_sel), dim3(64), 0, c->stream, p);
+    else if (n <= 128) hipLaunchKernelGGL((opt_motion64_kernel<2, 1>), dim3(p.n_sel), dim3(64), 0, c->stream, p);
+    else if (n <= 192) hipLaunchKernelGGL((opt_motion64_kernel<3, 1>), dim3(p.n_sel), dim3(64), 0, c->stream, p);
+    else if (n <= 256) hipLaunchKernelGGL((opt_motion64_kernel<4, 1>), dim3(p.n_sel), dim3(64), 0, c->stream, p);
+    else if (n <= 512) hipLaunchKernelGGL((opt_motion64_kernel<8, 1>), dim3(p.n_sel), dim3(64), 0, c->stream, p);
+    else if (n <= 1024) hipLaunchKernelGGL((opt_motion64_kernel<4, 4>), dim3(p.n_sel), dim3(256), 0, c->stream, p);
+    else if (n <= 2048) hipLaunchKernelGGL((opt_motion64_kernel<8, 4>), dim3(p.n_sel), dim3(256), 0, c->stream, p);
+    else return set_err(c, "motion: unsupported track count");
     RS_HIP(hipGetLastError());
     return 0;
 }
@@ -246,7 +259,7 @@ int launch_plan_sum(rship_ctx* c, const double* in, uint32_t rows, uint32_t cols
     if (ensure(c, c->chunk_out, (size_t)rows * (c->plan_chunks + 1) * 8) || ensure(c, c->win_out, (size_t)rows * c->plan_wins * 8))
         return 1;
     ProfScope ps(c, RSHIP_K_REDUCE);
-    hipLaunchKernelGGL(plan_sum_kernel, dim3(rows * c->plan_wins), dim3(kBlock), 0, c->stream, in, cols,
+    hipLaunchKernelGGL(plan_sum_kernel, dim3(rows * c->plan_wins), dim3(64), 0, c->stream, in, cols,
                        c->plan_has_idx ? (const uint32_t*)c->plan_idx.p : nullptr, (const uint32_t*)c->plan_chunk_off.p,
                        c->plan_chunks, (const uint32_t*)c->plan_win_off.p, c->plan_wins, (double*)c->chunk_out.p,
                        (double*)c->win_out.p);
@@ -411,6 +424,7 @@ const char* rship_last_error(const rship_ctx* c) { return c ? c->err.c_str() : "
 int rship_set_option(rship_ctx* c, int option, int value) {
     switch (option) {
         case RSHIP_OPT_LBFGS_REEVAL: c->lbfgs_reeval = value != 0; return 0;
+        case RSHIP_OPT_TRACKS_HINT: c->tracks_hint = value > 0 ? (uint32_t)value : 0u; return 0;
         default: return set_err(c, "set_option: unknown option");
     }
 }
@@ -762,7 +776,7 @@ int rship_finish_init(rship_ctx* c, const int32_t* kd, const double* fd) {
     Motion64Params p{};
     fill_motion(c, p);
     p.max_iters = 0;
-    if (launch_motion64(c, p, rpt_for(c->max_n))) return 1;
+    if (launch_motion64(c, p)) return 1;
     c->init_pending = false;
     return sync_stream(c);
 }
@@ -777,7 +791,7 @@ int rship_init_k_simple(rship_ctx* c, const int32_t* kd, const double* fd) {
     fill_motion(c, p);
     p.init_h = nullptr;
     p.simple_k = 1;
-    if (launch_motion64(c, p, rpt_for(c->max_n))) return 1;
+    if (launch_motion64(c, p)) return 1;
     return sync_stream(c);
 }
 
@@ -792,7 +806,7 @@ int rship_opt_motion_detail(rship_ctx* c, const int32_t* kd, const double* fd, u
     Motion64Params p{};
     fill_motion(c, p);
     p.per_frame = (uint32_t*)d.p;
-    int rc = launch_motion64(c, p, rpt_for(c->max_n));
+    int rc = launch_motion64(c, p);
     c->init_pending = false;
     hipError_t e = hipStreamSynchronize(c->stream);
     prof_collect(c);
@@ -813,7 +827,7 @@ int rship_opt_motion(rship_ctx* c, const int32_t* kd, const double* fd, uint64_t
     Motion64Params p{};
     fill_motion(c, p);
     p.stats = stats ? (unsigned long long*)c->stats.p : nullptr;
-    if (launch_motion64(c, p, rpt_for(c->max_n))) return 1;
+    if (launch_motion64(c, p)) return 1;
     c->init_pending = false;
     if (stats) {
         if (ensure_pinned(c, 32)) return 1;

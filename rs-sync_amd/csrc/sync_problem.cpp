@@ -757,6 +757,9 @@ void SyncProblemHip::pack_frames() {
         cut[d] = best;
     }
     if (S == 1) upload_new_records();
+    uint32_t max_tracks = 0;
+    for (size_t i = 0; i < nf; ++i) max_tracks = std::max(max_tracks, table[i].n_rays);
+    set_option(RSHIP_OPT_TRACKS_HINT, (int)max_tracks);
     uint32_t bad = 0;
     for (size_t d = 0; d < S; ++d) {
         Shard& sh = shards_[d];
@@ -1237,7 +1240,7 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
     std::vector<int> converge_counter(W, 0);
     std::vector<char> active(W, 1);
     costs.assign(W, 0.0);
-    std::vector<double> l1, g1, lt, lt2, cur(W), x0(W), trial((size_t)half_bt * W);
+    std::vector<double> l1, g1, lt, cur(W), x0(W), trial;
     double ts[16];
     {
         double t = t0;
@@ -1245,39 +1248,46 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
         ts[max_bt] = t;
     }
     size_t n_active = W;
+    int prev_hit = -1;
     for (int it = 0; it < max_outer && n_active; ++it) { // :309
         for (size_t w = 0; w < W; ++w) cur[w] = active[w] ? d[w] : kOff;
         if (!simplified) opt_motion(cur, nullptr); // :311
         // do_opt_delay (:298-305) -> Backtrack::Step (backtrack.cpp:3-13)
         for (size_t w = 0; w < W; ++w) x0[w] = active[w] ? d[w] - delay_b * delay_v[w] : kOff;
         loss(x0, l1, &g1, simplified);
-        // The <= 10 backtracking trials (backtrack.cpp:7-11) are evaluated five at a time in one
-        // batched launch; the first that satisfies the Armijo test is taken, which is what the
-        // sequential loop returns.  The second five are only evaluated for windows whose first five
-        // all failed (steps of 1e-3 .. 1e-7 times the gradient: rare).
+        // The <= 10 backtracking trials (backtrack.cpp:7-11) are evaluated in one or two batched launches
+        // and the first that satisfies the Armijo test is taken, which is what the sequential loop
+        // returns.  The first batch holds as many trials as the previous outer iteration needed (at
+        // least five): the step scale barely changes between iterations, so the second batch -- the
+        // remaining trials, for the windows whose first batch failed throughout -- is rarely launched.
         std::vector<int> hit(W, -1); // index of the first successful trial
-        for (int half = 0; half < 2; ++half) {
+        const int n_first = std::min(max_bt, std::max(half_bt, prev_hit + 1));
+        for (int b0 = 0; b0 < max_bt; b0 = (b0 == 0 ? n_first : max_bt)) {
+            const int nb = (b0 == 0 ? n_first : max_bt) - b0;
+            if (nb <= 0) break;
             bool need = false;
+            trial.assign((size_t)nb * W, kOff);
             for (size_t w = 0; w < W; ++w) {
                 const bool want = active[w] && hit[w] < 0;
                 need = need || want;
-                for (int i = 0; i < half_bt; ++i)
-                    trial[(size_t)i * W + w] = want ? x0[w] - ts[half * half_bt + i] * g1[w] : kOff;
+                for (int i = 0; i < nb && want; ++i) trial[(size_t)i * W + w] = x0[w] - ts[b0 + i] * g1[w];
             }
             if (!need) break;
             loss(trial, lt, nullptr, simplified);
             for (size_t w = 0; w < W; ++w) {
                 if (!active[w] || hit[w] >= 0) continue;
                 const double m = g1[w] * g1[w];
-                for (int i = 0; i < half_bt; ++i) {
-                    const int gi = half * half_bt + i;
-                    if (l1[w] - lt[(size_t)i * W + w] >= ts[gi] * c_armijo * m) {
-                        hit[w] = gi;
+                for (int i = 0; i < nb; ++i) {
+                    if (l1[w] - lt[(size_t)i * W + w] >= ts[b0 + i] * c_armijo * m) {
+                        hit[w] = b0 + i;
                         break;
                     }
                 }
             }
         }
+        prev_hit = half_bt - 1;
+        for (size_t w = 0; w < W; ++w)
+            if (active[w]) prev_hit = std::max(prev_hit, hit[w] >= 0 ? hit[w] : max_bt - 1);
         for (size_t w = 0; w < W; ++w) {
             if (!active[w]) continue;
             const double v = l1[w], p = g1[w];

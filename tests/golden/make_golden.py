@@ -41,6 +41,17 @@ def main():
     o2 = OracleProblem(seed=SEED)
     o2.SetGyroQuaternionsTimestamped(ts_us, q_ts)
     fs2, start2, n2 = o2.gyro_info()
+    # a noise-free scene: there the comparison with the product is tight (1e-7 s per outer iteration),
+    # while on the noisy one above the optimiser amplifies rounding differences (DESIGN.md "Parity")
+    Fc, Nc = 16, 96
+    gyro_c = synth.make_gyro(0.0, (Fc + 2) / synth.FPS, seed=43)
+    frames_c = list(synth.make_frames(gyro_c, 0, Fc, Nc, seed=43, noise=0.0, outliers=0.0))
+    oc = OracleProblem(seed=SEED, threads=1, faithful=True)
+    oc.SetGyroQuaternions(gyro_c.quats, gyro_c.fs, gyro_c.t0)
+    for fr, ta, tb, ra, rb in frames_c:
+        oc.SetTrackResult(fr, ta, tb, ra, rb)
+    cc, dc_, trace_c = oc.sync_trace(0.0355, 0, Fc - 1, 0.0, 0.1)
+    cs, ds_, trace_s = oc.sync_simplified_trace(0.0355, 0, Fc - 1, 0.0, 0.1)
     pairs = np.array([ora.sample_pair(SEED, fr, st, h, n) for fr, st, h, n in
                       [(0, 0, 0, 2), (30, 5, 7, 128), (-3, ora.STREAM_SYNC_INIT, 199, 2048), (2 ** 40, ora.STREAM_DEBUG + 3, 19, 17)]])
     np.savez_compressed(
@@ -52,6 +63,11 @@ def main():
         presync_delays=delays, presync_costs=costs, presync_frame_costs=fcost, presync_best_h=bh,
         presync_result=np.array(pre), debug_delays=dbg_d, debug_costs=dbg_c,
         sync_result=np.array([c, d]), sync_trace=trace, sync_M=M, sync_k=k, P_frame33=P,
+        clean_gyro_quats=gyro_c.quats, clean_gyro_fs=gyro_c.fs, clean_gyro_t0=gyro_c.t0,
+        clean_ts_a=np.array([f[1] for f in frames_c]), clean_ts_b=np.array([f[2] for f in frames_c]),
+        clean_rays_a=np.array([f[3] for f in frames_c]), clean_rays_b=np.array([f[4] for f in frames_c]),
+        clean_sync_result=np.array([cc, dc_]), clean_sync_trace=trace_c,
+        clean_simplified_result=np.array([cs, ds_]), clean_simplified_trace=trace_s,
         ts_us=ts_us, ts_quats=q_ts, ts_fs=fs2, ts_start=start2, ts_knots=o2.gyro_knots(), sample_pairs=pairs)
     print("written", F, N, "presync", pre, "sync", c, d, len(trace))
 
