@@ -77,6 +77,10 @@ int rssync_ext_set_verbose(rssync_problem* p, int verbose);
  * When a line search's best step is not its last, 0 (default) keeps value and gradient as the last trial
  * left them while the iterate moves to the best step (the published LineSearch); 1 re-evaluates there. */
 int rssync_ext_set_lbfgs_reeval(rssync_problem* p, int reeval);
+/* Sync's outer loop normally runs on the device when one GPU holds all frames and no reduce hook is set (the
+ * scalar decisions are taken between the launches, the host polls every few iterations); 1 keeps it on the
+ * host, where it always runs otherwise.  Both give the same bits.  Environment: RSSYNC_HOST_LOOP=1. */
+int rssync_ext_set_host_loop(rssync_problem* p, int host_loop);
 /* line searches of the last rssync_ext_opt_motion call whose best step was not the last one tried */
 int rssync_ext_lbfgs_best_not_last(rssync_problem* p, uint64_t* count);
 /* ONE object, several GPUs (the reference parallelises over frames inside the object, core_private.cpp:73,231,

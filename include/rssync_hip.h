@@ -174,6 +174,14 @@ int rship_loss_enqueue(rship_ctx* c, const int32_t* kd, const double* fd, uint32
 int rship_loss_collect(rship_ctx* c, uint32_t n_delays, double* win_loss, double* win_grad,
                        double* chunk_loss, double* chunk_grad);
 
+/* Sync's outer loop (core_private.cpp:298-331) for the W windows (= groups) of the selection with the scalar
+ * decisions taken on the device between the launches (kernels/syncloop.hpp): the host only polls a counter
+ * every few iterations.  Same arithmetic as the host loop in sync_problem.cpp; used when one device holds all
+ * frames and no exchange with other ranks is needed.  d0[W] in; d_out[W], iters[W], trace[W][max_outer][6] out. */
+int rship_has_device_loop(void); /* 1 where rship_sync_run exists (0 in the CPU test double) */
+int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_center, double search_radius,
+                   int simplified, double* d_out, int32_t* iters, double* trace);
+
 /* per-slot state in selection order: M[3n], k[n] */
 int rship_get_motion(rship_ctx* c, double* M, double* k, uint32_t cap, uint32_t* n);
 int rship_set_motion(rship_ctx* c, const double* M, const double* k, uint32_t n);

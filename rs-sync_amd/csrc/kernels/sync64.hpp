@@ -140,10 +140,26 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
     __shared__ double s_red[NB][2][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t sf = blockIdx.x;
+    const uint32_t g = p.grp ? p.grp[sf] : 0u;
+    {
+        // nothing to evaluate for this slot's window (a finished window, a line search that has already
+        // succeeded): zeros and out, before anything is fetched
+        bool any = false;
+        for (uint32_t b = 0; b < p.n_delays; ++b) {
+            const double f = p.fd[b * p.n_grp + g];
+            any = any || f == f;
+        }
+        if (!any) {
+            for (uint32_t b = tid; b < p.n_delays; b += kBlock) {
+                p.part_loss[(size_t)b * p.n_sel + sf] = 0.0;
+                if (GRAD) p.part_grad[(size_t)b * p.n_sel + sf] = 0.0;
+            }
+            return;
+        }
+    }
     const uint32_t fi = p.sel[sf];
     const FrameRec fr = p.frames[fi];
     const uint32_t N = fr.n;
-    const uint32_t g = p.grp ? p.grp[sf] : 0u;
     const double Mx = SIMPLE ? 0.0 : p.M[3 * sf], My = SIMPLE ? 0.0 : p.M[3 * sf + 1], Mz = SIMPLE ? 0.0 : p.M[3 * sf + 2];
     const double kk = p.k[sf];
     const d3 Mv = d3{Mx, My, Mz};
@@ -154,19 +170,31 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
         Spline64 sp[NB];
         int base[NB];
         double fdv[NB];
-        bool on[NB];
-        __syncthreads(); // windows and s_red of the previous group are free
+        bool on[NB], any_on = false;
+        int kdv[NB];
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const uint32_t b = b0 + q;
             on[q] = b < p.n_delays;
-            const int kd = on[q] ? p.kd[b * p.n_grp + g] : 0;
+            kdv[q] = on[q] ? p.kd[b * p.n_grp + g] : 0;
             fdv[q] = on[q] ? p.fd[b * p.n_grp + g] : 0.0;
-            if (fdv[q] != fdv[q]) on[q] = false; // group switched off for this evaluation (workgroup-uniform)
+            if (fdv[q] != fdv[q]) on[q] = false; // window switched off for this evaluation (workgroup-uniform)
+            any_on = any_on || on[q];
+        }
+        if (!any_on) { // a whole batch of skipped delays
+            if (tid < NB && b0 + tid < p.n_delays) {
+                p.part_loss[(size_t)(b0 + tid) * p.n_sel + sf] = 0.0;
+                if (GRAD) p.part_grad[(size_t)(b0 + tid) * p.n_sel + sf] = 0.0;
+            }
+            continue;
+        }
+        __syncthreads(); // windows and s_red of the previous group are free
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
             sp[q].g = p.coef;
             sp[q].n = p.n_knots;
-            base[q] = fr.base_knot + kd;
-            if (on[q]) frame_window64(sp[q], s_win[q], fr, kd);
+            base[q] = fr.base_knot + kdv[q];
+            if (on[q]) frame_window64(sp[q], s_win[q], fr, kdv[q]);
         }
         __syncthreads();
         double L[NB], G[NB];
@@ -328,6 +356,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (NW == 1 ? (RPT >= 8 ? 3 : 4
     // two-loop scratch: every thread writes the same values and reads them back itself;
     // the barrier inside each evaluation separates one iteration's use from the next
     __shared__ double s_rho[kNB], s_alpha[kNB];
+    __shared__ double s_inv_ys[kNB]; // 1 / (y . s) of each stored pair: the value the two-loop recursion divides for
     __shared__ double s_red[NW];
     const int tid = threadIdx.x;
     const uint32_t sf = blockIdx.x;
@@ -428,7 +457,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (NW == 1 ? (RPT >= 8 ? 3 : 4
 #pragma unroll 1
         for (int i = it; i != limit; --i) {
             const int tp = (i + (kNB - 1)) % kNB;
-            const double r = 1.0 / dot3d(s_Y[tp], s_S[tp]);
+            const double r = s_inv_ys[tp]; // = 1.0 / dot3d(s_Y[tp], s_S[tp]), computed when the pair was stored
             const double al = r * dot3d(s_S[tp], dir);
             s_rho[it - i] = r; // it - i in [0, kNB)
             s_alpha[it - i] = al;
@@ -480,7 +509,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (NW == 1 ? (RPT >= 8 ? 3 : 4
         const int op = it % kNB;
         __syncthreads(); // every thread has finished reading the history for this iteration
         if (tid == 0) {
-            for (int c = 0; c < 3; ++c) { s_S[op][c] = x[c] - oldx[c]; s_Y[op][c] = g[c] - oldg[c]; }
+            double sv[3], yv[3];
+            for (int c = 0; c < 3; ++c) { sv[c] = x[c] - oldx[c]; yv[c] = g[c] - oldg[c]; }
+            for (int c = 0; c < 3; ++c) { s_S[op][c] = sv[c]; s_Y[op][c] = yv[c]; }
+            s_inv_ys[op] = 1.0 / dot3d(yv, sv);
         }
         __syncthreads();
     }

@@ -1,0 +1,221 @@
+// syncloop.hpp -- Sync's outer loop (core_private.cpp:298-331) kept on the device between kernel launches.
+// Part of the single HIP translation unit rssync_kernels.hip (included there, in order).
+//
+// One outer iteration is: per-frame motion optimisation at d; loss + gradient at x0 = d - 0.3 v; up to
+// ten line-search losses; a handful of scalar decisions per window.  With the decisions on the host
+// every iteration costs two or three stream synchronisations (~25 us each, more than the kernels of a
+// 60-frame window).  Here the decisions are three small kernels between the launches (one workgroup per
+// window, which first adds that window's per-slot sums in the plan's association, then lets thread 0
+// run the scalar logic), and the host only looks at a counter of still-active windows every few
+// iterations.  The arithmetic of the decisions is the host loop's (sync_problem.cpp: sync_windows),
+// operation for operation, with contraction off: both paths return the same bits.
+#pragma once
+
+namespace {
+
+struct SyncWin { // per window
+    double d, v;     // delay, momentum (delay_v, core_private.cpp:261)
+    double x0;       // d - 0.3 v of this iteration
+    double l1, g1;   // loss and d loss / d delay at x0
+    int active, conv, hit, iters;
+};
+
+struct SyncLoopParams {
+    SyncWin* win;          // [W]
+    uint32_t n_win;
+    const double* part;    // per-slot sums of the launch just finished: [rows][n_sel]
+    uint32_t n_sel, rows;
+    // the plan (windows = groups): chunk_off over slots (identity positions), win_chunk_off
+    const uint32_t* chunk_off;
+    const uint32_t* win_chunk_off;
+    double* chunk_tmp;     // [W][rows][max chunks per window]: scratch
+    uint32_t chunk_stride; // max chunks per window
+    // delays for the launches that follow
+    int32_t* mo_kd; double* mo_fd;   // motion: [W]
+    int32_t* lg_kd; double* lg_fd;   // loss + gradient: [W]
+    int32_t* tr_kd; double* tr_fd;   // trials: [10][W]
+    double fs;
+    double ts[11];         // line-search step sizes t0 * decay^i (backtrack.cpp:7-12), computed by the host
+    double c_armijo, delay_b, search_center, search_radius;
+    int it, max_outer;
+    int* prev_hit;         // [2]: largest successful trial index of the previous iteration (double-buffered)
+    int* n_active;         // [max_outer]: windows still active after iteration i
+    double* trace;         // [max_outer][W][6]: row k of window w is its k-th outer iteration
+};
+
+constexpr int kMaxBt = 10, kHalfBt = 5;
+
+__device__ __forceinline__ void split64_dev(double delay, double fs, int32_t* kd, double* fd) {
+#pragma clang fp contract(off)
+    if (delay != delay) { *kd = 0; *fd = delay; return; } // NaN = window switched off
+    const double D = delay * fs;
+    const double kClamp = (double)(1 << 29);
+    if (!(fabs(D) <= 1.79769313486231570e308)) { *kd = 0; *fd = 0.0; return; }
+    const double fl = floor(D);
+    if (fl > kClamp) { *kd = 1 << 29; *fd = 0.0; return; }
+    if (fl < -kClamp) { *kd = -(1 << 29); *fd = 0.0; return; }
+    *kd = (int32_t)fl;
+    *fd = D - fl;
+}
+
+// window sums of p.part rows under the plan: chunks sequentially, then chunks in order (plan_sum_kernel's
+// association); s_tot[r] for r < rows, valid for every thread after the call.  Small windows (the reference's
+// 60-frame windows) are first copied to LDS with coalesced loads, so that the sequential additions do not
+// wait for a global load each.
+constexpr uint32_t kStageDoubles = 2048; // 16 KB
+__device__ __forceinline__ void window_sums(const SyncLoopParams& p, uint32_t w, double* s_tot, double* s_stage) {
+    const uint32_t c0 = p.win_chunk_off[w], c1 = p.win_chunk_off[w + 1], nc = c1 - c0;
+    const uint32_t j_lo = p.chunk_off[c0], j_hi = p.chunk_off[c1], span = j_hi - j_lo; // the window's slots
+    double* tmp = p.chunk_tmp + (size_t)w * p.rows * p.chunk_stride;
+    const bool staged = p.rows * span <= kStageDoubles;
+    if (staged) {
+        for (uint32_t e = threadIdx.x; e < p.rows * span; e += blockDim.x)
+            s_stage[e] = p.part[(size_t)(e / span) * p.n_sel + j_lo + e % span];
+        __syncthreads();
+    }
+    for (uint32_t e = threadIdx.x; e < p.rows * nc; e += blockDim.x) {
+        const uint32_t r = e / nc, c = c0 + e % nc;
+        double acc = 0.0;
+        uint32_t j = p.chunk_off[c];
+        const uint32_t j1 = p.chunk_off[c + 1];
+        if (staged) {
+            const double* row = s_stage + (size_t)r * span - j_lo;
+            for (; j + 8 <= j1; j += 8) {
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = row[j + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += v[q];
+            }
+            for (; j < j1; ++j) acc += row[j];
+        } else {
+            const double* row = p.part + (size_t)r * p.n_sel;
+            for (; j + 8 <= j1; j += 8) { // eight loads in flight, the additions still in slot order
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = row[j + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += v[q];
+            }
+            for (; j < j1; ++j) acc += row[j];
+        }
+        tmp[(size_t)r * p.chunk_stride + (c - c0)] = acc;
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < p.rows; r += blockDim.x) {
+        double acc = 0.0;
+        for (uint32_t c = 0; c < nc; ++c) acc += tmp[(size_t)r * p.chunk_stride + c];
+        s_tot[r] = acc;
+    }
+    __syncthreads();
+}
+
+// stage 0: before the first iteration -- delays of the first motion and loss+gradient launches
+__global__ __launch_bounds__(64) void sync_begin_kernel(SyncLoopParams p) {
+#pragma clang fp contract(off)
+    const uint32_t w = blockIdx.x * 64 + threadIdx.x;
+    if (w >= p.n_win) return;
+    SyncWin& s = p.win[w];
+    s.x0 = s.active ? s.d - p.delay_b * s.v : __builtin_nan("");
+    split64_dev(s.active ? s.d : __builtin_nan(""), p.fs, &p.mo_kd[w], &p.mo_fd[w]);
+    split64_dev(s.x0, p.fs, &p.lg_kd[w], &p.lg_fd[w]);
+    if (w == 0) { p.prev_hit[0] = kHalfBt - 1; p.prev_hit[1] = kHalfBt - 1; }
+}
+
+// which trials the first batch holds: as many as the previous iteration needed, at least five
+__device__ __forceinline__ int first_batch(const SyncLoopParams& p) {
+    const int ph = p.prev_hit[p.it & 1];
+    const int n = ph + 1 < kHalfBt ? kHalfBt : ph + 1;
+    return n > kMaxBt ? kMaxBt : n;
+}
+
+// stage G: after loss + gradient (rows: loss, gradient) -- first batch of line-search trials
+__global__ __launch_bounds__(kBlock) void sync_grad_kernel(SyncLoopParams p) {
+#pragma clang fp contract(off)
+    __shared__ double s_tot[2 * kMaxBt];
+    __shared__ double s_stage[kStageDoubles];
+    const uint32_t w = blockIdx.x;
+    window_sums(p, w, s_tot, s_stage);
+    if (threadIdx.x != 0) return;
+    SyncWin& s = p.win[w];
+    p.prev_hit[(p.it + 1) & 1] = kHalfBt - 1; // every window writes the same reset value for the next iteration
+    const int nf = first_batch(p);
+    if (s.active) {
+        s.l1 = s_tot[0];
+        s.g1 = s_tot[1];
+        s.hit = -1;
+    }
+    for (int i = 0; i < kMaxBt; ++i) {
+        const double td = (s.active && i < nf) ? s.x0 - p.ts[i] * s.g1 : __builtin_nan("");
+        split64_dev(td, p.fs, &p.tr_kd[(size_t)i * p.n_win + w], &p.tr_fd[(size_t)i * p.n_win + w]);
+    }
+}
+
+// the first trial of rows [b0, b1) that satisfies the Armijo test (backtrack.cpp:9)
+__device__ __forceinline__ void armijo(const SyncLoopParams& p, SyncWin& s, const double* lt, int b0, int b1) {
+#pragma clang fp contract(off)
+    if (!s.active || s.hit >= 0) return;
+    const double m = s.g1 * s.g1;
+    for (int i = b0; i < b1; ++i) {
+        if (s.l1 - lt[i] >= p.ts[i] * p.c_armijo * m) {
+            s.hit = i;
+            break;
+        }
+    }
+}
+
+// stage T1: after the first batch of trials (rows: the ten trials) -- Armijo on it, then the second batch for
+// the windows that found none
+__global__ __launch_bounds__(kBlock) void sync_trial1_kernel(SyncLoopParams p) {
+#pragma clang fp contract(off)
+    __shared__ double s_tot[2 * kMaxBt];
+    __shared__ double s_stage[kStageDoubles];
+    const uint32_t w = blockIdx.x;
+    window_sums(p, w, s_tot, s_stage);
+    if (threadIdx.x != 0) return;
+    SyncWin& s = p.win[w];
+    const int nf = first_batch(p);
+    armijo(p, s, s_tot, 0, nf);
+    for (int i = 0; i < kMaxBt; ++i) {
+        const double td = (s.active && s.hit < 0 && i >= nf) ? s.x0 - p.ts[i] * s.g1 : __builtin_nan("");
+        split64_dev(td, p.fs, &p.tr_kd[(size_t)i * p.n_win + w], &p.tr_fd[(size_t)i * p.n_win + w]);
+    }
+}
+
+// stage T2: after the second batch -- Armijo on it, the step (core_private.cpp:298-305), the stopping rules
+// (:316-328), the trace row, and the delays of the next iteration's launches
+__global__ __launch_bounds__(kBlock) void sync_step_kernel(SyncLoopParams p) {
+#pragma clang fp contract(off)
+    __shared__ double s_tot[2 * kMaxBt];
+    __shared__ double s_stage[kStageDoubles];
+    const uint32_t w = blockIdx.x;
+    window_sums(p, w, s_tot, s_stage);
+    if (threadIdx.x != 0) return;
+    SyncWin& s = p.win[w];
+    const int nf = first_batch(p);
+    armijo(p, s, s_tot, nf, kMaxBt);
+    if (s.active) {
+        const double v = s.l1, g = s.g1;
+        // never satisfied: t0 * decay^max_bt, untested (backtrack.cpp:11-12)
+        const double t = s.hit >= 0 ? p.ts[s.hit] : p.ts[kMaxBt];
+        const int trials = s.hit >= 0 ? s.hit + 1 : kMaxBt;
+        const double step = -t * g;
+        s.v = p.delay_b * s.v + step; // :301
+        s.d += s.v;                   // :302
+        const double step_size = fabs(step);
+        double* row = p.trace + ((size_t)s.iters * p.n_win + w) * 6; // [iteration][window][6]
+        row[0] = s.d; row[1] = step; row[2] = v; row[3] = g; row[4] = t; row[5] = (double)trials;
+        s.iters += 1;
+        if (step_size < 1e-4) s.conv++; else s.conv = 0;                            // :316-320
+        bool stop = s.conv > 5;                                                     // :322-324
+        if (!stop && fabs(s.d - p.search_center) > p.search_radius) stop = true;    // :326-328
+        atomicMax(&p.prev_hit[(p.it + 1) & 1], s.hit >= 0 ? s.hit : kMaxBt - 1);
+        if (stop || p.it + 1 == p.max_outer) s.active = 0;
+        else atomicAdd(&p.n_active[p.it], 1);
+    }
+    s.x0 = s.active ? s.d - p.delay_b * s.v : __builtin_nan("");
+    split64_dev(s.active ? s.d : __builtin_nan(""), p.fs, &p.mo_kd[w], &p.mo_fd[w]);
+    split64_dev(s.x0, p.fs, &p.lg_kd[w], &p.lg_fd[w]);
+}
+
+} // namespace

@@ -21,6 +21,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -39,6 +40,7 @@ using rs::f4;
 #include "kernels/lmeds.hpp"
 #include "kernels/support.hpp"
 #include "kernels/sync64.hpp"
+#include "kernels/syncloop.hpp"
 
 // ===========================================================================
 // host side of the C-ABI
@@ -68,6 +70,8 @@ struct rship_ctx {
     DevBuf coef, coef64, raw, rays_a, rays_b, rays64, frames, sel, M, k, grp, grp_off, init_h;
     // reduction plan (rship_set_plan): windows -> chunks -> slots
     DevBuf plan_idx, plan_chunk_off, plan_win_off, chunk_out, win_out;
+    uint32_t plan_max_chunks = 0; // most chunks in one window
+    DevBuf loop_state;            // rship_sync_run: windows, delay arrays, counters, trace
     bool plan_has_idx = false;
     uint32_t plan_chunks = 0, plan_wins = 0, plan_len = 0;
     // what the last *_enqueue left for its *_collect
@@ -360,6 +364,7 @@ void* rccl_sym(rship_ctx* c, const char* name) {
 extern "C" {
 
 int rship_max_tracks(void) { return kMaxRpt * kBlock; }
+int rship_has_device_loop(void) { return 1; }
 
 // Staging memory for the host solver: pinned, so that rship_upload_raw is a true asynchronous DMA
 // at PCIe rate (a pageable source is staged through a bounce buffer at ~1 GB/s: round 1's 0.24 s
@@ -408,7 +413,7 @@ void rship_destroy(rship_ctx* c) {
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     DevBuf* bufs[] = {&c->coef, &c->coef64, &c->raw, &c->rays_a, &c->rays_b, &c->rays64, &c->frames, &c->sel, &c->M, &c->k, &c->grp, &c->grp_off,
-                      &c->plan_idx, &c->plan_chunk_off, &c->plan_win_off, &c->chunk_out, &c->win_out, &c->kd, &c->kd64, &c->init_h,
+                      &c->plan_idx, &c->plan_chunk_off, &c->plan_win_off, &c->chunk_out, &c->win_out, &c->loop_state, &c->kd, &c->kd64, &c->init_h,
                       &c->frame_cost, &c->best_h, &c->costs, &c->part, &c->flags, &c->stats};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -607,6 +612,8 @@ int rship_set_plan(rship_ctx* c, const uint32_t* plan_idx, uint32_t plan_len, co
     RS_HIP(hipMemcpyAsync(c->plan_win_off.p, win_chunk_off, (size_t)(n_win + 1) * 4, hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipStreamSynchronize(c->stream));
     c->plan_has_idx = plan_idx != nullptr;
+    c->plan_max_chunks = 0;
+    for (uint32_t w = 0; w < n_win; ++w) c->plan_max_chunks = std::max(c->plan_max_chunks, win_chunk_off[w + 1] - win_chunk_off[w]);
     c->plan_chunks = n_chunks;
     c->plan_wins = n_win;
     c->plan_len = plan_len;
@@ -903,6 +910,149 @@ int rship_loss_collect(rship_ctx* c, uint32_t n_delays, double* win_loss, double
     if (chunk_loss) memcpy(chunk_loss, base + c->pend.off_chunk, cn * 8);
     if (chunk_grad && c->pend.grad) memcpy(chunk_grad, base + c->pend.off_chunk + cn * 8, cn * 8);
     c->pend.rows = 0;
+    return 0;
+}
+
+// Sync's whole outer loop (core_private.cpp:298-331) for the W windows (= groups) of the selection, driven from
+// the device: see kernels/syncloop.hpp.  d0[W] initial delays (after rship_init_motion, or rship_init_k_simple
+// for the simplified mode); on return d_out[W], iters[W] and trace[W][max_outer][6] (rows as
+// rssync_ext_sync_trace).  The plan must be one window per group over the slots in order.
+int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_center, double search_radius,
+                   int simplified, double* d_out, int32_t* iters, double* trace) {
+    DeviceGuard dev_guard(c);
+    if (check_ready(c)) return 1;
+    const uint32_t W = c->n_grp, ns = c->n_sel;
+    if (c->plan_wins != W || c->plan_has_idx || c->plan_len != ns) return set_err(c, "sync_run: the plan must be the selection's groups");
+    if (max_outer <= 0) return set_err(c, "sync_run: no iterations");
+    // one allocation: windows | motion delays | loss delays | trial delays | counters | trace | chunk scratch
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t o_win = take(W * sizeof(SyncWin));
+    const size_t o_mokd = take(W * 4), o_mofd = take(W * 8), o_lgkd = take(W * 4), o_lgfd = take(W * 8);
+    const size_t o_trkd = take((size_t)kMaxBt * W * 4), o_trfd = take((size_t)kMaxBt * W * 8);
+    const size_t o_prev = take(8), o_nact = take((size_t)max_outer * 4);
+    const size_t o_trace = take((size_t)W * max_outer * 48);
+    const size_t o_tmp = take((size_t)W * 2 * kMaxBt * (c->plan_max_chunks + 1) * 8);
+    if (ensure(c, c->loop_state, off)) return 1;
+    char* base = (char*)c->loop_state.p;
+    if (ensure(c, c->part, (size_t)2 * kMaxBt * ns * 8)) return 1;
+
+    std::vector<SyncWin> hw(W);
+    for (uint32_t w = 0; w < W; ++w) {
+        hw[w] = SyncWin{};
+        hw[w].d = d0[w];
+        hw[w].active = 1;
+        hw[w].hit = -1;
+    }
+    RS_HIP(hipMemcpyAsync(base + o_win, hw.data(), W * sizeof(SyncWin), hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemsetAsync(base + o_nact, 0, (size_t)max_outer * 4, c->stream));
+
+    SyncLoopParams lp{};
+    lp.win = (SyncWin*)(base + o_win);
+    lp.n_win = W;
+    lp.part = (const double*)c->part.p;
+    lp.n_sel = ns;
+    lp.chunk_off = (const uint32_t*)c->plan_chunk_off.p;
+    lp.win_chunk_off = (const uint32_t*)c->plan_win_off.p;
+    lp.chunk_tmp = (double*)(base + o_tmp);
+    lp.chunk_stride = c->plan_max_chunks + 1;
+    lp.mo_kd = (int32_t*)(base + o_mokd); lp.mo_fd = (double*)(base + o_mofd);
+    lp.lg_kd = (int32_t*)(base + o_lgkd); lp.lg_fd = (double*)(base + o_lgfd);
+    lp.tr_kd = (int32_t*)(base + o_trkd); lp.tr_fd = (double*)(base + o_trfd);
+    lp.fs = c->fs;
+    {
+        double t = 1e-3; // t0, decay = 0.1 (core_private.cpp:226): the host loop's sequence, bit for bit
+        for (int i = 0; i <= kMaxBt; ++i) { lp.ts[i] = t; t *= .1; }
+    }
+    lp.c_armijo = 2e-4;
+    lp.delay_b = .3;
+    lp.search_center = search_center;
+    lp.search_radius = search_radius;
+    lp.max_outer = max_outer;
+    lp.prev_hit = (int*)(base + o_prev);
+    lp.n_active = (int*)(base + o_nact);
+    lp.trace = (double*)(base + o_trace);
+
+    Motion64Params mp{};
+    fill_motion(c, mp);
+    mp.kd = lp.mo_kd;
+    mp.fd = lp.mo_fd;
+    Loss64Params qp{};
+    qp.rays = rays64_of(c);
+    qp.frames = (const FrameRec*)c->frames.p;
+    qp.sel = (const uint32_t*)c->sel.p;
+    qp.n_sel = ns;
+    qp.coef = (const d4*)c->coef64.p;
+    qp.n_knots = (int)c->n_knots;
+    qp.fs = c->fs;
+    qp.grp = W > 1 ? (const uint32_t*)c->grp.p : nullptr;
+    qp.n_grp = W;
+    qp.M = (const double*)c->M.p;
+    qp.k = (const double*)c->k.p;
+    qp.part_loss = (double*)c->part.p;
+    const int rpt = rpt_for(c->max_n);
+    auto loss_launch = [&](bool grad) -> int {
+        if (simplified) return grad ? launch_loss64<true, true>(c, qp, rpt) : launch_loss64<false, true>(c, qp, rpt);
+        return grad ? launch_loss64<true, false>(c, qp, rpt) : launch_loss64<false, false>(c, qp, rpt);
+    };
+
+    if (ensure_pinned(c, (size_t)max_outer * 4 + 64)) return 1;
+    hipLaunchKernelGGL(sync_begin_kernel, dim3((W + 63) / 64), dim3(64), 0, c->stream, lp);
+    RS_HIP(hipGetLastError());
+    const int kLook = 8; // iterations enqueued between two looks at the counter of active windows
+    int it = 0;
+    bool done = false;
+    while (it < max_outer && !done) {
+        const int until = std::min(max_outer, it + kLook);
+        for (; it < until; ++it) {
+            lp.it = it;
+            if (!simplified) {
+                if (launch_motion64(c, mp)) return 1; // :311 (finishes a pending GuessMotion on its first launch)
+                c->init_pending = false;
+                mp.init_h = (int32_t*)c->init_h.p;
+            }
+            // loss + gradient at x0 (:298-299 -> backtrack.cpp:4)
+            qp.kd = lp.lg_kd; qp.fd = lp.lg_fd; qp.n_delays = 1;
+            qp.part_grad = qp.part_loss + (size_t)ns;
+            if (loss_launch(true)) return 1;
+            lp.rows = 2;
+            {
+                ProfScope ps(c, RSHIP_K_REDUCE);
+                hipLaunchKernelGGL(sync_grad_kernel, dim3(W), dim3(W > 64 ? 64 : kBlock), 0, c->stream, lp);
+            }
+            // the trials, in two batches (first: as many as the previous iteration needed)
+            qp.kd = lp.tr_kd; qp.fd = lp.tr_fd; qp.n_delays = kMaxBt;
+            qp.part_grad = nullptr;
+            lp.rows = kMaxBt;
+            if (loss_launch(false)) return 1;
+            {
+                ProfScope ps(c, RSHIP_K_REDUCE);
+                hipLaunchKernelGGL(sync_trial1_kernel, dim3(W), dim3(W > 64 ? 64 : kBlock), 0, c->stream, lp);
+            }
+            if (loss_launch(false)) return 1;
+            {
+                ProfScope ps(c, RSHIP_K_REDUCE);
+                hipLaunchKernelGGL(sync_step_kernel, dim3(W), dim3(W > 64 ? 64 : kBlock), 0, c->stream, lp);
+            }
+            RS_HIP(hipGetLastError());
+        }
+        RS_HIP(hipMemcpyAsync(c->pinned, base + o_nact, (size_t)it * 4, hipMemcpyDeviceToHost, c->stream));
+        if (sync_stream(c)) return 1;
+        done = ((const int*)c->pinned)[it - 1] == 0;
+    }
+    // the windows and the rows of the iterations that ran ([iteration][window][6] on the device), through pinned memory
+    const size_t tr_bytes = (size_t)it * W * 48, win_bytes = W * sizeof(SyncWin);
+    if (ensure_pinned(c, tr_bytes + win_bytes + 64)) return 1;
+    RS_HIP(hipMemcpyAsync(c->pinned, base + o_win, win_bytes, hipMemcpyDeviceToHost, c->stream));
+    RS_HIP(hipMemcpyAsync((char*)c->pinned + win_bytes, base + o_trace, tr_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (sync_stream(c)) return 1;
+    memcpy(hw.data(), c->pinned, win_bytes);
+    const double* tr = (const double*)((const char*)c->pinned + win_bytes);
+    for (uint32_t w = 0; w < W; ++w) {
+        d_out[w] = hw[w].d;
+        iters[w] = hw[w].iters;
+        for (int k = 0; k < hw[w].iters; ++k) memcpy(trace + ((size_t)w * max_outer + k) * 6, tr + ((size_t)k * W + w) * 6, 48);
+    }
     return 0;
 }
 

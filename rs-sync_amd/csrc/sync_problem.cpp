@@ -264,6 +264,7 @@ class SyncProblemHip final : public ISyncProblem {
     bool has_frame(int64_t id) const { return frames_.count(id) != 0; }
     size_t frame_tracks(int64_t id) const { return frames_.at(id).n; }
     uint32_t sync_calls = 0;
+    bool host_loop = false; // keep Sync's outer loop on the host even where the device could run it (tests)
     uint64_t last_best_not_last = 0; // of the last rssync_ext_opt_motion call
 
    private:
@@ -317,6 +318,7 @@ SyncProblemHip::SyncProblemHip() {
     if (const char* s = std::getenv("RSSYNC_SEED")) seed = std::strtoull(s, nullptr, 0);
     if (const char* s = std::getenv("RSSYNC_MAX_OUTER_ITERS")) max_outer = std::atoi(s);
     if (const char* s = std::getenv("RSSYNC_QUIET")) verbose = !(s[0] && s[0] != '0');
+    if (const char* s = std::getenv("RSSYNC_HOST_LOOP")) host_loop = s[0] && s[0] != '0';
     // RSSYNC_GPUS: how many GPUs this object spreads its frames over ("4" = devices 0..3) or which
     // ("0,2,5"); default: the calling thread's current device only
     std::vector<int> ids;
@@ -855,8 +857,10 @@ void SyncProblemHip::apply_selection(const std::vector<uint32_t>& slots, const s
             sh.win_chunk_off.push_back((uint32_t)coff.size() - 1);
         }
         sh.n_chunks = (uint32_t)coff.size() - 1;
-        hip_check(sh, rship_set_plan(sh.ctx, pidx.data(), (uint32_t)pidx.size(), coff.data(), sh.n_chunks, sh.win_chunk_off.data(),
-                                     (uint32_t)n_win),
+        bool identity = pidx.size() == sh.sel.size();
+        for (size_t j = 0; j < pidx.size() && identity; ++j) identity = pidx[j] == j;
+        hip_check(sh, rship_set_plan(sh.ctx, identity ? nullptr : pidx.data(), (uint32_t)pidx.size(), coff.data(), sh.n_chunks,
+                                     sh.win_chunk_off.data(), (uint32_t)n_win),
                   "set plan");
     }
 }
@@ -1232,6 +1236,35 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
     }
     traces.assign(W, {});
 
+    // One device holds every frame and nobody else takes part in the sums: the loop below runs on the device
+    // (rship_sync_run, kernels/syncloop.hpp -- the same decisions, taken between the launches without a host
+    // round trip), and only its results are read back.
+    if (shards_.size() == 1 && !distributed() && !host_loop && rship_has_device_loop() && max_outer > 0 && !sel_.empty()) {
+        Shard& sh = shards_[0];
+        std::vector<double> tr((size_t)W * max_outer * 6, 0.0);
+        std::vector<int32_t> its(W, 0);
+        hip_check(sh, rship_sync_run(sh.ctx, d.data(), max_outer, search_center, search_radius, simplified ? 1 : 0, d.data(),
+                                     its.data(), tr.data()),
+                  "sync loop");
+        for (size_t w = 0; w < W; ++w)
+            traces[w].assign(tr.begin() + w * (size_t)max_outer * 6, tr.begin() + (w * (size_t)max_outer + its[w]) * 6);
+        if (verbose && W == 1) { // :330, the lines the host loop would have written
+            int conv = 0;
+            for (int it = 0; it < its[0]; ++it) {
+                const double* row = &traces[0][(size_t)it * 6];
+                const double step_size = std::fabs(row[1]);
+                if (step_size < 1e-4) conv++; else conv = 0;
+                const bool stop = conv > 5 || std::fabs(row[0] - search_center) > search_radius;
+                if (!stop) std::cerr << row[0] << " " << step_size << std::endl;
+            }
+        }
+        std::vector<double> lfin;
+        loss(d, lfin, nullptr, simplified); // :333
+        costs = lfin;
+        delays_out = d;
+        return;
+    }
+
     const double c_armijo = 2e-4, decay = .1, t0 = 1e-3; // :226
     const int max_bt = 10, half_bt = 5;
     const double delay_b = .3; // :260
@@ -1518,6 +1551,10 @@ int rssync_ext_set_lbfgs_reeval(rssync_problem* p, int reeval) {
     return guarded([&] {
         p->impl->set_option(RSHIP_OPT_LBFGS_REEVAL, reeval);
     });
+}
+int rssync_ext_set_host_loop(rssync_problem* p, int host_loop) {
+    p->impl->host_loop = host_loop != 0;
+    return 0;
 }
 int rssync_ext_lbfgs_best_not_last(rssync_problem* p, uint64_t* count) {
     *count = p->impl->last_best_not_last;

@@ -574,6 +574,11 @@ int rship_loss_collect(rship_ctx* c, uint32_t n_delays, double* win_loss, double
     return 0;
 }
 
+int rship_has_device_loop(void) { return 0; } // the host loop is what this double is there to exercise
+int rship_sync_run(rship_ctx* c, const double*, int, double, double, int, double*, int32_t*, double*) {
+    return fail(c, "sync_run: device only");
+}
+
 int rship_get_motion(rship_ctx* c, double* M, double* k, uint32_t cap, uint32_t* n) {
     uint32_t cnt = (uint32_t)std::min<size_t>(c->sel.size(), cap);
     for (uint32_t i = 0; i < cnt; ++i) {

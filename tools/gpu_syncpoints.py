@@ -34,13 +34,22 @@ def loop(h):
 seq, bat = problem(), problem()
 loop(seq); bat.sync_points(pos, WINDOW, 0.0, 0.001, 0.1)    # warm-up (also advances both streams equally)
 t = time.perf_counter(); ds = loop(seq); t_seq = time.perf_counter() - t
-bat.profile(True); bat.profile_reset()
 t = time.perf_counter(); _, db = bat.sync_points(pos, WINDOW, 0.0, 0.001, 0.1); t_bat = time.perf_counter() - t
-prof = bat.profile_get() if hasattr(bat, "profile_get") else None
+# kernel breakdown from a second, profiled run (two HIP events per launch make the host the bottleneck of a
+# loop of ~10 us launches: not the run that is timed); same sampler streams as a third sequential pass would use
+loop(seq)
+bat.profile(True); bat.profile_reset()
+t = time.perf_counter(); bat.sync_points(pos, WINDOW, 0.0, 0.001, 0.1); t_prof = time.perf_counter() - t
+prof = bat.profile_get()
+hostloop = problem(); hostloop.set_host_loop(True)
+hostloop.sync_points(pos, WINDOW, 0.0, 0.001, 0.1)
+t = time.perf_counter(); _, dh = hostloop.sync_points(pos, WINDOW, 0.0, 0.001, 0.1); t_host = time.perf_counter() - t
 iters = [len(bat.window_trace(w)) for w in range(len(pos))]
 print(json.dumps({"frames": F, "tracks": N, "window": WINDOW, "positions": len(pos),
                   "sequential_s": round(t_seq, 4), "batched_s": round(t_bat, 4), "speedup": round(t_seq / t_bat, 2),
+                  "batched_host_loop_s": round(t_host, 4), "batched_profiled_s": round(t_prof, 4),
                   "identical": bool(np.array_equal(ds, db)), "max_abs_diff": float(np.abs(ds - db).max()),
+                  "host_loop_identical": bool(np.array_equal(dh, db)),
                   "delay_err_vs_truth_ms": {"median": float(np.median(np.abs(db - synth.D_TRUE)) * 1e3),
                                            "max": float(np.abs(db - synth.D_TRUE).max() * 1e3)},
                   "outer_iters_per_position": {"mean": float(np.mean(iters)), "max": int(np.max(iters))},
