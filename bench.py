@@ -28,6 +28,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 BYTES_PER_RR = 32      # 8 fp32 per ray pair read per (frame, delay) evaluation
+FLOP_PER_RR_PRESYNC = 390       # ~230 flop per residual row + 20 hypotheses x ~8
+FP32_VECTOR_PEAK_TF = 157.3     # MI355X_MICROARCH.md: peak FP32 (vector)
+PMC_SUMMARY = "r2_pmc_summary.json"
 
 
 def main():
@@ -76,9 +79,17 @@ def main():
     # one gyro track for the whole window, identical on every rank
     gyro = synth.make_gyro(0.0, (total_frames + 2) / synth.FPS, seed=0x5EED0003)
     prob = rssync_amd.SyncProblem(seed=0x5EED0003, max_outer_iters=args.outer_iters, verbose=False)
+    # host side of the boundary, outside the timed region: generate the frames, then hand them over with the
+    # reference's calls (SetTrackResult copies into pinned staging and starts the upload)
     t_gen = time.time()
-    synth.fill(prob, gyro, f_begin, f_end, N, seed=0x5EED0003)
+    frames_in = list(synth.make_frames(gyro, f_begin, f_end, N, seed=0x5EED0003))
     t_gen = time.time() - t_gen
+    t_set = time.time()
+    prob.SetGyroQuaternions(gyro.quats, gyro.fs, gyro.t0)
+    for fr in frames_in:
+        prob.SetTrackResult(*fr)
+    t_set = time.time() - t_set
+    del frames_in
 
     if world > 1:
         from rssync_amd.dist import make_reduce_hook, use_native_rccl
@@ -160,27 +171,30 @@ def main():
                     "avg_launch_ms": round(avg_ms, 4), "launches": n_l,
                     "note": "equivalent bandwidth: 32 B per nominal ray-residual; the kernel reuses each ray "
                             "across the candidates of a chunk and is VALU/LDS-bound (DESIGN.md)"}
-        # HBM traffic of that kernel from the PMC run committed under profiles/ (separate --pmc
-        # passes for FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-        # for gfx950); only valid for the default workload.  The same file holds the kernel's VALU
-        # instruction count, which gives the roofline that actually bounds it (VALU issue).
-        roof_valu = None
+        # HBM traffic of that kernel: NOT measured by this run (counters need their own rocprofv3 --pmc passes);
+        # read from the PMC summary committed under profiles/ (tools/collect_pmc.sh: separate passes for
+        # FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), which is
+        # only valid for the default workload
+        roof_flop = None
+        if roof:
+            # nominal arithmetic of the same launches: ~390 flop per PreSync ray-residual (230
+            # for the residual row + 20 hypotheses x 8) against the fp32 vector peak, from this run's HIP events
+            flops = F * N * n_cand * FLOP_PER_RR_PRESYNC
+            ach_tf = flops / (roof["avg_launch_ms"] * 1e-3) / 1e12
+            roof_flop = {"bound": "fp32-vector", "kernel": "lmeds_kernel", "achieved": round(ach_tf, 2),
+                         "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach_tf / FP32_VECTOR_PEAK_TF, 4),
+                         "note": "nominal 390 flop per ray-residual x ray-residuals of one launch / live launch time; "
+                                 "what limits the kernel: DESIGN.md section 3 and profiles/r2_valu_rate.txt"}
         if roof and (F, N, n_cand) == (4096, 2048, 800):
-            try:
-                raw = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")))["lmeds_kernel<8, 0>"]
-                roof["traffic"] = round((2 * raw["FETCH_SIZE"]["mean_per_launch_KiB"] +
-                                         raw["WRITE_SIZE"]["mean_per_launch_KiB"]) * 1024 / 1e9, 4)
-                roof["traffic_unit"] = "GB per launch (profiles/r1_pmc_summary.json)"
-                insts = raw["SQ_INSTS_VALU"]["mean_per_launch"]
-                peak = 1024 * 2.4e9 / 4.43  # wave64 VALU instructions/s: tools/ubench/valu_rate.hip on MI355X
-                ach = insts / (roof["avg_launch_ms"] * 1e-3)
-                roof_valu = {"bound": "valu-issue", "kernel": "lmeds_kernel", "achieved": round(ach / 1e9, 2),
-                             "peak": round(peak / 1e9, 2), "unit": "G wave-instr/s", "frac": round(ach / peak, 4),
-                             "note": "SQ_INSTS_VALU per launch from profiles/r1_pmc_summary.json over the live "
-                                     "launch time; peak = 1024 SIMDs x 2.4 GHz / 4.43 cycles per wave64 VALU "
-                                     "instruction (measured, tools/ubench)"}
-            except Exception:
-                pass
+            pmc_path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
+            if os.path.exists(pmc_path):
+                raw = json.load(open(pmc_path))
+                key = [k for k in raw if k.startswith("lmeds_kernel<8, 0")]
+                if key:
+                    ctr = raw[key[0]]
+                    roof["traffic"] = round((2 * ctr["FETCH_SIZE"]["mean_per_launch_KiB"] +
+                                             ctr["WRITE_SIZE"]["mean_per_launch_KiB"]) * 1024 / 1e9, 4)
+                    roof["traffic_unit"] = "GB per launch, from profiles/%s (a separate rocprofv3 --pmc run, not this one)" % PMC_SUMMARY
         kernels = {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in prof.items()}
         cpu = None
         if world == 1 and args.cpu_frames > 0:
@@ -190,12 +204,15 @@ def main():
             "value": value, "unit": "ray-residuals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": "PreSync sweep in fp32 (92 % of the nominal work), Sync in fp64 (the reference's arithmetic)",
             "config": {"workload": "PreSync(radius 200 ms, step 0.5 ms) + Sync(<=20 outer iters)",
                        "frames_per_gpu": F, "tracks": N, "candidates": n_cand,
                        "sync_outer_iters": iters_done, "gyro_hz": gyro.fs, "parallelism": "frames sharded x%d" % world},
-            "roofline": roof, "roofline_valu": roof_valu, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roof, "roofline_flop": roof_flop, "cpu_baseline": cpu, "kernels": kernels,
             "presync_ms_per_step": t_pre / args.steps * 1e3,
-            "result": result, "host": {"gen_s": round(t_gen, 2), "pack_upload_s": round(t_up, 3)},
+            "result": result, "host": {"gen_s": round(t_gen, 2), "set_track_result_s": round(t_set, 3), "pack_upload_s": round(t_up, 3),
+                     "note": "set_track_result_s = the SetTrackResult loop over all frames (checks + copy into pinned "
+                             "staging, upload started); pack_upload_s = waiting for that upload + packing kernel"},
         }
         if cpu:
             # reported for context only: the roofline fraction, not this ratio, says how good the kernels are

@@ -6,8 +6,7 @@ namespace {
 
 
 constexpr int kBlock = 256;
-constexpr int kWinMax = 80;  // knots of the spline staged in LDS per workgroup (5 KB; with the LMedS tile
-                             // a workgroup stays at 31.3 KB, five per CU)
+constexpr int kWinMax = 80;  // knots of the spline staged in LDS per workgroup (5 KB)
 constexpr uint32_t kInfBits = 0x7f800000u;
 
 // ---------------------------------------------------------------------------
@@ -95,24 +94,27 @@ struct Spline {
 constexpr int kPathGlobal = 0;   // general: any parameter (extrapolation branches included), table read from L2
 constexpr int kPathInterior = 2; // staged in LDS and strictly inside the knots (0 <= idx <= n-2)
 
+// CAP = knots the LDS window holds (a compile-time constant: it is the stride between the four coefficient
+// kinds, folded into the ds_read offsets)
+template <int CAP = kWinMax>
 __device__ __forceinline__ void stage_window(Spline& s, f4* s_win, int lo, int hi) {
     const int n = s.n;
     const bool interior = lo >= 0 && hi <= n - 2;
     lo = lo < 0 ? 0 : (lo > n - 1 ? n - 1 : lo);
     hi = hi < 0 ? 0 : (hi > n - 1 ? n - 1 : hi);
     int wlen = hi - lo + 1;
-    s.path = (wlen <= kWinMax && interior) ? kPathInterior : kPathGlobal;
-    if (wlen > kWinMax) wlen = kWinMax;
+    s.path = (wlen <= CAP && interior) ? kPathInterior : kPathGlobal;
+    if (wlen > CAP) wlen = CAP;
     s.w0 = lo;
     s.wlen = wlen;
     s.lds = s_win;
     for (int e = threadIdx.x; e < wlen * 4; e += kBlock) {
         int knot = e >> 2, kind = e & 3;
-        s_win[kind * kWinMax + knot] = s.g[(size_t)(lo + knot) * 4 + kind];
+        s_win[kind * CAP + knot] = s.g[(size_t)(lo + knot) * 4 + kind];
     }
 }
 
-template <int PATH>
+template <int PATH, int CAP = kWinMax>
 __device__ __forceinline__ void fetch_coef(const Spline& s, int ci, f4& y, f4& b, f4& c, f4& d) {
     if (PATH == kPathGlobal) {
         const f4* p = s.g + (size_t)ci * 4;
@@ -120,9 +122,9 @@ __device__ __forceinline__ void fetch_coef(const Spline& s, int ci, f4& y, f4& b
     } else {
         const int rel = ci - s.w0;
         y = s.lds[rel];
-        b = s.lds[kWinMax + rel];
-        c = s.lds[2 * kWinMax + rel];
-        d = s.lds[3 * kWinMax + rel];
+        b = s.lds[CAP + rel];
+        c = s.lds[2 * CAP + rel];
+        d = s.lds[3 * CAP + rel];
     }
 }
 
@@ -141,15 +143,15 @@ __device__ __forceinline__ rs::Knot locate_sweep(float t, int base, float fd) {
 
 // one row of P = ar x br (core_private.cpp:24-28) and, if DERIV, dP/dx (x in knots).
 // A = {ax,bx,ay,by}, B = {az,bz,ta,tb} as stored in HBM.
-template <bool DERIV, int PATH, bool SWEEP = false>
+template <bool DERIV, int PATH, bool SWEEP = false, int CAP = kWinMax>
 __device__ __forceinline__ void residual_row(const Spline& s, f4 A, f4 B, int base, float fd, f3& P, f3& dP) {
     f4 ya, ba, ca, da, yb, bb, cb, db;
     rs::Knot ka = (PATH == kPathInterior) ? (SWEEP ? locate_sweep(B.z, base, fd) : rs::spline_locate_interior(B.z, base, fd))
                                           : rs::spline_locate(B.z, base, fd, s.n);
-    fetch_coef<PATH>(s, ka.ci, ya, ba, ca, da);
+    fetch_coef<PATH, CAP>(s, ka.ci, ya, ba, ca, da);
     rs::Knot kb = (PATH == kPathInterior) ? (SWEEP ? locate_sweep(B.w, base, fd) : rs::spline_locate_interior(B.w, base, fd))
                                           : rs::spline_locate(B.w, base, fd, s.n);
-    fetch_coef<PATH>(s, kb.ci, yb, bb, cb, db);
+    fetch_coef<PATH, CAP>(s, kb.ci, yb, bb, cb, db);
     if (!DERIV && PATH == kPathInterior) {
         // hot path, all in packed fp32.  Horner per end on the component pairs (w,x), (y,z) exactly as
         // ds_read_b128 delivers them (same fma chain per component as rs::horner, so the values are

@@ -55,10 +55,12 @@ __device__ __forceinline__ f3 hypothesis(const Tile& t, uint64_t seed, int64_t f
 }
 
 // wave-wide count of |r[]| < pivot (pivot: bit pattern of a non-negative float, uniform).
-// The kernel is bound by VALU issue (one wave64 instruction per 4 cycles per SIMD, PMC-measured),
-// while the scalar unit is mostly idle: each register costs ONE v_cmp (the abs modifier is free,
-// NaN never counts) whose 64-lane mask is counted with s_bcnt1_i32_b64 and added on the SALU.
-// The total arrives in an SGPR, so no cross-lane reduction is needed either.
+// Each register costs ONE v_cmp (the abs modifier is free, NaN never counts) whose 64-lane mask is counted
+// with s_bcnt1_i32_b64 and added on the scalar unit; the total arrives in an SGPR, so no cross-lane
+// reduction is needed.  (Measured alternative, round 2: v_cmp into VCC + v_addc_co_u32 into a per-lane
+// counter for 3 of every 8 registers, to take load off the scalar unit -- two scalar instructions per
+// register run at ~6 cycles per register per SIMD, tools/ubench/valu_rate.hip -- changed the kernel by
+// -1.5 % .. +0.5 % depending on the build: not kept.)
 template <int NR>
 __device__ __forceinline__ uint32_t wave_count_lt(const uint32_t (&r)[NR], uint32_t pivot) {
     const float pv = __uint_as_float(pivot);
@@ -150,18 +152,46 @@ __device__ __forceinline__ uint32_t select_kth(const uint32_t (&r)[NR], uint32_t
     }
 }
 
+// The frame's two ray streams as buffer resources: a row is addressed as (descriptor in SGPRs) + (one per-thread
+// byte offset, tid * 16) + (a per-row scalar offset, j * 4096), so the eight rows of a thread need ONE address
+// register instead of eight 64-bit pointers -- the kernel sits at the 96-VGPR limit of five waves per SIMD,
+// and hipcc had hoisted those pointers out of the candidate loop and spilled them.  Rows beyond the frame
+// read as zero (hardware range check).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct RayRsrc {
+    __amdgpu_buffer_rsrc_t a, b;
+};
+__device__ __forceinline__ RayRsrc make_ray_rsrc(const f4* rays_a, const f4* rays_b, uint32_t n) {
+    // the inputs are uniform over the workgroup (frame record via blockIdx); say so explicitly, or every load
+    // is wrapped in a waterfall loop
+    auto uni = [](const f4* p) {
+        const uint64_t v = (uint64_t)(uintptr_t)p;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        return (void*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    };
+    const int bytes = __builtin_amdgcn_readfirstlane((int)(n * 16u));
+    RayRsrc r;
+    r.a = __builtin_amdgcn_make_buffer_rsrc(uni(rays_a), 0, bytes, 0x00020000);
+    r.b = __builtin_amdgcn_make_buffer_rsrc(uni(rays_b), 0, bytes, 0x00020000);
+    return r;
+}
+__device__ __forceinline__ f4 load_ray(__amdgpu_buffer_rsrc_t rs_, uint32_t voff, uint32_t soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)voff, (int)soff, 0);
+    return f4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+
 // stage A of the LMedS kernel: this thread's rows of P for one delay, written to the LDS tile as
 // unit rows, norms kept in nrm[]; returns RSHIP_BAD_P if a row is not finite.  Rows >= N are not
 // touched: the kernel fills them with NaN once (their residuals compare above every threshold).
-template <int PATH, bool SWEEP>
-__device__ __forceinline__ uint32_t lmeds_row(const Spline& sp, const f4* __restrict__ rays_a,
-                                              const f4* __restrict__ rays_b, uint32_t N, uint32_t row, int base, float fd,
+template <int PATH, bool SWEEP, int CAP>
+__device__ __forceinline__ uint32_t lmeds_row(const Spline& sp, f4 A, f4 B, uint32_t N, uint32_t row, int base, float fd,
                                               const Tile& tile, float& nrm) {
     uint32_t bad = 0;
     nrm = 0.f;
     if (row < N) {
         f3 P, dP;
-        residual_row<false, PATH, SWEEP>(sp, rays_a[row], rays_b[row], base, fd, P, dP);
+        residual_row<false, PATH, SWEEP, CAP>(sp, A, B, base, fd, P, dP);
         const float n2 = rs::dot(P, P);
         if (!finite_f(n2)) bad = RSHIP_BAD_P;
         // safe_normalize (core_private.cpp:35-36): rows with |P| < 1e-12 stay as they are
@@ -173,21 +203,24 @@ __device__ __forceinline__ uint32_t lmeds_row(const Spline& sp, const f4* __rest
     return bad;
 }
 
-template <int RPT, bool SWEEP>
-__device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const f4* __restrict__ rays_a,
-                                               const f4* __restrict__ rays_b, uint32_t N, int base, float fd,
+template <int RPT, bool SWEEP, int CAP>
+__device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& rays, uint32_t N, int base, float fd,
                                                const Tile& tile, float (&nrm)[RPT]) {
     uint32_t bad = 0;
+    const uint32_t voff = threadIdx.x * 16u;
     if (sp.path == kPathInterior) {
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
-            bad |= lmeds_row<kPathInterior, SWEEP>(sp, rays_a, rays_b, N, j * kBlock + threadIdx.x, base, fd, tile, nrm[j]);
+            const f4 A = load_ray(rays.a, voff, (uint32_t)j * kBlock * 16u), B = load_ray(rays.b, voff, (uint32_t)j * kBlock * 16u);
+            bad |= lmeds_row<kPathInterior, SWEEP, CAP>(sp, A, B, N, j * kBlock + threadIdx.x, base, fd, tile, nrm[j]);
         }
     } else { // rare (ends of the gyro track, wild delays): keep the code small, not fast
         float tmp[RPT];
 #pragma unroll 1
-        for (int j = 0; j < RPT; ++j)
-            bad |= lmeds_row<kPathGlobal, false>(sp, rays_a, rays_b, N, j * kBlock + threadIdx.x, base, fd, tile, tmp[j]);
+        for (int j = 0; j < RPT; ++j) {
+            const f4 A = load_ray(rays.a, voff, (uint32_t)j * kBlock * 16u), B = load_ray(rays.b, voff, (uint32_t)j * kBlock * 16u);
+            bad |= lmeds_row<kPathGlobal, false, CAP>(sp, A, B, N, j * kBlock + threadIdx.x, base, fd, tile, tmp[j]);
+        }
 #pragma unroll
         for (int j = 0; j < RPT; ++j) nrm[j] = tmp[j];
     }
@@ -196,7 +229,10 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const f4* __res
 
 // waves per SIMD each kernel is compiled for (second __launch_bounds__ argument): the
 // LMedS tile is LDS-limited to 3 workgroups per CU at 8 rows per thread
-__host__ __device__ constexpr int lmeds_waves(int rpt) { return 5; }
+#ifndef RS_LMEDS_WAVES
+#define RS_LMEDS_WAVES 5
+#endif
+__host__ __device__ constexpr int lmeds_waves(int rpt) { return RS_LMEDS_WAVES; }
 __host__ __device__ constexpr int loss_waves(int rpt, bool grad) { return (grad || rpt >= 8) ? 3 : 4; }
 
 constexpr int kMaxChunk = 32; // candidates per workgroup (rship: chunk <= kMaxChunk)
@@ -222,19 +258,23 @@ __device__ __forceinline__ uint32_t wave_pop(uint32_t* counter) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
 }
 
-template <int RPT, int MODE> // MODE 0: PreSync cost per candidate; 1: GuessMotion's hypothesis search (Sync start)
+// WIN = knots of the LDS spline window (kWinMax in the product).  Round 2 measured a 28-knot window with a
+// 24-entry direction buffer: 27,088 B of LDS and 80 VGPRs, SIX workgroups per CU instead of five (the occupancy
+// API confirmed it) -- and the same launch time within 0.1 %, while four workgroups per CU had been 12 % slower
+// than five: beyond five waves per SIMD the kernel no longer gains from more resident waves.
+template <int RPT, int MODE, int WIN> // MODE 0: PreSync cost per candidate; 1: GuessMotion's hypothesis search (Sync start)
 __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsParams p) {
+    constexpr int kHyp = kHypBatch;
     constexpr int ROWS = kBlock * RPT;
     constexpr int NR = 4 * RPT; // residual registers per lane: a wave spans the whole tile
     __shared__ __attribute__((aligned(16))) float s_n[3][ROWS];
-    __shared__ f4 s_win[4 * kWinMax];
-    __shared__ f4 s_hyp[kHypBatch];
+    __shared__ f4 s_win[4 * WIN];
+    __shared__ f4 s_hyp[kHyp];
     __shared__ double s_red[2][4];
     // best (quantile, hypothesis) so far, packed (bits << 32 | h): a 64-bit min is exactly
     // "smaller quantile wins, ties go to the earlier hypothesis" (core_private.cpp:53 strict <)
     __shared__ unsigned long long s_key;
     __shared__ uint32_t s_next; // hypothesis queue of the current batch
-
     const int tid = threadIdx.x, lane = tid & 63;
     // blocks b and b+8 share an XCD (round-robin dispatch): keep the chunks of one
     // frame on one XCD so its rays are fetched into one L2 only
@@ -252,8 +292,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
 
     // rays are re-read per candidate: the chunks of a frame share an XCD, so after the
     // first touch they come from that XCD's L2 (keeping them in registers costs 64 VGPRs)
-    const f4* __restrict__ rays_a = p.rays_a + fr.off;
-    const f4* __restrict__ rays_b = p.rays_b + fr.off;
+    const RayRsrc rays = make_ray_rsrc(p.rays_a + fr.off, p.rays_b + fr.off, N);
 
     const uint32_t c0 = chunk * p.chunk;
     const uint32_t c1 = (c0 + p.chunk < p.n_cand) ? c0 + p.chunk : p.n_cand;
@@ -277,7 +316,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
             kd_lo = v < kd_lo ? v : kd_lo;
             kd_hi = v > kd_hi ? v : kd_hi;
         }
-        stage_window(sp, s_win, fr.base_knot + (int)floorf(fr.tmin) + kd_lo,
+        stage_window<WIN>(sp, s_win, fr.base_knot + (int)floorf(fr.tmin) + kd_lo,
                      fr.base_knot + (int)floorf(fr.tmax) + kd_hi + 1);
     }
 #pragma unroll
@@ -299,7 +338,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         uint32_t bad = 0;
         // ---- stage A: rows of P -> LDS tile as unit rows; norms stay in registers ----
         float nrm[RPT];
-        bad |= lmeds_rows<RPT, MODE == 0>(sp, rays_a, rays_b, N, base, fd, tile, nrm);
+        bad |= lmeds_rows<RPT, MODE == 0, WIN>(sp, rays, N, base, fd, tile, nrm);
 
         // ---- stage C: the hypotheses.  The best quantile of the previous candidate (x1.25: between
         // neighbouring candidates it moves by -20..+26 %, 1st..99th percentile) serves as a
@@ -312,8 +351,8 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         unsigned long long best;
         for (;;) {
             if (tid == 0) s_key = ((unsigned long long)guess << 32);
-            for (uint32_t batch = 0; batch < p.n_hyp; batch += kHypBatch) {
-                const uint32_t nb = (p.n_hyp - batch < (uint32_t)kHypBatch) ? p.n_hyp - batch : (uint32_t)kHypBatch;
+            for (uint32_t batch = 0; batch < p.n_hyp; batch += kHyp) {
+                const uint32_t nb = (p.n_hyp - batch < (uint32_t)kHyp) ? p.n_hyp - batch : (uint32_t)kHyp;
                 __syncthreads(); // tile written / previous batch consumed
                 if ((uint32_t)tid < nb) {
                     const f3 v = hypothesis(tile, p.seed, fr.id, stream, batch + tid, N);
@@ -371,7 +410,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         prev_best = bT;
         f3 Mv = f3{0, 0, 0};
         if (bH >= 0) {
-            if (p.n_hyp <= (uint32_t)kHypBatch) { // the winner's direction is still in the batch buffer
+            if (p.n_hyp <= (uint32_t)kHyp) { // the winner's direction is still in the batch buffer
                 const f4 hv = s_hyp[bH];
                 Mv = f3{hv.x, hv.y, hv.z};
             } else {

@@ -205,14 +205,14 @@ uint32_t sel_max_n(const rship_ctx* c) {
     return m;
 }
 
-template <int MODE>
+template <int MODE, int WIN>
 int launch_lmeds(rship_ctx* c, const LmedsParams& p, int rpt, uint32_t grid) {
     ProfScope ps(c, MODE == 1 ? RSHIP_K_INIT : RSHIP_K_LMEDS);
     switch (rpt) {
-        case 1: hipLaunchKernelGGL((lmeds_kernel<1, MODE>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-        case 2: hipLaunchKernelGGL((lmeds_kernel<2, MODE>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-        case 4: hipLaunchKernelGGL((lmeds_kernel<4, MODE>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-        case 8: hipLaunchKernelGGL((lmeds_kernel<8, MODE>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+        case 1: hipLaunchKernelGGL((lmeds_kernel<1, MODE, WIN>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+        case 2: hipLaunchKernelGGL((lmeds_kernel<2, MODE, WIN>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+        case 4: hipLaunchKernelGGL((lmeds_kernel<4, MODE, WIN>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+        case 8: hipLaunchKernelGGL((lmeds_kernel<8, MODE, WIN>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
         default: return set_err(c, "lmeds: unsupported rows-per-thread");
     }
     RS_HIP(hipGetLastError());
@@ -677,7 +677,7 @@ int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, uint
     uint32_t groups = (ns + 7) / 8;
     uint64_t grid = (uint64_t)groups * 8 * p.n_chunks;
     if (grid > 0x7fffffffull) return set_err(c, "presync: grid too large");
-    if (launch_lmeds<0>(c, p, rpt_for(c->max_n), (uint32_t)grid)) return 1;
+    if (launch_lmeds<0, kWinMax>(c, p, rpt_for(c->max_n), (uint32_t)grid)) return 1;
     if (launch_plan_sum(c, p.frame_cost, n_cand, ns)) return 1;
     size_t end = 0;
     if (queue_sums_to_host(c, n_cand, 0, &c->pend.off_chunk, &end)) return 1;
@@ -766,7 +766,7 @@ int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t
     p.best_h = (int32_t*)c->init_h.p;
     p.flags = (uint32_t*)c->flags.p;
     uint32_t groups = (c->n_sel + 7) / 8;
-    if (launch_lmeds<1>(c, p, rpt_for(c->max_n), groups * 8)) return 1;
+    if (launch_lmeds<1, kWinMax>(c, p, rpt_for(c->max_n), groups * 8)) return 1;
     c->init_pending = true;
     c->init_seed = seed;
     c->init_stream = stream;

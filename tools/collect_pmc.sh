@@ -8,7 +8,7 @@ OUT=${1:-gpurun_out/pmc}
 ROOT=$(pwd)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-GROUPS_=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" \
+GROUPS_=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_INSTS_SMEM SQ_INSTS_VMEM_WR" \
          "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
          "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" \
          "SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE")
@@ -17,7 +17,7 @@ for g in "${GROUPS_[@]}"; do
     d="$ROOT/$OUT/pass$i"
     rm -rf "$d"
     (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $g -d "$d" -o pmc --output-format csv -- \
-        python3 "$ROOT/bench.py" --steps 1 --warmup 0 --cpu-frames 0 > "$ROOT/$OUT/pass$i.log" 2>&1) || \
+        python3 "$ROOT/bench.py" --steps 3 --warmup 1 --cpu-frames 0 > "$ROOT/$OUT/pass$i.log" 2>&1) || \
         { echo "pass $i ($g) failed"; tail -5 "$ROOT/$OUT/pass$i.log"; }
     echo "pass $i done: $g"
     i=$((i + 1))
