@@ -227,12 +227,11 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
     return bad;
 }
 
-// waves per SIMD each kernel is compiled for (second __launch_bounds__ argument): the
-// LMedS tile is LDS-limited to 3 workgroups per CU at 8 rows per thread
-#ifndef RS_LMEDS_WAVES
-#define RS_LMEDS_WAVES 5
-#endif
-__host__ __device__ constexpr int lmeds_waves(int rpt) { return RS_LMEDS_WAVES; }
+// waves per SIMD the LMedS kernel is compiled for (second __launch_bounds__ argument).  Up to 2048 rows
+// (8 per thread) the 24 KB tile lets five workgroups share a CU; 4096 / 8192 rows (16 / 32 per thread, 48 /
+// 96 KB of tile, 64 / 128 residual registers per lane) run at two / one -- slower per row, but a frame of a
+// dense tracker is accepted instead of refused.
+__host__ __device__ constexpr int lmeds_waves(int rpt) { return rpt <= 8 ? 5 : (rpt == 16 ? 2 : 1); }
 __host__ __device__ constexpr int loss_waves(int rpt, bool grad) { return (grad || rpt >= 8) ? 3 : 4; }
 
 constexpr int kMaxChunk = 32; // candidates per workgroup (rship: chunk <= kMaxChunk)

@@ -348,7 +348,7 @@ __device__ __forceinline__ double dot3d(const double* a, const double* b) { retu
 __device__ __forceinline__ double clamp_k(double k) { return (k < 10.0) ? 10.0 : ((1000.0 < k) ? 1000.0 : k); } // inline_utils.hpp:50
 
 template <int RPT, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (NW == 1 ? (RPT >= 8 ? 3 : 4) : 2)) void opt_motion64_kernel(Motion64Params p) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? (RPT <= 8 ? 3 : (RPT == 16 ? 2 : 1)) : (NW == 1 ? (RPT >= 8 ? 3 : 4) : 2)) void opt_motion64_kernel(Motion64Params p) {
     constexpr int kThreads = 64 * NW;
     __shared__ d4 s_win[4 * kWinMax];
     __shared__ double s_part[2][NW][5];

@@ -89,15 +89,20 @@ __device__ __forceinline__ void window_sums(const SyncLoopParams& p, uint32_t w,
             }
             for (; j < j1; ++j) acc += row[j];
         } else {
+            // a chunk has at most 64 slots (the host's kChunk): all of them in flight at once, then the
+            // additions in slot order -- one memory round trip per chunk instead of eight
             const double* row = p.part + (size_t)r * p.n_sel;
-            for (; j + 8 <= j1; j += 8) { // eight loads in flight, the additions still in slot order
-                double v[8];
+            const uint32_t cnt = j1 - j;
+            if (cnt <= 64) {
+                double v[64];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = row[j + q];
+                for (int q = 0; q < 64; ++q) v[q] = (uint32_t)q < cnt ? row[j + q] : 0.0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) acc += v[q];
+                for (int q = 0; q < 64; ++q)
+                    if ((uint32_t)q < cnt) acc += v[q];
+            } else {
+                for (; j < j1; ++j) acc += row[j];
             }
-            for (; j < j1; ++j) acc += row[j];
         }
         tmp[(size_t)r * p.chunk_stride + (c - c0)] = acc;
     }

@@ -197,7 +197,7 @@ int rpt_for(uint32_t max_n) {
     return rpt;
 }
 
-constexpr int kMaxRpt = 8;
+constexpr int kMaxRpt = 32; // 8192 tracks per frame
 
 uint32_t sel_max_n(const rship_ctx* c) {
     uint32_t m = 0;
@@ -213,6 +213,8 @@ int launch_lmeds(rship_ctx* c, const LmedsParams& p, int rpt, uint32_t grid) {
         case 2: hipLaunchKernelGGL((lmeds_kernel<2, MODE, WIN>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
         case 4: hipLaunchKernelGGL((lmeds_kernel<4, MODE, WIN>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
         case 8: hipLaunchKernelGGL((lmeds_kernel<8, MODE, WIN>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+        case 16: hipLaunchKernelGGL((lmeds_kernel<16, MODE, WIN>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+        case 32: hipLaunchKernelGGL((lmeds_kernel<32, MODE, WIN>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
         default: return set_err(c, "lmeds: unsupported rows-per-thread");
     }
     RS_HIP(hipGetLastError());
@@ -227,6 +229,8 @@ int launch_loss64(rship_ctx* c, const Loss64Params& p, int rpt) {
         case 2: hipLaunchKernelGGL((loss64_kernel<2, GRAD, SIMPLE>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
         case 4: hipLaunchKernelGGL((loss64_kernel<4, GRAD, SIMPLE>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
         case 8: hipLaunchKernelGGL((loss64_kernel<8, GRAD, SIMPLE>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        case 16: hipLaunchKernelGGL((loss64_kernel<16, GRAD, SIMPLE>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        case 32: hipLaunchKernelGGL((loss64_kernel<32, GRAD, SIMPLE>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
         default: return set_err(c, "loss: unsupported rows-per-thread");
     }
     RS_HIP(hipGetLastError());
@@ -252,6 +256,8 @@ int launch_motion64(rship_ctx* c, const Motion64Params& p) {
     else if (n <= 512) hipLaunchKernelGGL((opt_motion64_kernel<8, 1>), dim3(p.n_sel), dim3(64), 0, c->stream, p);
     else if (n <= 1024) hipLaunchKernelGGL((opt_motion64_kernel<4, 4>), dim3(p.n_sel), dim3(256), 0, c->stream, p);
     else if (n <= 2048) hipLaunchKernelGGL((opt_motion64_kernel<8, 4>), dim3(p.n_sel), dim3(256), 0, c->stream, p);
+    else if (n <= 4096) hipLaunchKernelGGL((opt_motion64_kernel<16, 4>), dim3(p.n_sel), dim3(256), 0, c->stream, p);
+    else if (n <= 8192) hipLaunchKernelGGL((opt_motion64_kernel<32, 4>), dim3(p.n_sel), dim3(256), 0, c->stream, p);
     else return set_err(c, "motion: unsupported track count");
     RS_HIP(hipGetLastError());
     return 0;

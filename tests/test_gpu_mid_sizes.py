@@ -184,3 +184,42 @@ def test_simplified_mode(N):
         np.testing.assert_allclose(k, [p[0] for p in per], rtol=1e-12)
         assert L[j] == pytest.approx(sum(p[1] for p in per), rel=1e-12)
         assert G[j] == pytest.approx(sum(p[2] for p in per), rel=1e-6, abs=1e-6 * abs(L[j]))
+
+
+@pytest.mark.parametrize("N", [2049, 4096, 5000])
+def test_more_than_2048_tracks_per_frame(N):
+    """frames of a dense tracker: 16 / 32 rows per thread (tile of 48 / 96 KB, 64 / 128 residual registers per
+    lane); same checks as at the other sizes, on a handful of frames"""
+    from rssync_amd import synth
+    F = 6
+    h, o = _pair(F, N, seed=70 + N, max_outer_iters=12)
+    Ph = h.problem_matrix(2, 0.0371, N)
+    assert np.abs(Ph - o.problem_matrix(2, 0.0371)).max() < 5e-7
+    assert np.abs(h.problem_matrix64(2, 0.0371, N) - o.problem_matrix(2, 0.0371)).max() < 1e-13
+    dh, ch, fch, bhh = h.presync_curve(0.0, 0, F, 0.004, 0.1, per_frame=F)
+    do, co, fco, bho = o.presync_curve(0.0, 0, F, 0.004, 0.1, per_frame=F)
+    np.testing.assert_array_equal(dh, do)
+    same = bhh == bho
+    assert same.mean() > 0.98
+    rel = np.abs(fch - fco) / fco
+    assert rel[same].max() < 1e-3 and np.median(rel[same]) < 2e-6
+    assert np.argmin(ch) == np.argmin(co)
+    Mh, kh = h.init_motion(0.036, 0, F - 1)
+    Lh, Gh = h.loss([0.036, 0.03], grad=True)
+    for j, dd in enumerate((0.036, 0.03)):
+        per = [o.loss(f, dd, Mh[f], kh[f]) for f in range(F)]
+        assert Lh[j] == pytest.approx(sum(p[0] for p in per), rel=1e-12)
+        assert Gh[j] == pytest.approx(sum(p[2] for p in per), rel=1e-10, abs=1e-10 * abs(Lh[j]))
+    c1, d1 = h.Sync(0.036, 0, F - 1, 0.0, 0.2)
+    assert np.isfinite(c1) and abs(d1 - synth.D_TRUE) < 2e-3
+
+
+def test_track_limit_is_a_documented_panic():
+    """the reference accepts any count (core_private.cpp:192-203); this build stops at 8192 per frame with a
+    message instead of computing something else"""
+    import rssync_amd
+    n = 8193
+    h = rssync_amd.SyncProblem()
+    ra = np.tile([0.0, 0.0, 1.0], (n, 1))
+    with pytest.raises(rssync_amd.RsSyncError, match="8193 tracks in one frame; this build accepts at most 8192"):
+        h.SetTrackResult(0, np.zeros(n), np.zeros(n), ra, ra)

@@ -185,7 +185,7 @@ def test_panics_follow_the_reference_messages(host, tiny_case):
     with pytest.raises(rssync_amd.RsSyncError, match="timestamps out of order at pos 11"):
         h.SetGyroQuaternionsTimestamped(ts, np.tile([1.0, 0, 0, 0], (50, 1)))
     with pytest.raises(rssync_amd.RsSyncError, match="tracks in one frame"):
-        n = 2049
+        n = 8193   # this build stops at 8192 tracks per frame (the reference has no limit)
         h.SetTrackResult(5, np.zeros(n), np.zeros(n), np.tile([0, 0, 1.0], (n, 1)), np.tile([0, 0, 1.0], (n, 1)))
 
 
