@@ -131,7 +131,7 @@ struct Loss64Params {
 // windows sit side by side in LDS, 10 KB each).  The line search's trials are far apart in time (steps of
 // 1e-3 .. 1e-12 times the gradient), so the windows cannot be shared; the rays can.  A pass per delay made
 // this kernel HBM/L2-bound (64 B per ray pair per delay: 6.5 TB/s effective at 4096 x 2048).
-constexpr int kLossBatch = 5;
+constexpr int kLossBatch = 5; // (6, at two workgroups per CU: 5 % slower)
 
 template <int RPT, bool GRAD, bool SIMPLE>
 __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
