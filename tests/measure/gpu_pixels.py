@@ -1,4 +1,4 @@
-"""rays_from_pixels_kernel at BASELINE size (4096 frames x 2048 tracks): kernel time, HBM rate,
+"""pack_frames_kernel on pixel frames at BASELINE size (4096 frames x 2048 tracks): kernel time, HBM rate,
 and the host route it replaces (CPU undistort -> SetTrackResult -> host packing).  GPU box."""
 import os, sys, time, json
 import numpy as np
@@ -29,7 +29,7 @@ for rep in range(3):
     n, ms = h.profile_get()["pixels"]
     res = {"launches": n, "kernel_ms": ms, "upload_call_s": round(t_up, 4)}
 pairs = F * N
-res["GB_per_s"] = round(pairs * 64 / (res["kernel_ms"] * 1e-3) / 1e9, 1)
+res["GB_per_s"] = round(pairs * 128 / (res["kernel_ms"] * 1e-3) / 1e9, 1)  # 32 B of pixels read, 32 + 64 B of packed streams written
 res["frac_of_8TBs"] = round(res["GB_per_s"] / 8000, 3)
 # the host route on a sample of frames: oracle undistort (C, fp64, 1 thread) + SetTrackResult
 S = min(F, 128)

@@ -1,0 +1,10 @@
+#!/bin/bash
+# every measurement script of the round, one after the other, on the GPU box (run from the repo root):
+#   bash tools/measure_all.sh r2        -> gpurun_out/r2_*.json / .txt
+P=${1:-r2}
+run() { name=$1; shift; echo "== $name"; timeout -k 10 600 "$@" > gpurun_out/${P}_$name 2> gpurun_out/${P}_$name.err || echo "   FAILED ($?)"; tail -c 600 gpurun_out/${P}_$name; echo; }
+run syncpoints.json python tools/gpu_syncpoints.py
+run orientation_sweep_c5.json python tools/gpu_orientations.py
+run pixels_kernel.json python tests/measure/gpu_pixels.py
+run config2_parity.json python tests/measure/gpu_config2_parity.py
+run fullsize_sync_parity.txt python tests/measure/gpu_fullsize_parity.py
