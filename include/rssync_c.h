@@ -118,6 +118,8 @@ int rssync_ext_upload(rssync_problem* p);
 int rssync_ext_sample_rate(rssync_problem* p, double* sample_rate, double* quats_start,
                            size_t* n_knots);
 int rssync_ext_gyro_knots(rssync_problem* p, double* out, size_t cap); /* [4*n_knots] */
+/* the spline table the kernels read: [n_knots][16] = y[4], b[4], c[4], d[4] over [w,x,y,z]; builds it if needed */
+int rssync_ext_gyro_table(rssync_problem* p, double* out, size_t cap);
 /* PreSync's whole curve: delays/costs [cap], optional per-frame matrices [n][n_frames] */
 int rssync_ext_presync_curve(rssync_problem* p, double initial_delay, int64_t frame_begin,
                              int64_t frame_end, double search_step, double search_radius,

@@ -57,7 +57,8 @@ typedef struct rship_frame {
 #define RSHIP_K_REDUCE 3 /* over-frames sums */
 #define RSHIP_K_INIT 4   /* the LMedS kernel in GuessMotion/GuessK mode (Sync start) */
 #define RSHIP_K_PIXELS 5 /* packing kernels: raw records (rays or pixels) -> packed fp32 + fp64 streams */
-#define RSHIP_K_COUNT 6
+#define RSHIP_K_GYRO 6   /* gyro pipeline: integration scan, resampling, spline solve */
+#define RSHIP_K_COUNT 7
 
 int rship_create(rship_ctx** out, int device /* -1 = current device */);
 void rship_destroy(rship_ctx* c);
@@ -76,10 +77,44 @@ int rship_max_tracks(void); /* largest per-frame track count the kernels accept:
 #define RSHIP_OPT_TRACKS_HINT 2
 int rship_set_option(rship_ctx* c, int option, int value);
 
-/* OptData::quats (core_private.hpp:18): coefficient table built on the host in fp64 by the spline
- * solver that replaces minispline.cpp:3-46: 16 doubles per knot = y[4], b[4], c[4], d[4] over
- * [w,x,y,z].  The device keeps it in fp64 (Sync kernels) and rounds it once to fp32 (PreSync). */
-int rship_upload_spline(rship_ctx* c, const double* coef16, uint32_t n_knots, double sample_rate);
+/* OptData::quats (core_private.hpp:18) is built ON THE DEVICE from whatever the caller has: uniform
+ * orientation samples, timestamped orientation samples, or timestamped angular rates.  The table holds 16
+ * doubles per knot = y[4], b[4], c[4], d[4] over [w,x,y,z] (the natural spline of minispline.cpp:3-46); the
+ * device keeps it in fp64 (Sync kernels) and a copy rounded once to fp32 (PreSync).
+ *
+ *   rship_gyro_uniform       core_private.cpp:135-140: the samples are the knots; spline solve.
+ *   rship_gyro_timestamped   core_private.cpp:142-190: order check, the integer-microsecond grid at the rate
+ *                            rounded to 50 Hz, slerp onto the grid, spline solve.
+ *   rship_gyro_rates_upload  + rship_gyro_rates_integrate: the reference driver's optdata_fill_gyro
+ *                            (core_testcode.cpp:36-52): q_i = normalise(dq_i q_{i-1}) as a scan of quaternion
+ *                            products, timestamps truncated to microseconds, then as the timestamped route.
+ *                            axis/sign permute the rate axes (output axis c = sign[c] * input axis axis[c]);
+ *                            one upload serves any number of integrations (the orientation sweep).
+ * The routes that can reject their input fill *out and return 0; `status` says what the reference would have
+ * complained about (its order of checks).  A nonzero return is a device failure. */
+#define RSHIP_GYRO_OK 0
+#define RSHIP_GYRO_OUT_OF_ORDER 1 /* bad_pos, bad_a = ts[pos-1], bad_b = ts[pos] */
+#define RSHIP_GYRO_BAD_KNOT 2     /* non-finite sample after interpolation */
+#define RSHIP_GYRO_SHORT_GRID 3   /* fewer than 2 grid points */
+#define RSHIP_GYRO_BAD_RATE 4     /* rate rounds to <= 0 Hz, or first == last timestamp */
+#define RSHIP_GYRO_BAD_START 5
+#define RSHIP_GYRO_BAD_INPUT 6    /* non-finite timestamp or rate (rates route) */
+#define RSHIP_GYRO_TOO_LARGE 7    /* negative timestamps or more than 2^26 grid points */
+typedef struct rship_gyro_result {
+    double fs, start;      /* grid rate (Hz), time of the first knot (s) */
+    uint64_t first_sample; /* grid index of the first knot */
+    uint64_t bad_pos;
+    int64_t bad_a, bad_b;
+    uint32_t n_knots;
+    int32_t status;
+} rship_gyro_result;
+int rship_gyro_uniform(rship_ctx* c, const double* quats, uint32_t n, double sample_rate);
+int rship_gyro_timestamped(rship_ctx* c, const int64_t* ts_us, const double* quats, uint32_t n, rship_gyro_result* out);
+int rship_gyro_rates_upload(rship_ctx* c, const double* ts_s, const double* rates, uint32_t n);
+int rship_gyro_rates_integrate(rship_ctx* c, const int32_t axis[3], const double sign[3], rship_gyro_result* out);
+/* read back: the knots [n_knots][4] / the fp64 table [n_knots][16] (tests, rssync_ext_gyro_knots) */
+int rship_gyro_knots(rship_ctx* c, double* out, uint32_t cap_knots);
+int rship_gyro_table(rship_ctx* c, double* out16, uint32_t cap_knots);
 
 /* OptData::frame_data (core_private.hpp:21).  Track data travels in three steps:
  *  1. SetTrackResult copies the caller's arrays into a host staging arena obtained from

@@ -22,6 +22,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -31,6 +32,7 @@
 #include "../../include/rssync_hip.h"
 #include "device_math.hpp"
 #include "lens_math.hpp"
+#include "gyro_math.hpp"
 
 using rs::f3;
 using rs::f4;
@@ -41,6 +43,7 @@ using rs::f4;
 #include "kernels/support.hpp"
 #include "kernels/sync64.hpp"
 #include "kernels/syncloop.hpp"
+#include "kernels/gyro.hpp"
 
 // ===========================================================================
 // host side of the C-ABI
@@ -71,6 +74,10 @@ struct rship_ctx {
     // reduction plan (rship_set_plan): windows -> chunks -> slots
     DevBuf plan_idx, plan_chunk_off, plan_win_off, chunk_out, win_out;
     uint32_t plan_max_chunks = 0; // most chunks in one window
+    // gyro pipeline (rship_gyro_*): inputs, intermediate orientations, grid knots, forward-sweep values, status
+    DevBuf g_ts, g_rates, g_us, g_dq, g_q, g_knots, g_cf, g_status;
+    uint32_t g_n = 0; // samples of the last rship_gyro_rates_upload
+    int64_t g_first_us = 0, g_last_us = 0;
     DevBuf loop_state;            // rship_sync_run: windows, delay arrays, counters, trace
     bool plan_has_idx = false;
     uint32_t plan_chunks = 0, plan_wins = 0, plan_len = 0;
@@ -420,7 +427,8 @@ void rship_destroy(rship_ctx* c) {
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     DevBuf* bufs[] = {&c->coef, &c->coef64, &c->raw, &c->rays_a, &c->rays_b, &c->rays64, &c->frames, &c->sel, &c->M, &c->k, &c->grp, &c->grp_off,
                       &c->plan_idx, &c->plan_chunk_off, &c->plan_win_off, &c->chunk_out, &c->win_out, &c->loop_state, &c->kd, &c->kd64, &c->init_h,
-                      &c->frame_cost, &c->best_h, &c->costs, &c->part, &c->flags, &c->stats};
+                      &c->frame_cost, &c->best_h, &c->costs, &c->part, &c->flags, &c->stats,
+                      &c->g_ts, &c->g_rates, &c->g_us, &c->g_dq, &c->g_q, &c->g_knots, &c->g_cf, &c->g_status};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -447,18 +455,170 @@ int rship_set_stream(rship_ctx* c, void* hip_stream) {
     return 0;
 }
 
-int rship_upload_spline(rship_ctx* c, const double* coef16, uint32_t n_knots, double sample_rate) {
-    DeviceGuard dev_guard(c);
-    if (n_knots < 2) return set_err(c, "spline: need >= 2 knots");
-    const size_t n = (size_t)n_knots * 16;
-    if (ensure(c, c->coef64, n * 8) || ensure(c, c->coef, n * 4)) return 1;
-    std::vector<float> f32(n); // rounded once, here (the PreSync kernel's table)
-    for (size_t i = 0; i < n; ++i) f32[i] = (float)coef16[i];
-    RS_HIP(hipMemcpyAsync(c->coef64.p, coef16, n * 8, hipMemcpyHostToDevice, c->stream));
-    RS_HIP(hipMemcpyAsync(c->coef.p, f32.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-    RS_HIP(hipStreamSynchronize(c->stream));
-    c->n_knots = n_knots;
+// ---- gyro pipeline ----------------------------------------------------------------------------------------
+namespace {
+
+constexpr uint32_t kMaxKnots = rs::kMaxKnots;
+
+const rs::SplinePivots* spline_pivots() {
+    static const rs::SplinePivots t = [] {
+        rs::SplinePivots p;
+        p.cp[0] = 0.0;
+        for (int i = 1; i < rs::kSplinePivots; ++i) p.cp[i] = rs::spline_next_pivot(p.cp[i - 1]);
+        return p;
+    }();
+    return &t;
+}
+
+// knots (c->g_knots, n of them) -> both coefficient tables
+int spline_from_knots(rship_ctx* c, uint32_t n, double sample_rate) {
+    if (n < 2) return set_err(c, "spline: need >= 2 knots");
+    if (n > kMaxKnots) return set_err(c, "spline: too many knots");
+    const rs::SplinePivots& piv = *spline_pivots();
+    if (rs::spline_next_pivot(piv.cp[rs::kSplinePivots - 1]) != piv.cp[rs::kSplinePivots - 1])
+        return set_err(c, "spline: pivots not stationary"); // cannot happen in IEEE double (stationary after ~30 rows)
+    const size_t n16 = (size_t)n * 16;
+    if (ensure(c, c->coef64, n16 * 8) || ensure(c, c->coef, n16 * 4) || ensure(c, c->g_cf, (size_t)n * 32)) return 1;
+    SplineParams p{};
+    p.knots = (const double*)c->g_knots.p;
+    p.cf = (double*)c->g_cf.p;
+    p.coef64 = (double*)c->coef64.p;
+    p.coef32 = (float*)c->coef.p;
+    p.n = n;
+    p.piv = piv;
+    const uint32_t threads = ((n + kSplineRun - 1) / kSplineRun) * 4;
+    {
+        ProfScope ps(c, RSHIP_K_GYRO);
+        hipLaunchKernelGGL(spline_forward_kernel, dim3((threads + 255) / 256), dim3(256), 0, c->stream, p);
+        hipLaunchKernelGGL(spline_finish_kernel, dim3((threads + 255) / 256), dim3(256), 0, c->stream, p);
+    }
+    RS_HIP(hipGetLastError());
+    c->n_knots = n;
     c->fs = sample_rate;
+    return 0;
+}
+
+// shared tail of the two timestamped routes: order check done, ts (us) and quats on the device
+int resample_and_solve(rship_ctx* c, const int64_t* d_ts, const double* d_quats, uint32_t n, int64_t first, int64_t last,
+                       rship_gyro_result* out) {
+    const int grid_status = rs::grid_of(first, last, n, kMaxKnots, out);
+    GyroStatus* st = (GyroStatus*)c->g_status.p;
+    const bool have_grid = grid_status == RSHIP_GYRO_OK;
+    if (have_grid) {
+        if (ensure(c, c->g_knots, (size_t)out->n_knots * 32)) return 1;
+        GyroResampleParams p{};
+        p.ts = d_ts; p.quats = d_quats; p.knots = (double*)c->g_knots.p; p.st = st;
+        p.n = n; p.m = out->n_knots; p.first_sample = out->first_sample; p.sr_hz = (uint64_t)out->fs;
+        {
+            ProfScope ps(c, RSHIP_K_GYRO);
+            hipLaunchKernelGGL(gyro_resample_kernel, dim3((p.m + 255) / 256), dim3(256), 0, c->stream, p);
+        }
+        RS_HIP(hipGetLastError());
+        if (spline_from_knots(c, out->n_knots, out->fs)) return 1;
+    }
+    // one look at the status; the reference's order of complaints (core_private.cpp:156-184)
+    if (ensure_pinned(c, 64)) return 1;
+    GyroStatus* h = (GyroStatus*)c->pinned;
+    int64_t* h_pair = (int64_t*)((char*)c->pinned + 32);
+    RS_HIP(hipMemcpyAsync(h, st, sizeof(GyroStatus), hipMemcpyDeviceToHost, c->stream));
+    if (sync_stream(c)) return 1;
+    out->status = RSHIP_GYRO_OK;
+    if (h->bad_input) out->status = RSHIP_GYRO_BAD_INPUT;
+    else if (grid_status == RSHIP_GYRO_BAD_RATE || grid_status == RSHIP_GYRO_TOO_LARGE) out->status = grid_status;
+    else if (h->out_of_order != kNoIndex) {
+        out->status = RSHIP_GYRO_OUT_OF_ORDER;
+        out->bad_pos = h->out_of_order;
+        RS_HIP(hipMemcpy(h_pair, d_ts + (h->out_of_order - 1), 16, hipMemcpyDeviceToHost));
+        out->bad_a = h_pair[0];
+        out->bad_b = h_pair[1];
+    } else if (grid_status != RSHIP_GYRO_OK) out->status = grid_status;
+    else if (h->bad_knot) out->status = RSHIP_GYRO_BAD_KNOT;
+    else if (!std::isfinite(out->fs)) out->status = RSHIP_GYRO_BAD_RATE;
+    else if (!std::isfinite(out->start)) out->status = RSHIP_GYRO_BAD_START;
+    if (out->status != RSHIP_GYRO_OK) c->n_knots = 0; // whatever was built is not a table to sweep over
+    return 0;
+}
+
+} // namespace
+
+int rship_gyro_uniform(rship_ctx* c, const double* quats, uint32_t n, double sample_rate) {
+    DeviceGuard dev_guard(c);
+    if (n < 2) return set_err(c, "spline: need >= 2 knots");
+    if (n > kMaxKnots) return set_err(c, "spline: too many knots");
+    if (ensure(c, c->g_knots, (size_t)n * 32)) return 1;
+    RS_HIP(hipMemcpyAsync(c->g_knots.p, quats, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    if (spline_from_knots(c, n, sample_rate)) return 1;
+    return sync_stream(c); // the caller's array may go away
+}
+
+int rship_gyro_timestamped(rship_ctx* c, const int64_t* ts_us, const double* quats, uint32_t n, rship_gyro_result* out) {
+    DeviceGuard dev_guard(c);
+    if (n < 2) return set_err(c, "gyro: need >= 2 samples");
+    if (ensure(c, c->g_us, (size_t)n * 8) || ensure(c, c->g_q, (size_t)n * 32) || ensure(c, c->g_status, sizeof(GyroStatus))) return 1;
+    RS_HIP(hipMemcpyAsync(c->g_us.p, ts_us, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemcpyAsync(c->g_q.p, quats, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope ps(c, RSHIP_K_GYRO);
+        hipLaunchKernelGGL(gyro_status_reset_kernel, dim3(1), dim3(1), 0, c->stream, (GyroStatus*)c->g_status.p);
+        hipLaunchKernelGGL(gyro_order_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const int64_t*)c->g_us.p,
+                           (const double*)c->g_q.p, n, (GyroStatus*)c->g_status.p);
+    }
+    RS_HIP(hipGetLastError());
+    return resample_and_solve(c, (const int64_t*)c->g_us.p, (const double*)c->g_q.p, n, ts_us[0], ts_us[n - 1], out);
+}
+
+int rship_gyro_rates_upload(rship_ctx* c, const double* ts_s, const double* rates, uint32_t n) {
+    DeviceGuard dev_guard(c);
+    if (n < 2) return set_err(c, "gyro: need >= 2 samples");
+    if (ensure(c, c->g_ts, (size_t)n * 8) || ensure(c, c->g_rates, (size_t)n * 24)) return 1;
+    RS_HIP(hipMemcpyAsync(c->g_ts.p, ts_s, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemcpyAsync(c->g_rates.p, rates, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipStreamSynchronize(c->stream)); // the caller's arrays may go away
+    c->g_n = n;
+    // the grid only needs the two end timestamps, truncated as the kernel truncates them (core_testcode.cpp:48-50)
+    c->g_first_us = (int64_t)(ts_s[0] * 1000000);
+    c->g_last_us = (int64_t)(ts_s[n - 1] * 1000000);
+    return 0;
+}
+
+int rship_gyro_rates_integrate(rship_ctx* c, const int32_t axis[3], const double sign[3], rship_gyro_result* out) {
+    DeviceGuard dev_guard(c);
+    const uint32_t n = c->g_n;
+    if (n < 2) return set_err(c, "gyro: no rates uploaded");
+    for (int k = 0; k < 3; ++k)
+        if (axis[k] < 0 || axis[k] > 2) return set_err(c, "gyro: axis out of range");
+    if (ensure(c, c->g_us, (size_t)n * 8) || ensure(c, c->g_dq, (size_t)n * 32) || ensure(c, c->g_q, (size_t)n * 32) ||
+        ensure(c, c->g_status, sizeof(GyroStatus)))
+        return 1;
+    GyroRatesParams p{};
+    p.ts = (const double*)c->g_ts.p; p.rates = (const double*)c->g_rates.p;
+    p.us = (int64_t*)c->g_us.p; p.dq = (double*)c->g_dq.p; p.st = (GyroStatus*)c->g_status.p; p.n = n;
+    for (int k = 0; k < 3; ++k) { p.axis[k] = axis[k]; p.sign[k] = sign[k]; }
+    {
+        ProfScope ps(c, RSHIP_K_GYRO);
+        hipLaunchKernelGGL(gyro_status_reset_kernel, dim3(1), dim3(1), 0, c->stream, p.st);
+        hipLaunchKernelGGL(gyro_rates_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, p);
+        hipLaunchKernelGGL(gyro_scan_kernel, dim3(1), dim3(kScanThreads), 0, c->stream, (const double*)c->g_dq.p, (double*)c->g_q.p, n);
+    }
+    RS_HIP(hipGetLastError());
+    return resample_and_solve(c, (const int64_t*)c->g_us.p, (const double*)c->g_q.p, n, c->g_first_us, c->g_last_us, out);
+}
+
+int rship_gyro_knots(rship_ctx* c, double* out, uint32_t cap_knots) {
+    DeviceGuard dev_guard(c);
+    if (cap_knots < c->n_knots) return set_err(c, "gyro_knots: buffer too small");
+    if (!c->n_knots) return 0;
+    RS_HIP(hipStreamSynchronize(c->stream));
+    RS_HIP(hipMemcpy(out, c->g_knots.p, (size_t)c->n_knots * 32, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rship_gyro_table(rship_ctx* c, double* out16, uint32_t cap_knots) {
+    DeviceGuard dev_guard(c);
+    if (cap_knots < c->n_knots) return set_err(c, "gyro_table: buffer too small");
+    if (!c->n_knots) return 0;
+    RS_HIP(hipStreamSynchronize(c->stream));
+    RS_HIP(hipMemcpy(out16, c->coef64.p, (size_t)c->n_knots * 128, hipMemcpyDeviceToHost));
     return 0;
 }
 

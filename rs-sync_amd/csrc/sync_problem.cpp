@@ -3,8 +3,8 @@
 // flat C-ABI of rssync_c.h.
 //
 // What stays on the host, and why (DESIGN.md "Host / device split"):
-//   * the gyro spline solve (O(G), sequential recurrence) and the integer-microsecond
-//     resampling of timestamped gyro data (exact integer arithmetic);
+//   * the O(1) part of the gyro setters (argument checks, the panics' wording); integration,
+//     resampling and the spline solve run on the device (rship_gyro_*);
 //   * fp64 copies of the tracks, their packing into the device layout, and the split of
 //     every time into integer knot + fp32 fraction;
 //   * the optimiser control flow of Sync (backtracking, momentum, convergence counters),
@@ -23,7 +23,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
-#include <future>
 #include <iostream>
 #include <limits>
 #include <map>
@@ -95,24 +94,6 @@ DelaySplit64 split_delay64(double delay, double fs) {
     if (fl > (double)kKnotClamp) return {kKnotClamp, 0.0};
     if (fl < -(double)kKnotClamp) return {-kKnotClamp, 0.0};
     return {(int32_t)fl, D - fl};
-}
-
-// quat.cpp:55-74 (only used by the timestamped gyro setter)
-void quat_slerp(const double* p, const double* q_in, double t, double* out) {
-    double q[4] = {q_in[0], q_in[1], q_in[2], q_in[3]};
-    double d = p[0] * q[0] + p[1] * q[1] + p[2] * q[2] + p[3] * q[3];
-    if (d < 0) {
-        for (double& v : q) v = -v;
-        d = p[0] * q[0] + p[1] * q[1] + p[2] * q[2] + p[3] * q[3];
-    }
-    const double theta = std::acos(d); // unclamped: NaN falls through to the lerp branch
-    double m1 = 1 - t, m2 = t;
-    if (theta > 1e-9) {
-        const double st = std::sin(theta);
-        m1 = std::sin((1 - t) * theta) / st;
-        m2 = std::sin(t * theta) / st;
-    }
-    for (int i = 0; i < 4; ++i) out[i] = m1 * p[i] + m2 * q[i];
 }
 
 // Host staging of the track data (core_private.hpp:8-13 FrameData; "copy at call time" is the
@@ -209,7 +190,8 @@ class SyncProblemHip final : public ISyncProblem {
 
     double sample_rate() const { return fs_; }
     double quats_start() const { return start_; }
-    const std::vector<double>& knots() const { return knots_; }
+    const std::vector<double>& knots(); // fetched from the device when it built them
+    size_t n_knots() const { return n_knots_; }
     rship_ctx* dev() { return shards_[0].ctx; }
     size_t n_devices() const { return shards_.size(); }
     void set_devices(const std::vector<int>& ids);
@@ -225,6 +207,7 @@ class SyncProblemHip final : public ISyncProblem {
 
     // pieces shared by the public calls and the diagnostics
     void ensure_device();
+    void ensure_spline() { if (spline_dirty_) build_spline(); }
     uint32_t select(int64_t begin, int64_t end_exclusive);
     std::vector<double> sweep(const std::vector<double>& delays, uint32_t stream_base, bool panics,
                               double* frame_costs, int32_t* best_h);
@@ -297,14 +280,18 @@ class SyncProblemHip final : public ISyncProblem {
     void combine(size_t rows, size_t n_win, Collect&& collect, double* out);
     void build_spline();
     void pack_frames();
-    void install_gyro(struct GyroGrid&& g, std::vector<double>* coef);
+    void accept_gyro(const rship_gyro_result& r);
+    void upload_rates(const double* ts, const double* rates, size_t count);
+    void integrate_rates(const char* orientation);
     double* stage_record(int64_t frame, uint64_t n_doubles, HostFrame& f);
     void upload_new_records();
     Arena arena_;
     uint64_t uploaded_ = 0; // arena offsets below this are on the device
 
     double fs_ = 0, start_ = 0;
-    std::vector<double> knots_; // 4 per sample, [w,x,y,z]
+    std::vector<double> knots_; // 4 per sample, [w,x,y,z]: the uniform setter's copy, or a cache of the device's
+    bool knots_cached_ = false;
+    size_t n_knots_ = 0;
     std::map<int64_t, HostFrame> frames_;
     std::vector<Shard> shards_;
     size_t plan_windows_ = 1;
@@ -366,6 +353,7 @@ void SyncProblemHip::destroy_shards() {
 void SyncProblemHip::set_devices(const std::vector<int>& ids) {
     if (ids.empty()) panic("set-devices: empty device list");
     if (native_exchange) panic("set-devices: not after rccl_init");
+    knots(); // the new devices rebuild the table from the knots: fetch them if only the old device has them
     destroy_shards();
     create_shards(ids);
     uploaded_ = 0;
@@ -397,80 +385,62 @@ void SyncProblemHip::profile_get(int kind, uint64_t* launches, double* total_ms)
     if (total_ms) *total_ms = ms;
 }
 
-// core_private.cpp:135-140
+// core_private.cpp:135-140: the samples are the knots.  Copied at call time; the table is built on the
+// device at the first use (rship_gyro_uniform).
 void SyncProblemHip::SetGyroQuaternions(const double* data, size_t count, double sample_rate,
                                         double first_timestamp) {
     if (count < 2) panic("set-gyro-quaternions: need at least 2 samples");
+    if (count > (size_t)UINT32_MAX) panic("set-gyro-quaternions: too many samples");
     if (fs_ != sample_rate || start_ != first_timestamp) frames_dirty_ = true; // ray offsets depend on both
     fs_ = sample_rate;
     start_ = first_timestamp;
     knots_.assign(data, data + 4 * count);
+    knots_cached_ = true;
+    n_knots_ = count;
     spline_dirty_ = true;
 }
 
-// core_private.cpp:142-190.  The grid is computed in the reference's integer types:
-// rate in micro-hertz and grid times in microseconds as uint64, first grid index by a
-// truncating division (the std::ceil at :152 is applied to an integer).
-static std::vector<double> spline_table(const std::vector<double>& knots);
-
-struct GyroGrid {
-    double fs = 0, start = 0;
-    std::vector<double> knots; // 4 per sample
-};
-
-static GyroGrid resample_timestamped(const int64_t* ts, const double* quats, size_t count) {
-    constexpr uint64_t kUhzInHz = 1000000ULL, kUsInSec = 1000000ULL;
-    if (count < 2) panic("set-gyro-quaternions: need at least 2 samples");
-    const uint64_t actual_sr_uhz = kUhzInHz * kUsInSec * (uint64_t)count / (uint64_t)(ts[count - 1] - ts[0]);
-    const int rounded_sr_hz = (int)(std::round((double)actual_sr_uhz / 50. / (double)kUhzInHz) * 50);
-    if (rounded_sr_hz <= 0) panic("set-gyro-quaternions: non-finite sample rate. wtf?");
-    std::vector<uint64_t> grid;
-    for (int sample = (int)((uint64_t)(ts[0] * rounded_sr_hz) / kUsInSec);
-         kUsInSec * (uint64_t)sample / (uint64_t)rounded_sr_hz < (uint64_t)ts[count - 1]; ++sample)
-        grid.push_back(kUsInSec * (uint64_t)sample / (uint64_t)rounded_sr_hz);
-    for (size_t i = 1; i < count; ++i)
-        if (ts[i - 1] > ts[i])
-            panic("set-gyro-quaternions:  timestamps out of order at pos " + std::to_string(i) + " (" +
-                  std::to_string(ts[i - 1]) + " > " + std::to_string(ts[i]) + ")");
-    if (grid.size() < 2) panic("set-gyro-quaternions: resampled grid has fewer than 2 points");
-    GyroGrid out;
-    std::vector<double>& nq = out.knots;
-    nq.resize(4 * grid.size());
-    for (size_t i = 0; i < grid.size(); ++i) {
-        const uint64_t t = grid[i];
-        // first sample whose (unsigned) timestamp is >= t
-        size_t idx = std::lower_bound(ts, ts + count, t, [](int64_t a, uint64_t b) { return (uint64_t)a < b; }) - ts;
-        if (idx > 0) {
-            double u = 1. * (double)(t - (uint64_t)ts[idx - 1]) / (double)(ts[idx] - ts[idx - 1]);
-            quat_slerp(quats + 4 * (idx - 1), quats + 4 * idx, u, &nq[4 * i]);
-        } else {
-            std::copy(quats, quats + 4, &nq[4 * i]);
-        }
-        if (!all_finite(&nq[4 * i], 4)) panic("set-gyro-quaternions: non-finite sample after interpolation");
+// What the reference's timestamped setter would have complained about (core_private.cpp:147-184), in its words.
+void SyncProblemHip::accept_gyro(const rship_gyro_result& r) {
+    switch (r.status) {
+        case RSHIP_GYRO_OK: break;
+        case RSHIP_GYRO_BAD_INPUT: n_knots_ = 0; panic("set-gyro-rates: non-finite numbers");
+        case RSHIP_GYRO_OUT_OF_ORDER:
+            n_knots_ = 0;
+            panic("set-gyro-quaternions:  timestamps out of order at pos " + std::to_string(r.bad_pos) + " (" +
+                  std::to_string(r.bad_a) + " > " + std::to_string(r.bad_b) + ")");
+        case RSHIP_GYRO_SHORT_GRID: n_knots_ = 0; panic("set-gyro-quaternions: resampled grid has fewer than 2 points");
+        case RSHIP_GYRO_BAD_KNOT: n_knots_ = 0; panic("set-gyro-quaternions: non-finite sample after interpolation");
+        case RSHIP_GYRO_BAD_START: n_knots_ = 0; panic("set-gyro-quaternions: non-finite first timestamp. wtf?");
+        case RSHIP_GYRO_TOO_LARGE: n_knots_ = 0; panic("set-gyro-quaternions: resampled grid too large");
+        default: n_knots_ = 0; panic("set-gyro-quaternions: non-finite sample rate. wtf?");
     }
-    out.fs = 1. * rounded_sr_hz;
-    out.start = 1. * (double)grid[0] / (double)kUsInSec;
-    if (!std::isfinite(out.fs)) panic("set-gyro-quaternions: non-finite sample rate. wtf?");
-    if (!std::isfinite(out.start)) panic("set-gyro-quaternions: non-finite first timestamp. wtf?");
-    return out;
+    if (fs_ != r.fs || start_ != r.start) frames_dirty_ = true;
+    fs_ = r.fs;
+    start_ = r.start;
+    n_knots_ = r.n_knots;
+    knots_.clear();
+    knots_cached_ = false; // on the device; fetched when somebody asks (knots())
+    spline_dirty_ = false; // the device built the table
 }
 
+// core_private.cpp:142-190, on the device: order check, integer-microsecond grid, slerp, spline solve.
+// Every device of the object does the (small) work itself rather than wait for a copy.
 void SyncProblemHip::SetGyroQuaternions(const int64_t* ts, const double* quats, size_t count) {
-    install_gyro(resample_timestamped(ts, quats, count), nullptr);
+    if (count < 2) panic("set-gyro-quaternions: need at least 2 samples");
+    if (count > (size_t)UINT32_MAX) panic("set-gyro-quaternions: too many samples");
+    rship_gyro_result r{};
+    for (Shard& sh : shards_) hip_check(sh, rship_gyro_timestamped(sh.ctx, ts, quats, (uint32_t)count, &r), "gyro");
+    accept_gyro(r);
 }
 
-void SyncProblemHip::install_gyro(GyroGrid&& g, std::vector<double>* coef) {
-    if (fs_ != g.fs || start_ != g.start) frames_dirty_ = true;
-    fs_ = g.fs;
-    start_ = g.start;
-    knots_.swap(g.knots);
-    spline_dirty_ = true;
-    if (coef) { // table already built (orientation sweep worker): upload it now
-        if (knots_.size() / 4 * 16 != coef->size()) panic("install-gyro: table size mismatch");
-        for (Shard& sh : shards_)
-            hip_check(sh, rship_upload_spline(sh.ctx, coef->data(), (uint32_t)(knots_.size() / 4), fs_), "upload spline");
-        spline_dirty_ = false;
+const std::vector<double>& SyncProblemHip::knots() {
+    if (!knots_cached_ && n_knots_) {
+        knots_.resize(4 * n_knots_);
+        hip_check(shards_[0], rship_gyro_knots(shards_[0].ctx, knots_.data(), (uint32_t)n_knots_), "gyro knots");
+        knots_cached_ = true;
     }
+    return knots_;
 }
 
 // a new record for `frame` in the staging arena (replaces any earlier one)
@@ -561,134 +531,72 @@ void SyncProblemHip::SetTrackPixels(int64_t frame, double time_a, double time_b,
 
 // optdata_fill_gyro (core_testcode.cpp:36-52): q_0 = identity, q_i = normalise(dq_i * q_{i-1}) with
 // dq_i the rotation by rate_i over (t_i - t_{i-1}) (quat.cpp:5-17), timestamps truncated to whole
-// microseconds, then the timestamped setter.  `orientation` is telemetry-parser's three-letter
-// string (position = output axis, letter = input axis, upper case +, lower case -) or NULL.
-static GyroGrid integrate_rates(const double* ts, const double* rates, size_t count, const char* orientation) {
+// microseconds, then the timestamped setter -- all of it on the device (rship_gyro_rates_*).
+// `orientation` is telemetry-parser's three-letter string (position = output axis, letter = input axis,
+// upper case +, lower case -) or NULL.
+static void parse_orientation(const char* orientation, int32_t axis[3], double sign[3]) {
+    for (int c = 0; c < 3; ++c) { axis[c] = c; sign[c] = 1.0; }
+    if (!orientation) return;
+    if (std::strlen(orientation) != 3) panic("set-gyro-rates: orientation must have 3 letters");
+    for (int c = 0; c < 3; ++c) {
+        const char lo = (char)std::tolower((unsigned char)orientation[c]);
+        if (lo < 'x' || lo > 'z') panic("set-gyro-rates: orientation letters are x, y, z");
+        axis[c] = lo - 'x';
+        sign[c] = orientation[c] == lo ? -1.0 : 1.0;
+    }
+}
+
+void SyncProblemHip::upload_rates(const double* ts, const double* rates, size_t count) {
     if (count < 2) panic("set-gyro-rates: need at least 2 samples");
-    if (!all_finite(ts, count) || !all_finite(rates, 3 * count)) panic("set-gyro-rates: non-finite numbers");
-    int axis[3] = {0, 1, 2};
-    double sign[3] = {1, 1, 1};
-    if (orientation) {
-        if (std::strlen(orientation) != 3) panic("set-gyro-rates: orientation must have 3 letters");
-        for (int c = 0; c < 3; ++c) {
-            const char lo = (char)std::tolower((unsigned char)orientation[c]);
-            if (lo < 'x' || lo > 'z') panic("set-gyro-rates: orientation letters are x, y, z");
-            axis[c] = lo - 'x';
-            sign[c] = orientation[c] == lo ? -1.0 : 1.0;
-        }
-    }
-    std::vector<double> q(4 * count);
-    std::vector<int64_t> us(count);
-    q[0] = 1; q[1] = q[2] = q[3] = 0;
-    for (size_t i = 1; i < count; ++i) {
-        const double dt = ts[i] - ts[i - 1];
-        const double w[3] = {rates[3 * i + axis[0]] * sign[0] * dt, rates[3 * i + axis[1]] * sign[1] * dt,
-                             rates[3 * i + axis[2]] * sign[2] * dt};
-        const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-        double d[4];
-        if (th2 > 0.) {
-            const double th = std::sqrt(th2), half = th * 0.5, kk = std::sin(half) / th;
-            d[0] = std::cos(half); d[1] = w[0] * kk; d[2] = w[1] * kk; d[3] = w[2] * kk;
-        } else {
-            d[0] = 1.; d[1] = w[0] * 0.5; d[2] = w[1] * 0.5; d[3] = w[2] * 0.5;
-        }
-        const double* p = &q[4 * (i - 1)];
-        double o[4] = {d[0] * p[0] - d[1] * p[1] - d[2] * p[2] - d[3] * p[3],
-                       d[0] * p[1] + d[1] * p[0] + d[2] * p[3] - d[3] * p[2],
-                       d[0] * p[2] - d[1] * p[3] + d[2] * p[0] + d[3] * p[1],
-                       d[0] * p[3] + d[1] * p[2] - d[2] * p[1] + d[3] * p[0]};
-        double nn = std::sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
-        if (nn == 0) nn = 1;
-        for (int c = 0; c < 4; ++c) q[4 * i + c] = o[c] / nn;
-    }
-    for (size_t i = 0; i < count; ++i) us[i] = (int64_t)(ts[i] * 1000000); // :48-50
-    return resample_timestamped(us.data(), q.data(), count);
+    if (count > (size_t)UINT32_MAX) panic("set-gyro-rates: too many samples");
+    if (!std::isfinite(ts[0]) || !std::isfinite(ts[count - 1])) panic("set-gyro-rates: non-finite numbers");
+    for (Shard& sh : shards_) hip_check(sh, rship_gyro_rates_upload(sh.ctx, ts, rates, (uint32_t)count), "gyro rates");
+}
+
+void SyncProblemHip::integrate_rates(const char* orientation) {
+    int32_t axis[3];
+    double sign[3];
+    parse_orientation(orientation, axis, sign);
+    rship_gyro_result r{};
+    for (Shard& sh : shards_) hip_check(sh, rship_gyro_rates_integrate(sh.ctx, axis, sign, &r), "gyro integrate");
+    accept_gyro(r);
 }
 
 void SyncProblemHip::SetGyroRates(const double* ts, const double* rates, size_t count, const char* orientation) {
-    install_gyro(integrate_rates(ts, rates, count, orientation), nullptr);
+    int32_t axis[3];
+    double sign[3];
+    parse_orientation(orientation, axis, sign); // complain about the string before anything is uploaded
+    upload_rates(ts, rates, count);
+    integrate_rates(orientation);
 }
 
 // The orientation-guessing block of the reference driver (core_testcode.cpp:186-224): for each
 // candidate IMU orientation re-integrate the rates, replace the gyro (tracks stay) and PreSync;
-// the caller ranks the costs.  Integration, resampling and the spline solve of orientation i+1
-// run on a host thread while the GPU sweeps orientation i.  The last orientation stays installed.
+// the caller ranks the costs.  The rates are uploaded once; an orientation is a permutation of the rate
+// axes inside the integration kernel.  The last orientation stays installed.
 void SyncProblemHip::orientation_sweep(const double* ts, const double* rates, size_t count,
                                        const std::vector<std::string>& orientations, double initial_delay,
                                        int64_t frame_begin, int64_t frame_end, double search_step,
                                        double search_radius, double* costs, double* delays) {
-    struct Prepared {
-        GyroGrid grid;
-        std::vector<double> coef;
-    };
-    auto prepare = [=](std::string o) {
-        Prepared p;
-        p.grid = integrate_rates(ts, rates, count, o.c_str());
-        p.coef = spline_table(p.grid.knots);
-        return p;
-    };
     if (orientations.empty()) return;
-    std::future<Prepared> next = std::async(std::launch::async, prepare, orientations[0]);
+    for (const std::string& o : orientations) {
+        int32_t axis[3];
+        double sign[3];
+        parse_orientation(o.c_str(), axis, sign);
+    }
+    upload_rates(ts, rates, count);
     for (size_t i = 0; i < orientations.size(); ++i) {
-        Prepared cur = next.get();
-        if (i + 1 < orientations.size()) next = std::async(std::launch::async, prepare, orientations[i + 1]);
-        install_gyro(std::move(cur.grid), &cur.coef);
+        integrate_rates(orientations[i].c_str());
         const std::pair<double, double> r = PreSync(initial_delay, frame_begin, frame_end, search_step, search_radius);
         costs[i] = r.first;
         delays[i] = r.second;
     }
 }
 
-// Natural cubic spline on unit-spaced knots, one per quaternion component
-// (replaces minispline.cpp:3-46 / ndspline.cpp:13-19).  Interior equations
-//   c[i-1]/3 + 4 c[i]/3 + c[i+1]/3 = y[i+1] - 2 y[i] + y[i-1],  c[0] = c[n-1] = 0,
-// solved by the Thomas recurrence in fp64, then d, b and the tail coefficients the
-// reference's extrapolation uses (minispline.cpp:43-44).  16 doubles per knot = y[4], b[4],
-// c[4], d[4]; the device keeps the table in fp64 and rounds a copy to fp32 for the PreSync kernel.
-static std::vector<double> spline_table(const std::vector<double>& knots) {
-    const size_t n = knots.size() / 4;
-    if (n < 2) panic("sync: gyro data was not set");
-    std::vector<double> coef(n * 16);
-    std::vector<double> c(n), cp(n), y(n);
-    for (int comp = 0; comp < 4; ++comp) {
-        for (size_t i = 0; i < n; ++i) y[i] = knots[4 * i + comp];
-        // forward sweep on rows 1..n-2 (rows 0 and n-1 pin c to zero)
-        cp[0] = 0.0;
-        c[0] = 0.0;
-        for (size_t i = 1; i + 1 < n; ++i) {
-            const double rhs = y[i + 1] - 2.0 * y[i] + y[i - 1];
-            const double denom = 4.0 / 3.0 - cp[i - 1] / 3.0;
-            cp[i] = (1.0 / 3.0) / denom;
-            c[i] = (rhs - c[i - 1] / 3.0) / denom;
-        }
-        c[n - 1] = 0.0;
-        for (size_t i = n - 1; i-- > 1;) c[i] -= cp[i] * c[i + 1];
-        double b_prev = 0, d_prev = 0;
-        for (size_t i = 0; i < n; ++i) {
-            double b, d;
-            if (i + 1 < n) {
-                d = (c[i + 1] - c[i]) / 3.0;
-                b = (y[i + 1] - y[i]) - (2.0 * c[i] + c[i + 1]) / 3.0;
-            } else {
-                d = 0.0;
-                b = 3.0 * d_prev + 2.0 * c[n - 2] + b_prev;
-            }
-            double* row = &coef[16 * i];
-            row[0 + comp] = y[i];
-            row[4 + comp] = b;
-            row[8 + comp] = c[i];
-            row[12 + comp] = d;
-            b_prev = b;
-            d_prev = d;
-        }
-    }
-    return coef;
-}
-
+// the uniform route's table (the other routes leave it built)
 void SyncProblemHip::build_spline() {
-    std::vector<double> coef = spline_table(knots_);
-    for (Shard& sh : shards_)
-        hip_check(sh, rship_upload_spline(sh.ctx, coef.data(), (uint32_t)(knots_.size() / 4), fs_), "upload spline");
+    const std::vector<double>& k = knots();
+    for (Shard& sh : shards_) hip_check(sh, rship_gyro_uniform(sh.ctx, k.data(), (uint32_t)n_knots_, fs_), "gyro table");
     spline_dirty_ = false;
 }
 
@@ -889,7 +797,7 @@ void SyncProblemHip::combine(size_t rows, size_t n_win, Collect&& collect, doubl
 }
 
 void SyncProblemHip::ensure_device() {
-    if (knots_.size() < 8) panic("sync: gyro data was not set");
+    if (n_knots_ < 2) panic("sync: gyro data was not set");
     if (spline_dirty_) build_spline();
     if (frames_dirty_) pack_frames();
 }
@@ -1592,14 +1500,25 @@ int rssync_ext_upload(rssync_problem* p) {
 int rssync_ext_sample_rate(rssync_problem* p, double* sample_rate, double* quats_start, size_t* n_knots) {
     if (sample_rate) *sample_rate = p->impl->sample_rate();
     if (quats_start) *quats_start = p->impl->quats_start();
-    if (n_knots) *n_knots = p->impl->knots().size() / 4;
+    if (n_knots) *n_knots = p->impl->n_knots();
     return 0;
 }
 int rssync_ext_gyro_knots(rssync_problem* p, double* out, size_t cap) {
-    const auto& k = p->impl->knots();
-    if (cap < k.size()) return 1;
-    std::copy(k.begin(), k.end(), out);
-    return 0;
+    return guarded([&] {
+        const auto& k = p->impl->knots();
+        if (cap < k.size()) panic("gyro-knots: buffer too small");
+        std::copy(k.begin(), k.end(), out);
+    });
+}
+
+int rssync_ext_gyro_table(rssync_problem* p, double* out, size_t cap) {
+    return guarded([&] {
+        SyncProblemHip* s = p->impl;
+        if (s->n_knots() < 2) panic("sync: gyro data was not set");
+        if (cap < 16 * s->n_knots()) panic("gyro-table: buffer too small");
+        s->ensure_spline();
+        if (rship_gyro_table(s->dev(), out, (uint32_t)s->n_knots())) panic(std::string("gyro table: ") + rship_last_error(s->dev()));
+    });
 }
 
 int rssync_ext_presync_curve(rssync_problem* p, double initial_delay, int64_t frame_begin, int64_t frame_end,

@@ -58,6 +58,7 @@ SIGNATURES = {
     "rssync_ext_upload": (C.c_int, [C.c_void_p]),
     "rssync_ext_sample_rate": (C.c_int, [C.c_void_p, _PD, _PD, C.POINTER(C.c_size_t)]),
     "rssync_ext_gyro_knots": (C.c_int, [C.c_void_p, _PD, C.c_size_t]),
+    "rssync_ext_gyro_table": (C.c_int, [C.c_void_p, _PD, C.c_size_t]),
     "rssync_ext_presync_curve": (C.c_int, [C.c_void_p, C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_double,
                                            _PD, _PD, C.c_int, C.POINTER(C.c_int), _PD, _PI32, C.POINTER(C.c_int)]),
     "rssync_ext_problem_matrix": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, _PF, _PF, C.c_size_t,
@@ -287,6 +288,13 @@ class SyncProblem:
         self._check(self._lib.rssync_ext_gyro_knots(self._h, _p(out), out.size))
         return out
 
+    def gyro_table(self):
+        """The device's spline table, (n_knots, 4, 4): [knot][y, b, c, d][w, x, y, z]."""
+        n = self.gyro_info()[2]
+        out = np.zeros((n, 4, 4))
+        self._check(self._lib.rssync_ext_gyro_table(self._h, _p(out), out.size))
+        return out
+
     def presync_curve(self, initial_delay, frame_begin, frame_end, search_step, search_radius, per_frame=False,
                       cap=None):
         if cap is None:
@@ -480,7 +488,7 @@ class SyncProblem:
         self._check(self._lib.rssync_ext_profile_reset(self._h))
 
     def profile_get(self):
-        names = ["lmeds", "loss", "motion", "reduce", "init", "pixels"]
+        names = ["lmeds", "loss", "motion", "reduce", "init", "pixels", "gyro"]
         out = {}
         for i, nm in enumerate(names):
             n, ms = C.c_uint64(), C.c_double()

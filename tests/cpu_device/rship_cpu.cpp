@@ -11,6 +11,7 @@
 #include "../../include/rssync_hip.h"
 #include "../../rs-sync_amd/csrc/device_math.hpp"
 #include "../../rs-sync_amd/csrc/lens_math.hpp"
+#include "../../rs-sync_amd/csrc/gyro_math.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -31,6 +32,7 @@ struct rship_ctx {
     std::vector<f4> coef; // 4 per knot (fp32, PreSync)
     std::vector<double> coef64; // 16 per knot (Sync)
     double fs = 0;
+    std::vector<double> knots, g_ts, g_rates; // gyro pipeline: grid knots, uploaded rates
     std::vector<double> raw;    // mirror of the host staging arena
     std::vector<f4> rays_a, rays_b;
     std::vector<double> q[4];   // fp64 streams {ax,bx} {ay,by} {az,bz} {ta,tb}, 2 doubles per ray each
@@ -156,12 +158,119 @@ int rship_set_option(rship_ctx* c, int option, int value) {
     return 0;
 }
 
-int rship_upload_spline(rship_ctx* c, const double* coef16, uint32_t n_knots, double sample_rate) {
-    c->coef64.assign(coef16, coef16 + (size_t)n_knots * 16);
-    c->coef.resize((size_t)n_knots * 4);
+// ---- gyro pipeline: the device's formulas (gyro_math.hpp), one sample after the other ----------------------
+static int table_from_knots(rship_ctx* c, double sample_rate) {
+    const size_t n = c->knots.size() / 4;
+    if (n < 2) return fail(c, "spline: need >= 2 knots");
+    rs::SplinePivots piv;
+    piv.cp[0] = 0.0;
+    for (int i = 1; i < rs::kSplinePivots; ++i) piv.cp[i] = rs::spline_next_pivot(piv.cp[i - 1]);
+    c->coef64.assign(n * 16, 0.0);
+    std::vector<double> cf(n), cc(n);
+    for (int comp = 0; comp < 4; ++comp) {
+        auto y = [&](size_t i) { return c->knots[4 * i + comp]; };
+        cf[0] = 0.0;
+        for (size_t i = 1; i + 1 < n; ++i) cf[i] = rs::spline_forward(y(i - 1), y(i), y(i + 1), rs::spline_pivot(piv, (uint32_t)(i - 1)), cf[i - 1]);
+        cf[n - 1] = 0.0;
+        cc[n - 1] = 0.0;
+        cc[0] = 0.0;
+        for (size_t i = n - 1; i-- > 1;) cc[i] = rs::spline_backward(cf[i], rs::spline_pivot(piv, (uint32_t)i), cc[i + 1]);
+        double b_prev = 0, d_prev = 0;
+        for (size_t i = 0; i < n; ++i) {
+            double b, d;
+            if (i + 1 < n) rs::spline_segment(y(i), y(i + 1), cc[i], cc[i + 1], &b, &d);
+            else rs::spline_tail(b_prev, d_prev, cc[n - 2], &b, &d);
+            double* r = &c->coef64[16 * i];
+            r[comp] = y(i); r[4 + comp] = b; r[8 + comp] = cc[i]; r[12 + comp] = d;
+            b_prev = b;
+            d_prev = d;
+        }
+    }
+    c->coef.resize(n * 4);
     float* f = reinterpret_cast<float*>(c->coef.data());
-    for (size_t i = 0; i < (size_t)n_knots * 16; ++i) f[i] = (float)coef16[i];
+    for (size_t i = 0; i < n * 16; ++i) f[i] = (float)c->coef64[i];
     c->fs = sample_rate;
+    return 0;
+}
+
+int rship_gyro_uniform(rship_ctx* c, const double* quats, uint32_t n, double sample_rate) {
+    c->knots.assign(quats, quats + 4 * (size_t)n);
+    return table_from_knots(c, sample_rate);
+}
+
+static int timestamped(rship_ctx* c, const int64_t* ts, const double* quats, uint32_t n, bool bad_input, rship_gyro_result* out) {
+    const int grid_status = rs::grid_of(ts[0], ts[n - 1], n, rs::kMaxKnots, out);
+    uint32_t out_of_order = 0;
+    for (uint32_t i = 1; i < n && !out_of_order; ++i)
+        if (ts[i - 1] > ts[i]) out_of_order = i;
+    bool bad_knot = false;
+    if (grid_status == RSHIP_GYRO_OK) {
+        c->knots.resize(4 * (size_t)out->n_knots);
+        for (uint32_t i = 0; i < out->n_knots; ++i)
+            if (!rs::resample_knot(ts, quats, n, rs::grid_time_us(out->first_sample + i, (uint64_t)out->fs), &c->knots[4 * (size_t)i])) bad_knot = true;
+        if (table_from_knots(c, out->fs)) return 1;
+    }
+    out->status = RSHIP_GYRO_OK;
+    if (bad_input) out->status = RSHIP_GYRO_BAD_INPUT;
+    else if (grid_status == RSHIP_GYRO_BAD_RATE || grid_status == RSHIP_GYRO_TOO_LARGE) out->status = grid_status;
+    else if (out_of_order) {
+        out->status = RSHIP_GYRO_OUT_OF_ORDER;
+        out->bad_pos = out_of_order;
+        out->bad_a = ts[out_of_order - 1];
+        out->bad_b = ts[out_of_order];
+    } else if (grid_status != RSHIP_GYRO_OK) out->status = grid_status;
+    else if (bad_knot) out->status = RSHIP_GYRO_BAD_KNOT;
+    else if (!std::isfinite(out->fs)) out->status = RSHIP_GYRO_BAD_RATE;
+    else if (!std::isfinite(out->start)) out->status = RSHIP_GYRO_BAD_START;
+    if (out->status != RSHIP_GYRO_OK) { c->knots.clear(); c->coef.clear(); c->coef64.clear(); }
+    return 0;
+}
+
+int rship_gyro_timestamped(rship_ctx* c, const int64_t* ts_us, const double* quats, uint32_t n, rship_gyro_result* out) {
+    if (n < 2) return fail(c, "gyro: need >= 2 samples");
+    return timestamped(c, ts_us, quats, n, false, out);
+}
+
+int rship_gyro_rates_upload(rship_ctx* c, const double* ts_s, const double* rates, uint32_t n) {
+    if (n < 2) return fail(c, "gyro: need >= 2 samples");
+    c->g_ts.assign(ts_s, ts_s + n);
+    c->g_rates.assign(rates, rates + 3 * (size_t)n);
+    return 0;
+}
+
+int rship_gyro_rates_integrate(rship_ctx* c, const int32_t axis[3], const double sign[3], rship_gyro_result* out) {
+    const uint32_t n = (uint32_t)c->g_ts.size();
+    if (n < 2) return fail(c, "gyro: no rates uploaded");
+    bool bad = false;
+    for (double v : c->g_ts) bad = bad || !std::isfinite(v);
+    for (double v : c->g_rates) bad = bad || !std::isfinite(v);
+    std::vector<double> q(4 * (size_t)n);
+    std::vector<int64_t> us(n);
+    double cur[4] = {1., 0., 0., 0.};
+    for (uint32_t i = 0; i < n; ++i) {
+        us[i] = std::isfinite(c->g_ts[i]) ? (int64_t)(c->g_ts[i] * 1000000) : 0;
+        if (i > 0) {
+            const double dt = c->g_ts[i] - c->g_ts[i - 1];
+            const double* r = &c->g_rates[3 * (size_t)i];
+            const double w[3] = {r[axis[0]] * sign[0] * dt, r[axis[1]] * sign[1] * dt, r[axis[2]] * sign[2] * dt};
+            double d[4];
+            rs::gyro_delta(w, d);
+            rs::quat_mul_norm(d, cur);
+        }
+        for (int k = 0; k < 4; ++k) q[4 * (size_t)i + k] = cur[k];
+    }
+    return timestamped(c, us.data(), q.data(), n, bad, out);
+}
+
+int rship_gyro_knots(rship_ctx* c, double* out, uint32_t cap_knots) {
+    if ((size_t)cap_knots * 4 < c->knots.size()) return fail(c, "gyro_knots: buffer too small");
+    std::copy(c->knots.begin(), c->knots.end(), out);
+    return 0;
+}
+
+int rship_gyro_table(rship_ctx* c, double* out16, uint32_t cap_knots) {
+    if ((size_t)cap_knots * 16 < c->coef64.size()) return fail(c, "gyro_table: buffer too small");
+    std::copy(c->coef64.begin(), c->coef64.end(), out16);
     return 0;
 }
 

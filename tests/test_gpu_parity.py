@@ -329,7 +329,7 @@ def test_timestamped_gyro_overload():
         for fr, ta, tb, ra, rb in synth.make_frames(g, 30, 30 + F, N, seed=5):
             p.SetTrackResult(fr, ta, tb, ra, rb)
     assert h.gyro_info() == o.gyro_info()
-    np.testing.assert_array_equal(h.gyro_knots(), o.gyro_knots())  # integer grid + slerp: bit-exact on the host
+    np.testing.assert_allclose(h.gyro_knots(), o.gyro_knots(), rtol=0, atol=1e-15)  # slerp on the device: its acos and sin
     ch, dh = h.PreSync(0.0, 30, 30 + F, 0.002, 0.1)
     co, do = o.PreSync(0.0, 30, 30 + F, 0.002, 0.1)
     assert dh == do and ch == pytest.approx(co, rel=2e-3)

@@ -6,5 +6,6 @@ run() { name=$1; shift; echo "== $name"; timeout -k 10 600 "$@" > gpurun_out/${P
 run syncpoints.json python tools/gpu_syncpoints.py
 run orientation_sweep_c5.json python tools/gpu_orientations.py
 run pixels_kernel.json python tests/measure/gpu_pixels.py
+run gyro_device.json python tests/measure/gpu_gyro.py
 run config2_parity.json python tests/measure/gpu_config2_parity.py
 run fullsize_sync_parity.txt python tests/measure/gpu_fullsize_parity.py
