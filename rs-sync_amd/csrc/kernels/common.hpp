@@ -52,16 +52,28 @@ __device__ __forceinline__ double dpp_d(double v) {
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double wave_sum_f64(double v) {
-    v += dpp_d<0x111, 0xf>(v);
-    v += dpp_d<0x112, 0xf>(v);
-    v += dpp_d<0x114, 0xf>(v);
-    v += dpp_d<0x118, 0xf>(v);
-    v += dpp_d<0x142, 0xa>(v);
-    v += dpp_d<0x143, 0xc>(v);
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+// row_shr:N with bound_ctrl: every lane is written (0 where the source lane is outside the row), so no register
+// has to be cleared first -- half the instructions of the old-value form for a 64-bit operand
+template <int CTRL>
+__device__ __forceinline__ double dpp_shr_d(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double read_lane_d(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+// Sum over the 64 lanes, the same value (and the same bits) in every lane: four shift-and-add steps inside the
+// rows of 16, then the four row sums R0..R3 as (R3 + R2) + (R1 + R0) -- the association of the classic
+// row_bcast:15 / row_bcast:31 ending, without its masked (old-value) moves.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_shr_d<0x111>(v);
+    v += dpp_shr_d<0x112>(v);
+    v += dpp_shr_d<0x114>(v);
+    v += dpp_shr_d<0x118>(v);
+    const double r0 = read_lane_d(v, 15), r1 = read_lane_d(v, 31), r2 = read_lane_d(v, 47), r3 = read_lane_d(v, 63);
+    return (r3 + r2) + (r1 + r0);
 }
 
 // workgroup sum of a per-thread fp32 partial: fp32 inside the wave, fp64 across

@@ -125,6 +125,7 @@ struct Loss64Params {
     const double* k;
     double* part_loss; // [n_delays][n_sel]
     double* part_grad; // [n_delays][n_sel] (GRAD)
+    uint32_t slot0;    // the launch covers slots slot0 .. slot0 + gridDim.x (a group of windows on its own stream)
 };
 
 // delays evaluated per pass over the rows: every ray pair is read once for kLossBatch delays (their spline
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
     __shared__ d4 s_win[NB][4 * kWinMax];
     __shared__ double s_red[NB][2][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t sf = blockIdx.x;
+    const uint32_t sf = blockIdx.x + p.slot0;
     const uint32_t g = p.grp ? p.grp[sf] : 0u;
     {
         // nothing to evaluate for this slot's window (a finished window, a line search that has already
@@ -284,6 +285,7 @@ struct Motion64Params {
     uint64_t seed;
     uint32_t stream_base, stream_stride; // sampler stream = base + group * stride
     int simple_k; // 1: k = clamp(100 / sqrt(sum |P_j|^2)) only (no-translation variant), no M, no optimisation
+    uint32_t slot0; // the launch covers slots slot0 .. slot0 + gridDim.x
 };
 
 constexpr int kInitNone = (int)0x80000000;
@@ -319,21 +321,23 @@ struct MotionEval64 {
         }
         double r0 = wave_sum_f64(L), r1 = wave_sum_f64(a0), r2 = wave_sum_f64(a1), r3 = wave_sum_f64(a2),
                r4 = wave_sum_f64(gs);
-        const int wave = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) {
-            part[buf][wave][0] = r0; part[buf][wave][1] = r1; part[buf][wave][2] = r2;
-            part[buf][wave][3] = r3; part[buf][wave][4] = r4;
-        }
-        __syncthreads();
-        double t[5];
+        double t[5] = {r0, r1, r2, r3, r4};
+        if (NW > 1) { // the waves' sums through LDS; a one-wave frame has them already
+            const int wave = threadIdx.x >> 6;
+            if ((threadIdx.x & 63) == 0) {
+                part[buf][wave][0] = r0; part[buf][wave][1] = r1; part[buf][wave][2] = r2;
+                part[buf][wave][3] = r3; part[buf][wave][4] = r4;
+            }
+            __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            double acc = part[buf][0][q];
+            for (int q = 0; q < 5; ++q) {
+                double acc = part[buf][0][q];
 #pragma unroll
-            for (int w = 1; w < NW; ++w) acc += part[buf][w][q];
-            t[q] = acc;
+                for (int w = 1; w < NW; ++w) acc += part[buf][w][q];
+                t[q] = acc;
+            }
+            buf ^= 1;
         }
-        buf ^= 1;
         ++evals;
         const double tt = t[4] * 2.0 / k2;
         g[0] = t[1] - tt * x[0];
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (RPT <= 8 ? 3 : (RPT == 16 ? 2 :
     __shared__ double s_inv_ys[kNB]; // 1 / (y . s) of each stored pair: the value the two-loop recursion divides for
     __shared__ double s_red[NW];
     const int tid = threadIdx.x;
-    const uint32_t sf = blockIdx.x;
+    const uint32_t sf = blockIdx.x + p.slot0;
     const uint32_t fi = p.sel[sf];
     const FrameRec fr = p.frames[fi];
     const uint32_t N = fr.n;

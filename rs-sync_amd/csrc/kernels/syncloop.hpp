@@ -13,6 +13,8 @@
 
 namespace {
 
+constexpr int kMaxBt = 10, kHalfBt = 5;
+
 struct SyncWin { // per window
     double d, v;     // delay, momentum (delay_v, core_private.cpp:261)
     double x0;       // d - 0.3 v of this iteration
@@ -23,6 +25,7 @@ struct SyncWin { // per window
 struct SyncLoopParams {
     SyncWin* win;          // [W]
     uint32_t n_win;
+    uint32_t win0, win1;   // the launch covers windows win0 .. win1 (a group of windows on its own stream)
     const double* part;    // per-slot sums of the launch just finished: [rows][n_sel]
     uint32_t n_sel, rows;
     // the plan (windows = groups): chunk_off over slots (identity positions), win_chunk_off
@@ -43,7 +46,6 @@ struct SyncLoopParams {
     double* trace;         // [max_outer][W][6]: row k of window w is its k-th outer iteration
 };
 
-constexpr int kMaxBt = 10, kHalfBt = 5;
 
 __device__ __forceinline__ void split64_dev(double delay, double fs, int32_t* kd, double* fd) {
 #pragma clang fp contract(off)
@@ -66,7 +68,9 @@ constexpr uint32_t kStageDoubles = 2048; // 16 KB
 __device__ __forceinline__ void window_sums(const SyncLoopParams& p, uint32_t w, double* s_tot, double* s_stage) {
     const uint32_t c0 = p.win_chunk_off[w], c1 = p.win_chunk_off[w + 1], nc = c1 - c0;
     const uint32_t j_lo = p.chunk_off[c0], j_hi = p.chunk_off[c1], span = j_hi - j_lo; // the window's slots
-    double* tmp = p.chunk_tmp + (size_t)w * p.rows * p.chunk_stride;
+    // a fixed region per window (not rows-dependent): groups of windows run these kernels side by side on their own
+    // streams, one with 2 rows while another has 10
+    double* tmp = p.chunk_tmp + (size_t)w * (2 * kMaxBt) * p.chunk_stride;
     const bool staged = p.rows * span <= kStageDoubles;
     if (staged) {
         for (uint32_t e = threadIdx.x; e < p.rows * span; e += blockDim.x)
@@ -118,13 +122,13 @@ __device__ __forceinline__ void window_sums(const SyncLoopParams& p, uint32_t w,
 // stage 0: before the first iteration -- delays of the first motion and loss+gradient launches
 __global__ __launch_bounds__(64) void sync_begin_kernel(SyncLoopParams p) {
 #pragma clang fp contract(off)
-    const uint32_t w = blockIdx.x * 64 + threadIdx.x;
-    if (w >= p.n_win) return;
+    const uint32_t w = p.win0 + blockIdx.x * 64 + threadIdx.x;
+    if (w >= p.win1) return;
     SyncWin& s = p.win[w];
     s.x0 = s.active ? s.d - p.delay_b * s.v : __builtin_nan("");
     split64_dev(s.active ? s.d : __builtin_nan(""), p.fs, &p.mo_kd[w], &p.mo_fd[w]);
     split64_dev(s.x0, p.fs, &p.lg_kd[w], &p.lg_fd[w]);
-    if (w == 0) { p.prev_hit[0] = kHalfBt - 1; p.prev_hit[1] = kHalfBt - 1; }
+    if (w == p.win0) { p.prev_hit[0] = kHalfBt - 1; p.prev_hit[1] = kHalfBt - 1; }
 }
 
 // which trials the first batch holds: as many as the previous iteration needed, at least five
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(kBlock) void sync_grad_kernel(SyncLoopParams p) {
 #pragma clang fp contract(off)
     __shared__ double s_tot[2 * kMaxBt];
     __shared__ double s_stage[kStageDoubles];
-    const uint32_t w = blockIdx.x;
+    const uint32_t w = blockIdx.x + p.win0;
     window_sums(p, w, s_tot, s_stage);
     if (threadIdx.x != 0) return;
     SyncWin& s = p.win[w];
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void sync_trial1_kernel(SyncLoopParams p) {
 #pragma clang fp contract(off)
     __shared__ double s_tot[2 * kMaxBt];
     __shared__ double s_stage[kStageDoubles];
-    const uint32_t w = blockIdx.x;
+    const uint32_t w = blockIdx.x + p.win0;
     window_sums(p, w, s_tot, s_stage);
     if (threadIdx.x != 0) return;
     SyncWin& s = p.win[w];
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void sync_step_kernel(SyncLoopParams p) {
 #pragma clang fp contract(off)
     __shared__ double s_tot[2 * kMaxBt];
     __shared__ double s_stage[kStageDoubles];
-    const uint32_t w = blockIdx.x;
+    const uint32_t w = blockIdx.x + p.win0;
     window_sums(p, w, s_tot, s_stage);
     if (threadIdx.x != 0) return;
     SyncWin& s = p.win[w];

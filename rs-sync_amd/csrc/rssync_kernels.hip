@@ -26,7 +26,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rssync_hip.h"
@@ -78,6 +80,9 @@ struct rship_ctx {
     DevBuf g_ts, g_rates, g_us, g_dq, g_q, g_knots, g_cf, g_status;
     uint32_t g_n = 0; // samples of the last rship_gyro_rates_upload
     int64_t g_first_us = 0, g_last_us = 0;
+    std::vector<hipStream_t> loop_streams; // rship_sync_run: one per group of windows
+    hipEvent_t loop_ready = nullptr;
+    std::vector<uint32_t> h_grp_off;       // host copy of the selection's group offsets
     DevBuf loop_state;            // rship_sync_run: windows, delay arrays, counters, trace
     bool plan_has_idx = false;
     uint32_t plan_chunks = 0, plan_wins = 0, plan_len = 0;
@@ -118,11 +123,14 @@ struct rship_ctx {
 
 namespace {
 
+std::mutex g_err_mutex; // rship_sync_run launches from several host threads
 int set_err(rship_ctx* c, const char* what, hipError_t e) {
+    std::lock_guard<std::mutex> lock(g_err_mutex);
     c->err = std::string(what) + ": " + hipGetErrorString(e);
     return 1;
 }
 int set_err(rship_ctx* c, const std::string& what) {
+    std::lock_guard<std::mutex> lock(g_err_mutex);
     c->err = what;
     return 1;
 }
@@ -229,15 +237,17 @@ int launch_lmeds(rship_ctx* c, const LmedsParams& p, int rpt, uint32_t grid) {
 }
 
 template <bool GRAD, bool SIMPLE>
-int launch_loss64(rship_ctx* c, const Loss64Params& p, int rpt) {
+int launch_loss64(rship_ctx* c, const Loss64Params& p, int rpt, hipStream_t st = nullptr, uint32_t count = 0) {
+    if (!st) st = c->stream;
+    if (!count) count = p.n_sel - p.slot0;
     ProfScope ps(c, RSHIP_K_LOSS);
     switch (rpt) {
-        case 1: hipLaunchKernelGGL((loss64_kernel<1, GRAD, SIMPLE>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
-        case 2: hipLaunchKernelGGL((loss64_kernel<2, GRAD, SIMPLE>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
-        case 4: hipLaunchKernelGGL((loss64_kernel<4, GRAD, SIMPLE>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
-        case 8: hipLaunchKernelGGL((loss64_kernel<8, GRAD, SIMPLE>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
-        case 16: hipLaunchKernelGGL((loss64_kernel<16, GRAD, SIMPLE>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
-        case 32: hipLaunchKernelGGL((loss64_kernel<32, GRAD, SIMPLE>), dim3(p.n_sel), dim3(kBlock), 0, c->stream, p); break;
+        case 1: hipLaunchKernelGGL((loss64_kernel<1, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((loss64_kernel<2, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
+        case 4: hipLaunchKernelGGL((loss64_kernel<4, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
+        case 8: hipLaunchKernelGGL((loss64_kernel<8, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
+        case 16: hipLaunchKernelGGL((loss64_kernel<16, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
+        case 32: hipLaunchKernelGGL((loss64_kernel<32, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
         default: return set_err(c, "loss: unsupported rows-per-thread");
     }
     RS_HIP(hipGetLastError());
@@ -247,7 +257,9 @@ int launch_loss64(rship_ctx* c, const Loss64Params& p, int rpt) {
 // The workgroup shape of the motion kernel follows the LARGEST frame of the whole problem (all devices:
 // RSHIP_OPT_TRACKS_HINT), not of the selection at hand: the shape fixes the order in which a frame's row
 // terms are added, and a frame must get the same sums whichever selection or device it is part of.
-int launch_motion64(rship_ctx* c, const Motion64Params& p) {
+int launch_motion64(rship_ctx* c, const Motion64Params& p, hipStream_t st = nullptr, uint32_t count = 0) {
+    if (!st) st = c->stream;
+    if (!count) count = p.n_sel - p.slot0;
     ProfScope ps(c, RSHIP_K_MOTION);
     const uint32_t n = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
     // One wave per frame up to 512 tracks: the evaluations of a frame are dominated by their fixed part (five
@@ -256,15 +268,15 @@ int launch_motion64(rship_ctx* c, const Motion64Params& p) {
     // many frames per CU this way.  Above that, four waves: with 8 / 16 waves (4 / 2 rows per thread at 2048
     // tracks) the launch took 7.8 / 12.4 ms per bench step instead of 4.75, and with two waves 5.15: the kernel is
     // bound by the work per evaluation, not by its slowest frame.
-    if (n <= 64) hipLaunchKernelGGL((opt_motion64_kernel<1, 1>), dim3(p.n_sel), dim3(64), 0, c->stream, p);
-    else if (n <= 128) hipLaunchKernelGGL((opt_motion64_kernel<2, 1>), dim3(p.n_sel), dim3(64), 0, c->stream, p);
-    else if (n <= 192) hipLaunchKernelGGL((opt_motion64_kernel<3, 1>), dim3(p.n_sel), dim3(64), 0, c->stream, p);
-    else if (n <= 256) hipLaunchKernelGGL((opt_motion64_kernel<4, 1>), dim3(p.n_sel), dim3(64), 0, c->stream, p);
-    else if (n <= 512) hipLaunchKernelGGL((opt_motion64_kernel<8, 1>), dim3(p.n_sel), dim3(64), 0, c->stream, p);
-    else if (n <= 1024) hipLaunchKernelGGL((opt_motion64_kernel<4, 4>), dim3(p.n_sel), dim3(256), 0, c->stream, p);
-    else if (n <= 2048) hipLaunchKernelGGL((opt_motion64_kernel<8, 4>), dim3(p.n_sel), dim3(256), 0, c->stream, p);
-    else if (n <= 4096) hipLaunchKernelGGL((opt_motion64_kernel<16, 4>), dim3(p.n_sel), dim3(256), 0, c->stream, p);
-    else if (n <= 8192) hipLaunchKernelGGL((opt_motion64_kernel<32, 4>), dim3(p.n_sel), dim3(256), 0, c->stream, p);
+    if (n <= 64) hipLaunchKernelGGL((opt_motion64_kernel<1, 1>), dim3(count), dim3(64), 0, st, p);
+    else if (n <= 128) hipLaunchKernelGGL((opt_motion64_kernel<2, 1>), dim3(count), dim3(64), 0, st, p);
+    else if (n <= 192) hipLaunchKernelGGL((opt_motion64_kernel<3, 1>), dim3(count), dim3(64), 0, st, p);
+    else if (n <= 256) hipLaunchKernelGGL((opt_motion64_kernel<4, 1>), dim3(count), dim3(64), 0, st, p);
+    else if (n <= 512) hipLaunchKernelGGL((opt_motion64_kernel<8, 1>), dim3(count), dim3(64), 0, st, p);
+    else if (n <= 1024) hipLaunchKernelGGL((opt_motion64_kernel<4, 4>), dim3(count), dim3(256), 0, st, p);
+    else if (n <= 2048) hipLaunchKernelGGL((opt_motion64_kernel<8, 4>), dim3(count), dim3(256), 0, st, p);
+    else if (n <= 4096) hipLaunchKernelGGL((opt_motion64_kernel<16, 4>), dim3(count), dim3(256), 0, st, p);
+    else if (n <= 8192) hipLaunchKernelGGL((opt_motion64_kernel<32, 4>), dim3(count), dim3(256), 0, st, p);
     else return set_err(c, "motion: unsupported track count");
     RS_HIP(hipGetLastError());
     return 0;
@@ -432,6 +444,8 @@ void rship_destroy(rship_ctx* c) {
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    for (hipStream_t st : c->loop_streams) (void)hipStreamDestroy(st);
+    if (c->loop_ready) (void)hipEventDestroy(c->loop_ready);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -749,6 +763,7 @@ int rship_select_slots(rship_ctx* c, const uint32_t* idx, uint32_t n, const uint
     RS_HIP(hipMemsetD32Async((hipDeviceptr_t)c->init_h.p, kInitNone, (size_t)n + 1, c->stream));
     RS_HIP(hipStreamSynchronize(c->stream));
     c->h_sel.assign(idx, idx + n);
+    c->h_grp_off = off;
     c->n_sel = n;
     c->n_grp = n_grp;
     c->max_n = sel_max_n(c);
@@ -1083,6 +1098,18 @@ int rship_loss_collect(rship_ctx* c, uint32_t n_delays, double* win_loss, double
 // the device: see kernels/syncloop.hpp.  d0[W] initial delays (after rship_init_motion, or rship_init_k_simple
 // for the simplified mode); on return d_out[W], iters[W] and trace[W][max_outer][6] (rows as
 // rssync_ext_sync_trace).  The plan must be one window per group over the slots in order.
+// How many groups of windows run their loops side by side (each on its own stream).  An iteration is a chain of
+// seven short launches, each as long as its slowest frame; with all windows in one chain the device idles most
+// of that time.  Windows do not see each other, so contiguous groups of them can run as independent chains.
+static uint32_t loop_groups(const rship_ctx* c, uint32_t n_win) {
+    uint32_t g = 4; // HIP's default number of hardware queues
+    if (const char* s = std::getenv("RSSYNC_LOOP_STREAMS")) { const int v = atoi(s); if (v >= 1 && v <= 16) g = (uint32_t)v; }
+    if (c->prof) g = 1; // the event pairs of the profile live on the context's stream
+    const uint32_t by_size = n_win / 8; // a chain per fewer than ~8 windows does not pay for its launches
+    if (g > by_size) g = by_size;
+    return g < 1 ? 1 : g;
+}
+
 int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_center, double search_radius,
                    int simplified, double* d_out, int32_t* iters, double* trace) {
     DeviceGuard dev_guard(c);
@@ -1090,18 +1117,27 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     const uint32_t W = c->n_grp, ns = c->n_sel;
     if (c->plan_wins != W || c->plan_has_idx || c->plan_len != ns) return set_err(c, "sync_run: the plan must be the selection's groups");
     if (max_outer <= 0) return set_err(c, "sync_run: no iterations");
-    // one allocation: windows | motion delays | loss delays | trial delays | counters | trace | chunk scratch
+    if (c->h_grp_off.size() != (size_t)W + 1) return set_err(c, "sync_run: no selection");
+    const uint32_t G = loop_groups(c, W);
+    // one allocation: windows | motion delays | loss delays | trial delays | per-group counters | trace | chunk scratch
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t o_win = take(W * sizeof(SyncWin));
     const size_t o_mokd = take(W * 4), o_mofd = take(W * 8), o_lgkd = take(W * 4), o_lgfd = take(W * 8);
     const size_t o_trkd = take((size_t)kMaxBt * W * 4), o_trfd = take((size_t)kMaxBt * W * 8);
-    const size_t o_prev = take(8), o_nact = take((size_t)max_outer * 4);
+    const size_t nact_stride = ((size_t)max_outer * 4 + 255) / 256 * 256;
+    const size_t o_prev = take((size_t)G * 256), o_nact = take((size_t)G * nact_stride);
     const size_t o_trace = take((size_t)W * max_outer * 48);
     const size_t o_tmp = take((size_t)W * 2 * kMaxBt * (c->plan_max_chunks + 1) * 8);
     if (ensure(c, c->loop_state, off)) return 1;
     char* base = (char*)c->loop_state.p;
     if (ensure(c, c->part, (size_t)2 * kMaxBt * ns * 8)) return 1;
+    while (c->loop_streams.size() < G) {
+        hipStream_t st = nullptr;
+        RS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        c->loop_streams.push_back(st);
+    }
+    if (!c->loop_ready) RS_HIP(hipEventCreateWithFlags(&c->loop_ready, hipEventDisableTiming));
 
     std::vector<SyncWin> hw(W);
     for (uint32_t w = 0; w < W; ++w) {
@@ -1111,7 +1147,7 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
         hw[w].hit = -1;
     }
     RS_HIP(hipMemcpyAsync(base + o_win, hw.data(), W * sizeof(SyncWin), hipMemcpyHostToDevice, c->stream));
-    RS_HIP(hipMemsetAsync(base + o_nact, 0, (size_t)max_outer * 4, c->stream));
+    RS_HIP(hipMemsetAsync(base + o_nact, 0, (size_t)G * nact_stride, c->stream));
 
     SyncLoopParams lp{};
     lp.win = (SyncWin*)(base + o_win);
@@ -1135,8 +1171,6 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     lp.search_center = search_center;
     lp.search_radius = search_radius;
     lp.max_outer = max_outer;
-    lp.prev_hit = (int*)(base + o_prev);
-    lp.n_active = (int*)(base + o_nact);
     lp.trace = (double*)(base + o_trace);
 
     Motion64Params mp{};
@@ -1157,57 +1191,122 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     qp.k = (const double*)c->k.p;
     qp.part_loss = (double*)c->part.p;
     const int rpt = rpt_for(c->max_n);
-    auto loss_launch = [&](bool grad) -> int {
-        if (simplified) return grad ? launch_loss64<true, true>(c, qp, rpt) : launch_loss64<false, true>(c, qp, rpt);
-        return grad ? launch_loss64<true, false>(c, qp, rpt) : launch_loss64<false, false>(c, qp, rpt);
-    };
 
-    if (ensure_pinned(c, (size_t)max_outer * 4 + 64)) return 1;
-    hipLaunchKernelGGL(sync_begin_kernel, dim3((W + 63) / 64), dim3(64), 0, c->stream, lp);
-    RS_HIP(hipGetLastError());
-    const int kLook = 8; // iterations enqueued between two looks at the counter of active windows
-    int it = 0;
-    bool done = false;
-    while (it < max_outer && !done) {
-        const int until = std::min(max_outer, it + kLook);
-        for (; it < until; ++it) {
-            lp.it = it;
-            if (!simplified) {
-                if (launch_motion64(c, mp)) return 1; // :311 (finishes a pending GuessMotion on its first launch)
-                c->init_pending = false;
-                mp.init_h = (int32_t*)c->init_h.p;
-            }
-            // loss + gradient at x0 (:298-299 -> backtrack.cpp:4)
-            qp.kd = lp.lg_kd; qp.fd = lp.lg_fd; qp.n_delays = 1;
-            qp.part_grad = qp.part_loss + (size_t)ns;
-            if (loss_launch(true)) return 1;
-            lp.rows = 2;
-            {
-                ProfScope ps(c, RSHIP_K_REDUCE);
-                hipLaunchKernelGGL(sync_grad_kernel, dim3(W), dim3(W > 64 ? 64 : kBlock), 0, c->stream, lp);
-            }
-            // the trials, in two batches (first: as many as the previous iteration needed)
-            qp.kd = lp.tr_kd; qp.fd = lp.tr_fd; qp.n_delays = kMaxBt;
-            qp.part_grad = nullptr;
-            lp.rows = kMaxBt;
-            if (loss_launch(false)) return 1;
-            {
-                ProfScope ps(c, RSHIP_K_REDUCE);
-                hipLaunchKernelGGL(sync_trial1_kernel, dim3(W), dim3(W > 64 ? 64 : kBlock), 0, c->stream, lp);
-            }
-            if (loss_launch(false)) return 1;
-            {
-                ProfScope ps(c, RSHIP_K_REDUCE);
-                hipLaunchKernelGGL(sync_step_kernel, dim3(W), dim3(W > 64 ? 64 : kBlock), 0, c->stream, lp);
-            }
+    // the groups: windows [w0, w1) = slots [s0, s1), balanced by slots
+    struct Group {
+        uint32_t w0, w1, s0, s1;
+        hipStream_t st;
+        int* prev_hit;
+        int* n_active;
+        int* h_nact; // pinned
+        int it = 0;
+        bool done = false;
+    };
+    std::vector<Group> groups(G);
+    if (ensure_pinned(c, (size_t)G * nact_stride + 64)) return 1;
+    {
+        uint32_t w = 0;
+        for (uint32_t g = 0; g < G; ++g) {
+            Group& gr = groups[g];
+            gr.w0 = w;
+            const uint64_t target = (uint64_t)ns * (g + 1) / G;
+            while (w < W && (g + 1 == G || c->h_grp_off[w + 1] <= target || w == gr.w0)) ++w;
+            if (g + 1 == G) w = W;
+            gr.w1 = w;
+            gr.s0 = c->h_grp_off[gr.w0];
+            gr.s1 = c->h_grp_off[gr.w1];
+            gr.st = G == 1 ? c->stream : c->loop_streams[g];
+            gr.prev_hit = (int*)(base + o_prev + (size_t)g * 256);
+            gr.n_active = (int*)(base + o_nact + (size_t)g * nact_stride);
+            gr.h_nact = (int*)((char*)c->pinned + (size_t)g * nact_stride);
+            gr.done = gr.w1 == gr.w0 || gr.s1 == gr.s0;
+        }
+    }
+    if (G > 1) { // what the context's stream has queued (selection, GuessMotion, the copies above) comes first
+        RS_HIP(hipEventRecord(c->loop_ready, c->stream));
+        for (Group& gr : groups) RS_HIP(hipStreamWaitEvent(gr.st, c->loop_ready, 0));
+    }
+    auto enqueue_iteration = [&](Group& gr) -> int {
+        SyncLoopParams l = lp;
+        l.win0 = gr.w0; l.win1 = gr.w1;
+        l.prev_hit = gr.prev_hit;
+        l.n_active = gr.n_active;
+        l.it = gr.it;
+        const uint32_t nw = gr.w1 - gr.w0, cnt = gr.s1 - gr.s0;
+        const dim3 ctl_block(nw > 64 ? 64 : kBlock);
+        Loss64Params q = qp;
+        q.slot0 = gr.s0;
+        auto loss_launch = [&](bool grad) -> int {
+            if (simplified) return grad ? launch_loss64<true, true>(c, q, rpt, gr.st, cnt) : launch_loss64<false, true>(c, q, rpt, gr.st, cnt);
+            return grad ? launch_loss64<true, false>(c, q, rpt, gr.st, cnt) : launch_loss64<false, false>(c, q, rpt, gr.st, cnt);
+        };
+        if (gr.it == 0) {
+            hipLaunchKernelGGL(sync_begin_kernel, dim3((nw + 63) / 64), dim3(64), 0, gr.st, l);
             RS_HIP(hipGetLastError());
         }
-        RS_HIP(hipMemcpyAsync(c->pinned, base + o_nact, (size_t)it * 4, hipMemcpyDeviceToHost, c->stream));
-        if (sync_stream(c)) return 1;
-        done = ((const int*)c->pinned)[it - 1] == 0;
+        if (!simplified) {
+            Motion64Params m = mp;
+            m.slot0 = gr.s0;
+            if (launch_motion64(c, m, gr.st, cnt)) return 1; // :311 (finishes a pending GuessMotion on its first launch)
+        }
+        // loss + gradient at x0 (:298-299 -> backtrack.cpp:4)
+        q.kd = l.lg_kd; q.fd = l.lg_fd; q.n_delays = 1;
+        q.part_grad = q.part_loss + (size_t)ns;
+        if (loss_launch(true)) return 1;
+        l.rows = 2;
+        {
+            ProfScope ps(c, RSHIP_K_REDUCE);
+            hipLaunchKernelGGL(sync_grad_kernel, dim3(nw), ctl_block, 0, gr.st, l);
+        }
+        // the trials, in two batches (first: as many as the previous iteration needed)
+        q.kd = l.tr_kd; q.fd = l.tr_fd; q.n_delays = kMaxBt;
+        q.part_grad = nullptr;
+        l.rows = kMaxBt;
+        if (loss_launch(false)) return 1;
+        {
+            ProfScope ps(c, RSHIP_K_REDUCE);
+            hipLaunchKernelGGL(sync_trial1_kernel, dim3(nw), ctl_block, 0, gr.st, l);
+        }
+        if (loss_launch(false)) return 1;
+        {
+            ProfScope ps(c, RSHIP_K_REDUCE);
+            hipLaunchKernelGGL(sync_step_kernel, dim3(nw), ctl_block, 0, gr.st, l);
+        }
+        RS_HIP(hipGetLastError());
+        gr.it += 1;
+        return 0;
+    };
+
+    const int kLook = 8; // iterations enqueued between two looks at a group's counter of active windows
+    // one host thread per group: a chain is ~7 launches per iteration and the launches of four chains from one
+    // thread would make the host the slowest part
+    auto run_group = [&](Group& gr) -> int {
+        DeviceGuard guard(c); // the current device is a per-thread setting
+        while (!gr.done) {
+            const int until = std::min(max_outer, gr.it + kLook);
+            while (gr.it < until)
+                if (enqueue_iteration(gr)) return 1;
+            RS_HIP(hipMemcpyAsync(gr.h_nact, gr.n_active, (size_t)gr.it * 4, hipMemcpyDeviceToHost, gr.st));
+            RS_HIP(hipStreamSynchronize(gr.st));
+            gr.done = gr.h_nact[gr.it - 1] == 0 || gr.it >= max_outer;
+        }
+        return 0;
+    };
+    {
+        std::vector<std::thread> workers;
+        std::vector<int> rc(G, 0);
+        for (uint32_t g = 1; g < G; ++g) workers.emplace_back([&, g] { rc[g] = run_group(groups[g]); });
+        rc[0] = run_group(groups[0]);
+        for (std::thread& t : workers) t.join();
+        for (uint32_t g = 0; g < G; ++g)
+            if (rc[g]) return 1;
     }
+    int it_max = 0;
+    for (const Group& gr : groups) it_max = std::max(it_max, gr.it);
+    c->init_pending = false;
+    if (G == 1) prof_collect(c);
     // the windows and the rows of the iterations that ran ([iteration][window][6] on the device), through pinned memory
-    const size_t tr_bytes = (size_t)it * W * 48, win_bytes = W * sizeof(SyncWin);
+    const size_t tr_bytes = (size_t)it_max * W * 48, win_bytes = W * sizeof(SyncWin);
     if (ensure_pinned(c, tr_bytes + win_bytes + 64)) return 1;
     RS_HIP(hipMemcpyAsync(c->pinned, base + o_win, win_bytes, hipMemcpyDeviceToHost, c->stream));
     RS_HIP(hipMemcpyAsync((char*)c->pinned + win_bytes, base + o_trace, tr_bytes, hipMemcpyDeviceToHost, c->stream));

@@ -715,3 +715,40 @@ def test_device_driven_sync_loop_equals_the_host_loop(small_case, clean_case):
     capped_h.set_host_loop(True)
     assert capped.Sync(0.03, 0, 63, 0.0, 0.2) == capped_h.Sync(0.03, 0, 63, 0.0, 0.2)
     assert len(capped.sync_trace()) == 3
+
+
+def test_window_groups_on_concurrent_streams_equal_the_host_loop():
+    """With 16 or more windows the device-driven loop runs contiguous groups of windows as independent chains of
+    launches, each on its own stream from its own host thread (rship_sync_run).  Windows do not see each other:
+    every delay, cost and trace row must be the host loop's, bit for bit, whatever the number of groups."""
+    import rssync_amd
+    from rssync_amd import synth
+    F, N, WINDOW = 400, 96, 24
+    g = synth.make_gyro(0, (F + 2) / synth.FPS, seed=41)
+    pos = list(range(0, F - WINDOW - 1, 11))   # 35 overlapping windows -> 4 groups
+    assert len(pos) >= 32
+    old = os.environ.get("RSSYNC_LOOP_STREAMS")
+    runs = {}
+    try:
+        for streams in ("host", "1", "3", "4"):
+            p = rssync_amd.SyncProblem(seed=SEED, verbose=False, max_outer_iters=60)
+            synth.fill(p, g, 0, F, N, seed=41)
+            if streams == "host":
+                p.set_host_loop(True)
+            else:
+                os.environ["RSSYNC_LOOP_STREAMS"] = streams
+            c, d = p.sync_points(pos, WINDOW, 0.0, 0.002, 0.1, repeats=2)
+            runs[streams] = (np.array(c), np.array(d), [np.array(p.window_trace(w)) for w in range(len(pos))])
+    finally:
+        if old is None:
+            os.environ.pop("RSSYNC_LOOP_STREAMS", None)
+        else:
+            os.environ["RSSYNC_LOOP_STREAMS"] = old
+    ref = runs["host"]
+    assert len({len(t) for t in ref[2]}) > 1   # windows stop at different iterations
+    for streams in ("1", "3", "4"):
+        c, d, tr = runs[streams]
+        np.testing.assert_array_equal(d, ref[1])
+        np.testing.assert_array_equal(c, ref[0])
+        for w in range(len(pos)):
+            np.testing.assert_array_equal(tr[w], ref[2][w])
