@@ -1,0 +1,109 @@
+"""Randomised differential cases, HIP against the CPU restatement: gyro rate, number of frames, ragged track
+counts (2 .. 700: every rows-per-thread instantiation, frames of one wave and of four), sparse frame ids, sweep
+step / radius / centre all drawn per seed.  What is compared is what does not depend on rounding noise: the fp64
+rows, the fp64 loss and its analytic gradient, PreSync's per-frame costs where both sides chose the same
+hypothesis, the arg-min of the sweep, and Sync on noise-free scenes."""
+import os
+
+import numpy as np
+import pytest
+
+import rssync_amd
+from rssync_amd import synth
+from oracle.oracle import OracleProblem
+
+pytestmark = pytest.mark.gpu
+
+RATES = [200.0, 400.0, 500.0, 800.0, 1000.0, 1600.0]
+
+
+def draw_case(seed, clean):
+    rng = np.random.default_rng(1000 + seed)
+    fs = RATES[int(rng.integers(len(RATES)))]
+    F = int(rng.integers(3, 15))
+    first = int(rng.integers(0, 40))
+    ids = first + np.sort(rng.choice(3 * F, size=F, replace=False))
+    n_max = int(rng.choice([40, 130, 256, 300, 520, 700]))
+    counts = [int(rng.integers(2, n_max + 1)) for _ in range(F)]
+    counts[int(rng.integers(F))] = n_max
+    g = synth.make_gyro(first / synth.FPS, (int(ids[-1]) + 2) / synth.FPS, fs=fs, seed=seed)
+    kw = dict(noise=0.0, outliers=0.0) if clean else {}
+    frames = []
+    for fid, n in zip(ids, counts):
+        (fr, ta, tb, ra, rb), = list(synth.make_frames(g, int(fid), int(fid) + 1, n_max, seed=seed, **kw))
+        frames.append((fr, ta[:n], tb[:n], ra[:n], rb[:n]))
+    return rng, g, frames, counts
+
+
+def build(seed, g, frames, **kw):
+    h = rssync_amd.SyncProblem(seed=seed, verbose=False, **kw)
+    o = OracleProblem(seed=seed, faithful=False, threads=min(os.cpu_count() or 1, 8), **kw)
+    for p in (h, o):
+        p.SetGyroQuaternions(g.quats, g.fs, g.t0)
+        for fr in frames:
+            p.SetTrackResult(*fr)
+    return h, o
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_noisy_case(seed):
+    rng, g, frames, counts = draw_case(seed, clean=False)
+    h, o = build(seed, g, frames)
+    ids = [fr[0] for fr in frames]
+    lo, hi = ids[0], ids[-1] + 1
+    # fp64 rows of a random frame at a random delay (also outside the gyro span)
+    for _ in range(3):
+        k = int(rng.integers(len(frames)))
+        delay = float(rng.choice([rng.uniform(-0.05, 0.08), rng.uniform(-3.0, 3.0)]))
+        P = h.problem_matrix64(ids[k], delay, counts[k])
+        Po = o.problem_matrix(ids[k], delay)
+        assert P.shape == Po.shape
+        assert np.abs(P - Po).max() < 1e-13 * max(1.0, np.abs(Po).max())
+    # the sweep
+    step = float(rng.choice([0.0005, 0.001, 0.002, 0.004]))
+    radius = float(rng.uniform(0.005, 0.06))
+    centre = synth.D_TRUE + float(rng.uniform(-0.01, 0.01))
+    nf = len(frames)
+    dh, ch, fch, bhh = h.presync_curve(centre, lo, hi, step, radius, per_frame=nf)
+    do, co, fco, bho = o.presync_curve(centre, lo, hi, step, radius, per_frame=nf)
+    np.testing.assert_array_equal(dh, do)
+    big = np.array([n >= 48 for n in counts])
+    if big.any():
+        same = (bhh == bho)[:, big]
+        assert same.mean() > 0.9
+        np.testing.assert_allclose(fch[:, big][same], fco[:, big][same], rtol=3e-3)
+    np.testing.assert_allclose(ch, co, rtol=0.05)
+    res_h, res_o = h.PreSync(centre, lo, hi, step, radius), o.PreSync(centre, lo, hi, step, radius)
+    margin = np.sort(co)[1] - np.sort(co)[0] if len(co) > 1 else 1.0
+    if margin > 0.02 * co.min():      # a clear minimum: the same candidate wins
+        assert res_h[1] == res_o[1]
+    # fp64 loss and gradient at the GPU's own motion estimates
+    d0 = res_h[1]
+    Mh, kh = h.init_motion(d0, lo, hi - 1)
+    for dd in (d0, d0 + 7e-4):
+        Lh, Gh = h.loss([dd], grad=True)
+        L = G = 0.0
+        for j, fid in enumerate(ids):
+            l, _, da, _ = o.loss(fid, dd, Mh[j], kh[j])
+            L += l
+            G += da
+        assert Lh[0] == pytest.approx(L, rel=1e-11)
+        assert Gh[0] == pytest.approx(G, rel=1e-9, abs=1e-9 * abs(L))
+
+
+@pytest.mark.parametrize("seed", range(100, 106))
+def test_random_clean_case_sync(seed):
+    """without noise the minimum is sharp and Sync is not chaotic: both sides end at the true delay"""
+    rng, g, frames, counts = draw_case(seed, clean=True)
+    if min(counts) < 16:   # GuessMotion on a handful of rows is a coin toss on either side
+        frames = [fr for fr, n in zip(frames, counts) if n >= 16]
+    h, o = build(seed, g, frames, max_outer_iters=60)
+    ids = [fr[0] for fr in frames]
+    lo, hi = ids[0], ids[-1]
+    start = synth.D_TRUE + float(rng.uniform(-0.002, 0.002))
+    ch, dh = h.Sync(start, lo, hi, 0.0, 0.5)
+    co, do = o.Sync(start, lo, hi, 0.0, 0.5)
+    # the two solvers agree far better than either agrees with the truth (a few frames, capped iterations)
+    assert abs(dh - do) < 2e-6, (dh, do)
+    assert abs(dh - synth.D_TRUE) < 3e-4, (dh, do)
+    assert ch == pytest.approx(co, rel=1e-3, abs=1e-9)
