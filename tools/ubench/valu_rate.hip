@@ -68,17 +68,19 @@ typedef float v2f __attribute__((ext_vector_type(2)));
                    "+v"(d[8]), "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15]) \
                  : "v"(da), "v"(db));
 
-enum { M_FMA, M_MUL, M_MOV, M_PKFMA, M_FMA64, M_CMPCNT, M_STAGEC, M_COUNT };
+enum { M_FMA, M_MUL, M_MOV, M_PKFMA, M_FMA64, M_CMPCNT, M_STAGEC, M_STAGEC2, M_STAGEC4, M_COUNT };
 const char* kNames[M_COUNT] = {"v_fma_f32", "v_mul_f32", "v_mov_b32", "v_pk_fma_f32", "v_fma_f64",
-                               "v_cmp+s_bcnt1+s_add", "stageC(3 b128 + 6 pk_fma + 4 cmp/cnt)"};
+                               "v_cmp+s_bcnt1+s_add", "stageC(3 b128 + 6 pk_fma + 4 cmp/cnt)",
+                               "stageC x2 hyp, count only (3 b128 + 12 pk_fma + 8 cmp/cnt)",
+                               "stageC x4 hyp, count only (3 b128 + 24 pk_fma + 16 cmp/cnt)"};
 // VALU instructions per loop iteration, per mode
-const int kValuPerIter[M_COUNT] = {64, 64, 64, 64, 64, 64, 80};
+const int kValuPerIter[M_COUNT] = {64, 64, 64, 64, 64, 64, 80, 160, 320};
 
 struct Stamp { unsigned long long t0, t1, r0, r1; };
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, Stamp* stamps, int iters, float a, float b) {
-    constexpr int kRows = MODE == M_STAGEC ? 2048 : 4; // 24 KB only where it is used (occupancy)
+    constexpr int kRows = (MODE == M_STAGEC || MODE == M_STAGEC2 || MODE == M_STAGEC4) ? 2048 : 4; // 24 KB only where it is used (occupancy)
     __shared__ __attribute__((aligned(16))) float tile[3][kRows];
     float x[16];
     v2f p[16];
@@ -134,6 +136,35 @@ __global__ __launch_bounds__(256) void k(float* out, Stamp* stamps, int iters, f
             a += 1e-9f;
             x[0] += (float)(cnt & 1u) * 1e-9f; // the next hypothesis depends on this one's count, as in the kernel
         }
+        if (MODE == M_STAGEC2 || MODE == M_STAGEC4) {
+            // one sweep of the tile for G hypotheses, counting only (no residual kept): the pre-filter form
+            constexpr int G = MODE == M_STAGEC2 ? 2 : 4;
+            const float4* p4x = (const float4*)tile[0];
+            const float4* p4y = (const float4*)tile[1];
+            const float4* p4z = (const float4*)tile[2];
+            const int lane = threadIdx.x & 63;
+            unsigned c[G];
+#pragma unroll
+            for (int q = 0; q < G; ++q) c[q] = 0;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                if ((m & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+                const int idx = m * 64 + lane;
+                const float4 X = p4x[idx], Y = p4y[idx], Z = p4z[idx];
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    const v2f r01 = v2f{X.x, X.y} * x[3 * q] + v2f{Y.x, Y.y} * x[3 * q + 1] + v2f{Z.x, Z.y} * x[3 * q + 2];
+                    const v2f r23 = v2f{X.z, X.w} * x[3 * q] + v2f{Y.z, Y.w} * x[3 * q + 1] + v2f{Z.z, Z.w} * x[3 * q + 2];
+                    c[q] += (unsigned)__builtin_popcountll(__builtin_amdgcn_fcmpf(a, __builtin_fabsf(r01.x), 2));
+                    c[q] += (unsigned)__builtin_popcountll(__builtin_amdgcn_fcmpf(a, __builtin_fabsf(r01.y), 2));
+                    c[q] += (unsigned)__builtin_popcountll(__builtin_amdgcn_fcmpf(a, __builtin_fabsf(r23.x), 2));
+                    c[q] += (unsigned)__builtin_popcountll(__builtin_amdgcn_fcmpf(a, __builtin_fabsf(r23.y), 2));
+                }
+            }
+            a += 1e-9f;
+#pragma unroll
+            for (int q = 0; q < G; ++q) { cnt += c[q]; x[3 * q] += (float)(c[q] & 1u) * 1e-9f; }
+        }
     }
     if (threadIdx.x == 0) {
         Stamp s;
@@ -163,7 +194,7 @@ void run(int waves_per_simd, FILE* csv) {
     Stamp* st;
     hipMalloc(&out, (size_t)grid * 256 * sizeof(float));
     hipMalloc(&st, (size_t)grid * sizeof(Stamp));
-    const int iters = (MODE == M_STAGEC || MODE == M_CMPCNT) ? 4000 : 8000;
+    const int iters = MODE == M_STAGEC4 ? 1000 : MODE == M_STAGEC2 ? 2000 : (MODE == M_STAGEC || MODE == M_CMPCNT) ? 4000 : 8000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -209,6 +240,8 @@ int main(int argc, char** argv) {
         run<M_FMA64>(w, csv);
         run<M_CMPCNT>(w, csv);
         run<M_STAGEC>(w, csv);
+        run<M_STAGEC2>(w, csv);
+        run<M_STAGEC4>(w, csv);
     }
     if (csv) fclose(csv);
     return 0;
