@@ -99,3 +99,49 @@ def test_several_contexts_on_the_gpu_equal_one(tmp_path):
         p = rssync_amd.SyncProblem(seed=5, max_outer_iters=12)
         p.set_devices(ids)
         _check(one, _run(_fill(p, case)))
+
+
+def _gyro_routes(make, device_lists):
+    """the gyro routes that run on the device (timestamped samples, angular rates, orientation sweep): every
+    device of the object builds the table itself, and a change of devices rebuilds it from the knots"""
+    from rssync_amd import synth
+    Fg = 40
+    g = synth.make_gyro(1.0, 1.0 + (Fg + 2) / synth.FPS, seed=13)   # first sample at t = 0 (unsigned timestamps)
+    frames = list(synth.make_frames(g, 30, 30 + Fg, 48, seed=13))
+    names = ["XYZ", "yXz", "ZxY"]
+    ref = None
+    for ids in device_lists:
+        p = make()
+        if ids:
+            p.set_devices(ids)
+        for fr in frames:
+            p.SetTrackResult(*fr)
+        out = {}
+        p.set_gyro_rates(g.times, g.rates, "XYZ")
+        out["info"] = p.gyro_info()
+        out["knots"] = p.gyro_knots().tolist()
+        out["table"] = p.gyro_table().tolist()
+        out["presync"] = p.PreSync(0.0, 30, 30 + Fg, 0.004, 0.06)
+        out["sync"] = p.Sync(out["presync"][1], 30, 30 + Fg - 1, 0.0, 0.2)
+        out["sweep"] = [x.tolist() for x in p.orientation_sweep(g.times, g.rates, names, 0.0, 30, 30 + Fg, 0.004, 0.06)]
+        ts_us = np.round(g.times * 1e6).astype(np.int64)
+        p.SetGyroQuaternionsTimestamped(ts_us, g.quats)
+        out["ts_presync"] = p.PreSync(0.0, 30, 30 + Fg, 0.004, 0.06)
+        p.set_devices([0, 0] if not ids else [0])   # the table follows the object to its new devices
+        out["moved"] = p.PreSync(0.0, 30, 30 + Fg, 0.004, 0.06)
+        assert out["moved"] == out["ts_presync"]
+        if ref is None:
+            ref = out
+        else:
+            _check(ref, out)
+
+
+def test_device_gyro_routes_on_fake_devices(hosttest_lib):
+    import rssync_amd
+    _gyro_routes(lambda: rssync_amd.SyncProblem(seed=5, max_outer_iters=12, _lib=hosttest_lib), [None, [0, 1], [2, 2, 2]])
+
+
+@pytest.mark.gpu
+def test_device_gyro_routes_on_several_contexts():
+    import rssync_amd
+    _gyro_routes(lambda: rssync_amd.SyncProblem(seed=5, max_outer_iters=12), [None, [0, 0], [0, 0, 0]])
