@@ -298,6 +298,7 @@ class SyncProblemHip final : public ISyncProblem {
     bool spline_dirty_ = true, frames_dirty_ = true;
     std::vector<int64_t> table_ids_;
     std::vector<uint32_t> sel_;
+    std::vector<int64_t> window_key_; // begins + ends of the windows select_windows has on the devices; empty = none
     size_t n_windows_ = 1;
 };
 
@@ -360,6 +361,7 @@ void SyncProblemHip::set_devices(const std::vector<int>& ids) {
     spline_dirty_ = true;
     frames_dirty_ = true;
     sel_.clear();
+    window_key_.clear();
 }
 
 void SyncProblemHip::set_option(int option, int value) {
@@ -711,6 +713,7 @@ void SyncProblemHip::pack_frames() {
     }
     if (bad) panic("set-track-result: non-finite numbers in rays (" + std::to_string(bad) + " tracks; lens parameters?)");
     sel_.clear();
+    window_key_.clear();
     frames_dirty_ = false;
 }
 
@@ -722,6 +725,7 @@ void SyncProblemHip::pack_frames() {
 // boundaries are multiples of kChunk in the frame table, which shard boundaries are as well.
 void SyncProblemHip::apply_selection(const std::vector<uint32_t>& slots, const std::vector<uint32_t>& grp_off,
                                      const std::vector<uint32_t>* plan_pos, const std::vector<uint32_t>* plan_off) {
+    window_key_.clear(); // whatever select_windows left on the devices is replaced
     const bool grouped = !grp_off.empty();
     const size_t n_grp = grouped ? grp_off.size() - 1 : 1;
     std::vector<uint32_t> def_off;
@@ -865,6 +869,7 @@ void SyncProblemHip::debug_rays(int64_t frame, float* a4, float* b4, size_t cap)
 // frame filters of core_private.cpp:65-68 / :218-219 / :340-343 on the sorted table
 uint32_t SyncProblemHip::select(int64_t begin, int64_t end_exclusive) {
     sel_.clear();
+    window_key_.clear();
     for (uint32_t i = 0; i < table_ids_.size(); ++i)
         if (table_ids_[i] >= begin && table_ids_[i] < end_exclusive) sel_.push_back(i);
     for (uint32_t i : sel_)
@@ -1097,6 +1102,11 @@ void SyncProblemHip::loss(const std::vector<double>& delays, std::vector<double>
 // selection for batched Sync: window w = frames with begin[w] <= id <= end[w] (end inclusive,
 // core_private.cpp:219); a frame covered by several windows gets one slot in each
 void SyncProblemHip::select_windows(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl) {
+    // the four Sync calls of a sync point select the same windows: what the devices hold is still right
+    // (GuessMotion rewrites every slot's state before anything reads it)
+    std::vector<int64_t> key(begins);
+    key.insert(key.end(), ends_incl.begin(), ends_incl.end());
+    if (!window_key_.empty() && key == window_key_) return;
     sel_.clear();
     std::vector<uint32_t> off(begins.size() + 1, 0);
     for (size_t w = 0; w < begins.size(); ++w) {
@@ -1110,6 +1120,7 @@ void SyncProblemHip::select_windows(const std::vector<int64_t>& begins, const st
     n_windows_ = std::max<size_t>(1, begins.size());
     if (begins.empty()) off.assign(2, 0u);
     apply_selection(sel_, off, nullptr, nullptr);
+    window_key_ = key; // apply_selection cleared it
 }
 
 // core_private.cpp:211-334 for W independent windows advanced in lock-step (W = 1 is
