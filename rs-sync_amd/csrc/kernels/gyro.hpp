@@ -5,9 +5,11 @@
 // Reference: core_testcode.cpp:36-52 (optdata_fill_gyro), core_private.cpp:142-190 (the timestamped
 // setter), minispline.cpp:3-46 (spline coefficients).  The arithmetic per sample is gyro_math.hpp's; what is
 // specific to the device is how the two sequential recurrences are cut:
-//   * integration q_i = normalise(dq_i q_{i-1}) is a scan under the quaternion product: one workgroup, every
-//     thread a contiguous chunk (sequential inside the chunk, with the reference's normalisation per step),
-//     a 1024-wide scan of the chunk products in LDS, then the chunk again from its prefix;
+//   * integration q_i = normalise(dq_i q_{i-1}) is a scan under the quaternion product: a workgroup takes a
+//     segment of kScanSegment samples, every thread a contiguous chunk of it (sequential inside the chunk, with the
+//     reference's normalisation per step), a 1024-wide scan of the chunk products in LDS, then the chunk again
+//     from its prefix; with more than one segment the segment totals are scanned the same way by one workgroup
+//     and a last pass multiplies every later segment by the product of the segments before it;
 //   * the spline's tridiagonal solve has data-independent pivots (tabulated, gyro_math.hpp) and a
 //     recurrence factor of 2 - sqrt(3) = 0.268 per row in both sweeps: what a row sees of a row k places away
 //     is below 0.268^k, so every thread solves a short run of rows after a warm-up of kSplineWarm rows started
@@ -71,12 +73,19 @@ __global__ __launch_bounds__(256) void gyro_order_kernel(const int64_t* ts, cons
     if (i > 0 && ts[i - 1] > ts[i]) atomicMin(&st->out_of_order, i);
 }
 
-// q_0 = dq_0 (identity), q_i = normalise(dq_i * q_{i-1}): ONE workgroup of kScanThreads
+// q_0 = dq_0 (identity), q_i = normalise(dq_i * q_{i-1}) within each segment of `seg` samples (one workgroup of
+// kScanThreads per segment); total[b] = the product over segment b (may be null)
 constexpr int kScanThreads = 1024;
+constexpr uint32_t kScanSegment = 32 * kScanThreads;
 
-__global__ __launch_bounds__(kScanThreads) void gyro_scan_kernel(const double* __restrict__ dq, double* __restrict__ q, uint32_t n) {
+__global__ __launch_bounds__(kScanThreads) void gyro_scan_kernel(const double* __restrict__ dq_all, double* __restrict__ q_all, uint32_t n_all,
+                                                                 uint32_t seg, double* __restrict__ total) {
     __shared__ double s[kScanThreads][4];
     const uint32_t t = threadIdx.x;
+    const size_t first = (size_t)blockIdx.x * seg;
+    const uint32_t n = n_all - first < seg ? (uint32_t)(n_all - first) : seg;
+    const double* dq = dq_all + 4 * first;
+    double* q = q_all + 4 * first;
     const uint32_t chunk = (n + kScanThreads - 1) / kScanThreads;
     const uint32_t lo = t * chunk < n ? t * chunk : n, hi = lo + chunk < n ? lo + chunk : n;
     double acc[4] = {1., 0., 0., 0.};
@@ -106,6 +115,19 @@ __global__ __launch_bounds__(kScanThreads) void gyro_scan_kernel(const double* _
         rs::quat_mul_norm(d, cur);
         for (int c = 0; c < 4; ++c) q[4 * (size_t)i + c] = cur[c];
     }
+    if (total && t == kScanThreads - 1)
+        for (int c = 0; c < 4; ++c) total[4 * (size_t)blockIdx.x + c] = s[t][c];
+}
+
+// q_i <- normalise(q_i * P) for the samples of segment b >= 1, P = product of the segments before it
+__global__ __launch_bounds__(256) void gyro_scan_fixup_kernel(double* __restrict__ q, uint32_t n, uint32_t seg, const double* __restrict__ prefix) {
+    const uint32_t i = seg + blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double* p = prefix + 4 * (size_t)(i / seg - 1);
+    double local[4] = {q[4 * (size_t)i], q[4 * (size_t)i + 1], q[4 * (size_t)i + 2], q[4 * (size_t)i + 3]};
+    double acc[4] = {p[0], p[1], p[2], p[3]};
+    rs::quat_mul_norm(local, acc); // acc <- normalise(local * acc)
+    for (int c = 0; c < 4; ++c) q[4 * (size_t)i + c] = acc[c];
 }
 
 struct GyroResampleParams {

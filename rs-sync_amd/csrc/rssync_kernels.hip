@@ -602,7 +602,7 @@ int rship_gyro_rates_integrate(rship_ctx* c, const int32_t axis[3], const double
     for (int k = 0; k < 3; ++k)
         if (axis[k] < 0 || axis[k] > 2) return set_err(c, "gyro: axis out of range");
     if (ensure(c, c->g_us, (size_t)n * 8) || ensure(c, c->g_dq, (size_t)n * 32) || ensure(c, c->g_q, (size_t)n * 32) ||
-        ensure(c, c->g_status, sizeof(GyroStatus)))
+        ensure(c, c->g_status, sizeof(GyroStatus)) || ensure(c, c->g_cf, (size_t)(n / kScanSegment + 2) * 64))
         return 1;
     GyroRatesParams p{};
     p.ts = (const double*)c->g_ts.p; p.rates = (const double*)c->g_rates.p;
@@ -612,7 +612,20 @@ int rship_gyro_rates_integrate(rship_ctx* c, const int32_t axis[3], const double
         ProfScope ps(c, RSHIP_K_GYRO);
         hipLaunchKernelGGL(gyro_status_reset_kernel, dim3(1), dim3(1), 0, c->stream, p.st);
         hipLaunchKernelGGL(gyro_rates_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, p);
-        hipLaunchKernelGGL(gyro_scan_kernel, dim3(1), dim3(kScanThreads), 0, c->stream, (const double*)c->g_dq.p, (double*)c->g_q.p, n);
+        const uint32_t n_seg = (n + kScanSegment - 1) / kScanSegment;
+        if (n_seg == 1) {
+            hipLaunchKernelGGL(gyro_scan_kernel, dim3(1), dim3(kScanThreads), 0, c->stream, (const double*)c->g_dq.p, (double*)c->g_q.p, n,
+                               kScanSegment, (double*)nullptr);
+        } else {
+            // segment totals -> their running products (the same kernel, one workgroup) -> every later segment times its prefix
+            double* tot = (double*)c->g_cf.p; // scratch of the spline solve, not yet in use: [n_seg][4] twice
+            double* pre = tot + 4 * (size_t)n_seg;
+            hipLaunchKernelGGL(gyro_scan_kernel, dim3(n_seg), dim3(kScanThreads), 0, c->stream, (const double*)c->g_dq.p, (double*)c->g_q.p, n,
+                               kScanSegment, tot);
+            hipLaunchKernelGGL(gyro_scan_kernel, dim3(1), dim3(kScanThreads), 0, c->stream, (const double*)tot, pre, n_seg, n_seg, (double*)nullptr);
+            hipLaunchKernelGGL(gyro_scan_fixup_kernel, dim3((n - kScanSegment + 255) / 256), dim3(256), 0, c->stream, (double*)c->g_q.p, n,
+                               kScanSegment, (const double*)pre);
+        }
     }
     RS_HIP(hipGetLastError());
     return resample_and_solve(c, (const int64_t*)c->g_us.p, (const double*)c->g_q.p, n, c->g_first_us, c->g_last_us, out);
