@@ -112,8 +112,18 @@ __device__ __forceinline__ void window_sums(const SyncLoopParams& p, uint32_t w,
     }
     __syncthreads();
     for (uint32_t r = threadIdx.x; r < p.rows; r += blockDim.x) {
+        // the chunk sums in order; sixteen loads in flight (one at a time, a 64-chunk window waited 64 L2 round trips)
+        const double* t = tmp + (size_t)r * p.chunk_stride;
         double acc = 0.0;
-        for (uint32_t c = 0; c < nc; ++c) acc += tmp[(size_t)r * p.chunk_stride + c];
+        uint32_t c = 0;
+        for (; c + 16 <= nc; c += 16) {
+            double v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = t[c + q];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc += v[q];
+        }
+        for (; c < nc; ++c) acc += t[c];
         s_tot[r] = acc;
     }
     __syncthreads();
