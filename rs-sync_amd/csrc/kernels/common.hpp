@@ -44,14 +44,6 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_d(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
 // row_shr:N with bound_ctrl: every lane is written (0 where the source lane is outside the row), so no register
 // has to be cleared first -- half the instructions of the old-value form for a 64-bit operand
 template <int CTRL>

@@ -1,8 +1,7 @@
 // rssync_kernels.hip -- gfx950 (CDNA4) kernels for the rs-sync PreSync/Sync hot
 // path and the thin C-ABI the host solver calls (include/rssync_hip.h).
 //
-// Kernels (all wave64, 256-thread workgroups, no MFMA: the path has no dense
-// contraction):
+// Kernels (all wave64, no MFMA: the path has no dense contraction):
 //   lmeds_kernel       one workgroup per (frame, chunk of candidate delays): residual
 //                      matrix P into an LDS tile, LMedS hypothesis search with an exact
 //                      lower-quartile selection, robust PreSync cost.  The same kernel
@@ -14,6 +13,10 @@
 //   pack_frames_kernel raw track records -> packed fp32 + fp64 streams.
 //   plan_sum_kernel    sums over the frames of each window in an association that does not
 //                      depend on the number of devices sharing the frames.
+//   sync_*_kernel      Sync's outer loop kept on the device: window sums + the scalar decisions
+//                      between the launches (kernels/syncloop.hpp).
+//   gyro_*, spline_*   the gyro side: integration scan, microsecond-grid resampling, spline
+//                      table (kernels/gyro.hpp).
 // Data layout and the roofline that bounds each kernel: DESIGN.md.
 // The kernels live in kernels/*.hpp (one header each, included below); this file holds the
 // device context and the launchers.
