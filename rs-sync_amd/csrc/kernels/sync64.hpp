@@ -295,16 +295,20 @@ constexpr int kNB = 10; // numBasis (ens::L_BFGS default)
 template <int RPT, int NW>
 struct MotionEval64 {
     d3 P[RPT];
-    double (*part)[NW][5]; // [2][NW][5] LDS, double-buffered
+    double (*part)[NW][4]; // [2][NW][4] LDS, double-buffered
     int buf;
     double k2;
     int evals;
 
-    // loss and dL/dM at x (core_private.cpp:99-114 in closed form)
+    // loss and dL/dM at x (core_private.cpp:99-114 in closed form).  With u_j = (P_j.x)^2 / s, s = |x|^2 / k^2:
+    //   dL/dx = t - (sum_j w_j u_j / s) 2x / k^2,   t = sum_j w_j (2 P_j.x / s) P_j,   w_j = 1 / (1 + u_j),
+    // and x.t = 2 sum_j w_j u_j, so the second term is x (x.t) / |x|^2: the loss does not depend on |x|, its
+    // gradient is t without its component along x -- four sums over the rows instead of five.
     __device__ __forceinline__ double operator()(const double x[3], double g[3]) {
-        const double s = (x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) / k2;
+        const double xx = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+        const double s = xx / k2;
         const double inv_s = 1.0 / s;
-        double L = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0, gs = 0.0;
+        double L = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const double px = P[j].x, py = P[j].y, pz = P[j].z;
@@ -317,20 +321,18 @@ struct MotionEval64 {
             a0 = fma(a, px, a0);
             a1 = fma(a, py, a1);
             a2 = fma(a, pz, a2);
-            gs = fma(w * v2, inv_s * inv_s, gs);
         }
-        double r0 = wave_sum_f64(L), r1 = wave_sum_f64(a0), r2 = wave_sum_f64(a1), r3 = wave_sum_f64(a2),
-               r4 = wave_sum_f64(gs);
-        double t[5] = {r0, r1, r2, r3, r4};
+        double r0 = wave_sum_f64(L), r1 = wave_sum_f64(a0), r2 = wave_sum_f64(a1), r3 = wave_sum_f64(a2);
+        double t[4] = {r0, r1, r2, r3};
         if (NW > 1) { // the waves' sums through LDS; a one-wave frame has them already
             const int wave = threadIdx.x >> 6;
             if ((threadIdx.x & 63) == 0) {
                 part[buf][wave][0] = r0; part[buf][wave][1] = r1; part[buf][wave][2] = r2;
-                part[buf][wave][3] = r3; part[buf][wave][4] = r4;
+                part[buf][wave][3] = r3;
             }
             __syncthreads();
 #pragma unroll
-            for (int q = 0; q < 5; ++q) {
+            for (int q = 0; q < 4; ++q) {
                 double acc = part[buf][0][q];
 #pragma unroll
                 for (int w = 1; w < NW; ++w) acc += part[buf][w][q];
@@ -339,7 +341,7 @@ struct MotionEval64 {
             buf ^= 1;
         }
         ++evals;
-        const double tt = t[4] * 2.0 / k2;
+        const double tt = (x[0] * t[1] + x[1] * t[2] + x[2] * t[3]) / xx;
         g[0] = t[1] - tt * x[0];
         g[1] = t[2] - tt * x[1];
         g[2] = t[3] - tt * x[2];
@@ -355,7 +357,7 @@ template <int RPT, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? (RPT <= 8 ? 3 : (RPT == 16 ? 2 : 1)) : (NW == 1 ? (RPT >= 8 ? 3 : 4) : 2)) void opt_motion64_kernel(Motion64Params p) {
     constexpr int kThreads = 64 * NW;
     __shared__ d4 s_win[4 * kWinMax];
-    __shared__ double s_part[2][NW][5];
+    __shared__ double s_part[2][NW][4];
     __shared__ double s_S[kNB][3], s_Y[kNB][3];
     // two-loop scratch: every thread writes the same values and reads them back itself;
     // the barrier inside each evaluation separates one iteration's use from the next

@@ -518,9 +518,10 @@ void motion_pass(rship_ctx* c, const int32_t* kdv, const double* fdv, int max_it
         int evals = 0;
         auto ev = [&](const double x[3], double g[3]) {
             ++evals;
-            const double s = (x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) / k2;
+            const double xx = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+            const double s = xx / k2;
             const double inv_s = 1.0 / s;
-            double L = 0, a0 = 0, a1 = 0, a2 = 0, gs = 0;
+            double L = 0, a0 = 0, a1 = 0, a2 = 0;
             for (const d3& p : P) {
                 const double px = p.x, py = p.y, pz = p.z;
                 const double pm = px * x[0] + py * x[1] + pz * x[2], v2 = pm * pm, u = v2 * inv_s;
@@ -528,9 +529,8 @@ void motion_pass(rship_ctx* c, const int32_t* kdv, const double* fdv, int max_it
                 L += rs::log1p_rcp_f64(u, &w);
                 const double a = w * 2.0 * pm * inv_s;
                 a0 += a * px; a1 += a * py; a2 += a * pz;
-                gs += w * v2 * inv_s * inv_s;
             }
-            const double tt = gs * 2.0 / k2;
+            const double tt = (x[0] * a0 + x[1] * a1 + x[2] * a2) / xx; // the gradient is t without its part along x
             g[0] = a0 - tt * x[0]; g[1] = a1 - tt * x[1]; g[2] = a2 - tt * x[2];
             return L;
         };
