@@ -15,6 +15,8 @@ from oracle.oracle import OracleProblem
 pytestmark = pytest.mark.gpu
 
 RATES = [200.0, 400.0, 500.0, 800.0, 1000.0, 1600.0]
+# RSSYNC_FUZZ_CASES=200 widens the seed ranges for a one-off soak; the committed default keeps the suite short
+EXTRA = int(os.environ.get("RSSYNC_FUZZ_CASES", "0"))
 
 
 def draw_case(seed, clean):
@@ -45,7 +47,7 @@ def build(seed, g, frames, **kw):
     return h, o
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(10 + EXTRA))
 def test_random_noisy_case(seed):
     rng, g, frames, counts = draw_case(seed, clean=False)
     h, o = build(seed, g, frames)
@@ -67,16 +69,22 @@ def test_random_noisy_case(seed):
     dh, ch, fch, bhh = h.presync_curve(centre, lo, hi, step, radius, per_frame=nf)
     do, co, fco, bho = o.presync_curve(centre, lo, hi, step, radius, per_frame=nf)
     np.testing.assert_array_equal(dh, do)
+    # With a handful of rows the lower quartile sits at the two rows that define the hypothesis, whose residuals
+    # are rounding noise (1e-16 in fp64, 1e-8 in fp32): which hypothesis wins there is not comparable, and a
+    # frame's cost follows the winner.  The comparison is therefore made on the frames with >= 48 tracks, and
+    # the curve / arg-min checks on their share of the sum (the cost is a plain sum over frames).
     big = np.array([n >= 48 for n in counts])
+    res_h, res_o = h.PreSync(centre, lo, hi, step, radius), o.PreSync(centre, lo, hi, step, radius)
+    assert res_h[0] == pytest.approx(float(ch.min()), rel=1e-12) and res_h[1] == dh[int(np.argmin(ch))]
     if big.any():
         same = (bhh == bho)[:, big]
         assert same.mean() > 0.9
         np.testing.assert_allclose(fch[:, big][same], fco[:, big][same], rtol=3e-3)
-    np.testing.assert_allclose(ch, co, rtol=0.05)
-    res_h, res_o = h.PreSync(centre, lo, hi, step, radius), o.PreSync(centre, lo, hi, step, radius)
-    margin = np.sort(co)[1] - np.sort(co)[0] if len(co) > 1 else 1.0
-    if margin > 0.02 * co.min():      # a clear minimum: the same candidate wins
-        assert res_h[1] == res_o[1]
+        cbh, cbo = fch[:, big].sum(axis=1), fco[:, big].sum(axis=1)
+        np.testing.assert_allclose(cbh, cbo, rtol=0.03)
+        srt = np.sort(cbo)
+        if len(srt) > 1 and srt[1] - srt[0] > 0.08 * srt[0]:   # a clear minimum: the same candidate wins
+            assert int(np.argmin(cbh)) == int(np.argmin(cbo))
     # fp64 loss and gradient at the GPU's own motion estimates
     d0 = res_h[1]
     Mh, kh = h.init_motion(d0, lo, hi - 1)
@@ -91,7 +99,7 @@ def test_random_noisy_case(seed):
         assert Gh[0] == pytest.approx(G, rel=1e-9, abs=1e-9 * abs(L))
 
 
-@pytest.mark.parametrize("seed", range(100, 106))
+@pytest.mark.parametrize("seed", range(100, 106 + EXTRA))
 def test_random_clean_case_sync(seed):
     """without noise the minimum is sharp and Sync is not chaotic: both sides end at the true delay"""
     rng, g, frames, counts = draw_case(seed, clean=True)
