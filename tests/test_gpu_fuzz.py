@@ -115,3 +115,29 @@ def test_random_clean_case_sync(seed):
     assert abs(dh - do) < 2e-6, (dh, do)
     assert abs(dh - synth.D_TRUE) < 3e-4, (dh, do)
     assert ch == pytest.approx(co, rel=1e-3, abs=1e-9)
+
+
+@pytest.mark.parametrize("seed", range(200, 203 + EXTRA // 5))
+def test_random_batched_windows_device_loop_equals_host_loop(seed):
+    """random sets of overlapping windows through the device-driven loop (groups of windows on concurrent streams)
+    and through the host loop: the same bits"""
+    rng = np.random.default_rng(seed)
+    F = int(rng.integers(150, 500))
+    N = int(rng.choice([20, 64, 130, 200, 300]))
+    window = int(rng.integers(8, 40))
+    dist = int(rng.integers(3, 15))
+    repeats = int(rng.integers(1, 4))
+    max_outer = int(rng.integers(5, 40))
+    g = synth.make_gyro(0, (F + 2) / synth.FPS, seed=seed)
+    pos = list(range(0, F - window - 1, dist))
+    out = []
+    for host in (False, True):
+        p = rssync_amd.SyncProblem(seed=seed, verbose=False, max_outer_iters=max_outer)
+        synth.fill(p, g, 0, F, N, seed=seed)
+        p.set_host_loop(host)
+        c, d = p.sync_points(pos, window, 0.0, 0.002, 0.06, repeats=repeats)
+        out.append((np.array(c), np.array(d), [np.array(p.window_trace(w)) for w in range(len(pos))]))
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][2], out[1][2]):
+        np.testing.assert_array_equal(a, b)
