@@ -4,10 +4,10 @@
 // One outer iteration is: per-frame motion optimisation at d; loss + gradient at x0 = d - 0.3 v; up to
 // ten line-search losses; a handful of scalar decisions per window.  With the decisions on the host
 // every iteration costs two or three stream synchronisations (~25 us each, more than the kernels of a
-// 60-frame window).  Here the decisions are three small kernels between the launches (one workgroup per
+// 60-frame window).  Here the decisions are two small kernels between the launches (one workgroup per
 // window, which first adds that window's per-slot sums in the plan's association, then lets thread 0
 // run the scalar logic), and the host only looks at a counter of still-active windows every few
-// iterations.  The arithmetic of the decisions is the host loop's (sync_problem.cpp: sync_windows),
+// iterations.  An iteration is five launches: motion, loss + gradient, decisions, trials, decisions.  The arithmetic of the decisions is the host loop's (sync_problem.cpp: sync_windows),
 // operation for operation, with contraction off: both paths return the same bits.
 #pragma once
 
@@ -20,6 +20,8 @@ struct SyncWin { // per window
     double x0;       // d - 0.3 v of this iteration
     double l1, g1;   // loss and d loss / d delay at x0
     int active, conv, hit, iters;
+    int phase; // 1: the first nf trials of this iteration found nothing, the rest are evaluated in the next launch
+    int nf;    // trials evaluated first (sync_step_kernel)
 };
 
 struct SyncLoopParams {
@@ -41,7 +43,7 @@ struct SyncLoopParams {
     double ts[11];         // line-search step sizes t0 * decay^i (backtrack.cpp:7-12), computed by the host
     double c_armijo, delay_b, search_center, search_radius;
     int it, max_outer;
-    int* prev_hit;         // [2]: largest successful trial index of the previous iteration (double-buffered)
+    int nf_fixed;          // 0: adaptive (below); k: always the first k trials first (tests: makes windows wait)
     int* n_active;         // [max_outer]: windows still active after iteration i
     double* trace;         // [max_outer][W][6]: row k of window w is its k-th outer iteration
 };
@@ -138,17 +140,20 @@ __global__ __launch_bounds__(64) void sync_begin_kernel(SyncLoopParams p) {
     s.x0 = s.active ? s.d - p.delay_b * s.v : __builtin_nan("");
     split64_dev(s.active ? s.d : __builtin_nan(""), p.fs, &p.mo_kd[w], &p.mo_fd[w]);
     split64_dev(s.x0, p.fs, &p.lg_kd[w], &p.lg_fd[w]);
-    if (w == p.win0) { p.prev_hit[0] = kHalfBt - 1; p.prev_hit[1] = kHalfBt - 1; }
 }
 
-// which trials the first batch holds: as many as the previous iteration needed, at least five
-__device__ __forceinline__ int first_batch(const SyncLoopParams& p) {
-    const int ph = p.prev_hit[p.it & 1];
-    const int n = ph + 1 < kHalfBt ? kHalfBt : ph + 1;
-    return n > kMaxBt ? kMaxBt : n;
+// Which trials a launch evaluates for a window.  The ten trials of a line search (backtrack.cpp:7-11) are
+// evaluated in ONE launch per outer iteration: the first nf of them, nf = two more than the index the window's
+// previous search stopped at, at least five (the step scale barely changes between iterations).  A window whose
+// search finds nothing among them waits one iteration (phase 1: no motion, no gradient launch for it) in which
+// the launch evaluates the remaining trials; then it steps.  The first trial that satisfies the Armijo test is
+// taken in trial order either way -- what the sequential loop returns.
+__device__ __forceinline__ bool trial_wanted(const SyncWin& s, int i) {
+    if (!s.active) return false;
+    return s.phase == 0 ? i < s.nf : i >= s.nf;
 }
 
-// stage G: after loss + gradient (rows: loss, gradient) -- first batch of line-search trials
+// stage G: after loss + gradient (rows: loss, gradient) -- the delays of the trial launch
 __global__ __launch_bounds__(kBlock) void sync_grad_kernel(SyncLoopParams p) {
 #pragma clang fp contract(off)
     __shared__ double s_tot[2 * kMaxBt];
@@ -157,15 +162,13 @@ __global__ __launch_bounds__(kBlock) void sync_grad_kernel(SyncLoopParams p) {
     window_sums(p, w, s_tot, s_stage);
     if (threadIdx.x != 0) return;
     SyncWin& s = p.win[w];
-    p.prev_hit[(p.it + 1) & 1] = kHalfBt - 1; // every window writes the same reset value for the next iteration
-    const int nf = first_batch(p);
-    if (s.active) {
+    if (s.active && s.phase == 0) { // (a waiting window keeps the loss and gradient of the iteration it waits in)
         s.l1 = s_tot[0];
         s.g1 = s_tot[1];
         s.hit = -1;
     }
     for (int i = 0; i < kMaxBt; ++i) {
-        const double td = (s.active && i < nf) ? s.x0 - p.ts[i] * s.g1 : __builtin_nan("");
+        const double td = trial_wanted(s, i) ? s.x0 - p.ts[i] * s.g1 : __builtin_nan("");
         split64_dev(td, p.fs, &p.tr_kd[(size_t)i * p.n_win + w], &p.tr_fd[(size_t)i * p.n_win + w]);
     }
 }
@@ -183,26 +186,9 @@ __device__ __forceinline__ void armijo(const SyncLoopParams& p, SyncWin& s, cons
     }
 }
 
-// stage T1: after the first batch of trials (rows: the ten trials) -- Armijo on it, then the second batch for
-// the windows that found none
-__global__ __launch_bounds__(kBlock) void sync_trial1_kernel(SyncLoopParams p) {
-#pragma clang fp contract(off)
-    __shared__ double s_tot[2 * kMaxBt];
-    __shared__ double s_stage[kStageDoubles];
-    const uint32_t w = blockIdx.x + p.win0;
-    window_sums(p, w, s_tot, s_stage);
-    if (threadIdx.x != 0) return;
-    SyncWin& s = p.win[w];
-    const int nf = first_batch(p);
-    armijo(p, s, s_tot, 0, nf);
-    for (int i = 0; i < kMaxBt; ++i) {
-        const double td = (s.active && s.hit < 0 && i >= nf) ? s.x0 - p.ts[i] * s.g1 : __builtin_nan("");
-        split64_dev(td, p.fs, &p.tr_kd[(size_t)i * p.n_win + w], &p.tr_fd[(size_t)i * p.n_win + w]);
-    }
-}
-
-// stage T2: after the second batch -- Armijo on it, the step (core_private.cpp:298-305), the stopping rules
-// (:316-328), the trace row, and the delays of the next iteration's launches
+// stage S: after the trials -- Armijo on them; the step (core_private.cpp:298-305), the stopping rules
+// (:316-328) and the trace row, or one more iteration for the rest of the trials; the delays of the next
+// iteration's launches
 __global__ __launch_bounds__(kBlock) void sync_step_kernel(SyncLoopParams p) {
 #pragma clang fp contract(off)
     __shared__ double s_tot[2 * kMaxBt];
@@ -211,9 +197,18 @@ __global__ __launch_bounds__(kBlock) void sync_step_kernel(SyncLoopParams p) {
     window_sums(p, w, s_tot, s_stage);
     if (threadIdx.x != 0) return;
     SyncWin& s = p.win[w];
-    const int nf = first_batch(p);
-    armijo(p, s, s_tot, nf, kMaxBt);
+    bool step_now = false;
     if (s.active) {
+        if (s.phase == 0) {
+            armijo(p, s, s_tot, 0, s.nf);
+            if (s.hit >= 0 || s.nf >= kMaxBt) step_now = true;
+            else s.phase = 1; // nothing among the first nf: the others are evaluated in the next iteration
+        } else {
+            armijo(p, s, s_tot, s.nf, kMaxBt);
+            step_now = true;
+        }
+    }
+    if (step_now) {
         const double v = s.l1, g = s.g1;
         // never satisfied: t0 * decay^max_bt, untested (backtrack.cpp:11-12)
         const double t = s.hit >= 0 ? p.ts[s.hit] : p.ts[kMaxBt];
@@ -222,19 +217,22 @@ __global__ __launch_bounds__(kBlock) void sync_step_kernel(SyncLoopParams p) {
         s.v = p.delay_b * s.v + step; // :301
         s.d += s.v;                   // :302
         const double step_size = fabs(step);
-        double* row = p.trace + ((size_t)s.iters * p.n_win + w) * 6; // [iteration][window][6]
+        double* row = p.trace + ((size_t)s.iters * p.n_win + w) * 6; // [iteration of the window][window][6]
         row[0] = s.d; row[1] = step; row[2] = v; row[3] = g; row[4] = t; row[5] = (double)trials;
         s.iters += 1;
+        s.phase = 0;
+        const int want = (s.hit >= 0 ? s.hit : kMaxBt - 1) + 2;
+        s.nf = p.nf_fixed ? p.nf_fixed : (want < kHalfBt ? kHalfBt : (want > kMaxBt ? kMaxBt : want));
         if (step_size < 1e-4) s.conv++; else s.conv = 0;                            // :316-320
         bool stop = s.conv > 5;                                                     // :322-324
         if (!stop && fabs(s.d - p.search_center) > p.search_radius) stop = true;    // :326-328
-        atomicMax(&p.prev_hit[(p.it + 1) & 1], s.hit >= 0 ? s.hit : kMaxBt - 1);
-        if (stop || p.it + 1 == p.max_outer) s.active = 0;
-        else atomicAdd(&p.n_active[p.it], 1);
+        if (stop || s.iters == p.max_outer) s.active = 0;                           // :309
     }
+    if (s.active) atomicAdd(&p.n_active[p.it], 1);
+    const bool go = s.active && s.phase == 0; // a waiting window has no motion and no gradient launch
     s.x0 = s.active ? s.d - p.delay_b * s.v : __builtin_nan("");
-    split64_dev(s.active ? s.d : __builtin_nan(""), p.fs, &p.mo_kd[w], &p.mo_fd[w]);
-    split64_dev(s.x0, p.fs, &p.lg_kd[w], &p.lg_fd[w]);
+    split64_dev(go ? s.d : __builtin_nan(""), p.fs, &p.mo_kd[w], &p.mo_fd[w]);
+    split64_dev(go ? s.x0 : __builtin_nan(""), p.fs, &p.lg_kd[w], &p.lg_fd[w]);
 }
 
 } // namespace

@@ -1115,7 +1115,7 @@ int rship_loss_collect(rship_ctx* c, uint32_t n_delays, double* win_loss, double
 // for the simplified mode); on return d_out[W], iters[W] and trace[W][max_outer][6] (rows as
 // rssync_ext_sync_trace).  The plan must be one window per group over the slots in order.
 // How many groups of windows run their loops side by side (each on its own stream).  An iteration is a chain of
-// seven short launches, each as long as its slowest frame; with all windows in one chain the device idles most
+// five short launches, each as long as its slowest frame; with all windows in one chain the device idles most
 // of that time.  Windows do not see each other, so contiguous groups of them can run as independent chains.
 static uint32_t loop_groups(const rship_ctx* c, uint32_t n_win) {
     uint32_t g = 4; // HIP's default number of hardware queues
@@ -1135,14 +1135,17 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     if (max_outer <= 0) return set_err(c, "sync_run: no iterations");
     if (c->h_grp_off.size() != (size_t)W + 1) return set_err(c, "sync_run: no selection");
     const uint32_t G = loop_groups(c, W);
+    int nf_fixed = 0; // test knob: always evaluate exactly this many trials first
+    if (const char* e = std::getenv("RSSYNC_LOOP_FIRST_TRIALS")) { const int v = atoi(e); if (v >= 1 && v <= kMaxBt) nf_fixed = v; }
+    const int max_launch = 2 * max_outer; // a window whose line search needs its later trials waits one iteration for them
     // one allocation: windows | motion delays | loss delays | trial delays | per-group counters | trace | chunk scratch
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t o_win = take(W * sizeof(SyncWin));
     const size_t o_mokd = take(W * 4), o_mofd = take(W * 8), o_lgkd = take(W * 4), o_lgfd = take(W * 8);
     const size_t o_trkd = take((size_t)kMaxBt * W * 4), o_trfd = take((size_t)kMaxBt * W * 8);
-    const size_t nact_stride = ((size_t)max_outer * 4 + 255) / 256 * 256;
-    const size_t o_prev = take((size_t)G * 256), o_nact = take((size_t)G * nact_stride);
+    const size_t nact_stride = ((size_t)max_launch * 4 + 255) / 256 * 256;
+    const size_t o_nact = take((size_t)G * nact_stride);
     const size_t o_trace = take((size_t)W * max_outer * 48);
     const size_t o_tmp = take((size_t)W * 2 * kMaxBt * (c->plan_max_chunks + 1) * 8);
     if (ensure(c, c->loop_state, off)) return 1;
@@ -1161,6 +1164,7 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
         hw[w].d = d0[w];
         hw[w].active = 1;
         hw[w].hit = -1;
+        hw[w].nf = nf_fixed ? nf_fixed : kHalfBt;
     }
     RS_HIP(hipMemcpyAsync(base + o_win, hw.data(), W * sizeof(SyncWin), hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipMemsetAsync(base + o_nact, 0, (size_t)G * nact_stride, c->stream));
@@ -1187,6 +1191,7 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     lp.search_center = search_center;
     lp.search_radius = search_radius;
     lp.max_outer = max_outer;
+    lp.nf_fixed = nf_fixed;
     lp.trace = (double*)(base + o_trace);
 
     Motion64Params mp{};
@@ -1212,7 +1217,6 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     struct Group {
         uint32_t w0, w1, s0, s1;
         hipStream_t st;
-        int* prev_hit;
         int* n_active;
         int* h_nact; // pinned
         int it = 0;
@@ -1232,7 +1236,6 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
             gr.s0 = c->h_grp_off[gr.w0];
             gr.s1 = c->h_grp_off[gr.w1];
             gr.st = G == 1 ? c->stream : c->loop_streams[g];
-            gr.prev_hit = (int*)(base + o_prev + (size_t)g * 256);
             gr.n_active = (int*)(base + o_nact + (size_t)g * nact_stride);
             gr.h_nact = (int*)((char*)c->pinned + (size_t)g * nact_stride);
             gr.done = gr.w1 == gr.w0 || gr.s1 == gr.s0;
@@ -1245,7 +1248,6 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     auto enqueue_iteration = [&](Group& gr) -> int {
         SyncLoopParams l = lp;
         l.win0 = gr.w0; l.win1 = gr.w1;
-        l.prev_hit = gr.prev_hit;
         l.n_active = gr.n_active;
         l.it = gr.it;
         const uint32_t nw = gr.w1 - gr.w0, cnt = gr.s1 - gr.s0;
@@ -1274,15 +1276,10 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
             ProfScope ps(c, RSHIP_K_REDUCE);
             hipLaunchKernelGGL(sync_grad_kernel, dim3(nw), ctl_block, 0, gr.st, l);
         }
-        // the trials, in two batches (first: as many as the previous iteration needed)
+        // the trials each window asked for, one launch (kernels/syncloop.hpp: trial_wanted)
         q.kd = l.tr_kd; q.fd = l.tr_fd; q.n_delays = kMaxBt;
         q.part_grad = nullptr;
         l.rows = kMaxBt;
-        if (loss_launch(false)) return 1;
-        {
-            ProfScope ps(c, RSHIP_K_REDUCE);
-            hipLaunchKernelGGL(sync_trial1_kernel, dim3(nw), ctl_block, 0, gr.st, l);
-        }
         if (loss_launch(false)) return 1;
         {
             ProfScope ps(c, RSHIP_K_REDUCE);
@@ -1294,17 +1291,18 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     };
 
     const int kLook = 8; // iterations enqueued between two looks at a group's counter of active windows
-    // one host thread per group: a chain is ~7 launches per iteration and the launches of four chains from one
+    // one host thread per group: a chain is five launches per iteration and the launches of four chains from one
     // thread would make the host the slowest part
     auto run_group = [&](Group& gr) -> int {
         DeviceGuard guard(c); // the current device is a per-thread setting
         while (!gr.done) {
-            const int until = std::min(max_outer, gr.it + kLook);
+            // (after the first block the windows still active are the stragglers: shorter blocks waste fewer empty launches)
+            const int until = std::min(max_launch, gr.it + (gr.it == 0 ? kLook : kLook / 2));
             while (gr.it < until)
                 if (enqueue_iteration(gr)) return 1;
             RS_HIP(hipMemcpyAsync(gr.h_nact, gr.n_active, (size_t)gr.it * 4, hipMemcpyDeviceToHost, gr.st));
             RS_HIP(hipStreamSynchronize(gr.st));
-            gr.done = gr.h_nact[gr.it - 1] == 0 || gr.it >= max_outer;
+            gr.done = gr.h_nact[gr.it - 1] == 0 || gr.it >= max_launch;
         }
         return 0;
     };
@@ -1319,6 +1317,7 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     }
     int it_max = 0;
     for (const Group& gr : groups) it_max = std::max(it_max, gr.it);
+    it_max = std::min(it_max, max_outer); // rows of the trace are indexed by a window's own iteration count
     c->init_pending = false;
     if (G == 1) prof_collect(c);
     // the windows and the rows of the iterations that ran ([iteration][window][6] on the device), through pinned memory

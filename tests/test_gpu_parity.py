@@ -730,23 +730,29 @@ def test_window_groups_on_concurrent_streams_equal_the_host_loop():
     old = os.environ.get("RSSYNC_LOOP_STREAMS")
     runs = {}
     try:
-        for streams in ("host", "1", "3", "4"):
+        for streams in ("host", "1", "3", "4", "4/first=1", "2/first=3"):
             p = rssync_amd.SyncProblem(seed=SEED, verbose=False, max_outer_iters=60)
             synth.fill(p, g, 0, F, N, seed=41)
+            os.environ.pop("RSSYNC_LOOP_FIRST_TRIALS", None)
             if streams == "host":
                 p.set_host_loop(True)
             else:
-                os.environ["RSSYNC_LOOP_STREAMS"] = streams
+                # "first=k": only k trials of a line search in the first launch, so that the windows wait an
+                # iteration for the others (the searches of this scene stop at the fourth or fifth trial)
+                if "/first=" in streams:
+                    os.environ["RSSYNC_LOOP_FIRST_TRIALS"] = streams.split("=")[1]
+                os.environ["RSSYNC_LOOP_STREAMS"] = streams.split("/")[0]
             c, d = p.sync_points(pos, WINDOW, 0.0, 0.002, 0.1, repeats=2)
             runs[streams] = (np.array(c), np.array(d), [np.array(p.window_trace(w)) for w in range(len(pos))])
     finally:
+        os.environ.pop("RSSYNC_LOOP_FIRST_TRIALS", None)
         if old is None:
             os.environ.pop("RSSYNC_LOOP_STREAMS", None)
         else:
             os.environ["RSSYNC_LOOP_STREAMS"] = old
     ref = runs["host"]
     assert len({len(t) for t in ref[2]}) > 1   # windows stop at different iterations
-    for streams in ("1", "3", "4"):
+    for streams in ("1", "3", "4", "4/first=1", "2/first=3"):
         c, d, tr = runs[streams]
         np.testing.assert_array_equal(d, ref[1])
         np.testing.assert_array_equal(c, ref[0])
