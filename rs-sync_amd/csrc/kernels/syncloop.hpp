@@ -22,6 +22,7 @@ struct SyncWin { // per window
     int active, conv, hit, iters;
     int phase; // 1: the first nf trials of this iteration found nothing, the rest are evaluated in the next launch
     int nf;    // trials evaluated first (sync_step_kernel)
+    int hit_prev; // index the previous search stopped at
 };
 
 struct SyncLoopParams {
@@ -143,8 +144,8 @@ __global__ __launch_bounds__(64) void sync_begin_kernel(SyncLoopParams p) {
 }
 
 // Which trials a launch evaluates for a window.  The ten trials of a line search (backtrack.cpp:7-11) are
-// evaluated in ONE launch per outer iteration: the first nf of them, nf = two more than the index the window's
-// previous search stopped at, at least five (the step scale barely changes between iterations).  A window whose
+// evaluated in ONE launch per outer iteration: the first nf of them, nf = one more than the larger index at which the window's
+// last two searches stopped, at least five (the step scale barely changes between iterations).  A window whose
 // search finds nothing among them waits one iteration (phase 1: no motion, no gradient launch for it) in which
 // the launch evaluates the remaining trials; then it steps.  The first trial that satisfies the Armijo test is
 // taken in trial order either way -- what the sequential loop returns.
@@ -221,7 +222,11 @@ __global__ __launch_bounds__(kBlock) void sync_step_kernel(SyncLoopParams p) {
         row[0] = s.d; row[1] = step; row[2] = v; row[3] = g; row[4] = t; row[5] = (double)trials;
         s.iters += 1;
         s.phase = 0;
-        const int want = (s.hit >= 0 ? s.hit : kMaxBt - 1) + 2;
+        // as many as the later of the last two searches needed (at bench size one trial is 0.06 ms of fp64 work:
+        // no blanket margin), at least five
+        const int last = s.hit >= 0 ? s.hit : kMaxBt - 1;
+        const int want = (last > s.hit_prev ? last : s.hit_prev) + 1;
+        s.hit_prev = last;
         s.nf = p.nf_fixed ? p.nf_fixed : (want < kHalfBt ? kHalfBt : (want > kMaxBt ? kMaxBt : want));
         if (step_size < 1e-4) s.conv++; else s.conv = 0;                            // :316-320
         bool stop = s.conv > 5;                                                     // :322-324
