@@ -167,6 +167,15 @@ __global__ __launch_bounds__(kBlock) void sync_grad_kernel(SyncLoopParams p) {
         s.l1 = s_tot[0];
         s.g1 = s_tot[1];
         s.hit = -1;
+        if (s.iters == 0 && !p.nf_fixed) {
+            // a call's first search has no history: steps of a millisecond and more have never been accepted, so the
+            // trials up to the first shorter one (and one more) go into the first launch.  Only the batching
+            // depends on this guess, never the result.
+            int i = 0;
+            while (i < kMaxBt - 1 && p.ts[i] * fabs(s.g1) >= 1e-3) ++i;
+            const int want = i + 2;
+            s.nf = want < kHalfBt ? kHalfBt : (want > kMaxBt ? kMaxBt : want);
+        }
     }
     for (int i = 0; i < kMaxBt; ++i) {
         const double td = trial_wanted(s, i) ? s.x0 - p.ts[i] * s.g1 : __builtin_nan("");
