@@ -158,3 +158,27 @@ def test_device_gyro_feeds_the_same_sync_as_host_integrated_quaternions():
     assert da == db and abs(ca - cb) <= 1e-5 * cb
     sa, sb = a.Sync(da, 30, 30 + F, 0.0, 0.1), b.Sync(db, 30, 30 + F, 0.0, 0.1)
     assert abs(sa[1] - sb[1]) < 1e-8
+
+
+def test_random_recordings_grid_exact_knots_close():
+    """the closed-form grid of the device route against the oracle's loop on random recordings (rates 47 Hz .. 3.2 kHz,
+    jittered sample times, random first timestamp): rate, first knot time and count exact, knots to the last bits"""
+    rng = np.random.default_rng(78)
+    for case in range(60):
+        n = int(rng.integers(2, 3000))
+        rate = float(rng.choice([47.0, 50.0, 99.0, 200.0, 399.7, 400.0, 1000.0, 1601.0, 3200.0]))
+        first = int(rng.integers(0, 3_000_000))
+        ts = first + np.cumsum(np.maximum(1, np.round(1e6 / rate * rng.uniform(0.6, 1.4, n)))).astype(np.int64)
+        q = rng.standard_normal((n, 4))
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        h, o = rssync_amd.SyncProblem(verbose=False), oracle.OracleProblem()
+        try:
+            o.SetGyroQuaternionsTimestamped(ts, q)
+        except oracle.OracleError:
+            with pytest.raises(rssync_amd.RsSyncError):
+                h.SetGyroQuaternionsTimestamped(ts, q)
+            continue
+        h.SetGyroQuaternionsTimestamped(ts, q)
+        assert h.gyro_info() == o.gyro_info(), (case, n, rate, first)
+        np.testing.assert_allclose(h.gyro_knots(), o.gyro_knots(), rtol=0, atol=2e-15)
+        np.testing.assert_array_equal(h.gyro_table(), thomas_table(h.gyro_knots()))

@@ -385,3 +385,41 @@ def test_simplified_mode_matches_the_oracle_and_recovers_the_delay_without_trans
             np.testing.assert_allclose(k, [p[0] for p in per], rtol=1e-12)
             assert L[j] == pytest.approx(sum(p[1] for p in per), rel=1e-12, abs=1e-12)
             assert G[j] == pytest.approx(sum(p[2] for p in per), rel=1e-6, abs=1e-6 * abs(L[j]))   # analytic vs +-1e-6 s
+
+
+def test_timestamped_grid_in_closed_form_equals_the_reference_loop(host):
+    """The timestamped gyro setter's grid (core_private.cpp:147-160) is a loop in the reference and in the oracle;
+    the product derives rate, first sample and count from the two end timestamps in closed form
+    (gyro_math.hpp: grid_of, shared by the device route and this CPU stand-in).  Random recordings: same rate,
+    same first knot time, same count, same knots; and the rates route (optdata_fill_gyro) on top of it."""
+    from oracle import oracle as ora
+    rng = np.random.default_rng(77)
+    for case in range(120):
+        n = int(rng.integers(2, 300))
+        rate = float(rng.choice([47.0, 50.0, 99.0, 200.0, 399.7, 400.0, 1000.0, 1601.0, 3200.0]))
+        first = int(rng.integers(0, 3_000_000))
+        dt = 1e6 / rate
+        ts = first + np.cumsum(np.maximum(1, np.round(dt * rng.uniform(0.6, 1.4, n)))).astype(np.int64)
+        q = rng.standard_normal((n, 4))
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        h, o = host(), ora.OracleProblem()
+        try:
+            o.SetGyroQuaternionsTimestamped(ts, q)
+        except ora.OracleError as e:          # e.g. fewer than two grid points: the same complaint on both sides
+            with pytest.raises(Exception, match=str(e).split(":")[-1].strip()[:24]):
+                h.SetGyroQuaternionsTimestamped(ts, q)
+            continue
+        h.SetGyroQuaternionsTimestamped(ts, q)
+        assert h.gyro_info() == o.gyro_info(), (case, n, rate, first)
+        np.testing.assert_array_equal(h.gyro_knots(), o.gyro_knots())
+    for case in range(20):
+        n = int(rng.integers(3, 400))
+        t = 0.5 + np.cumsum(rng.uniform(0.001, 0.004, n))
+        r = rng.standard_normal((n, 3))
+        name = ["XYZ", "yXz", "ZxY", None][case % 4]
+        q, us = ora.integrate_gyro(t, r, name)
+        h, o = host(), ora.OracleProblem()
+        h.set_gyro_rates(t, r, name)
+        o.SetGyroQuaternionsTimestamped(us, q)
+        assert h.gyro_info() == o.gyro_info()
+        np.testing.assert_allclose(h.gyro_knots(), o.gyro_knots(), rtol=0, atol=1e-15)
