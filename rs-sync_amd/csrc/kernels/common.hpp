@@ -101,7 +101,7 @@ constexpr int kPathInterior = 2; // staged in LDS and strictly inside the knots 
 // CAP = knots the LDS window holds (a compile-time constant: it is the stride between the four coefficient
 // kinds, folded into the ds_read offsets)
 template <int CAP = kWinMax>
-__device__ __forceinline__ void stage_window(Spline& s, f4* s_win, int lo, int hi) {
+__device__ __forceinline__ void stage_window(Spline& s, f4* s_win, int lo, int hi, int n_threads = kBlock) {
     const int n = s.n;
     const bool interior = lo >= 0 && hi <= n - 2;
     lo = lo < 0 ? 0 : (lo > n - 1 ? n - 1 : lo);
@@ -112,7 +112,7 @@ __device__ __forceinline__ void stage_window(Spline& s, f4* s_win, int lo, int h
     s.w0 = lo;
     s.wlen = wlen;
     s.lds = s_win;
-    for (int e = threadIdx.x; e < wlen * 4; e += kBlock) {
+    for (int e = threadIdx.x; e < wlen * 4; e += n_threads) {
         int knot = e >> 2, kind = e & 3;
         s_win[kind * CAP + knot] = s.g[(size_t)(lo + knot) * 4 + kind];
     }

@@ -1,0 +1,182 @@
+// lmeds_small.hpp -- K2 for frames of up to 256 tracks: ONE WAVE per (frame, chunk of candidate delays).
+// Part of the single HIP translation unit rssync_kernels.hip (included there, after lmeds.hpp).
+//
+// The reference's own data has ~130 tracks per frame.  The tile kernel (lmeds.hpp) spends a four-wave
+// workgroup on such a frame: half its lanes have no row, and per candidate it crosses five workgroup barriers
+// (tile written, hypotheses prepared by one wave while three wait, queue drained, two sums) for a few hundred
+// instructions of work -- at 130 tracks it ran at ~12 k cycles per candidate with five workgroups per CU.
+// Here a frame is one wave: its <= 4 rows per lane stay in registers for the whole candidate, the twenty
+// hypotheses are tried one after the other in hypothesis order (the reference's sequential loop,
+// core_private.cpp:41-56, with its strict "<": the first of equal medians wins), the best (quantile, index) lives
+// in scalar registers, and nothing waits for another wave.  Arithmetic per row and per hypothesis is the tile
+// kernel's, operation for operation (same P rows, same directions, same residual fma chain, same exact
+// selection); only the order in which a frame's cost terms are added differs (one wave sum instead of four).
+// Which of the two kernels a frame gets is fixed per PROBLEM (largest frame of all devices), like the motion
+// kernel's shape, so that a frame's cost does not depend on the selection it is part of.
+#pragma once
+
+namespace {
+
+constexpr int kSmallMaxRpt = 4; // 256 tracks
+
+template <int RPT, int MODE>
+__global__ __launch_bounds__(64, RPT <= 3 ? 6 : 5) void lmeds_small_kernel(LmedsParams p) {
+    constexpr int ROWS = 64 * RPT;
+    constexpr int kHyp = kHypBatch;
+    __shared__ float s_n[3][ROWS];   // unit rows, for the hypotheses' row pairs
+    __shared__ f4 s_win[4 * kWinMax];
+    __shared__ int s_kd[kMaxChunk];
+    __shared__ float s_fd[kMaxChunk];
+    const int lane = threadIdx.x;
+    const uint32_t sf = blockIdx.x / p.n_chunks, chunk = blockIdx.x % p.n_chunks;
+    if (sf >= p.n_sel) return;
+    const uint32_t fi = p.sel[sf];
+    const FrameRec fr = p.frames[fi];
+    const uint32_t N = fr.n;
+    const uint32_t kq = N / 4; // core_private.cpp:52
+    const uint32_t g = p.grp ? p.grp[sf] : 0u;
+    const Tile tile{s_n[0], s_n[1], s_n[2]};
+    const RayRsrc rays = make_ray_rsrc(p.rays_a + fr.off, p.rays_b + fr.off, N);
+
+    const uint32_t c0 = chunk * p.chunk;
+    const uint32_t c1 = (c0 + p.chunk < p.n_cand) ? c0 + p.chunk : p.n_cand;
+    if (c0 >= c1) return;
+    if ((uint32_t)lane < c1 - c0) {
+        s_kd[lane] = p.kd[(c0 + lane) * p.n_grp + g];
+        s_fd[lane] = p.fd[(c0 + lane) * p.n_grp + g];
+    }
+    Spline sp;
+    sp.g = p.coef;
+    sp.n = p.n_knots;
+    {
+        int kd_lo = p.kd[c0 * p.n_grp + g], kd_hi = kd_lo;
+        for (uint32_t c = c0 + 1; c < c1; ++c) {
+            const int v = p.kd[c * p.n_grp + g];
+            kd_lo = v < kd_lo ? v : kd_lo;
+            kd_hi = v > kd_hi ? v : kd_hi;
+        }
+        stage_window<kWinMax>(sp, s_win, fr.base_knot + (int)floorf(fr.tmin) + kd_lo, fr.base_knot + (int)floorf(fr.tmax) + kd_hi + 1, 64);
+    }
+    __syncthreads();
+
+    uint32_t prev_best = kInfBits;
+    const uint32_t voff = (uint32_t)lane * 16u;
+    for (uint32_t c = c0; c < c1; ++c) {
+        const int base = fr.base_knot + s_kd[c - c0];
+        const float fd = s_fd[c - c0];
+        const uint32_t stream = p.stream_base + c + g * p.stream_stride;
+        uint32_t bad = 0;
+        // ---- rows of P, as unit rows in registers (and in LDS for the row pairs); norms in registers ----
+        float nx[RPT], ny[RPT], nz[RPT], nrm[RPT];
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const uint32_t row = j * 64 + lane;
+            const f4 A = load_ray(rays.a, voff, (uint32_t)j * 64u * 16u), B = load_ray(rays.b, voff, (uint32_t)j * 64u * 16u);
+            const float nan = __uint_as_float(0x7fc00000u);
+            nx[j] = ny[j] = nz[j] = nan; // rows beyond N: their residuals compare above every threshold
+            nrm[j] = 0.f;
+            if (row < N) {
+                f3 P, dP;
+                if (sp.path == kPathInterior) residual_row<false, kPathInterior, MODE == 0, kWinMax>(sp, A, B, base, fd, P, dP);
+                else residual_row<false, kPathGlobal, false, kWinMax>(sp, A, B, base, fd, P, dP);
+                const float n2 = rs::dot(P, P);
+                if (!finite_f(n2)) bad = RSHIP_BAD_P;
+                const bool tiny = n2 < 1e-24f; // safe_normalize (core_private.cpp:35-36)
+                const float inv = tiny ? 1.f : rs::rsqrt_fast(n2);
+                nx[j] = P.x * inv; ny[j] = P.y * inv; nz[j] = P.z * inv;
+                nrm[j] = tiny ? 1.f : n2 * inv;
+            }
+            s_n[0][row] = nx[j]; s_n[1][row] = ny[j]; s_n[2][row] = nz[j];
+        }
+        __syncthreads(); // the wave's rows are in LDS
+
+        // ---- the hypotheses, in order.  The previous candidate's best quantile (x1.25) is a provisional bound
+        // as in the tile kernel; if nothing beats it the candidate is redone without it. ----
+        uint32_t guess = kInfBits;
+        if (prev_best < 0x7e000000u && prev_best > 0x00800000u) guess = uniform_u32(__float_as_uint(__uint_as_float(prev_best) * 1.25f));
+        uint32_t T;
+        int bH;
+        f3 Mv;
+        for (;;) {
+            T = guess;
+            bH = -1;
+            Mv = f3{0, 0, 0};
+            for (uint32_t batch = 0; batch < p.n_hyp; batch += kHyp) {
+                const uint32_t nb = (p.n_hyp - batch < (uint32_t)kHyp) ? p.n_hyp - batch : (uint32_t)kHyp;
+                f3 v = f3{0, 0, 0};
+                if ((uint32_t)lane < nb) v = hypothesis(tile, p.seed, fr.id, stream, batch + lane, N);
+                for (uint32_t j = 0; j < nb; ++j) {
+                    const float hx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), j));
+                    const float hy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), j));
+                    const float hz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.z), j));
+                    uint32_t r2[RPT];
+#pragma unroll
+                    for (int q = 0; q < RPT; ++q) r2[q] = __float_as_uint(fmaf(nz[q], hz, fmaf(ny[q], hy, nx[q] * hx)));
+                    // med < least_med (core_private.cpp:51-53): more than kq |residuals| below the best so far
+                    uint32_t hi2 = T;
+                    const uint32_t tot = wave_count_lt(r2, hi2);
+                    if (tot > kq) {
+                        if (hi2 == kInfBits) {
+                            float mx = 0.f;
+#pragma unroll
+                            for (int q = 0; q < RPT; ++q) mx = fmaxf(mx, fabsf(__uint_as_float(r2[q])));
+                            mx = wave_max_f32(mx);
+                            if (finite_f(mx)) hi2 = __float_as_uint(mx) + 1u;
+                        }
+                        const uint32_t kth = select_kth(r2, kq, hi2, tot);
+                        if (kth < T) { // (always, by the count; the comparison keeps "first wins" explicit)
+                            T = kth;
+                            bH = (int)(batch + j);
+                            Mv = f3{hx, hy, hz};
+                        }
+                    }
+                }
+            }
+            if (guess == kInfBits || bH >= 0) break;
+            guess = kInfBits; // nothing beat the provisional bound: once more without it
+        }
+        const uint32_t bT = bH >= 0 ? T : kInfBits;
+        prev_best = bT;
+        if (!(finite_f(Mv.x) && finite_f(Mv.y) && finite_f(Mv.z))) bad |= RSHIP_BAD_M;
+        if (MODE == 1) { // GuessMotion: only the winner's index leaves this kernel
+            if (lane == 0) p.best_h[sf] = bH;
+            __syncthreads(); // the rows in LDS are read (hypotheses) before the next candidate rewrites them
+            continue;
+        }
+
+        // ---- k = clamp(100 / |P M|), cost = sqrt(sum sqrt(log1p(r^2))) (core_private.cpp:79-85) ----
+        float pm[RPT];
+        float ss = 0.f;
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const uint32_t row = q * 64 + lane;
+            const float v = nrm[q] * rs::dot(f3{nx[q], ny[q], nz[q]}, Mv);
+            pm[q] = row < N ? v : 0.f;
+            ss = fmaf(pm[q], pm[q], ss);
+        }
+        const double ss_tot = (double)wave_sum_f32(ss);
+        float kf = 100.0f * rs::rsqrt_fast((float)ss_tot);
+        kf = (kf < 10.f) ? 10.f : ((1000.f < kf) ? 1000.f : kf);
+        {
+            const float sc = kf * rs::rsqrt_fast(rs::dot(Mv, Mv));
+            float acc = 0.f, rsum = 0.f;
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const float r = pm[q] * sc;
+                rsum += fabsf(r);
+                acc += __builtin_amdgcn_sqrtf(rs::log1p_pos_fast(r * r));
+            }
+            if (!finite_f(rsum)) bad |= RSHIP_BAD_R;
+            else if (!finite_f(acc)) bad |= RSHIP_BAD_RHO;
+            const double acc_tot = (double)wave_sum_f32(acc);
+            if (lane == 0) {
+                p.frame_cost[(size_t)c * p.n_sel + sf] = sqrt(acc_tot);
+                if (p.best_h) p.best_h[(size_t)c * p.n_sel + sf] = bH;
+            }
+        }
+        if (bad) atomicOr(p.flags, bad);
+        __syncthreads(); // the rows in LDS are read (hypotheses) before the next candidate rewrites them
+    }
+}
+
+} // namespace

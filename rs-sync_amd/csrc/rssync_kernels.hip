@@ -6,6 +6,7 @@
 //                      matrix P into an LDS tile, LMedS hypothesis search with an exact
 //                      lower-quartile selection, robust PreSync cost.  The same kernel
 //                      in INIT mode is Sync's GuessMotion/GuessK.
+//   lmeds_small_kernel the same for frames of up to 256 tracks: one wave per (frame, chunk), rows in registers.
 //   loss64_kernel      one workgroup per frame: residual + robust loss (+ analytic
 //                      d/d-delay) for a batch of delays, fp64 (the reference's arithmetic).
 //   opt_motion64_kernel one workgroup per frame: P in registers (fp64), restated L-BFGS on the
@@ -45,6 +46,7 @@ using rs::f4;
 // the kernels, one header per kernel, all in this translation unit
 #include "kernels/common.hpp"
 #include "kernels/lmeds.hpp"
+#include "kernels/lmeds_small.hpp"
 #include "kernels/support.hpp"
 #include "kernels/sync64.hpp"
 #include "kernels/syncloop.hpp"
@@ -226,6 +228,22 @@ uint32_t sel_max_n(const rship_ctx* c) {
 template <int MODE, int WIN>
 int launch_lmeds(rship_ctx* c, const LmedsParams& p, int rpt, uint32_t grid) {
     ProfScope ps(c, MODE == 1 ? RSHIP_K_INIT : RSHIP_K_LMEDS);
+    // Frames of up to 256 tracks (the reference's own data: ~130): one wave per (frame, chunk) instead of a
+    // four-wave workgroup (kernels/lmeds_small.hpp).  Decided from the largest frame of the whole PROBLEM, so that
+    // a frame's cost does not depend on the selection or the device it is evaluated in.
+    const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
+    if (n_all <= 64u * kSmallMaxRpt && !std::getenv("RSSYNC_NO_SMALL_LMEDS")) {
+        const uint32_t g1 = p.n_sel * p.n_chunks;
+        switch ((n_all + 63u) / 64u) {
+            case 0:
+            case 1: hipLaunchKernelGGL((lmeds_small_kernel<1, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
+            case 2: hipLaunchKernelGGL((lmeds_small_kernel<2, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
+            case 3: hipLaunchKernelGGL((lmeds_small_kernel<3, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
+            default: hipLaunchKernelGGL((lmeds_small_kernel<4, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
+        }
+        RS_HIP(hipGetLastError());
+        return 0;
+    }
     switch (rpt) {
         case 1: hipLaunchKernelGGL((lmeds_kernel<1, MODE, WIN>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
         case 2: hipLaunchKernelGGL((lmeds_kernel<2, MODE, WIN>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
