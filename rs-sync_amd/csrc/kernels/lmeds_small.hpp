@@ -109,9 +109,16 @@ __global__ __launch_bounds__(64, RPT <= 3 ? 6 : 5) void lmeds_small_kernel(Lmeds
                     const float hx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), j));
                     const float hy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), j));
                     const float hz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.z), j));
+                    // residuals r = nP v (core_private.cpp:48), two rows per packed operation, in the very expression
+                    // of the tile kernel (so that the compiler contracts it into the same mul + fma + fma)
                     uint32_t r2[RPT];
 #pragma unroll
-                    for (int q = 0; q < RPT; ++q) r2[q] = __float_as_uint(fmaf(nz[q], hz, fmaf(ny[q], hy, nx[q] * hx)));
+                    for (int q = 0; q < RPT; q += 2) {
+                        const int q1 = q + 1 < RPT ? q + 1 : q;
+                        const v2f r01 = v2f{nx[q], nx[q1]} * hx + v2f{ny[q], ny[q1]} * hy + v2f{nz[q], nz[q1]} * hz;
+                        r2[q] = __float_as_uint(r01.x);
+                        if (q + 1 < RPT) r2[q + 1] = __float_as_uint(r01.y);
+                    }
                     // med < least_med (core_private.cpp:51-53): more than kq |residuals| below the best so far
                     uint32_t hi2 = T;
                     const uint32_t tot = wave_count_lt(r2, hi2);

@@ -223,3 +223,39 @@ def test_track_limit_is_a_documented_panic():
     ra = np.tile([0.0, 0.0, 1.0], (n, 1))
     with pytest.raises(rssync_amd.RsSyncError, match="8193 tracks in one frame; this build accepts at most 8192"):
         h.SetTrackResult(0, np.zeros(n), np.zeros(n), ra, ra)
+
+
+def test_one_wave_kernel_for_small_frames_agrees_with_the_tile_kernel(monkeypatch):
+    """Frames of up to 256 tracks run PreSync / GuessMotion in lmeds_small_kernel (one wave per frame, rows in
+    registers, hypotheses in order); RSSYNC_NO_SMALL_LMEDS=1 sends them through the four-wave tile kernel.  Same
+    rows, same directions, same exact selection: the winning hypothesis of every (frame, candidate) is identical,
+    the costs agree to the order of their summation, GuessMotion's winners are the same."""
+    import rssync_amd
+    from rssync_amd import synth
+    F = 14
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=17)
+    for n_max in (5, 64, 65, 130, 192, 200, 256):
+        frames = list(synth.make_frames(g, 0, F, n_max, seed=17))
+        counts = [max(2, n_max - 7 * (i % 3)) for i in range(F)]   # ragged, the largest frame decides the kernel
+        counts[3] = n_max
+        out = {}
+        for tile in (False, True):
+            if tile:
+                monkeypatch.setenv("RSSYNC_NO_SMALL_LMEDS", "1")
+            else:
+                monkeypatch.delenv("RSSYNC_NO_SMALL_LMEDS", raising=False)
+            p = rssync_amd.SyncProblem(seed=SEED, verbose=False)
+            p.SetGyroQuaternions(g.quats, g.fs, g.t0)
+            for (fr, ta, tb, ra, rb), n in zip(frames, counts):
+                p.SetTrackResult(fr, ta[:n], tb[:n], ra[:n], rb[:n])
+            d, c, fc, bh = p.presync_curve(0.03, 0, F, 0.0005, 0.02, per_frame=F)
+            M, k = p.init_motion(0.0362, 0, F - 1)
+            out[tile] = (d, c, fc, bh, M, k)
+        monkeypatch.delenv("RSSYNC_NO_SMALL_LMEDS", raising=False)
+        a, b = out[False], out[True]
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[3], b[3])                  # winning hypothesis per (candidate, frame)
+        np.testing.assert_allclose(a[2], b[2], rtol=2e-6)          # frame costs: fp32 sums in another order
+        np.testing.assert_allclose(a[1], b[1], rtol=2e-6)
+        np.testing.assert_array_equal(a[4], b[4])                  # GuessMotion: same winner, finished in fp64
+        np.testing.assert_array_equal(a[5], b[5])
