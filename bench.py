@@ -6,18 +6,31 @@ frames x 2048 tracks.  One "step" = one pass of the hot path over the window:
 ``PreSync(0, begin, end, 0.5 ms, 200 ms)`` (800 candidate delays, BASELINE
 configs[1] sweep parameters) followed by ``Sync(d_presync, begin, end-1, 0, 0.2)``
 capped at 20 outer iterations (configs[2]), on 4096 frames x 2048 tracks per GPU
-(weak scaling: every rank owns 4096 frames, the window is world*4096 frames).
+(weak scaling: every GPU owns 4096 frames, the window is N*4096 frames).
 
 Nominal work per step: frames*tracks*candidates for PreSync +
 frames*tracks per Sync outer iteration.  value = nominal ray-residuals of all
-ranks / wall time (max over ranks); inputs are resident in HBM before timing.
+GPUs / wall time (max over ranks); inputs are resident in HBM before timing.
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 needs no external launcher.  Two ways of using N GPUs (the reference parallelises over frames inside one
+object, core_private.cpp:73,231,245,263):
+
+  --mode ranks   (default) one process per GPU.  Started either by ``python -m torch.distributed.run
+                 --nproc-per-node N bench.py --gpus N`` (RANK/LOCAL_RANK/WORLD_SIZE in the environment) or by
+                 this script itself: without WORLD_SIZE the parent -- which never touches a GPU -- starts N fresh
+                 rank processes, waits for them and returns their status; rank 0 prints the JSON line.  The sums
+                 over frames are exchanged through the library's own RCCL communicator (--exchange native) or
+                 through torch.distributed (--exchange torch).
+  --mode inproc  one process, one object, ``set_devices(range(N))``: the library spreads the frames over the N
+                 GPUs and adds their partial sums on the host.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,12 +41,13 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 BYTES_PER_RR = 32      # 8 fp32 per ray pair read per (frame, delay) evaluation
+BYTES_PER_RR_F64 = 64  # the Sync kernels read the fp64 streams: 8 doubles per ray pair per evaluation
 FLOP_PER_RR_PRESYNC = 390       # ~230 flop per residual row + 20 hypotheses x ~8
 FP32_VECTOR_PEAK_TF = 157.3     # MI355X_MICROARCH.md: peak FP32 (vector)
-PMC_SUMMARY = "r2_pmc_summary.json"
+PMC_SUMMARIES = ("r3_pmc_summary.json", "r2_pmc_summary.json")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -44,41 +58,124 @@ def main():
     ap.add_argument("--search-radius", type=float, default=0.2)
     ap.add_argument("--outer-iters", type=int, default=20)
     ap.add_argument("--cpu-frames", type=int, default=192, help="frames of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--exchange", default="torch", choices=["torch", "native"],
-                    help="multi-GPU sum: torch.distributed all_reduce through a Python hook (default), or the "
-                         "library's own RCCL communicator (rssync_ext_rccl_init; nccl backend only)")
+    ap.add_argument("--mode", default="ranks", choices=["ranks", "inproc"],
+                    help="ranks: one process per GPU (self-spawned unless WORLD_SIZE is set); inproc: one object "
+                         "driving all GPUs of this process")
+    ap.add_argument("--exchange", default="native", choices=["native", "torch"],
+                    help="multi-rank sums: the library's own RCCL communicator (default; nccl backend only), or "
+                         "torch.distributed all_reduce through a reduce hook")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse "
-                                                      "several ranks on one GPU)")
-    args = ap.parse_args()
+                                                      "several ranks on one GPU or on the CPU stand-in)")
+    ap.add_argument("--spawn-timeout", type=float, default=1500.0, help="seconds the self-spawned ranks may take")
+    ap.add_argument("--rehearse-cpu", default=None, metavar="LIB",
+                    help="TESTS ONLY: run the launcher / exchange logic against the CPU stand-in for the device ABI "
+                         "(tests/_build/librssync_hosttest.so); the printed value is then meaningless and marked so")
+    return ap.parse_args(argv)
 
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """Parent of a self-launched multi-rank run: start one fresh process per GPU, wait, pass on the status.
+    Nothing here imports torch or touches a GPU (a process that has initialised the GPU must not be replaced or
+    forked from); the children inherit stdout, rank 0 prints the JSON line."""
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RSSYNC_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    deadline = time.time() + args.spawn_timeout
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print("bench: rank process %d exited with %d; stopping the others" % (p.pid, code), file=sys.stderr)
+                for q in live:
+                    q.terminate()
+        if live and time.time() > deadline:
+            print("bench: ranks still running after %.0f s; stopping them" % args.spawn_timeout, file=sys.stderr)
+            for q in live:
+                q.kill()
+            rc = rc or 124
+            deadline = float("inf")
+        if live:
+            time.sleep(0.05)
+    return rc
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.mode == "ranks" and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    run(args)
+
+
+def run(args):
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    rehearsal = args.rehearse_cpu is not None
+    inproc = args.mode == "inproc"
+    world = 1 if inproc else int(os.environ.get("WORLD_SIZE", "1"))
+    rank = 0 if inproc else int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    dev = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(dev)
-    torch.zeros(1, device="cuda")  # make this process's HIP context current on its GPU before the library opens it
+    if not inproc and world != args.gpus:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    n_dev = args.gpus if inproc else 1      # GPUs this process drives
+    n_gpus = args.gpus
+    launcher = "inproc" if inproc else ("self-spawned" if os.environ.get("RSSYNC_BENCH_SPAWNED") else
+                                        ("torch.distributed.run" if world > 1 else "direct"))
+    on_gpu = not rehearsal
+    if on_gpu:
+        if inproc and torch.cuda.device_count() < n_dev:
+            raise SystemExit("--mode inproc --gpus %d: this process sees %d GPUs" % (n_dev, torch.cuda.device_count()))
+        dev = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(dev)
+        torch.zeros(1, device="cuda")  # make this process's HIP context current on its GPU before the library opens it
+    backend = args.backend if on_gpu else "gloo"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(backend)
+    red_dev = "cuda" if (on_gpu and backend == "nccl") else "cpu"
 
     import rssync_amd
     from rssync_amd import synth
 
+    lib = None
+    if rehearsal:
+        import ctypes
+        from rssync_amd.problem import bind
+        lib = bind(ctypes.CDLL(os.path.abspath(args.rehearse_cpu)))
+
     F, N = args.frames, args.tracks
-    f_begin, f_end = rank * F, (rank + 1) * F
-    total_frames = world * F
+    per_proc = F * n_dev
+    f_begin, f_end = rank * per_proc, (rank + 1) * per_proc
+    total_frames = world * per_proc
     # one gyro track for the whole window, identical on every rank
     gyro = synth.make_gyro(0.0, (total_frames + 2) / synth.FPS, seed=0x5EED0003)
-    prob = rssync_amd.SyncProblem(seed=0x5EED0003, max_outer_iters=args.outer_iters, verbose=False)
+    prob = rssync_amd.SyncProblem(seed=0x5EED0003, max_outer_iters=args.outer_iters, verbose=False, _lib=lib)
+    if inproc and n_dev > 1:
+        prob.set_devices(list(range(n_dev)))
     # host side of the boundary, outside the timed region: generate the frames, then hand them over with the
     # reference's calls (SetTrackResult copies into pinned staging and starts the upload)
     t_gen = time.time()
@@ -91,30 +188,35 @@ def main():
     t_set = time.time() - t_set
     del frames_in
 
+    exchange = None
     if world > 1:
         from rssync_amd.dist import make_reduce_hook, use_native_rccl
         # the only exchange of the path: a sum of a few doubles, as an RCCL all-reduce over xGMI
-        if args.exchange == "native" and args.backend == "nccl":
-            use_native_rccl(prob)
-        else:
-            prob.set_reduce_hook(make_reduce_hook("cuda" if args.backend == "nccl" else "cpu"))
+        prob.set_tracks_hint(N)  # every rank holds frames of N tracks: no exchange needed to agree on kernel shapes
+        if args.exchange == "native" and backend == "nccl":
+            exchange = use_native_rccl(prob)  # "native-rccl", or "torch-hook" with the reason if RCCL refused
+        if exchange != "native-rccl":
+            prob.set_reduce_hook(make_reduce_hook(red_dev))
+            exchange = "torch-%s-hook" % backend + ("" if exchange is None else " (native RCCL init failed: %s)" % exchange)
+
+    def dev_sync():
+        if on_gpu:
+            torch.cuda.synchronize()
 
     t_up = time.time()
     prob.upload()  # rays + spline into HBM before the timed region
-    torch.cuda.synchronize()
+    dev_sync()
     t_up = time.time() - t_up
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
 
-    n_cand = None
     iters_done = []
     result = {}
 
     def step():
-        nonlocal n_cand
         c0, d0 = prob.PreSync(0.0, 0, total_frames, args.search_step, args.search_radius)
         c1, d1 = prob.Sync(d0, 0, total_frames - 1, 0.0, args.search_radius)
         iters_done.append(len(prob.sync_trace()))
@@ -125,6 +227,7 @@ def main():
     iters_done.clear()
     prob.profile(True)
     prob.profile_reset()
+    x_calls0, x_doubles0 = prob.exchange_stats()
     barrier()
     t0 = time.perf_counter()
     t_pre = 0.0
@@ -137,10 +240,13 @@ def main():
         result.update(presync_delay=d0, presync_cost=c0, sync_delay=d1, sync_cost=c1)
     barrier()
     elapsed = time.perf_counter() - t0
+    x_calls, x_doubles = prob.exchange_stats()
+    x_calls -= x_calls0
+    x_doubles -= x_doubles0
     prof = prob.profile_get()
     prob.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -155,13 +261,13 @@ def main():
     rr_step = rr_presync + rr_sync
     value = rr_step * args.steps / elapsed
 
-    out = None
     if rank == 0:
         # roofline of the dominant kernel (the PreSync LMedS tile kernel), from HIP events on the
-        # stream it runs on: algorithmic bytes = 32 B x ray-residuals one launch processes (this
-        # rank's frames x tracks x candidates) / average launch duration
+        # stream it runs on: algorithmic bytes = 32 B x ray-residuals one launch processes (one
+        # GPU's frames x tracks x candidates) / average launch duration.  With --mode inproc the
+        # event times of the N contexts are summed and so are their launch counts: still per launch.
         n_l, ms_l = prof["lmeds"]
-        roof = None
+        roof = roof_flop = None
         if n_l:
             avg_ms = ms_l / n_l
             alg_bytes = F * N * n_cand * BYTES_PER_RR
@@ -171,55 +277,79 @@ def main():
                     "avg_launch_ms": round(avg_ms, 4), "launches": n_l,
                     "note": "equivalent bandwidth: 32 B per nominal ray-residual; the kernel reuses each ray "
                             "across the candidates of a chunk and is VALU/LDS-bound (DESIGN.md)"}
-        # HBM traffic of that kernel: NOT measured by this run (counters need their own rocprofv3 --pmc passes);
-        # read from the PMC summary committed under profiles/ (tools/collect_pmc.sh: separate passes for
-        # FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), which is
-        # only valid for the default workload
-        roof_flop = None
-        if roof:
             # nominal arithmetic of the same launches: ~390 flop per PreSync ray-residual (230
             # for the residual row + 20 hypotheses x 8) against the fp32 vector peak, from this run's HIP events
             flops = F * N * n_cand * FLOP_PER_RR_PRESYNC
-            ach_tf = flops / (roof["avg_launch_ms"] * 1e-3) / 1e12
+            ach_tf = flops / (avg_ms * 1e-3) / 1e12
             roof_flop = {"bound": "fp32-vector", "kernel": "lmeds_kernel", "achieved": round(ach_tf, 2),
                          "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach_tf / FP32_VECTOR_PEAK_TF, 4),
                          "note": "nominal 390 flop per ray-residual x ray-residuals of one launch / live launch time; "
                                  "what limits the kernel: DESIGN.md section 3 and profiles/r2_valu_rate.txt"}
+        # HBM traffic of that kernel: NOT measured by this run (counters need their own rocprofv3 --pmc passes);
+        # read from the PMC summary committed under profiles/ (tools/collect_pmc.sh: separate passes for
+        # FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), which is
+        # only valid for the default workload
         if roof and (F, N, n_cand) == (4096, 2048, 800):
-            pmc_path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
-            if os.path.exists(pmc_path):
+            for name in PMC_SUMMARIES:
+                pmc_path = os.path.join(ROOT, "profiles", name)
+                if not os.path.exists(pmc_path):
+                    continue
                 raw = json.load(open(pmc_path))
                 key = [k for k in raw if k.startswith("lmeds_kernel<8, 0")]
                 if key:
                     ctr = raw[key[0]]
                     roof["traffic"] = round((2 * ctr["FETCH_SIZE"]["mean_per_launch_KiB"] +
                                              ctr["WRITE_SIZE"]["mean_per_launch_KiB"]) * 1024 / 1e9, 4)
-                    roof["traffic_unit"] = "GB per launch, from profiles/%s (a separate rocprofv3 --pmc run, not this one)" % PMC_SUMMARY
+                    roof["traffic_unit"] = "GB per launch, from profiles/%s (a separate rocprofv3 --pmc run, not this one)" % name
+                    break
+        # second roofline: K1's loss + analytic-gradient launch (one delay per window, every fp64 ray pair of the
+        # GPU's frames read once: 64 B per ray pair), the HBM-bound kernel of the Sync phase, from its own events
+        n_g, ms_g = prof["loss_grad"]
+        roof_k1 = None
+        if n_g:
+            avg_ms = ms_g / n_g
+            ach = F * N * BYTES_PER_RR_F64 / (avg_ms * 1e-3) / 1e9
+            roof_k1 = {"bound": "hbm", "kernel": "loss64_kernel<.,GRAD>", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_ms, 4),
+                       "launches": n_g, "note": "64 B (fp64 streams) x frames x tracks of one GPU / live launch time"}
         kernels = {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in prof.items()}
         cpu = None
-        if world == 1 and args.cpu_frames > 0:
+        if n_gpus == 1 and args.cpu_frames > 0:
             cpu = cpu_baseline(gyro, min(args.cpu_frames, F), N, args)
         out = {
             "metric": "ray-residuals/sec (PreSync sweep + Sync iter), 4096 frames x 2048 tracks",
-            "value": value, "unit": "ray-residuals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "ray-residuals/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "dtype_note": "PreSync sweep in fp32 (92 % of the nominal work), Sync in fp64 (the reference's arithmetic)",
             "config": {"workload": "PreSync(radius 200 ms, step 0.5 ms) + Sync(<=20 outer iters)",
                        "frames_per_gpu": F, "tracks": N, "candidates": n_cand,
-                       "sync_outer_iters": iters_done, "gyro_hz": gyro.fs, "parallelism": "frames sharded x%d" % world},
-            "roofline": roof, "roofline_flop": roof_flop, "cpu_baseline": cpu, "kernels": kernels,
+                       "sync_outer_iters": iters_done, "gyro_hz": gyro.fs,
+                       "parallelism": "frames sharded x%d (%s)" % (n_gpus, "one object, in-process" if inproc else
+                                                                   "one process per GPU")},
+            "multi_gpu": {"mode": args.mode, "launcher": launcher, "processes": world, "devices_per_process": n_dev,
+                          "exchange": exchange, "rccl_ranks": world if exchange == "native-rccl" else 0,
+                          "exchanges_per_step": x_calls / max(args.steps, 1),
+                          "doubles_per_step": x_doubles / max(args.steps, 1),
+                          "note": "exchange = how the sums over frames cross process boundaries (none within one "
+                                  "process: --mode inproc adds the devices' chunk sums on the host)"},
+            "roofline": roof, "roofline_flop": roof_flop, "roofline_k1": roof_k1, "cpu_baseline": cpu, "kernels": kernels,
             "presync_ms_per_step": t_pre / args.steps * 1e3,
             "result": result, "host": {"gen_s": round(t_gen, 2), "set_track_result_s": round(t_set, 3), "pack_upload_s": round(t_up, 3),
                      "note": "set_track_result_s = the SetTrackResult loop over all frames (checks + copy into pinned "
                              "staging, upload started); pack_upload_s = waiting for that upload + packing kernel"},
         }
+        if rehearsal:
+            out["rehearsal"] = "CPU stand-in for the device ABI (%s): launcher and exchange logic only, value is NOT a " \
+                               "measurement" % os.path.basename(args.rehearse_cpu)
         if cpu:
             # reported for context only: the roofline fraction, not this ratio, says how good the kernels are
-            out["gpu_over_cpu"] = round(value / world / cpu["value"], 1)
-        print(json.dumps(out))
+            out["gpu_over_cpu"] = round(value / n_gpus / cpu["value"], 1)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if exchange == "native-rccl":
+            prob.rccl_shutdown()
         dist.destroy_process_group()
 
 

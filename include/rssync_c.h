@@ -110,6 +110,27 @@ int rssync_ext_set_reduce_hook(rssync_problem* p, rssync_reduce_fn fn, void* use
  * the sums of PreSync / Sync are all-reduced with ncclAllReduce on the problem's stream. */
 int rssync_ext_rccl_unique_id(rssync_problem* p, void* id128);
 int rssync_ext_rccl_init(rssync_problem* p, const void* id128, int rank, int world_size);
+/* leave that communicator (collective: every rank calls it); the problem is a single rank again */
+int rssync_ext_rccl_shutdown(rssync_problem* p);
+/* Ranks must pick the same kernel shapes, which follow the largest per-frame track count of the WHOLE problem
+ * (a frame's sums must not depend on which rank holds it).  Give that count here (0 = not given, the default)
+ * or let the ranks agree on it themselves: then every collective call (PreSync, Sync, ...) starts with one
+ * extra exchange of ~150 doubles. */
+int rssync_ext_set_tracks_hint(rssync_problem* p, uint32_t max_tracks_all_ranks);
+/* exchanges with other ranks so far (reduce hook or native RCCL): calls and doubles summed */
+int rssync_ext_exchange_stats(rssync_problem* p, uint64_t* calls, uint64_t* doubles);
+/* Diagnostics of the bit-exactness tests (tests/test_gpu_bitexact.py).  GuessMotion's 200-hypothesis search runs
+ * in fp32 and leaves one winning hypothesis index per slot (window-major, frames ascending); with recording on,
+ * the winners of the last Sync / sync_windows / sync_simplified call can be read back, and set_init_override
+ * installs a list in place of the search's result for the NEXT such call only -- so that two builds of the
+ * library (the GPU one and the CPU stand-in of the tests) can be started from the same motion estimates. */
+int rssync_ext_record_init_winners(rssync_problem* p, int on);
+int rssync_ext_last_init_winners(rssync_problem* p, int32_t* out, size_t cap, size_t* n);
+int rssync_ext_set_init_override(rssync_problem* p, const int32_t* winners, size_t n);
+/* the Sync kernels' fp64 building blocks on caller data: op 0 a / b, 1 sqrt(a), 2 log1p and 1/(1+a) as the
+ * kernels compute them (out[2i], out[2i+1]), 3 fma(a, b, a), 4 the kernels' 64-lane sum of each block of 64
+ * values (out[block]) */
+int rssync_ext_debug_math64(rssync_problem* p, int op, const double* a, const double* b, double* out, size_t n);
 /* pack the tracks and the gyro spline and copy them to HBM now (otherwise done lazily by the
  * first PreSync/Sync/DebugPreSync after a setter) */
 int rssync_ext_upload(rssync_problem* p);
@@ -216,7 +237,8 @@ int rssync_ext_sync_trace(rssync_problem* p, double* trace, int cap_rows, int* n
 /* the internal device context (rship_ctx*, include/rssync_hip.h) behind this problem, for
  * kernel-level tests and profiling tools; owned by the problem */
 void* rssync_ext_device_context(rssync_problem* p);
-/* HIP-event kernel timing: kind 0 LMedS tile (PreSync), 1 loss, 2 motion, 3 reduce, 4 LMedS init (Sync) */
+/* HIP-event kernel timing: kind 0 LMedS tile (PreSync), 1 loss (line-search trials, final loss), 2 motion,
+ * 3 reduce, 4 LMedS init (Sync), 5 packing, 6 gyro, 7 loss + analytic gradient */
 int rssync_ext_profile(rssync_problem* p, int enable);
 int rssync_ext_profile_get(rssync_problem* p, int kind, uint64_t* launches, double* total_ms);
 int rssync_ext_profile_reset(rssync_problem* p);

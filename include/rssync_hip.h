@@ -52,13 +52,14 @@ typedef struct rship_frame {
 
 /* kernel kinds for rship_profile_get */
 #define RSHIP_K_LMEDS 0  /* PreSync tile kernel */
-#define RSHIP_K_LOSS 1   /* residual + robust loss (+ analytic d/d-delay) */
+#define RSHIP_K_LOSS 1   /* residual + robust loss at a batch of delays (line-search trials, final loss) */
 #define RSHIP_K_MOTION 2 /* per-frame motion L-BFGS */
 #define RSHIP_K_REDUCE 3 /* over-frames sums */
 #define RSHIP_K_INIT 4   /* the LMedS kernel in GuessMotion/GuessK mode (Sync start) */
 #define RSHIP_K_PIXELS 5 /* packing kernels: raw records (rays or pixels) -> packed fp32 + fp64 streams */
 #define RSHIP_K_GYRO 6   /* gyro pipeline: integration scan, resampling, spline solve */
-#define RSHIP_K_COUNT 7
+#define RSHIP_K_LOSS_GRAD 7 /* residual + robust loss + analytic d/d-delay (one delay per window) */
+#define RSHIP_K_COUNT 8
 
 int rship_create(rship_ctx** out, int device /* -1 = current device */);
 void rship_destroy(rship_ctx* c);
@@ -233,6 +234,7 @@ int rship_set_motion(rship_ctx* c, const double* M, const double* k, uint32_t n)
 int rship_rccl_unique_id(rship_ctx* c, void* id128);
 int rship_rccl_init(rship_ctx* c, const void* id128, int rank, int world);
 int rship_rccl_allreduce(rship_ctx* c, double* buf, uint64_t n);
+int rship_rccl_shutdown(rship_ctx* c); /* ncclCommDestroy; collective */
 
 /* debug: the packed float4 streams of one frame of the table */
 int rship_debug_rays(rship_ctx* c, uint32_t frame_index, float* a4, float* b4, uint32_t cap_rays);
@@ -250,6 +252,14 @@ int rship_debug_problem64(rship_ctx* c, uint32_t sel_index, int32_t kd, double f
  * out[2i+1] = how many lie below the bound */
 int rship_debug_select(rship_ctx* c, const float* vals, uint32_t n_problems, uint32_t n, uint32_t kq,
                        const float* upper, uint32_t* out);
+
+/* the fp64 building blocks of the Sync kernels on caller data (tests: the CPU stand-in must give the same bits):
+ * op 0 a / b, 1 sqrt(a), 2 log1p_rcp_f64(a) -> out[2i] = value, out[2i+1] = 1 / (1 + a), 3 fma(a, b, a),
+ * 4 the kernels' wave sum of every block of 64 values of a -> out[block] */
+int rship_debug_math64(rship_ctx* c, int op, const double* a, const double* b, double* out, uint32_t n);
+/* GuessMotion's pending winners (hypothesis index per slot of the selection, local slot order) after
+ * rship_init_motion: copy them out (get) and / or replace them (set); either may be NULL */
+int rship_debug_init_h(rship_ctx* c, int32_t* get, const int32_t* set, uint32_t n);
 
 /* HIP-event timing of every launch, accumulated per kernel kind */
 int rship_profile_enable(rship_ctx* c, int on);

@@ -22,6 +22,12 @@
 #define RS_HD inline
 #endif
 
+// Contraction is OFF for everything in this header (restored at its end): every fused multiply-add is spelled
+// fma_t / fmaf / fma, so the bits do not depend on a compiler's choice of what to fuse.
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
 namespace rs {
 
 // fast reciprocal / reciprocal square root: v_rcp_f32 / v_rsq_f32 on the device (about 1 ulp)
@@ -57,8 +63,11 @@ RS_HD double floor_t(double x) { return floor(x); }
 RS_HD float two_over(float n2) { return 2.f * rcp_fast(n2); }
 RS_HD double two_over(double n2) { return 2.0 / n2; }
 
+// Every multiply-add below is written out (fma_t) and the functions are compiled with contraction off: the
+// value of an expression then does not depend on what a compiler chooses to fuse, and the CPU stand-in of the
+// tests (g++ -ffp-contract=off) computes the same bits as the device (tests/test_gpu_bitexact.py).
 template <typename T> RS_HD v3<T> cross(v3<T> a, v3<T> b) {
-    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+    return {fma_t(a.y, b.z, -(a.z * b.y)), fma_t(a.z, b.x, -(a.x * b.z)), fma_t(a.x, b.y, -(a.y * b.x))};
 }
 template <typename T> RS_HD T dot(v3<T> a, v3<T> b) { return fma_t(a.x, b.x, fma_t(a.y, b.y, a.z * b.z)); }
 template <typename T> RS_HD T dot4(v4<T> a, v4<T> b) { return fma_t(a.x, b.x, fma_t(a.y, b.y, fma_t(a.z, b.z, a.w * b.w))); }
@@ -148,8 +157,8 @@ RS_HD v3<T> rotate_inv(v4<T> q, T two_over_n2, v3<T> v) {
     v3<T> u = {q.y, q.z, q.w};
     v3<T> t = cross(u, v);
     v3<T> t2 = cross(u, t);
-    return {fma_t(two_over_n2, t2.x - q.x * t.x, v.x), fma_t(two_over_n2, t2.y - q.x * t.y, v.y),
-            fma_t(two_over_n2, t2.z - q.x * t.z, v.z)};
+    return {fma_t(two_over_n2, fma_t(-q.x, t.x, t2.x), v.x), fma_t(two_over_n2, fma_t(-q.x, t.y, t2.y), v.y),
+            fma_t(two_over_n2, fma_t(-q.x, t.z, t2.z), v.z)};
 }
 
 // One end of a ray pair: rotated ray r = R(S(x)/|S(x)|)^T ray and, if DERIV,
@@ -165,8 +174,8 @@ RS_HD void rotate_ray(v4<T> y, v4<T> b, v4<T> c, v4<T> d, KnotT<T> kn, v3<T> ray
         v4<T> dq = horner_deriv(b, c, d, kn.h);
         v3<T> u = {q.y, q.z, q.w}, du = {dq.y, dq.z, dq.w};
         v3<T> uxdu = cross(u, du);
-        v3<T> W = {s * (q.x * du.x - dq.x * u.x - uxdu.x), s * (q.x * du.y - dq.x * u.y - uxdu.y),
-                   s * (q.x * du.z - dq.x * u.z - uxdu.z)};
+        v3<T> W = {s * (fma_t(q.x, du.x, -(dq.x * u.x)) - uxdu.x), s * (fma_t(q.x, du.y, -(dq.x * u.y)) - uxdu.y),
+                   s * (fma_t(q.x, du.z, -(dq.x * u.z)) - uxdu.z)};
         dr = cross(r, W);
     }
 }
@@ -202,8 +211,10 @@ RS_HD float loss_term(float pm, float inv_s) { return log1p_pos(pm * pm * inv_s)
 //   w = 1 + u (its rounding error wl is carried to first order),  w = 2^e m,  m in [sqrt(1/2), sqrt(2)),
 //   log(m) = 2 atanh(s),  s = (m - 1)/(m + 1),  |s| <= 0.1716  (odd series in s up to s^19),
 //   log1p(u) = e ln2 + log(m) + wl / w.
-// Both 1/(m+1) and 1/m (hence 1/w) come from ONE reciprocal of m (m + 1), refined by two
-// Newton steps from the hardware seed.
+// Both 1/(m+1) and 1/m (hence 1/w) come from ONE reciprocal of m (m + 1) -- an IEEE division, correctly
+// rounded on the device and on the host alike.  (Round 2 refined the hardware's v_rcp_f64 seed with two Newton
+// steps: five instructions fewer, but the last bit then depended on a seed no CPU can reproduce, and the
+// device could not be compared bit for bit with anything.)
 RS_HD double log1p_rcp_f64(double u, double* rc) {
     const double w = 1.0 + u;
     const double wl = u - (w - 1.0);
@@ -219,13 +230,7 @@ RS_HD double log1p_rcp_f64(double u, double* rc) {
     e = low ? e - 1 : e;
     const double m1 = m + 1.0;
     const double p = m * m1;
-#if defined(__HIP_DEVICE_COMPILE__)
-    double ip = __builtin_amdgcn_rcp(p);
-#else
-    double ip = (double)(1.0f / (float)p); // a seed of comparable quality to the hardware's
-#endif
-    ip = fma(fma(-p, ip, 1.0), ip, ip);
-    ip = fma(fma(-p, ip, 1.0), ip, ip);
+    const double ip = 1.0 / p;
     const double inv_m = ip * m1, inv_m1 = ip * m;
     const double sft = (m - 1.0) * inv_m1;
     const double z = sft * sft;
@@ -246,3 +251,7 @@ RS_HD double log1p_rcp_f64(double u, double* rc) {
 }
 
 } // namespace rs
+
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif

@@ -11,6 +11,11 @@
 // evaluation.  gfx950 issues fp64 FMA at half the fp32 rate; Sync is ~10 % of a PreSync + Sync step.
 #pragma once
 
+// The fp64 kernels are compiled with contraction off (restored at the end of this header): what is fused is
+// written as fma(), so that tests/cpu_device/rship_cpu.cpp -- the same expressions under g++
+// -ffp-contract=off, summed in the kernels' association -- reproduces them bit for bit.
+#pragma clang fp contract(off)
+
 namespace {
 
 using rs::d3;
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
     const double kk = p.k[sf];
     const d3 Mv = d3{Mx, My, Mz};
     // r = (P.M) k / |M|  (core_private.cpp:120)  ->  u = (P.M)^2 * inv_s;  SIMPLE: u = |P|^2 k^2
-    const double inv_s = SIMPLE ? kk * kk : kk * kk / (Mx * Mx + My * My + Mz * Mz);
+    const double inv_s = rs::loss_inv_s(SIMPLE, kk, Mv);
 
     for (uint32_t b0 = 0; b0 < p.n_delays; b0 += NB) {
         Spline64 sp[NB];
@@ -212,17 +217,7 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
                     if (!on[q]) continue;
                     d3 P, dP;
                     residual_row64<GRAD>(sp[q], X, Y, Z, T, base[q], fdv[q], P, dP);
-                    double w;
-                    if (SIMPLE) {
-                        const double u = rs::dot(P, P) * inv_s;
-                        L[q] += rs::log1p_rcp_f64(u, &w);
-                        if (GRAD) G[q] = fma(w * 2.0 * inv_s, rs::dot(P, dP), G[q]);
-                    } else {
-                        const double pm = rs::dot(P, Mv);
-                        const double u = pm * pm * inv_s;
-                        L[q] += rs::log1p_rcp_f64(u, &w); // core_private.cpp:121-122
-                        if (GRAD) G[q] = fma(w * 2.0 * pm * inv_s, rs::dot(dP, Mv), G[q]);
-                    }
+                    rs::loss_row<GRAD, SIMPLE>(P, dP, Mv, inv_s, L[q], G[q]); // core_private.cpp:121-122
                 }
             }
         }
@@ -289,7 +284,7 @@ struct Motion64Params {
 };
 
 constexpr int kInitNone = (int)0x80000000;
-constexpr int kNB = 10; // numBasis (ens::L_BFGS default)
+constexpr int kNB = rs::kLbfgsBasis; // numBasis (ens::L_BFGS default)
 
 // NW = waves per workgroup (4 in the product: measured fastest, see launch_motion64)
 template <int RPT, int NW>
@@ -305,23 +300,11 @@ struct MotionEval64 {
     // and x.t = 2 sum_j w_j u_j, so the second term is x (x.t) / |x|^2: the loss does not depend on |x|, its
     // gradient is t without its component along x -- four sums over the rows instead of five.
     __device__ __forceinline__ double operator()(const double x[3], double g[3]) {
-        const double xx = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
-        const double s = xx / k2;
-        const double inv_s = 1.0 / s;
+        double xx;
+        const double inv_s = rs::motion_inv_s(x, k2, &xx);
         double L = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            const double px = P[j].x, py = P[j].y, pz = P[j].z;
-            const double pm = fma(px, x[0], fma(py, x[1], pz * x[2]));
-            const double v2 = pm * pm;
-            const double u = v2 * inv_s;
-            double w; // 1 / (1 + u)
-            L += rs::log1p_rcp_f64(u, &w);
-            const double a = w * 2.0 * pm * inv_s;
-            a0 = fma(a, px, a0);
-            a1 = fma(a, py, a1);
-            a2 = fma(a, pz, a2);
-        }
+        for (int j = 0; j < RPT; ++j) rs::motion_row(P[j], x, inv_s, L, a0, a1, a2);
         double r0 = wave_sum_f64(L), r1 = wave_sum_f64(a0), r2 = wave_sum_f64(a1), r3 = wave_sum_f64(a2);
         double t[4] = {r0, r1, r2, r3};
         if (NW > 1) { // the waves' sums through LDS; a one-wave frame has them already
@@ -341,17 +324,36 @@ struct MotionEval64 {
             buf ^= 1;
         }
         ++evals;
-        const double tt = (x[0] * t[1] + x[1] * t[2] + x[2] * t[3]) / xx;
-        g[0] = t[1] - tt * x[0];
-        g[1] = t[2] - tt * x[1];
-        g[2] = t[3] - tt * x[2];
-        return t[0];
+        return rs::motion_finish(x, xx, t, g);
     }
 };
 
-__device__ __forceinline__ double dot3d(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+// the L-BFGS history of rs::lbfgs3 in LDS: control flow is uniform over the workgroup, every thread runs the
+// same scalar logic on the same sums; thread 0 stores a pair between two barriers
+struct LbfgsHistLds {
+    double (*s_S)[3];
+    double (*s_Y)[3];
+    double* s_inv_ys;
+    double* s_rho;
+    double* s_alpha;
+    __device__ __forceinline__ const double* S(int i) const { return s_S[i]; }
+    __device__ __forceinline__ const double* Y(int i) const { return s_Y[i]; }
+    __device__ __forceinline__ double inv_ys(int i) const { return s_inv_ys[i]; }
+    // two-loop scratch: every thread writes the same values and reads them back itself; the barrier inside each
+    // evaluation separates one iteration's use from the next
+    __device__ __forceinline__ double& rho(int i) { return s_rho[i]; }
+    __device__ __forceinline__ double& alpha(int i) { return s_alpha[i]; }
+    __device__ __forceinline__ void store(int op, const double sv[3], const double yv[3]) {
+        __syncthreads(); // every thread has finished reading the history for this iteration
+        if (threadIdx.x == 0) {
+            for (int c = 0; c < 3; ++c) { s_S[op][c] = sv[c]; s_Y[op][c] = yv[c]; }
+            s_inv_ys[op] = 1.0 / rs::dot3(yv, sv);
+        }
+        __syncthreads();
+    }
+};
 
-__device__ __forceinline__ double clamp_k(double k) { return (k < 10.0) ? 10.0 : ((1000.0 < k) ? 1000.0 : k); } // inline_utils.hpp:50
+__device__ __forceinline__ double clamp_k(double k) { return rs::clamp_k64(k); } // inline_utils.hpp:50
 
 template <int RPT, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? (RPT <= 8 ? 3 : (RPT == 16 ? 2 : 1)) : (NW == 1 ? (RPT >= 8 ? 3 : 4) : 2)) void opt_motion64_kernel(Motion64Params p) {
@@ -435,93 +437,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (RPT <= 8 ? 3 : (RPT == 16 ? 2 :
     if (p.max_iters <= 0 || p.simple_k) return;
     ev.k2 = kk * kk;
 
-    const int maxIterations = p.max_iters; // core_private.cpp:265
-    const double minGradientNorm = 1e-4;   // core_private.cpp:266
-    const double armijo = 1e-4, wolfe = 0.9, factr = 1e-15, minStep = 1e-20, maxStep = 1e20;
-    const int maxLineSearchTrials = 50;
-
-    double g[3], oldx[3], oldg[3], dir[3];
-    double fval = ev(x, g);
-    int it = 0, best_not_last = 0;
-    for (; it != maxIterations; ++it) {
-        const double prev = fval;
-        if (sqrt(dot3d(g, g)) < minGradientNorm) break;
-        if (fval != fval) break;
-        double scale;
-        if (it > 0) {
-            const int pp = (it - 1) % kNB;
-            const double yy = dot3d(s_Y[pp], s_Y[pp]);
-            scale = dot3d(s_S[pp], s_Y[pp]) / ((yy >= 1e-10) ? yy : 1.0);
-        } else {
-            const double gn = sqrt(dot3d(g, g));
-            scale = (gn >= 1e-5) ? 1.0 / gn : 1.0;
-        }
-        if (scale == 0.0 || scale != scale) break;
-        // two-loop recursion
-        dir[0] = g[0]; dir[1] = g[1]; dir[2] = g[2];
-        const int limit = (kNB > it) ? 0 : (it - kNB);
-#pragma unroll 1
-        for (int i = it; i != limit; --i) {
-            const int tp = (i + (kNB - 1)) % kNB;
-            const double r = s_inv_ys[tp]; // = 1.0 / dot3d(s_Y[tp], s_S[tp]), computed when the pair was stored
-            const double al = r * dot3d(s_S[tp], dir);
-            s_rho[it - i] = r; // it - i in [0, kNB)
-            s_alpha[it - i] = al;
-            dir[0] -= al * s_Y[tp][0]; dir[1] -= al * s_Y[tp][1]; dir[2] -= al * s_Y[tp][2];
-        }
-        dir[0] *= scale; dir[1] *= scale; dir[2] *= scale;
-#pragma unroll 1
-        for (int i = limit; i < it; ++i) {
-            const int tp = i % kNB;
-            const double beta = s_rho[it - i - 1] * dot3d(s_Y[tp], dir);
-            const double cf = s_alpha[it - i - 1] - beta;
-            dir[0] += cf * s_S[tp][0]; dir[1] += cf * s_S[tp][1]; dir[2] += cf * s_S[tp][2];
-        }
-        dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2];
-        oldx[0] = x[0]; oldx[1] = x[1]; oldx[2] = x[2];
-        oldg[0] = g[0]; oldg[1] = g[1]; oldg[2] = g[2];
-        // line search
-        const double dg0 = dot3d(g, dir);
-        if (dg0 > 0.0) break;
-        const double f0 = fval, lin = armijo * dg0;
-        double step = 1.0, bestStep = 1.0, bestObj = 1.79769313486231570e308, lastStep = 1.0;
-        int trials = 0;
-        for (;;) {
-            double xn[3] = {x[0] + step * dir[0], x[1] + step * dir[1], x[2] + step * dir[2]};
-            fval = ev(xn, g);
-            lastStep = step;
-            if (fval < bestObj) { bestStep = step; bestObj = fval; }
-            ++trials;
-            double width;
-            if (fval > f0 + step * lin) {
-                width = 0.5;
-            } else {
-                const double dg = dot3d(g, dir);
-                if (dg < wolfe * dg0) width = 2.1;
-                else if (dg > -wolfe * dg0) width = 0.5;
-                else break;
-            }
-            if (step < minStep || step > maxStep || trials >= maxLineSearchTrials) break;
-            step *= width;
-        }
-        x[0] += bestStep * dir[0]; x[1] += bestStep * dir[1]; x[2] += bestStep * dir[2];
-        if (bestStep != lastStep) {
-            ++best_not_last;
-            if (p.reeval) fval = ev(x, g);
-        }
-        if (bestStep == 0.0) break;
-        const double denom = fmax(fmax(fabs(prev), fabs(fval)), 1.0);
-        if ((prev - fval) / denom <= factr) break;
-        const int op = it % kNB;
-        __syncthreads(); // every thread has finished reading the history for this iteration
-        if (tid == 0) {
-            double sv[3], yv[3];
-            for (int c = 0; c < 3; ++c) { sv[c] = x[c] - oldx[c]; yv[c] = g[c] - oldg[c]; }
-            for (int c = 0; c < 3; ++c) { s_S[op][c] = sv[c]; s_Y[op][c] = yv[c]; }
-            s_inv_ys[op] = 1.0 / dot3d(yv, sv);
-        }
-        __syncthreads();
-    }
+    LbfgsHistLds hist{s_S, s_Y, s_inv_ys, s_rho, s_alpha};
+    int best_not_last = 0;
+    const int it = rs::lbfgs3(ev, hist, x, p.max_iters /* core_private.cpp:265 */, p.reeval, &best_not_last);
     if (tid == 0) {
         p.M[3 * sf] = x[0]; p.M[3 * sf + 1] = x[1]; p.M[3 * sf + 2] = x[2];
         if (p.stats) {
@@ -566,4 +484,25 @@ __global__ __launch_bounds__(kBlock) void debug_problem64_kernel(Debug64Params p
     }
 }
 
+// debug: the fp64 building blocks whose bits the CPU stand-in must reproduce (tests/test_gpu_bitexact.py names
+// the operation if one ever differs): op 0 a / b, 1 sqrt(a), 2 log1p_rcp_f64(a) -> {value, 1/(1+a)},
+// 3 fma(a, b, a), 4 the wave sum of each block of 64 values of a (out[block])
+__global__ __launch_bounds__(64) void debug_math64_kernel(int op, const double* __restrict__ a, const double* __restrict__ b,
+                                                          double* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    const double x = i < n ? a[i] : 0.0, y = (i < n && b) ? b[i] : 0.0;
+    if (op == 4) {
+        const double t = wave_sum_f64(x);
+        if (threadIdx.x == 0) out[blockIdx.x] = t;
+        return;
+    }
+    if (i >= n) return;
+    if (op == 0) out[i] = x / y;
+    else if (op == 1) out[i] = sqrt(x);
+    else if (op == 2) { double rc; out[2 * i] = rs::log1p_rcp_f64(x, &rc); out[2 * i + 1] = rc; }
+    else out[i] = fma(x, y, x);
+}
+
 } // namespace
+
+#pragma clang fp contract(fast)

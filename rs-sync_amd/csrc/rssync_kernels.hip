@@ -37,6 +37,7 @@
 
 #include "../../include/rssync_hip.h"
 #include "device_math.hpp"
+#include "sync_math.hpp"
 #include "lens_math.hpp"
 #include "gyro_math.hpp"
 
@@ -102,6 +103,7 @@ struct rship_ctx {
     double fs = 0;
     int lbfgs_reeval = 0; // RSHIP_OPT_LBFGS_REEVAL
     uint32_t tracks_hint = 0; // RSHIP_OPT_TRACKS_HINT
+    bool no_small_lmeds = false; // RSSYNC_NO_SMALL_LMEDS=1 (read once, at creation): the tile kernel for every frame size (A/B tests)
     float max_span = 0.f; // widest frame, in knots (frame table)
     // native exchange (RCCL through dlopen)
     void* rccl_lib = nullptr;
@@ -232,7 +234,7 @@ int launch_lmeds(rship_ctx* c, const LmedsParams& p, int rpt, uint32_t grid) {
     // four-wave workgroup (kernels/lmeds_small.hpp).  Decided from the largest frame of the whole PROBLEM, so that
     // a frame's cost does not depend on the selection or the device it is evaluated in.
     const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
-    if (n_all <= 64u * kSmallMaxRpt && !std::getenv("RSSYNC_NO_SMALL_LMEDS")) {
+    if (n_all <= 64u * kSmallMaxRpt && !c->no_small_lmeds) {
         const uint32_t g1 = p.n_sel * p.n_chunks;
         switch ((n_all + 63u) / 64u) {
             case 0:
@@ -261,7 +263,7 @@ template <bool GRAD, bool SIMPLE>
 int launch_loss64(rship_ctx* c, const Loss64Params& p, int rpt, hipStream_t st = nullptr, uint32_t count = 0) {
     if (!st) st = c->stream;
     if (!count) count = p.n_sel - p.slot0;
-    ProfScope ps(c, RSHIP_K_LOSS);
+    ProfScope ps(c, GRAD ? RSHIP_K_LOSS_GRAD : RSHIP_K_LOSS);
     switch (rpt) {
         case 1: hipLaunchKernelGGL((loss64_kernel<1, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
         case 2: hipLaunchKernelGGL((loss64_kernel<2, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
@@ -431,6 +433,7 @@ int rship_create(rship_ctx** out, int device) {
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) return 2; // no GPU: the product path has no CPU fallback
     rship_ctx* c = new rship_ctx();
+    if (const char* s = std::getenv("RSSYNC_NO_SMALL_LMEDS")) c->no_small_lmeds = s[0] && s[0] != '0';
     if (device >= 0) {
         e = hipSetDevice(device);
         if (e != hipSuccess) { delete c; return 3; }
@@ -1256,7 +1259,10 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
             gr.st = G == 1 ? c->stream : c->loop_streams[g];
             gr.n_active = (int*)(base + o_nact + (size_t)g * nact_stride);
             gr.h_nact = (int*)((char*)c->pinned + (size_t)g * nact_stride);
-            gr.done = gr.w1 == gr.w0 || gr.s1 == gr.s0;
+            // (windows without frames still iterate: their sums are zero, the steps are zero and the convergence
+            // counter stops them after six iterations, exactly like the host loop -- only a group without
+            // windows has nothing to do)
+            gr.done = gr.w1 == gr.w0;
         }
     }
     if (G > 1) { // what the context's stream has queued (selection, GuessMotion, the copies above) comes first
@@ -1280,7 +1286,7 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
             hipLaunchKernelGGL(sync_begin_kernel, dim3((nw + 63) / 64), dim3(64), 0, gr.st, l);
             RS_HIP(hipGetLastError());
         }
-        if (!simplified) {
+        if (!simplified && cnt) {
             Motion64Params m = mp;
             m.slot0 = gr.s0;
             if (launch_motion64(c, m, gr.st, cnt)) return 1; // :311 (finishes a pending GuessMotion on its first launch)
@@ -1288,7 +1294,7 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
         // loss + gradient at x0 (:298-299 -> backtrack.cpp:4)
         q.kd = l.lg_kd; q.fd = l.lg_fd; q.n_delays = 1;
         q.part_grad = q.part_loss + (size_t)ns;
-        if (loss_launch(true)) return 1;
+        if (cnt && loss_launch(true)) return 1;
         l.rows = 2;
         {
             ProfScope ps(c, RSHIP_K_REDUCE);
@@ -1298,7 +1304,7 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
         q.kd = l.tr_kd; q.fd = l.tr_fd; q.n_delays = kMaxBt;
         q.part_grad = nullptr;
         l.rows = kMaxBt;
-        if (loss_launch(false)) return 1;
+        if (cnt && loss_launch(false)) return 1;
         {
             ProfScope ps(c, RSHIP_K_REDUCE);
             hipLaunchKernelGGL(sync_step_kernel, dim3(nw), ctl_block, 0, gr.st, l);
@@ -1418,6 +1424,18 @@ int rship_rccl_allreduce(rship_ctx* c, double* buf, uint64_t n) {
     return 0;
 }
 
+int rship_rccl_shutdown(rship_ctx* c) {
+    DeviceGuard dev_guard(c);
+    if (!c->rccl_comm) return 0;
+    RS_HIP(hipStreamSynchronize(c->stream));
+    auto destroy = (rccl_destroy_fn)rccl_sym(c, "ncclCommDestroy");
+    if (!destroy) return 1;
+    const int rc = destroy(c->rccl_comm);
+    c->rccl_comm = nullptr;
+    if (rc) return set_err(c, "rccl: ncclCommDestroy failed (" + std::to_string(rc) + ")");
+    return 0;
+}
+
 int rship_debug_rays(rship_ctx* c, uint32_t frame_index, float* a4, float* b4, uint32_t cap_rays) {
     DeviceGuard dev_guard(c);
     if (frame_index >= c->n_frames) return set_err(c, "debug_rays: index out of range");
@@ -1487,6 +1505,38 @@ int rship_debug_problem64(rship_ctx* c, uint32_t sel_index, int32_t kd, double f
     if (e == hipSuccess) e = hipMemcpy(P, out.p, (size_t)n * 24, hipMemcpyDeviceToHost);
     if (e == hipSuccess && dP) e = hipMemcpy(dP, (double*)out.p + (size_t)n * 3, (size_t)n * 24, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return set_err(c, "debug_problem64", e);
+    return 0;
+}
+
+int rship_debug_math64(rship_ctx* c, int op, const double* a, const double* b, double* out, uint32_t n) {
+    DeviceGuard dev_guard(c);
+    if (op < 0 || op > 4 || !n) return set_err(c, "debug_math64: bad arguments");
+    const uint32_t blocks = (n + 63) / 64;
+    const size_t n_out = op == 2 ? 2 * (size_t)n : (op == 4 ? blocks : n);
+    TempBuf da, db, dout;
+    if (ensure(c, da, (size_t)n * 8) || ensure(c, dout, n_out * 8) || (b && ensure(c, db, (size_t)n * 8))) return 1;
+    hipError_t e = hipMemcpy(da.p, a, (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && b) e = hipMemcpy(db.p, b, (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(debug_math64_kernel, dim3(blocks), dim3(64), 0, c->stream, op, (const double*)da.p,
+                           b ? (const double*)db.p : nullptr, (double*)dout.p, n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, dout.p, n_out * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return set_err(c, "debug_math64", e);
+    return 0;
+}
+
+// the pending winners of GuessMotion's hypothesis search, per slot of the selection: read (get) and / or
+// overwrite (set) them before the next motion launch turns them into M and k
+int rship_debug_init_h(rship_ctx* c, int32_t* get, const int32_t* set, uint32_t n) {
+    DeviceGuard dev_guard(c);
+    if (n != c->n_sel) return set_err(c, "debug_init_h: count differs from the selection");
+    if (!n) return 0;
+    RS_HIP(hipStreamSynchronize(c->stream));
+    if (get) RS_HIP(hipMemcpy(get, c->init_h.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (set) RS_HIP(hipMemcpy(c->init_h.p, set, (size_t)n * 4, hipMemcpyHostToDevice));
     return 0;
 }
 

@@ -233,7 +233,13 @@ class SyncProblemHip final : public ISyncProblem {
     std::vector<std::vector<double>> traces; // per window of the last sync_windows call
     bool native_exchange = false; // RCCL communicator inside the device context (rssync_ext_rccl_init)
     bool distributed() const { return native_exchange || reduce_fn; }
+    uint64_t exchange_calls = 0, exchange_doubles = 0; // sums exchanged with other ranks so far
+    void rccl_shutdown();
+    // The largest per-frame track count over ALL ranks, given by the caller (0 = not given: the ranks agree on
+    // it with one small exchange per call, agree_on_tracks_hint).
+    void set_tracks_hint(uint32_t n) { tracks_hint_explicit_ = n; }
     void reduce(double* buf, size_t n) {
+        if (distributed()) { exchange_calls += 1; exchange_doubles += n; }
         if (native_exchange) hip_check(shards_[0], rship_rccl_allreduce(shards_[0].ctx, buf, n), "rccl all-reduce");
         else if (reduce_fn) {
             const int rc = reduce_fn(buf, n, reduce_user);
@@ -246,6 +252,11 @@ class SyncProblemHip final : public ISyncProblem {
     size_t table_size() const { return table_ids_.size(); }
     bool has_frame(int64_t id) const { return frames_.count(id) != 0; }
     size_t frame_tracks(int64_t id) const { return frames_.at(id).n; }
+    // diagnostics of the bit-exactness tests: GuessMotion's winning hypothesis per slot (global slot order) of
+    // the last Sync-type call, and winners to install instead of the search's in the next one
+    bool record_init = false;
+    std::vector<int32_t> last_init_winners, init_override;
+    void exchange_init_winners();
     uint32_t sync_calls = 0;
     bool host_loop = false; // keep Sync's outer loop on the host even where the device could run it (tests)
     uint64_t last_best_not_last = 0; // of the last rssync_ext_opt_motion call
@@ -271,6 +282,10 @@ class SyncProblemHip final : public ISyncProblem {
     }
     void create_shards(const std::vector<int>& ids);
     void destroy_shards();
+    void agree_on_tracks_hint();
+    // options that live in the device contexts, kept here so that set_devices (new contexts) does not lose them
+    int opt_lbfgs_reeval_ = 0, opt_profile_ = 0;
+    uint32_t tracks_hint_explicit_ = 0, local_max_tracks_ = 0, applied_hint_ = 0xffffffffu;
     // slots (table indices, window-major; off = window offsets or empty for one ungrouped window) -> per-shard
     // selections; plan windows = the given lists of slot positions (plan_off/plan_pos) or, if empty, the groups
     void apply_selection(const std::vector<uint32_t>& slots, const std::vector<uint32_t>& grp_off,
@@ -343,6 +358,10 @@ void SyncProblemHip::create_shards(const std::vector<int>& ids) {
         }
         shards_.push_back(sh);
     }
+    // what the caller had switched on applies to the new contexts as well
+    applied_hint_ = 0xffffffffu;
+    if (opt_lbfgs_reeval_) set_option(RSHIP_OPT_LBFGS_REEVAL, opt_lbfgs_reeval_);
+    if (opt_profile_) profile_enable(opt_profile_);
 }
 
 void SyncProblemHip::destroy_shards() {
@@ -365,10 +384,52 @@ void SyncProblemHip::set_devices(const std::vector<int>& ids) {
 }
 
 void SyncProblemHip::set_option(int option, int value) {
+    if (option == RSHIP_OPT_LBFGS_REEVAL) opt_lbfgs_reeval_ = value != 0;
     for (Shard& sh : shards_) hip_check(sh, rship_set_option(sh.ctx, option, value), "set option");
 }
 void SyncProblemHip::profile_enable(int on) {
+    opt_profile_ = on != 0;
     for (Shard& sh : shards_) hip_check(sh, rship_profile_enable(sh.ctx, on), "profile");
+}
+
+// Kernels whose workgroup shape fixes the order of a frame's sums pick the shape from the largest frame of the
+// whole PROBLEM (RSHIP_OPT_TRACKS_HINT), so that a frame gets the same sums on any device, in any selection and
+// on any rank.  Only the size CLASS matters (multiples of 64 tracks up to 8192, powers of two above: every
+// threshold the launchers test is one of those), so ranks agree on it with a sum: each adds a one into the slot
+// of its own class and the highest occupied slot wins -- the reduce hook knows neither rank nor world size.
+// One small exchange per collective call, unless the caller has given the number (rssync_ext_set_tracks_hint).
+void SyncProblemHip::agree_on_tracks_hint() {
+    constexpr uint32_t kFine = 128; // classes 0..128: ceil(n / 64)
+    auto cls = [](uint32_t n) -> uint32_t {
+        if (n <= 64u * kFine) return (n + 63u) / 64u;
+        uint32_t c = kFine;
+        for (uint64_t cap = 64ull * kFine; cap < n; cap *= 2) ++c;
+        return c;
+    };
+    auto bound = [](uint32_t c) -> uint32_t {
+        if (c <= kFine) return 64u * c;
+        const uint64_t v = (64ull * kFine) << (c - kFine);
+        return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v;
+    };
+    uint32_t c = cls(tracks_hint_explicit_ ? tracks_hint_explicit_ : local_max_tracks_);
+    if (!tracks_hint_explicit_ && distributed()) {
+        double slots[kFine + 21] = {};
+        slots[c] = 1.0;
+        reduce(slots, kFine + 21);
+        for (uint32_t i = 0; i < kFine + 21; ++i)
+            if (slots[i] > 0) c = i;
+    }
+    const uint32_t hint = bound(c);
+    if (hint != applied_hint_) {
+        set_option(RSHIP_OPT_TRACKS_HINT, (int)std::min<uint32_t>(hint, 0x7fffffffu));
+        applied_hint_ = hint;
+    }
+}
+
+void SyncProblemHip::rccl_shutdown() {
+    if (!native_exchange) return;
+    hip_check(shards_[0], rship_rccl_shutdown(shards_[0].ctx), "rccl shutdown");
+    native_exchange = false;
 }
 void SyncProblemHip::profile_reset() {
     for (Shard& sh : shards_) hip_check(sh, rship_profile_reset(sh.ctx), "profile");
@@ -669,9 +730,8 @@ void SyncProblemHip::pack_frames() {
         cut[d] = best;
     }
     if (S == 1) upload_new_records();
-    uint32_t max_tracks = 0;
-    for (size_t i = 0; i < nf; ++i) max_tracks = std::max(max_tracks, table[i].n_rays);
-    set_option(RSHIP_OPT_TRACKS_HINT, (int)max_tracks);
+    local_max_tracks_ = 0;
+    for (size_t i = 0; i < nf; ++i) local_max_tracks_ = std::max(local_max_tracks_, table[i].n_rays);
     uint32_t bad = 0;
     for (size_t d = 0; d < S; ++d) {
         Shard& sh = shards_[d];
@@ -804,6 +864,7 @@ void SyncProblemHip::ensure_device() {
     if (n_knots_ < 2) panic("sync: gyro data was not set");
     if (spline_dirty_) build_spline();
     if (frames_dirty_) pack_frames();
+    agree_on_tracks_hint(); // (an exchange when other ranks take part: every public call is collective then)
 }
 
 uint32_t SyncProblemHip::get_motion(double* M, double* k, uint32_t cap) {
@@ -1034,6 +1095,26 @@ void SyncProblemHip::init_motion(const std::vector<double>& delays, uint32_t cal
                       "init motion");
 }
 
+void SyncProblemHip::exchange_init_winners() {
+    const size_t ns = sel_.size();
+    const bool set = !init_override.empty();
+    if (set && init_override.size() != ns)
+        panic("init-override: " + std::to_string(init_override.size()) + " winners for " + std::to_string(ns) + " slots");
+    if (record_init) last_init_winners.assign(ns, std::numeric_limits<int32_t>::min());
+    std::vector<int32_t> got, put;
+    for (Shard& sh : shards_) {
+        const size_t nl = sh.sel.size();
+        if (!nl) continue;
+        got.assign(nl, 0);
+        put.assign(nl, 0);
+        for (size_t j = 0; j < nl && set; ++j) put[j] = init_override[sh.slot_global[j]];
+        hip_check(sh, rship_debug_init_h(sh.ctx, record_init ? got.data() : nullptr, set ? put.data() : nullptr, (uint32_t)nl),
+                  "init winners");
+        for (size_t j = 0; j < nl && record_init; ++j) last_init_winners[sh.slot_global[j]] = set ? put[j] : got[j];
+    }
+    init_override.clear(); // for one call only
+}
+
 void SyncProblemHip::opt_motion(const std::vector<double>& delays, uint64_t* stats) {
     std::vector<int32_t> kd;
     std::vector<double> fd;
@@ -1152,6 +1233,7 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
     } else {
         init_motion(d, call_stride);
         if (call_stride == 1) sync_calls += (uint32_t)W;
+        if (record_init || !init_override.empty()) exchange_init_winners();
     }
     traces.assign(W, {});
 
@@ -1501,6 +1583,41 @@ int rssync_ext_rccl_init(rssync_problem* p, const void* id128, int rank, int wor
     return guarded([&] {
         if (rship_rccl_init(p->impl->dev(), id128, rank, world_size)) panic(std::string("hip: ") + rship_last_error(p->impl->dev()));
         p->impl->native_exchange = true;
+    });
+}
+
+int rssync_ext_rccl_shutdown(rssync_problem* p) {
+    return guarded([&] { p->impl->rccl_shutdown(); });
+}
+
+int rssync_ext_set_tracks_hint(rssync_problem* p, uint32_t max_tracks_all_ranks) {
+    p->impl->set_tracks_hint(max_tracks_all_ranks);
+    return 0;
+}
+
+int rssync_ext_exchange_stats(rssync_problem* p, uint64_t* calls, uint64_t* doubles) {
+    if (calls) *calls = p->impl->exchange_calls;
+    if (doubles) *doubles = p->impl->exchange_doubles;
+    return 0;
+}
+
+int rssync_ext_record_init_winners(rssync_problem* p, int on) {
+    p->impl->record_init = on != 0;
+    return 0;
+}
+int rssync_ext_last_init_winners(rssync_problem* p, int32_t* out, size_t cap, size_t* n) {
+    const std::vector<int32_t>& w = p->impl->last_init_winners;
+    if (n) *n = w.size();
+    if (out) std::copy(w.begin(), w.begin() + std::min(cap, w.size()), out);
+    return 0;
+}
+int rssync_ext_set_init_override(rssync_problem* p, const int32_t* winners, size_t n) {
+    p->impl->init_override.assign(winners, winners + n);
+    return 0;
+}
+int rssync_ext_debug_math64(rssync_problem* p, int op, const double* a, const double* b, double* out, size_t n) {
+    return guarded([&] {
+        if (rship_debug_math64(p->impl->dev(), op, a, b, out, (uint32_t)n)) panic(std::string("hip: ") + rship_last_error(p->impl->dev()));
     });
 }
 

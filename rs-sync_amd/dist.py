@@ -38,15 +38,49 @@ def make_reduce_hook(device=None, capacity=8192):
     return hook
 
 
-def use_native_rccl(problem):
+def use_native_rccl(problem, strict=False):
     """Give `problem` its own RCCL communicator (no Python in the exchange): rank 0's unique id is
-    broadcast through the already initialised torch.distributed group, then every rank joins."""
+    broadcast through the already initialised torch.distributed group, then every rank joins.
+
+    Returns "native-rccl", or -- if any rank could not join (librccl missing, init refused) and `strict` is
+    false -- the first failure's message after every rank has left the communicator again: the caller then
+    installs a reduce hook instead.  The ranks agree on the outcome, so they never end up on different paths.
+    """
+    import torch
     import torch.distributed as dist
 
     rank, world = dist.get_rank(), dist.get_world_size()
-    ids = [problem.rccl_unique_id() if rank == 0 else None]
+    err = None
+    ids = [None]
+    if rank == 0:
+        try:
+            ids = [problem.rccl_unique_id()]
+        except Exception as exc:  # noqa: BLE001
+            err = "rank 0: %s" % exc
     dist.broadcast_object_list(ids, src=0)
-    problem.rccl_init(ids[0], rank, world)
+    joined = False
+    if ids[0] is not None:
+        try:
+            problem.rccl_init(ids[0], rank, world)
+            joined = True
+        except Exception as exc:  # noqa: BLE001
+            err = "rank %d: %s" % (rank, exc)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    ok = torch.tensor([1 if joined else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
+        return "native-rccl"
+    errs = [None] * world
+    dist.all_gather_object(errs, err)
+    first = next((e for e in errs if e), "unknown")
+    if joined:
+        try:
+            problem.rccl_shutdown()
+        except Exception:  # noqa: BLE001
+            pass
+    if strict:
+        raise RuntimeError("native RCCL exchange unavailable: " + first)
+    return first
 
 
 def shard(frame_begin, frame_end, rank, world):

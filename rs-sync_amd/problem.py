@@ -19,7 +19,9 @@ class RsSyncError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "librssync_core.so")
+    """librssync_core.so next to this file.  RSSYNC_LIB names another BUILD of the same library (kernel A/B
+    scripts select their variants this way instead of copying over the product .so)."""
+    return os.environ.get("RSSYNC_LIB") or os.path.join(_HERE, "librssync_core.so")
 
 
 REDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_size_t, C.c_void_p)
@@ -55,6 +57,13 @@ SIGNATURES = {
     "rssync_ext_set_reduce_hook": (C.c_int, [C.c_void_p, REDUCE_FN, C.c_void_p]),
     "rssync_ext_rccl_unique_id": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rssync_ext_rccl_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "rssync_ext_rccl_shutdown": (C.c_int, [C.c_void_p]),
+    "rssync_ext_set_tracks_hint": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rssync_ext_exchange_stats": (C.c_int, [C.c_void_p, _PU64, _PU64]),
+    "rssync_ext_record_init_winners": (C.c_int, [C.c_void_p, C.c_int]),
+    "rssync_ext_last_init_winners": (C.c_int, [C.c_void_p, _PI32, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "rssync_ext_set_init_override": (C.c_int, [C.c_void_p, _PI32, C.c_size_t]),
+    "rssync_ext_debug_math64": (C.c_int, [C.c_void_p, C.c_int, _PD, _PD, _PD, C.c_size_t]),
     "rssync_ext_upload": (C.c_int, [C.c_void_p]),
     "rssync_ext_sample_rate": (C.c_int, [C.c_void_p, _PD, _PD, C.POINTER(C.c_size_t)]),
     "rssync_ext_gyro_knots": (C.c_int, [C.c_void_p, _PD, C.c_size_t]),
@@ -273,6 +282,45 @@ class SyncProblem:
         self._check(self._lib.rssync_ext_rccl_init(self._h, C.create_string_buffer(unique_id, 128), int(rank),
                                                    int(world_size)))
 
+    def rccl_shutdown(self):
+        """Leave the library's RCCL communicator (collective)."""
+        self._check(self._lib.rssync_ext_rccl_shutdown(self._h))
+
+    def set_tracks_hint(self, max_tracks_all_ranks):
+        """Largest per-frame track count over all ranks (0: the ranks agree on it with an exchange per call)."""
+        self._lib.rssync_ext_set_tracks_hint(self._h, int(max_tracks_all_ranks))
+
+    def exchange_stats(self):
+        """(calls, doubles) exchanged with other ranks so far, through the hook or the native communicator."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._lib.rssync_ext_exchange_stats(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def record_init_winners(self, on=True):
+        self._lib.rssync_ext_record_init_winners(self._h, 1 if on else 0)
+
+    def last_init_winners(self):
+        """GuessMotion's winning hypothesis per slot of the last Sync-type call (needs record_init_winners)."""
+        n = C.c_size_t()
+        self._lib.rssync_ext_last_init_winners(self._h, None, 0, C.byref(n))
+        out = np.zeros(n.value, np.int32)
+        self._lib.rssync_ext_last_init_winners(self._h, _p(out, _PI32), out.size, C.byref(n))
+        return out
+
+    def set_init_override(self, winners):
+        """Install these winners instead of the search's in the next Sync-type call (bit-exactness tests)."""
+        w = np.ascontiguousarray(winners, np.int32)
+        self._lib.rssync_ext_set_init_override(self._h, _p(w, _PI32), w.size)
+
+    def debug_math64(self, op, a, b=None):
+        """The Sync kernels' fp64 building blocks on arrays: 0 a/b, 1 sqrt, 2 (log1p, 1/(1+a)), 3 fma(a,b,a), 4 wave sums."""
+        a = _d(a)
+        b = _d(b) if b is not None else None
+        n = a.size
+        out = np.zeros(2 * n if op == 2 else ((n + 63) // 64 if op == 4 else n))
+        self._check(self._lib.rssync_ext_debug_math64(self._h, int(op), _p(a), _p(b) if b is not None else None, _p(out), n))
+        return out.reshape(n, 2) if op == 2 else out
+
     def upload(self):
         """Pack tracks + spline and copy them to HBM now (otherwise lazy)."""
         self._check(self._lib.rssync_ext_upload(self._h))
@@ -488,7 +536,7 @@ class SyncProblem:
         self._check(self._lib.rssync_ext_profile_reset(self._h))
 
     def profile_get(self):
-        names = ["lmeds", "loss", "motion", "reduce", "init", "pixels", "gyro"]
+        names = ["lmeds", "loss", "motion", "reduce", "init", "pixels", "gyro", "loss_grad"]
         out = {}
         for i, nm in enumerate(names):
             n, ms = C.c_uint64(), C.c_double()

@@ -4,12 +4,22 @@
 // rship_* entry points.  To exercise that host code on a machine without a GPU -- the Sync
 // control loop, frame selection, delay splitting, panics, and the multi-rank reduce hook under
 // gloo -- the tests link the SAME sync_problem.cpp against this file instead of the HIP
-// translation unit.  It evaluates the kernels' arithmetic (the shared header device_math.hpp,
-// fp32) sequentially on the CPU.  It is built only by tests/conftest.py into
+// translation unit.  It evaluates the kernels' arithmetic (the shared headers device_math.hpp and
+// sync_math.hpp) on the CPU.
+//
+// For Sync (fp64) it is also the DEVICE-ASSOCIATION ORACLE: the row terms come from the same source as the
+// kernels' (contraction off on both sides), and the sums over rows are taken in the kernels' own order --
+// rows-per-thread partials, the row_shr / readlane wave tree of wave_sum_f64, waves in order -- so that the
+// GPU library and this stand-in must agree BIT FOR BIT on every loss, gradient, motion estimate and Sync trace
+// (tests/test_gpu_bitexact.py).  What then differs between this file and oracle/rssync_oracle.c (sequential
+// sums, libm's log1p) is the effect of reassociation alone, measured on the CPU (profiles/r3_reassociation.json).
+// PreSync's fp32 search is evaluated sequentially here (the device uses hardware reciprocals there): the
+// tests compare it statistically, and start both sides of a bit-exactness test from the same winners.  It is built only by tests/conftest.py into
 // tests/_build/librssync_hosttest.so, is never part of librssync_core.so, and nothing under
 // rs-sync_amd/ can load it.
 #include "../../include/rssync_hip.h"
 #include "../../rs-sync_amd/csrc/device_math.hpp"
+#include "../../rs-sync_amd/csrc/sync_math.hpp"
 #include "../../rs-sync_amd/csrc/lens_math.hpp"
 #include "../../rs-sync_amd/csrc/gyro_math.hpp"
 
@@ -40,6 +50,7 @@ struct rship_ctx {
     std::vector<uint32_t> sel, grp, grp_off; // slots, slot -> window, window offsets
     std::vector<double> M, k;                // per slot
     int lbfgs_reeval = 0;
+    uint32_t tracks_hint = 0;
     // reduction plan and the results of the last *_enqueue
     std::vector<uint32_t> plan_idx, plan_chunk_off, plan_win_off;
     bool plan_has_idx = false;
@@ -152,7 +163,7 @@ void rship_destroy(rship_ctx* c) { delete c; }
 const char* rship_last_error(const rship_ctx* c) { return c->err.c_str(); }
 int rship_set_stream(rship_ctx*, void*) { return 0; }
 int rship_set_option(rship_ctx* c, int option, int value) {
-    if (option == RSHIP_OPT_TRACKS_HINT) return 0; // the test double sums sequentially whatever the shape
+    if (option == RSHIP_OPT_TRACKS_HINT) { c->tracks_hint = value > 0 ? (uint32_t)value : 0u; return 0; } // K3's workgroup shape
     if (option != RSHIP_OPT_LBFGS_REEVAL) return fail(c, "set_option: unknown option");
     c->lbfgs_reeval = value != 0;
     return 0;
@@ -336,6 +347,7 @@ int rship_pack_frames(rship_ctx* c, const rship_frame* table, const rship_pack_f
 int rship_rccl_unique_id(rship_ctx* c, void*) { return fail(c, "rccl: device only"); }
 int rship_rccl_init(rship_ctx* c, const void*, int, int) { return fail(c, "rccl: device only"); }
 int rship_rccl_allreduce(rship_ctx* c, double*, uint64_t) { return fail(c, "rccl: device only"); }
+int rship_rccl_shutdown(rship_ctx* c) { return fail(c, "rccl: device only"); }
 
 int rship_debug_rays(rship_ctx* c, uint32_t frame_index, float* a4, float* b4, uint32_t cap) {
     if (frame_index >= c->frames.size()) return fail(c, "debug_rays: index out of range");
@@ -475,13 +487,48 @@ int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t
 }
 
 namespace {
-double clampk64(double k) { return (k < 10.0) ? 10.0 : ((1000.0 < k) ? 1000.0 : k); }
 
-// opt_motion64_kernel's prologue: GuessMotion's winner -> M in fp64, GuessK; returns the fp64 rows
-void finish_slot(rship_ctx* c, size_t sl, int32_t kd, double fd, bool simple_k, std::vector<d3>& P) {
+// wave_sum_f64 of kernels/common.hpp on 64 lane values: four row_shr steps inside the rows of 16 (a lane whose
+// source is outside its row adds 0), then the four row totals as (R3 + R2) + (R1 + R0)
+double wave_sum_order(const double* lanes) {
+    double v[64], t[64];
+    for (int l = 0; l < 64; ++l) v[l] = lanes[l];
+    for (int sh = 1; sh <= 8; sh *= 2) {
+        for (int l = 0; l < 64; ++l) t[l] = v[l] + ((l & 15) >= sh ? v[l - sh] : 0.0);
+        for (int l = 0; l < 64; ++l) v[l] = t[l];
+    }
+    return (v[63] + v[47]) + (v[31] + v[15]);
+}
+
+// the workgroup shape launch_motion64 picks (rows per thread, waves) from the largest frame of the problem
+void motion_shape(const rship_ctx* c, int& rpt, int& nw) {
+    uint32_t n = c->tracks_hint;
+    for (uint32_t i : c->sel) n = std::max(n, c->frames[i].n_rays);
+    if (n <= 64) { rpt = 1; nw = 1; }
+    else if (n <= 128) { rpt = 2; nw = 1; }
+    else if (n <= 192) { rpt = 3; nw = 1; }
+    else if (n <= 256) { rpt = 4; nw = 1; }
+    else if (n <= 512) { rpt = 8; nw = 1; }
+    else { nw = 4; rpt = 4; while ((uint32_t)rpt * 256u < n) rpt *= 2; }
+}
+
+// sum over a workgroup of per-thread values in the kernels' order: wave sums, then the waves left to right
+double block_sum_order(const std::vector<double>& per_thread, int nw) {
+    double tot = 0.0;
+    for (int w = 0; w < nw; ++w) {
+        const double sw = wave_sum_order(per_thread.data() + 64 * w);
+        tot = w == 0 ? sw : tot + sw;
+    }
+    return tot;
+}
+
+// opt_motion64_kernel's prologue: the fp64 rows as the workgroup holds them (row j * threads + tid in thread
+// tid's register j; zero beyond the frame), GuessMotion's winner -> M in fp64, GuessK
+void finish_slot(rship_ctx* c, size_t sl, int32_t kd, double fd, bool simple_k, int rpt, int nw, std::vector<d3>& P) {
     const uint32_t fi = c->sel[sl], grp = c->grp[sl];
     const rship_frame& fr = c->frames[fi];
-    P.resize(fr.n_rays);
+    const int threads = 64 * nw;
+    P.assign((size_t)rpt * threads, d3{0, 0, 0});
     for (uint32_t i = 0; i < fr.n_rays; ++i) row64(c, fr, i, kd, fd, P[i], nullptr);
     const int32_t pend = sl < c->init_h.size() ? c->init_h[sl] : kNone;
     if (!simple_k && pend == kNone) return;
@@ -493,116 +540,82 @@ void finish_slot(rship_ctx* c, size_t sl, int32_t kd, double fd, bool simple_k, 
         const double nn = std::sqrt(rs::dot(Mv, Mv));
         if (!(nn < 1e-12)) Mv = rs::scale(Mv, 1.0 / nn);
     }
-    double ss = 0;
-    for (const d3& p : P) {
-        const double pm = simple_k ? std::sqrt(rs::dot(p, p)) : rs::dot(p, Mv);
-        ss += pm * pm;
+    std::vector<double> part((size_t)threads, 0.0);
+    for (int t = 0; t < threads; ++t) {
+        double ss = 0.0;
+        for (int j = 0; j < rpt; ++j) {
+            const d3& p = P[(size_t)j * threads + t];
+            const double pm = simple_k ? std::sqrt(rs::dot(p, p)) : rs::dot(p, Mv);
+            ss = std::fma(pm, pm, ss);
+        }
+        part[t] = ss;
     }
+    const double tot = block_sum_order(part, nw);
     if (!simple_k) { c->M[3 * sl] = Mv.x; c->M[3 * sl + 1] = Mv.y; c->M[3 * sl + 2] = Mv.z; }
-    c->k[sl] = clampk64(100.0 / std::sqrt(ss));
+    c->k[sl] = rs::clamp_k64(100.0 / std::sqrt(tot));
     if (sl < c->init_h.size()) c->init_h[sl] = kNone;
 }
 
-// the kernel's L-BFGS (kernels/sync64.hpp: opt_motion64_kernel), sequential
+// MotionEval64 of kernels/sync64.hpp: the row terms of rs::motion_row per thread, the four sums in the
+// workgroup's order
+struct MotionEvalCpu {
+    const std::vector<d3>* P;
+    int rpt, nw;
+    double k2;
+    int evals = 0;
+    double operator()(const double x[3], double g[3]) {
+        const int threads = 64 * nw;
+        double xx;
+        const double inv_s = rs::motion_inv_s(x, k2, &xx);
+        std::vector<double> part[4];
+        for (auto& v : part) v.assign((size_t)threads, 0.0);
+        for (int t = 0; t < threads; ++t) {
+            double L = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            for (int j = 0; j < rpt; ++j) rs::motion_row((*P)[(size_t)j * threads + t], x, inv_s, L, a0, a1, a2);
+            part[0][t] = L; part[1][t] = a0; part[2][t] = a1; part[3][t] = a2;
+        }
+        double tsum[4];
+        for (int q = 0; q < 4; ++q) tsum[q] = block_sum_order(part[q], nw);
+        ++evals;
+        return rs::motion_finish(x, xx, tsum, g);
+    }
+};
+
+struct LbfgsHistCpu {
+    double s_S[rs::kLbfgsBasis][3], s_Y[rs::kLbfgsBasis][3], s_inv_ys[rs::kLbfgsBasis], s_rho[rs::kLbfgsBasis], s_alpha[rs::kLbfgsBasis];
+    const double* S(int i) const { return s_S[i]; }
+    const double* Y(int i) const { return s_Y[i]; }
+    double inv_ys(int i) const { return s_inv_ys[i]; }
+    double& rho(int i) { return s_rho[i]; }
+    double& alpha(int i) { return s_alpha[i]; }
+    void store(int op, const double sv[3], const double yv[3]) {
+        for (int c = 0; c < 3; ++c) { s_S[op][c] = sv[c]; s_Y[op][c] = yv[c]; }
+        s_inv_ys[op] = 1.0 / rs::dot3(yv, sv);
+    }
+};
+
+// opt_motion64_kernel, one slot after the other
 void motion_pass(rship_ctx* c, const int32_t* kdv, const double* fdv, int max_iters, bool simple_k, uint64_t* stats) {
     uint64_t tot_it = 0, tot_ev = 0, tot_bnl = 0;
+    int rpt = 1, nw = 1;
+    motion_shape(c, rpt, nw);
     for (size_t sl = 0; sl < c->sel.size(); ++sl) {
         const uint32_t grp = c->grp[sl];
         const int32_t kd = kdv[grp];
         const double fd = fdv[grp];
         if (fd != fd) continue; // window switched off
         std::vector<d3> P;
-        finish_slot(c, sl, kd, fd, simple_k, P);
+        finish_slot(c, sl, kd, fd, simple_k, rpt, nw, P);
         if (max_iters <= 0 || simple_k) continue;
-        const double k2 = c->k[sl] * c->k[sl];
-        int evals = 0;
-        auto ev = [&](const double x[3], double g[3]) {
-            ++evals;
-            const double xx = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
-            const double s = xx / k2;
-            const double inv_s = 1.0 / s;
-            double L = 0, a0 = 0, a1 = 0, a2 = 0;
-            for (const d3& p : P) {
-                const double px = p.x, py = p.y, pz = p.z;
-                const double pm = px * x[0] + py * x[1] + pz * x[2], v2 = pm * pm, u = v2 * inv_s;
-                double w; // 1 / (1 + u), from the kernel's own fp64 routine
-                L += rs::log1p_rcp_f64(u, &w);
-                const double a = w * 2.0 * pm * inv_s;
-                a0 += a * px; a1 += a * py; a2 += a * pz;
-            }
-            const double tt = (x[0] * a0 + x[1] * a1 + x[2] * a2) / xx; // the gradient is t without its part along x
-            g[0] = a0 - tt * x[0]; g[1] = a1 - tt * x[1]; g[2] = a2 - tt * x[2];
-            return L;
-        };
-        auto dot3 = [](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
-        constexpr int NB = 10;
-        double S[NB][3], Y[NB][3], rho[NB], alpha[NB];
-        double x[3] = {c->M[3 * sl], c->M[3 * sl + 1], c->M[3 * sl + 2]}, g[3], oldx[3], oldg[3], dir[3];
-        double fval = ev(x, g);
-        int it = 0;
-        for (; it != max_iters; ++it) {
-            const double prev = fval;
-            if (std::sqrt(dot3(g, g)) < 1e-4 || fval != fval) break;
-            double scale;
-            if (it > 0) {
-                int pp = (it - 1) % NB;
-                double yy = dot3(Y[pp], Y[pp]);
-                scale = dot3(S[pp], Y[pp]) / ((yy >= 1e-10) ? yy : 1.0);
-            } else {
-                double gn = std::sqrt(dot3(g, g));
-                scale = (gn >= 1e-5) ? 1.0 / gn : 1.0;
-            }
-            if (scale == 0.0 || scale != scale) break;
-            for (int q = 0; q < 3; ++q) dir[q] = g[q];
-            int limit = (NB > it) ? 0 : (it - NB);
-            for (int i = it; i != limit; --i) {
-                int tp = (i + NB - 1) % NB;
-                rho[it - i] = 1.0 / dot3(Y[tp], S[tp]);
-                alpha[it - i] = rho[it - i] * dot3(S[tp], dir);
-                for (int q = 0; q < 3; ++q) dir[q] -= alpha[it - i] * Y[tp][q];
-            }
-            for (int q = 0; q < 3; ++q) dir[q] *= scale;
-            for (int i = limit; i < it; ++i) {
-                int tp = i % NB;
-                double beta = rho[it - i - 1] * dot3(Y[tp], dir);
-                for (int q = 0; q < 3; ++q) dir[q] += (alpha[it - i - 1] - beta) * S[tp][q];
-            }
-            for (int q = 0; q < 3; ++q) { dir[q] = -dir[q]; oldx[q] = x[q]; oldg[q] = g[q]; }
-            const double dg0 = dot3(g, dir);
-            if (dg0 > 0.0) break;
-            const double f0 = fval, lin = 1e-4 * dg0;
-            double step = 1.0, bestStep = 1.0, bestObj = 1.79769313486231570e308, lastStep = 1.0;
-            int trials = 0;
-            for (;;) {
-                double xn[3] = {x[0] + step * dir[0], x[1] + step * dir[1], x[2] + step * dir[2]};
-                fval = ev(xn, g);
-                lastStep = step;
-                if (fval < bestObj) { bestStep = step; bestObj = fval; }
-                ++trials;
-                double width;
-                if (fval > f0 + step * lin) width = 0.5;
-                else {
-                    double dg = dot3(g, dir);
-                    if (dg < 0.9 * dg0) width = 2.1;
-                    else if (dg > -0.9 * dg0) width = 0.5;
-                    else break;
-                }
-                if (step < 1e-20 || step > 1e20 || trials >= 50) break;
-                step *= width;
-            }
-            for (int q = 0; q < 3; ++q) x[q] += bestStep * dir[q];
-            if (bestStep != lastStep) {
-                ++tot_bnl;
-                if (c->lbfgs_reeval) fval = ev(x, g);
-            }
-            if (bestStep == 0.0) break;
-            if ((prev - fval) / std::fmax(std::fmax(std::fabs(prev), std::fabs(fval)), 1.0) <= 1e-15) break;
-            int op = it % NB;
-            for (int q = 0; q < 3; ++q) { S[op][q] = x[q] - oldx[q]; Y[op][q] = g[q] - oldg[q]; }
-        }
+        MotionEvalCpu ev{&P, rpt, nw, c->k[sl] * c->k[sl]};
+        LbfgsHistCpu hist;
+        double x[3] = {c->M[3 * sl], c->M[3 * sl + 1], c->M[3 * sl + 2]};
+        int bnl = 0;
+        const int it = rs::lbfgs3(ev, hist, x, max_iters, c->lbfgs_reeval, &bnl);
         c->M[3 * sl] = x[0]; c->M[3 * sl + 1] = x[1]; c->M[3 * sl + 2] = x[2];
         tot_it += (uint64_t)it;
-        tot_ev += (uint64_t)evals;
+        tot_ev += (uint64_t)ev.evals;
+        tot_bnl += (uint64_t)bnl;
     }
     if (stats) { stats[0] = tot_it; stats[1] = tot_ev; stats[2] = tot_bnl; }
 }
@@ -636,25 +649,22 @@ int rship_loss_enqueue(rship_ctx* c, const int32_t* kd, const double* fd, uint32
             const double fdw = fd[b * ng + w];
             for (uint32_t sl = c->grp_off[w]; fdw == fdw && sl < c->grp_off[w + 1]; ++sl) {
                 const rship_frame& fr = c->frames[c->sel[sl]];
-                const double Mx = c->M[3 * sl], My = c->M[3 * sl + 1], Mz = c->M[3 * sl + 2], kk = c->k[sl];
+                const double Mx = simple ? 0.0 : c->M[3 * sl], My = simple ? 0.0 : c->M[3 * sl + 1], Mz = simple ? 0.0 : c->M[3 * sl + 2];
+                const double kk = c->k[sl];
                 const d3 Mv{Mx, My, Mz};
-                const double inv_s = simple ? kk * kk : kk * kk / (Mx * Mx + My * My + Mz * Mz);
-                double Lf = 0, Gf = 0;
+                const double inv_s = rs::loss_inv_s(simple, kk, Mv);
+                // loss64_kernel: 256 threads, thread tid takes rows tid, tid + 256, ...; wave sums; waves in order
+                std::vector<double> Lt(256, 0.0), Gt(256, 0.0);
                 for (uint32_t i = 0; i < fr.n_rays; ++i) {
-                    d3 P, dP;
+                    d3 P, dP{0, 0, 0};
                     row64(c, fr, i, kdw, fdw, P, want_grad ? &dP : nullptr);
-                    double wgt;
-                    if (simple) {
-                        Lf += rs::log1p_rcp_f64(rs::dot(P, P) * inv_s, &wgt);
-                        if (want_grad) Gf += wgt * 2.0 * inv_s * rs::dot(P, dP);
-                    } else {
-                        const double pm = rs::dot(P, Mv), u = pm * pm * inv_s;
-                        Lf += rs::log1p_rcp_f64(u, &wgt);
-                        if (want_grad) Gf += wgt * 2.0 * pm * inv_s * rs::dot(dP, Mv);
-                    }
+                    double& L = Lt[i & 255u];
+                    double& G = Gt[i & 255u];
+                    if (simple) { if (want_grad) rs::loss_row<true, true>(P, dP, Mv, inv_s, L, G); else rs::loss_row<false, true>(P, dP, Mv, inv_s, L, G); }
+                    else { if (want_grad) rs::loss_row<true, false>(P, dP, Mv, inv_s, L, G); else rs::loss_row<false, false>(P, dP, Mv, inv_s, L, G); }
                 }
-                part[(size_t)b * ns + sl] = Lf;
-                if (want_grad) part[(size_t)(n_delays + b) * ns + sl] = Gf * c->fs;
+                part[(size_t)b * ns + sl] = block_sum_order(Lt, 4);
+                if (want_grad) part[(size_t)(n_delays + b) * ns + sl] = block_sum_order(Gt, 4) * c->fs;
             }
         }
     }
@@ -728,6 +738,33 @@ int rship_debug_problem64(rship_ctx* c, uint32_t sel_index, int32_t kd, double f
         P[3 * i] = p.x; P[3 * i + 1] = p.y; P[3 * i + 2] = p.z;
         if (dP) { dP[3 * i] = d.x * c->fs; dP[3 * i + 1] = d.y * c->fs; dP[3 * i + 2] = d.z * c->fs; }
     }
+    return 0;
+}
+
+int rship_debug_math64(rship_ctx* c, int op, const double* a, const double* b, double* out, uint32_t n) {
+    if (op < 0 || op > 4 || !n) return fail(c, "debug_math64: bad arguments");
+    if (op == 4) {
+        for (uint32_t blk = 0; blk < (n + 63) / 64; ++blk) {
+            double lanes[64];
+            for (uint32_t l = 0; l < 64; ++l) lanes[l] = blk * 64 + l < n ? a[blk * 64 + l] : 0.0;
+            out[blk] = wave_sum_order(lanes);
+        }
+        return 0;
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        const double x = a[i], y = b ? b[i] : 0.0;
+        if (op == 0) out[i] = x / y;
+        else if (op == 1) out[i] = std::sqrt(x);
+        else if (op == 2) { double rc; out[2 * i] = rs::log1p_rcp_f64(x, &rc); out[2 * i + 1] = rc; }
+        else out[i] = std::fma(x, y, x);
+    }
+    return 0;
+}
+
+int rship_debug_init_h(rship_ctx* c, int32_t* get, const int32_t* set, uint32_t n) {
+    if (n != c->sel.size() || c->init_h.size() != n) return fail(c, "debug_init_h: count differs from the selection");
+    if (get) std::copy(c->init_h.begin(), c->init_h.end(), get);
+    if (set) c->init_h.assign(set, set + n);
     return 0;
 }
 

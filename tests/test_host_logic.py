@@ -131,7 +131,13 @@ def test_reduce_hook_is_called_twice_per_outer_iteration(host, tiny_case):
     calls = []
     h.set_reduce_hook(lambda a: calls.append(len(a)))
     h.PreSync(0.0, 0, F, 0.01, 0.05)
-    assert len(calls) == 1 and calls[0] == 10 + 4      # candidate costs + 4 status flags, one exchange
+    # without a hint the ranks first agree on the size class of the largest frame (149 slots), then the sweep:
+    # candidate costs + 4 status flags in one exchange
+    assert calls == [149, 10 + 4]
+    calls.clear()
+    h.set_tracks_hint(tiny_case["N"])                  # given by the caller: no agreement exchange
+    h.PreSync(0.0, 0, F, 0.01, 0.05)
+    assert calls == [10 + 4]
     calls.clear()
     h.Sync(0.036, 0, F - 1, 0.0, 0.2)
     iters = len(h.sync_trace())
@@ -276,6 +282,7 @@ def test_pre_sync_windows_equal_separate_presync_calls(host, tiny_case):
         assert costs[w] == pytest.approx(c, rel=1e-14, abs=0)
     calls = []
     h.set_reduce_hook(lambda a: calls.append(len(a)))
+    h.set_tracks_hint(tiny_case["N"])                 # (otherwise every call starts with the size-class agreement)
     h.pre_sync_windows(0.03, b, e, 0.004, 0.04)
     assert calls == [20 * len(b) + 4]                 # one exchange for all windows
     calls.clear()
