@@ -261,6 +261,10 @@ int rship_debug_math64(rship_ctx* c, int op, const double* a, const double* b, d
  * rship_init_motion: copy them out (get) and / or replace them (set); either may be NULL */
 int rship_debug_init_h(rship_ctx* c, int32_t* get, const int32_t* set, uint32_t n);
 
+/* per-wave trip counts of the LMedS tile kernel's stage C (builds with -DRSSYNC_K2_COUNTERS=1; zeros otherwise):
+ * see kernels/lmeds.hpp for the meaning of the 16 slots */
+int rship_debug_k2_counters(rship_ctx* c, uint64_t out[16], int reset);
+
 /* HIP-event timing of every launch, accumulated per kernel kind */
 int rship_profile_enable(rship_ctx* c, int on);
 int rship_profile_get(rship_ctx* c, int kind, uint64_t* launches, double* total_ms);

@@ -83,6 +83,9 @@ def load():
     lib.ora_lbfgs_motion.argtypes = [C.c_void_p, C.c_int64, C.c_double, _PD, C.c_double, _PI, _PI, _PD]
     lib.ora_sync_trace.argtypes = [C.c_void_p, C.c_double, C.c_int64, C.c_int64, C.c_double, C.c_double, _PD, _PD,
                                    _PD, C.c_int, _PI]
+    lib.ora_set_init_override.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_size_t]
+    lib.ora_last_init_winners.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_size_t]
+    lib.ora_last_init_winners.restype = C.c_size_t
     lib.ora_sync_state.argtypes = [C.c_void_p, _PD, _PD, C.c_int, _PI]
     lib.ora_sync_simplified_trace.argtypes = lib.ora_sync_trace.argtypes
     lib.ora_loss_simplified.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_double, _PD, _PD, _PD]
@@ -317,6 +320,17 @@ class OracleProblem:
         self._check(self._lib.ora_loss_simplified(self._h, int(frame), float(delay_k), float(delay), C.byref(k),
                                                   C.byref(L), C.byref(g)))
         return k.value, L.value, g.value
+
+    def set_init_override(self, winners):
+        """test hook: these hypothesis indices instead of GuessMotion's search in the next Sync"""
+        w = np.ascontiguousarray(winners, np.int32)
+        self._lib.ora_set_init_override(self._h, w.ctypes.data_as(C.POINTER(C.c_int32)), w.size)
+
+    def last_init_winners(self):
+        n = self._lib.ora_last_init_winners(self._h, None, 0)
+        out = np.zeros(n, np.int32)
+        self._lib.ora_last_init_winners(self._h, out.ctypes.data_as(C.POINTER(C.c_int32)), n)
+        return out
 
     def sync_state(self, cap=1 << 16):
         M, k, n = np.zeros((cap, 3)), np.zeros(cap), C.c_int()

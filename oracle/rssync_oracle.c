@@ -9,6 +9,7 @@
 #include "rssync_oracle.h"
 
 #include <math.h>
+#include <stdint.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -41,6 +42,12 @@ struct ora_problem {
     int nthreads, max_outer, faithful, verbose, lbfgs_reeval;
     long lbfgs_best_not_last; /* line searches whose best step was not the last one tried */
     uint32_t sync_calls;
+    /* test hooks: GuessMotion's winning hypothesis per selected frame of the last Sync, and winners to use
+     * instead of the search in the next one (so that two implementations can be started from the same estimates) */
+    int32_t* last_init;
+    size_t n_last_init;
+    int32_t* init_override;
+    size_t n_init_override;
     /* frames selected by the last Sync (indices into frames) */
     size_t* sel;
     size_t nsel;
@@ -76,6 +83,8 @@ void ora_destroy(ora_problem* p) {
     for (size_t i = 0; i < p->nframes; ++i) frame_free(&p->frames[i]);
     free(p->frames);
     free(p->sel);
+    free(p->last_init);
+    free(p->init_override);
     free(p);
 }
 
@@ -1004,7 +1013,20 @@ static void sync_init_fn(void* vctx, size_t i) {
         free(buf);
         return;
     }
-    guess_motion(buf, n, 200, c->p->seed, f->id, c->stream, buf + 3 * n, buf + 6 * n, f->M, NULL, NULL); /* :125-128 */
+    int bh = -1;
+    if (c->p->init_override) { /* test hook: this hypothesis instead of the search's winner */
+        bh = c->p->init_override[i];
+        f->M[0] = f->M[1] = f->M[2] = 0;
+        if (bh >= 0) {
+            uint32_t i0, i1;
+            ora_sample_pair(c->p->seed, f->id, c->stream, (uint32_t)bh, (uint32_t)n, &i0, &i1);
+            cross3(buf + 3 * i0, buf + 3 * i1, f->M); /* :45-46 */
+            safe_normalize3(f->M);
+        }
+    } else {
+        guess_motion(buf, n, 200, c->p->seed, f->id, c->stream, buf + 3 * n, buf + 6 * n, f->M, &bh, NULL); /* :125-128 */
+    }
+    if (c->p->last_init) c->p->last_init[i] = bh;
     if (c->p->faithful) compute_problem(c->p, f, c->delay, buf); /* :131 recomputes P */
     double ss = 0;
     for (size_t j = 0; j < n; ++j) {
@@ -1080,7 +1102,18 @@ static int sync_trace_impl(ora_problem* p, int simplified, double initial_delay,
     double d = initial_delay;
     sync_ctx ctx = {p, d, ORA_STREAM_SYNC_INIT + p->sync_calls, fl, fg, 0, simplified};
     if (!simplified) p->sync_calls++;
+    if (p->init_override && p->n_init_override != nf) {
+        free(fl); free(fg);
+        return fail(p, "init override: count differs from the selected frames");
+    }
+    free(p->last_init);
+    p->last_init = (int32_t*)malloc((nf ? nf : 1) * sizeof(int32_t));
+    p->n_last_init = nf;
+    for (size_t i = 0; i < nf; ++i) p->last_init[i] = INT32_MIN;
     parallel_for(p->nthreads, nf, sync_init_fn, &ctx);
+    free(p->init_override); /* for one call only */
+    p->init_override = NULL;
+    p->n_init_override = 0;
 
     const double c_armijo = 2e-4, decay = .1, t0 = 1e-3; /* :226 */
     const int max_bt = 10;
@@ -1127,6 +1160,18 @@ static int sync_trace_impl(ora_problem* p, int simplified, double initial_delay,
     if (n_rows) *n_rows = rows;
     free(fl); free(fg);
     return 0;
+}
+
+void ora_set_init_override(ora_problem* p, const int32_t* winners, size_t n) {
+    free(p->init_override);
+    p->init_override = (int32_t*)malloc((n ? n : 1) * sizeof(int32_t));
+    memcpy(p->init_override, winners, n * sizeof(int32_t));
+    p->n_init_override = n;
+}
+
+size_t ora_last_init_winners(const ora_problem* p, int32_t* out, size_t cap) {
+    for (size_t i = 0; i < p->n_last_init && i < cap; ++i) out[i] = p->last_init[i];
+    return p->n_last_init;
 }
 
 int ora_sync_trace(ora_problem* p, double initial_delay, int64_t frame_begin,

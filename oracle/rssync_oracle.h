@@ -119,6 +119,10 @@ int ora_loss(const ora_problem* p, int64_t frame, double delay, const double M[3
 int ora_lbfgs_motion(const ora_problem* p, int64_t frame, double delay, double M[3], double k,
                      int* iters, int* evals, double* final_loss);
 /* Sync with a per-outer-iteration trace: rows of {delay_after, step, loss_at_x0, t} */
+/* test hooks: GuessMotion's winning hypothesis index per selected frame of the last Sync (INT32_MIN: simplified
+ * mode), and a list of winners to use in place of the search in the NEXT Sync only */
+void ora_set_init_override(ora_problem* p, const int32_t* winners, size_t n);
+size_t ora_last_init_winners(const ora_problem* p, int32_t* out, size_t cap);
 int ora_sync_trace(ora_problem* p, double initial_delay, int64_t frame_begin,
                    int64_t frame_end, double search_center, double search_radius, double* cost,
                    double* delay, double* trace, int cap, int* n_rows);

@@ -194,10 +194,16 @@ RS_HD float log1p_pos(float u) {
 // Same with the hardware logarithm (v_log_f32, about 1 ulp of log2) in place of libm's logf: 7
 // instructions.  Used only for the PreSync cost, which is compared between candidates, never
 // differentiated or line-searched.
+#ifndef RSSYNC_K2_D_NORCP
+#define RSSYNC_K2_D_NORCP 0
+#endif
 RS_HD float log1p_pos_fast(float u) {
     const float w = 1.0f + u;
     const float c = (w - 1.0f) - u;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && RSSYNC_K2_D_NORCP
+    // measured variant: 1/w as max(2 - w, 0) (the correction c / w only matters while w is close to 1)
+    return fmaf(__builtin_amdgcn_logf(w), 0.69314718055994531f, -c * fmaxf(2.0f - w, 0.f));
+#elif defined(__HIP_DEVICE_COMPILE__)
     return fmaf(__builtin_amdgcn_logf(w), 0.69314718055994531f, -c * rcp_fast(w));
 #else
     return log2f(w) * 0.69314718055994531f - c * rcp_fast(w);

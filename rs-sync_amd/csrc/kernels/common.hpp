@@ -147,8 +147,18 @@ __device__ __forceinline__ rs::Knot locate_sweep(float t, int base, float fd) {
 
 // one row of P = ar x br (core_private.cpp:24-28) and, if DERIV, dP/dx (x in knots).
 // A = {ax,bx,ay,by}, B = {az,bz,ta,tb} as stored in HBM.
-template <bool DERIV, int PATH, bool SWEEP = false, int CAP = kWinMax>
-__device__ __forceinline__ void residual_row(const Spline& s, f4 A, f4 B, int base, float fd, f3& P, f3& dP) {
+// NEWTON (hot path only): the interpolated quaternions are within ~1e-5 of unit length (unit knots a few
+// milliradians apart), so 1/|q|^2 = 2 - |q|^2 up to (1 - |q|^2)^2 -- below fp32 rounding while |1 - |q|^2| < 2^-12
+// -- and the two v_rcp_f32 (quarter rate) with their clamps become one packed fma.  *qerr collects
+// max |1 - |q|^2| over the rows a thread computes; the caller redoes them without NEWTON if any lane of the
+// wave exceeds kNewtonMaxErr (non-unit knots: the reference normalises whatever it is given, ndspline.cpp:21-27).
+#ifndef RSSYNC_K2_NEWTON
+#define RSSYNC_K2_NEWTON 1
+#endif
+constexpr float kNewtonMaxErr = 2.44140625e-4f; // 2^-12: (2^-12)^2 = 2^-24 relative, half an fp32 ulp
+
+template <bool DERIV, int PATH, bool SWEEP = false, int CAP = kWinMax, bool NEWTON = false>
+__device__ __forceinline__ void residual_row(const Spline& s, f4 A, f4 B, int base, float fd, f3& P, f3& dP, float* qerr = nullptr) {
     f4 ya, ba, ca, da, yb, bb, cb, db;
     rs::Knot ka = (PATH == kPathInterior) ? (SWEEP ? locate_sweep(B.z, base, fd) : rs::spline_locate_interior(B.z, base, fd))
                                           : rs::spline_locate(B.z, base, fd, s.n);
@@ -175,7 +185,14 @@ __device__ __forceinline__ void residual_row(const Spline& s, f4 A, f4 B, int ba
         const v2f n2 = qw * qw + qx * qx + qy * qy + qz * qz;
         // R(q/|q|)^T v = v + (2/|q|^2) (u x (u x v) - w (u x v)), u = (qx,qy,qz)  (rs::rotate_inv);
         // |q|^2 = 0 leaves v unchanged (u = 0 times a large finite factor)
-        const v2f sc = {2.f * rs::rcp_fast(fmaxf(n2.x, 1e-30f)), 2.f * rs::rcp_fast(fmaxf(n2.y, 1e-30f))};
+        v2f sc;
+        if (NEWTON) {
+            const v2f e = v2f{1.f, 1.f} - n2;
+            sc = e * 2.f + v2f{2.f, 2.f}; // 2 (2 - n2)
+            *qerr = __builtin_fmaxf(*qerr, __builtin_fmaxf(__builtin_fabsf(e.x), __builtin_fabsf(e.y)));
+        } else {
+            sc = v2f{2.f * rs::rcp_fast(fmaxf(n2.x, 1e-30f)), 2.f * rs::rcp_fast(fmaxf(n2.y, 1e-30f))};
+        }
         const v2f tx = qy * vz - qz * vy, ty = qz * vx - qx * vz, tz = qx * vy - qy * vx;
         const v2f ux = qy * tz - qz * ty, uy = qz * tx - qx * tz, uz = qx * ty - qy * tx;
         const v2f rx = vx + sc * (ux - qw * tx), ry = vy + sc * (uy - qw * ty), rz = vz + sc * (uz - qw * tz);

@@ -4,6 +4,21 @@
 
 namespace {
 
+// Dynamic trip counts for the instruction budget of K2 (profiles/r3_k2_budget.md): a variant build
+// (-DRSSYNC_K2_COUNTERS=1, tools/k2_build_variant.sh) counts, per wave, how often each part of stage C runs.
+#ifndef RSSYNC_K2_COUNTERS
+#define RSSYNC_K2_COUNTERS 0
+#endif
+#if RSSYNC_K2_COUNTERS
+__device__ unsigned long long g_k2_counters[16];
+#define K2_COUNT(i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_k2_counters[i], 1ull); } while (0)
+#else
+#define K2_COUNT(i) do { } while (0)
+#endif
+// 0 (frame, candidate) pairs   1 queue pops   2 hypotheses swept   3 sweeps that beat the bound (exact selections)
+// 4 counting passes inside the exact selection   5 selections ended by the single-element min pass
+// 6 candidates redone without the provisional bound   7 sweeps that started without any bound (wave max)
+
 // ---------------------------------------------------------------------------
 // K2: LMedS tile kernel
 
@@ -119,6 +134,7 @@ __device__ __forceinline__ uint32_t select_kth(const uint32_t (&r)[NR], uint32_t
     for (int it = 0;; ++it) {
         if (hi - lo == 1u) return lo;
         if (c_hi - c_lo == 1u) {
+            K2_COUNT(5);
             // the single element in [lo, hi): smallest |x| >= lo; |x| < lo wraps to a huge difference
             uint32_t mn = 0xffffffffu;
 #pragma unroll
@@ -145,6 +161,7 @@ __device__ __forceinline__ uint32_t select_kth(const uint32_t (&r)[NR], uint32_t
         }
         if (!(piv > lo && piv < hi)) piv = lo + ((hi - lo) >> 1); // bit bisection: guaranteed finish
         const uint32_t c = wave_count_lt(r, piv);
+        K2_COUNT(4);
         a1 = a2; c1 = c2;
         a2 = piv; c2 = c;
         if (c <= kq) { lo = piv; c_lo = c; }
@@ -184,14 +201,14 @@ __device__ __forceinline__ f4 load_ray(__amdgpu_buffer_rsrc_t rs_, uint32_t voff
 // stage A of the LMedS kernel: this thread's rows of P for one delay, written to the LDS tile as
 // unit rows, norms kept in nrm[]; returns RSHIP_BAD_P if a row is not finite.  Rows >= N are not
 // touched: the kernel fills them with NaN once (their residuals compare above every threshold).
-template <int PATH, bool SWEEP, int CAP>
+template <int PATH, bool SWEEP, int CAP, bool NEWTON = false>
 __device__ __forceinline__ uint32_t lmeds_row(const Spline& sp, f4 A, f4 B, uint32_t N, uint32_t row, int base, float fd,
-                                              const Tile& tile, float& nrm) {
+                                              const Tile& tile, float& nrm, float* qerr = nullptr) {
     uint32_t bad = 0;
     nrm = 0.f;
     if (row < N) {
         f3 P, dP;
-        residual_row<false, PATH, SWEEP, CAP>(sp, A, B, base, fd, P, dP);
+        residual_row<false, PATH, SWEEP, CAP, NEWTON>(sp, A, B, base, fd, P, dP, qerr);
         const float n2 = rs::dot(P, P);
         if (!finite_f(n2)) bad = RSHIP_BAD_P;
         // safe_normalize (core_private.cpp:35-36): rows with |P| < 1e-12 stay as they are
@@ -209,11 +226,30 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
     uint32_t bad = 0;
     const uint32_t voff = threadIdx.x * 16u;
     if (sp.path == kPathInterior) {
+#if RSSYNC_K2_NEWTON
+        float qerr = 0.f; // max |1 - |q|^2| over this thread's rows (NaN never raises it: such rows are flagged by their P)
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const f4 A = load_ray(rays.a, voff, (uint32_t)j * kBlock * 16u), B = load_ray(rays.b, voff, (uint32_t)j * kBlock * 16u);
+            bad |= lmeds_row<kPathInterior, SWEEP, CAP, true>(sp, A, B, N, j * kBlock + threadIdx.x, base, fd, tile, nrm[j], &qerr);
+        }
+        if (__builtin_amdgcn_ballot_w64(qerr >= kNewtonMaxErr) != 0) { // never, for orientations: redo with the reciprocal
+            bad = 0;
+#pragma unroll 1
+            for (int j = 0; j < RPT; ++j) {
+                const f4 A = load_ray(rays.a, voff, (uint32_t)j * kBlock * 16u), B = load_ray(rays.b, voff, (uint32_t)j * kBlock * 16u);
+                float t;
+                bad |= lmeds_row<kPathInterior, SWEEP, CAP, false>(sp, A, B, N, j * kBlock + threadIdx.x, base, fd, tile, t);
+                nrm[j] = t;
+            }
+        }
+#else
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const f4 A = load_ray(rays.a, voff, (uint32_t)j * kBlock * 16u), B = load_ray(rays.b, voff, (uint32_t)j * kBlock * 16u);
             bad |= lmeds_row<kPathInterior, SWEEP, CAP>(sp, A, B, N, j * kBlock + threadIdx.x, base, fd, tile, nrm[j]);
         }
+#endif
     } else { // rare (ends of the gyro track, wild delays): keep the code small, not fast
         float tmp[RPT];
 #pragma unroll 1
@@ -233,6 +269,14 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
 // dense tracker is accepted instead of refused.
 __host__ __device__ constexpr int lmeds_waves(int rpt) { return rpt <= 8 ? 5 : (rpt == 16 ? 2 : 1); }
 __host__ __device__ constexpr int loss_waves(int rpt, bool grad) { return (grad || rpt >= 8) ? 3 : 4; }
+
+// Measured variant (-DRSSYNC_K2_PAIRS=1): the hypotheses' row pairs depend only on (seed, frame id, stream, h, N),
+// not on the data, so all 256 threads draw them for kPairSpan candidates at once into LDS (u16 pairs) and the
+// twenty lanes that build the directions read them there instead of running the 64-bit sampler.
+#ifndef RSSYNC_K2_PAIRS
+#define RSSYNC_K2_PAIRS 0
+#endif
+constexpr int kPairCap = 220; // pairs held in LDS (880 B: the kernel stays under five workgroups' worth of a CU's LDS)
 
 constexpr int kMaxChunk = 32; // candidates per workgroup (rship: chunk <= kMaxChunk); 64 and 100 measured: no change
 constexpr int kHypBatch = 64; // hypothesis directions prepared per batch (one per lane of wave 0)
@@ -274,6 +318,9 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     // "smaller quantile wins, ties go to the earlier hypothesis" (core_private.cpp:53 strict <)
     __shared__ unsigned long long s_key;
     __shared__ uint32_t s_next; // hypothesis queue of the current batch
+#if RSSYNC_K2_PAIRS
+    __shared__ uint32_t s_pairs[kPairCap];
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     // blocks b and b+8 share an XCD (round-robin dispatch): keep the chunks of one
     // frame on one XCD so its rays are fetched into one L2 only
@@ -330,11 +377,28 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     const f4* p4z = reinterpret_cast<const f4*>(tile.nz);
     uint32_t prev_best = kInfBits; // winning quantile of the previous candidate of this chunk
 
+#if RSSYNC_K2_PAIRS
+    const uint32_t pair_span = (p.n_hyp <= (uint32_t)kPairCap) ? (uint32_t)kPairCap / p.n_hyp : 0u; // candidates per refill
+    uint32_t pair_c0 = c0;
+#endif
     for (uint32_t c = c0; c < c1; ++c) {
         const int base = fr.base_knot + s_kd[c - c0];
         const float fd = s_fd[c - c0];
         const uint32_t stream = p.stream_base + c + g * p.stream_stride; // g != 0 only for batched GuessMotion
         uint32_t bad = 0;
+#if RSSYNC_K2_PAIRS
+        if (pair_span && (c == c0 || c - pair_c0 == pair_span)) {
+            // (the readers of the previous span finished before the barriers of the previous candidate's stage D)
+            pair_c0 = c;
+            const uint32_t n_c = (c1 - c < pair_span) ? c1 - c : pair_span;
+            for (uint32_t e = tid; e < n_c * p.n_hyp; e += kBlock) {
+                const uint32_t cc = e / p.n_hyp, h = e % p.n_hyp;
+                uint32_t i0, i1;
+                rs::sample_pair(p.seed, fr.id, p.stream_base + (c + cc) + g * p.stream_stride, h, N, i0, i1);
+                s_pairs[e] = i0 | (i1 << 16);
+            }
+        }
+#endif
         // ---- stage A: rows of P -> LDS tile as unit rows; norms stay in registers ----
         float nrm[RPT];
         bad |= lmeds_rows<RPT, MODE == 0, WIN>(sp, rays, N, base, fd, tile, nrm);
@@ -354,14 +418,29 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                 const uint32_t nb = (p.n_hyp - batch < (uint32_t)kHyp) ? p.n_hyp - batch : (uint32_t)kHyp;
                 __syncthreads(); // tile written / previous batch consumed
                 if ((uint32_t)tid < nb) {
+#if RSSYNC_K2_PAIRS
+                    f3 v;
+                    if (pair_span) {
+                        const uint32_t pr = s_pairs[(c - pair_c0) * p.n_hyp + batch + tid];
+                        const uint32_t i0 = pr & 0xffffu, i1 = pr >> 16;
+                        v = rs::cross(f3{tile.nx[i0], tile.ny[i0], tile.nz[i0]}, f3{tile.nx[i1], tile.ny[i1], tile.nz[i1]});
+                        const float nn = sqrtf(rs::dot(v, v));
+                        if (!(nn < 1e-12f)) v = rs::scale(v, 1.0f / nn);
+                    } else {
+                        v = hypothesis(tile, p.seed, fr.id, stream, batch + tid, N);
+                    }
+#else
                     const f3 v = hypothesis(tile, p.seed, fr.id, stream, batch + tid, N);
+#endif
                     s_hyp[tid] = f4{v.x, v.y, v.z, 0.f};
                 }
                 if (tid == 0) s_next = 0;
                 __syncthreads();
                 for (;;) { // waves pull hypotheses from the queue: no wave idles at the barrier
                     const uint32_t j = wave_pop(&s_next);
+                    K2_COUNT(1);
                     if (j >= nb) break;
+                    K2_COUNT(2);
                     const uint32_t h = batch + j;
                     const f4 hv = s_hyp[j];
                     // residuals r = nP v (core_private.cpp:48); |r| orders like the r^2 of :49-52
@@ -386,7 +465,9 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                     uint32_t hi2 = T + ((T != kInfBits && g > h) ? 1u : 0u);
                     const uint32_t tot = wave_count_lt(r2, hi2);
                     if (tot > kq) {
+                        K2_COUNT(3);
                         if (hi2 == kInfBits) { // no bound yet: start the bracket at the largest residual
+                            K2_COUNT(7);
                             float mx = 0.f;
 #pragma unroll
                             for (int m = 0; m < NR; ++m) mx = fmaxf(mx, fabsf(__uint_as_float(r2[m])));
@@ -402,11 +483,13 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
             best = s_key;
             if (guess == kInfBits || best != ((unsigned long long)guess << 32)) break;
             guess = kInfBits; // nothing beat the provisional bound: redo this candidate without it
+            if (tid == 0) K2_COUNT(6);
             __syncthreads();  // everyone has read s_key before it is reset
         }
         const uint32_t bT = (uint32_t)(best >> 32);
         const int bH = (bT == kInfBits) ? -1 : (int)(uint32_t)best;
         prev_best = bT;
+        if (tid == 0) K2_COUNT(0);
         f3 Mv = f3{0, 0, 0};
         if (bH >= 0) {
             if (p.n_hyp <= (uint32_t)kHyp) { // the winner's direction is still in the batch buffer

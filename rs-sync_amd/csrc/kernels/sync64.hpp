@@ -206,7 +206,10 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
         double L[NB], G[NB];
 #pragma unroll
         for (int q = 0; q < NB; ++q) L[q] = G[q] = 0.0;
-#pragma unroll 1
+#ifndef RSSYNC_K1_UNROLL
+#define RSSYNC_K1_UNROLL 1
+#endif
+#pragma unroll RSSYNC_K1_UNROLL
         for (int j = 0; j < RPT; ++j) {
             const uint32_t row = j * kBlock + tid;
             if (row < N) {
@@ -281,6 +284,13 @@ struct Motion64Params {
     uint32_t stream_base, stream_stride; // sampler stream = base + group * stride
     int simple_k; // 1: k = clamp(100 / sqrt(sum |P_j|^2)) only (no-translation variant), no M, no optimisation
     uint32_t slot0; // the launch covers slots slot0 .. slot0 + gridDim.x
+    // Longest first: workgroup b of the launch takes slot order[slot0 + b] (null: slot0 + b), a permutation of the
+    // launch's slots sorted by how many evaluations each needed in the previous launch (motion_order_kernel); a
+    // launch is as long as its slowest frame plus whatever is queued behind it, and the frames that need 60
+    // evaluations instead of 20 are the same ones from one outer iteration to the next.  Which workgroup computes a
+    // slot changes nothing in the slot's result.
+    const uint32_t* order;
+    uint32_t* evals_out; // [n_sel]: evaluations of this launch per slot (input of the next ordering), or null
 };
 
 constexpr int kInitNone = (int)0x80000000;
@@ -367,14 +377,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (RPT <= 8 ? 3 : (RPT == 16 ? 2 :
     __shared__ double s_inv_ys[kNB]; // 1 / (y . s) of each stored pair: the value the two-loop recursion divides for
     __shared__ double s_red[NW];
     const int tid = threadIdx.x;
-    const uint32_t sf = blockIdx.x + p.slot0;
+    const uint32_t sf = p.order ? p.order[blockIdx.x + p.slot0] : blockIdx.x + p.slot0;
     const uint32_t fi = p.sel[sf];
     const FrameRec fr = p.frames[fi];
     const uint32_t N = fr.n;
     const uint32_t grp = p.grp ? p.grp[sf] : 0u;
     const int kd = p.kd[grp];
     const double fd = p.fd[grp];
-    if (fd != fd) return; // this window is not being optimised in this call (workgroup-uniform)
+    if (fd != fd) { // this window is not being optimised in this call (workgroup-uniform)
+        if (tid == 0 && p.evals_out) p.evals_out[sf] = 0;
+        return;
+    }
 
     Spline64 sp;
     sp.g = p.coef;
@@ -451,6 +464,36 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (RPT <= 8 ? 3 : (RPT == 16 ? 2 :
             p.per_frame[2 * sf] = (uint32_t)it;
             p.per_frame[2 * sf + 1] = (uint32_t)ev.evals;
         }
+        if (p.evals_out) p.evals_out[sf] = (uint32_t)ev.evals;
+    }
+}
+
+// order[slot0 .. slot0 + count) = the slots slot0 .. slot0 + count sorted by evals[] descending (a counting sort over
+// min(evals, 255) in one workgroup; the order among equal counts is whatever the atomics give -- it only decides
+// which workgroup computes which slot)
+__global__ __launch_bounds__(1024) void motion_order_kernel(const uint32_t* __restrict__ evals, uint32_t* __restrict__ order,
+                                                            uint32_t slot0, uint32_t count) {
+    __shared__ uint32_t s_bin[256];
+    for (uint32_t b = threadIdx.x; b < 256; b += blockDim.x) s_bin[b] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+        const uint32_t e = evals[slot0 + i];
+        atomicAdd(&s_bin[e < 255u ? e : 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { // start of each bin, largest count first
+        uint32_t at = 0;
+        for (int b = 255; b >= 0; --b) {
+            const uint32_t n = s_bin[b];
+            s_bin[b] = at;
+            at += n;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+        const uint32_t e = evals[slot0 + i];
+        const uint32_t pos = atomicAdd(&s_bin[e < 255u ? e : 255u], 1u);
+        order[slot0 + pos] = slot0 + i;
     }
 }
 

@@ -79,6 +79,11 @@ struct rship_ctx {
     std::string err;
     // problem data
     DevBuf coef, coef64, raw, rays_a, rays_b, rays64, frames, sel, M, k, grp, grp_off, init_h;
+    DevBuf mo_evals, mo_order; // per slot: evaluations of the last motion launch; launch order (longest first)
+    // mo_order is a permutation of each of these slot ranges (the ranges the motion launches of the last call covered);
+    // mo_identity: it is the identity, hence a permutation of any range
+    std::vector<std::pair<uint32_t, uint32_t>> mo_ranges;
+    bool mo_identity = false;
     // reduction plan (rship_set_plan): windows -> chunks -> slots
     DevBuf plan_idx, plan_chunk_off, plan_win_off, chunk_out, win_out;
     uint32_t plan_max_chunks = 0; // most chunks in one window
@@ -280,6 +285,8 @@ int launch_loss64(rship_ctx* c, const Loss64Params& p, int rpt, hipStream_t st =
 // The workgroup shape of the motion kernel follows the LARGEST frame of the whole problem (all devices:
 // RSHIP_OPT_TRACKS_HINT), not of the selection at hand: the shape fixes the order in which a frame's row
 // terms are added, and a frame must get the same sums whichever selection or device it is part of.
+constexpr uint32_t kOrderMinSlots = 512; // fewer workgroups than the chip holds at once: nothing to order
+
 int launch_motion64(rship_ctx* c, const Motion64Params& p, hipStream_t st = nullptr, uint32_t count = 0) {
     if (!st) st = c->stream;
     if (!count) count = p.n_sel - p.slot0;
@@ -302,6 +309,11 @@ int launch_motion64(rship_ctx* c, const Motion64Params& p, hipStream_t st = null
     else if (n <= 8192) hipLaunchKernelGGL((opt_motion64_kernel<32, 4>), dim3(count), dim3(256), 0, st, p);
     else return set_err(c, "motion: unsupported track count");
     RS_HIP(hipGetLastError());
+    // the order of the NEXT launch over these slots, from this one's evaluation counts
+    if (p.evals_out && c->mo_order.p && p.max_iters > 0 && !p.simple_k && count >= kOrderMinSlots) {
+        hipLaunchKernelGGL(motion_order_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)p.evals_out, (uint32_t*)c->mo_order.p, p.slot0, count);
+        RS_HIP(hipGetLastError());
+    }
     return 0;
 }
 
@@ -781,6 +793,7 @@ int rship_select_slots(rship_ctx* c, const uint32_t* idx, uint32_t n, const uint
         ensure(c, c->grp_off, (size_t)(n_grp + 1) * 4))
         return 1;
     if (ensure(c, c->M, (size_t)n * 24 + 24) || ensure(c, c->k, (size_t)n * 8 + 8) || ensure(c, c->init_h, (size_t)n * 4 + 4)) return 1;
+    if (ensure(c, c->mo_evals, (size_t)n * 4 + 4) || ensure(c, c->mo_order, (size_t)n * 4 + 4)) return 1;
     c->init_pending = false;
     std::vector<uint32_t> g(n, 0), off(n_grp + 1, 0);
     if (grp_off) {
@@ -798,6 +811,15 @@ int rship_select_slots(rship_ctx* c, const uint32_t* idx, uint32_t n, const uint
     RS_HIP(hipMemsetAsync(c->M.p, 0, (size_t)n * 24 + 24, c->stream));
     RS_HIP(hipMemsetAsync(c->k.p, 0, (size_t)n * 8 + 8, c->stream));
     RS_HIP(hipMemsetD32Async((hipDeviceptr_t)c->init_h.p, kInitNone, (size_t)n + 1, c->stream));
+    {   // launch order of the motion kernel: identity until a launch has left evaluation counts
+        std::vector<uint32_t> ident(n + 1);
+        for (uint32_t i = 0; i <= n; ++i) ident[i] = i;
+        RS_HIP(hipMemcpyAsync(c->mo_order.p, ident.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+        RS_HIP(hipMemsetAsync(c->mo_evals.p, 0, (size_t)n * 4 + 4, c->stream));
+        RS_HIP(hipStreamSynchronize(c->stream)); // ident goes out of scope
+        c->mo_identity = true;
+        c->mo_ranges.clear();
+    }
     RS_HIP(hipStreamSynchronize(c->stream));
     c->h_sel.assign(idx, idx + n);
     c->h_grp_off = off;
@@ -950,7 +972,24 @@ void fill_motion(rship_ctx* c, Motion64Params& p) {
     p.stream_base = c->init_stream;
     p.stream_stride = c->init_stride;
     p.simple_k = 0;
+    p.evals_out = (uint32_t*)c->mo_evals.p;
+    p.order = (const uint32_t*)c->mo_order.p; // the caller has called prepare_order for its slot ranges
 }
+
+// Before a call launches the motion kernel over the slot ranges `ranges` (one per stream group): the launch order
+// left by earlier launches is only usable if it was built for the same ranges; otherwise back to the identity.
+int prepare_order(rship_ctx* c, const std::vector<std::pair<uint32_t, uint32_t>>& ranges) {
+    if (!c->mo_identity && ranges != c->mo_ranges) {
+        std::vector<uint32_t> ident(c->n_sel + 1);
+        for (uint32_t i = 0; i <= c->n_sel; ++i) ident[i] = i;
+        RS_HIP(hipStreamSynchronize(c->stream));
+        RS_HIP(hipMemcpy(c->mo_order.p, ident.data(), (size_t)(c->n_sel + 1) * 4, hipMemcpyHostToDevice));
+    }
+    c->mo_identity = false;
+    c->mo_ranges = ranges;
+    return 0;
+}
+int prepare_order_all(rship_ctx* c) { return prepare_order(c, {{0u, c->n_sel}}); }
 } // namespace
 
 // FrameState::GuessMotion's hypothesis search (core_private.cpp:125-128 -> :34-59, 200 hypotheses) in the
@@ -1001,7 +1040,7 @@ int rship_finish_init(rship_ctx* c, const int32_t* kd, const double* fd) {
     Motion64Params p{};
     fill_motion(c, p);
     p.max_iters = 0;
-    if (launch_motion64(c, p)) return 1;
+    if (prepare_order_all(c) || launch_motion64(c, p)) return 1;
     c->init_pending = false;
     return sync_stream(c);
 }
@@ -1016,7 +1055,7 @@ int rship_init_k_simple(rship_ctx* c, const int32_t* kd, const double* fd) {
     fill_motion(c, p);
     p.init_h = nullptr;
     p.simple_k = 1;
-    if (launch_motion64(c, p)) return 1;
+    if (prepare_order_all(c) || launch_motion64(c, p)) return 1;
     return sync_stream(c);
 }
 
@@ -1031,7 +1070,7 @@ int rship_opt_motion_detail(rship_ctx* c, const int32_t* kd, const double* fd, u
     Motion64Params p{};
     fill_motion(c, p);
     p.per_frame = (uint32_t*)d.p;
-    int rc = launch_motion64(c, p);
+    int rc = prepare_order_all(c) || launch_motion64(c, p);
     c->init_pending = false;
     hipError_t e = hipStreamSynchronize(c->stream);
     prof_collect(c);
@@ -1052,7 +1091,7 @@ int rship_opt_motion(rship_ctx* c, const int32_t* kd, const double* fd, uint64_t
     Motion64Params p{};
     fill_motion(c, p);
     p.stats = stats ? (unsigned long long*)c->stats.p : nullptr;
-    if (launch_motion64(c, p)) return 1;
+    if (prepare_order_all(c) || launch_motion64(c, p)) return 1;
     c->init_pending = false;
     if (stats) {
         if (ensure_pinned(c, 32)) return 1;
@@ -1264,6 +1303,11 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
             // windows has nothing to do)
             gr.done = gr.w1 == gr.w0;
         }
+    }
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> ranges;
+        for (const Group& gr : groups) ranges.emplace_back(gr.s0, gr.s1 - gr.s0);
+        if (prepare_order(c, ranges)) return 1;
     }
     if (G > 1) { // what the context's stream has queued (selection, GuessMotion, the copies above) comes first
         RS_HIP(hipEventRecord(c->loop_ready, c->stream));
@@ -1537,6 +1581,23 @@ int rship_debug_init_h(rship_ctx* c, int32_t* get, const int32_t* set, uint32_t 
     RS_HIP(hipStreamSynchronize(c->stream));
     if (get) RS_HIP(hipMemcpy(get, c->init_h.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     if (set) RS_HIP(hipMemcpy(c->init_h.p, set, (size_t)n * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// dynamic trip counts of the LMedS tile kernel (variant builds with -DRSSYNC_K2_COUNTERS=1 only; zeros otherwise)
+int rship_debug_k2_counters(rship_ctx* c, uint64_t out[16], int reset) {
+    DeviceGuard dev_guard(c);
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+#if RSSYNC_K2_COUNTERS
+    RS_HIP(hipStreamSynchronize(c->stream));
+    RS_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k2_counters), 16 * sizeof(uint64_t)));
+    if (reset) {
+        const uint64_t zero[16] = {};
+        RS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_k2_counters), zero, sizeof(zero)));
+    }
+#else
+    (void)reset;
+#endif
     return 0;
 }
 

@@ -1093,6 +1093,7 @@ void SyncProblemHip::init_motion(const std::vector<double>& delays, uint32_t cal
             hip_check(sh, rship_init_motion(sh.ctx, kd.data(), fd.data(), 200 /* core_private.cpp:127 */,
                                             kStreamSyncInit + sync_calls, call_stride, seed),
                       "init motion");
+    if (record_init || !init_override.empty()) exchange_init_winners();
 }
 
 void SyncProblemHip::exchange_init_winners() {
@@ -1233,7 +1234,6 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
     } else {
         init_motion(d, call_stride);
         if (call_stride == 1) sync_calls += (uint32_t)W;
-        if (record_init || !init_override.empty()) exchange_init_winners();
     }
     traces.assign(W, {});
 

@@ -768,6 +768,10 @@ int rship_debug_init_h(rship_ctx* c, int32_t* get, const int32_t* set, uint32_t 
     return 0;
 }
 
+int rship_debug_k2_counters(rship_ctx*, uint64_t out[16], int) {
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    return 0;
+}
 int rship_debug_select(rship_ctx* c, const float*, uint32_t, uint32_t, uint32_t, const float*, uint32_t*) {
     return fail(c, "debug_select: device only");
 }

@@ -1,0 +1,73 @@
+"""bench.py --gpus N without an external launcher: the parent starts N rank processes itself (never touching
+a GPU), waits, and passes their status on.  Rehearsed here on the CPU stand-in for the device ABI with the
+gloo backend (the same launcher and exchange code paths; the printed value is marked as a rehearsal).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "2", "--warmup", "1", "--cpu-frames", "0", "--tracks", "96", "--search-step", "0.004",
+         "--search-radius", "0.1", "--outer-iters", "6"]
+
+
+def _run(cmd, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    return p.returncode, lines, p.stderr
+
+
+def _lib(hosttest_lib):
+    return os.path.join(ROOT, "tests", "_build", "librssync_hosttest.so")
+
+
+def test_self_spawned_ranks_match_one_process(hosttest_lib):
+    lib = _lib(hosttest_lib)
+    rc, one, err = _run([sys.executable, "bench.py", "--gpus", "1", "--frames", "16", "--rehearse-cpu", lib] + SMALL)
+    assert rc == 0 and len(one) == 1, err
+    rc, two, err = _run([sys.executable, "bench.py", "--gpus", "2", "--frames", "8", "--rehearse-cpu", lib] + SMALL)
+    assert rc == 0, err
+    assert len(two) == 1, "exactly one JSON line (rank 0's)"
+    a, b = json.loads(one[0]), json.loads(two[0])
+    assert a["n_gpus"] == 1 and a["multi_gpu"]["launcher"] == "direct" and a["multi_gpu"]["exchange"] is None
+    assert b["n_gpus"] == 2 and b["multi_gpu"]["launcher"] == "self-spawned" and b["multi_gpu"]["processes"] == 2
+    assert b["multi_gpu"]["exchange"].startswith("torch-gloo-hook") and b["multi_gpu"]["exchanges_per_step"] >= 3
+    assert "rehearsal" in a and "rehearsal" in b
+    # the same 16-frame window, whole or sharded over two ranks: same arg-min, same refinement
+    assert b["result"]["presync_delay"] == a["result"]["presync_delay"]
+    assert b["result"]["sync_delay"] == pytest.approx(a["result"]["sync_delay"], abs=1e-9)
+    assert b["config"]["sync_outer_iters"] == a["config"]["sync_outer_iters"]
+    # weak scaling bookkeeping: per-GPU work fixed, whole-job value
+    assert b["config"]["frames_per_gpu"] == 8 and b["scaling"] == "weak"
+
+
+def test_external_launcher_still_works(hosttest_lib):
+    lib = _lib(hosttest_lib)
+    rc, out, err = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", "29611", "bench.py", "--gpus", "2", "--frames", "8",
+                         "--rehearse-cpu", lib] + SMALL)
+    assert rc == 0 and len(out) == 1, err
+    d = json.loads(out[0])
+    assert d["n_gpus"] == 2 and d["multi_gpu"]["launcher"] == "torch.distributed.run"
+
+
+def test_inproc_mode_one_object_several_devices(hosttest_lib):
+    lib = _lib(hosttest_lib)
+    rc, out, err = _run([sys.executable, "bench.py", "--gpus", "2", "--mode", "inproc", "--frames", "8", "--rehearse-cpu", lib] + SMALL)
+    assert rc == 0 and len(out) == 1, err
+    d = json.loads(out[0])
+    assert d["n_gpus"] == 2 and d["multi_gpu"]["mode"] == "inproc" and d["multi_gpu"]["devices_per_process"] == 2
+    assert d["multi_gpu"]["exchanges_per_step"] == 0
+
+
+def test_a_failing_rank_fails_the_run(hosttest_lib):
+    rc, out, err = _run([sys.executable, "bench.py", "--gpus", "2", "--frames", "8", "--rehearse-cpu", "/nonexistent/lib.so"] + SMALL)
+    assert rc != 0 and not out
+    assert "rank process" in err
