@@ -194,17 +194,15 @@ RS_HD float log1p_pos(float u) {
 // Same with the hardware logarithm (v_log_f32, about 1 ulp of log2) in place of libm's logf: 7
 // instructions.  Used only for the PreSync cost, which is compared between candidates, never
 // differentiated or line-searched.
-#ifndef RSSYNC_K2_D_NORCP
-#define RSSYNC_K2_D_NORCP 0
-#endif
+// The correction c / w only matters while w is close to 1 (c <= ulp(w) / 2, and log(w) grows): 1 / w is taken as
+// max(2 - w, 0), exact to (w - 1)^2 where it matters -- the result stays within 9e-8 relative of log1p over
+// 1e-12 .. 1e6 (3e-8 with a true reciprocal; v_log_f32 itself is good to ~1e-7) -- and the row loses one of its
+// three quarter-rate instructions (round 3 A/B: -0.15 ms per PreSync launch).
 RS_HD float log1p_pos_fast(float u) {
     const float w = 1.0f + u;
     const float c = (w - 1.0f) - u;
-#if defined(__HIP_DEVICE_COMPILE__) && RSSYNC_K2_D_NORCP
-    // measured variant: 1/w as max(2 - w, 0) (the correction c / w only matters while w is close to 1)
+#if defined(__HIP_DEVICE_COMPILE__)
     return fmaf(__builtin_amdgcn_logf(w), 0.69314718055994531f, -c * fmaxf(2.0f - w, 0.f));
-#elif defined(__HIP_DEVICE_COMPILE__)
-    return fmaf(__builtin_amdgcn_logf(w), 0.69314718055994531f, -c * rcp_fast(w));
 #else
     return log2f(w) * 0.69314718055994531f - c * rcp_fast(w);
 #endif

@@ -270,14 +270,6 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
 __host__ __device__ constexpr int lmeds_waves(int rpt) { return rpt <= 8 ? 5 : (rpt == 16 ? 2 : 1); }
 __host__ __device__ constexpr int loss_waves(int rpt, bool grad) { return (grad || rpt >= 8) ? 3 : 4; }
 
-// Measured variant (-DRSSYNC_K2_PAIRS=1): the hypotheses' row pairs depend only on (seed, frame id, stream, h, N),
-// not on the data, so all 256 threads draw them for kPairSpan candidates at once into LDS (u16 pairs) and the
-// twenty lanes that build the directions read them there instead of running the 64-bit sampler.
-#ifndef RSSYNC_K2_PAIRS
-#define RSSYNC_K2_PAIRS 0
-#endif
-constexpr int kPairCap = 220; // pairs held in LDS (880 B: the kernel stays under five workgroups' worth of a CU's LDS)
-
 constexpr int kMaxChunk = 32; // candidates per workgroup (rship: chunk <= kMaxChunk); 64 and 100 measured: no change
 constexpr int kHypBatch = 64; // hypothesis directions prepared per batch (one per lane of wave 0)
 
@@ -318,9 +310,6 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     // "smaller quantile wins, ties go to the earlier hypothesis" (core_private.cpp:53 strict <)
     __shared__ unsigned long long s_key;
     __shared__ uint32_t s_next; // hypothesis queue of the current batch
-#if RSSYNC_K2_PAIRS
-    __shared__ uint32_t s_pairs[kPairCap];
-#endif
     const int tid = threadIdx.x, lane = tid & 63;
     // blocks b and b+8 share an XCD (round-robin dispatch): keep the chunks of one
     // frame on one XCD so its rays are fetched into one L2 only
@@ -377,28 +366,11 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     const f4* p4z = reinterpret_cast<const f4*>(tile.nz);
     uint32_t prev_best = kInfBits; // winning quantile of the previous candidate of this chunk
 
-#if RSSYNC_K2_PAIRS
-    const uint32_t pair_span = (p.n_hyp <= (uint32_t)kPairCap) ? (uint32_t)kPairCap / p.n_hyp : 0u; // candidates per refill
-    uint32_t pair_c0 = c0;
-#endif
     for (uint32_t c = c0; c < c1; ++c) {
         const int base = fr.base_knot + s_kd[c - c0];
         const float fd = s_fd[c - c0];
         const uint32_t stream = p.stream_base + c + g * p.stream_stride; // g != 0 only for batched GuessMotion
         uint32_t bad = 0;
-#if RSSYNC_K2_PAIRS
-        if (pair_span && (c == c0 || c - pair_c0 == pair_span)) {
-            // (the readers of the previous span finished before the barriers of the previous candidate's stage D)
-            pair_c0 = c;
-            const uint32_t n_c = (c1 - c < pair_span) ? c1 - c : pair_span;
-            for (uint32_t e = tid; e < n_c * p.n_hyp; e += kBlock) {
-                const uint32_t cc = e / p.n_hyp, h = e % p.n_hyp;
-                uint32_t i0, i1;
-                rs::sample_pair(p.seed, fr.id, p.stream_base + (c + cc) + g * p.stream_stride, h, N, i0, i1);
-                s_pairs[e] = i0 | (i1 << 16);
-            }
-        }
-#endif
         // ---- stage A: rows of P -> LDS tile as unit rows; norms stay in registers ----
         float nrm[RPT];
         bad |= lmeds_rows<RPT, MODE == 0, WIN>(sp, rays, N, base, fd, tile, nrm);
@@ -418,20 +390,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                 const uint32_t nb = (p.n_hyp - batch < (uint32_t)kHyp) ? p.n_hyp - batch : (uint32_t)kHyp;
                 __syncthreads(); // tile written / previous batch consumed
                 if ((uint32_t)tid < nb) {
-#if RSSYNC_K2_PAIRS
-                    f3 v;
-                    if (pair_span) {
-                        const uint32_t pr = s_pairs[(c - pair_c0) * p.n_hyp + batch + tid];
-                        const uint32_t i0 = pr & 0xffffu, i1 = pr >> 16;
-                        v = rs::cross(f3{tile.nx[i0], tile.ny[i0], tile.nz[i0]}, f3{tile.nx[i1], tile.ny[i1], tile.nz[i1]});
-                        const float nn = sqrtf(rs::dot(v, v));
-                        if (!(nn < 1e-12f)) v = rs::scale(v, 1.0f / nn);
-                    } else {
-                        v = hypothesis(tile, p.seed, fr.id, stream, batch + tid, N);
-                    }
-#else
                     const f3 v = hypothesis(tile, p.seed, fr.id, stream, batch + tid, N);
-#endif
                     s_hyp[tid] = f4{v.x, v.y, v.z, 0.f};
                 }
                 if (tid == 0) s_next = 0;

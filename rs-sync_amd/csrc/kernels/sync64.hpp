@@ -206,10 +206,7 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
         double L[NB], G[NB];
 #pragma unroll
         for (int q = 0; q < NB; ++q) L[q] = G[q] = 0.0;
-#ifndef RSSYNC_K1_UNROLL
-#define RSSYNC_K1_UNROLL 1
-#endif
-#pragma unroll RSSYNC_K1_UNROLL
+#pragma unroll 1 // (unroll 2 measured in round 3: the gradient launch stays at 0.122 ms)
         for (int j = 0; j < RPT; ++j) {
             const uint32_t row = j * kBlock + tid;
             if (row < N) {

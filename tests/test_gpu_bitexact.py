@@ -85,12 +85,16 @@ def test_every_evaluation_is_bit_identical(hosttest_lib, F, N):
         np.testing.assert_array_equal(_bits(Pg), _bits(Pc))
         np.testing.assert_array_equal(_bits(dPg), _bits(dPc))
     gpu.record_init_winners()
-    cpu.record_init_winners()
     Mg, kg = gpu.init_motion(d0, 0, F - 1)
     win = gpu.last_init_winners()
-    Mc0, kc0 = cpu.init_motion(d0, 0, F - 1)       # the stand-in's own fp32 search ...
-    n_diff = int(np.sum(cpu.last_init_winners() != win))
-    cpu.set_init_override(win)                     # ... and started from the device's winners
+    # the stand-in's own fp32 search (a second instance: every call advances the sampler's call counter) ...
+    import rssync_amd
+    own = rssync_amd.SyncProblem(seed=77, max_outer_iters=20, _lib=hosttest_lib)
+    _fill_both(own, own, gyro, frames)
+    own.record_init_winners()
+    own.init_motion(d0, 0, F - 1)
+    n_diff = int(np.sum(own.last_init_winners() != win))
+    cpu.set_init_override(win)                     # ... and the stand-in started from the device's winners
     Mc, kc = cpu.init_motion(d0, 0, F - 1)
     np.testing.assert_array_equal(_bits(Mg), _bits(Mc))
     np.testing.assert_array_equal(_bits(kg), _bits(kc))
