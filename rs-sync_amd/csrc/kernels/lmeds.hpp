@@ -18,6 +18,7 @@ __device__ unsigned long long g_k2_counters[16];
 // 0 (frame, candidate) pairs   1 queue pops   2 hypotheses swept   3 sweeps that beat the bound (exact selections)
 // 4 counting passes inside the exact selection   5 selections ended by the single-element min pass
 // 6 candidates redone without the provisional bound   7 sweeps that started without any bound (wave max)
+// 8 contenders swept again and closed exactly (lazy selection: overlapping brackets)
 
 // ---------------------------------------------------------------------------
 // K2: LMedS tile kernel
@@ -117,22 +118,29 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 
 __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-// Exact kq-th smallest (0-based) of the wave's |r[]| as a bit pattern, given an exclusive upper
-// bound hi with count(|r| < hi) = c_hi > kq.  |r| orders exactly like the r^2 the reference sorts
-// (core_private.cpp:49-52), so this is the element std::sort would leave at index kq, before
-// squaring.  A bracket [lo, hi) with counts c_lo <= kq < c_hi is narrowed by counting passes;
-// pivots come from a secant step on the empirical CDF of |r| (close to uniform around the lower
-// quartile, so the CDF is nearly linear there: ~8 passes instead of 31 bit-bisection passes), with
-// bracket interpolation and plain bisection of the bit pattern as fallbacks.  Ends when the
-// bracket is one bit pattern wide or holds exactly one element, which a min pass extracts.
-// All bookkeeping is wave-uniform and kept on the scalar unit (bit patterns of non-negative
-// floats order like unsigned integers); only the secant formula itself runs on the VALU.
+// Quartile selection on the wave's |r[]| (NR registers per lane = the whole tile).  |r| orders exactly like the
+// r^2 the reference sorts (core_private.cpp:49-52), so the kq-th smallest |r| (0-based) is the element std::sort
+// would leave at index kq, before squaring.  Bit patterns of non-negative floats order like unsigned integers.
+//
+// A BRACKET [lo, hi) with counts c_lo = count(|r| < lo) <= kq < c_hi = count(|r| < hi) contains that element.
+// narrow_kth narrows it by counting passes (wave_count_lt): pivots come from a secant step on the empirical CDF of
+// |r| (close to uniform around the lower quartile, so the CDF is nearly linear there), with bracket interpolation
+// and plain bisection of the bit pattern as fallbacks.  It stops
+//   * when the bracket is one bit pattern wide, hi = lo + 1: lo IS the element (a bracket that holds exactly one
+//     element is closed by a min pass that extracts it) -- always, if stop_elems == 0;
+//   * or, if stop_elems > 0, as soon as hi < hi_limit and the bracket holds at most stop_elems elements: the
+//     caller only needs to know the element that closely (lazy selection, below).
+// All bookkeeping is wave-uniform and kept on the scalar unit; only the secant formula itself runs on the VALU.
+struct Bracket {
+    uint32_t lo, c_lo, hi, c_hi;
+};
 template <int NR>
-__device__ __forceinline__ uint32_t select_kth(const uint32_t (&r)[NR], uint32_t kq, uint32_t hi, uint32_t c_hi) {
-    uint32_t lo = 0, c_lo = 0;
-    uint32_t a1 = 0, c1 = 0, a2 = hi, c2 = c_hi; // the two most recent (pivot, count) points
+__device__ __forceinline__ void narrow_kth(const uint32_t (&r)[NR], uint32_t kq, Bracket& b, uint32_t stop_elems, uint32_t hi_limit) {
+    uint32_t lo = b.lo, c_lo = b.c_lo, hi = b.hi, c_hi = b.c_hi;
+    uint32_t a1 = lo, c1 = c_lo, a2 = hi, c2 = c_hi; // the two most recent (pivot, count) points
     for (int it = 0;; ++it) {
-        if (hi - lo == 1u) return lo;
+        if (hi - lo == 1u) break;
+        if (stop_elems && hi < hi_limit && c_hi - c_lo <= stop_elems) break;
         if (c_hi - c_lo == 1u) {
             K2_COUNT(5);
             // the single element in [lo, hi): smallest |x| >= lo; |x| < lo wraps to a huge difference
@@ -142,7 +150,9 @@ __device__ __forceinline__ uint32_t select_kth(const uint32_t (&r)[NR], uint32_t
                 uint32_t d = (r[m] & 0x7fffffffu) - lo;
                 mn = d < mn ? d : mn;
             }
-            return lo + wave_min_u32(mn);
+            lo += wave_min_u32(mn);
+            hi = lo + 1u;
+            break;
         }
         uint32_t piv = 0;
         if (it < 24) {
@@ -167,6 +177,14 @@ __device__ __forceinline__ uint32_t select_kth(const uint32_t (&r)[NR], uint32_t
         if (c <= kq) { lo = piv; c_lo = c; }
         else { hi = piv; c_hi = c; }
     }
+    b.lo = lo; b.c_lo = c_lo; b.hi = hi; b.c_hi = c_hi;
+}
+// the exact kq-th smallest, given an exclusive upper bound hi with count(|r| < hi) = c_hi > kq
+template <int NR>
+__device__ __forceinline__ uint32_t select_kth(const uint32_t (&r)[NR], uint32_t kq, uint32_t hi, uint32_t c_hi) {
+    Bracket b{0u, 0u, hi, c_hi};
+    narrow_kth(r, kq, b, 0u, 0u);
+    return b.lo;
 }
 
 // The frame's two ray streams as buffer resources: a row is addressed as (descriptor in SGPRs) + (one per-thread
@@ -293,11 +311,45 @@ __device__ __forceinline__ uint32_t wave_pop(uint32_t* counter) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
 }
 
+// residuals r = nP v of one hypothesis for the whole tile, in the wave's registers (core_private.cpp:48); |r| orders
+// like the r^2 of :49-52.  Registers 4m..4m+3 <-> rows 4 (64 m + lane) .. +3.
+template <int NR>
+__device__ __forceinline__ void sweep_tile(const f4* p4x, const f4* p4y, const f4* p4z, int lane, f3 hv, uint32_t (&r2)[NR]) {
+#pragma unroll
+    for (int m = 0; m < NR / 4; ++m) {
+        if ((m & 1) == 0) __builtin_amdgcn_sched_barrier(0); // bound the LDS reads in flight
+        const int idx = m * 64 + lane;
+        // ds_read_b128 per array: full LDS rate (ds_read2_b64 pairs run at half of it)
+        const f4 x = p4x[idx], y = p4y[idx], z = p4z[idx];
+        const v2f r01 = v2f{x.x, x.y} * hv.x + v2f{y.x, y.y} * hv.y + v2f{z.x, z.y} * hv.z;
+        const v2f r23 = v2f{x.z, x.w} * hv.x + v2f{y.z, y.w} * hv.y + v2f{z.z, z.w} * hv.z;
+        r2[4 * m] = __float_as_uint(r01.x);
+        r2[4 * m + 1] = __float_as_uint(r01.y);
+        r2[4 * m + 2] = __float_as_uint(r23.x);
+        r2[4 * m + 3] = __float_as_uint(r23.y);
+    }
+}
+
+// LAZY SELECTION (round 3).  The arg-min over hypotheses of (lower quartile, index) needs the quartiles only to
+// COMPARE them.  Round 2 selected the exact quartile of every hypothesis that beat the current bound -- 3.9 of 20
+// per candidate, ~6 counting passes and a min pass each: a fifth of the kernel's instructions
+// (profiles/r3_k2_counters.json).  Now a hypothesis that beats the bound narrows its bracket only until it holds at
+// most kLazyElems elements and ends below the bound, publishes the bracket's upper end as the new (exclusive)
+// bound -- still an upper bound of the best quartile, so nothing better is ever turned away -- and is recorded as a
+// CONTENDER {h, lo, hi, counts}.  At the end of the candidate, contenders whose lo is not below the smallest hi
+// have lost for certain; if one contender is left it has won without its quartile ever being known exactly;
+// if several are left (their brackets overlap) each is swept again and its bracket closed exactly from where it
+// stopped, and the packed (quartile, index) minimum decides as before.  The winner is the exact arg-min with the
+// reference's first-wins tie rule either way (tests: identical best_h and costs against the exact selection,
+// RSSYNC_K2_EXACT_SELECT=1, on every (frame, candidate) of full-size sweeps).
+constexpr uint32_t kLazyElems = 4;
+constexpr int kContCap = 24; // contender records per candidate; beyond that a hypothesis closes its bracket at once
+
 // WIN = knots of the LDS spline window (kWinMax in the product).  Round 2 measured a 28-knot window with a
 // 24-entry direction buffer: 27,088 B of LDS and 80 VGPRs, SIX workgroups per CU instead of five (the occupancy
 // API confirmed it) -- and the same launch time within 0.1 %, while four workgroups per CU had been 12 % slower
 // than five: beyond five waves per SIMD the kernel no longer gains from more resident waves.
-template <int RPT, int MODE, int WIN> // MODE 0: PreSync cost per candidate; 1: GuessMotion's hypothesis search (Sync start)
+template <int RPT, int MODE, int WIN, bool LAZY = true> // MODE 0: PreSync cost per candidate; 1: GuessMotion's hypothesis search (Sync start)
 __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsParams p) {
     constexpr int kHyp = kHypBatch;
     constexpr int ROWS = kBlock * RPT;
@@ -310,6 +362,12 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     // "smaller quantile wins, ties go to the earlier hypothesis" (core_private.cpp:53 strict <)
     __shared__ unsigned long long s_key;
     __shared__ uint32_t s_next; // hypothesis queue of the current batch
+    // lazy selection: the contenders of the current candidate, and the exact (quartile, index) keys of those that
+    // had to be closed
+    __shared__ uint32_t s_ch[LAZY ? kContCap : 1], s_clo[LAZY ? kContCap : 1], s_chi[LAZY ? kContCap : 1], s_cclo[LAZY ? kContCap : 1],
+        s_cchi[LAZY ? kContCap : 1];
+    __shared__ uint32_t s_ncont;
+    __shared__ unsigned long long s_exact;
     const int tid = threadIdx.x, lane = tid & 63;
     // blocks b and b+8 share an XCD (round-robin dispatch): keep the chunks of one
     // frame on one XCD so its rays are fetched into one L2 only
@@ -383,6 +441,9 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         uint32_t guess = kInfBits;
         if (prev_best < 0x7e000000u && prev_best > 0x00800000u)
             guess = uniform_u32(__float_as_uint(__uint_as_float(prev_best) * 1.25f));
+        uint32_t bT; // the winner's quartile (exact selection) or an upper bound of it (lazy): the next candidate's bound
+        int bH;
+        if (!LAZY) {
         unsigned long long best;
         for (;;) {
             if (tid == 0) s_key = ((unsigned long long)guess << 32);
@@ -402,21 +463,8 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                     K2_COUNT(2);
                     const uint32_t h = batch + j;
                     const f4 hv = s_hyp[j];
-                    // residuals r = nP v (core_private.cpp:48); |r| orders like the r^2 of :49-52
-                    uint32_t r2[NR]; // registers 4m..4m+3 <-> rows 4 (64 m + lane) .. +3
-#pragma unroll
-                    for (int m = 0; m < NR / 4; ++m) {
-                        if ((m & 1) == 0) __builtin_amdgcn_sched_barrier(0); // bound the LDS reads in flight
-                        const int idx = m * 64 + lane;
-                        // ds_read_b128 per array: full LDS rate (ds_read2_b64 pairs run at half of it)
-                        const f4 x = p4x[idx], y = p4y[idx], z = p4z[idx];
-                        const v2f r01 = v2f{x.x, x.y} * hv.x + v2f{y.x, y.y} * hv.y + v2f{z.x, z.y} * hv.z;
-                        const v2f r23 = v2f{x.z, x.w} * hv.x + v2f{y.z, y.w} * hv.y + v2f{z.z, z.w} * hv.z;
-                        r2[4 * m] = __float_as_uint(r01.x);
-                        r2[4 * m + 1] = __float_as_uint(r01.y);
-                        r2[4 * m + 2] = __float_as_uint(r23.x);
-                        r2[4 * m + 3] = __float_as_uint(r23.y);
-                    }
+                    uint32_t r2[NR];
+                    sweep_tile(p4x, p4y, p4z, lane, f3{hv.x, hv.y, hv.z}, r2);
                     // (quantile_h, h) < (T, g)  <=>  more than kq |residuals| lie below T (+1 ulp if g > h):
                     // med < least_med of core_private.cpp:51-53 with the reference's first-wins tie rule
                     const unsigned long long key = __hip_atomic_load(&s_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -445,8 +493,109 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
             if (tid == 0) K2_COUNT(6);
             __syncthreads();  // everyone has read s_key before it is reset
         }
-        const uint32_t bT = (uint32_t)(best >> 32);
-        const int bH = (bT == kInfBits) ? -1 : (int)(uint32_t)best;
+        bT = (uint32_t)(best >> 32);
+        bH = (bT == kInfBits) ? -1 : (int)(uint32_t)best;
+        } else {
+        // ---- lazy selection: s_key's high word is an EXCLUSIVE upper bound of the best quartile found so far ----
+        uint32_t n_cont;
+        for (;;) {
+            if (tid == 0) { s_key = ((unsigned long long)guess << 32); s_ncont = 0; s_exact = ~0ull; }
+            for (uint32_t batch = 0; batch < p.n_hyp; batch += kHyp) {
+                const uint32_t nb = (p.n_hyp - batch < (uint32_t)kHyp) ? p.n_hyp - batch : (uint32_t)kHyp;
+                __syncthreads(); // tile written / previous batch consumed
+                if ((uint32_t)tid < nb) {
+                    const f3 v = hypothesis(tile, p.seed, fr.id, stream, batch + tid, N);
+                    s_hyp[tid] = f4{v.x, v.y, v.z, 0.f};
+                }
+                if (tid == 0) s_next = 0;
+                __syncthreads();
+                for (;;) {
+                    const uint32_t j = wave_pop(&s_next);
+                    K2_COUNT(1);
+                    if (j >= nb) break;
+                    K2_COUNT(2);
+                    const uint32_t h = batch + j;
+                    const f4 hv = s_hyp[j];
+                    uint32_t r2[NR];
+                    sweep_tile(p4x, p4y, p4z, lane, f3{hv.x, hv.y, hv.z}, r2);
+                    // quartile_h < T  <=>  more than kq |residuals| lie below T.  A hypothesis whose quartile EQUALS the
+                    // best one passes as well (T is exclusive and above it): ties are settled among the contenders.
+                    const uint32_t T = (uint32_t)(__hip_atomic_load(&s_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32);
+                    const uint32_t tot = wave_count_lt(r2, T);
+                    if (tot > kq) {
+                        K2_COUNT(3);
+                        Bracket b{0u, 0u, T, tot};
+                        if (T == kInfBits) { // no bound yet: start the bracket at the largest residual
+                            K2_COUNT(7);
+                            float mx = 0.f;
+#pragma unroll
+                            for (int m = 0; m < NR; ++m) mx = fmaxf(mx, fabsf(__uint_as_float(r2[m])));
+                            mx = wave_max_f32(mx);
+                            if (finite_f(mx)) b.hi = __float_as_uint(mx) + 1u; // count(|r| < hi) is still tot
+                        }
+                        narrow_kth(r2, kq, b, kLazyElems, T); // until it ends below T and holds <= kLazyElems elements (or is closed)
+                        uint32_t slot = 0;
+                        if (lane == 0) {
+                            atomicMin(&s_key, (unsigned long long)b.hi << 32);
+                            slot = atomicAdd(&s_ncont, 1u);
+                        }
+                        slot = uniform_u32(slot);
+                        if (slot < (uint32_t)kContCap) {
+                            if (lane == 0) { s_ch[slot] = h; s_clo[slot] = b.lo; s_chi[slot] = b.hi; s_cclo[slot] = b.c_lo; s_cchi[slot] = b.c_hi; }
+                        } else { // no room for a record: close the bracket now, the exact key takes part in the decision
+                            narrow_kth(r2, kq, b, 0u, 0u);
+                            if (lane == 0) atomicMin(&s_exact, ((unsigned long long)b.lo << 32) | h);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            n_cont = s_ncont;
+            if (guess == kInfBits || n_cont != 0u) break;
+            guess = kInfBits; // nothing beat the provisional bound: redo this candidate without it
+            if (tid == 0) K2_COUNT(6);
+            __syncthreads();  // everyone has read the counters before they are reset
+        }
+        // ---- the decision among the contenders (every thread computes the same) ----
+        const uint32_t n_rec = n_cont < (uint32_t)kContCap ? n_cont : (uint32_t)kContCap;
+        const unsigned long long ovf = s_exact; // only set when records overflowed
+        uint32_t m_hi = kInfBits;
+        for (uint32_t i = 0; i < n_rec; ++i) m_hi = s_chi[i] < m_hi ? s_chi[i] : m_hi;
+        if (ovf != ~0ull && (uint32_t)(ovf >> 32) + 1u < m_hi) m_hi = (uint32_t)(ovf >> 32) + 1u;
+        uint32_t n_alive = (ovf != ~0ull && (uint32_t)(ovf >> 32) < m_hi) ? 1u : 0u;
+        uint32_t w_slot = 0;
+        for (uint32_t i = 0; i < n_rec; ++i)
+            if (s_clo[i] < m_hi) { ++n_alive; w_slot = i; } // (lo >= the smallest hi: its quartile is above another's)
+        if (n_cont == 0u) {
+            bH = -1;
+            bT = kInfBits;
+        } else if (n_alive == 1u && ovf == ~0ull) {
+            bH = (int)s_ch[w_slot]; // the only one left: the arg-min, its quartile known to lie in [lo, hi)
+            bT = s_chi[w_slot];
+        } else {
+            // overlapping brackets: close them exactly, from where they stopped
+            __syncthreads(); // (every thread has read the records' decision inputs)
+            if (tid == 0) s_next = 0;
+            __syncthreads();
+            for (;;) {
+                const uint32_t j = wave_pop(&s_next);
+                if (j >= n_rec) break;
+                if (!(s_clo[j] < m_hi)) continue;
+                K2_COUNT(8);
+                const uint32_t h = s_ch[j];
+                const f3 v = hypothesis(tile, p.seed, fr.id, stream, h, N);
+                uint32_t r2[NR];
+                sweep_tile(p4x, p4y, p4z, lane, v, r2);
+                Bracket b{s_clo[j], s_cclo[j], s_chi[j], s_cchi[j]};
+                narrow_kth(r2, kq, b, 0u, 0u);
+                if (lane == 0) atomicMin(&s_exact, ((unsigned long long)b.lo << 32) | h);
+            }
+            __syncthreads();
+            const unsigned long long best = s_exact; // smaller quartile wins, ties go to the earlier hypothesis (core_private.cpp:53)
+            bH = (int)(uint32_t)best;
+            bT = (uint32_t)(best >> 32) + 1u;
+        }
+        }
         prev_best = bT;
         if (tid == 0) K2_COUNT(0);
         f3 Mv = f3{0, 0, 0};

@@ -108,6 +108,8 @@ struct rship_ctx {
     double fs = 0;
     int lbfgs_reeval = 0; // RSHIP_OPT_LBFGS_REEVAL
     uint32_t tracks_hint = 0; // RSHIP_OPT_TRACKS_HINT
+    bool exact_select = false;   // RSSYNC_K2_EXACT_SELECT=1 (read once, at creation): PreSync's tile kernel with round 2's exact
+                                 // selection of every quartile instead of the lazy one (A/B tests: identical results)
     bool no_small_lmeds = false; // RSSYNC_NO_SMALL_LMEDS=1 (read once, at creation): the tile kernel for every frame size (A/B tests)
     float max_span = 0.f; // widest frame, in knots (frame table)
     // native exchange (RCCL through dlopen)
@@ -247,6 +249,19 @@ int launch_lmeds(rship_ctx* c, const LmedsParams& p, int rpt, uint32_t grid) {
             case 2: hipLaunchKernelGGL((lmeds_small_kernel<2, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
             case 3: hipLaunchKernelGGL((lmeds_small_kernel<3, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
             default: hipLaunchKernelGGL((lmeds_small_kernel<4, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
+        }
+        RS_HIP(hipGetLastError());
+        return 0;
+    }
+    if (MODE == 0 && c->exact_select) {
+        switch (rpt) {
+            case 1: hipLaunchKernelGGL((lmeds_kernel<1, 0, WIN, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+            case 2: hipLaunchKernelGGL((lmeds_kernel<2, 0, WIN, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+            case 4: hipLaunchKernelGGL((lmeds_kernel<4, 0, WIN, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+            case 8: hipLaunchKernelGGL((lmeds_kernel<8, 0, WIN, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+            case 16: hipLaunchKernelGGL((lmeds_kernel<16, 0, WIN, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+            case 32: hipLaunchKernelGGL((lmeds_kernel<32, 0, WIN, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+            default: return set_err(c, "lmeds: unsupported rows-per-thread");
         }
         RS_HIP(hipGetLastError());
         return 0;
@@ -446,6 +461,7 @@ int rship_create(rship_ctx** out, int device) {
     if (e != hipSuccess || ndev == 0) return 2; // no GPU: the product path has no CPU fallback
     rship_ctx* c = new rship_ctx();
     if (const char* s = std::getenv("RSSYNC_NO_SMALL_LMEDS")) c->no_small_lmeds = s[0] && s[0] != '0';
+    if (const char* s = std::getenv("RSSYNC_K2_EXACT_SELECT")) c->exact_select = s[0] && s[0] != '0';
     if (device >= 0) {
         e = hipSetDevice(device);
         if (e != hipSuccess) { delete c; return 3; }
@@ -1204,6 +1220,7 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     const size_t o_win = take(W * sizeof(SyncWin));
     const size_t o_mokd = take(W * 4), o_mofd = take(W * 8), o_lgkd = take(W * 4), o_lgfd = take(W * 8);
     const size_t o_trkd = take((size_t)kMaxBt * W * 4), o_trfd = take((size_t)kMaxBt * W * 8);
+    const size_t o_trthr = take((size_t)kMaxBt * W * 8), o_tracc = take((size_t)kMaxBt * W * 8), o_trfail = take((size_t)kMaxBt * W * 4);
     const size_t nact_stride = ((size_t)max_launch * 4 + 255) / 256 * 256;
     const size_t o_nact = take((size_t)G * nact_stride);
     const size_t o_trace = take((size_t)W * max_outer * 48);
@@ -1241,6 +1258,8 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     lp.mo_kd = (int32_t*)(base + o_mokd); lp.mo_fd = (double*)(base + o_mofd);
     lp.lg_kd = (int32_t*)(base + o_lgkd); lp.lg_fd = (double*)(base + o_lgfd);
     lp.tr_kd = (int32_t*)(base + o_trkd); lp.tr_fd = (double*)(base + o_trfd);
+    lp.tr_thr = (double*)(base + o_trthr); lp.tr_acc = (double*)(base + o_tracc); lp.tr_fail = (uint32_t*)(base + o_trfail);
+    const bool early_exit = !std::getenv("RSSYNC_NO_TRIAL_EARLY_EXIT"); // (A/B and tests: identical results either way)
     lp.fs = c->fs;
     {
         double t = 1e-3; // t0, decay = 0.1 (core_private.cpp:226): the host loop's sequence, bit for bit
@@ -1347,6 +1366,7 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
         // the trials each window asked for, one launch (kernels/syncloop.hpp: trial_wanted)
         q.kd = l.tr_kd; q.fd = l.tr_fd; q.n_delays = kMaxBt;
         q.part_grad = nullptr;
+        if (early_exit) { q.tr_thr = l.tr_thr; q.tr_acc = l.tr_acc; q.tr_fail = l.tr_fail; q.grp_off = (const uint32_t*)c->grp_off.p; }
         l.rows = kMaxBt;
         if (cnt && loss_launch(false)) return 1;
         {
