@@ -342,7 +342,10 @@ __device__ __forceinline__ void sweep_tile(const f4* p4x, const f4* p4y, const f
 // stopped, and the packed (quartile, index) minimum decides as before.  The winner is the exact arg-min with the
 // reference's first-wins tie rule either way (tests: identical best_h and costs against the exact selection,
 // RSSYNC_K2_EXACT_SELECT=1, on every (frame, candidate) of full-size sweeps).
-constexpr uint32_t kLazyElems = 4;
+#ifndef RSSYNC_K2_LAZY_ELEMS
+#define RSSYNC_K2_LAZY_ELEMS 4
+#endif
+constexpr uint32_t kLazyElems = RSSYNC_K2_LAZY_ELEMS;
 constexpr int kContCap = 24; // contender records per candidate; beyond that a hypothesis closes its bracket at once
 
 // WIN = knots of the LDS spline window (kWinMax in the product).  Round 2 measured a 28-knot window with a

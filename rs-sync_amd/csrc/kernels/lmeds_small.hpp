@@ -68,26 +68,43 @@ __global__ __launch_bounds__(64, RPT <= 3 ? 6 : 5) void lmeds_small_kernel(Lmeds
         uint32_t bad = 0;
         // ---- rows of P, as unit rows in registers (and in LDS for the row pairs); norms in registers ----
         float nx[RPT], ny[RPT], nz[RPT], nrm[RPT];
+        // (the tile kernel's stage A, operation for operation -- including its reciprocal-free normalisation of the
+        // interpolated quaternions and the fallback when they are not near unit length: common.hpp, NEWTON)
+        auto rows = [&](auto newton_tag, float* qerr) {
+            constexpr bool NEWTON = decltype(newton_tag)::value;
 #pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            const uint32_t row = j * 64 + lane;
-            const f4 A = load_ray(rays.a, voff, (uint32_t)j * 64u * 16u), B = load_ray(rays.b, voff, (uint32_t)j * 64u * 16u);
-            const float nan = __uint_as_float(0x7fc00000u);
-            nx[j] = ny[j] = nz[j] = nan; // rows beyond N: their residuals compare above every threshold
-            nrm[j] = 0.f;
-            if (row < N) {
-                f3 P, dP;
-                if (sp.path == kPathInterior) residual_row<false, kPathInterior, MODE == 0, kWinMax>(sp, A, B, base, fd, P, dP);
-                else residual_row<false, kPathGlobal, false, kWinMax>(sp, A, B, base, fd, P, dP);
-                const float n2 = rs::dot(P, P);
-                if (!finite_f(n2)) bad = RSHIP_BAD_P;
-                const bool tiny = n2 < 1e-24f; // safe_normalize (core_private.cpp:35-36)
-                const float inv = tiny ? 1.f : rs::rsqrt_fast(n2);
-                nx[j] = P.x * inv; ny[j] = P.y * inv; nz[j] = P.z * inv;
-                nrm[j] = tiny ? 1.f : n2 * inv;
+            for (int j = 0; j < RPT; ++j) {
+                const uint32_t row = j * 64 + lane;
+                const f4 A = load_ray(rays.a, voff, (uint32_t)j * 64u * 16u), B = load_ray(rays.b, voff, (uint32_t)j * 64u * 16u);
+                const float nan = __uint_as_float(0x7fc00000u);
+                nx[j] = ny[j] = nz[j] = nan; // rows beyond N: their residuals compare above every threshold
+                nrm[j] = 0.f;
+                if (row < N) {
+                    f3 P, dP;
+                    if (sp.path == kPathInterior) residual_row<false, kPathInterior, MODE == 0, kWinMax, NEWTON>(sp, A, B, base, fd, P, dP, qerr);
+                    else residual_row<false, kPathGlobal, false, kWinMax>(sp, A, B, base, fd, P, dP);
+                    const float n2 = rs::dot(P, P);
+                    if (!finite_f(n2)) bad = RSHIP_BAD_P;
+                    const bool tiny = n2 < 1e-24f; // safe_normalize (core_private.cpp:35-36)
+                    const float inv = tiny ? 1.f : rs::rsqrt_fast(n2);
+                    nx[j] = P.x * inv; ny[j] = P.y * inv; nz[j] = P.z * inv;
+                    nrm[j] = tiny ? 1.f : n2 * inv;
+                }
+                s_n[0][row] = nx[j]; s_n[1][row] = ny[j]; s_n[2][row] = nz[j];
             }
-            s_n[0][row] = nx[j]; s_n[1][row] = ny[j]; s_n[2][row] = nz[j];
+        };
+#if RSSYNC_K2_NEWTON
+        {
+            float qerr = 0.f;
+            rows(std::true_type{}, &qerr);
+            if (__builtin_amdgcn_ballot_w64(qerr >= kNewtonMaxErr) != 0) {
+                bad = 0;
+                rows(std::false_type{}, nullptr);
+            }
         }
+#else
+        rows(std::false_type{}, nullptr);
+#endif
         __syncthreads(); // the wave's rows are in LDS
 
         // ---- the hypotheses, in order.  The previous candidate's best quantile (x1.25) is a provisional bound

@@ -131,19 +131,7 @@ struct Loss64Params {
     double* part_loss; // [n_delays][n_sel]
     double* part_grad; // [n_delays][n_sel] (GRAD)
     uint32_t slot0;    // the launch covers slots slot0 .. slot0 + gridDim.x (a group of windows on its own stream)
-    // Line-search trials only (device-driven loop): EARLY EXIT of trials that have already failed.  Every term of
-    // the loss is >= 0, so the sum of the slots finished so far is a lower bound of the trial's loss; once it
-    // exceeds thr = l1 - t c m (backtrack.cpp:9: the trial is accepted iff its loss is <= thr) the Armijo test can
-    // only fail, whatever the remaining slots add, and workgroups that have not started skip that delay.  The
-    // decision kernel treats a flagged trial as failed and otherwise tests the complete sum exactly as before, so
-    // the search returns what the sequential loop returns; only the work spent on hopeless trials (the steps of
-    // 1e-3 .. 1e-7 times the gradient, tens of seconds away, which the reference evaluates in full) disappears.
-    const double* tr_thr;  // [n_delays][n_grp], or null
-    double* tr_acc;        // [n_delays][n_grp] running sum of the slots finished so far (the first kTrialAccSlots of a window)
-    uint32_t* tr_fail;     // [n_delays][n_grp] 1 = the trial has failed for certain
-    const uint32_t* grp_off; // [n_grp + 1] first slot of every window
 };
-constexpr uint32_t kTrialAccSlots = 1024; // slots of a window that add to its running sums (more: contention on one word)
 
 // delays evaluated per pass over the rows: every ray pair is read once for kLossBatch delays (their spline
 // windows sit side by side in LDS, 10 KB each).  The line search's trials are far apart in time (steps of
@@ -197,9 +185,6 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
             kdv[q] = on[q] ? p.kd[b * p.n_grp + g] : 0;
             fdv[q] = on[q] ? p.fd[b * p.n_grp + g] : 0.0;
             if (fdv[q] != fdv[q]) on[q] = false; // window switched off for this evaluation (workgroup-uniform)
-            if (!GRAD && on[q] && p.tr_fail &&
-                __hip_atomic_load(&p.tr_fail[b * p.n_grp + g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
-                on[q] = false; // this trial has failed already: its sum is no longer needed (a zero is written)
             any_on = any_on || on[q];
         }
         if (!any_on) { // a whole batch of skipped delays
@@ -252,14 +237,6 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
             const bool live = fdb == fdb;
             const double mine = live ? s_red[tid][0][0] + s_red[tid][0][1] + s_red[tid][0][2] + s_red[tid][0][3] : 0.0;
             p.part_loss[(size_t)b * p.n_sel + sf] = mine;
-            if (!GRAD && p.tr_thr && live && sf - p.grp_off[g] < kTrialAccSlots) {
-                // (a skipped delay adds its zero: harmless)  The margin covers the rounding of both sums many times over.
-                const size_t at = (size_t)b * p.n_grp + g;
-                const double thr = p.tr_thr[at];
-                const double before = __hip_atomic_fetch_add(&p.tr_acc[at], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (before + mine > thr + 1e-9 * (fabs(thr) + before + mine))
-                    __hip_atomic_store(&p.tr_fail[at], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
             if (GRAD)
                 p.part_grad[(size_t)b * p.n_sel + sf] =
                     live ? (s_red[tid][1][0] + s_red[tid][1][1] + s_red[tid][1][2] + s_red[tid][1][3]) * p.fs : 0.0;

@@ -40,8 +40,6 @@ struct SyncLoopParams {
     int32_t* mo_kd; double* mo_fd;   // motion: [W]
     int32_t* lg_kd; double* lg_fd;   // loss + gradient: [W]
     int32_t* tr_kd; double* tr_fd;   // trials: [10][W]
-    // early exit of failed trials (loss64_kernel): thresholds, running sums, flags, all [10][W]
-    double* tr_thr; double* tr_acc; uint32_t* tr_fail;
     double fs;
     double ts[11];         // line-search step sizes t0 * decay^i (backtrack.cpp:7-12), computed by the host
     double c_armijo, delay_b, search_center, search_radius;
@@ -179,24 +177,18 @@ __global__ __launch_bounds__(kBlock) void sync_grad_kernel(SyncLoopParams p) {
             s.nf = want < kHalfBt ? kHalfBt : (want > kMaxBt ? kMaxBt : want);
         }
     }
-    const double m = s.g1 * s.g1;
     for (int i = 0; i < kMaxBt; ++i) {
         const double td = trial_wanted(s, i) ? s.x0 - p.ts[i] * s.g1 : __builtin_nan("");
         split64_dev(td, p.fs, &p.tr_kd[(size_t)i * p.n_win + w], &p.tr_fd[(size_t)i * p.n_win + w]);
-        // trial i is accepted iff l1 - loss_i >= t_i c m (backtrack.cpp:9), i.e. iff loss_i <= l1 - t_i c m
-        p.tr_thr[(size_t)i * p.n_win + w] = s.l1 - p.ts[i] * p.c_armijo * m;
-        p.tr_acc[(size_t)i * p.n_win + w] = 0.0;
-        p.tr_fail[(size_t)i * p.n_win + w] = 0u;
     }
 }
 
 // the first trial of rows [b0, b1) that satisfies the Armijo test (backtrack.cpp:9)
-__device__ __forceinline__ void armijo(const SyncLoopParams& p, SyncWin& s, uint32_t w, const double* lt, int b0, int b1) {
+__device__ __forceinline__ void armijo(const SyncLoopParams& p, SyncWin& s, const double* lt, int b0, int b1) {
 #pragma clang fp contract(off)
     if (!s.active || s.hit >= 0) return;
     const double m = s.g1 * s.g1;
     for (int i = b0; i < b1; ++i) {
-        if (p.tr_fail[(size_t)i * p.n_win + w]) continue; // its partial sum already exceeded the threshold: lt[i] is incomplete
         if (s.l1 - lt[i] >= p.ts[i] * p.c_armijo * m) {
             s.hit = i;
             break;
@@ -218,11 +210,11 @@ __global__ __launch_bounds__(kBlock) void sync_step_kernel(SyncLoopParams p) {
     bool step_now = false;
     if (s.active) {
         if (s.phase == 0) {
-            armijo(p, s, w, s_tot, 0, s.nf);
+            armijo(p, s, s_tot, 0, s.nf);
             if (s.hit >= 0 || s.nf >= kMaxBt) step_now = true;
             else s.phase = 1; // nothing among the first nf: the others are evaluated in the next iteration
         } else {
-            armijo(p, s, w, s_tot, s.nf, kMaxBt);
+            armijo(p, s, s_tot, s.nf, kMaxBt);
             step_now = true;
         }
     }

@@ -1220,7 +1220,6 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     const size_t o_win = take(W * sizeof(SyncWin));
     const size_t o_mokd = take(W * 4), o_mofd = take(W * 8), o_lgkd = take(W * 4), o_lgfd = take(W * 8);
     const size_t o_trkd = take((size_t)kMaxBt * W * 4), o_trfd = take((size_t)kMaxBt * W * 8);
-    const size_t o_trthr = take((size_t)kMaxBt * W * 8), o_tracc = take((size_t)kMaxBt * W * 8), o_trfail = take((size_t)kMaxBt * W * 4);
     const size_t nact_stride = ((size_t)max_launch * 4 + 255) / 256 * 256;
     const size_t o_nact = take((size_t)G * nact_stride);
     const size_t o_trace = take((size_t)W * max_outer * 48);
@@ -1258,8 +1257,6 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     lp.mo_kd = (int32_t*)(base + o_mokd); lp.mo_fd = (double*)(base + o_mofd);
     lp.lg_kd = (int32_t*)(base + o_lgkd); lp.lg_fd = (double*)(base + o_lgfd);
     lp.tr_kd = (int32_t*)(base + o_trkd); lp.tr_fd = (double*)(base + o_trfd);
-    lp.tr_thr = (double*)(base + o_trthr); lp.tr_acc = (double*)(base + o_tracc); lp.tr_fail = (uint32_t*)(base + o_trfail);
-    const bool early_exit = !std::getenv("RSSYNC_NO_TRIAL_EARLY_EXIT"); // (A/B and tests: identical results either way)
     lp.fs = c->fs;
     {
         double t = 1e-3; // t0, decay = 0.1 (core_private.cpp:226): the host loop's sequence, bit for bit
@@ -1366,7 +1363,6 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
         // the trials each window asked for, one launch (kernels/syncloop.hpp: trial_wanted)
         q.kd = l.tr_kd; q.fd = l.tr_fd; q.n_delays = kMaxBt;
         q.part_grad = nullptr;
-        if (early_exit) { q.tr_thr = l.tr_thr; q.tr_acc = l.tr_acc; q.tr_fail = l.tr_fail; q.grp_off = (const uint32_t*)c->grp_off.p; }
         l.rows = kMaxBt;
         if (cnt && loss_launch(false)) return 1;
         {
