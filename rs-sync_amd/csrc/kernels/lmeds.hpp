@@ -343,7 +343,7 @@ __device__ __forceinline__ void sweep_tile(const f4* p4x, const f4* p4y, const f
 // reference's first-wins tie rule either way (tests: identical best_h and costs against the exact selection,
 // RSSYNC_K2_EXACT_SELECT=1, on every (frame, candidate) of full-size sweeps).
 #ifndef RSSYNC_K2_LAZY_ELEMS
-#define RSSYNC_K2_LAZY_ELEMS 4
+#define RSSYNC_K2_LAZY_ELEMS 16 // round 3 A/B (profiles/r3_k2_ab2.txt), ms per launch: 1 (= closed at once) 45.7, 4: 41.2, 16: 40.2, 48: 41.1
 #endif
 constexpr uint32_t kLazyElems = RSSYNC_K2_LAZY_ELEMS;
 constexpr int kContCap = 24; // contender records per candidate; beyond that a hypothesis closes its bracket at once
