@@ -92,8 +92,10 @@ def _check_product(h, gold):
     # Sync path follows the CPU solver within the north-star 1e-4 s at every outer iteration
     c2, d2 = h.Sync(float(gold["presync_result"][1]), f0, f0 + F - 1, 0.0, 0.1)
     tr = h.sync_trace()
-    # noisy scene: the optimiser amplifies rounding differences (DESIGN.md "Parity"; the CPU solver moved by
-    # 1e-9 s differs from itself by more): loose here, tight on the noise-free scene below
+    # noisy scene: the optimiser amplifies rounding differences.  What the device computes is bit-identical to the CPU
+    # stand-in in device order (tests/test_gpu_bitexact.py); stand-in and reference-order oracle differ by the
+    # reassociation scatter measured in profiles/r3_reassociation.json (0.1 ms median, 0.44 ms max on such windows).
+    # Loose here, tight on the noise-free scene below.
     assert abs(d2 - gold["sync_result"][1]) < 3e-4
     assert c2 == pytest.approx(gold["sync_result"][0], rel=5e-3)
     assert abs(len(tr) - len(gold["sync_trace"])) <= 3

@@ -259,3 +259,42 @@ def test_one_wave_kernel_for_small_frames_agrees_with_the_tile_kernel(monkeypatc
         np.testing.assert_allclose(a[1], b[1], rtol=2e-6)
         np.testing.assert_array_equal(a[4], b[4])                  # GuessMotion: same winner, finished in fp64
         np.testing.assert_array_equal(a[5], b[5])
+
+
+def test_one_wave_kernel_with_several_candidates_per_chunk(monkeypatch):
+    """64 frames x 130 tracks x 400 candidates: chunks of >= 2 candidates, so the one-wave kernel carries the
+    previous candidate's quartile (x 1.25) as a provisional bound and redoes a candidate that nothing beats
+    (lmeds_small.hpp) -- ADVICE r2: every earlier small-frame case stayed at one candidate per chunk.  Winners must
+    be those of the tile kernel (RSSYNC_NO_SMALL_LMEDS=1) exactly, and the oracle's except at fp32 near-ties."""
+    import rssync_amd
+    from rssync_amd import synth
+    from oracle.oracle import OracleProblem
+    F, N = 64, 130
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=23)
+    frames = list(synth.make_frames(g, 0, F, N, seed=23))
+    out = {}
+    for tile in (False, True):
+        if tile:
+            monkeypatch.setenv("RSSYNC_NO_SMALL_LMEDS", "1")
+        else:
+            monkeypatch.delenv("RSSYNC_NO_SMALL_LMEDS", raising=False)
+        p = rssync_amd.SyncProblem(seed=SEED, verbose=False)
+        p.SetGyroQuaternions(g.quats, g.fs, g.t0)
+        for fr in frames:
+            p.SetTrackResult(*fr)
+        out[tile] = p.presync_curve(0.0, 0, F, 0.0005, 0.1, per_frame=F)
+    monkeypatch.delenv("RSSYNC_NO_SMALL_LMEDS", raising=False)
+    (d, c, fc, bh), (d2, c2, fc2, bh2) = out[False], out[True]
+    assert len(d) == 400 and 400 * F >= 16384          # the host picks chunks of >= 2 candidates from this size on
+    np.testing.assert_array_equal(bh, bh2)
+    np.testing.assert_allclose(fc, fc2, rtol=2e-6)
+    o = OracleProblem(seed=SEED, threads=os.cpu_count() or 1, faithful=False)
+    o.SetGyroQuaternions(g.quats, g.fs, g.t0)
+    for fr in frames:
+        o.SetTrackResult(*fr)
+    do, co, fco, bho = o.presync_curve(0.0, 0, F, 0.0005, 0.1, per_frame=F)
+    np.testing.assert_array_equal(d, do)
+    same = bh == bho
+    assert same.mean() > 0.995
+    np.testing.assert_allclose(fc[same], fco[same], rtol=3e-3)
+    assert d[int(np.argmin(c))] == do[int(np.argmin(co))]
