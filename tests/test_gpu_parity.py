@@ -62,8 +62,29 @@ def test_residual_matrix_outside_the_gyro_span(hip_small, ora_small, small_case)
         assert np.abs(Ph - Po).max() < 2e-4, delay  # extrapolated quaternions are far from unit: looser
 
 
-def test_presync_curve_per_frame(hip_small, ora_small, small_case):
+def _hip_with_kernel(small_case, kernel, monkeypatch):
+    """a fresh problem on the GPU whose <= 256-track frames run PreSync / GuessMotion in the one-wave kernel (the
+    default) or in the four-wave tile kernel's one-row-per-thread instantiation, lmeds_kernel<1, .> (VERDICT r2,
+    next #7: compared with the oracle directly, not only with the one-wave kernel).  The switch is read when the
+    device context is created."""
+    import rssync_amd
+    from conftest import fill
+    if kernel == "tile":
+        monkeypatch.setenv("RSSYNC_NO_SMALL_LMEDS", "1")
+    else:
+        monkeypatch.delenv("RSSYNC_NO_SMALL_LMEDS", raising=False)
+    p = rssync_amd.SyncProblem(seed=SEED)
+    monkeypatch.delenv("RSSYNC_NO_SMALL_LMEDS", raising=False)
+    return fill(p, small_case)
+
+
+KERNELS = ["one-wave", "tile"]
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_presync_curve_per_frame(ora_small, small_case, kernel, monkeypatch):
     F = small_case["F"]
+    hip_small = _hip_with_kernel(small_case, kernel, monkeypatch)
     do, co, fco, bho = ora_small.presync_curve(0.0, 0, F, 0.002, 0.2, per_frame=F)
     dh, ch, fch, bhh = hip_small.presync_curve(0.0, 0, F, 0.002, 0.2, per_frame=F)
     np.testing.assert_array_equal(do, dh)  # candidate delays: bit-exact (core_private.cpp:69-70)
@@ -105,13 +126,12 @@ def test_lmeds_selection_is_exact(hip_small, small_case):
     assert mismatches <= 1
 
 
-def test_init_motion_matches_oracle(ora_small, small_case):
-    import rssync_amd
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_init_motion_matches_oracle(ora_small, small_case, kernel, monkeypatch):
     from oracle import oracle as ora
-    from conftest import fill
     F = small_case["F"]
     d0 = 0.036
-    hip = fill(rssync_amd.SyncProblem(seed=SEED), small_case)  # fresh: sampler stream = SYNC_INIT + 0
+    hip = _hip_with_kernel(small_case, kernel, monkeypatch)  # fresh: sampler stream = SYNC_INIT + 0
     Mh, kh = hip.init_motion(d0, 0, F - 1)
     agree = 0
     for f in range(F):
@@ -249,13 +269,17 @@ def test_debug_presync_and_frame_ranges(hip_small, ora_small):
     assert c == 0.0 and d == pytest.approx(-0.05)
 
 
-def test_ragged_and_tiny_frames(small_case):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_ragged_and_tiny_frames(small_case, kernel, monkeypatch):
     """frames with different track counts, down to the minimum of 2, and re-setting a frame"""
     import rssync_amd
     from oracle.oracle import OracleProblem
     g = small_case["gyro"]
     counts = [2, 3, 5, 63, 64, 65, 127, 255, 256, 200, 17]
+    if kernel == "tile":
+        monkeypatch.setenv("RSSYNC_NO_SMALL_LMEDS", "1")
     h = rssync_amd.SyncProblem(seed=SEED)
+    monkeypatch.delenv("RSSYNC_NO_SMALL_LMEDS", raising=False)
     o = OracleProblem(seed=SEED, faithful=False)
     for p in (h, o):
         p.SetGyroQuaternions(g.quats, g.fs, g.t0)
