@@ -219,6 +219,19 @@ int rship_has_device_loop(void); /* 1 where rship_sync_run exists (0 in the CPU 
 int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_center, double search_radius,
                    int simplified, double* d_out, int32_t* iters, double* trace);
 
+/* The WINDOW EXECUTOR (kernels/executor.hpp): Sync for the W windows of the selection, `repeats` chained calls each
+ * (the reference driver runs four per sync point, core_testcode.cpp:314), in ONE launch scheduled on the device --
+ * tasks (window, phase, frame) pulled from a queue by persistent one-wave workgroups; windows advance
+ * independently.  Frames of up to 256 tracks (rship_exec_supported), every window non-empty.  Call after
+ * rship_select_slots + rship_set_plan (no rship_init_motion: the search is the executor's first phase).  Window w
+ * samples its call r with stream_first + r + w * stream_stride.  Out: d_out[W], cost[W] = loss at the returned
+ * delay, iters[W][repeats], trace[W][trace_rows][6] with the rows of a window's calls back to back
+ * (trace_rows >= repeats * max_outer).  Same bits as the chain of launches. */
+int rship_exec_supported(rship_ctx* c);
+int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream_first, uint32_t stream_stride, uint64_t seed,
+                    int max_outer, double search_center, double search_radius, double* d_out, double* cost, int32_t* iters,
+                    double* trace, uint32_t trace_rows);
+
 /* per-slot state in selection order: M[3n], k[n] */
 int rship_get_motion(rship_ctx* c, double* M, double* k, uint32_t cap, uint32_t* n);
 int rship_set_motion(rship_ctx* c, const double* M, const double* k, uint32_t n);

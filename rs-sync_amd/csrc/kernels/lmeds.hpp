@@ -35,6 +35,7 @@ struct LmedsParams {
     const float* fd;
     uint32_t n_cand, chunk, n_chunks;
     uint32_t n_hyp, stream_base, stream_stride; // sampler stream = base + candidate + group * stride
+    const uint32_t* win_stream; // or, if not null (window executor): win_stream[group] + candidate
     uint64_t seed;
     const uint32_t* grp; // slot -> group (window) or null; delays are indexed [candidate][group]
     uint32_t n_grp;      // >= 1

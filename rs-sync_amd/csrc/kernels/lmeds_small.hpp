@@ -19,16 +19,24 @@ namespace {
 
 constexpr int kSmallMaxRpt = 4; // 256 tracks
 
+// LDS of one wave's work on a (frame, chunk): the kernel below owns one; the window executor (executor.hpp) lends its own
+template <int RPT>
+struct LmedsSmallLds {
+    float n[3][64 * RPT]; // unit rows, for the hypotheses' row pairs
+    f4 win[4 * kWinMax];
+    int kd[kMaxChunk];
+    float fd[kMaxChunk];
+};
+
+// the work of one wave (64 threads, the whole workgroup) on slot sf, chunk `chunk`
 template <int RPT, int MODE>
-__global__ __launch_bounds__(64, RPT <= 3 ? 6 : 5) void lmeds_small_kernel(LmedsParams p) {
-    constexpr int ROWS = 64 * RPT;
+__device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t sf, uint32_t chunk, LmedsSmallLds<RPT>& lds) {
     constexpr int kHyp = kHypBatch;
-    __shared__ float s_n[3][ROWS];   // unit rows, for the hypotheses' row pairs
-    __shared__ f4 s_win[4 * kWinMax];
-    __shared__ int s_kd[kMaxChunk];
-    __shared__ float s_fd[kMaxChunk];
+    float (&s_n)[3][64 * RPT] = lds.n;
+    f4* s_win = lds.win;
+    int* s_kd = lds.kd;
+    float* s_fd = lds.fd;
     const int lane = threadIdx.x;
-    const uint32_t sf = blockIdx.x / p.n_chunks, chunk = blockIdx.x % p.n_chunks;
     if (sf >= p.n_sel) return;
     const uint32_t fi = p.sel[sf];
     const FrameRec fr = p.frames[fi];
@@ -64,7 +72,7 @@ __global__ __launch_bounds__(64, RPT <= 3 ? 6 : 5) void lmeds_small_kernel(Lmeds
     for (uint32_t c = c0; c < c1; ++c) {
         const int base = fr.base_knot + s_kd[c - c0];
         const float fd = s_fd[c - c0];
-        const uint32_t stream = p.stream_base + c + g * p.stream_stride;
+        const uint32_t stream = p.win_stream ? p.win_stream[g] + c : p.stream_base + c + g * p.stream_stride;
         uint32_t bad = 0;
         // ---- rows of P, as unit rows in registers (and in LDS for the row pairs); norms in registers ----
         float nx[RPT], ny[RPT], nz[RPT], nrm[RPT];
@@ -201,6 +209,12 @@ __global__ __launch_bounds__(64, RPT <= 3 ? 6 : 5) void lmeds_small_kernel(Lmeds
         if (bad) atomicOr(p.flags, bad);
         __syncthreads(); // the rows in LDS are read (hypotheses) before the next candidate rewrites them
     }
+}
+
+template <int RPT, int MODE>
+__global__ __launch_bounds__(64, RPT <= 3 ? 6 : 5) void lmeds_small_kernel(LmedsParams p) {
+    __shared__ LmedsSmallLds<RPT> lds;
+    lmeds_small_body<RPT, MODE>(p, blockIdx.x / p.n_chunks, blockIdx.x % p.n_chunks, lds);
 }
 
 } // namespace

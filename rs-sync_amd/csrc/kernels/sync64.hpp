@@ -280,6 +280,7 @@ struct Motion64Params {
     int32_t* init_h;
     uint64_t seed;
     uint32_t stream_base, stream_stride; // sampler stream = base + group * stride
+    const uint32_t* win_stream;          // or, if not null (window executor): win_stream[group]
     int simple_k; // 1: k = clamp(100 / sqrt(sum |P_j|^2)) only (no-translation variant), no M, no optimisation
     uint32_t slot0; // the launch covers slots slot0 .. slot0 + gridDim.x
     // Longest first: workgroup b of the launch takes slot order[slot0 + b] (null: slot0 + b), a permutation of the
@@ -363,19 +364,31 @@ struct LbfgsHistLds {
 
 __device__ __forceinline__ double clamp_k(double k) { return rs::clamp_k64(k); } // inline_utils.hpp:50
 
-template <int RPT, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? (RPT <= 8 ? 3 : (RPT == 16 ? 2 : 1)) : (NW == 1 ? (RPT >= 8 ? 3 : 4) : 2)) void opt_motion64_kernel(Motion64Params p) {
-    constexpr int kThreads = 64 * NW;
-    __shared__ d4 s_win[4 * kWinMax];
-    __shared__ double s_part[2][NW][4];
-    __shared__ double s_S[kNB][3], s_Y[kNB][3];
+// LDS of one workgroup's work on a slot: the kernel below owns one; the window executor (executor.hpp) lends its own
+template <int NW>
+struct MotionLds {
+    d4 win[4 * kWinMax];
+    double part[2][NW][4];
+    double S[kNB][3], Y[kNB][3];
     // two-loop scratch: every thread writes the same values and reads them back itself;
     // the barrier inside each evaluation separates one iteration's use from the next
-    __shared__ double s_rho[kNB], s_alpha[kNB];
-    __shared__ double s_inv_ys[kNB]; // 1 / (y . s) of each stored pair: the value the two-loop recursion divides for
-    __shared__ double s_red[NW];
+    double rho[kNB], alpha[kNB];
+    double inv_ys[kNB]; // 1 / (y . s) of each stored pair: the value the two-loop recursion divides for
+    double red[NW];
+};
+
+template <int RPT, int NW>
+__device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint32_t sf, MotionLds<NW>& lds) {
+    constexpr int kThreads = 64 * NW;
+    d4* s_win = lds.win;
+    double (*s_part)[NW][4] = lds.part;
+    double (*s_S)[3] = lds.S;
+    double (*s_Y)[3] = lds.Y;
+    double* s_rho = lds.rho;
+    double* s_alpha = lds.alpha;
+    double* s_inv_ys = lds.inv_ys;
+    double* s_red = lds.red;
     const int tid = threadIdx.x;
-    const uint32_t sf = p.order ? p.order[blockIdx.x + p.slot0] : blockIdx.x + p.slot0;
     const uint32_t fi = p.sel[sf];
     const FrameRec fr = p.frames[fi];
     const uint32_t N = fr.n;
@@ -414,7 +427,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (RPT <= 8 ? 3 : (RPT == 16 ? 2 :
         d3 Mv = d3{0, 0, 0};
         if (!p.simple_k && pend >= 0) {
             uint32_t i0, i1;
-            rs::sample_pair(p.seed, fr.id, p.stream_base + grp * p.stream_stride, (uint32_t)pend, N, i0, i1);
+            rs::sample_pair(p.seed, fr.id, p.win_stream ? p.win_stream[grp] : p.stream_base + grp * p.stream_stride, (uint32_t)pend, N, i0, i1);
             d3 P0, P1, dP;
             residual_row64<false>(sp, p.rays, (size_t)fr.off + i0, base, fd, P0, dP);
             residual_row64<false>(sp, p.rays, (size_t)fr.off + i1, base, fd, P1, dP);
@@ -464,6 +477,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (RPT <= 8 ? 3 : (RPT == 16 ? 2 :
         }
         if (p.evals_out) p.evals_out[sf] = (uint32_t)ev.evals;
     }
+}
+
+template <int RPT, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? (RPT <= 8 ? 3 : (RPT == 16 ? 2 : 1)) : (NW == 1 ? (RPT >= 8 ? 3 : 4) : 2)) void opt_motion64_kernel(Motion64Params p) {
+    __shared__ MotionLds<NW> lds;
+    opt_motion64_body<RPT, NW>(p, p.order ? p.order[blockIdx.x + p.slot0] : blockIdx.x + p.slot0, lds);
 }
 
 // order[slot0 .. slot0 + count) = the slots slot0 .. slot0 + count sorted by evals[] descending (a counting sort over

@@ -154,18 +154,12 @@ __device__ __forceinline__ bool trial_wanted(const SyncWin& s, int i) {
     return s.phase == 0 ? i < s.nf : i >= s.nf;
 }
 
-// stage G: after loss + gradient (rows: loss, gradient) -- the delays of the trial launch
-__global__ __launch_bounds__(kBlock) void sync_grad_kernel(SyncLoopParams p) {
+// after loss + gradient: the window's sums l1, g1 (backtrack.cpp:4) and how many trials go first
+__device__ __forceinline__ void grad_decide(const SyncLoopParams& p, SyncWin& s, double l1, double g1) {
 #pragma clang fp contract(off)
-    __shared__ double s_tot[2 * kMaxBt];
-    __shared__ double s_stage[kStageDoubles];
-    const uint32_t w = blockIdx.x + p.win0;
-    window_sums(p, w, s_tot, s_stage);
-    if (threadIdx.x != 0) return;
-    SyncWin& s = p.win[w];
     if (s.active && s.phase == 0) { // (a waiting window keeps the loss and gradient of the iteration it waits in)
-        s.l1 = s_tot[0];
-        s.g1 = s_tot[1];
+        s.l1 = l1;
+        s.g1 = g1;
         s.hit = -1;
         if (s.iters == 0 && !p.nf_fixed) {
             // a call's first search has no history: steps of a millisecond and more have never been accepted, so the
@@ -177,10 +171,27 @@ __global__ __launch_bounds__(kBlock) void sync_grad_kernel(SyncLoopParams p) {
             s.nf = want < kHalfBt ? kHalfBt : (want > kMaxBt ? kMaxBt : want);
         }
     }
+}
+// the delays of the trials the window wants evaluated next: tr_kd / tr_fd [10][stride], NaN for the others
+__device__ __forceinline__ void trial_delays(const SyncLoopParams& p, const SyncWin& s, int32_t* tr_kd, double* tr_fd, size_t stride) {
+#pragma clang fp contract(off)
     for (int i = 0; i < kMaxBt; ++i) {
         const double td = trial_wanted(s, i) ? s.x0 - p.ts[i] * s.g1 : __builtin_nan("");
-        split64_dev(td, p.fs, &p.tr_kd[(size_t)i * p.n_win + w], &p.tr_fd[(size_t)i * p.n_win + w]);
+        split64_dev(td, p.fs, &tr_kd[(size_t)i * stride], &tr_fd[(size_t)i * stride]);
     }
+}
+
+// stage G: after loss + gradient (rows: loss, gradient) -- the delays of the trial launch
+__global__ __launch_bounds__(kBlock) void sync_grad_kernel(SyncLoopParams p) {
+#pragma clang fp contract(off)
+    __shared__ double s_tot[2 * kMaxBt];
+    __shared__ double s_stage[kStageDoubles];
+    const uint32_t w = blockIdx.x + p.win0;
+    window_sums(p, w, s_tot, s_stage);
+    if (threadIdx.x != 0) return;
+    SyncWin& s = p.win[w];
+    grad_decide(p, s, s_tot[0], s_tot[1]);
+    trial_delays(p, s, p.tr_kd + w, p.tr_fd + w, p.n_win);
 }
 
 // the first trial of rows [b0, b1) that satisfies the Armijo test (backtrack.cpp:9)
@@ -196,25 +207,19 @@ __device__ __forceinline__ void armijo(const SyncLoopParams& p, SyncWin& s, cons
     }
 }
 
-// stage S: after the trials -- Armijo on them; the step (core_private.cpp:298-305), the stopping rules
-// (:316-328) and the trace row, or one more iteration for the rest of the trials; the delays of the next
-// iteration's launches
-__global__ __launch_bounds__(kBlock) void sync_step_kernel(SyncLoopParams p) {
+// after the trials: Armijo on the rows just evaluated (lt[10]); then either the window waits for its remaining
+// trials (returns false) or it steps (core_private.cpp:298-305): momentum, delay, the stopping rules (:316-328) and
+// the trace row, written at rows + iteration * row_stride.  Leaves x0 of the next iteration in s.x0.
+__device__ __forceinline__ bool step_decide(const SyncLoopParams& p, SyncWin& s, const double* lt, double* rows, size_t row_stride) {
 #pragma clang fp contract(off)
-    __shared__ double s_tot[2 * kMaxBt];
-    __shared__ double s_stage[kStageDoubles];
-    const uint32_t w = blockIdx.x + p.win0;
-    window_sums(p, w, s_tot, s_stage);
-    if (threadIdx.x != 0) return;
-    SyncWin& s = p.win[w];
     bool step_now = false;
     if (s.active) {
         if (s.phase == 0) {
-            armijo(p, s, s_tot, 0, s.nf);
+            armijo(p, s, lt, 0, s.nf);
             if (s.hit >= 0 || s.nf >= kMaxBt) step_now = true;
-            else s.phase = 1; // nothing among the first nf: the others are evaluated in the next iteration
+            else s.phase = 1; // nothing among the first nf: the others are evaluated next
         } else {
-            armijo(p, s, s_tot, s.nf, kMaxBt);
+            armijo(p, s, lt, s.nf, kMaxBt);
             step_now = true;
         }
     }
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(kBlock) void sync_step_kernel(SyncLoopParams p) {
         s.v = p.delay_b * s.v + step; // :301
         s.d += s.v;                   // :302
         const double step_size = fabs(step);
-        double* row = p.trace + ((size_t)s.iters * p.n_win + w) * 6; // [iteration of the window][window][6]
+        double* row = rows + (size_t)s.iters * row_stride;
         row[0] = s.d; row[1] = step; row[2] = v; row[3] = g; row[4] = t; row[5] = (double)trials;
         s.iters += 1;
         s.phase = 0;
@@ -242,9 +247,22 @@ __global__ __launch_bounds__(kBlock) void sync_step_kernel(SyncLoopParams p) {
         if (!stop && fabs(s.d - p.search_center) > p.search_radius) stop = true;    // :326-328
         if (stop || s.iters == p.max_outer) s.active = 0;                           // :309
     }
+    s.x0 = s.active ? s.d - p.delay_b * s.v : __builtin_nan("");
+    return step_now;
+}
+
+// stage S: after the trials -- the decision above; the delays of the next iteration's launches
+__global__ __launch_bounds__(kBlock) void sync_step_kernel(SyncLoopParams p) {
+#pragma clang fp contract(off)
+    __shared__ double s_tot[2 * kMaxBt];
+    __shared__ double s_stage[kStageDoubles];
+    const uint32_t w = blockIdx.x + p.win0;
+    window_sums(p, w, s_tot, s_stage);
+    if (threadIdx.x != 0) return;
+    SyncWin& s = p.win[w];
+    step_decide(p, s, s_tot, p.trace + (size_t)w * 6, (size_t)p.n_win * 6); // [iteration of the window][window][6]
     if (s.active) atomicAdd(&p.n_active[p.it], 1);
     const bool go = s.active && s.phase == 0; // a waiting window has no motion and no gradient launch
-    s.x0 = s.active ? s.d - p.delay_b * s.v : __builtin_nan("");
     split64_dev(go ? s.d : __builtin_nan(""), p.fs, &p.mo_kd[w], &p.mo_fd[w]);
     split64_dev(go ? s.x0 : __builtin_nan(""), p.fs, &p.lg_kd[w], &p.lg_fd[w]);
 }

@@ -51,6 +51,7 @@ using rs::f4;
 #include "kernels/support.hpp"
 #include "kernels/sync64.hpp"
 #include "kernels/syncloop.hpp"
+#include "kernels/executor.hpp"
 #include "kernels/gyro.hpp"
 
 // ===========================================================================
@@ -1416,6 +1417,201 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
         d_out[w] = hw[w].d;
         iters[w] = hw[w].iters;
         for (int k = 0; k < hw[w].iters; ++k) memcpy(trace + ((size_t)w * max_outer + k) * 6, tr + ((size_t)k * W + w) * 6, 48);
+    }
+    return 0;
+}
+
+// Sync for the W windows of the selection, `repeats` chained calls each (the reference driver's four, core_testcode.cpp:
+// 314), in ONE launch of the window executor (kernels/executor.hpp): frames of up to 256 tracks.  d0[W] in; d_out[W],
+// cost[W] (loss at the returned delay), iters[W][repeats], and the trace rows of all calls of a window back to back,
+// trace[W][trace_rows][6] (trace_rows >= repeats * max_outer).  Window w samples call r with stream_first + r + w * stride.
+int rship_exec_supported(rship_ctx* c) {
+    const uint32_t n = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
+    return n >= 2 && n <= 64u * kSmallMaxRpt ? 1 : 0;
+}
+
+int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream_first, uint32_t stream_stride, uint64_t seed,
+                    int max_outer, double search_center, double search_radius, double* d_out, double* cost, int32_t* iters,
+                    double* trace, uint32_t trace_rows) {
+    DeviceGuard dev_guard(c);
+    if (check_ready(c)) return 1;
+    const uint32_t W = c->n_grp, ns = c->n_sel;
+    if (!rship_exec_supported(c)) return set_err(c, "sync_exec: frames of more than 256 tracks");
+    if (c->plan_wins != W || c->plan_has_idx || c->plan_len != ns) return set_err(c, "sync_exec: the plan must be the selection's groups");
+    if (max_outer <= 0 || repeats < 1 || repeats > kExecMaxCalls) return set_err(c, "sync_exec: bad iteration or call count");
+    if (trace_rows < (uint32_t)repeats * (uint32_t)max_outer) return set_err(c, "sync_exec: trace too small");
+    if (c->h_grp_off.size() != (size_t)W + 1) return set_err(c, "sync_exec: no selection");
+    for (uint32_t w = 0; w < W; ++w)
+        if (c->h_grp_off[w + 1] == c->h_grp_off[w]) return set_err(c, "sync_exec: a window without frames");
+    int nf_fixed = 0;
+    if (const char* e = std::getenv("RSSYNC_LOOP_FIRST_TRIALS")) { const int v = atoi(e); if (v >= 1 && v <= kMaxBt) nf_fixed = v; }
+    uint32_t q_cap = 64;
+    while (q_cap < ns + 1) q_cap *= 2;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t o_win = take(W * sizeof(ExecWin));
+    const size_t o_inkd = take(W * 4), o_infd = take(W * 4), o_stream = take(W * 4);
+    const size_t o_mokd = take(W * 4), o_mofd = take(W * 8), o_lgkd = take(W * 4), o_lgfd = take(W * 8);
+    const size_t o_trkd = take((size_t)kMaxBt * W * 4), o_trfd = take((size_t)kMaxBt * W * 8);
+    const size_t o_q = take((size_t)q_cap * 4), o_ctl = take(64);
+    const size_t o_trace = take((size_t)W * trace_rows * 48);
+    if (ensure(c, c->loop_state, off) || ensure(c, c->part, (size_t)2 * kMaxBt * ns * 8) || ensure(c, c->flags, 16)) return 1;
+    char* base = (char*)c->loop_state.p;
+
+    // host-side initial state: every window in its first call, its slots queued for the search
+    std::vector<ExecWin> hw(W);
+    std::vector<int32_t> in_kd(W);
+    std::vector<float> in_fd(W);
+    std::vector<uint32_t> streams(W), queue(q_cap, 0u);
+    const double kClamp = (double)(1 << 29);
+    for (uint32_t w = 0; w < W; ++w) {
+        ExecWin& e = hw[w];
+        e = ExecWin{};
+        e.s.d = d0[w];
+        e.s.active = 1;
+        e.s.hit = -1;
+        e.s.nf = nf_fixed ? nf_fixed : kHalfBt;
+        e.s.x0 = d0[w] - .3 * 0.0;
+        e.slot0 = c->h_grp_off[w];
+        e.n_slots = c->h_grp_off[w + 1] - c->h_grp_off[w];
+        e.phase = kPhInit;
+        e.remaining = e.n_slots;
+        streams[w] = stream_first + w * stream_stride;
+        // the fp32 split of the host solver (sync_problem.cpp: split_delay)
+        const double D = d0[w] * c->fs;
+        if (!std::isfinite(D)) { in_kd[w] = 0; in_fd[w] = 0.f; }
+        else {
+            double fl = std::floor(D);
+            float f = (float)(D - fl);
+            if (f >= 1.0f) { f = 0.f; fl += 1.0; }
+            fl = std::min(std::max(fl, -kClamp), kClamp);
+            in_kd[w] = (int32_t)fl;
+            in_fd[w] = f;
+        }
+    }
+    for (uint32_t j = 0; j < ns; ++j) queue[j] = j + 1u;
+    const uint32_t ctl[4] = {0u /* head */, ns /* tail */, 0u /* done */, 0u /* abort */};
+    RS_HIP(hipMemcpyAsync(base + o_win, hw.data(), W * sizeof(ExecWin), hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemcpyAsync(base + o_inkd, in_kd.data(), W * 4, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemcpyAsync(base + o_infd, in_fd.data(), W * 4, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemcpyAsync(base + o_stream, streams.data(), W * 4, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemcpyAsync(base + o_q, queue.data(), (size_t)q_cap * 4, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemcpyAsync(base + o_ctl, ctl, sizeof(ctl), hipMemcpyHostToDevice, c->stream));
+
+    ExecParams ep{};
+    {
+        double t = 1e-3; // t0, decay = 0.1 (core_private.cpp:226): the host loop's sequence, bit for bit
+        for (int i = 0; i <= kMaxBt; ++i) { ep.lp.ts[i] = t; t *= .1; }
+    }
+    ep.lp.fs = c->fs;
+    ep.lp.c_armijo = 2e-4;
+    ep.lp.delay_b = .3;
+    ep.lp.search_center = search_center;
+    ep.lp.search_radius = search_radius;
+    ep.lp.max_outer = max_outer;
+    ep.lp.nf_fixed = nf_fixed;
+    ep.win = (ExecWin*)(base + o_win);
+    ep.n_win = W;
+    ep.n_sel = ns;
+    ep.grp = (const uint32_t*)c->grp.p;
+    ep.in_kd = (int32_t*)(base + o_inkd); ep.in_fd = (float*)(base + o_infd);
+    ep.win_stream = (uint32_t*)(base + o_stream);
+    ep.mo_kd = (int32_t*)(base + o_mokd); ep.mo_fd = (double*)(base + o_mofd);
+    ep.lg_kd = (int32_t*)(base + o_lgkd); ep.lg_fd = (double*)(base + o_lgfd);
+    ep.tr_kd = (int32_t*)(base + o_trkd); ep.tr_fd = (double*)(base + o_trfd);
+    ep.part = (double*)c->part.p;
+    ep.chunk_off = (const uint32_t*)c->plan_chunk_off.p;
+    ep.win_chunk_off = (const uint32_t*)c->plan_win_off.p;
+    ep.trace = (double*)(base + o_trace);
+    ep.trace_rows = trace_rows;
+    ep.stream_first = stream_first;
+    ep.stream_stride = stream_stride;
+    ep.repeats = repeats;
+    ep.q = (uint32_t*)(base + o_q);
+    ep.q_mask = q_cap - 1;
+    ep.q_head = (uint32_t*)(base + o_ctl);
+    ep.q_tail = ep.q_head + 1;
+    ep.done = ep.q_head + 2;
+    ep.abort_flag = ep.q_head + 3;
+    ep.spin_limit = 1u << 23; // ~ seconds of polling an empty queue: something is wrong
+    // GuessMotion's search (fp32, one wave per frame)
+    ep.init.rays_a = (const f4*)c->rays_a.p;
+    ep.init.rays_b = (const f4*)c->rays_b.p;
+    ep.init.frames = (const FrameRec*)c->frames.p;
+    ep.init.sel = (const uint32_t*)c->sel.p;
+    ep.init.n_sel = ns;
+    ep.init.coef = (const f4*)c->coef.p;
+    ep.init.n_knots = (int)c->n_knots;
+    ep.init.kd = ep.in_kd;
+    ep.init.fd = ep.in_fd;
+    ep.init.n_cand = 1; ep.init.chunk = 1; ep.init.n_chunks = 1;
+    ep.init.n_hyp = 200; // core_private.cpp:127
+    ep.init.seed = seed;
+    ep.init.win_stream = ep.win_stream;
+    ep.init.grp = ep.grp;
+    ep.init.n_grp = W;
+    ep.init.best_h = (int32_t*)c->init_h.p;
+    ep.init.flags = (uint32_t*)c->flags.p;
+    // motion
+    fill_motion(c, ep.mo);
+    ep.mo.kd = ep.mo_kd;
+    ep.mo.fd = ep.mo_fd;
+    ep.mo.grp = ep.grp;
+    ep.mo.seed = seed;
+    ep.mo.win_stream = ep.win_stream;
+    ep.mo.order = nullptr;
+    ep.mo.evals_out = nullptr;
+    // loss
+    ep.lo.rays = rays64_of(c);
+    ep.lo.frames = (const FrameRec*)c->frames.p;
+    ep.lo.sel = (const uint32_t*)c->sel.p;
+    ep.lo.n_sel = ns;
+    ep.lo.coef = (const d4*)c->coef64.p;
+    ep.lo.n_knots = (int)c->n_knots;
+    ep.lo.fs = c->fs;
+    ep.lo.M = (const double*)c->M.p;
+    ep.lo.k = (const double*)c->k.p;
+
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+    uint32_t waves = (uint32_t)n_cu * 8u; // what the chip holds at once (LDS: ~19 KB per wave); more would only idle
+    if (waves > ns) waves = ns;
+    const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
+    {
+        ProfScope ps(c, RSHIP_K_MOTION);
+        switch ((n_all + 63u) / 64u) {
+            case 0:
+            case 1: hipLaunchKernelGGL((sync_exec_kernel<1>), dim3(waves), dim3(64), 0, c->stream, ep); break;
+            case 2: hipLaunchKernelGGL((sync_exec_kernel<2>), dim3(waves), dim3(64), 0, c->stream, ep); break;
+            case 3: hipLaunchKernelGGL((sync_exec_kernel<3>), dim3(waves), dim3(64), 0, c->stream, ep); break;
+            default: hipLaunchKernelGGL((sync_exec_kernel<4>), dim3(waves), dim3(64), 0, c->stream, ep); break;
+        }
+    }
+    RS_HIP(hipGetLastError());
+    c->init_pending = false;
+    // results: the windows first (how many rows each has written), then that many rows of every window
+    if (ensure_pinned(c, W * sizeof(ExecWin) + 64)) return 1;
+    uint32_t* h_ctl = (uint32_t*)((char*)c->pinned + W * sizeof(ExecWin));
+    RS_HIP(hipMemcpyAsync(c->pinned, base + o_win, W * sizeof(ExecWin), hipMemcpyDeviceToHost, c->stream));
+    RS_HIP(hipMemcpyAsync(h_ctl, base + o_ctl, 16, hipMemcpyDeviceToHost, c->stream));
+    if (sync_stream(c)) return 1;
+    if (h_ctl[3]) return set_err(c, "sync_exec: watchdog (a wave polled an empty task queue for seconds)");
+    if (h_ctl[2] != W) return set_err(c, "sync_exec: " + std::to_string(h_ctl[2]) + " of " + std::to_string(W) + " windows finished");
+    memcpy(hw.data(), c->pinned, W * sizeof(ExecWin));
+    uint32_t rows_max = 0;
+    for (uint32_t w = 0; w < W; ++w) rows_max = std::max(rows_max, (uint32_t)hw[w].trace_base);
+    if (rows_max) {
+        if (ensure_pinned(c, (size_t)W * rows_max * 48 + 64)) return 1;
+        RS_HIP(hipMemcpy2DAsync(c->pinned, (size_t)rows_max * 48, base + o_trace, (size_t)trace_rows * 48, (size_t)rows_max * 48, W,
+                                hipMemcpyDeviceToHost, c->stream));
+        if (sync_stream(c)) return 1;
+    }
+    for (uint32_t w = 0; w < W; ++w) {
+        d_out[w] = hw[w].s.d;
+        cost[w] = hw[w].cost;
+        for (int r = 0; r < repeats; ++r) iters[(size_t)w * repeats + r] = hw[w].iters_call[r];
+        if (hw[w].trace_base)
+            memcpy(trace + (size_t)w * trace_rows * 6, (const char*)c->pinned + (size_t)w * rows_max * 48, (size_t)hw[w].trace_base * 48);
     }
     return 0;
 }

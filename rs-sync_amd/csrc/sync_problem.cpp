@@ -258,6 +258,11 @@ class SyncProblemHip final : public ISyncProblem {
     std::vector<int32_t> last_init_winners, init_override;
     void exchange_init_winners();
     uint32_t sync_calls = 0;
+    bool use_executor = true; // small frames: Sync's calls of all windows in one device-scheduled launch (RSSYNC_NO_EXECUTOR=1: the chain of launches)
+    bool executor_ok(bool simplified);
+    void sync_exec(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl, const std::vector<double>& initial,
+                   double search_center, double search_radius, int repeats, uint32_t stream_first, uint32_t stream_stride,
+                   std::vector<double>& costs, std::vector<double>& delays_out);
     bool host_loop = false; // keep Sync's outer loop on the host even where the device could run it (tests)
     uint64_t last_best_not_last = 0; // of the last rssync_ext_opt_motion call
 
@@ -322,6 +327,7 @@ SyncProblemHip::SyncProblemHip() {
     if (const char* s = std::getenv("RSSYNC_MAX_OUTER_ITERS")) max_outer = std::atoi(s);
     if (const char* s = std::getenv("RSSYNC_QUIET")) verbose = !(s[0] && s[0] != '0');
     if (const char* s = std::getenv("RSSYNC_HOST_LOOP")) host_loop = s[0] && s[0] != '0';
+    if (const char* s = std::getenv("RSSYNC_NO_EXECUTOR")) use_executor = !(s[0] && s[0] != '0');
     // RSSYNC_GPUS: how many GPUs this object spreads its frames over ("4" = devices 0..3) or which
     // ("0,2,5"); default: the calling thread's current device only
     std::vector<int> ids;
@@ -1218,6 +1224,43 @@ void SyncProblemHip::select_windows(const std::vector<int64_t>& begins, const st
 //    five and the first that satisfies the Armijo test is taken, which is what the
 //    sequential loop returns;
 //  * P is computed once per motion optimisation, not three times per evaluation (:94-97).
+// Can the window executor (kernels/executor.hpp) run the current selection?  One device holding every frame, nobody
+// else in the sums, frames of up to 256 tracks, no empty window.
+bool SyncProblemHip::executor_ok(bool simplified) {
+    if (!use_executor || simplified || shards_.size() != 1 || distributed() || host_loop || max_outer <= 0 || sel_.empty()) return false;
+    if (!rship_has_device_loop() || !rship_exec_supported(shards_[0].ctx)) return false;
+    if (record_init || !init_override.empty()) return false; // (the diagnostics hook into the separate search launch)
+    const Shard& sh = shards_[0];
+    if (sh.win_chunk_off.size() != n_windows_ + 1) return false;
+    for (size_t w = 0; w < n_windows_; ++w)
+        if (sh.win_chunk_off[w + 1] == sh.win_chunk_off[w]) return false; // a window without frames
+    return true;
+}
+
+// `repeats` chained Sync calls on the selected windows in one launch; fills traces (all calls' rows per window)
+void SyncProblemHip::sync_exec(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl,
+                               const std::vector<double>& initial, double search_center, double search_radius, int repeats,
+                               uint32_t stream_first, uint32_t stream_stride, std::vector<double>& costs,
+                               std::vector<double>& delays_out) {
+    (void)begins; (void)ends_incl;
+    const size_t W = n_windows_;
+    Shard& sh = shards_[0];
+    const uint32_t rows = (uint32_t)repeats * (uint32_t)max_outer;
+    std::vector<double> tr((size_t)W * rows * 6, 0.0);
+    std::vector<int32_t> its(W * (size_t)repeats, 0);
+    costs.assign(W, 0.0);
+    delays_out.assign(W, 0.0);
+    hip_check(sh, rship_sync_exec(sh.ctx, initial.data(), repeats, stream_first, stream_stride, seed, max_outer, search_center,
+                                  search_radius, delays_out.data(), costs.data(), its.data(), tr.data(), rows),
+              "sync executor");
+    traces.assign(W, {});
+    for (size_t w = 0; w < W; ++w) {
+        size_t n = 0;
+        for (int r = 0; r < repeats; ++r) n += (size_t)its[w * repeats + r];
+        traces[w].assign(tr.begin() + w * (size_t)rows * 6, tr.begin() + (w * (size_t)rows + n) * 6);
+    }
+}
+
 void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl,
                                   const std::vector<double>& initial, double search_center, double search_radius,
                                   std::vector<double>& costs, std::vector<double>& delays_out, uint32_t call_stride,
@@ -1225,6 +1268,23 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
     ensure_device();
     const size_t W = begins.size();
     select_windows(begins, ends_incl);
+    if (executor_ok(simplified)) {
+        // frames of up to 256 tracks: the search, the loop and the final loss of every window as one launch
+        sync_exec(begins, ends_incl, initial, search_center, search_radius, 1, kStreamSyncInit + sync_calls, call_stride, costs,
+                  delays_out);
+        if (call_stride == 1) sync_calls += (uint32_t)W;
+        if (verbose && W == 1) { // :330, the lines the host loop would have written
+            int conv = 0;
+            for (size_t it = 0; it * 6 < traces[0].size(); ++it) {
+                const double* row = &traces[0][it * 6];
+                const double step_size = std::fabs(row[1]);
+                if (step_size < 1e-4) conv++; else conv = 0;
+                const bool stop = conv > 5 || std::fabs(row[0] - search_center) > search_radius;
+                if (!stop) std::cerr << row[0] << " " << step_size << std::endl;
+            }
+        }
+        return;
+    }
     std::vector<double> d(initial);
     // :218-223; window w samples with stream SYNC_INIT + sync_calls + w * call_stride.  With
     // stride 1 the call consumes W consecutive call numbers; sync_points() interleaves
@@ -1435,6 +1495,18 @@ void SyncProblemHip::sync_points(const std::vector<int64_t>& positions, int64_t 
         presync_windows(initial_delay, positions, ends, presync_step, presync_radius, c, d);
     }
     const uint32_t first_call = sync_calls;
+    if (repeats >= 1 && repeats <= 8) {
+        // all repeats of all positions in ONE launch where the executor can run them: a position starts its next
+        // call the moment it has finished the previous one
+        ensure_device();
+        select_windows(positions, ends);
+        if (executor_ok(false)) {
+            sync_exec(positions, ends, d, initial_delay, radius, repeats, kStreamSyncInit + first_call, (uint32_t)repeats, costs,
+                      delays_out);
+            sync_calls = first_call + (uint32_t)(W * (size_t)repeats);
+            return;
+        }
+    }
     std::vector<std::vector<double>> all(W);
     for (int r = 0; r < repeats; ++r) { // :314 (Sync's range is end-inclusive: window + 1 frames)
         sync_calls = first_call + (uint32_t)r;

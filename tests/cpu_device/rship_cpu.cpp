@@ -693,6 +693,11 @@ int rship_loss_collect(rship_ctx* c, uint32_t n_delays, double* win_loss, double
     return 0;
 }
 
+int rship_exec_supported(rship_ctx*) { return 0; } // the window executor is a device scheduler: nothing to stand in for
+int rship_sync_exec(rship_ctx* c, const double*, int, uint32_t, uint32_t, uint64_t, int, double, double, double*, double*, int32_t*,
+                    double*, uint32_t) {
+    return fail(c, "sync_exec: device only");
+}
 int rship_has_device_loop(void) { return 0; } // the host loop is what this double is there to exercise
 int rship_sync_run(rship_ctx* c, const double*, int, double, double, int, double*, int32_t*, double*) {
     return fail(c, "sync_run: device only");

@@ -1,0 +1,113 @@
+"""The window executor (kernels/executor.hpp: Sync for frames of up to 256 tracks as ONE device-scheduled launch --
+tasks (window, phase, frame) pulled from a queue by persistent waves, windows advancing independently, a sync
+point's four calls chained per window) against the chain of launches it replaces (RSSYNC_NO_EXECUTOR=1, read when a
+problem is created): the same task bodies, sums and decisions, so the SAME BITS -- delays, costs, every trace row."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _two(**kw):
+    import rssync_amd
+    a = rssync_amd.SyncProblem(**kw)
+    os.environ["RSSYNC_NO_EXECUTOR"] = "1"
+    try:
+        b = rssync_amd.SyncProblem(**kw)
+    finally:
+        del os.environ["RSSYNC_NO_EXECUTOR"]
+    return a, b
+
+
+def _bits(x):
+    return np.ascontiguousarray(x, np.float64).view(np.uint64)
+
+
+def _fill(ps, gyro, frames):
+    for p in ps:
+        p.SetGyroQuaternions(gyro.quats, gyro.fs, gyro.t0)
+        for fr in frames:
+            p.SetTrackResult(*fr)
+
+
+@pytest.mark.parametrize("N", [256, 130, 64, 40])
+def test_single_sync_call(built, N):
+    from rssync_amd import synth
+    F = 48
+    gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=11)
+    frames = list(synth.make_frames(gyro, 0, F, N, seed=11))
+    ex, ch = _two(seed=31, max_outer_iters=60)
+    _fill((ex, ch), gyro, frames)
+    d0 = ex.PreSync(0.0, 0, F, 0.002, 0.1)[1]
+    assert d0 == ch.PreSync(0.0, 0, F, 0.002, 0.1)[1]
+    r1, r2 = ex.Sync(d0, 0, F - 1, 0.0, 0.1), ch.Sync(d0, 0, F - 1, 0.0, 0.1)
+    t1, t2 = ex.sync_trace(), ch.sync_trace()
+    assert t1.shape == t2.shape and len(t1) >= 3
+    np.testing.assert_array_equal(_bits(t1), _bits(t2))
+    assert r1 == r2
+    # a second call continues the sampler's call counter on both sides
+    assert ex.Sync(r1[1], 0, F - 1, 0.0, 0.1) == ch.Sync(r2[1], 0, F - 1, 0.0, 0.1)
+    np.testing.assert_array_equal(_bits(ex.sync_trace()), _bits(ch.sync_trace()))
+
+
+def test_overlapping_ragged_windows_and_the_iteration_cap(built):
+    from rssync_amd import synth
+    F = 60
+    gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=12)
+    rng = np.random.default_rng(8)
+    frames = []
+    for fr in range(F):
+        frames += list(synth.make_frames(gyro, fr, fr + 1, int(rng.integers(2, 256)), seed=12))
+    ex, ch = _two(seed=32, max_outer_iters=7)   # the cap stops most windows before they converge
+    _fill((ex, ch), gyro, frames)
+    b = [0, 5, 11, 20, 21, 40, 3]
+    e = [14, 25, 30, 44, 59, 59, 3]            # one window is a single frame
+    d0 = np.linspace(0.034, 0.039, len(b))
+    (c1, d1), (c2, d2) = ex.sync_windows(d0, b, e, 0.0, 0.2), ch.sync_windows(d0, b, e, 0.0, 0.2)
+    np.testing.assert_array_equal(_bits(d1), _bits(d2))
+    np.testing.assert_array_equal(_bits(c1), _bits(c2))
+    for w in range(len(b)):
+        np.testing.assert_array_equal(_bits(ex.window_trace(w)), _bits(ch.window_trace(w)))
+
+
+@pytest.mark.parametrize("first_trials", [None, "1", "10"])
+def test_sync_points_four_chained_calls(built, monkeypatch, first_trials):
+    """the reference driver's loop (core_testcode.cpp:303-316): PreSync then four Sync calls per position; with
+    RSSYNC_LOOP_FIRST_TRIALS=1 every line search has to wait for its later trials"""
+    from rssync_amd import synth
+    if first_trials:
+        monkeypatch.setenv("RSSYNC_LOOP_FIRST_TRIALS", first_trials)
+    F, N, window = 150, 130, 30
+    gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=13)
+    frames = list(synth.make_frames(gyro, 0, F, N, seed=13))
+    ex, ch = _two(seed=33, max_outer_iters=400)
+    _fill((ex, ch), gyro, frames)
+    pos = list(range(0, F - window - 1, 9))
+    (c1, d1), (c2, d2) = ex.sync_points(pos, window, 0.0, 0.002, 0.1), ch.sync_points(pos, window, 0.0, 0.002, 0.1)
+    np.testing.assert_array_equal(_bits(d1), _bits(d2))
+    np.testing.assert_array_equal(_bits(c1), _bits(c2))
+    for w in range(len(pos)):
+        t1, t2 = ex.window_trace(w), ch.window_trace(w)
+        assert t1.shape == t2.shape and len(t1) >= 4
+        np.testing.assert_array_equal(_bits(t1), _bits(t2))
+    # and the sequential calls through the ISyncProblem methods give the same delays
+    seq = []
+    for p0 in pos[:3]:
+        d = ch.PreSync(0.0, p0, p0 + window, 0.002, 0.1)[1]
+        for _ in range(4):
+            d = ch.Sync(d, p0, p0 + window, 0.0, 0.1)[1]
+        seq.append(d)
+    ex2, _ = _two(seed=33, max_outer_iters=400)
+    _fill((ex2,), gyro, frames)
+    _, dd = ex2.sync_points(pos[:3], window, 0.0, 0.002, 0.1)
+    ch3 = _two(seed=33, max_outer_iters=400)[1]
+    _fill((ch3,), gyro, frames)
+    seq3 = []
+    for p0 in pos[:3]:
+        d = ch3.PreSync(0.0, p0, p0 + window, 0.002, 0.1)[1]
+        for _ in range(4):
+            d = ch3.Sync(d, p0, p0 + window, 0.0, 0.1)[1]
+        seq3.append(d)
+    np.testing.assert_array_equal(_bits(dd), _bits(seq3))
