@@ -78,6 +78,22 @@ __device__ __forceinline__ double block_sum(float v, double* slot) {
     return slot[0] + slot[1] + slot[2] + slot[3];
 }
 
+// Data that other workgroups write DURING the launch (the window executor, executor.hpp): per-XCD L2s are not
+// coherent and a CU's L1 is never refreshed, so such words are loaded and stored with `sc1` (relaxed agent-scope
+// atomics: the access goes past L1 and is served / written through coherently) on both sides, and a signal (a
+// counter add, a queue cell) is sent only after `s_waitcnt vmcnt(0)`.  SC1 = false: the plain access of every other kernel.
+template <bool SC1, class T>
+__device__ __forceinline__ T ld_m(const T* p) {
+    if (SC1) return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool SC1, class T>
+__device__ __forceinline__ void st_m(T* p, T v) {
+    if (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+__device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ bool finite_f(float x) { return (__float_as_uint(x) & kInfBits) != kInfBits; }
 
 // ---------------------------------------------------------------------------

@@ -27,6 +27,19 @@
 
 namespace {
 
+// -DRSSYNC_EXEC_STATS=1: wall-clock ticks (s_memrealtime, 100 MHz) per activity, summed over the waves
+#ifndef RSSYNC_EXEC_STATS
+#define RSSYNC_EXEC_STATS 0
+#endif
+#if RSSYNC_EXEC_STATS
+__device__ unsigned long long g_exec_stats[16]; // 0-4 task phases, 5 decide, 6 pop (waiting included), 8+ph task counts, 13 decides, 14 pops
+#define EXEC_T0() const unsigned long long t0__ = __builtin_amdgcn_s_memrealtime()
+#define EXEC_ADD(i, n) do { if (threadIdx.x == 0) { atomicAdd(&g_exec_stats[i], __builtin_amdgcn_s_memrealtime() - t0__); atomicAdd(&g_exec_stats[n], 1ull); } } while (0)
+#else
+#define EXEC_T0() do { } while (0)
+#define EXEC_ADD(i, n) do { } while (0)
+#endif
+
 constexpr int kExecMaxCalls = 8;
 enum : int { kPhInit = 0, kPhMotion = 1, kPhGrad = 2, kPhTrials = 3, kPhFinal = 4, kPhDone = 5 };
 
@@ -34,8 +47,10 @@ struct ExecWin {
     SyncWin s;               // the loop state of the current call
     uint32_t slot0, n_slots; // the window's slots
     int phase, call;
-    uint32_t remaining;      // tasks of the current phase still running
+    uint32_t remaining;      // tasks of the current phase still running (8-byte aligned, with its pad a word of its own)
+    uint32_t remaining_pad;
     int trace_base;          // trace rows written by the earlier calls
+    int pad2;
     double cost;             // loss at the returned delay (core_private.cpp:333), after the last call
     int iters_call[kExecMaxCalls];
 };
@@ -60,8 +75,11 @@ struct ExecParams {
     uint32_t trace_rows;
     uint32_t stream_first, stream_stride; // stream of window w in call r: stream_first + r + w * stream_stride
     int repeats;
-    uint32_t* q;                     // task queue: slot + 1, 0 = empty
-    uint32_t q_mask;
+    // task queue: a ring of 64-bit cells {lap, slot}.  Entry i (a number that only grows) lives in cell i & q_mask and
+    // carries lap (i >> q_shift) + 1: the consumer that claimed number i waits for exactly that lap, so a cell never
+    // has to be cleared and a value left over from an earlier lap is never mistaken for a task.
+    unsigned long long* q;
+    uint32_t q_mask, q_shift;
     uint32_t* q_head; uint32_t* q_tail;
     uint32_t* done;                  // windows finished
     uint32_t* abort_flag;
@@ -83,48 +101,65 @@ __device__ __forceinline__ void split32_dev(double delay, double fs, int32_t* kd
     *fd = f;
 }
 
+// ---- hand-off protocol (MI355X_MICROARCH.md, "inter-workgroup visibility"): every word another workgroup of this
+// launch may have written is loaded with sc1 (ld_m<true>) and stored with sc1 (st_m<true>); a signal -- the add to a
+// window's counter, a queue cell -- goes out only after the signalling wave's s_waitcnt vmcnt(0); the wave whose
+// add came last (told by the value the add returned) reads the others' results.  Words that only ATOMICS change
+// (the counters) are also read with atomics: an sc1 load of such a word was seen to return a stale value for
+// seconds.  No agent-scope fence anywhere: a fence writes back / invalidates a whole L2 (~3.5 us, several times that
+// with eight waves per CU), and per task that was 20x the task (this file's first version: 232 ms for the workload
+// the launch chain does in 30).
+
 __device__ __forceinline__ uint32_t exec_pop(const ExecParams& p) {
     uint32_t idx = 0;
     if (threadIdx.x == 0) idx = __hip_atomic_fetch_add(p.q_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     idx = uniform_u32(idx);
-    uint32_t* cell = p.q + (idx & p.q_mask);
+    const unsigned long long* cell = p.q + (idx & p.q_mask);
+    const uint32_t lap = (idx >> p.q_shift) + 1u;
     for (uint32_t spins = 0;; ++spins) {
-        const uint32_t v = uniform_u32(__hip_atomic_load(cell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
-        if (v) {
-            if (threadIdx.x == 0) __hip_atomic_store(cell, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return v - 1u;
+        const unsigned long long v = ld_m<true>(cell);
+        const uint32_t v_lap = uniform_u32((uint32_t)(v >> 32)), v_slot = uniform_u32((uint32_t)v);
+        if (v_lap == lap) return v_slot;
+        if ((spins & 7u) == 7u) {
+            uint32_t dn = 0, ab = 0;
+            if (threadIdx.x == 0) {
+                dn = __hip_atomic_fetch_add(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ab = __hip_atomic_fetch_add(p.abort_flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (uniform_u32(dn) >= p.n_win) return 0xffffffffu;
+            if (uniform_u32(ab)) return 0xffffffffu;
+            if (spins > p.spin_limit) {
+                if (threadIdx.x == 0) __hip_atomic_fetch_add(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return 0xffffffffu;
+            }
         }
-        if (uniform_u32(__hip_atomic_load(p.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= p.n_win) return 0xffffffffu;
-        if (uniform_u32(__hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return 0xffffffffu;
-        if (spins > p.spin_limit) {
-            if (threadIdx.x == 0) __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return 0xffffffffu;
-        }
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(16);
     }
 }
 
-// the window's slots as tasks of its (already published) next phase
-__device__ __forceinline__ void exec_push(const ExecParams& p, ExecWin& w) {
-    if (threadIdx.x == 0) __hip_atomic_store(&w.remaining, w.n_slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence(); // the window's new state and delays before its tasks
+// the window's slots as tasks of its (already stored) next phase
+__device__ __forceinline__ void exec_push(const ExecParams& p, uint32_t w, uint32_t slot0, uint32_t n_slots) {
+    if (threadIdx.x == 0) st_m<true>(&p.win[w].remaining, n_slots);
+    wait_stores(); // the window's new state, its delays and its counter before its tasks
     uint32_t base = 0;
-    if (threadIdx.x == 0) base = __hip_atomic_fetch_add(p.q_tail, w.n_slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) base = __hip_atomic_fetch_add(p.q_tail, n_slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     base = uniform_u32(base);
-    for (uint32_t i = threadIdx.x; i < w.n_slots; i += 64)
-        __hip_atomic_store(p.q + ((base + i) & p.q_mask), w.slot0 + i + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t i = threadIdx.x; i < n_slots; i += 64) {
+        const uint32_t e = base + i;
+        st_m<true>(p.q + (e & p.q_mask), ((unsigned long long)((e >> p.q_shift) + 1u) << 32) | (slot0 + i));
+    }
 }
 
 // FrameState::Loss (and its analytic d/d-delay) of one slot at one delay by ONE wave, in the association of
 // loss64_kernel for frames of up to 256 tracks: thread t of that kernel's four waves holds row t, each wave is
-// summed by wave_sum_f64, the four wave sums are added left to right.
+// summed by wave_sum_f64, the four wave sums are added left to right.  Mv, kk: the slot's motion estimate.
 template <bool GRAD>
-__device__ __forceinline__ void loss64_wave(const Loss64Params& q, uint32_t sf, int kd, double fd, d4* s_win, double& L_out, double& G_out) {
+__device__ __forceinline__ void loss64_wave(const Loss64Params& q, uint32_t sf, d3 Mv, double kk, int kd, double fd, d4* s_win,
+                                            double& L_out, double& G_out) {
     const int lane = threadIdx.x;
     const FrameRec fr = q.frames[q.sel[sf]];
     const uint32_t N = fr.n;
-    const d3 Mv = d3{q.M[3 * sf], q.M[3 * sf + 1], q.M[3 * sf + 2]};
-    const double inv_s = rs::loss_inv_s(false, q.k[sf], Mv);
+    const double inv_s = rs::loss_inv_s(false, kk, Mv);
     Spline64 sp;
     sp.g = q.coef;
     sp.n = q.n_knots;
@@ -154,67 +189,108 @@ __device__ __forceinline__ void loss64_wave(const Loss64Params& q, uint32_t sf, 
     G_out = GRAD ? (Gw[0] + Gw[1] + Gw[2] + Gw[3]) * q.fs : 0.0;
 }
 
-// the window's sum of row r of part[] in the plan's order (window_sums / plan_sum_kernel: chunks sequentially, then
-// the chunks in order); lane r < rows computes row r
-__device__ __forceinline__ double exec_window_sum(const ExecParams& p, uint32_t w, uint32_t r) {
+constexpr uint32_t kExecStage = 1280; // doubles of LDS the decisions may use for a window's per-slot values (10 KB)
+
+// The window's sums of rows [0, rows) of part[] (only those in `mask`) in the plan's order (window_sums /
+// plan_sum_kernel: a chunk sequentially, then the chunks in order); out[r] valid in every lane.  The values are
+// fetched by all lanes at once (sc1) into LDS, the additions then run on LDS.
+__device__ __forceinline__ void exec_window_sums(const ExecParams& p, uint32_t w, uint32_t slot0, uint32_t n_slots, uint32_t rows,
+                                                 uint32_t mask, double* stage, double* out) {
 #pragma clang fp contract(off)
-    const double* row = p.part + (size_t)r * p.n_sel;
-    double tot = 0.0;
-    for (uint32_t c = p.win_chunk_off[w]; c < p.win_chunk_off[w + 1]; ++c) {
-        double acc = 0.0;
-        for (uint32_t j = p.chunk_off[c]; j < p.chunk_off[c + 1]; ++j) acc += row[j];
-        tot += acc;
+    const int lane = threadIdx.x;
+    const bool staged = rows * n_slots <= kExecStage;
+    __syncthreads();
+    if (staged) {
+        for (uint32_t e = lane; e < rows * n_slots; e += 64) {
+            const uint32_t r = e / n_slots, j = e % n_slots;
+            if ((mask >> r) & 1u) stage[e] = ld_m<true>(&p.part[(size_t)r * p.n_sel + slot0 + j]);
+        }
+        __syncthreads();
     }
-    return tot;
+    double mine = 0.0;
+    if ((uint32_t)lane < rows && ((mask >> lane) & 1u)) {
+        const uint32_t r = (uint32_t)lane;
+        double tot = 0.0;
+        for (uint32_t c = p.win_chunk_off[w]; c < p.win_chunk_off[w + 1]; ++c) {
+            double acc = 0.0;
+            for (uint32_t j = p.chunk_off[c]; j < p.chunk_off[c + 1]; ++j)
+                acc += staged ? stage[r * n_slots + (j - slot0)] : ld_m<true>(&p.part[(size_t)r * p.n_sel + j]);
+            tot += acc;
+        }
+        mine = tot;
+    }
+    for (uint32_t r = 0; r < rows; ++r) out[r] = read_lane_d(mine, (int)r);
 }
 
-__device__ __forceinline__ double lane_bcast_d(double v, int lane) { return read_lane_d(v, lane); }
+// a window's record moves between global memory and LDS as 8-byte words, all lanes at once
+constexpr int kWinWords = (int)((sizeof(ExecWin) + 7) / 8);
+static_assert(kWinWords <= 64, "ExecWin must fit one word per lane");
+__device__ __forceinline__ void exec_load_win(const ExecWin* src, ExecWin* lds_copy) {
+    __syncthreads();
+    if ((int)threadIdx.x < kWinWords)
+        ((unsigned long long*)lds_copy)[threadIdx.x] = ld_m<true>((const unsigned long long*)src + threadIdx.x);
+    __syncthreads();
+}
+__device__ __forceinline__ void exec_store_win(ExecWin* dst, const ExecWin* lds_copy) {
+    __syncthreads();
+    // (the counter is not part of the copy: exec_push sets it, the tasks decrement it)
+    constexpr int kSkip = (int)(offsetof(ExecWin, remaining) / 8);
+    static_assert(offsetof(ExecWin, remaining) % 8 == 0 && offsetof(ExecWin, remaining_pad) == offsetof(ExecWin, remaining) + 4, "layout");
+    if ((int)threadIdx.x < kWinWords && (int)threadIdx.x != kSkip)
+        st_m<true>((unsigned long long*)dst + threadIdx.x, ((const unsigned long long*)lds_copy)[threadIdx.x]);
+}
 
 // the decisions of window w after the last task of its phase; executed by one whole wave
-__device__ __forceinline__ void exec_decide(const ExecParams& p, uint32_t w) {
+__device__ __forceinline__ void exec_decide(const ExecParams& p, uint32_t w, ExecWin* L, double* stage) {
 #pragma clang fp contract(off)
-    ExecWin& W = p.win[w];
-    SyncWin& s = W.s;
     const int lane = threadIdx.x;
-    const int ph = W.phase;
+    exec_load_win(&p.win[w], L);
+    SyncWin& s = L->s;
+    const int ph = L->phase;
+    const uint32_t slot0 = L->slot0, n_slots = L->n_slots;
+    bool finished = false;
     if (ph == kPhInit) {
         if (lane == 0) {
-            split64_dev(s.d, p.lp.fs, &p.mo_kd[w], &p.mo_fd[w]);
-            W.phase = kPhMotion;
+            int32_t kd; double fd;
+            split64_dev(s.d, p.lp.fs, &kd, &fd);          // :311 at d ...
+            st_m<true>(&p.mo_kd[w], kd); st_m<true>(&p.mo_fd[w], fd);
+            split64_dev(s.x0, p.lp.fs, &kd, &fd);         // ... then loss + derivative at x0 = d - 0.3 v (:298-299)
+            st_m<true>(&p.lg_kd[w], kd); st_m<true>(&p.lg_fd[w], fd);
+            L->phase = kPhMotion;
         }
-    } else if (ph == kPhMotion) {
+    } else if (ph == kPhMotion) { // (the frame's loss and derivative at x0 came with its motion task)
+        double sums[2];
+        exec_window_sums(p, w, slot0, n_slots, 2u, 3u, stage, sums);
         if (lane == 0) {
-            split64_dev(s.x0, p.lp.fs, &p.lg_kd[w], &p.lg_fd[w]); // loss + derivative at x0 = d - 0.3 v (:298-299)
-            W.phase = kPhGrad;
-        }
-    } else if (ph == kPhGrad) {
-        const double sum = lane < 2 ? exec_window_sum(p, w, (uint32_t)lane) : 0.0;
-        const double l1 = lane_bcast_d(sum, 0), g1 = lane_bcast_d(sum, 1);
-        if (lane == 0) {
-            grad_decide(p.lp, s, l1, g1);
-            trial_delays(p.lp, s, p.tr_kd + w, p.tr_fd + w, p.n_win);
-            W.phase = kPhTrials;
+            grad_decide(p.lp, s, sums[0], sums[1]);
+            int32_t kd[kMaxBt]; double fd[kMaxBt];
+            trial_delays(p.lp, s, kd, fd, 1);
+            for (int i = 0; i < kMaxBt; ++i) { st_m<true>(&p.tr_kd[(size_t)i * p.n_win + w], kd[i]); st_m<true>(&p.tr_fd[(size_t)i * p.n_win + w], fd[i]); }
+            L->phase = kPhTrials;
         }
     } else if (ph == kPhTrials) {
+        uint32_t mask = 0; // only the rows that were evaluated
+        for (int i = 0; i < kMaxBt; ++i) mask |= trial_wanted(s, i) ? (1u << i) : 0u;
         double lt[kMaxBt];
-        {
-            const bool mine = lane < kMaxBt && trial_wanted(s, lane); // only the rows that were evaluated
-            const double sum = mine ? exec_window_sum(p, w, (uint32_t)lane) : 0.0;
-#pragma unroll
-            for (int i = 0; i < kMaxBt; ++i) lt[i] = lane_bcast_d(sum, i);
-        }
+        exec_window_sums(p, w, slot0, n_slots, (uint32_t)kMaxBt, mask, stage, lt);
         if (lane == 0) {
-            const bool stepped = step_decide(p.lp, s, lt, p.trace + ((size_t)w * p.trace_rows + W.trace_base) * 6, 6);
+            const bool stepped = step_decide(p.lp, s, lt, p.trace + ((size_t)w * p.trace_rows + L->trace_base) * 6, 6);
+            int32_t kd; double fd;
             if (!stepped) {
-                trial_delays(p.lp, s, p.tr_kd + w, p.tr_fd + w, p.n_win); // the rest of the trials
+                int32_t kdv[kMaxBt]; double fdv[kMaxBt];
+                trial_delays(p.lp, s, kdv, fdv, 1); // the rest of the trials
+                for (int i = 0; i < kMaxBt; ++i) { st_m<true>(&p.tr_kd[(size_t)i * p.n_win + w], kdv[i]); st_m<true>(&p.tr_fd[(size_t)i * p.n_win + w], fdv[i]); }
             } else if (s.active) {
-                split64_dev(s.d, p.lp.fs, &p.mo_kd[w], &p.mo_fd[w]); // :311 at the new delay
-                W.phase = kPhMotion;
+                split64_dev(s.d, p.lp.fs, &kd, &fd);
+                st_m<true>(&p.mo_kd[w], kd); st_m<true>(&p.mo_fd[w], fd);
+                split64_dev(s.x0, p.lp.fs, &kd, &fd);
+                st_m<true>(&p.lg_kd[w], kd); st_m<true>(&p.lg_fd[w], fd);
+                L->phase = kPhMotion;
             } else {
-                W.iters_call[W.call] = s.iters;
-                W.trace_base += s.iters;
-                if (W.call + 1 < p.repeats) { // the next Sync call of this sync point starts where this one ended (core_testcode.cpp:314)
-                    W.call += 1;
+                L->iters_call[L->call] = s.iters;
+                L->trace_base += s.iters;
+                if (L->call + 1 < p.repeats) { // the next Sync call of this sync point starts where this one ended (core_testcode.cpp:314)
+                    L->call += 1;
                     const double d = s.d;
                     s = SyncWin{};
                     s.d = d;
@@ -222,73 +298,98 @@ __device__ __forceinline__ void exec_decide(const ExecParams& p, uint32_t w) {
                     s.hit = -1;
                     s.nf = p.lp.nf_fixed ? p.lp.nf_fixed : kHalfBt;
                     s.x0 = s.d - p.lp.delay_b * s.v;
-                    p.win_stream[w] = p.stream_first + (uint32_t)W.call + w * p.stream_stride;
-                    split32_dev(s.d, p.lp.fs, &p.in_kd[w], &p.in_fd[w]);
-                    W.phase = kPhInit;
+                    st_m<true>(&p.win_stream[w], p.stream_first + (uint32_t)L->call + w * p.stream_stride);
+                    int32_t ikd; float ifd;
+                    split32_dev(s.d, p.lp.fs, &ikd, &ifd);
+                    st_m<true>(&p.in_kd[w], ikd); st_m<true>(&p.in_fd[w], ifd);
+                    L->phase = kPhInit;
                 } else {
-                    split64_dev(s.d, p.lp.fs, &p.lg_kd[w], &p.lg_fd[w]); // :333
-                    W.phase = kPhFinal;
+                    split64_dev(s.d, p.lp.fs, &kd, &fd); // :333
+                    st_m<true>(&p.lg_kd[w], kd); st_m<true>(&p.lg_fd[w], fd);
+                    L->phase = kPhFinal;
                 }
             }
         }
     } else if (ph == kPhFinal) {
-        const double sum = lane < 1 ? exec_window_sum(p, w, 0u) : 0.0;
+        double sum[1];
+        exec_window_sums(p, w, slot0, n_slots, 1u, 1u, stage, sum);
         if (lane == 0) {
-            W.cost = sum;
-            W.phase = kPhDone;
+            L->cost = sum[0];
+            L->phase = kPhDone;
         }
-        __threadfence();
-        if (lane == 0) __hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        finished = true;
+    }
+    exec_store_win(&p.win[w], L);
+    if (finished) {
+        wait_stores();
+        if (lane == 0) __hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    exec_push(p, W);
+    exec_push(p, w, slot0, n_slots);
 }
 
-// LDS of one executor wave: the search's tile and fp32 window, the fp64 window and L-BFGS history
+// LDS of one executor wave: the search's tile and fp32 window, the fp64 window and L-BFGS history; the decisions
+// reuse the fp64 window as staging for a window's per-slot values
 template <int RPT>
 struct ExecLds {
     LmedsSmallLds<RPT> small;
     MotionLds<1> mo;
+    ExecWin win;
 };
+static_assert(sizeof(d4) * 4 * kWinMax >= kExecStage * sizeof(double), "staging area");
 
 template <int RPT> // rows per lane of the one-wave kernels: frames of up to 64 * RPT tracks
 __global__ __launch_bounds__(64) void sync_exec_kernel(ExecParams p) {
     __shared__ ExecLds<RPT> lds;
     const int lane = threadIdx.x;
     for (;;) {
-        const uint32_t slot = exec_pop(p);
+        uint32_t slot;
+        {
+            EXEC_T0();
+            slot = exec_pop(p);
+            EXEC_ADD(6, 14);
+        }
         if (slot == 0xffffffffu) break;
         const uint32_t w = p.grp[slot];
-        ExecWin& W = p.win[w];
-        const int ph = W.phase;
+        const int ph = ld_m<true>(&p.win[w].phase);
+        EXEC_T0();
         if (ph == kPhInit) {
-            lmeds_small_body<RPT, 1>(p.init, slot, 0u, lds.small);
+            lmeds_small_body<RPT, 1, true>(p.init, slot, 0u, lds.small);
         } else if (ph == kPhMotion) {
-            opt_motion64_body<RPT, 1>(p.mo, slot, lds.mo);
-        } else if (ph == kPhGrad) {
-            double L, G;
-            loss64_wave<true>(p.lo, slot, p.lg_kd[w], p.lg_fd[w], lds.mo.win, L, G);
-            if (lane == 0) { p.part[slot] = L; p.part[(size_t)p.n_sel + slot] = G; }
-        } else if (ph == kPhTrials) {
-            for (int i = 0; i < kMaxBt; ++i) {
-                const double fd = p.tr_fd[(size_t)i * p.n_win + w];
-                if (fd != fd) continue; // not asked for
-                double L, G;
-                loss64_wave<false>(p.lo, slot, p.tr_kd[(size_t)i * p.n_win + w], fd, lds.mo.win, L, G);
-                if (lane == 0) p.part[(size_t)i * p.n_sel + slot] = L;
+            opt_motion64_body<RPT, 1, true>(p.mo, slot, lds.mo);
+            // the frame's loss and derivative at x0 with the motion estimate just found (the wave's own stores: it
+            // waits for them and reads them back past L1)
+            wait_stores();
+            const d3 Mv = d3{ld_m<true>(&p.lo.M[3 * slot]), ld_m<true>(&p.lo.M[3 * slot + 1]), ld_m<true>(&p.lo.M[3 * slot + 2])};
+            double Lv, Gv;
+            loss64_wave<true>(p.lo, slot, Mv, ld_m<true>(&p.lo.k[slot]), ld_m<true>(&p.lg_kd[w]), ld_m<true>(&p.lg_fd[w]), lds.mo.win, Lv, Gv);
+            if (lane == 0) { st_m<true>(&p.part[slot], Lv); st_m<true>(&p.part[(size_t)p.n_sel + slot], Gv); }
+        } else if (ph == kPhTrials || ph == kPhFinal) {
+            const d3 Mv = d3{ld_m<true>(&p.lo.M[3 * slot]), ld_m<true>(&p.lo.M[3 * slot + 1]), ld_m<true>(&p.lo.M[3 * slot + 2])};
+            const double kk = ld_m<true>(&p.lo.k[slot]);
+            if (ph == kPhFinal) {
+                double Lv, Gv;
+                loss64_wave<false>(p.lo, slot, Mv, kk, ld_m<true>(&p.lg_kd[w]), ld_m<true>(&p.lg_fd[w]), lds.mo.win, Lv, Gv);
+                if (lane == 0) st_m<true>(&p.part[slot], Lv);
+            } else {
+                for (int i = 0; i < kMaxBt; ++i) {
+                    const double fd = ld_m<true>(&p.tr_fd[(size_t)i * p.n_win + w]);
+                    if (fd != fd) continue; // not asked for
+                    double Lv, Gv;
+                    loss64_wave<false>(p.lo, slot, Mv, kk, ld_m<true>(&p.tr_kd[(size_t)i * p.n_win + w]), fd, lds.mo.win, Lv, Gv);
+                    if (lane == 0) st_m<true>(&p.part[(size_t)i * p.n_sel + slot], Lv);
+                }
             }
-        } else if (ph == kPhFinal) {
-            double L, G;
-            loss64_wave<false>(p.lo, slot, p.lg_kd[w], p.lg_fd[w], lds.mo.win, L, G);
-            if (lane == 0) p.part[slot] = L;
         }
-        __threadfence(); // this task's results before the count
+        EXEC_ADD(ph, 8 + ph);
+        wait_stores(); // this task's results before the count
         uint32_t left = 0;
-        if (lane == 0) left = __hip_atomic_fetch_sub(&W.remaining, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) left = __hip_atomic_fetch_sub(&p.win[w].remaining, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         left = uniform_u32(left);
-        if (left == 1u) {
-            __threadfence(); // everybody's results before the sums
-            exec_decide(p, w);
+        if (left == 1u) { // the last task of the window's phase: the add has returned, the others' results are there
+            EXEC_T0();
+            exec_decide(p, w, &lds.win, (double*)lds.mo.win);
+            EXEC_ADD(5, 13);
         }
     }
 }

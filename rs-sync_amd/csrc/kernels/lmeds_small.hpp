@@ -29,7 +29,7 @@ struct LmedsSmallLds {
 };
 
 // the work of one wave (64 threads, the whole workgroup) on slot sf, chunk `chunk`
-template <int RPT, int MODE>
+template <int RPT, int MODE, bool SC1 = false> // SC1: the delays, the stream and the winners are shared with other workgroups of this launch
 __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t sf, uint32_t chunk, LmedsSmallLds<RPT>& lds) {
     constexpr int kHyp = kHypBatch;
     float (&s_n)[3][64 * RPT] = lds.n;
@@ -50,16 +50,16 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
     const uint32_t c1 = (c0 + p.chunk < p.n_cand) ? c0 + p.chunk : p.n_cand;
     if (c0 >= c1) return;
     if ((uint32_t)lane < c1 - c0) {
-        s_kd[lane] = p.kd[(c0 + lane) * p.n_grp + g];
-        s_fd[lane] = p.fd[(c0 + lane) * p.n_grp + g];
+        s_kd[lane] = ld_m<SC1>(&p.kd[(c0 + lane) * p.n_grp + g]);
+        s_fd[lane] = ld_m<SC1>(&p.fd[(c0 + lane) * p.n_grp + g]);
     }
     Spline sp;
     sp.g = p.coef;
     sp.n = p.n_knots;
     {
-        int kd_lo = p.kd[c0 * p.n_grp + g], kd_hi = kd_lo;
+        int kd_lo = ld_m<SC1>(&p.kd[c0 * p.n_grp + g]), kd_hi = kd_lo;
         for (uint32_t c = c0 + 1; c < c1; ++c) {
-            const int v = p.kd[c * p.n_grp + g];
+            const int v = ld_m<SC1>(&p.kd[c * p.n_grp + g]);
             kd_lo = v < kd_lo ? v : kd_lo;
             kd_hi = v > kd_hi ? v : kd_hi;
         }
@@ -72,7 +72,7 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
     for (uint32_t c = c0; c < c1; ++c) {
         const int base = fr.base_knot + s_kd[c - c0];
         const float fd = s_fd[c - c0];
-        const uint32_t stream = p.win_stream ? p.win_stream[g] + c : p.stream_base + c + g * p.stream_stride;
+        const uint32_t stream = p.win_stream ? ld_m<SC1>(&p.win_stream[g]) + c : p.stream_base + c + g * p.stream_stride;
         uint32_t bad = 0;
         // ---- rows of P, as unit rows in registers (and in LDS for the row pairs); norms in registers ----
         float nx[RPT], ny[RPT], nz[RPT], nrm[RPT];
@@ -171,7 +171,7 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
         prev_best = bT;
         if (!(finite_f(Mv.x) && finite_f(Mv.y) && finite_f(Mv.z))) bad |= RSHIP_BAD_M;
         if (MODE == 1) { // GuessMotion: only the winner's index leaves this kernel
-            if (lane == 0) p.best_h[sf] = bH;
+            if (lane == 0) st_m<SC1>(&p.best_h[sf], (int32_t)bH);
             __syncthreads(); // the rows in LDS are read (hypotheses) before the next candidate rewrites them
             continue;
         }

@@ -377,7 +377,7 @@ struct MotionLds {
     double red[NW];
 };
 
-template <int RPT, int NW>
+template <int RPT, int NW, bool SC1 = false> // SC1: M, k, the pending winners and the delays are written by other workgroups of this launch
 __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint32_t sf, MotionLds<NW>& lds) {
     constexpr int kThreads = 64 * NW;
     d4* s_win = lds.win;
@@ -393,8 +393,8 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
     const FrameRec fr = p.frames[fi];
     const uint32_t N = fr.n;
     const uint32_t grp = p.grp ? p.grp[sf] : 0u;
-    const int kd = p.kd[grp];
-    const double fd = p.fd[grp];
+    const int kd = ld_m<SC1>(&p.kd[grp]);
+    const double fd = ld_m<SC1>(&p.fd[grp]);
     if (fd != fd) { // this window is not being optimised in this call (workgroup-uniform)
         if (tid == 0 && p.evals_out) p.evals_out[sf] = 0;
         return;
@@ -421,13 +421,13 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
 
     double x[3];
     double kk;
-    const int pend = p.init_h ? p.init_h[sf] : kInitNone;
+    const int pend = p.init_h ? ld_m<SC1>(&p.init_h[sf]) : kInitNone;
     if (p.simple_k || pend != kInitNone) {
         // GuessMotion's winner recomputed in fp64, then GuessK (core_private.cpp:125-133)
         d3 Mv = d3{0, 0, 0};
         if (!p.simple_k && pend >= 0) {
             uint32_t i0, i1;
-            rs::sample_pair(p.seed, fr.id, p.win_stream ? p.win_stream[grp] : p.stream_base + grp * p.stream_stride, (uint32_t)pend, N, i0, i1);
+            rs::sample_pair(p.seed, fr.id, p.win_stream ? ld_m<SC1>(&p.win_stream[grp]) : p.stream_base + grp * p.stream_stride, (uint32_t)pend, N, i0, i1);
             d3 P0, P1, dP;
             residual_row64<false>(sp, p.rays, (size_t)fr.off + i0, base, fd, P0, dP);
             residual_row64<false>(sp, p.rays, (size_t)fr.off + i1, base, fd, P1, dP);
@@ -450,13 +450,13 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
         kk = clamp_k(100.0 / sqrt(tot)); // :132; tot = 0 gives +inf -> 1000
         x[0] = Mv.x; x[1] = Mv.y; x[2] = Mv.z;
         if (tid == 0) {
-            if (!p.simple_k) { p.M[3 * sf] = x[0]; p.M[3 * sf + 1] = x[1]; p.M[3 * sf + 2] = x[2]; }
-            p.k[sf] = kk;
-            if (p.init_h) p.init_h[sf] = kInitNone;
+            if (!p.simple_k) { st_m<SC1>(&p.M[3 * sf], x[0]); st_m<SC1>(&p.M[3 * sf + 1], x[1]); st_m<SC1>(&p.M[3 * sf + 2], x[2]); }
+            st_m<SC1>(&p.k[sf], kk);
+            if (p.init_h) st_m<SC1>(&p.init_h[sf], (int32_t)kInitNone);
         }
     } else {
-        x[0] = p.M[3 * sf]; x[1] = p.M[3 * sf + 1]; x[2] = p.M[3 * sf + 2];
-        kk = p.k[sf];
+        x[0] = ld_m<SC1>(&p.M[3 * sf]); x[1] = ld_m<SC1>(&p.M[3 * sf + 1]); x[2] = ld_m<SC1>(&p.M[3 * sf + 2]);
+        kk = ld_m<SC1>(&p.k[sf]);
     }
     if (p.max_iters <= 0 || p.simple_k) return;
     ev.k2 = kk * kk;
@@ -465,7 +465,7 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
     int best_not_last = 0;
     const int it = rs::lbfgs3(ev, hist, x, p.max_iters /* core_private.cpp:265 */, p.reeval, &best_not_last);
     if (tid == 0) {
-        p.M[3 * sf] = x[0]; p.M[3 * sf + 1] = x[1]; p.M[3 * sf + 2] = x[2];
+        st_m<SC1>(&p.M[3 * sf], x[0]); st_m<SC1>(&p.M[3 * sf + 1], x[1]); st_m<SC1>(&p.M[3 * sf + 2], x[2]);
         if (p.stats) {
             atomicAdd(&p.stats[0], (unsigned long long)it);
             atomicAdd(&p.stats[1], (unsigned long long)ev.evals);

@@ -1445,15 +1445,21 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
         if (c->h_grp_off[w + 1] == c->h_grp_off[w]) return set_err(c, "sync_exec: a window without frames");
     int nf_fixed = 0;
     if (const char* e = std::getenv("RSSYNC_LOOP_FIRST_TRIALS")) { const int v = atoi(e); if (v >= 1 && v <= kMaxBt) nf_fixed = v; }
-    uint32_t q_cap = 64;
-    while (q_cap < ns + 1) q_cap *= 2;
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+    uint32_t waves = (uint32_t)n_cu * 8u; // what the chip holds at once (LDS: ~19 KB per wave); more would only idle
+    if (waves > ns) waves = ns;
+    // ring of {lap, slot} cells, several times the entries that can be outstanding (<= ns) plus the numbers idle waves
+    // have claimed ahead (<= waves)
+    uint32_t q_cap = 256, q_shift = 8;
+    while (q_cap < 4 * (ns + waves)) { q_cap *= 2; ++q_shift; }
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t o_win = take(W * sizeof(ExecWin));
     const size_t o_inkd = take(W * 4), o_infd = take(W * 4), o_stream = take(W * 4);
     const size_t o_mokd = take(W * 4), o_mofd = take(W * 8), o_lgkd = take(W * 4), o_lgfd = take(W * 8);
     const size_t o_trkd = take((size_t)kMaxBt * W * 4), o_trfd = take((size_t)kMaxBt * W * 8);
-    const size_t o_q = take((size_t)q_cap * 4), o_ctl = take(64);
+    const size_t o_q = take((size_t)q_cap * 8), o_ctl = take(64);
     const size_t o_trace = take((size_t)W * trace_rows * 48);
     if (ensure(c, c->loop_state, off) || ensure(c, c->part, (size_t)2 * kMaxBt * ns * 8) || ensure(c, c->flags, 16)) return 1;
     char* base = (char*)c->loop_state.p;
@@ -1462,7 +1468,8 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     std::vector<ExecWin> hw(W);
     std::vector<int32_t> in_kd(W);
     std::vector<float> in_fd(W);
-    std::vector<uint32_t> streams(W), queue(q_cap, 0u);
+    std::vector<uint32_t> streams(W);
+    std::vector<unsigned long long> queue(q_cap, 0ull);
     const double kClamp = (double)(1 << 29);
     for (uint32_t w = 0; w < W; ++w) {
         ExecWin& e = hw[w];
@@ -1489,13 +1496,13 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
             in_fd[w] = f;
         }
     }
-    for (uint32_t j = 0; j < ns; ++j) queue[j] = j + 1u;
+    for (uint32_t j = 0; j < ns; ++j) queue[j] = (1ull << 32) | j; // lap 1
     const uint32_t ctl[4] = {0u /* head */, ns /* tail */, 0u /* done */, 0u /* abort */};
     RS_HIP(hipMemcpyAsync(base + o_win, hw.data(), W * sizeof(ExecWin), hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipMemcpyAsync(base + o_inkd, in_kd.data(), W * 4, hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipMemcpyAsync(base + o_infd, in_fd.data(), W * 4, hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipMemcpyAsync(base + o_stream, streams.data(), W * 4, hipMemcpyHostToDevice, c->stream));
-    RS_HIP(hipMemcpyAsync(base + o_q, queue.data(), (size_t)q_cap * 4, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemcpyAsync(base + o_q, queue.data(), (size_t)q_cap * 8, hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipMemcpyAsync(base + o_ctl, ctl, sizeof(ctl), hipMemcpyHostToDevice, c->stream));
 
     ExecParams ep{};
@@ -1527,8 +1534,9 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     ep.stream_first = stream_first;
     ep.stream_stride = stream_stride;
     ep.repeats = repeats;
-    ep.q = (uint32_t*)(base + o_q);
+    ep.q = (unsigned long long*)(base + o_q);
     ep.q_mask = q_cap - 1;
+    ep.q_shift = q_shift;
     ep.q_head = (uint32_t*)(base + o_ctl);
     ep.q_tail = ep.q_head + 1;
     ep.done = ep.q_head + 2;
@@ -1572,10 +1580,6 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     ep.lo.M = (const double*)c->M.p;
     ep.lo.k = (const double*)c->k.p;
 
-    int n_cu = 256;
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
-    uint32_t waves = (uint32_t)n_cu * 8u; // what the chip holds at once (LDS: ~19 KB per wave); more would only idle
-    if (waves > ns) waves = ns;
     const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
     {
         ProfScope ps(c, RSHIP_K_MOTION);
@@ -1595,7 +1599,29 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     RS_HIP(hipMemcpyAsync(c->pinned, base + o_win, W * sizeof(ExecWin), hipMemcpyDeviceToHost, c->stream));
     RS_HIP(hipMemcpyAsync(h_ctl, base + o_ctl, 16, hipMemcpyDeviceToHost, c->stream));
     if (sync_stream(c)) return 1;
-    if (h_ctl[3]) return set_err(c, "sync_exec: watchdog (a wave polled an empty task queue for seconds)");
+#if RSSYNC_EXEC_STATS
+    {
+        unsigned long long st[16];
+        RS_HIP(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_exec_stats), sizeof(st)));
+        const unsigned long long zero[16] = {};
+        RS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_exec_stats), zero, sizeof(zero)));
+        const char* nm[7] = {"init", "motion", "grad", "trials", "final", "decide", "pop"};
+        const int cnt[7] = {8, 9, 10, 11, 12, 13, 14};
+        for (int i = 0; i < 7; ++i)
+            fprintf(stderr, "exec %-7s %9llu x  %10.3f ms wave-time  (%.2f us each)\n", nm[i], st[cnt[i]], st[i] * 1e-5,
+                    st[cnt[i]] ? st[i] * 1e-2 / st[cnt[i]] : 0.0);
+    }
+#endif
+    if (h_ctl[3]) {
+        const ExecWin* e = (const ExecWin*)c->pinned;
+        std::string st = "sync_exec: watchdog (a wave polled an empty task queue for seconds); queue head " + std::to_string(h_ctl[0]) +
+                         " tail " + std::to_string(h_ctl[1]) + ", windows done " + std::to_string(h_ctl[2]) + " of " + std::to_string(W);
+        for (uint32_t w = 0; w < W && w < 4; ++w)
+            st += "; window " + std::to_string(w) + ": phase " + std::to_string(e[w].phase) + " call " + std::to_string(e[w].call) +
+                  " tasks left " + std::to_string(e[w].remaining) + " of " + std::to_string(e[w].n_slots) + " iterations " +
+                  std::to_string(e[w].s.iters) + " active " + std::to_string(e[w].s.active) + " trial phase " + std::to_string(e[w].s.phase);
+        return set_err(c, st);
+    }
     if (h_ctl[2] != W) return set_err(c, "sync_exec: " + std::to_string(h_ctl[2]) + " of " + std::to_string(W) + " windows finished");
     memcpy(hw.data(), c->pinned, W * sizeof(ExecWin));
     uint32_t rows_max = 0;
