@@ -258,7 +258,10 @@ class SyncProblemHip final : public ISyncProblem {
     std::vector<int32_t> last_init_winners, init_override;
     void exchange_init_winners();
     uint32_t sync_calls = 0;
-    bool use_executor = true; // small frames: Sync's calls of all windows in one device-scheduled launch (RSSYNC_NO_EXECUTOR=1: the chain of launches)
+    // RSSYNC_EXECUTOR=1: frames of up to 256 tracks run Sync's calls of all windows as ONE device-scheduled launch
+    // (kernels/executor.hpp) instead of the chain of launches.  Same bits; measured at parity with the chain on the
+    // reference's workload (33 against 30 ms, profiles/r3_syncpoints.json), so the chain stays the default.
+    bool use_executor = false;
     bool executor_ok(bool simplified);
     void sync_exec(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl, const std::vector<double>& initial,
                    double search_center, double search_radius, int repeats, uint32_t stream_first, uint32_t stream_stride,
@@ -327,7 +330,7 @@ SyncProblemHip::SyncProblemHip() {
     if (const char* s = std::getenv("RSSYNC_MAX_OUTER_ITERS")) max_outer = std::atoi(s);
     if (const char* s = std::getenv("RSSYNC_QUIET")) verbose = !(s[0] && s[0] != '0');
     if (const char* s = std::getenv("RSSYNC_HOST_LOOP")) host_loop = s[0] && s[0] != '0';
-    if (const char* s = std::getenv("RSSYNC_NO_EXECUTOR")) use_executor = !(s[0] && s[0] != '0');
+    if (const char* s = std::getenv("RSSYNC_EXECUTOR")) use_executor = s[0] && s[0] != '0';
     // RSSYNC_GPUS: how many GPUs this object spreads its frames over ("4" = devices 0..3) or which
     // ("0,2,5"); default: the calling thread's current device only
     std::vector<int> ids;

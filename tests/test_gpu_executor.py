@@ -1,7 +1,7 @@
 """The window executor (kernels/executor.hpp: Sync for frames of up to 256 tracks as ONE device-scheduled launch --
 tasks (window, phase, frame) pulled from a queue by persistent waves, windows advancing independently, a sync
-point's four calls chained per window) against the chain of launches it replaces (RSSYNC_NO_EXECUTOR=1, read when a
-problem is created): the same task bodies, sums and decisions, so the SAME BITS -- delays, costs, every trace row."""
+point's four calls chained per window; opt-in with RSSYNC_EXECUTOR=1, read when a problem is created) against the
+chain of launches: the same task bodies, sums and decisions, so the SAME BITS -- delays, costs, every trace row."""
 import os
 
 import numpy as np
@@ -12,12 +12,12 @@ pytestmark = pytest.mark.gpu
 
 def _two(**kw):
     import rssync_amd
-    a = rssync_amd.SyncProblem(**kw)
-    os.environ["RSSYNC_NO_EXECUTOR"] = "1"
+    os.environ["RSSYNC_EXECUTOR"] = "1"
     try:
-        b = rssync_amd.SyncProblem(**kw)
+        a = rssync_amd.SyncProblem(**kw)
     finally:
-        del os.environ["RSSYNC_NO_EXECUTOR"]
+        del os.environ["RSSYNC_EXECUTOR"]
+    b = rssync_amd.SyncProblem(**kw)
     return a, b
 
 
@@ -93,12 +93,6 @@ def test_sync_points_four_chained_calls(built, monkeypatch, first_trials):
         assert t1.shape == t2.shape and len(t1) >= 4
         np.testing.assert_array_equal(_bits(t1), _bits(t2))
     # and the sequential calls through the ISyncProblem methods give the same delays
-    seq = []
-    for p0 in pos[:3]:
-        d = ch.PreSync(0.0, p0, p0 + window, 0.002, 0.1)[1]
-        for _ in range(4):
-            d = ch.Sync(d, p0, p0 + window, 0.0, 0.1)[1]
-        seq.append(d)
     ex2, _ = _two(seed=33, max_outer_iters=400)
     _fill((ex2,), gyro, frames)
     _, dd = ex2.sync_points(pos[:3], window, 0.0, 0.002, 0.1)

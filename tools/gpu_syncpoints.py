@@ -41,13 +41,19 @@ loop(seq)
 bat.profile(True); bat.profile_reset()
 t = time.perf_counter(); bat.sync_points(pos, WINDOW, 0.0, 0.001, 0.1); t_prof = time.perf_counter() - t
 prof = bat.profile_get()
+os.environ["RSSYNC_EXECUTOR"] = "1"    # the window executor (opt-in): one device-scheduled launch for all calls of all windows
+execp = problem()
+del os.environ["RSSYNC_EXECUTOR"]
+execp.sync_points(pos, WINDOW, 0.0, 0.001, 0.1)
+t = time.perf_counter(); _, de = execp.sync_points(pos, WINDOW, 0.0, 0.001, 0.1); t_exec = time.perf_counter() - t
 hostloop = problem(); hostloop.set_host_loop(True)
 hostloop.sync_points(pos, WINDOW, 0.0, 0.001, 0.1)
 t = time.perf_counter(); _, dh = hostloop.sync_points(pos, WINDOW, 0.0, 0.001, 0.1); t_host = time.perf_counter() - t
 iters = [len(bat.window_trace(w)) for w in range(len(pos))]
 print(json.dumps({"frames": F, "tracks": N, "window": WINDOW, "positions": len(pos),
                   "sequential_s": round(t_seq, 4), "batched_s": round(t_bat, 4), "speedup": round(t_seq / t_bat, 2),
-                  "batched_host_loop_s": round(t_host, 4), "batched_profiled_s": round(t_prof, 4),
+                  "batched_host_loop_s": round(t_host, 4), "batched_executor_s": round(t_exec, 4),
+                  "executor_identical": bool(np.array_equal(de, db)), "batched_profiled_s": round(t_prof, 4),
                   "identical": bool(np.array_equal(ds, db)), "max_abs_diff": float(np.abs(ds - db).max()),
                   "host_loop_identical": bool(np.array_equal(dh, db)),
                   "delay_err_vs_truth_ms": {"median": float(np.median(np.abs(db - synth.D_TRUE)) * 1e3),
