@@ -109,6 +109,7 @@ struct rship_ctx {
     double fs = 0;
     int lbfgs_reeval = 0; // RSHIP_OPT_LBFGS_REEVAL
     uint32_t tracks_hint = 0; // RSHIP_OPT_TRACKS_HINT
+    bool no_motion_order = false; // RSSYNC_NO_MOTION_ORDER=1 (A/B): the motion kernel's workgroups in slot order, not longest-first
     bool exact_select = false;   // RSSYNC_K2_EXACT_SELECT=1 (read once, at creation): PreSync's tile kernel with round 2's exact
                                  // selection of every quartile instead of the lazy one (A/B tests: identical results)
     bool no_small_lmeds = false; // RSSYNC_NO_SMALL_LMEDS=1 (read once, at creation): the tile kernel for every frame size (A/B tests)
@@ -326,7 +327,7 @@ int launch_motion64(rship_ctx* c, const Motion64Params& p, hipStream_t st = null
     else return set_err(c, "motion: unsupported track count");
     RS_HIP(hipGetLastError());
     // the order of the NEXT launch over these slots, from this one's evaluation counts
-    if (p.evals_out && c->mo_order.p && p.max_iters > 0 && !p.simple_k && count >= kOrderMinSlots) {
+    if (p.evals_out && c->mo_order.p && p.max_iters > 0 && !p.simple_k && count >= kOrderMinSlots && !c->no_motion_order) {
         hipLaunchKernelGGL(motion_order_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)p.evals_out, (uint32_t*)c->mo_order.p, p.slot0, count);
         RS_HIP(hipGetLastError());
     }
@@ -463,6 +464,7 @@ int rship_create(rship_ctx** out, int device) {
     rship_ctx* c = new rship_ctx();
     if (const char* s = std::getenv("RSSYNC_NO_SMALL_LMEDS")) c->no_small_lmeds = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_K2_EXACT_SELECT")) c->exact_select = s[0] && s[0] != '0';
+    if (const char* s = std::getenv("RSSYNC_NO_MOTION_ORDER")) c->no_motion_order = s[0] && s[0] != '0';
     if (device >= 0) {
         e = hipSetDevice(device);
         if (e != hipSuccess) { delete c; return 3; }
