@@ -19,6 +19,7 @@ __device__ unsigned long long g_k2_counters[16];
 // 4 counting passes inside the exact selection   5 selections ended by the single-element min pass
 // 6 candidates redone without the provisional bound   7 sweeps that started without any bound (wave max)
 // 8 contenders swept again and closed exactly (lazy selection: overlapping brackets)
+// 9 sweeps that needed their last group of rows (early rejection did not apply)
 
 // ---------------------------------------------------------------------------
 // K2: LMedS tile kernel
@@ -78,12 +79,12 @@ __device__ __forceinline__ f3 hypothesis(const Tile& t, uint64_t seed, int64_t f
 // counter for 3 of every 8 registers, to take load off the scalar unit -- two scalar instructions per
 // register run at ~6 cycles per register per SIMD, tools/ubench/valu_rate.hip -- changed the kernel by
 // -1.5 % .. +0.5 % depending on the build: not kept.)
-template <int NR>
+template <int NR, int R0 = 0, int R1 = NR> // registers [R0, R1)
 __device__ __forceinline__ uint32_t wave_count_lt(const uint32_t (&r)[NR], uint32_t pivot) {
     const float pv = __uint_as_float(pivot);
     uint32_t cnt = 0;
 #pragma unroll
-    for (int m = 0; m < NR; ++m)
+    for (int m = R0; m < R1; ++m)
         cnt += (uint32_t)__builtin_popcountll(__builtin_amdgcn_fcmpf(pv, fabsf(__uint_as_float(r[m])), 2 /* FCMP_OGT */));
     return cnt;
 }
@@ -314,10 +315,10 @@ __device__ __forceinline__ uint32_t wave_pop(uint32_t* counter) {
 
 // residuals r = nP v of one hypothesis for the whole tile, in the wave's registers (core_private.cpp:48); |r| orders
 // like the r^2 of :49-52.  Registers 4m..4m+3 <-> rows 4 (64 m + lane) .. +3.
-template <int NR>
+template <int NR, int G0 = 0, int G1 = NR / 4> // groups [G0, G1) of four rows per lane
 __device__ __forceinline__ void sweep_tile(const f4* p4x, const f4* p4y, const f4* p4z, int lane, f3 hv, uint32_t (&r2)[NR]) {
 #pragma unroll
-    for (int m = 0; m < NR / 4; ++m) {
+    for (int m = G0; m < G1; ++m) {
         if ((m & 1) == 0) __builtin_amdgcn_sched_barrier(0); // bound the LDS reads in flight
         const int idx = m * 64 + lane;
         // ds_read_b128 per array: full LDS rate (ds_read2_b64 pairs run at half of it)
@@ -347,6 +348,9 @@ __device__ __forceinline__ void sweep_tile(const f4* p4x, const f4* p4y, const f
 #define RSSYNC_K2_LAZY_ELEMS 16 // round 3 A/B (profiles/r3_k2_ab2.txt), ms per launch: 1 (= closed at once) 45.7, 4: 41.2, 16: 40.2, 48: 41.1
 #endif
 constexpr uint32_t kLazyElems = RSSYNC_K2_LAZY_ELEMS;
+#ifndef RSSYNC_K2_EARLY_REJECT
+#define RSSYNC_K2_EARLY_REJECT 1
+#endif
 constexpr int kContCap = 24; // contender records per candidate; beyond that a hypothesis closes its bracket at once
 
 // WIN = knots of the LDS spline window (kWinMax in the product).  Round 2 measured a 28-knot window with a
@@ -521,11 +525,29 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                     const uint32_t h = batch + j;
                     const f4 hv = s_hyp[j];
                     uint32_t r2[NR];
-                    sweep_tile(p4x, p4y, p4z, lane, f3{hv.x, hv.y, hv.z}, r2);
                     // quartile_h < T  <=>  more than kq |residuals| lie below T.  A hypothesis whose quartile EQUALS the
                     // best one passes as well (T is exclusive and above it): ties are settled among the contenders.
+                    // (T is read before the sweep: a bound that has tightened meanwhile only makes this test milder.)
                     const uint32_t T = (uint32_t)(__hip_atomic_load(&s_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32);
-                    const uint32_t tot = wave_count_lt(r2, T);
+                    uint32_t tot;
+#if RSSYNC_K2_EARLY_REJECT
+                    if (NR >= 16) {
+                        // Four of five hypotheses only have to be turned away, and most of those have a few per cent of
+                        // their residuals below T: once all rows but the last 256 are counted and even 256 more could
+                        // not lift the count above kq, the last group of rows is neither read nor multiplied.
+                        constexpr int GL = NR / 4 - 1;
+                        sweep_tile<NR, 0, GL>(p4x, p4y, p4z, lane, f3{hv.x, hv.y, hv.z}, r2);
+                        tot = wave_count_lt<NR, 0, 4 * GL>(r2, T);
+                        if (tot + 256u <= kq) continue;
+                        K2_COUNT(9);
+                        sweep_tile<NR, GL, GL + 1>(p4x, p4y, p4z, lane, f3{hv.x, hv.y, hv.z}, r2);
+                        tot += wave_count_lt<NR, 4 * GL, NR>(r2, T);
+                    } else
+#endif
+                    {
+                        sweep_tile(p4x, p4y, p4z, lane, f3{hv.x, hv.y, hv.z}, r2);
+                        tot = wave_count_lt(r2, T);
+                    }
                     if (tot > kq) {
                         K2_COUNT(3);
                         Bracket b{0u, 0u, T, tot};

@@ -31,7 +31,7 @@ lib.rship_debug_k2_counters(p.device_context(), buf, 1)
 raw = [int(x) for x in buf]
 pairs = raw[0] or 1
 names = ["frame_candidates", "queue_pops", "hypotheses_swept", "exact_selections", "selection_counting_passes",
-         "selection_min_endings", "candidates_redone", "sweeps_without_bound", "contenders_closed_exactly"]
+         "selection_min_endings", "candidates_redone", "sweeps_without_bound", "contenders_closed_exactly", "sweeps_completed"]
 out = {"frames": F, "tracks": N, "presync": [c, d], "raw": dict(zip(names, raw)),
        "per_frame_candidate": {n: raw[i] / pairs for i, n in enumerate(names)}}
 print(json.dumps(out, indent=1))
