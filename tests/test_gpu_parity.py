@@ -780,3 +780,46 @@ def test_window_groups_on_concurrent_streams_equal_the_host_loop():
         np.testing.assert_array_equal(c, ref[0])
         for w in range(len(pos)):
             np.testing.assert_array_equal(tr[w], ref[2][w])
+
+
+def test_two_ranks_with_different_frame_sizes_pick_the_same_kernels(tmp_path):
+    """the kernel a frame runs in (one-wave or tile LMedS; the motion kernel's shape) must follow
+    the largest frame of the WHOLE problem, not of the rank.  Two ranks on this box's GPU (gloo for the sums), one
+    with 96-track frames, one with 600-track frames: every frame's PreSync cost, winning hypothesis, GuessMotion
+    estimate and GuessK are the single-process run's bit for bit; the window sums agree to their association."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    import rssync_amd
+    from rssync_amd import synth
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = [str(tmp_path / f"r{r}.json") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "gpu_dist_worker.py"), str(r), "2", str(port), outs[r]])
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    res = [json.load(open(o)) for o in outs]
+    F = 16
+    n_of = lambda fr: 96 if fr < 8 else 600
+    gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=6)
+    one = rssync_amd.SyncProblem(seed=321, max_outer_iters=6)
+    one.SetGyroQuaternions(gyro.quats, gyro.fs, gyro.t0)
+    for fr in range(F):
+        one.SetTrackResult(*next(iter(synth.make_frames(gyro, fr, fr + 1, n_of(fr), seed=6))))
+    d, c, fc, bh = one.presync_curve(0.0, 0, F, 0.004, 0.06, per_frame=F)
+    M, k = one.init_motion(0.03, 0, F - 1)
+    cs, ds = one.Sync(0.036, 0, F - 1, 0.0, 0.2)
+    for r in res:
+        b, e = r["frames"]
+        np.testing.assert_array_equal(np.asarray(r["best_h"]), bh[:, b:e])
+        np.testing.assert_array_equal(np.asarray(r["frame_costs"]).view(np.uint64), np.ascontiguousarray(fc[:, b:e]).view(np.uint64))
+        np.testing.assert_array_equal(np.asarray(r["M"]).view(np.uint64), np.ascontiguousarray(M[b:e]).view(np.uint64))
+        np.testing.assert_array_equal(np.asarray(r["k"]).view(np.uint64), np.ascontiguousarray(k[b:e]).view(np.uint64))
+        np.testing.assert_allclose(r["curve"], c, rtol=1e-13)
+        assert r["sync"][1] == pytest.approx(ds, abs=1e-9) and r["iters"] == len(one.sync_trace())
+    assert res[0]["sync"] == res[1]["sync"] and res[0]["curve"] == res[1]["curve"]
