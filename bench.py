@@ -331,6 +331,9 @@ def run(args):
                           "exchange": exchange, "rccl_ranks": world if exchange == "native-rccl" else 0,
                           "exchanges_per_step": x_calls / max(args.steps, 1),
                           "doubles_per_step": x_doubles / max(args.steps, 1),
+                          "sync_loop": ("device, window sums all-reduced on the stream (ncclAllReduce between the kernels)"
+                                        if exchange == "native-rccl" else "device" if world == 1 and n_dev == 1 else
+                                        "host, one exchange per launch"),
                           "note": "exchange = how the sums over frames cross process boundaries (none within one "
                                   "process: --mode inproc adds the devices' chunk sums on the host)"},
             "roofline": roof, "roofline_flop": roof_flop, "roofline_k1": roof_k1, "cpu_baseline": cpu, "kernels": kernels,

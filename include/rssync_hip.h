@@ -248,6 +248,9 @@ int rship_rccl_unique_id(rship_ctx* c, void* id128);
 int rship_rccl_init(rship_ctx* c, const void* id128, int rank, int world);
 int rship_rccl_allreduce(rship_ctx* c, double* buf, uint64_t n);
 int rship_rccl_shutdown(rship_ctx* c); /* ncclCommDestroy; collective */
+/* with a communicator, rship_sync_run all-reduces the window sums ON THE STREAM between its kernels (two
+ * ncclAllReduce per enqueued iteration, no host round trip); this many the last run enqueued */
+uint64_t rship_loop_exchanges(const rship_ctx* c);
 
 /* debug: the packed float4 streams of one frame of the table */
 int rship_debug_rays(rship_ctx* c, uint32_t frame_index, float* a4, float* b4, uint32_t cap_rays);

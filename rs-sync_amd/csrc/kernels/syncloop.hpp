@@ -45,6 +45,11 @@ struct SyncLoopParams {
     double c_armijo, delay_b, search_center, search_radius;
     int it, max_outer;
     int nf_fixed;          // 0: adaptive (below); k: always the first k trials first (tests: makes windows wait)
+    // Frames sharded over ranks (one process per GPU, the library's RCCL communicator): the window sums of a launch are
+    // written to ext_sums[row][window] by sync_sums_kernel, all-reduced over the ranks ON THE STREAM (ncclAllReduce
+    // between the kernels, no host round trip), and the decision kernels read them there instead of adding the
+    // per-slot values themselves.  Every rank sees the same sums and takes the same decisions.  Null: one rank.
+    double* ext_sums;
     int* n_active;         // [max_outer]: windows still active after iteration i
     double* trace;         // [max_outer][W][6]: row k of window w is its k-th outer iteration
 };
@@ -181,13 +186,32 @@ __device__ __forceinline__ void trial_delays(const SyncLoopParams& p, const Sync
     }
 }
 
+// rank mode: this rank's part of the window sums of the launch just finished -> ext_sums[row][window]
+__global__ __launch_bounds__(kBlock) void sync_sums_kernel(SyncLoopParams p) {
+#pragma clang fp contract(off)
+    __shared__ double s_tot[2 * kMaxBt];
+    __shared__ double s_stage[kStageDoubles];
+    const uint32_t w = blockIdx.x + p.win0;
+    window_sums(p, w, s_tot, s_stage);
+    for (uint32_t r = threadIdx.x; r < p.rows; r += blockDim.x) p.ext_sums[(size_t)r * p.n_win + w] = s_tot[r];
+}
+// the window's sums for the decision kernels: added here, or (rank mode) read where the all-reduce left them
+__device__ __forceinline__ void decision_sums(const SyncLoopParams& p, uint32_t w, double* s_tot, double* s_stage) {
+    if (p.ext_sums) {
+        for (uint32_t r = threadIdx.x; r < p.rows; r += blockDim.x) s_tot[r] = p.ext_sums[(size_t)r * p.n_win + w];
+        __syncthreads();
+    } else {
+        window_sums(p, w, s_tot, s_stage);
+    }
+}
+
 // stage G: after loss + gradient (rows: loss, gradient) -- the delays of the trial launch
 __global__ __launch_bounds__(kBlock) void sync_grad_kernel(SyncLoopParams p) {
 #pragma clang fp contract(off)
     __shared__ double s_tot[2 * kMaxBt];
     __shared__ double s_stage[kStageDoubles];
     const uint32_t w = blockIdx.x + p.win0;
-    window_sums(p, w, s_tot, s_stage);
+    decision_sums(p, w, s_tot, s_stage);
     if (threadIdx.x != 0) return;
     SyncWin& s = p.win[w];
     grad_decide(p, s, s_tot[0], s_tot[1]);
@@ -257,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void sync_step_kernel(SyncLoopParams p) {
     __shared__ double s_tot[2 * kMaxBt];
     __shared__ double s_stage[kStageDoubles];
     const uint32_t w = blockIdx.x + p.win0;
-    window_sums(p, w, s_tot, s_stage);
+    decision_sums(p, w, s_tot, s_stage);
     if (threadIdx.x != 0) return;
     SyncWin& s = p.win[w];
     step_decide(p, s, s_tot, p.trace + (size_t)w * 6, (size_t)p.n_win * 6); // [iteration of the window][window][6]

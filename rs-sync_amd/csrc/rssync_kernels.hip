@@ -118,6 +118,7 @@ struct rship_ctx {
     void* rccl_lib = nullptr;
     void* rccl_comm = nullptr;
     DevBuf rccl_buf;
+    uint64_t loop_exchanges = 0; // all-reduces the last rship_sync_run enqueued on the stream (rank mode)
     std::vector<uint32_t> h_frame_n; // per table frame
     std::vector<uint32_t> h_sel;
     std::vector<uint32_t> h_delays, h_delays64; // staging of upload_delays / upload_delays64
@@ -1208,12 +1209,20 @@ static uint32_t loop_groups(const rship_ctx* c, uint32_t n_win) {
 int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_center, double search_radius,
                    int simplified, double* d_out, int32_t* iters, double* trace) {
     DeviceGuard dev_guard(c);
-    if (check_ready(c)) return 1;
+    // Rank mode: the frames are sharded over processes and this context holds the library's RCCL communicator.  The
+    // loop is the same; the window sums are all-reduced on the stream between the kernels.  A rank may hold no frame of
+    // the selection at all: it still takes part in every all-reduce.
+    const bool ranked = c->rccl_comm != nullptr;
+    if (!c->n_knots) return set_err(c, "no gyro spline uploaded");
+    if (!ranked && check_ready(c)) return 1;
     const uint32_t W = c->n_grp, ns = c->n_sel;
     if (c->plan_wins != W || c->plan_has_idx || c->plan_len != ns) return set_err(c, "sync_run: the plan must be the selection's groups");
     if (max_outer <= 0) return set_err(c, "sync_run: no iterations");
     if (c->h_grp_off.size() != (size_t)W + 1) return set_err(c, "sync_run: no selection");
-    const uint32_t G = loop_groups(c, W);
+    const uint32_t G = ranked ? 1u : loop_groups(c, W); // (one communicator: its collectives on one stream, in one order)
+    rccl_allreduce_fn allreduce = nullptr;
+    if (ranked && !(allreduce = (rccl_allreduce_fn)rccl_sym(c, "ncclAllReduce"))) return 1;
+    c->loop_exchanges = 0;
     int nf_fixed = 0; // test knob: always evaluate exactly this many trials first
     if (const char* e = std::getenv("RSSYNC_LOOP_FIRST_TRIALS")) { const int v = atoi(e); if (v >= 1 && v <= kMaxBt) nf_fixed = v; }
     const int max_launch = 2 * max_outer; // a window whose line search needs its later trials waits one iteration for them
@@ -1227,9 +1236,10 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     const size_t o_nact = take((size_t)G * nact_stride);
     const size_t o_trace = take((size_t)W * max_outer * 48);
     const size_t o_tmp = take((size_t)W * 2 * kMaxBt * (c->plan_max_chunks + 1) * 8);
+    const size_t o_ext = take((size_t)2 * kMaxBt * W * 8);
     if (ensure(c, c->loop_state, off)) return 1;
     char* base = (char*)c->loop_state.p;
-    if (ensure(c, c->part, (size_t)2 * kMaxBt * ns * 8)) return 1;
+    if (ensure(c, c->part, (size_t)2 * kMaxBt * (ns + 1) * 8)) return 1;
     while (c->loop_streams.size() < G) {
         hipStream_t st = nullptr;
         RS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -1272,6 +1282,7 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     lp.max_outer = max_outer;
     lp.nf_fixed = nf_fixed;
     lp.trace = (double*)(base + o_trace);
+    lp.ext_sums = ranked ? (double*)(base + o_ext) : nullptr;
 
     Motion64Params mp{};
     fill_motion(c, mp);
@@ -1359,6 +1370,16 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
         q.part_grad = q.part_loss + (size_t)ns;
         if (cnt && loss_launch(true)) return 1;
         l.rows = 2;
+        auto exchange = [&](uint32_t rows) -> int { // rank mode: this rank's window sums, then the sum over the ranks, on the stream
+            if (!ranked) return 0;
+            hipLaunchKernelGGL(sync_sums_kernel, dim3(nw), ctl_block, 0, gr.st, l);
+            RS_HIP(hipGetLastError());
+            const int rc = allreduce(l.ext_sums, l.ext_sums, (size_t)rows * W, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->rccl_comm, gr.st);
+            if (rc) return set_err(c, "rccl: ncclAllReduce failed (" + std::to_string(rc) + ")");
+            c->loop_exchanges += 1;
+            return 0;
+        };
+        if (exchange(2)) return 1;
         {
             ProfScope ps(c, RSHIP_K_REDUCE);
             hipLaunchKernelGGL(sync_grad_kernel, dim3(nw), ctl_block, 0, gr.st, l);
@@ -1368,6 +1389,7 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
         q.part_grad = nullptr;
         l.rows = kMaxBt;
         if (cnt && loss_launch(false)) return 1;
+        if (exchange(kMaxBt)) return 1;
         {
             ProfScope ps(c, RSHIP_K_REDUCE);
             hipLaunchKernelGGL(sync_step_kernel, dim3(nw), ctl_block, 0, gr.st, l);
@@ -1707,6 +1729,8 @@ int rship_rccl_allreduce(rship_ctx* c, double* buf, uint64_t n) {
     RS_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
+
+uint64_t rship_loop_exchanges(const rship_ctx* c) { return c->loop_exchanges; }
 
 int rship_rccl_shutdown(rship_ctx* c) {
     DeviceGuard dev_guard(c);

@@ -1303,13 +1303,23 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
     // One device holds every frame and nobody else takes part in the sums: the loop below runs on the device
     // (rship_sync_run, kernels/syncloop.hpp -- the same decisions, taken between the launches without a host
     // round trip), and only its results are read back.
-    if (shards_.size() == 1 && !distributed() && !host_loop && rship_has_device_loop() && max_outer > 0 && !sel_.empty()) {
+    // With ranks and the library's own RCCL communicator the loop stays on the device as well: the window sums are
+    // all-reduced on the stream between the kernels.  (Whether a rank holds frames of the selection must not decide
+    // the path then: every rank has to issue the same collectives.)
+    const bool device_loop = shards_.size() == 1 && !host_loop && rship_has_device_loop() && max_outer > 0 &&
+                             (native_exchange || (!distributed() && !sel_.empty()));
+    if (device_loop) {
         Shard& sh = shards_[0];
         std::vector<double> tr((size_t)W * max_outer * 6, 0.0);
         std::vector<int32_t> its(W, 0);
         hip_check(sh, rship_sync_run(sh.ctx, d.data(), max_outer, search_center, search_radius, simplified ? 1 : 0, d.data(),
                                      its.data(), tr.data()),
                   "sync loop");
+        if (native_exchange) { // the all-reduces the loop enqueued between its kernels
+            const uint64_t n = rship_loop_exchanges(sh.ctx);
+            exchange_calls += n;
+            exchange_doubles += n * 6 * W; // (two rows + ten rows per pair of exchanges)
+        }
         for (size_t w = 0; w < W; ++w)
             traces[w].assign(tr.begin() + w * (size_t)max_outer * 6, tr.begin() + (w * (size_t)max_outer + its[w]) * 6);
         if (verbose && W == 1) { // :330, the lines the host loop would have written

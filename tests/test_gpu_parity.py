@@ -620,7 +620,16 @@ def test_rccl_reduce_hook_on_the_device(tmp_path):
                    timeout=300)
     r = json.load(open(out))
     assert r["backend"] == "nccl"
-    assert r["plain"] == r["rccl"] == r["native"]
+    assert r["plain"] == r["rccl"] == r["native"] == r["native_host"]
+    # With the library's communicator Sync's loop stays on the device (rship_sync_run: window sums -> ncclAllReduce on
+    # the stream -> decisions); with one rank the all-reduce is the identity, so every trace row is the plain device
+    # loop's and the host loop's, bit for bit -- also with several windows, one of them without frames.
+    for k in ("_trace", "_windows"):
+        assert r["plain" + k] == r["rccl" + k] == r["native" + k] == r["native_host" + k], k
+    its = r["native"][4]
+    # device loop: two all-reduces per ENQUEUED iteration (blocks of eight) + the final loss; host loop: per launch
+    assert r["native_sync_exchanges"] in (2 * 8 + 1, 2 * 16 + 1) and r["native_sync_exchanges"] >= 2 * its + 1
+    assert 2 * its + 1 <= r["native_host_sync_exchanges"] <= 3 * its + 1
     # PreSync: the size-class agreement + the sweep; Sync: the agreement + 2 per outer iteration + the final loss
     assert r["exchanges"] == (1 + 1) + (1 + 2 * r["rccl"][4] + 1)
 
