@@ -46,9 +46,9 @@ class ISyncProblem {
     // Feature tracks between `frame` and the next frame: unit rays (xyz
     // interleaved, lens already undistorted) and the capture time of each ray's
     // image row.  Setting a frame again replaces it.
-    // LIMIT of this build (the reference has none, core_private.cpp:192-203): at most
-    // 8192 tracks per frame (rship_max_tracks() in rssync_hip.h); a larger count is a
-    // panic ("set-track-result: N tracks in one frame; this build accepts at most 8192").
+    // Any count, as in the reference (core_private.cpp:192-203), up to the indexing bound
+    // of 2^24 tracks per frame (rship_max_tracks() in rssync_hip.h).  Frames of more than
+    // 8192 tracks run slower, exact variants of the kernels.
     virtual void SetTrackResult(int64_t frame, const double* ts_a, const double* ts_b,
                                 const double* rays_a, const double* rays_b, size_t count) = 0;
     // Brute-force sweep of the delay over initial_delay +- search_radius in

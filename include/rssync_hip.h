@@ -66,8 +66,10 @@ void rship_destroy(rship_ctx* c);
 const char* rship_last_error(const rship_ctx* c);
 /* launch on a caller-owned hipStream_t (NULL = the context's own stream) */
 int rship_set_stream(rship_ctx* c, void* hip_stream);
-int rship_max_tracks(void); /* largest per-frame track count the kernels accept: 8192 (32 rows per thread of a
-                               256-thread workgroup; the reference itself has no limit, core_private.cpp:192-203) */
+int rship_max_tracks(void); /* largest per-frame track count accepted: 2^24, an indexing bound (the reference has none,
+                               core_private.cpp:192-203; a problem holds at most 2^32 rays).  Up to 8192 tracks a frame's
+                               rows live in registers / LDS; larger frames run the kernels' slow exact variants
+                               (kernels/lmeds_big.hpp, loss64_kernel<0>, opt_motion64_kernel<0, 4>) */
 /* Behaviour switches.  RSHIP_OPT_LBFGS_REEVAL: what the restated ens::L_BFGS does when a line search's
  * best step is not its last -- 0 (default): iterate at the best step, value and gradient as the last
  * trial left them (the published LineSearch); 1: evaluate once more at the best step. */

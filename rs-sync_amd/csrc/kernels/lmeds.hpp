@@ -44,6 +44,10 @@ struct LmedsParams {
     int32_t* best_h;    // [n_cand][n_sel] or null; INIT mode: [n_sel], the winning hypothesis per slot (-1 = none),
                         // from which opt_motion64_kernel recomputes M and k in fp64
     uint32_t* flags;
+    // frames of more than 8192 tracks (kernels/lmeds_big.hpp): the workgroups' tiles in global memory,
+    // gridDim.x x scratch_rows x 5 floats
+    float* scratch;
+    uint32_t scratch_rows;
 };
 
 // ---- LMedS tile in LDS, struct-of-arrays: unit rows n = safe_normalize(P).  The norms |P|

@@ -139,6 +139,8 @@ struct Loss64Params {
 // this kernel HBM/L2-bound (64 B per ray pair per delay: 6.5 TB/s effective at 4096 x 2048).
 constexpr int kLossBatch = 5; // (6, at two workgroups per CU: 5 % slower)
 
+// RPT = rows per thread the launch covers (the largest frame's); 0 = as many as this frame needs (frames of more
+// than 8192 tracks).  A thread adds its rows in order either way, so a frame's sums do not depend on RPT.
 template <int RPT, bool GRAD, bool SIMPLE>
 __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
     constexpr int NB = GRAD ? 1 : kLossBatch;
@@ -206,8 +208,9 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
         double L[NB], G[NB];
 #pragma unroll
         for (int q = 0; q < NB; ++q) L[q] = G[q] = 0.0;
+        const int rpt = RPT ? RPT : (int)((N + kBlock - 1) / kBlock);
 #pragma unroll 1 // (unroll 2 measured in round 3: the gradient launch stays at 0.122 ms)
-        for (int j = 0; j < RPT; ++j) {
+        for (int j = 0; j < rpt; ++j) {
             const uint32_t row = j * kBlock + tid;
             if (row < N) {
                 const size_t idx = (size_t)fr.off + row;
@@ -290,6 +293,10 @@ struct Motion64Params {
     // slot changes nothing in the slot's result.
     const uint32_t* order;
     uint32_t* evals_out; // [n_sel]: evaluations of this launch per slot (input of the next ordering), or null
+    // frames of more than 8192 tracks (RPT = 0): the rows of P per workgroup in global memory instead of registers,
+    // n_sel x 3 x scratch_rows doubles (per slot: x, y, z planes; scratch_rows a multiple of the workgroup size)
+    double* scratch;
+    uint32_t scratch_rows;
 };
 
 constexpr int kInitNone = (int)0x80000000;
@@ -298,7 +305,10 @@ constexpr int kNB = rs::kLbfgsBasis; // numBasis (ens::L_BFGS default)
 // NW = waves per workgroup (4 in the product: measured fastest, see launch_motion64)
 template <int RPT, int NW>
 struct MotionEval64 {
-    d3 P[RPT];
+    d3 P[RPT ? RPT : 1];
+    const double* gP; // RPT == 0: the rows in global memory, plane stride g_rows, rpt rows per thread (zero beyond the frame)
+    uint32_t g_rows;
+    int rpt;
     double (*part)[NW][4]; // [2][NW][4] LDS, double-buffered
     int buf;
     double k2;
@@ -312,8 +322,15 @@ struct MotionEval64 {
         double xx;
         const double inv_s = rs::motion_inv_s(x, k2, &xx);
         double L = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        if constexpr (RPT != 0) {
 #pragma unroll
-        for (int j = 0; j < RPT; ++j) rs::motion_row(P[j], x, inv_s, L, a0, a1, a2);
+            for (int j = 0; j < RPT; ++j) rs::motion_row(P[j], x, inv_s, L, a0, a1, a2);
+        } else {
+            for (int j = 0; j < rpt; ++j) {
+                const size_t i = (size_t)j * (64 * NW) + threadIdx.x;
+                rs::motion_row(d3{gP[i], gP[g_rows + i], gP[2 * (size_t)g_rows + i]}, x, inv_s, L, a0, a1, a2);
+            }
+        }
         double r0 = wave_sum_f64(L), r1 = wave_sum_f64(a0), r2 = wave_sum_f64(a1), r3 = wave_sum_f64(a2);
         double t[4] = {r0, r1, r2, r3};
         if (NW > 1) { // the waves' sums through LDS; a one-wave frame has them already
@@ -411,12 +428,28 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
     ev.buf = 0;
     ev.evals = 0;
     const int base = fr.base_knot + kd;
+    ev.gP = nullptr;
+    ev.g_rows = 0;
+    ev.rpt = RPT;
+    if constexpr (RPT != 0) {
 #pragma unroll
-    for (int j = 0; j < RPT; ++j) {
-        const uint32_t row = j * kThreads + tid;
-        d3 P = d3{0, 0, 0}, dP;
-        if (row < N) residual_row64<false>(sp, p.rays, (size_t)fr.off + row, base, fd, P, dP);
-        ev.P[j] = P; // zero rows contribute log1p(0) = 0 and no gradient
+        for (int j = 0; j < RPT; ++j) {
+            const uint32_t row = j * kThreads + tid;
+            d3 P = d3{0, 0, 0}, dP;
+            if (row < N) residual_row64<false>(sp, p.rays, (size_t)fr.off + row, base, fd, P, dP);
+            ev.P[j] = P; // zero rows contribute log1p(0) = 0 and no gradient
+        }
+    } else { // the same rows, kept in this workgroup's scratch (only this thread reads what it writes)
+        double* gp = p.scratch + (size_t)sf * 3 * p.scratch_rows; // per SLOT: launches of several stream groups run side by side
+        ev.gP = gp;
+        ev.g_rows = p.scratch_rows;
+        ev.rpt = (int)((N + kThreads - 1) / kThreads);
+        for (int j = 0; j < ev.rpt; ++j) {
+            const uint32_t row = j * kThreads + tid;
+            d3 P = d3{0, 0, 0}, dP;
+            if (row < N) residual_row64<false>(sp, p.rays, (size_t)fr.off + row, base, fd, P, dP);
+            gp[row] = P.x; gp[p.scratch_rows + row] = P.y; gp[2 * (size_t)p.scratch_rows + row] = P.z;
+        }
     }
 
     double x[3];
@@ -436,10 +469,19 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
             if (!(nn < 1e-12)) Mv = rs::scale(Mv, 1.0 / nn); // safe_normalize, inline_utils.hpp:5-11
         }
         double ss = 0.0;
+        if constexpr (RPT != 0) {
 #pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            const double pm = p.simple_k ? sqrt(rs::dot(ev.P[j], ev.P[j])) : rs::dot(ev.P[j], Mv);
-            ss = fma(pm, pm, ss);
+            for (int j = 0; j < RPT; ++j) {
+                const double pm = p.simple_k ? sqrt(rs::dot(ev.P[j], ev.P[j])) : rs::dot(ev.P[j], Mv);
+                ss = fma(pm, pm, ss);
+            }
+        } else {
+            for (int j = 0; j < ev.rpt; ++j) {
+                const size_t i = (size_t)j * kThreads + tid;
+                const d3 Pj = d3{ev.gP[i], ev.gP[ev.g_rows + i], ev.gP[2 * (size_t)ev.g_rows + i]};
+                const double pm = p.simple_k ? sqrt(rs::dot(Pj, Pj)) : rs::dot(Pj, Mv);
+                ss = fma(pm, pm, ss);
+            }
         }
         const double sw = wave_sum_f64(ss);
         if ((tid & 63) == 0) s_red[tid >> 6] = sw;
@@ -480,7 +522,7 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
 }
 
 template <int RPT, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? (RPT <= 8 ? 3 : (RPT == 16 ? 2 : 1)) : (NW == 1 ? (RPT >= 8 ? 3 : 4) : 2)) void opt_motion64_kernel(Motion64Params p) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? (RPT == 0 ? 2 : (RPT <= 8 ? 3 : (RPT == 16 ? 2 : 1))) : (NW == 1 ? (RPT >= 8 ? 3 : 4) : 2)) void opt_motion64_kernel(Motion64Params p) {
     __shared__ MotionLds<NW> lds;
     opt_motion64_body<RPT, NW>(p, p.order ? p.order[blockIdx.x + p.slot0] : blockIdx.x + p.slot0, lds);
 }

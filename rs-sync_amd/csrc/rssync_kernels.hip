@@ -48,6 +48,7 @@ using rs::f4;
 #include "kernels/common.hpp"
 #include "kernels/lmeds.hpp"
 #include "kernels/lmeds_small.hpp"
+#include "kernels/lmeds_big.hpp"
 #include "kernels/support.hpp"
 #include "kernels/sync64.hpp"
 #include "kernels/syncloop.hpp"
@@ -118,6 +119,7 @@ struct rship_ctx {
     void* rccl_lib = nullptr;
     void* rccl_comm = nullptr;
     DevBuf rccl_buf;
+    DevBuf big_scratch, mo_scratch; // frames of more than 8192 tracks: the LMedS tiles / the motion kernel's rows
     uint64_t loop_exchanges = 0; // all-reduces the last rship_sync_run enqueued on the stream (rank mode)
     std::vector<uint32_t> h_frame_n; // per table frame
     std::vector<uint32_t> h_sel;
@@ -223,13 +225,17 @@ int sync_stream(rship_ctx* c) {
     return 0;
 }
 
+constexpr int kMaxRpt = 32; // 8192 tracks per frame in registers / LDS; larger frames take the kernels' slow paths
+
+// rows per thread of a 256-thread workgroup that cover max_n tracks (a power of two); 0 = more than kMaxRpt: the
+// kernels' runtime-length variants (loss64_kernel<0>, opt_motion64_kernel<0, 4>, lmeds_big_kernel)
 int rpt_for(uint32_t max_n) {
+    if (max_n > (uint32_t)kMaxRpt * kBlock) return 0;
     int rpt = 1;
     while ((uint32_t)rpt * kBlock < max_n) rpt *= 2;
     return rpt;
 }
-
-constexpr int kMaxRpt = 32; // 8192 tracks per frame
+uint32_t big_rows(const rship_ctx* c) { return (c->max_n + kBlock - 1) / kBlock * kBlock; }
 
 uint32_t sel_max_n(const rship_ctx* c) {
     uint32_t m = 0;
@@ -253,6 +259,23 @@ int launch_lmeds(rship_ctx* c, const LmedsParams& p, int rpt, uint32_t grid) {
             case 3: hipLaunchKernelGGL((lmeds_small_kernel<3, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
             default: hipLaunchKernelGGL((lmeds_small_kernel<4, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
         }
+        RS_HIP(hipGetLastError());
+        return 0;
+    }
+    if (n_all > (uint32_t)kMaxRpt * kBlock) {
+        // more than 8192 tracks somewhere in the problem: the slow exact path (kernels/lmeds_big.hpp), tiles in a
+        // scratch that a fixed number of workgroups share by walking over the (frame, chunk) items
+        const uint32_t rows = big_rows(c);
+        const uint64_t total = (uint64_t)p.n_sel * p.n_chunks;
+        uint64_t g1 = total < 2048 ? total : 2048;
+        const uint64_t per_wg = (uint64_t)rows * kBigScratchFloats * 4;
+        const uint64_t fit = ((uint64_t)4 << 30) / per_wg; // at most 4 GB of tiles
+        if (g1 > fit) g1 = fit ? fit : 1;
+        if (ensure(c, c->big_scratch, (size_t)(g1 * per_wg))) return 1;
+        LmedsParams q = p;
+        q.scratch = (float*)c->big_scratch.p;
+        q.scratch_rows = rows;
+        hipLaunchKernelGGL((lmeds_big_kernel<MODE>), dim3((uint32_t)g1), dim3(kBlock), 0, c->stream, q);
         RS_HIP(hipGetLastError());
         return 0;
     }
@@ -288,6 +311,7 @@ int launch_loss64(rship_ctx* c, const Loss64Params& p, int rpt, hipStream_t st =
     if (!count) count = p.n_sel - p.slot0;
     ProfScope ps(c, GRAD ? RSHIP_K_LOSS_GRAD : RSHIP_K_LOSS);
     switch (rpt) {
+        case 0: hipLaunchKernelGGL((loss64_kernel<0, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
         case 1: hipLaunchKernelGGL((loss64_kernel<1, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
         case 2: hipLaunchKernelGGL((loss64_kernel<2, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
         case 4: hipLaunchKernelGGL((loss64_kernel<4, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
@@ -325,7 +349,10 @@ int launch_motion64(rship_ctx* c, const Motion64Params& p, hipStream_t st = null
     else if (n <= 2048) hipLaunchKernelGGL((opt_motion64_kernel<8, 4>), dim3(count), dim3(256), 0, st, p);
     else if (n <= 4096) hipLaunchKernelGGL((opt_motion64_kernel<16, 4>), dim3(count), dim3(256), 0, st, p);
     else if (n <= 8192) hipLaunchKernelGGL((opt_motion64_kernel<32, 4>), dim3(count), dim3(256), 0, st, p);
-    else return set_err(c, "motion: unsupported track count");
+    else { // rows of P in global memory (per slot, set up by fill_motion), as many per thread as the frame needs
+        if (!p.scratch || p.scratch_rows < c->max_n) return set_err(c, "motion: no scratch for frames of more than 8192 tracks");
+        hipLaunchKernelGGL((opt_motion64_kernel<0, 4>), dim3(count), dim3(256), 0, st, p);
+    }
     RS_HIP(hipGetLastError());
     // the order of the NEXT launch over these slots, from this one's evaluation counts
     if (p.evals_out && c->mo_order.p && p.max_iters > 0 && !p.simple_k && count >= kOrderMinSlots && !c->no_motion_order) {
@@ -441,7 +468,10 @@ void* rccl_sym(rship_ctx* c, const char* name) {
 
 extern "C" {
 
-int rship_max_tracks(void) { return kMaxRpt * kBlock; }
+// An indexing bound, not a kernel one: 2^24 tracks per frame (the packing kernel's grid), 2^32 rays per problem
+// (32-bit offsets).  Up to kMaxRpt * kBlock = 8192 tracks per frame the kernels keep a frame's rows in registers /
+// LDS; beyond that they take their slow exact variants (rows in global memory).
+int rship_max_tracks(void) { return 1 << 24; }
 int rship_has_device_loop(void) { return 1; }
 
 // Staging memory for the host solver: pinned, so that rship_upload_raw is a true asynchronous DMA
@@ -496,6 +526,7 @@ void rship_destroy(rship_ctx* c) {
     DevBuf* bufs[] = {&c->coef, &c->coef64, &c->raw, &c->rays_a, &c->rays_b, &c->rays64, &c->frames, &c->sel, &c->M, &c->k, &c->grp, &c->grp_off,
                       &c->plan_idx, &c->plan_chunk_off, &c->plan_win_off, &c->chunk_out, &c->win_out, &c->loop_state, &c->kd, &c->kd64, &c->init_h,
                       &c->frame_cost, &c->best_h, &c->costs, &c->part, &c->flags, &c->stats,
+                      &c->big_scratch, &c->mo_scratch, &c->mo_evals, &c->mo_order,
                       &c->g_ts, &c->g_rates, &c->g_us, &c->g_dq, &c->g_q, &c->g_knots, &c->g_cf, &c->g_status};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -973,7 +1004,17 @@ int rship_presync_collect(rship_ctx* c, uint32_t n_cand, double* win_costs, doub
 }
 
 namespace {
-void fill_motion(rship_ctx* c, Motion64Params& p) {
+// (returns 1 only if the scratch of the large-frame path cannot be allocated: c->err is set, the launch then fails)
+int fill_motion(rship_ctx* c, Motion64Params& p) {
+    p.scratch = nullptr;
+    p.scratch_rows = 0;
+    const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
+    if (n_all > (uint32_t)kMaxRpt * kBlock) {
+        const uint32_t rows = big_rows(c);
+        if (ensure(c, c->mo_scratch, (size_t)(c->n_sel ? c->n_sel : 1) * 3 * rows * 8)) return 1;
+        p.scratch = (double*)c->mo_scratch.p;
+        p.scratch_rows = rows;
+    }
     p.rays = rays64_of(c);
     p.frames = (const FrameRec*)c->frames.p;
     p.sel = (const uint32_t*)c->sel.p;
@@ -994,6 +1035,7 @@ void fill_motion(rship_ctx* c, Motion64Params& p) {
     p.simple_k = 0;
     p.evals_out = (uint32_t*)c->mo_evals.p;
     p.order = (const uint32_t*)c->mo_order.p; // the caller has called prepare_order for its slot ranges
+    return 0;
 }
 
 // Before a call launches the motion kernel over the slot ranges `ranges` (one per stream group): the launch order
@@ -1058,7 +1100,7 @@ int rship_finish_init(rship_ctx* c, const int32_t* kd, const double* fd) {
     if (!c->init_pending) return 0;
     if (upload_delays64(c, kd, fd, c->n_grp)) return 1;
     Motion64Params p{};
-    fill_motion(c, p);
+    if (fill_motion(c, p)) return 1;
     p.max_iters = 0;
     if (prepare_order_all(c) || launch_motion64(c, p)) return 1;
     c->init_pending = false;
@@ -1072,7 +1114,7 @@ int rship_init_k_simple(rship_ctx* c, const int32_t* kd, const double* fd) {
     if (check_ready(c)) return 1;
     if (upload_delays64(c, kd, fd, c->n_grp)) return 1;
     Motion64Params p{};
-    fill_motion(c, p);
+    if (fill_motion(c, p)) return 1;
     p.init_h = nullptr;
     p.simple_k = 1;
     if (prepare_order_all(c) || launch_motion64(c, p)) return 1;
@@ -1088,7 +1130,7 @@ int rship_opt_motion_detail(rship_ctx* c, const int32_t* kd, const double* fd, u
     RS_HIP(hipMemsetAsync(d.p, 0, (size_t)c->n_sel * 8 + 8, c->stream));
     if (upload_delays64(c, kd, fd, c->n_grp)) return 1;
     Motion64Params p{};
-    fill_motion(c, p);
+    if (fill_motion(c, p)) return 1;
     p.per_frame = (uint32_t*)d.p;
     int rc = prepare_order_all(c) || launch_motion64(c, p);
     c->init_pending = false;
@@ -1109,7 +1151,7 @@ int rship_opt_motion(rship_ctx* c, const int32_t* kd, const double* fd, uint64_t
     }
     if (upload_delays64(c, kd, fd, c->n_grp)) return 1;
     Motion64Params p{};
-    fill_motion(c, p);
+    if (fill_motion(c, p)) return 1;
     p.stats = stats ? (unsigned long long*)c->stats.p : nullptr;
     if (prepare_order_all(c) || launch_motion64(c, p)) return 1;
     c->init_pending = false;
@@ -1285,7 +1327,7 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     lp.ext_sums = ranked ? (double*)(base + o_ext) : nullptr;
 
     Motion64Params mp{};
-    fill_motion(c, mp);
+    if (fill_motion(c, mp)) return 1;
     mp.kd = lp.mo_kd;
     mp.fd = lp.mo_fd;
     Loss64Params qp{};
@@ -1585,7 +1627,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     ep.init.best_h = (int32_t*)c->init_h.p;
     ep.init.flags = (uint32_t*)c->flags.p;
     // motion
-    fill_motion(c, ep.mo);
+    if (fill_motion(c, ep.mo)) return 1;
     ep.mo.kd = ep.mo_kd;
     ep.mo.fd = ep.mo_fd;
     ep.mo.grp = ep.grp;

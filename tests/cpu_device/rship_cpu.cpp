@@ -157,7 +157,7 @@ float clampk(float k) { return (k < 10.f) ? 10.f : ((1000.f < k) ? 1000.f : k); 
 
 extern "C" {
 
-int rship_max_tracks(void) { return 8192; }
+int rship_max_tracks(void) { return 1 << 24; }
 int rship_create(rship_ctx** out, int) { *out = new rship_ctx(); return 0; } // any device ordinal: a fake device
 void rship_destroy(rship_ctx* c) { delete c; }
 const char* rship_last_error(const rship_ctx* c) { return c->err.c_str(); }

@@ -71,7 +71,7 @@ def _scene(F, N, seed, **kw):
     return gyro, list(synth.make_frames(gyro, 0, F, N, seed=seed, **kw))
 
 
-@pytest.mark.parametrize("F,N", [(12, 130), (10, 600), (6, 2048), (7, 257)])
+@pytest.mark.parametrize("F,N", [(12, 130), (10, 600), (6, 2048), (7, 257), (3, 9000)])
 def test_every_evaluation_is_bit_identical(hosttest_lib, F, N):
     """per evaluation: fp64 rows, GuessMotion's M / GuessK, the loss and its analytic derivative at several delays,
     one motion optimisation (end points, iteration and evaluation counts) -- noisy scene, 10 % outliers"""

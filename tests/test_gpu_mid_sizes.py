@@ -214,15 +214,82 @@ def test_more_than_2048_tracks_per_frame(N):
     assert np.isfinite(c1) and abs(d1 - synth.D_TRUE) < 2e-3
 
 
-def test_track_limit_is_a_documented_panic():
-    """the reference accepts any count (core_private.cpp:192-203); this build stops at 8192 per frame with a
-    message instead of computing something else"""
+def _check_large_frames(h, o, F, N_of, n_cand_step=0.01):
+    from rssync_amd import synth
+    for fr in (0, F - 1):
+        N = N_of(fr)
+        Ph = h.problem_matrix(fr, 0.0371, N)
+        assert np.abs(Ph - o.problem_matrix(fr, 0.0371)).max() < 5e-7
+        assert np.abs(h.problem_matrix64(fr, 0.0371, N) - o.problem_matrix(fr, 0.0371)).max() < 1e-13
+    dh, ch, fch, bhh = h.presync_curve(0.0, 0, F, n_cand_step, 0.1, per_frame=F)
+    do, co, fco, bho = o.presync_curve(0.0, 0, F, n_cand_step, 0.1, per_frame=F)
+    np.testing.assert_array_equal(dh, do)
+    same = bhh == bho
+    assert same.mean() > 0.97, same.mean()
+    rel = np.abs(fch - fco) / fco
+    assert rel[same].max() < 1e-3 and np.median(rel[same]) < 2e-6
+    assert np.argmin(ch) == np.argmin(co)
+    np.testing.assert_allclose(ch, co, rtol=5e-3)
+    from oracle import oracle as ora
+    Mh, kh = h.init_motion(0.036, 0, F - 1)        # (first Sync-side call of a fresh problem: stream SYNC_INIT + 0)
+    agree = 0
+    for f in range(F):
+        Mo, bh, med = o.guess_motion(f, 0.036, 200, ora.STREAM_SYNC_INIT + 0)
+        if np.abs(Mh[f] - Mo).max() < 1e-12:
+            agree += 1
+            ko = np.clip(100 / np.linalg.norm(o.problem_matrix(f, 0.036) @ Mo), 10, 1000)
+            assert kh[f] == pytest.approx(ko, rel=1e-12)
+    assert agree >= F - 1                          # the fp32 search may flip one near-tie
+    Lh, Gh = h.loss([0.036, 0.03], grad=True)
+    for j, dd in enumerate((0.036, 0.03)):
+        per = [o.loss(f, dd, Mh[f], kh[f]) for f in range(F)]
+        assert Lh[j] == pytest.approx(sum(p[0] for p in per), rel=1e-12)
+        assert Gh[j] == pytest.approx(sum(p[2] for p in per), rel=1e-10, abs=1e-10 * abs(Lh[j]))
+    L5 = h.loss([0.036, 0.03, 0.035, 0.0371, 0.04])       # the five-delay batch kernel
+    assert L5[0] == pytest.approx(Lh[0], rel=1e-13) and L5[1] == pytest.approx(Lh[1], rel=1e-13)
+    c1, d1 = h.Sync(0.036, 0, F - 1, 0.0, 0.2)
+    c2, d2 = o.Sync(0.036, 0, F - 1, 0.0, 0.2)
+    assert abs(d1 - synth.D_TRUE) < 1e-4 and abs(d1 - d2) < 1e-4
+    assert c1 == pytest.approx(c2, rel=1e-3)
+
+
+@pytest.mark.parametrize("N", [8193, 10000])
+def test_more_than_8192_tracks_per_frame(N):
+    """The reference accepts any count (core_private.cpp:192-203).  Above 8192 tracks a frame no longer fits the
+    tile kernel's LDS / registers: lmeds_big_kernel (tile in global memory, hypotheses in order, quartile by
+    bisection), loss64_kernel<0> and opt_motion64_kernel<0, 4> (as many rows per thread as the frame needs, P in
+    global memory).  Same checks against the oracle as at every other size."""
+    F = 4
+    h, o = _pair(F, N, seed=90 + N, noise=3e-4, outliers=0.05, max_outer_iters=12)
+    _check_large_frames(h, o, F, lambda fr: N)
+
+
+def test_large_and_small_frames_in_one_problem():
+    """one frame of 9000 tracks among frames of 300: the whole problem takes the large-frame kernels (the kernel
+    choice follows the problem's largest frame), every frame still matches the oracle"""
     import rssync_amd
-    n = 8193
-    h = rssync_amd.SyncProblem()
-    ra = np.tile([0.0, 0.0, 1.0], (n, 1))
-    with pytest.raises(rssync_amd.RsSyncError, match="8193 tracks in one frame; this build accepts at most 8192"):
-        h.SetTrackResult(0, np.zeros(n), np.zeros(n), ra, ra)
+    from rssync_amd import synth
+    from oracle.oracle import OracleProblem
+    F = 5
+    n_of = lambda fr: 9000 if fr == 2 else 300
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=17)
+    h = rssync_amd.SyncProblem(seed=SEED, max_outer_iters=12)
+    o = OracleProblem(seed=SEED, threads=THREADS, faithful=False, max_outer_iters=12)
+    for p in (h, o):
+        p.SetGyroQuaternions(g.quats, g.fs, g.t0)
+        for fr in range(F):
+            p.SetTrackResult(*next(iter(synth.make_frames(g, fr, fr + 1, n_of(fr), seed=17, noise=3e-4, outliers=0.05))))
+    _check_large_frames(h, o, F, n_of, n_cand_step=0.02)
+
+
+def test_track_limit_is_an_indexing_bound():
+    """what is left of the limit: 2^24 tracks per frame (32-bit indexing), far beyond what fits next to the frame's
+    own 96 bytes per track; the message names it"""
+    import ctypes
+    import rssync_amd
+    lib = ctypes.CDLL(rssync_amd.library_path())
+    lib.rship_max_tracks.restype = ctypes.c_int
+    assert lib.rship_max_tracks() == 1 << 24
 
 
 def test_one_wave_kernel_for_small_frames_agrees_with_the_tile_kernel(monkeypatch):

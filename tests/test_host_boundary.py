@@ -49,7 +49,7 @@ def test_library_loads_and_binds(built):
     lib = rssync_amd.load_library()
     assert lib.rssync_last_error() is not None
     lib.rship_max_tracks.restype = ctypes.c_int
-    assert lib.rship_max_tracks() == 8192
+    assert lib.rship_max_tracks() == 1 << 24
 
 
 CLIENT = r"""
@@ -187,6 +187,6 @@ int main(void) {
     out = subprocess.run([str(exe)], capture_output=True, text=True, cwd=tmp_path)
     assert out.returncode == 0
     msg, tracks = out.stdout.strip().rsplit("|", 1)
-    assert tracks == "8192"
+    assert tracks == str(1 << 24)
     if not torch.cuda.is_available():
         assert "no usable HIP device" in msg and "no CPU fallback" in msg

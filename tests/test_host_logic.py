@@ -190,9 +190,8 @@ def test_panics_follow_the_reference_messages(host, tiny_case):
     ts[10], ts[11] = ts[11], ts[10]
     with pytest.raises(rssync_amd.RsSyncError, match="timestamps out of order at pos 11"):
         h.SetGyroQuaternionsTimestamped(ts, np.tile([1.0, 0, 0, 0], (50, 1)))
-    with pytest.raises(rssync_amd.RsSyncError, match="tracks in one frame"):
-        n = 8193   # this build stops at 8192 tracks per frame (the reference has no limit)
-        h.SetTrackResult(5, np.zeros(n), np.zeros(n), np.tile([0, 0, 1.0], (n, 1)), np.tile([0, 0, 1.0], (n, 1)))
+    n = 8193   # no per-frame limit, as in the reference (core_private.cpp:192-203): accepted like any other frame
+    h.SetTrackResult(5, np.zeros(n), np.zeros(n), np.tile([0, 0, 1.0], (n, 1)), np.tile([0, 0, 1.0], (n, 1)))
 
 
 def test_timestamped_gyro_and_gyro_replacement(host, tiny_case):
