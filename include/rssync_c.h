@@ -81,6 +81,11 @@ int rssync_ext_set_lbfgs_reeval(rssync_problem* p, int reeval);
  * scalar decisions are taken between the launches, the host polls every few iterations); 1 keeps it on the
  * host, where it always runs otherwise.  Both give the same bits.  Environment: RSSYNC_HOST_LOOP=1. */
 int rssync_ext_set_host_loop(rssync_problem* p, int host_loop);
+/* With frames sharded over ranks: the library's own RCCL communicator keeps Sync's loop on the device (the window
+ * sums are all-reduced on the stream between the kernels); a reduce hook normally means the host loop, one hook
+ * call per launch.  1 = keep the loop on the device with a hook too: the hook is called between the kernels on the
+ * window sums (the stream is drained at each call).  Same structure as the RCCL path, any transport. */
+int rssync_ext_set_hook_device_loop(rssync_problem* p, int on);
 /* line searches of the last rssync_ext_opt_motion call whose best step was not the last one tried */
 int rssync_ext_lbfgs_best_not_last(rssync_problem* p, uint64_t* count);
 /* ONE object, several GPUs (the reference parallelises over frames inside the object, core_private.cpp:73,231,

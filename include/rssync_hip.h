@@ -253,6 +253,11 @@ int rship_rccl_shutdown(rship_ctx* c); /* ncclCommDestroy; collective */
 /* with a communicator, rship_sync_run all-reduces the window sums ON THE STREAM between its kernels (two
  * ncclAllReduce per enqueued iteration, no host round trip); this many the last run enqueued */
 uint64_t rship_loop_exchanges(const rship_ctx* c);
+/* The same loop with a HOST exchange instead of the communicator (the solver's reduce hook: any transport): the
+ * window sums are copied to the host, fn(user, sums, n) adds the other ranks' in place (0 = ok), and they are copied
+ * back -- the stream is drained at every exchange, the decisions still never leave the device.  NULL switches it off. */
+typedef int (*rship_loop_exchange_fn)(void* user, double* sums, uint64_t n);
+int rship_set_loop_exchange(rship_ctx* c, rship_loop_exchange_fn fn, void* user);
 
 /* debug: the packed float4 streams of one frame of the table */
 int rship_debug_rays(rship_ctx* c, uint32_t frame_index, float* a4, float* b4, uint32_t cap_rays);

@@ -120,6 +120,8 @@ struct rship_ctx {
     void* rccl_comm = nullptr;
     DevBuf rccl_buf;
     DevBuf big_scratch, mo_scratch; // frames of more than 8192 tracks: the LMedS tiles / the motion kernel's rows
+    rship_loop_exchange_fn loop_xchg = nullptr; // host exchange for the device-driven loop (rship_set_loop_exchange)
+    void* loop_xchg_user = nullptr;
     uint64_t loop_exchanges = 0; // all-reduces the last rship_sync_run enqueued on the stream (rank mode)
     std::vector<uint32_t> h_frame_n; // per table frame
     std::vector<uint32_t> h_sel;
@@ -1254,7 +1256,7 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     // Rank mode: the frames are sharded over processes and this context holds the library's RCCL communicator.  The
     // loop is the same; the window sums are all-reduced on the stream between the kernels.  A rank may hold no frame of
     // the selection at all: it still takes part in every all-reduce.
-    const bool ranked = c->rccl_comm != nullptr;
+    const bool ranked = c->rccl_comm != nullptr || c->loop_xchg != nullptr;
     if (!c->n_knots) return set_err(c, "no gyro spline uploaded");
     if (!ranked && check_ready(c)) return 1;
     const uint32_t W = c->n_grp, ns = c->n_sel;
@@ -1263,7 +1265,8 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     if (c->h_grp_off.size() != (size_t)W + 1) return set_err(c, "sync_run: no selection");
     const uint32_t G = ranked ? 1u : loop_groups(c, W); // (one communicator: its collectives on one stream, in one order)
     rccl_allreduce_fn allreduce = nullptr;
-    if (ranked && !(allreduce = (rccl_allreduce_fn)rccl_sym(c, "ncclAllReduce"))) return 1;
+    if (ranked && !c->loop_xchg && !(allreduce = (rccl_allreduce_fn)rccl_sym(c, "ncclAllReduce"))) return 1;
+    std::vector<double> xbuf; // host exchange: the sums of one launch
     c->loop_exchanges = 0;
     int nf_fixed = 0; // test knob: always evaluate exactly this many trials first
     if (const char* e = std::getenv("RSSYNC_LOOP_FIRST_TRIALS")) { const int v = atoi(e); if (v >= 1 && v <= kMaxBt) nf_fixed = v; }
@@ -1416,9 +1419,19 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
             if (!ranked) return 0;
             hipLaunchKernelGGL(sync_sums_kernel, dim3(nw), ctl_block, 0, gr.st, l);
             RS_HIP(hipGetLastError());
+            c->loop_exchanges += 1;
+            if (c->loop_xchg) { // through the host: drain, add the other ranks' sums, send back
+                xbuf.resize((size_t)rows * W);
+                RS_HIP(hipMemcpyAsync(xbuf.data(), l.ext_sums, xbuf.size() * 8, hipMemcpyDeviceToHost, gr.st));
+                RS_HIP(hipStreamSynchronize(gr.st));
+                const int rc = c->loop_xchg(c->loop_xchg_user, xbuf.data(), xbuf.size());
+                if (rc) return set_err(c, "sync_run: the loop's host exchange failed (" + std::to_string(rc) + ")");
+                RS_HIP(hipMemcpyAsync(l.ext_sums, xbuf.data(), xbuf.size() * 8, hipMemcpyHostToDevice, gr.st));
+                RS_HIP(hipStreamSynchronize(gr.st)); // (xbuf is pageable and reused)
+                return 0;
+            }
             const int rc = allreduce(l.ext_sums, l.ext_sums, (size_t)rows * W, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->rccl_comm, gr.st);
             if (rc) return set_err(c, "rccl: ncclAllReduce failed (" + std::to_string(rc) + ")");
-            c->loop_exchanges += 1;
             return 0;
         };
         if (exchange(2)) return 1;
@@ -1773,6 +1786,11 @@ int rship_rccl_allreduce(rship_ctx* c, double* buf, uint64_t n) {
 }
 
 uint64_t rship_loop_exchanges(const rship_ctx* c) { return c->loop_exchanges; }
+int rship_set_loop_exchange(rship_ctx* c, rship_loop_exchange_fn fn, void* user) {
+    c->loop_xchg = fn;
+    c->loop_xchg_user = user;
+    return 0;
+}
 
 int rship_rccl_shutdown(rship_ctx* c) {
     DeviceGuard dev_guard(c);

@@ -232,6 +232,10 @@ class SyncProblemHip final : public ISyncProblem {
                          std::vector<double>& delays_out);
     std::vector<std::vector<double>> traces; // per window of the last sync_windows call
     bool native_exchange = false; // RCCL communicator inside the device context (rssync_ext_rccl_init)
+    // With a reduce hook Sync's loop runs on the host (an exchange per launch).  hook_device_loop = true keeps it on
+    // the device and calls the hook between the kernels instead (rship_set_loop_exchange): the same structure as with
+    // the RCCL communicator, any transport -- and the way two ranks sharing one GPU can exercise that structure.
+    bool hook_device_loop = false;
     bool distributed() const { return native_exchange || reduce_fn; }
     uint64_t exchange_calls = 0, exchange_doubles = 0; // sums exchanged with other ranks so far
     void rccl_shutdown();
@@ -1306,10 +1310,20 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
     // With ranks and the library's own RCCL communicator the loop stays on the device as well: the window sums are
     // all-reduced on the stream between the kernels.  (Whether a rank holds frames of the selection must not decide
     // the path then: every rank has to issue the same collectives.)
+    const bool hook_loop = hook_device_loop && reduce_fn && !native_exchange;
     const bool device_loop = shards_.size() == 1 && !host_loop && rship_has_device_loop() && max_outer > 0 &&
-                             (native_exchange || (!distributed() && !sel_.empty()));
+                             (native_exchange || hook_loop || (!distributed() && !sel_.empty()));
     if (device_loop) {
         Shard& sh = shards_[0];
+        struct Tramp {
+            static int call(void* user, double* sums, uint64_t n) {
+                SyncProblemHip* self = static_cast<SyncProblemHip*>(user);
+                const int rc = self->reduce_fn(sums, (size_t)n, self->reduce_user);
+                if (rc == 0) { self->exchange_calls += 1; self->exchange_doubles += n; }
+                return rc;
+            }
+        };
+        rship_set_loop_exchange(sh.ctx, hook_loop ? &Tramp::call : nullptr, hook_loop ? this : nullptr);
         std::vector<double> tr((size_t)W * max_outer * 6, 0.0);
         std::vector<int32_t> its(W, 0);
         hip_check(sh, rship_sync_run(sh.ctx, d.data(), max_outer, search_center, search_radius, simplified ? 1 : 0, d.data(),
@@ -1640,6 +1654,10 @@ int rssync_ext_set_lbfgs_reeval(rssync_problem* p, int reeval) {
 }
 int rssync_ext_set_host_loop(rssync_problem* p, int host_loop) {
     p->impl->host_loop = host_loop != 0;
+    return 0;
+}
+int rssync_ext_set_hook_device_loop(rssync_problem* p, int on) {
+    p->impl->hook_device_loop = on != 0;
     return 0;
 }
 int rssync_ext_lbfgs_best_not_last(rssync_problem* p, uint64_t* count) {

@@ -51,6 +51,7 @@ SIGNATURES = {
     "rssync_ext_set_lbfgs_reeval": (C.c_int, [C.c_void_p, C.c_int]),
     "rssync_ext_lbfgs_best_not_last": (C.c_int, [C.c_void_p, _PU64]),
     "rssync_ext_set_host_loop": (C.c_int, [C.c_void_p, C.c_int]),
+    "rssync_ext_set_hook_device_loop": (C.c_int, [C.c_void_p, C.c_int]),
     "rssync_ext_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rssync_ext_set_devices": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     "rssync_ext_device_count": (C.c_int, [C.c_void_p]),
@@ -231,6 +232,10 @@ class SyncProblem:
     def set_host_loop(self, host_loop=True):
         """keep Sync's outer loop on the host (it runs on the device where one GPU holds all frames)"""
         self._lib.rssync_ext_set_host_loop(self._h, 1 if host_loop else 0)
+
+    def set_hook_device_loop(self, on=True):
+        """with a reduce hook: Sync's loop on the device, the hook called between the kernels on the window sums"""
+        self._lib.rssync_ext_set_hook_device_loop(self._h, 1 if on else 0)
 
     def lbfgs_best_not_last(self):
         n = C.c_uint64()

@@ -349,6 +349,7 @@ int rship_rccl_init(rship_ctx* c, const void*, int, int) { return fail(c, "rccl:
 int rship_rccl_allreduce(rship_ctx* c, double*, uint64_t) { return fail(c, "rccl: device only"); }
 int rship_rccl_shutdown(rship_ctx* c) { return fail(c, "rccl: device only"); }
 uint64_t rship_loop_exchanges(const rship_ctx*) { return 0; }
+int rship_set_loop_exchange(rship_ctx*, rship_loop_exchange_fn, void*) { return 0; }
 
 int rship_debug_rays(rship_ctx* c, uint32_t frame_index, float* a4, float* b4, uint32_t cap) {
     if (frame_index >= c->frames.size()) return fail(c, "debug_rays: index out of range");

@@ -833,3 +833,35 @@ def test_two_ranks_with_different_frame_sizes_pick_the_same_kernels(tmp_path):
         np.testing.assert_allclose(r["curve"], c, rtol=1e-13)
         assert r["sync"][1] == pytest.approx(ds, abs=1e-9) and r["iters"] == len(one.sync_trace())
     assert res[0]["sync"] == res[1]["sync"] and res[0]["curve"] == res[1]["curve"]
+
+
+def test_ranked_device_loop_with_two_ranks(tmp_path):
+    """with ranks, Sync's loop stays on the device -- window sums of this rank -> sum over the
+    ranks -> the decision kernels, on every rank.  Two ranks share this box's GPU (RCCL cannot: the sum travels through
+    the reduce hook over gloo, called between the kernels; with the library's communicator the same step is an
+    ncclAllReduce on the stream, test_rccl_reduce_hook_on_the_device).  Uneven frame split, windows that lie on one
+    rank only / on both / on none: every trace row equals the host loop's with the same hook, on both ranks, bit for
+    bit; and the exchanges are two per enqueued iteration instead of two to three blocking ones per iteration."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = [str(tmp_path / f"r{r}.json") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "gpu_rank_loop_worker.py"), str(r), "2", str(port), outs[r]])
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    res = [json.load(open(o)) for o in outs]
+    for r in res:
+        for key in ("sync", "trace", "cw", "dw", "wtr", "simplified", "simplified_trace"):
+            assert r["host"][key] == r["device"][key], key
+        assert len(r["device"]["trace"]) >= 5
+        its = len(r["device"]["trace"])
+        assert r["device"]["exchanges"] == 2 * min(14, -(-its // 8) * 8) + 1     # (explicit hint: no agreement exchange)
+    for key in ("sync", "trace", "cw", "dw", "wtr", "simplified"):
+        assert res[0]["device"][key] == res[1]["device"][key], key               # both ranks took the same decisions
