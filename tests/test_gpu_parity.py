@@ -628,8 +628,8 @@ def test_rccl_reduce_hook_on_the_device(tmp_path):
         assert r["plain" + k] == r["rccl" + k] == r["native" + k] == r["native_host" + k], k
     its = r["native"][4]
     # the size-class agreement + the final loss, and in between -- device loop: two all-reduces per ENQUEUED iteration
-    # (blocks of eight, at most max_outer_iters = 12); host loop: one per launch
-    assert r["native_sync_exchanges"] == 1 + 2 * min(12, -(-its // 8) * 8) + 1
+    # (a block of eight, then blocks of four); host loop: one per launch
+    assert r["native_sync_exchanges"] == 1 + 2 * _enqueued(its) + 1
     assert 1 + 2 * its + 1 <= r["native_host_sync_exchanges"] <= 1 + 3 * its + 1
     # PreSync: the size-class agreement + the sweep; Sync: the agreement + 2 per outer iteration + the final loss
     assert r["rccl_sync_exchanges"] == 1 + 2 * r["rccl"][4] + 1 and r["exchanges"] > r["rccl_sync_exchanges"]
@@ -835,6 +835,11 @@ def test_two_ranks_with_different_frame_sizes_pick_the_same_kernels(tmp_path):
     assert res[0]["sync"] == res[1]["sync"] and res[0]["curve"] == res[1]["curve"]
 
 
+def _enqueued(its):
+    """iterations rship_sync_run enqueues for a loop that ends after `its`: a block of eight, then blocks of four"""
+    return 8 if its <= 8 else 8 + 4 * -(-(its - 8) // 4)
+
+
 def test_ranked_device_loop_with_two_ranks(tmp_path):
     """with ranks, Sync's loop stays on the device -- window sums of this rank -> sum over the
     ranks -> the decision kernels, on every rank.  Two ranks share this box's GPU (RCCL cannot: the sum travels through
@@ -862,6 +867,6 @@ def test_ranked_device_loop_with_two_ranks(tmp_path):
             assert r["host"][key] == r["device"][key], key
         assert len(r["device"]["trace"]) >= 5
         its = len(r["device"]["trace"])
-        assert r["device"]["exchanges"] == 2 * min(14, -(-its // 8) * 8) + 1     # (explicit hint: no agreement exchange)
+        assert r["device"]["exchanges"] == 2 * _enqueued(its) + 1     # (explicit hint: no agreement exchange)
     for key in ("sync", "trace", "cw", "dw", "wtr", "simplified"):
         assert res[0]["device"][key] == res[1]["device"][key], key               # both ranks took the same decisions
