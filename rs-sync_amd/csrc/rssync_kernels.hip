@@ -1526,7 +1526,9 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     if (const char* e = std::getenv("RSSYNC_LOOP_FIRST_TRIALS")) { const int v = atoi(e); if (v >= 1 && v <= kMaxBt) nf_fixed = v; }
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
-    uint32_t waves = (uint32_t)n_cu * 8u; // what the chip holds at once (LDS: ~19 KB per wave); more would only idle
+    uint32_t per_cu = 8; // what the chip holds at once (LDS: ~19 KB per wave); more would only idle
+    if (const char* s = std::getenv("RSSYNC_EXEC_WAVES_PER_CU")) { const int v = atoi(s); if (v >= 1 && v <= 8) per_cu = (uint32_t)v; }
+    uint32_t waves = (uint32_t)n_cu * per_cu;
     if (waves > ns) waves = ns;
     // ring of {lap, slot} cells, several times the entries that can be outstanding (<= ns) plus the numbers idle waves
     // have claimed ahead (<= waves)
