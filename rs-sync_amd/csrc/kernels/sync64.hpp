@@ -299,6 +299,24 @@ struct Motion64Params {
     uint32_t scratch_rows;
 };
 
+// -DRSSYNC_K3_TIMING=1 (with -DRSSYNC_K2_COUNTERS=1, whose counter array it shares): core-clock ticks of wave 0 of
+// every workgroup of the motion kernel -- [10] inside evaluations, [11] evaluations, [12] whole L-BFGS, [13] frames
+// optimised, [14] prologue (rows of P, GuessMotion finish)   (tools/gpu_k3_timing.py)
+#ifndef RSSYNC_K3_TIMING
+#define RSSYNC_K3_TIMING 0
+#endif
+#if RSSYNC_K3_TIMING && RSSYNC_K2_COUNTERS
+#define K3_T0() const long long k3t0__ = clock64()
+#define K3_ACC(v) do { (v) += clock64() - k3t0__; } while (0) // into a register: one atomic per workgroup at the end
+#define K3_ADD(i, n) do { if (threadIdx.x == 0) { atomicAdd(&g_k2_counters[i], (unsigned long long)(clock64() - k3t0__)); if (n) atomicAdd(&g_k2_counters[n], 1ull); } } while (0)
+#define K3_FLUSH(ev) do { if (threadIdx.x == 0) { atomicAdd(&g_k2_counters[10], (unsigned long long)(ev).t_eval); atomicAdd(&g_k2_counters[11], (unsigned long long)(ev).evals); } } while (0)
+#else
+#define K3_T0() do { } while (0)
+#define K3_ACC(v) do { } while (0)
+#define K3_ADD(i, n) do { } while (0)
+#define K3_FLUSH(ev) do { } while (0)
+#endif
+
 constexpr int kInitNone = (int)0x80000000;
 constexpr int kNB = rs::kLbfgsBasis; // numBasis (ens::L_BFGS default)
 
@@ -313,14 +331,16 @@ struct MotionEval64 {
     int buf;
     double k2;
     int evals;
+    long long t_eval = 0; // (timing build)
 
     // loss and dL/dM at x (core_private.cpp:99-114 in closed form).  With u_j = (P_j.x)^2 / s, s = |x|^2 / k^2:
     //   dL/dx = t - (sum_j w_j u_j / s) 2x / k^2,   t = sum_j w_j (2 P_j.x / s) P_j,   w_j = 1 / (1 + u_j),
     // and x.t = 2 sum_j w_j u_j, so the second term is x (x.t) / |x|^2: the loss does not depend on |x|, its
     // gradient is t without its component along x -- four sums over the rows instead of five.
     __device__ __forceinline__ double operator()(const double x[3], double g[3]) {
-        double xx;
-        const double inv_s = rs::motion_inv_s(x, k2, &xx);
+        K3_T0();
+        double inv_xx;
+        const double inv_s = rs::motion_inv_s(x, k2, &inv_xx);
         double L = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
         if constexpr (RPT != 0) {
 #pragma unroll
@@ -350,7 +370,9 @@ struct MotionEval64 {
             buf ^= 1;
         }
         ++evals;
-        return rs::motion_finish(x, xx, t, g);
+        const double fv = rs::motion_finish(x, inv_xx, t, g);
+        K3_ACC(t_eval);
+        return fv;
     }
 };
 
@@ -505,7 +527,10 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
 
     LbfgsHistLds hist{s_S, s_Y, s_inv_ys, s_rho, s_alpha};
     int best_not_last = 0;
+    K3_T0();
     const int it = rs::lbfgs3(ev, hist, x, p.max_iters /* core_private.cpp:265 */, p.reeval, &best_not_last);
+    K3_ADD(12, 13);
+    K3_FLUSH(ev);
     if (tid == 0) {
         st_m<SC1>(&p.M[3 * sf], x[0]); st_m<SC1>(&p.M[3 * sf + 1], x[1]); st_m<SC1>(&p.M[3 * sf + 2], x[2]);
         if (p.stats) {

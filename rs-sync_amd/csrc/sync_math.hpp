@@ -65,17 +65,19 @@ RS_DEV void motion_row(d3 P, const double x[3], double inv_s, double& L, double&
     a1 = fma(a, P.y, a1);
     a2 = fma(a, P.z, a2);
 }
-// s = |x|^2 / k^2 of core_private.cpp:100-104 as its reciprocal
-RS_DEV double motion_inv_s(const double x[3], double k2, double* xx_out) {
+// s = |x|^2 / k^2 of core_private.cpp:100-104 as its reciprocal k^2 / |x|^2, and 1 / |x|^2 for motion_finish: two
+// independent divisions at the head of an evaluation.  (Round 2 divided three times in a row -- |x|^2 / k^2, its
+// reciprocal, and (x.t) / |x|^2 after the sums: an evaluation of a small frame is one chain of dependent fp64
+// operations, ~1 us in a single wave, and a division is a dozen links of it.)
+RS_DEV double motion_inv_s(const double x[3], double k2, double* inv_xx_out) {
     const double xx = dot3(x, x);
-    *xx_out = xx;
-    const double s = xx / k2;
-    return 1.0 / s;
+    *inv_xx_out = 1.0 / xx;
+    return k2 / xx;
 }
 // after the sums t = {L, t_x, t_y, t_z}: the loss does not depend on |x|, so its gradient is t without its
 // component along x  (x.t = 2 sum_j w_j u_j is exactly the sum the chain rule's second term needs)
-RS_DEV double motion_finish(const double x[3], double xx, const double t[4], double g[3]) {
-    const double tt = dot3(x, t + 1) / xx;
+RS_DEV double motion_finish(const double x[3], double inv_xx, const double t[4], double g[3]) {
+    const double tt = dot3(x, t + 1) * inv_xx;
     g[0] = fma(-tt, x[0], t[1]);
     g[1] = fma(-tt, x[1], t[2]);
     g[2] = fma(-tt, x[2], t[3]);

@@ -567,8 +567,8 @@ struct MotionEvalCpu {
     int evals = 0;
     double operator()(const double x[3], double g[3]) {
         const int threads = 64 * nw;
-        double xx;
-        const double inv_s = rs::motion_inv_s(x, k2, &xx);
+        double inv_xx;
+        const double inv_s = rs::motion_inv_s(x, k2, &inv_xx);
         std::vector<double> part[4];
         for (auto& v : part) v.assign((size_t)threads, 0.0);
         for (int t = 0; t < threads; ++t) {
@@ -579,7 +579,7 @@ struct MotionEvalCpu {
         double tsum[4];
         for (int q = 0; q < 4; ++q) tsum[q] = block_sum_order(part[q], nw);
         ++evals;
-        return rs::motion_finish(x, xx, tsum, g);
+        return rs::motion_finish(x, inv_xx, tsum, g);
     }
 };
 
