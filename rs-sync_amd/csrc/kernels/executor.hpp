@@ -150,45 +150,6 @@ __device__ __forceinline__ void exec_push(const ExecParams& p, uint32_t w, uint3
     }
 }
 
-// FrameState::Loss (and its analytic d/d-delay) of one slot at one delay by ONE wave, in the association of
-// loss64_kernel for frames of up to 256 tracks: thread t of that kernel's four waves holds row t, each wave is
-// summed by wave_sum_f64, the four wave sums are added left to right.  Mv, kk: the slot's motion estimate.
-template <bool GRAD>
-__device__ __forceinline__ void loss64_wave(const Loss64Params& q, uint32_t sf, d3 Mv, double kk, int kd, double fd, d4* s_win,
-                                            double& L_out, double& G_out) {
-    const int lane = threadIdx.x;
-    const FrameRec fr = q.frames[q.sel[sf]];
-    const uint32_t N = fr.n;
-    const double inv_s = rs::loss_inv_s(false, kk, Mv);
-    Spline64 sp;
-    sp.g = q.coef;
-    sp.n = q.n_knots;
-    __syncthreads(); // the window's previous users are done
-    frame_window64(sp, s_win, fr, kd);
-    __syncthreads();
-    const int base = fr.base_knot + kd;
-    double Lw[4], Gw[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        Lw[w] = 0.0;
-        Gw[w] = 0.0;
-        if ((uint32_t)w * 64u < N) { // (a wave without rows sums zeros to zero)
-            const uint32_t row = (uint32_t)w * 64u + lane;
-            double L = 0.0, G = 0.0;
-            if (row < N) {
-                const size_t idx = (size_t)fr.off + row;
-                d3 P, dP;
-                residual_row64<GRAD>(sp, q.rays.q0[idx], q.rays.q1[idx], q.rays.q2[idx], q.rays.q3[idx], base, fd, P, dP);
-                rs::loss_row<GRAD, false>(P, dP, Mv, inv_s, L, G);
-            }
-            Lw[w] = wave_sum_f64(L);
-            if (GRAD) Gw[w] = wave_sum_f64(G);
-        }
-    }
-    L_out = Lw[0] + Lw[1] + Lw[2] + Lw[3];
-    G_out = GRAD ? (Gw[0] + Gw[1] + Gw[2] + Gw[3]) * q.fs : 0.0;
-}
-
 constexpr uint32_t kExecStage = 1280; // doubles of LDS the decisions may use for a window's per-slot values (10 KB)
 
 // The window's sums of rows [0, rows) of part[] (only those in `mask`) in the plan's order (window_sums /

@@ -247,6 +247,69 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
     }
 }
 
+// FrameState::Loss (and its analytic d/d-delay) of one slot at one delay by ONE wave, in the association of
+// loss64_kernel for frames of up to 256 tracks: thread t of that kernel's four waves holds row t, each wave is
+// summed by wave_sum_f64, the four wave sums are added left to right.  Mv, kk: the slot's motion estimate.
+// (A frame of 130 tracks leaves two of the four waves of loss64_kernel's workgroup idle, and the workgroup holds its
+// registers all the same: three per CU.  One wave per slot puts four times as many slots on the chip; the window
+// executor evaluates its loss tasks this way too.)
+template <bool GRAD, bool SIMPLE = false>
+__device__ __forceinline__ void loss64_wave(const Loss64Params& q, uint32_t sf, d3 Mv, double kk, int kd, double fd, d4* s_win,
+                                            double& L_out, double& G_out) {
+    const int lane = threadIdx.x;
+    const FrameRec fr = q.frames[q.sel[sf]];
+    const uint32_t N = fr.n;
+    const double inv_s = rs::loss_inv_s(SIMPLE, kk, Mv);
+    Spline64 sp;
+    sp.g = q.coef;
+    sp.n = q.n_knots;
+    __syncthreads(); // the window's previous users are done
+    frame_window64(sp, s_win, fr, kd);
+    __syncthreads();
+    const int base = fr.base_knot + kd;
+    double Lw[4], Gw[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        Lw[w] = 0.0;
+        Gw[w] = 0.0;
+        if ((uint32_t)w * 64u < N) { // (a wave without rows sums zeros to zero)
+            const uint32_t row = (uint32_t)w * 64u + lane;
+            double L = 0.0, G = 0.0;
+            if (row < N) {
+                const size_t idx = (size_t)fr.off + row;
+                d3 P, dP;
+                residual_row64<GRAD>(sp, q.rays.q0[idx], q.rays.q1[idx], q.rays.q2[idx], q.rays.q3[idx], base, fd, P, dP);
+                rs::loss_row<GRAD, SIMPLE>(P, dP, Mv, inv_s, L, G);
+            }
+            Lw[w] = wave_sum_f64(L);
+            if (GRAD) Gw[w] = wave_sum_f64(G);
+        }
+    }
+    L_out = Lw[0] + Lw[1] + Lw[2] + Lw[3];
+    G_out = GRAD ? (Gw[0] + Gw[1] + Gw[2] + Gw[3]) * q.fs : 0.0;
+}
+
+// K1 for frames of up to 256 tracks: one WAVE per slot, the delays one after the other (same bits as loss64_kernel:
+// tests/test_gpu_mid_sizes.py::test_one_wave_loss_kernel_equals_the_workgroup_kernel)
+template <bool GRAD, bool SIMPLE>
+__global__ __launch_bounds__(64, 3) void loss64_small_kernel(Loss64Params p) {
+    __shared__ d4 s_win[4 * kWinMax];
+    const int lane = threadIdx.x;
+    const uint32_t sf = blockIdx.x + p.slot0;
+    const uint32_t g = p.grp ? p.grp[sf] : 0u;
+    const d3 Mv = SIMPLE ? d3{0.0, 0.0, 0.0} : d3{p.M[3 * sf], p.M[3 * sf + 1], p.M[3 * sf + 2]};
+    const double kk = p.k[sf];
+    for (uint32_t b = 0; b < p.n_delays; ++b) {
+        const double fd = p.fd[b * p.n_grp + g];
+        double Lv = 0.0, Gv = 0.0;
+        if (fd == fd) loss64_wave<GRAD, SIMPLE>(p, sf, Mv, kk, p.kd[b * p.n_grp + g], fd, s_win, Lv, Gv); // (NaN: switched off, zeros)
+        if (lane == 0) {
+            p.part_loss[(size_t)b * p.n_sel + sf] = Lv;
+            if (GRAD) p.part_grad[(size_t)b * p.n_sel + sf] = Gv;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K3: per-slot L-BFGS on the motion vector, P resident in registers in fp64.
 // Restates ens::L_BFGS as called at core_private.cpp:264-294 (MaxIterations 200,

@@ -110,6 +110,7 @@ struct rship_ctx {
     double fs = 0;
     int lbfgs_reeval = 0; // RSHIP_OPT_LBFGS_REEVAL
     uint32_t tracks_hint = 0; // RSHIP_OPT_TRACKS_HINT
+    bool no_small_loss = false;   // RSSYNC_NO_SMALL_LOSS=1 (A/B): frames of up to 256 tracks in the four-wave loss kernel
     bool no_motion_order = false; // RSSYNC_NO_MOTION_ORDER=1 (A/B): the motion kernel's workgroups in slot order, not longest-first
     bool exact_select = false;   // RSSYNC_K2_EXACT_SELECT=1 (read once, at creation): PreSync's tile kernel with round 2's exact
                                  // selection of every quartile instead of the lazy one (A/B tests: identical results)
@@ -312,6 +313,14 @@ int launch_loss64(rship_ctx* c, const Loss64Params& p, int rpt, hipStream_t st =
     if (!st) st = c->stream;
     if (!count) count = p.n_sel - p.slot0;
     ProfScope ps(c, GRAD ? RSHIP_K_LOSS_GRAD : RSHIP_K_LOSS);
+    // frames of up to 256 tracks (the reference's own: ~130): one wave per slot instead of a four-wave workgroup that
+    // half idles -- the same sums in the same order (loss64_wave), four times as many slots on the chip
+    const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
+    if (n_all <= 256u && !c->no_small_loss) {
+        hipLaunchKernelGGL((loss64_small_kernel<GRAD, SIMPLE>), dim3(count), dim3(64), 0, st, p);
+        RS_HIP(hipGetLastError());
+        return 0;
+    }
     switch (rpt) {
         case 0: hipLaunchKernelGGL((loss64_kernel<0, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
         case 1: hipLaunchKernelGGL((loss64_kernel<1, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
@@ -498,6 +507,7 @@ int rship_create(rship_ctx** out, int device) {
     if (const char* s = std::getenv("RSSYNC_NO_SMALL_LMEDS")) c->no_small_lmeds = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_K2_EXACT_SELECT")) c->exact_select = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_NO_MOTION_ORDER")) c->no_motion_order = s[0] && s[0] != '0';
+    if (const char* s = std::getenv("RSSYNC_NO_SMALL_LOSS")) c->no_small_loss = s[0] && s[0] != '0';
     if (device >= 0) {
         e = hipSetDevice(device);
         if (e != hipSuccess) { delete c; return 3; }

@@ -368,3 +368,39 @@ def test_one_wave_kernel_with_several_candidates_per_chunk(monkeypatch):
     assert same.mean() > 0.995
     np.testing.assert_allclose(fc[same], fco[same], rtol=3e-3)
     assert d[int(np.argmin(c))] == do[int(np.argmin(co))]
+
+
+@pytest.mark.parametrize("N", [40, 130, 256])
+def test_one_wave_loss_kernel_equals_the_workgroup_kernel(N, monkeypatch):
+    """Frames of up to 256 tracks: loss64_small_kernel evaluates a slot's loss / derivative with ONE wave in the
+    four-wave kernel's association (four times as many slots on the chip); RSSYNC_NO_SMALL_LOSS=1 keeps
+    loss64_kernel.  Loss, derivative, the five-delay batch with switched-off windows, simplified mode and whole Sync
+    traces: the same bits."""
+    import rssync_amd
+    from rssync_amd import synth
+    F = 24
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=33)
+    rng = np.random.default_rng(N)
+    frames = []
+    for fr in range(F):
+        n = N if fr % 3 else int(rng.integers(max(2, N // 2), N + 1))
+        frames += list(synth.make_frames(g, fr, fr + 1, n, seed=33))
+    res = []
+    for off in ("0", "1"):
+        monkeypatch.setenv("RSSYNC_NO_SMALL_LOSS", off)
+        p = rssync_amd.SyncProblem(seed=SEED, max_outer_iters=15)
+        p.SetGyroQuaternions(g.quats, g.fs, g.t0)
+        for fr in frames:
+            p.SetTrackResult(*fr)
+        p.init_motion(0.036, 0, F - 1)
+        delays = [0.036, 0.0371, 0.03, 0.0365, 0.04, 0.05, -0.02]
+        L, G = p.loss(delays, grad=True)
+        L5 = p.loss(delays)
+        cs = p.Sync(0.036, 0, F - 1, 0.0, 0.2)
+        tr = p.sync_trace()
+        cw, dw = p.sync_windows([0.036, 0.038, 0.03], [0, 10, 100], [13, 23, 120], 0.0, 0.2)
+        wtr = np.concatenate([p.window_trace(w) for w in range(2)])
+        ss = p.SyncSimplified(0.0355, 0, F - 1, 0.0, 0.1)
+        res.append((L, G, L5, np.array(cs), tr, cw, dw, wtr, np.array(ss), p.sync_trace()))
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
