@@ -41,8 +41,11 @@ def main():
         # several windows: [0, 20] lies on rank 0 alone, [28, 39] on rank 1 alone, [10, 35] on both, [100, 120] nowhere
         cw, dw = p.sync_windows([0.036, 0.037, 0.0365, 0.03], [0, 28, 10, 100], [20, 39, 35, 120], 0.0, 0.2)
         wtr = [p.window_trace(w).tolist() for w in range(4)]
+        one = p.Sync(0.0362, 0, 20, 0.0, 0.2)        # a single window none of whose frames rank 1 holds
+        one_tr = p.sync_trace().tolist()
         sc = p.SyncSimplified(0.0355, 0, F - 1, 0.0, 0.1)
         res[mode] = dict(sync=list(cs), trace=tr, exchanges=x1 - x0, cw=cw.tolist(), dw=dw.tolist(), wtr=wtr,
+                         one=list(one), one_trace=one_tr,
                          simplified=list(sc), simplified_trace=p.sync_trace().tolist())
     with open(out, "w") as f:
         json.dump(res, f)

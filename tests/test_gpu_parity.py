@@ -863,10 +863,11 @@ def test_ranked_device_loop_with_two_ranks(tmp_path):
         assert p.wait(timeout=300) == 0
     res = [json.load(open(o)) for o in outs]
     for r in res:
-        for key in ("sync", "trace", "cw", "dw", "wtr", "simplified", "simplified_trace"):
+        for key in ("sync", "trace", "cw", "dw", "wtr", "one", "one_trace", "simplified", "simplified_trace"):
             assert r["host"][key] == r["device"][key], key
         assert len(r["device"]["trace"]) >= 5
         its = len(r["device"]["trace"])
         assert r["device"]["exchanges"] == 2 * _enqueued(its) + 1     # (explicit hint: no agreement exchange)
-    for key in ("sync", "trace", "cw", "dw", "wtr", "simplified"):
+    for key in ("sync", "trace", "cw", "dw", "wtr", "one", "one_trace", "simplified"):
         assert res[0]["device"][key] == res[1]["device"][key], key               # both ranks took the same decisions
+    assert len(res[1]["device"]["one_trace"]) >= 3                               # (rank 1 held none of that window's frames)
