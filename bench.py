@@ -61,6 +61,10 @@ def parse_args(argv=None):
     ap.add_argument("--mode", default="ranks", choices=["ranks", "inproc"],
                     help="ranks: one process per GPU (self-spawned unless WORLD_SIZE is set); inproc: one object "
                          "driving all GPUs of this process")
+    ap.add_argument("--hook-device-loop", action="store_true",
+                    help="with --exchange torch: keep Sync's loop on the device and call the hook on the window sums "
+                         "between the kernels (the structure of the native RCCL path with a host transport; default: "
+                         "the host loop, one hook call per launch)")
     ap.add_argument("--exchange", default="native", choices=["native", "torch"],
                     help="multi-rank sums: the library's own RCCL communicator (default; nccl backend only), or "
                          "torch.distributed all_reduce through a reduce hook")
@@ -198,6 +202,8 @@ def run(args):
         if exchange != "native-rccl":
             prob.set_reduce_hook(make_reduce_hook(red_dev))
             exchange = "torch-%s-hook" % backend + ("" if exchange is None else " (native RCCL init failed: %s)" % exchange)
+            if args.hook_device_loop:
+                prob.set_hook_device_loop(True)
 
     def dev_sync():
         if on_gpu:
@@ -333,6 +339,8 @@ def run(args):
                           "doubles_per_step": x_doubles / max(args.steps, 1),
                           "sync_loop": ("device, window sums all-reduced on the stream (ncclAllReduce between the kernels)"
                                         if exchange == "native-rccl" else "device" if world == 1 and n_dev == 1 else
+                                        "device, the hook called on the window sums between the kernels (stream drained)"
+                                        if args.hook_device_loop and world > 1 and n_dev == 1 else
                                         "host, one exchange per launch"),
                           "note": "exchange = how the sums over frames cross process boundaries (none within one "
                                   "process: --mode inproc adds the devices' chunk sums on the host)"},
