@@ -15,6 +15,19 @@ __device__ unsigned long long g_k2_counters[16];
 #else
 #define K2_COUNT(i) do { } while (0)
 #endif
+// -DRSSYNC_K2_TIMING=1 (with the counters): per wave, core-clock ticks spent waiting at the candidate loop's
+// barriers [10] and in the whole kernel [11]; by barrier: tile written [12], directions ready [13], sweeps done [14],
+// the two workgroup sums of stage D [15]   (tools/gpu_k2_counters.py prints the raw array)
+#ifndef RSSYNC_K2_TIMING
+#define RSSYNC_K2_TIMING 0
+#endif
+#if RSSYNC_K2_TIMING && RSSYNC_K2_COUNTERS
+#define K2_SYNC(slot) do { const long long t__ = clock64(); __syncthreads(); const long long d__ = clock64() - t__; k2_bar += d__; k2_by[slot] += d__; } while (0)
+#define K2_TIMED(slot, expr) do { const long long t__ = clock64(); expr; const long long d__ = clock64() - t__; k2_bar += d__; k2_by[slot] += d__; } while (0)
+#else
+#define K2_SYNC(slot) __syncthreads()
+#define K2_TIMED(slot, expr) expr
+#endif
 // 0 (frame, candidate) pairs   1 queue pops   2 hypotheses swept   3 sweeps that beat the bound (exact selections)
 // 4 counting passes inside the exact selection   5 selections ended by the single-element min pass
 // 6 candidates redone without the provisional bound   7 sweeps that started without any bound (wave max)
@@ -381,6 +394,10 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     __shared__ uint32_t s_ncont;
     __shared__ unsigned long long s_exact;
     const int tid = threadIdx.x, lane = tid & 63;
+#if RSSYNC_K2_TIMING && RSSYNC_K2_COUNTERS
+    long long k2_bar = 0, k2_by[4] = {0, 0, 0, 0};
+    const long long k2_t0 = clock64();
+#endif
     // blocks b and b+8 share an XCD (round-robin dispatch): keep the chunks of one
     // frame on one XCD so its rays are fetched into one L2 only
     const uint32_t per = 8u * p.n_chunks;
@@ -514,13 +531,13 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
             if (tid == 0) { s_key = ((unsigned long long)guess << 32); s_ncont = 0; s_exact = ~0ull; }
             for (uint32_t batch = 0; batch < p.n_hyp; batch += kHyp) {
                 const uint32_t nb = (p.n_hyp - batch < (uint32_t)kHyp) ? p.n_hyp - batch : (uint32_t)kHyp;
-                __syncthreads(); // tile written / previous batch consumed
+                K2_SYNC(0); // tile written / previous batch consumed
                 if ((uint32_t)tid < nb) {
                     const f3 v = hypothesis(tile, p.seed, fr.id, stream, batch + tid, N);
                     s_hyp[tid] = f4{v.x, v.y, v.z, 0.f};
                 }
                 if (tid == 0) s_next = 0;
-                __syncthreads();
+                K2_SYNC(1);
                 for (;;) {
                     const uint32_t j = wave_pop(&s_next);
                     K2_COUNT(1);
@@ -579,7 +596,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                     }
                 }
             }
-            __syncthreads();
+            K2_SYNC(2);
             n_cont = s_ncont;
             if (guess == kInfBits || n_cont != 0u) break;
             guess = kInfBits; // nothing beat the provisional bound: redo this candidate without it
@@ -655,7 +672,8 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
             pm[j] = row < N ? v : 0.f;
             ss = fmaf(pm[j], pm[j], ss);
         }
-        double ss_tot = block_sum(ss, s_red[0]);
+        double ss_tot;
+        K2_TIMED(3, ss_tot = block_sum(ss, s_red[0]));
         // core_private.cpp:79, 100 / ||P M|| as 100 * rsq (v_rsq_f32, 1 ulp); ss = 0 gives +inf -> clamp
         float kf = 100.0f * rs::rsqrt_fast((float)ss_tot);
         kf = (kf < 10.f) ? 10.f : ((1000.f < kf) ? 1000.f : kf);
@@ -675,7 +693,8 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
             }
             if (!finite_f(rsum)) bad |= RSHIP_BAD_R;
             else if (!finite_f(acc)) bad |= RSHIP_BAD_RHO;
-            double acc_tot = block_sum(acc, s_red[1]);
+            double acc_tot;
+            K2_TIMED(3, acc_tot = block_sum(acc, s_red[1]));
             if (tid == 0) {
                 p.frame_cost[(size_t)c * p.n_sel + sf] = sqrt(acc_tot); // core_private.cpp:85
                 if (p.best_h) p.best_h[(size_t)c * p.n_sel + sf] = bH;
@@ -687,6 +706,13 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         // the workgroup sum barrier of stage D, which thread 0 has passed by then.  s_hyp, s_next
         // and the sum slots are rewritten only after further barriers of the next candidate.
     }
+#if RSSYNC_K2_TIMING && RSSYNC_K2_COUNTERS
+    if (lane == 0 && MODE == 0) {
+        atomicAdd(&g_k2_counters[10], (unsigned long long)k2_bar);
+        atomicAdd(&g_k2_counters[11], (unsigned long long)(clock64() - k2_t0));
+        for (int q = 0; q < 4; ++q) atomicAdd(&g_k2_counters[12 + q], (unsigned long long)k2_by[q]);
+    }
+#endif
 }
 
 } // namespace

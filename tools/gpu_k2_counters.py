@@ -35,3 +35,8 @@ names = ["frame_candidates", "queue_pops", "hypotheses_swept", "exact_selections
 out = {"frames": F, "tracks": N, "presync": [c, d], "raw": dict(zip(names, raw)),
        "per_frame_candidate": {n: raw[i] / pairs for i, n in enumerate(names)}}
 print(json.dumps(out, indent=1))
+if raw[11]:  # a -DRSSYNC_K2_TIMING=1 build: ticks of every wave waiting at the candidate loop's barriers
+    import sys as _s
+    _s.stderr.write(json.dumps({"barrier_share_of_wave_time": raw[10] / raw[11],
+                                "by_barrier": {"tile_written": raw[12] / raw[11], "directions_ready": raw[13] / raw[11],
+                                               "sweeps_done": raw[14] / raw[11], "stage_D_sums": raw[15] / raw[11]}}) + "\n")
