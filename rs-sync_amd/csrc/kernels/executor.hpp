@@ -333,11 +333,19 @@ __global__ __launch_bounds__(64) void sync_exec_kernel(ExecParams p) {
                 loss64_wave<false>(p.lo, slot, Mv, kk, ld_m<true>(&p.lg_kd[w]), ld_m<true>(&p.lg_fd[w]), lds.mo.win, Lv, Gv);
                 if (lane == 0) st_m<true>(&p.part[slot], Lv);
             } else {
+                // the window's ten trial delays in ONE round trip (lane i fetches trial i; a load past L1 takes ~1.5 us,
+                // and ten of them one after the other were most of a trial task)
+                double my_fd = __builtin_nan("");
+                int my_kd = 0;
+                if (lane < kMaxBt) {
+                    my_fd = ld_m<true>(&p.tr_fd[(size_t)lane * p.n_win + w]);
+                    my_kd = ld_m<true>(&p.tr_kd[(size_t)lane * p.n_win + w]);
+                }
                 for (int i = 0; i < kMaxBt; ++i) {
-                    const double fd = ld_m<true>(&p.tr_fd[(size_t)i * p.n_win + w]);
+                    const double fd = read_lane_d(my_fd, i);
                     if (fd != fd) continue; // not asked for
                     double Lv, Gv;
-                    loss64_wave<false>(p.lo, slot, Mv, kk, ld_m<true>(&p.tr_kd[(size_t)i * p.n_win + w]), fd, lds.mo.win, Lv, Gv);
+                    loss64_wave<false>(p.lo, slot, Mv, kk, __builtin_amdgcn_readlane(my_kd, i), fd, lds.mo.win, Lv, Gv);
                     if (lane == 0) st_m<true>(&p.part[(size_t)i * p.n_sel + slot], Lv);
                 }
             }
