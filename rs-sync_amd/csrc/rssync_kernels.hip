@@ -110,6 +110,7 @@ struct rship_ctx {
     double fs = 0;
     int lbfgs_reeval = 0; // RSHIP_OPT_LBFGS_REEVAL
     uint32_t tracks_hint = 0; // RSHIP_OPT_TRACKS_HINT
+    bool force_big = false;       // RSSYNC_FORCE_BIG=1 (tests): every frame through the kernels for frames of more than 8192 tracks
     bool no_small_loss = false;   // RSSYNC_NO_SMALL_LOSS=1 (A/B): frames of up to 256 tracks in the four-wave loss kernel
     bool no_motion_order = false; // RSSYNC_NO_MOTION_ORDER=1 (A/B): the motion kernel's workgroups in slot order, not longest-first
     bool exact_select = false;   // RSSYNC_K2_EXACT_SELECT=1 (read once, at creation): PreSync's tile kernel with round 2's exact
@@ -239,6 +240,7 @@ int rpt_for(uint32_t max_n) {
     return rpt;
 }
 uint32_t big_rows(const rship_ctx* c) { return (c->max_n + kBlock - 1) / kBlock * kBlock; }
+int rpt_of(const rship_ctx* c) { return c->force_big ? 0 : rpt_for(c->max_n); }
 
 uint32_t sel_max_n(const rship_ctx* c) {
     uint32_t m = 0;
@@ -252,7 +254,7 @@ int launch_lmeds(rship_ctx* c, const LmedsParams& p, int rpt, uint32_t grid) {
     // Frames of up to 256 tracks (the reference's own data: ~130): one wave per (frame, chunk) instead of a
     // four-wave workgroup (kernels/lmeds_small.hpp).  Decided from the largest frame of the whole PROBLEM, so that
     // a frame's cost does not depend on the selection or the device it is evaluated in.
-    const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
+    const uint32_t n_all = c->force_big ? 0xffffffffu : (c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n);
     if (n_all <= 64u * kSmallMaxRpt && !c->no_small_lmeds) {
         const uint32_t g1 = p.n_sel * p.n_chunks;
         switch ((n_all + 63u) / 64u) {
@@ -316,7 +318,7 @@ int launch_loss64(rship_ctx* c, const Loss64Params& p, int rpt, hipStream_t st =
     // frames of up to 256 tracks (the reference's own: ~130): one wave per slot instead of a four-wave workgroup that
     // half idles -- the same sums in the same order (loss64_wave), four times as many slots on the chip
     const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
-    if (n_all <= 256u && !c->no_small_loss) {
+    if (n_all <= 256u && !c->no_small_loss && !c->force_big) {
         hipLaunchKernelGGL((loss64_small_kernel<GRAD, SIMPLE>), dim3(count), dim3(64), 0, st, p);
         RS_HIP(hipGetLastError());
         return 0;
@@ -351,7 +353,10 @@ int launch_motion64(rship_ctx* c, const Motion64Params& p, hipStream_t st = null
     // many frames per CU this way.  Above that, four waves: with 8 / 16 waves (4 / 2 rows per thread at 2048
     // tracks) the launch took 7.8 / 12.4 ms per bench step instead of 4.75, and with two waves 5.15: the kernel is
     // bound by the work per evaluation, not by its slowest frame.
-    if (n <= 64) hipLaunchKernelGGL((opt_motion64_kernel<1, 1>), dim3(count), dim3(64), 0, st, p);
+    if (c->force_big) {
+        if (!p.scratch || p.scratch_rows < c->max_n) return set_err(c, "motion: no scratch for the large-frame kernel");
+        hipLaunchKernelGGL((opt_motion64_kernel<0, 4>), dim3(count), dim3(256), 0, st, p);
+    } else if (n <= 64) hipLaunchKernelGGL((opt_motion64_kernel<1, 1>), dim3(count), dim3(64), 0, st, p);
     else if (n <= 128) hipLaunchKernelGGL((opt_motion64_kernel<2, 1>), dim3(count), dim3(64), 0, st, p);
     else if (n <= 192) hipLaunchKernelGGL((opt_motion64_kernel<3, 1>), dim3(count), dim3(64), 0, st, p);
     else if (n <= 256) hipLaunchKernelGGL((opt_motion64_kernel<4, 1>), dim3(count), dim3(64), 0, st, p);
@@ -508,6 +513,7 @@ int rship_create(rship_ctx** out, int device) {
     if (const char* s = std::getenv("RSSYNC_K2_EXACT_SELECT")) c->exact_select = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_NO_MOTION_ORDER")) c->no_motion_order = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_NO_SMALL_LOSS")) c->no_small_loss = s[0] && s[0] != '0';
+    if (const char* s = std::getenv("RSSYNC_FORCE_BIG")) c->force_big = s[0] && s[0] != '0';
     if (device >= 0) {
         e = hipSetDevice(device);
         if (e != hipSuccess) { delete c; return 3; }
@@ -980,7 +986,7 @@ int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, uint
     uint32_t groups = (ns + 7) / 8;
     uint64_t grid = (uint64_t)groups * 8 * p.n_chunks;
     if (grid > 0x7fffffffull) return set_err(c, "presync: grid too large");
-    if (launch_lmeds<0, kWinMax>(c, p, rpt_for(c->max_n), (uint32_t)grid)) return 1;
+    if (launch_lmeds<0, kWinMax>(c, p, rpt_of(c), (uint32_t)grid)) return 1;
     if (launch_plan_sum(c, p.frame_cost, n_cand, ns)) return 1;
     size_t end = 0;
     if (queue_sums_to_host(c, n_cand, 0, &c->pend.off_chunk, &end)) return 1;
@@ -1021,7 +1027,7 @@ int fill_motion(rship_ctx* c, Motion64Params& p) {
     p.scratch = nullptr;
     p.scratch_rows = 0;
     const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
-    if (n_all > (uint32_t)kMaxRpt * kBlock) {
+    if (n_all > (uint32_t)kMaxRpt * kBlock || c->force_big) {
         const uint32_t rows = big_rows(c);
         if (ensure(c, c->mo_scratch, (size_t)(c->n_sel ? c->n_sel : 1) * 3 * rows * 8)) return 1;
         p.scratch = (double*)c->mo_scratch.p;
@@ -1097,7 +1103,7 @@ int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t
     p.best_h = (int32_t*)c->init_h.p;
     p.flags = (uint32_t*)c->flags.p;
     uint32_t groups = (c->n_sel + 7) / 8;
-    if (launch_lmeds<1, kWinMax>(c, p, rpt_for(c->max_n), groups * 8)) return 1;
+    if (launch_lmeds<1, kWinMax>(c, p, rpt_of(c), groups * 8)) return 1;
     c->init_pending = true;
     c->init_seed = seed;
     c->init_stream = stream;
@@ -1206,7 +1212,7 @@ int rship_loss_enqueue(rship_ctx* c, const int32_t* kd, const double* fd, uint32
     p.k = (const double*)c->k.p;
     p.part_loss = (double*)c->part.p;
     p.part_grad = p.part_loss + (size_t)n_delays * ns;
-    const int rpt = rpt_for(c->max_n);
+    const int rpt = rpt_of(c);
     int rc;
     if (simple) rc = want_grad ? launch_loss64<true, true>(c, p, rpt) : launch_loss64<false, true>(c, p, rpt);
     else rc = want_grad ? launch_loss64<true, false>(c, p, rpt) : launch_loss64<false, false>(c, p, rpt);
@@ -1356,7 +1362,7 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
     qp.M = (const double*)c->M.p;
     qp.k = (const double*)c->k.p;
     qp.part_loss = (double*)c->part.p;
-    const int rpt = rpt_for(c->max_n);
+    const int rpt = rpt_of(c);
 
     // the groups: windows [w0, w1) = slots [s0, s1), balanced by slots
     struct Group {

@@ -404,3 +404,51 @@ def test_one_wave_loss_kernel_equals_the_workgroup_kernel(N, monkeypatch):
         res.append((L, G, L5, np.array(cs), tr, cw, dw, wtr, np.array(ss), p.sync_trace()))
     for a, b in zip(*res):
         np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+
+
+@pytest.mark.parametrize("N,F,step", [(2048, 24, 0.002), (600, 32, 0.001)])
+def test_large_frame_kernels_against_the_regular_ones(N, F, step, monkeypatch):
+    """RSSYNC_FORCE_BIG=1 sends ordinary frames through the kernels written for frames of more than 8192 tracks
+    (lmeds_big_kernel, loss64_kernel<0>, opt_motion64_kernel<0, 4>).  Sync's fp64 side adds a frame's rows in the
+    same order in both families (256 threads, rows j * 256 + t in thread t): GuessK, losses, derivatives and optimised
+    motions are the same BITS.  The fp32 search differs only in how a row is computed (general spline path, true
+    reciprocal) -- the winning hypothesis of a (frame, candidate) pair is the same in > 99 % of the pairs, their costs
+    agree to 1e-4 and PreSync returns the same delay: the large-frame selection (order of hypotheses,
+    bisection, strict first-wins) is the tile kernel's."""
+    import rssync_amd
+    from rssync_amd import synth
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=61)
+    res = []
+    for big in ("0", "1"):
+        monkeypatch.setenv("RSSYNC_FORCE_BIG", big)
+        p = rssync_amd.SyncProblem(seed=SEED, max_outer_iters=10)
+        synth.fill(p, g, 0, F, N, seed=61)
+        dh, ch, fch, bhh = p.presync_curve(0.0, 0, F, step, 0.1, per_frame=F)
+        ps = p.PreSync(0.0, 0, F, step, 0.1)
+        p.record_init_winners()
+        M0, k0 = p.init_motion(0.036, 0, F - 1)
+        win = p.last_init_winners()
+        res.append(dict(dh=dh, ch=ch, fch=fch, bhh=bhh, ps=ps, M0=M0, k0=k0, win=win, p=p))
+    a, b = res
+    np.testing.assert_array_equal(a["dh"], b["dh"])
+    same = a["bhh"] == b["bhh"]
+    assert same.mean() > 0.99, same.mean()
+    rel = np.abs(a["fch"] - b["fch"]) / a["fch"]
+    assert rel[same].max() < 1e-4 and np.median(rel[same]) < 1e-6
+    np.testing.assert_allclose(a["ch"], b["ch"], rtol=2e-3)   # (a flipped near-tie moves one frame's cost)
+    assert a["ps"][1] == b["ps"][1]
+    # fp64 side: from the same winners, the same bits
+    same_f = np.flatnonzero(a["win"] == b["win"])
+    assert same_f.size >= F - 1
+    np.testing.assert_array_equal(a["M0"][same_f], b["M0"][same_f])
+    np.testing.assert_array_equal(a["k0"][same_f], b["k0"][same_f])
+    b["p"].set_motion(a["M0"], a["k0"])            # continue both from the regular run's state
+    a["p"].set_motion(a["M0"], a["k0"])
+    delays = [0.036, 0.0371, 0.03, 0.0365, 0.05]
+    for q in (a, b):
+        q["L"], q["G"] = q["p"].loss(delays, grad=True)
+        q["L5"] = q["p"].loss(delays)
+        q["M1"], q["k1"], q["it"], q["ev"] = q["p"].opt_motion(0.0365)
+    for key in ("L", "G", "L5", "M1", "k1"):
+        np.testing.assert_array_equal(a[key], b[key])
+    assert (a["it"], a["ev"]) == (b["it"], b["ev"])
