@@ -262,12 +262,15 @@ class SyncProblemHip final : public ISyncProblem {
     std::vector<int32_t> last_init_winners, init_override;
     void exchange_init_winners();
     uint32_t sync_calls = 0;
-    // RSSYNC_EXECUTOR=1: frames of up to 256 tracks run Sync's calls of all windows as ONE device-scheduled launch
-    // (kernels/executor.hpp) instead of the chain of launches.  Same bits; measured at parity with the chain on the
-    // reference's workload (33 against 30 ms, profiles/r3_syncpoints.json), so the chain stays the default.
-    bool use_executor = false;
+    // Frames of up to 256 tracks run Sync's calls of all windows as ONE device-scheduled launch (kernels/executor.hpp)
+    // instead of the chain of launches: the same bits, 27-28 ms against 30-35 on the reference's workload
+    // (profiles/r3_syncpoints.json).  RSSYNC_EXECUTOR=0 keeps the chain.  If the executor ever gives up (its
+    // watchdog), the call is redone by the chain -- same values -- and this object stays with the chain.
+    bool use_executor = true;
+    bool executor_warned_ = false;
+    bool executor_test_fail_ = false; // RSSYNC_EXECUTOR_FAIL=1 (tests): pretend it gave up
     bool executor_ok(bool simplified);
-    void sync_exec(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl, const std::vector<double>& initial,
+    bool sync_exec(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl, const std::vector<double>& initial,
                    double search_center, double search_radius, int repeats, uint32_t stream_first, uint32_t stream_stride,
                    std::vector<double>& costs, std::vector<double>& delays_out);
     bool host_loop = false; // keep Sync's outer loop on the host even where the device could run it (tests)
@@ -335,6 +338,7 @@ SyncProblemHip::SyncProblemHip() {
     if (const char* s = std::getenv("RSSYNC_QUIET")) verbose = !(s[0] && s[0] != '0');
     if (const char* s = std::getenv("RSSYNC_HOST_LOOP")) host_loop = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_EXECUTOR")) use_executor = s[0] && s[0] != '0';
+    if (const char* s = std::getenv("RSSYNC_EXECUTOR_FAIL")) executor_test_fail_ = s[0] && s[0] != '0';
     // RSSYNC_GPUS: how many GPUs this object spreads its frames over ("4" = devices 0..3) or which
     // ("0,2,5"); default: the calling thread's current device only
     std::vector<int> ids;
@@ -1244,8 +1248,10 @@ bool SyncProblemHip::executor_ok(bool simplified) {
     return true;
 }
 
-// `repeats` chained Sync calls on the selected windows in one launch; fills traces (all calls' rows per window)
-void SyncProblemHip::sync_exec(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl,
+// `repeats` chained Sync calls on the selected windows in one launch; fills traces (all calls' rows per window).
+// false: the executor gave up (its watchdog, an allocation) -- nothing the caller hands out has been touched, the
+// chain of launches takes over from the same inputs and returns the same values.
+bool SyncProblemHip::sync_exec(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl,
                                const std::vector<double>& initial, double search_center, double search_radius, int repeats,
                                uint32_t stream_first, uint32_t stream_stride, std::vector<double>& costs,
                                std::vector<double>& delays_out) {
@@ -1255,17 +1261,27 @@ void SyncProblemHip::sync_exec(const std::vector<int64_t>& begins, const std::ve
     const uint32_t rows = (uint32_t)repeats * (uint32_t)max_outer;
     std::vector<double> tr((size_t)W * rows * 6, 0.0);
     std::vector<int32_t> its(W * (size_t)repeats, 0);
-    costs.assign(W, 0.0);
-    delays_out.assign(W, 0.0);
-    hip_check(sh, rship_sync_exec(sh.ctx, initial.data(), repeats, stream_first, stream_stride, seed, max_outer, search_center,
-                                  search_radius, delays_out.data(), costs.data(), its.data(), tr.data(), rows),
-              "sync executor");
+    std::vector<double> c_out(W, 0.0), d_out(W, 0.0);
+    if (executor_test_fail_ ||
+        rship_sync_exec(sh.ctx, initial.data(), repeats, stream_first, stream_stride, seed, max_outer, search_center,
+                        search_radius, d_out.data(), c_out.data(), its.data(), tr.data(), rows)) {
+        if (!executor_warned_) {
+            std::cerr << "rssync: window executor: " << (executor_test_fail_ ? "switched off by RSSYNC_EXECUTOR_FAIL" : rship_last_error(sh.ctx))
+                      << " -- continuing with the launch chain" << std::endl;
+            executor_warned_ = true;
+        }
+        use_executor = false;
+        return false;
+    }
+    costs = c_out;
+    delays_out = d_out;
     traces.assign(W, {});
     for (size_t w = 0; w < W; ++w) {
         size_t n = 0;
         for (int r = 0; r < repeats; ++r) n += (size_t)its[w * repeats + r];
         traces[w].assign(tr.begin() + w * (size_t)rows * 6, tr.begin() + (w * (size_t)rows + n) * 6);
     }
+    return true;
 }
 
 void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl,
@@ -1275,10 +1291,10 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
     ensure_device();
     const size_t W = begins.size();
     select_windows(begins, ends_incl);
-    if (executor_ok(simplified)) {
+    if (executor_ok(simplified) &&
         // frames of up to 256 tracks: the search, the loop and the final loss of every window as one launch
         sync_exec(begins, ends_incl, initial, search_center, search_radius, 1, kStreamSyncInit + sync_calls, call_stride, costs,
-                  delays_out);
+                  delays_out)) {
         if (call_stride == 1) sync_calls += (uint32_t)W;
         if (verbose && W == 1) { // :330, the lines the host loop would have written
             int conv = 0;
@@ -1527,9 +1543,8 @@ void SyncProblemHip::sync_points(const std::vector<int64_t>& positions, int64_t 
         // call the moment it has finished the previous one
         ensure_device();
         select_windows(positions, ends);
-        if (executor_ok(false)) {
-            sync_exec(positions, ends, d, initial_delay, radius, repeats, kStreamSyncInit + first_call, (uint32_t)repeats, costs,
-                      delays_out);
+        if (executor_ok(false) && sync_exec(positions, ends, d, initial_delay, radius, repeats, kStreamSyncInit + first_call,
+                                            (uint32_t)repeats, costs, delays_out)) {
             sync_calls = first_call + (uint32_t)(W * (size_t)repeats);
             return;
         }

@@ -1,7 +1,7 @@
 """The window executor (kernels/executor.hpp: Sync for frames of up to 256 tracks as ONE device-scheduled launch --
 tasks (window, phase, frame) pulled from a queue by persistent waves, windows advancing independently, a sync
-point's four calls chained per window; opt-in with RSSYNC_EXECUTOR=1, read when a problem is created) against the
-chain of launches: the same task bodies, sums and decisions, so the SAME BITS -- delays, costs, every trace row."""
+point's four calls chained per window; the default for such frames, RSSYNC_EXECUTOR=0 -- read when a problem is
+created -- keeps the chain) against the chain of launches: the same task bodies, sums and decisions, so the SAME BITS -- delays, costs, every trace row."""
 import os
 
 import numpy as np
@@ -12,12 +12,12 @@ pytestmark = pytest.mark.gpu
 
 def _two(**kw):
     import rssync_amd
-    os.environ["RSSYNC_EXECUTOR"] = "1"
+    a = rssync_amd.SyncProblem(**kw)          # the executor (default)
+    os.environ["RSSYNC_EXECUTOR"] = "0"
     try:
-        a = rssync_amd.SyncProblem(**kw)
+        b = rssync_amd.SyncProblem(**kw)      # the chain of launches
     finally:
         del os.environ["RSSYNC_EXECUTOR"]
-    b = rssync_amd.SyncProblem(**kw)
     return a, b
 
 
@@ -105,3 +105,29 @@ def test_sync_points_four_chained_calls(built, monkeypatch, first_trials):
             d = ch3.Sync(d, p0, p0 + window, 0.0, 0.1)[1]
         seq3.append(d)
     np.testing.assert_array_equal(_bits(dd), _bits(seq3))
+
+
+def test_the_chain_takes_over_if_the_executor_gives_up(monkeypatch, capfd):
+    """RSSYNC_EXECUTOR_FAIL=1 makes the executor report failure (as its watchdog would): the call is redone by the
+    chain of launches from the same inputs -- same values, one line on stderr -- and the object stays with the chain"""
+    import rssync_amd
+    from rssync_amd import synth
+    F, N = 30, 100
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=4)
+    frames = list(synth.make_frames(g, 0, F, N, seed=4))
+    monkeypatch.setenv("RSSYNC_EXECUTOR_FAIL", "1")
+    a = rssync_amd.SyncProblem(seed=7, max_outer_iters=12)
+    monkeypatch.delenv("RSSYNC_EXECUTOR_FAIL")
+    monkeypatch.setenv("RSSYNC_EXECUTOR", "0")
+    b = rssync_amd.SyncProblem(seed=7, max_outer_iters=12)
+    _fill((a, b), g, frames)
+    pos = [0, 5, 10]
+    ra = a.sync_points(pos, 15, 0.0, 0.002, 0.1)
+    rb = b.sync_points(pos, 15, 0.0, 0.002, 0.1)
+    np.testing.assert_array_equal(_bits(ra[1]), _bits(rb[1]))
+    np.testing.assert_array_equal(_bits(ra[0]), _bits(rb[0]))
+    for w in range(len(pos)):
+        np.testing.assert_array_equal(_bits(a.window_trace(w)), _bits(b.window_trace(w)))
+    assert a.Sync(0.036, 0, F - 1, 0.0, 0.2) == b.Sync(0.036, 0, F - 1, 0.0, 0.2)
+    err = capfd.readouterr().err
+    assert err.count("continuing with the launch chain") == 1

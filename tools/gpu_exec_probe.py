@@ -3,7 +3,6 @@ RSSYNC_LIB=rs-sync_amd/_variants/lib_execstats.so, prints wave-time per activity
 python tools/gpu_exec_probe.py [windows]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["RSSYNC_EXECUTOR"] = "1"
 import numpy as np
 import rssync_amd
 from rssync_amd import synth

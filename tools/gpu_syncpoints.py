@@ -31,6 +31,7 @@ def loop(h):
     return np.array(out)
 
 
+os.environ["RSSYNC_EXECUTOR"] = "0"    # seq / bat / hostloop: the chain of launches
 seq, bat = problem(), problem()
 loop(seq); bat.sync_points(pos, WINDOW, 0.0, 0.001, 0.1)    # warm-up (also advances both streams equally)
 t = time.perf_counter(); ds = loop(seq); t_seq = time.perf_counter() - t
@@ -41,9 +42,9 @@ loop(seq)
 bat.profile(True); bat.profile_reset()
 t = time.perf_counter(); bat.sync_points(pos, WINDOW, 0.0, 0.001, 0.1); t_prof = time.perf_counter() - t
 prof = bat.profile_get()
-os.environ["RSSYNC_EXECUTOR"] = "1"    # the window executor (opt-in): one device-scheduled launch for all calls of all windows
-execp = problem()
 del os.environ["RSSYNC_EXECUTOR"]
+execp = problem()                      # the window executor (default for frames of up to 256 tracks)
+os.environ["RSSYNC_EXECUTOR"] = "0"
 execp.sync_points(pos, WINDOW, 0.0, 0.001, 0.1)
 t = time.perf_counter(); _, de = execp.sync_points(pos, WINDOW, 0.0, 0.001, 0.1); t_exec = time.perf_counter() - t
 hostloop = problem(); hostloop.set_host_loop(True)
