@@ -110,6 +110,16 @@ __device__ __forceinline__ void split32_dev(double delay, double fs, int32_t* kd
 // with eight waves per CU), and per task that was 20x the task (this file's first version: 232 ms for the workload
 // the launch chain does in 30).
 
+// How an idle wave waits: it re-reads its cell every RSSYNC_EXEC_SLEEP x 64 cycles and looks at the two counters that
+// only atomics change (windows done, abort) every RSSYNC_EXEC_POLL_MASK + 1 reads.  With a thousand idle waves the
+// atomic reads compete with the working waves' own atomics (the phase counters, the queue's head and tail): every 8th
+// read, 27.6 ms for the 98 sync points; every 16th, 24.1 (profiles/r3_executor_stats.txt).
+#ifndef RSSYNC_EXEC_POLL_MASK
+#define RSSYNC_EXEC_POLL_MASK 1023
+#endif
+#ifndef RSSYNC_EXEC_SLEEP
+#define RSSYNC_EXEC_SLEEP 16
+#endif
 __device__ __forceinline__ uint32_t exec_pop(const ExecParams& p) {
     uint32_t idx = 0;
     if (threadIdx.x == 0) idx = __hip_atomic_fetch_add(p.q_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -120,33 +130,35 @@ __device__ __forceinline__ uint32_t exec_pop(const ExecParams& p) {
         const unsigned long long v = ld_m<true>(cell);
         const uint32_t v_lap = uniform_u32((uint32_t)(v >> 32)), v_slot = uniform_u32((uint32_t)v);
         if (v_lap == lap) return v_slot;
-        if ((spins & 7u) == 7u) {
-            uint32_t dn = 0, ab = 0;
-            if (threadIdx.x == 0) {
-                dn = __hip_atomic_fetch_add(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ab = __hip_atomic_fetch_add(p.abort_flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (uniform_u32(dn) >= p.n_win) return 0xffffffffu;
-            if (uniform_u32(ab)) return 0xffffffffu;
+        if ((spins & (uint32_t)RSSYNC_EXEC_POLL_MASK) == (uint32_t)RSSYNC_EXEC_POLL_MASK) { // (lanes 0 and 1 read one counter each: one round trip)
+            uint32_t v2 = 0;
+            if (threadIdx.x < 2) v2 = __hip_atomic_fetch_add(threadIdx.x == 0 ? p.done : p.abort_flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t dn = (uint32_t)__builtin_amdgcn_readlane((int)v2, 0), ab = (uint32_t)__builtin_amdgcn_readlane((int)v2, 1);
+            if (dn >= p.n_win) return 0xffffffffu;
+            if (ab) return 0xffffffffu;
             if (spins > p.spin_limit) {
                 if (threadIdx.x == 0) __hip_atomic_fetch_add(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return 0xffffffffu;
             }
         }
-        __builtin_amdgcn_s_sleep(16);
+        __builtin_amdgcn_s_sleep(RSSYNC_EXEC_SLEEP);
     }
 }
 
 // the window's slots as tasks of its (already stored) next phase
-__device__ __forceinline__ void exec_push(const ExecParams& p, uint32_t w, uint32_t slot0, uint32_t n_slots) {
+// (a cell's low word: the task's phase in the top byte -- the consumer need not fetch the window's record to learn
+// it -- and the slot below; slots are < 2^24, checked by the launcher)
+__device__ __forceinline__ void exec_push(const ExecParams& p, uint32_t w, uint32_t slot0, uint32_t n_slots, int phase) {
     if (threadIdx.x == 0) st_m<true>(&p.win[w].remaining, n_slots);
-    wait_stores(); // the window's new state, its delays and its counter before its tasks
+    // the numbers of the new entries are reserved while the window's new state, its delays and its counter drain:
+    // one wait for both, and only then the cells
     uint32_t base = 0;
     if (threadIdx.x == 0) base = __hip_atomic_fetch_add(p.q_tail, n_slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    wait_stores();
     base = uniform_u32(base);
     for (uint32_t i = threadIdx.x; i < n_slots; i += 64) {
         const uint32_t e = base + i;
-        st_m<true>(p.q + (e & p.q_mask), ((unsigned long long)((e >> p.q_shift) + 1u) << 32) | (slot0 + i));
+        st_m<true>(p.q + (e & p.q_mask), ((unsigned long long)((e >> p.q_shift) + 1u) << 32) | ((uint32_t)phase << 24) | (slot0 + i));
     }
 }
 
@@ -283,10 +295,23 @@ __device__ __forceinline__ void exec_decide(const ExecParams& p, uint32_t w, Exe
     exec_store_win(&p.win[w], L);
     if (finished) {
         wait_stores();
-        if (lane == 0) __hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t before = 0;
+        if (lane == 0) before = __hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (uniform_u32(before) + 1u == p.n_win) {
+            // the last window: one end marker per wave of the launch (every wave takes exactly one and leaves), so
+            // that idle waves need not poll the "windows done" counter
+            const uint32_t n = gridDim.x;
+            uint32_t base = 0;
+            if (lane == 0) base = __hip_atomic_fetch_add(p.q_tail, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            base = uniform_u32(base);
+            for (uint32_t i = lane; i < n; i += 64) {
+                const uint32_t e = base + i;
+                st_m<true>(p.q + (e & p.q_mask), ((unsigned long long)((e >> p.q_shift) + 1u) << 32) | 0xffffffffull);
+            }
+        }
         return;
     }
-    exec_push(p, w, slot0, n_slots);
+    exec_push(p, w, slot0, n_slots, L->phase);
 }
 
 // LDS of one executor wave: the search's tile and fp32 window, the fp64 window and L-BFGS history; the decisions
@@ -311,19 +336,20 @@ __global__ __launch_bounds__(64) void sync_exec_kernel(ExecParams p) {
             EXEC_ADD(6, 14);
         }
         if (slot == 0xffffffffu) break;
+        const int ph = (int)(slot >> 24); // (the cell carries the phase: exec_push)
+        slot &= 0x00ffffffu;
         const uint32_t w = p.grp[slot];
-        const int ph = ld_m<true>(&p.win[w].phase);
         EXEC_T0();
         if (ph == kPhInit) {
             lmeds_small_body<RPT, 1, true>(p.init, slot, 0u, lds.small);
         } else if (ph == kPhMotion) {
-            opt_motion64_body<RPT, 1, true>(p.mo, slot, lds.mo);
-            // the frame's loss and derivative at x0 with the motion estimate just found (the wave's own stores: it
-            // waits for them and reads them back past L1)
-            wait_stores();
-            const d3 Mv = d3{ld_m<true>(&p.lo.M[3 * slot]), ld_m<true>(&p.lo.M[3 * slot + 1]), ld_m<true>(&p.lo.M[3 * slot + 2])};
+            // the frame's loss and derivative at x0 with the motion estimate just found (handed over in registers:
+            // the values the body has stored)
+            double mk[4];
+            opt_motion64_body<RPT, 1, true>(p.mo, slot, lds.mo, mk);
+            const d3 Mv = d3{mk[0], mk[1], mk[2]};
             double Lv, Gv;
-            loss64_wave<true>(p.lo, slot, Mv, ld_m<true>(&p.lo.k[slot]), ld_m<true>(&p.lg_kd[w]), ld_m<true>(&p.lg_fd[w]), lds.mo.win, Lv, Gv);
+            loss64_wave<true>(p.lo, slot, Mv, mk[3], ld_m<true>(&p.lg_kd[w]), ld_m<true>(&p.lg_fd[w]), lds.mo.win, Lv, Gv);
             if (lane == 0) { st_m<true>(&p.part[slot], Lv); st_m<true>(&p.part[(size_t)p.n_sel + slot], Gv); }
         } else if (ph == kPhTrials || ph == kPhFinal) {
             const d3 Mv = d3{ld_m<true>(&p.lo.M[3 * slot]), ld_m<true>(&p.lo.M[3 * slot + 1]), ld_m<true>(&p.lo.M[3 * slot + 2])};

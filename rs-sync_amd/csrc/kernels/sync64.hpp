@@ -480,7 +480,7 @@ struct MotionLds {
 };
 
 template <int RPT, int NW, bool SC1 = false> // SC1: M, k, the pending winners and the delays are written by other workgroups of this launch
-__device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint32_t sf, MotionLds<NW>& lds) {
+__device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint32_t sf, MotionLds<NW>& lds, double* mk_out = nullptr) {
     constexpr int kThreads = 64 * NW;
     d4* s_win = lds.win;
     double (*s_part)[NW][4] = lds.part;
@@ -497,8 +497,14 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
     const uint32_t grp = p.grp ? p.grp[sf] : 0u;
     const int kd = ld_m<SC1>(&p.kd[grp]);
     const double fd = ld_m<SC1>(&p.fd[grp]);
+    // (everything the slot may need from memory is requested at once: with SC1 a load is a round trip of ~1.5 us, and
+    // the branches below would put three of them one after the other)
+    const int pend = p.init_h ? ld_m<SC1>(&p.init_h[sf]) : kInitNone;
+    const double m_x = ld_m<SC1>(&p.M[3 * sf]), m_y = ld_m<SC1>(&p.M[3 * sf + 1]), m_z = ld_m<SC1>(&p.M[3 * sf + 2]);
+    const double m_k = ld_m<SC1>(&p.k[sf]);
     if (fd != fd) { // this window is not being optimised in this call (workgroup-uniform)
         if (tid == 0 && p.evals_out) p.evals_out[sf] = 0;
+        if (mk_out) { mk_out[0] = m_x; mk_out[1] = m_y; mk_out[2] = m_z; mk_out[3] = m_k; } // (what memory holds)
         return;
     }
 
@@ -539,7 +545,6 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
 
     double x[3];
     double kk;
-    const int pend = p.init_h ? ld_m<SC1>(&p.init_h[sf]) : kInitNone;
     if (p.simple_k || pend != kInitNone) {
         // GuessMotion's winner recomputed in fp64, then GuessK (core_private.cpp:125-133)
         d3 Mv = d3{0, 0, 0};
@@ -582,9 +587,10 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
             if (p.init_h) st_m<SC1>(&p.init_h[sf], (int32_t)kInitNone);
         }
     } else {
-        x[0] = ld_m<SC1>(&p.M[3 * sf]); x[1] = ld_m<SC1>(&p.M[3 * sf + 1]); x[2] = ld_m<SC1>(&p.M[3 * sf + 2]);
-        kk = ld_m<SC1>(&p.k[sf]);
+        x[0] = m_x; x[1] = m_y; x[2] = m_z;
+        kk = m_k;
     }
+    if (mk_out) { mk_out[0] = x[0]; mk_out[1] = x[1]; mk_out[2] = x[2]; mk_out[3] = kk; }
     if (p.max_iters <= 0 || p.simple_k) return;
     ev.k2 = kk * kk;
 
@@ -594,6 +600,7 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
     const int it = rs::lbfgs3(ev, hist, x, p.max_iters /* core_private.cpp:265 */, p.reeval, &best_not_last);
     K3_ADD(12, 13);
     K3_FLUSH(ev);
+    if (mk_out) { mk_out[0] = x[0]; mk_out[1] = x[1]; mk_out[2] = x[2]; }
     if (tid == 0) {
         st_m<SC1>(&p.M[3 * sf], x[0]); st_m<SC1>(&p.M[3 * sf + 1], x[1]); st_m<SC1>(&p.M[3 * sf + 2], x[2]);
         if (p.stats) {

@@ -1522,7 +1522,7 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
 // trace[W][trace_rows][6] (trace_rows >= repeats * max_outer).  Window w samples call r with stream_first + r + w * stride.
 int rship_exec_supported(rship_ctx* c) {
     const uint32_t n = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
-    return n >= 2 && n <= 64u * kSmallMaxRpt ? 1 : 0;
+    return n >= 2 && n <= 64u * kSmallMaxRpt && c->n_sel < (1u << 24) ? 1 : 0; // (a queue cell holds the slot in 24 bits)
 }
 
 int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream_first, uint32_t stream_stride, uint64_t seed,
@@ -1593,7 +1593,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
             in_fd[w] = f;
         }
     }
-    for (uint32_t j = 0; j < ns; ++j) queue[j] = (1ull << 32) | j; // lap 1
+    for (uint32_t j = 0; j < ns; ++j) queue[j] = (1ull << 32) | ((unsigned long long)kPhInit << 24) | j; // lap 1, the search
     const uint32_t ctl[4] = {0u /* head */, ns /* tail */, 0u /* done */, 0u /* abort */};
     RS_HIP(hipMemcpyAsync(base + o_win, hw.data(), W * sizeof(ExecWin), hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipMemcpyAsync(base + o_inkd, in_kd.data(), W * 4, hipMemcpyHostToDevice, c->stream));
@@ -1638,7 +1638,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     ep.q_tail = ep.q_head + 1;
     ep.done = ep.q_head + 2;
     ep.abort_flag = ep.q_head + 3;
-    ep.spin_limit = 1u << 23; // ~ seconds of polling an empty queue: something is wrong
+    ep.spin_limit = 1u << 21; // ~ 5-10 s of polling an empty queue: something is wrong
     // GuessMotion's search (fp32, one wave per frame)
     ep.init.rays_a = (const f4*)c->rays_a.p;
     ep.init.rays_b = (const f4*)c->rays_b.p;
