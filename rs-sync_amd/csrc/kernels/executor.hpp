@@ -113,7 +113,8 @@ __device__ __forceinline__ void split32_dev(double delay, double fs, int32_t* kd
 // How an idle wave waits: it re-reads its cell every RSSYNC_EXEC_SLEEP x 64 cycles and looks at the two counters that
 // only atomics change (windows done, abort) every RSSYNC_EXEC_POLL_MASK + 1 reads.  With a thousand idle waves the
 // atomic reads compete with the working waves' own atomics (the phase counters, the queue's head and tail): every 8th
-// read, 27.6 ms for the 98 sync points; every 16th, 24.1 (profiles/r3_executor_stats.txt).
+// read, 27.6 ms for the 98 sync points; every 16th, 24.1; every 256th, 21.4 (profiles/r3_executor_stats.txt) -- so the
+// "done" counter is not polled at all (end markers, exec_decide) and the abort flag every 1024th read.
 #ifndef RSSYNC_EXEC_POLL_MASK
 #define RSSYNC_EXEC_POLL_MASK 1023
 #endif

@@ -263,7 +263,7 @@ class SyncProblemHip final : public ISyncProblem {
     void exchange_init_winners();
     uint32_t sync_calls = 0;
     // Frames of up to 256 tracks run Sync's calls of all windows as ONE device-scheduled launch (kernels/executor.hpp)
-    // instead of the chain of launches: the same bits, 27-28 ms against 30-35 on the reference's workload
+    // instead of the chain of launches: the same bits, 21 ms against 30-35 on the reference's workload
     // (profiles/r3_syncpoints.json).  RSSYNC_EXECUTOR=0 keeps the chain.  If the executor ever gives up (its
     // watchdog), the call is redone by the chain -- same values -- and this object stays with the chain.
     bool use_executor = true;
