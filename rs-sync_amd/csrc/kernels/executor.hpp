@@ -127,16 +127,24 @@ __device__ __forceinline__ uint32_t exec_pop(const ExecParams& p) {
     idx = uniform_u32(idx);
     const unsigned long long* cell = p.q + (idx & p.q_mask);
     const uint32_t lap = (idx >> p.q_shift) + 1u;
+    uint32_t seen_tail = 0xffffffffu;
     for (uint32_t spins = 0;; ++spins) {
         const unsigned long long v = ld_m<true>(cell);
         const uint32_t v_lap = uniform_u32((uint32_t)(v >> 32)), v_slot = uniform_u32((uint32_t)v);
         if (v_lap == lap) return v_slot;
-        if ((spins & (uint32_t)RSSYNC_EXEC_POLL_MASK) == (uint32_t)RSSYNC_EXEC_POLL_MASK) { // (lanes 0 and 1 read one counter each: one round trip)
-            uint32_t v2 = 0;
-            if (threadIdx.x < 2) v2 = __hip_atomic_fetch_add(threadIdx.x == 0 ? p.done : p.abort_flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t dn = (uint32_t)__builtin_amdgcn_readlane((int)v2, 0), ab = (uint32_t)__builtin_amdgcn_readlane((int)v2, 1);
-            if (dn >= p.n_win) return 0xffffffffu;
+        if ((spins & (uint32_t)RSSYNC_EXEC_POLL_MASK) == (uint32_t)RSSYNC_EXEC_POLL_MASK) {
+            // rarely (every ~2 ms): the counters that only atomics change, lanes 0..2 one each in one round trip
+            uint32_t v3 = 0;
+            if (threadIdx.x < 3)
+                v3 = __hip_atomic_fetch_add(threadIdx.x == 0 ? p.done : (threadIdx.x == 1 ? p.abort_flag : p.q_tail), 0u, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t dn = (uint32_t)__builtin_amdgcn_readlane((int)v3, 0), ab = (uint32_t)__builtin_amdgcn_readlane((int)v3, 1),
+                           tl = (uint32_t)__builtin_amdgcn_readlane((int)v3, 2);
+            if (dn >= p.n_win) return 0xffffffffu; // (normally the end marker arrives first)
             if (ab) return 0xffffffffu;
+            // the watchdog measures the time since the last PUSH by anybody, not this wave's own wait: one long
+            // window at the end of a large run keeps every other wave idle for as long as it takes
+            if (tl != seen_tail) { seen_tail = tl; spins = 0; }
             if (spins > p.spin_limit) {
                 if (threadIdx.x == 0) __hip_atomic_fetch_add(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return 0xffffffffu;
