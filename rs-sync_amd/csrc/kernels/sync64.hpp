@@ -29,8 +29,13 @@ struct Spline64 {
     const d4* lds;            // [4][kWinMax]
     int n;
     int w0, wlen;
-    int path; // kPathGlobal / kPathInterior, uniform over the workgroup
+    int path; // kPathGlobal / kPathLds64 / kPathInterior, uniform over the workgroup
 };
+
+// the general parameter logic (extrapolation branches) with the coefficients from the LDS window: a delay that puts a
+// frame partly or wholly beyond the gyro track -- a line search's first trials are seconds away -- touches only knots
+// of the CLAMPED range, which is what gets staged (round 3: those delays read the table from L2, 15-35 % slower)
+constexpr int kPathLds64 = 1;
 
 __device__ __forceinline__ void stage_window64(Spline64& s, d4* s_win, int lo, int hi) {
     const int n = s.n;
@@ -38,7 +43,7 @@ __device__ __forceinline__ void stage_window64(Spline64& s, d4* s_win, int lo, i
     lo = lo < 0 ? 0 : (lo > n - 1 ? n - 1 : lo);
     hi = hi < 0 ? 0 : (hi > n - 1 ? n - 1 : hi);
     int wlen = hi - lo + 1;
-    s.path = (wlen <= kWinMax && interior) ? kPathInterior : kPathGlobal;
+    s.path = wlen <= kWinMax ? (interior ? kPathInterior : kPathLds64) : kPathGlobal;
     if (wlen > kWinMax) wlen = kWinMax;
     s.w0 = lo;
     s.wlen = wlen;
@@ -93,6 +98,7 @@ template <bool DERIV>
 __device__ __forceinline__ void residual_row64(const Spline64& s, double2 X, double2 Y, double2 Z, double2 T, int base, double fd,
                                                d3& P, d3& dP) {
     if (s.path == kPathInterior) residual_row64<DERIV, kPathInterior>(s, X, Y, Z, T, base, fd, P, dP);
+    else if (s.path == kPathLds64) residual_row64<DERIV, kPathLds64>(s, X, Y, Z, T, base, fd, P, dP);
     else residual_row64<DERIV, kPathGlobal>(s, X, Y, Z, T, base, fd, P, dP);
 }
 template <bool DERIV>
