@@ -1,3 +1,5 @@
+"""K1 (five delays per launch) at 2048 x 2048: launch time for delays that keep the frames inside the gyro track and
+for delays that put them (far) outside it.  python tools/gpu_k1_delays_probe.py  (GPU box)"""
 import os, sys, json
 sys.path.insert(0, os.getcwd())
 import numpy as np, rssync_amd
