@@ -32,7 +32,8 @@ namespace {
 #define RSSYNC_EXEC_STATS 0
 #endif
 #if RSSYNC_EXEC_STATS
-__device__ unsigned long long g_exec_stats[16]; // 0-4 task phases, 5 decide, 6 pop (waiting included), 8+ph task counts, 13 decides, 14 pops
+__device__ unsigned long long g_exec_stats[48]; // [16+ph] wall ticks of a window's phases (tasks pushed -> last task done), [32+ph] their number
+__device__ unsigned long long g_exec_tlast[4096]; // 0-4 task phases, 5 decide, 6 pop (waiting included), 8+ph task counts, 13 decides, 14 pops
 #define EXEC_T0() const unsigned long long t0__ = __builtin_amdgcn_s_memrealtime()
 #define EXEC_ADD(i, n) do { if (threadIdx.x == 0) { atomicAdd(&g_exec_stats[i], __builtin_amdgcn_s_memrealtime() - t0__); atomicAdd(&g_exec_stats[n], 1ull); } } while (0)
 #else
@@ -226,9 +227,21 @@ __device__ __forceinline__ void exec_store_win(ExecWin* dst, const ExecWin* lds_
 __device__ __forceinline__ void exec_decide(const ExecParams& p, uint32_t w, ExecWin* L, double* stage) {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x;
+#if RSSYNC_EXEC_STATS
+    const unsigned long long t_dec__ = __builtin_amdgcn_s_memrealtime();
+#endif
     exec_load_win(&p.win[w], L);
     SyncWin& s = L->s;
     const int ph = L->phase;
+#if RSSYNC_EXEC_STATS
+    if (lane == 0 && w < 4096u) {
+        const unsigned long long tl = ld_m<true>(&g_exec_tlast[w]); // (written by a wave of another XCD: past L1 / L2)
+        if (tl) {
+            atomicAdd(&g_exec_stats[16 + ph], t_dec__ - tl);
+            atomicAdd(&g_exec_stats[32 + ph], 1ull);
+        }
+    }
+#endif
     const uint32_t slot0 = L->slot0, n_slots = L->n_slots;
     bool finished = false;
     if (ph == kPhInit) {
@@ -321,6 +334,9 @@ __device__ __forceinline__ void exec_decide(const ExecParams& p, uint32_t w, Exe
         return;
     }
     exec_push(p, w, slot0, n_slots, L->phase);
+#if RSSYNC_EXEC_STATS
+    if (lane == 0 && w < 4096u) st_m<true>(&g_exec_tlast[w], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 // LDS of one executor wave: the search's tile and fp32 window, the fp64 window and L-BFGS history; the decisions

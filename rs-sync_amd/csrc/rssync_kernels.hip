@@ -1698,15 +1698,20 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     if (sync_stream(c)) return 1;
 #if RSSYNC_EXEC_STATS
     {
-        unsigned long long st[16];
+        unsigned long long st[48];
         RS_HIP(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_exec_stats), sizeof(st)));
-        const unsigned long long zero[16] = {};
+        const unsigned long long zero[48] = {};
         RS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_exec_stats), zero, sizeof(zero)));
+        std::vector<unsigned long long> zl(4096, 0ull);
+        RS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_exec_tlast), zl.data(), zl.size() * 8));
         const char* nm[7] = {"init", "motion", "grad", "trials", "final", "decide", "pop"};
         const int cnt[7] = {8, 9, 10, 11, 12, 13, 14};
         for (int i = 0; i < 7; ++i)
             fprintf(stderr, "exec %-7s %9llu x  %10.3f ms wave-time  (%.2f us each)\n", nm[i], st[cnt[i]], st[i] * 1e-5,
                     st[cnt[i]] ? st[i] * 1e-2 / st[cnt[i]] : 0.0);
+        for (int ph = 0; ph < 5; ++ph) // a window's phases on the wall clock: its tasks pushed -> its last task done
+            if (st[32 + ph])
+                fprintf(stderr, "exec phase %-7s %9llu x  %.2f us each (wall)\n", nm[ph], st[32 + ph], st[16 + ph] * 1e-2 / st[32 + ph]);
     }
 #endif
     if (h_ctl[3]) {
