@@ -67,8 +67,8 @@ RS_DEV void motion_row(d3 P, const double x[3], double inv_s, double& L, double&
 }
 // s = |x|^2 / k^2 of core_private.cpp:100-104 as its reciprocal k^2 / |x|^2, and 1 / |x|^2 for motion_finish: two
 // independent divisions at the head of an evaluation.  (Round 2 divided three times in a row -- |x|^2 / k^2, its
-// reciprocal, and (x.t) / |x|^2 after the sums: an evaluation of a small frame is one chain of dependent fp64
-// operations, ~1 us in a single wave, and a division is a dozen links of it.)
+// reciprocal, and (x.t) / |x|^2 after the sums; a division is a dozen fp64 instructions of the ~300 of a small
+// frame's evaluation.)
 RS_DEV double motion_inv_s(const double x[3], double k2, double* inv_xx_out) {
     const double xx = dot3(x, x);
     *inv_xx_out = 1.0 / xx;
