@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""What rounding-level differences do to Sync on noisy data -- a pure CPU measurement.
+"""What rounding-level differences do to Sync on noisy data -- a pure CPU measurement, per scene of tests/noisy_scenes.py.
 
 Two implementations of the same algorithm on the same inputs, started from the SAME motion estimates (GuessMotion's
 winning hypotheses are transplanted, so the fp32/fp64 search plays no part):
@@ -13,7 +13,11 @@ log1p).  On noise-free scenes that is 1e-11 s; on the reference's own workload s
 tracks, 1e-3 rad noise, 10 % outliers) the per-frame L-BFGS turns it into other basins for some frames.  Control:
 the reference-order oracle against itself started 1e-9 s away.
 
-    python tests/measure/reassociation.py > profiles/r3_reassociation.json
+The file this writes is what the tests' tolerances are read from (noisy_scenes.bound_s), and
+tests/test_reassociation.py::test_the_measurement_file_is_current recomputes two scenes and demands the same numbers:
+re-run after ANY change to sync_math.hpp / device_math.hpp / the stand-in / the oracle.
+
+    python tests/measure/reassociation.py > profiles/r4_reassociation.json
 """
 import ctypes
 import json
@@ -25,10 +29,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-import rssync_amd  # noqa: E402
-from rssync_amd import synth  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import noisy_scenes as ns  # noqa: E402
 from rssync_amd.problem import bind  # noqa: E402
-from oracle.oracle import OracleProblem  # noqa: E402
 
 
 def hosttest():
@@ -39,54 +42,42 @@ def hosttest():
     return bind(ctypes.CDLL(out))
 
 
-def stats(x):
-    x = np.abs(np.asarray(x, float))
-    return {"median": float(np.median(x)), "p90": float(np.percentile(x, 90)), "max": float(x.max())}
+def measure(scene, lib):
+    dev, ora, ctl = scene.device(lib), scene.oracle(), scene.oracle()
+    recs = ns.run_scene(scene, dev, ora, control=ctl)
+    first = []
+    trace_d = 0.0
+    for r in recs:
+        td, to = r["trace_dev"], r["trace_ora"]
+        # the first outer iteration, before anything has been amplified: loss and derivative at the look-ahead point
+        first.append([abs(td[0, 2] - to[0, 2]) / abs(to[0, 2]), abs(td[0, 3] - to[0, 3]) / max(abs(to[0, 3]), 1e-300)])
+        n = min(len(td), len(to))
+        trace_d = max(trace_d, float(np.abs(td[:n, 0] - to[:n, 0]).max()))
+    first = np.asarray(first)
+    return {
+        "what": (scene.__doc__ or "").strip(),
+        "calls": len(recs), "frames_per_call": scene.calls[0][2] - scene.calls[0][1] + 1, "tracks": int(len(scene.frames[0][1])),
+        "max_outer_iters": scene.max_outer_iters,
+        "device_order_minus_reference_order_s": ns.stats([r["d_dev"] - r["d_ora"] for r in recs]),
+        "control_reference_order_started_1e-9_s_away_s": ns.stats([r["d_ctl"] - r["d_ora"] for r in recs]),
+        "delay_after_each_outer_iteration_max_abs_s": trace_d,
+        "cost_rel": float(max(abs(r["c_dev"] - r["c_ora"]) / abs(r["c_ora"]) for r in recs)),
+        "first_iteration_loss_rel": float(first[:, 0].max()), "first_iteration_derivative_rel": float(first[:, 1].max()),
+        "outer_iterations": {"device_order": [len(r["trace_dev"]) for r in recs], "reference_order": [len(r["trace_ora"]) for r in recs]},
+        "delays_s": {"device_order": [r["d_dev"] for r in recs], "reference_order": [r["d_ora"] for r in recs]},
+    }
 
 
 def main():
     lib = hosttest()
-    out = {"what": __doc__.split("\n")[0], "scenes": {}}
-    for name, kw, F, N, window, n_win in (
-            ("reference_workload_noisy", {}, 400, 130, 60, 24),
-            ("config1_noisy", {}, 64, 256, 63, 1),
-            ("reference_workload_clean", {"noise": 0.0, "outliers": 0.0}, 200, 130, 60, 8)):
-        gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=31)
-        frames = list(synth.make_frames(gyro, 0, F, N, seed=31, **kw))
-        dev = rssync_amd.SyncProblem(seed=99, max_outer_iters=400, _lib=lib)
-        ora = OracleProblem(seed=99, max_outer_iters=400, threads=os.cpu_count() or 1, faithful=False)
-        ora2 = OracleProblem(seed=99, max_outer_iters=400, threads=os.cpu_count() or 1, faithful=False)
-        for p in (dev, ora, ora2):
-            p.SetGyroQuaternions(gyro.quats, gyro.fs, gyro.t0)
-            for fr in frames:
-                p.SetTrackResult(*fr)
-        d_dev, d_ora, d_ctl, it_dev, it_ora, first_rows = [], [], [], [], [], []
-        for w in range(n_win):
-            b = w * ((F - window - 1) // max(n_win - 1, 1)) if n_win > 1 else 0
-            e = b + window
-            d0 = ora.PreSync(0.0, b, e, 0.002, 0.1)[1]
-            co, do, tro = ora.sync_trace(d0, b, e, 0.0, 0.1)
-            win = ora.last_init_winners()
-            ora2.set_init_override(win)
-            c2, d2, tr2 = ora2.sync_trace(d0 + 1e-9, b, e, 0.0, 0.1)
-            dev.set_init_override(win)
-            cd, dd = dev.Sync(d0, b, e, 0.0, 0.1)
-            trd = dev.sync_trace()
-            d_dev.append(dd - do)
-            d_ctl.append(d2 - do)
-            d_ora.append(do)
-            it_dev.append(len(trd))
-            it_ora.append(len(tro))
-            # the first outer iteration, before anything has been amplified: loss and derivative at the look-ahead point
-            first_rows.append([abs(trd[0, 2] - tro[0, 2]) / abs(tro[0, 2]), abs(trd[0, 3] - tro[0, 3]) / max(abs(tro[0, 3]), 1e-300)])
-        fr_ = np.asarray(first_rows)
-        out["scenes"][name] = {
-            "frames_per_window": window + 1, "tracks": N, "windows": n_win,
-            "device_order_minus_reference_order_s": stats(d_dev),
-            "control_reference_order_started_1e-9_s_away_s": stats(d_ctl),
-            "first_iteration_loss_rel": float(fr_[:, 0].max()), "first_iteration_derivative_rel": float(fr_[:, 1].max()),
-            "outer_iterations": {"device_order": it_dev, "reference_order": it_ora},
-        }
+    out = {"what": __doc__.split("\n")[0], "north_star_s": ns.NORTH_STAR_S, "scenes": {}}
+    for name, make in ns.SCENES.items():
+        scene = make()
+        scene.__doc__ = make.__doc__ if make.__doc__ else (ns.big_frames.__doc__ if name.startswith("big_") else "")
+        out["scenes"][name] = measure(scene, lib)
+        m = out["scenes"][name]["device_order_minus_reference_order_s"]["max"]
+        out["scenes"][name]["asserted_bound_s"] = ns.NORTH_STAR_S if m < ns.NORTH_STAR_S else 2.5 * m
+        print(name, out["scenes"][name]["device_order_minus_reference_order_s"], file=sys.stderr, flush=True)
     print(json.dumps(out, indent=1))
 
 

@@ -88,20 +88,27 @@ def _check_product(h, gold):
     dd, dc = h.DebugPreSync(0.0, f0, f0 + F, 0.1, 9)
     np.testing.assert_array_equal(dd, gold["debug_delays"])
     np.testing.assert_allclose(dc, gold["debug_costs"], rtol=5e-3)
-    # Sync from the stored PreSync result against the stored trace (24 x 128, noise + outliers): the fp64
-    # Sync path follows the CPU solver within the north-star 1e-4 s at every outer iteration
+    # Sync from the stored PreSync result against the stored trace (24 x 128, noise + outliers).  A noisy scene: the
+    # optimiser amplifies rounding differences.  What the device computes is bit-identical to the CPU stand-in in
+    # device order (tests/test_gpu_bitexact.py); stand-in and reference-order oracle differ by the reassociation
+    # scatter measured per scene in profiles/r4_reassociation.json -- on THIS scene 1.8e-5 s, so the north-star
+    # 1e-4 s is what is asserted (tests/noisy_scenes.py).  Both start from the oracle's GuessMotion winners.
+    import noisy_scenes as ns
+    scene = ns.golden_noisy()
+    m = ns.measured(scene.name)
+    o = scene.oracle()
+    c2o, d2o, tro = o.sync_trace(float(gold["presync_result"][1]), f0, f0 + F - 1, 0.0, 0.1)
+    np.testing.assert_allclose(tro, gold["sync_trace"], rtol=1e-9, atol=1e-12)   # (the oracle still reproduces the fixture)
+    h.set_init_override(o.last_init_winners())
     c2, d2 = h.Sync(float(gold["presync_result"][1]), f0, f0 + F - 1, 0.0, 0.1)
     tr = h.sync_trace()
-    # noisy scene: the optimiser amplifies rounding differences.  What the device computes is bit-identical to the CPU
-    # stand-in in device order (tests/test_gpu_bitexact.py); stand-in and reference-order oracle differ by the
-    # reassociation scatter measured in profiles/r3_reassociation.json (0.1 ms median, 0.44 ms max on such windows).
-    # Loose here, tight on the noise-free scene below.
-    assert abs(d2 - gold["sync_result"][1]) < 3e-4
-    assert c2 == pytest.approx(gold["sync_result"][0], rel=5e-3)
-    assert abs(len(tr) - len(gold["sync_trace"])) <= 3
+    assert ns.bound_s(scene.name) == ns.NORTH_STAR_S
+    assert abs(d2 - gold["sync_result"][1]) < ns.bound_s(scene.name)
+    assert d2 == pytest.approx(m["delays_s"]["device_order"][0], rel=0, abs=1e-9)   # = the CPU stand-in's result
+    assert c2 == pytest.approx(gold["sync_result"][0], rel=2.5 * m["cost_rel"])
+    assert [len(tr)] == m["outer_iterations"]["device_order"]
     n = min(len(tr), len(gold["sync_trace"]))
-    np.testing.assert_allclose(tr[:n, 0], gold["sync_trace"][:n, 0], atol=5e-4)
-    np.testing.assert_allclose(tr[:n, 2], gold["sync_trace"][:n, 2], rtol=1e-2)
+    np.testing.assert_allclose(tr[:n, 0], gold["sync_trace"][:n, 0], atol=2.5 * m["delay_after_each_outer_iteration_max_abs_s"])
     # noise-free scene: every outer iteration of Sync (and of the simplified mode) follows the stored trace
     hc = type(h)(seed=int(gold["seed"]), _lib=h._lib)
     hc.SetGyroQuaternions(gold["clean_gyro_quats"], float(gold["clean_gyro_fs"]), float(gold["clean_gyro_t0"]))
