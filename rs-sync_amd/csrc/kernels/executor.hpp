@@ -20,8 +20,8 @@
 // evaluated by one wave), sums and decisions are the same functions.  tests/test_gpu_executor.py: identical bits.
 //
 // Termination: tasks never wait for other tasks, so every pushed task ends; a wave leaves when all windows are done
-// (or a watchdog has tripped: a wave that polls an empty queue spin_limit times raises the abort flag, everybody
-// leaves, the host reports the failure).  A grid larger than the chip holds is harmless: the workgroups that are
+// (or a watchdog has tripped: a wave that waits for a task while nobody has pushed one for watchdog_ticks of the
+// constant 100 MHz clock -- 5 s -- raises the abort flag, everybody leaves, the host reports the failure).  A grid larger than the chip holds is harmless: the workgroups that are
 // resident can finish everything by themselves.
 #pragma once
 
@@ -84,7 +84,8 @@ struct ExecParams {
     uint32_t* q_head; uint32_t* q_tail;
     uint32_t* done;                  // windows finished
     uint32_t* abort_flag;
-    uint32_t spin_limit;
+    // (head, tail, done and abort each sit on a 128-byte line of their own: rship_sync_exec)
+    unsigned long long watchdog_ticks; // s_memrealtime ticks (100 MHz) without a push by anybody before a waiting wave gives up
 };
 
 // host split_delay (sync_problem.cpp) on the device: delay * fs = kd + fd, fd in [0, 1) as fp32
@@ -129,6 +130,7 @@ __device__ __forceinline__ uint32_t exec_pop(const ExecParams& p) {
     const unsigned long long* cell = p.q + (idx & p.q_mask);
     const uint32_t lap = (idx >> p.q_shift) + 1u;
     uint32_t seen_tail = 0xffffffffu;
+    unsigned long long t_push = __builtin_amdgcn_s_memrealtime(); // when the tail was last seen to move (or this wait began)
     for (uint32_t spins = 0;; ++spins) {
         const unsigned long long v = ld_m<true>(cell);
         const uint32_t v_lap = uniform_u32((uint32_t)(v >> 32)), v_slot = uniform_u32((uint32_t)v);
@@ -143,10 +145,12 @@ __device__ __forceinline__ uint32_t exec_pop(const ExecParams& p) {
                            tl = (uint32_t)__builtin_amdgcn_readlane((int)v3, 2);
             if (dn >= p.n_win) return 0xffffffffu; // (normally the end marker arrives first)
             if (ab) return 0xffffffffu;
-            // the watchdog measures the time since the last PUSH by anybody, not this wave's own wait: one long
-            // window at the end of a large run keeps every other wave idle for as long as it takes
-            if (tl != seen_tail) { seen_tail = tl; spins = 0; }
-            if (spins > p.spin_limit) {
+            // the watchdog measures the TIME since the last PUSH by anybody (the constant 100 MHz clock, not a number of
+            // polls whose length depends on the load), not this wave's own wait: one long window at the end of a large
+            // run keeps every other wave idle for as long as it takes
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (tl != seen_tail) { seen_tail = tl; t_push = now; }
+            if (now - t_push > p.watchdog_ticks) {
                 if (threadIdx.x == 0) __hip_atomic_fetch_add(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return 0xffffffffu;
             }

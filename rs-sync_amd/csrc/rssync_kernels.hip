@@ -1556,7 +1556,12 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     const size_t o_inkd = take(W * 4), o_infd = take(W * 4), o_stream = take(W * 4);
     const size_t o_mokd = take(W * 4), o_mofd = take(W * 8), o_lgkd = take(W * 4), o_lgfd = take(W * 8);
     const size_t o_trkd = take((size_t)kMaxBt * W * 4), o_trfd = take((size_t)kMaxBt * W * 8);
-    const size_t o_q = take((size_t)q_cap * 8), o_ctl = take(64);
+    // the four control words -- queue head, queue tail, windows done, abort flag -- each on a 128-byte line of its own:
+    // every pop adds to the head, every push to the tail, and the idle waves' (rare) looks at done / abort / tail
+    // would otherwise all land on the line the working waves' atomics are queued on (MI355X_MICROARCH.md, atomics:
+    // one contended line is served serially)
+    constexpr size_t kCtlStride = 128;
+    const size_t o_q = take((size_t)q_cap * 8), o_ctl = take(4 * kCtlStride);
     const size_t o_trace = take((size_t)W * trace_rows * 48);
     if (ensure(c, c->loop_state, off) || ensure(c, c->part, (size_t)2 * kMaxBt * ns * 8) || ensure(c, c->flags, 16)) return 1;
     char* base = (char*)c->loop_state.p;
@@ -1594,7 +1599,8 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
         }
     }
     for (uint32_t j = 0; j < ns; ++j) queue[j] = (1ull << 32) | ((unsigned long long)kPhInit << 24) | j; // lap 1, the search
-    const uint32_t ctl[4] = {0u /* head */, ns /* tail */, 0u /* done */, 0u /* abort */};
+    uint32_t ctl[4 * kCtlStride / 4] = {};
+    ctl[kCtlStride / 4] = ns; // head 0, tail ns, done 0, abort 0
     RS_HIP(hipMemcpyAsync(base + o_win, hw.data(), W * sizeof(ExecWin), hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipMemcpyAsync(base + o_inkd, in_kd.data(), W * 4, hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipMemcpyAsync(base + o_infd, in_fd.data(), W * 4, hipMemcpyHostToDevice, c->stream));
@@ -1635,10 +1641,14 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     ep.q_mask = q_cap - 1;
     ep.q_shift = q_shift;
     ep.q_head = (uint32_t*)(base + o_ctl);
-    ep.q_tail = ep.q_head + 1;
-    ep.done = ep.q_head + 2;
-    ep.abort_flag = ep.q_head + 3;
-    ep.spin_limit = 1u << 21; // ~ 5-10 s of polling an empty queue: something is wrong
+    ep.q_tail = (uint32_t*)(base + o_ctl + kCtlStride);
+    ep.done = (uint32_t*)(base + o_ctl + 2 * kCtlStride);
+    ep.abort_flag = (uint32_t*)(base + o_ctl + 3 * kCtlStride);
+    // the watchdog: nobody has pushed anything for this long (s_memrealtime ticks, 100 MHz) while a wave waits for a
+    // task -- something is wrong.  (The longest task is one frame's 200-iteration L-BFGS: milliseconds.)
+    double wd_s = 5.0;
+    if (const char* s = std::getenv("RSSYNC_EXEC_WATCHDOG_S")) { const double v = atof(s); if (v > 0.0 && v < 600.0) wd_s = v; }
+    ep.watchdog_ticks = (unsigned long long)(wd_s * 1e8);
     // GuessMotion's search (fp32, one wave per frame)
     ep.init.rays_a = (const f4*)c->rays_a.p;
     ep.init.rays_b = (const f4*)c->rays_b.p;
@@ -1694,7 +1704,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     if (ensure_pinned(c, W * sizeof(ExecWin) + 64)) return 1;
     uint32_t* h_ctl = (uint32_t*)((char*)c->pinned + W * sizeof(ExecWin));
     RS_HIP(hipMemcpyAsync(c->pinned, base + o_win, W * sizeof(ExecWin), hipMemcpyDeviceToHost, c->stream));
-    RS_HIP(hipMemcpyAsync(h_ctl, base + o_ctl, 16, hipMemcpyDeviceToHost, c->stream));
+    for (int i = 0; i < 4; ++i) RS_HIP(hipMemcpyAsync(h_ctl + i, base + o_ctl + i * kCtlStride, 4, hipMemcpyDeviceToHost, c->stream));
     if (sync_stream(c)) return 1;
 #if RSSYNC_EXEC_STATS
     {
