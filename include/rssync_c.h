@@ -124,6 +124,12 @@ int rssync_ext_rccl_shutdown(rssync_problem* p);
 int rssync_ext_set_tracks_hint(rssync_problem* p, uint32_t max_tracks_all_ranks);
 /* exchanges with other ranks so far (reduce hook or native RCCL): calls and doubles summed */
 int rssync_ext_exchange_stats(rssync_problem* p, uint64_t* calls, uint64_t* doubles);
+/* The window executor (Sync of small frames as one device-scheduled launch).
+ * check on: every call it has run is run again by the launch chain and must give the same bits, or the call panics
+ * (a debug mode, also RSSYNC_EXECUTOR_CHECK=1).  stats: calls the executor completed, of those verified against the
+ * chain, and queue[4] of the last run = {numbers claimed, numbers pushed, cells of the ring, waves launched}. */
+int rssync_ext_set_executor_check(rssync_problem* p, int on);
+int rssync_ext_executor_stats(rssync_problem* p, uint64_t* runs, uint64_t* checked, uint32_t queue[4]);
 /* Diagnostics of the bit-exactness tests (tests/test_gpu_bitexact.py).  GuessMotion's 200-hypothesis search runs
  * in fp32 and leaves one winning hypothesis index per slot (window-major, frames ascending); with recording on,
  * the winners of the last Sync / sync_windows / sync_simplified call can be read back, and set_init_override

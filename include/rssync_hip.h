@@ -230,6 +230,10 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
  * delay, iters[W][repeats], trace[W][trace_rows][6] with the rows of a window's calls back to back
  * (trace_rows >= repeats * max_outer).  Same bits as the chain of launches. */
 int rship_exec_supported(rship_ctx* c);
+/* the last rship_sync_exec of this context: out[0] queue numbers claimed (head), out[1] queue numbers pushed (tail:
+ * every task and end marker ever queued), out[2] cells of the queue ring (the numbers wrap around it), out[3] waves
+ * launched; zeros before the first run (and in the CPU test double) */
+int rship_exec_stats(rship_ctx* c, uint32_t out[4]);
 int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream_first, uint32_t stream_stride, uint64_t seed,
                     int max_outer, double search_center, double search_radius, double* d_out, double* cost, int32_t* iters,
                     double* trace, uint32_t trace_rows);

@@ -125,6 +125,7 @@ struct rship_ctx {
     rship_loop_exchange_fn loop_xchg = nullptr; // host exchange for the device-driven loop (rship_set_loop_exchange)
     void* loop_xchg_user = nullptr;
     uint64_t loop_exchanges = 0; // all-reduces the last rship_sync_run enqueued on the stream (rank mode)
+    uint32_t exec_last[4] = {0, 0, 0, 0}; // rship_exec_stats: head, tail, ring cells, waves of the last rship_sync_exec
     std::vector<uint32_t> h_frame_n; // per table frame
     std::vector<uint32_t> h_sel;
     std::vector<uint32_t> h_delays, h_delays64; // staging of upload_delays / upload_delays64
@@ -1724,6 +1725,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
                 fprintf(stderr, "exec phase %-7s %9llu x  %.2f us each (wall)\n", nm[ph], st[32 + ph], st[16 + ph] * 1e-2 / st[32 + ph]);
     }
 #endif
+    c->exec_last[0] = h_ctl[0]; c->exec_last[1] = h_ctl[1]; c->exec_last[2] = q_cap; c->exec_last[3] = waves;
     if (h_ctl[3]) {
         const ExecWin* e = (const ExecWin*)c->pinned;
         std::string st = "sync_exec: watchdog (a wave polled an empty task queue for seconds); queue head " + std::to_string(h_ctl[0]) +
@@ -1751,6 +1753,11 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
         if (hw[w].trace_base)
             memcpy(trace + (size_t)w * trace_rows * 6, (const char*)c->pinned + (size_t)w * rows_max * 48, (size_t)hw[w].trace_base * 48);
     }
+    return 0;
+}
+
+int rship_exec_stats(rship_ctx* c, uint32_t out[4]) {
+    for (int i = 0; i < 4; ++i) out[i] = c->exec_last[i];
     return 0;
 }
 

@@ -269,7 +269,20 @@ class SyncProblemHip final : public ISyncProblem {
     bool use_executor = true;
     bool executor_warned_ = false;
     bool executor_test_fail_ = false; // RSSYNC_EXECUTOR_FAIL=1 (tests): pretend it gave up
+    // RSSYNC_EXECUTOR_CHECK=1 / rssync_ext_set_executor_check: every call the executor has run is run AGAIN by the launch
+    // chain from the same inputs and the two results -- delays, costs, every trace row -- must be the same bits, or the
+    // call panics.  A debug mode (it doubles the work): the executor's cross-workgroup hand-offs are a measured
+    // protocol, not an architectural guarantee, and a stale word would otherwise be silent.
+    bool executor_check = false;
+    uint64_t executor_runs = 0, executor_checked = 0; // calls the executor completed / of those, verified against the chain
+    void check_against_chain(const char* what, const std::vector<double>& c_exec, const std::vector<double>& d_exec,
+                             const std::vector<std::vector<double>>& tr_exec, const std::vector<double>& c_chain,
+                             const std::vector<double>& d_chain);
     bool executor_ok(bool simplified);
+    void executor_queue_stats(uint32_t out[4]) {
+        out[0] = out[1] = out[2] = out[3] = 0;
+        if (shards_.size() == 1 && shards_[0].ctx) (void)rship_exec_stats(shards_[0].ctx, out);
+    }
     bool sync_exec(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl, const std::vector<double>& initial,
                    double search_center, double search_radius, int repeats, uint32_t stream_first, uint32_t stream_stride,
                    std::vector<double>& costs, std::vector<double>& delays_out);
@@ -339,6 +352,7 @@ SyncProblemHip::SyncProblemHip() {
     if (const char* s = std::getenv("RSSYNC_HOST_LOOP")) host_loop = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_EXECUTOR")) use_executor = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_EXECUTOR_FAIL")) executor_test_fail_ = s[0] && s[0] != '0';
+    if (const char* s = std::getenv("RSSYNC_EXECUTOR_CHECK")) executor_check = s[0] && s[0] != '0';
     // RSSYNC_GPUS: how many GPUs this object spreads its frames over ("4" = devices 0..3) or which
     // ("0,2,5"); default: the calling thread's current device only
     std::vector<int> ids;
@@ -1281,7 +1295,28 @@ bool SyncProblemHip::sync_exec(const std::vector<int64_t>& begins, const std::ve
         for (int r = 0; r < repeats; ++r) n += (size_t)its[w * repeats + r];
         traces[w].assign(tr.begin() + w * (size_t)rows * 6, tr.begin() + (w * (size_t)rows + n) * 6);
     }
+    executor_runs += 1;
     return true;
+}
+
+// RSSYNC_EXECUTOR_CHECK: the executor's results against the launch chain's for the same call (`traces` holds the chain's)
+void SyncProblemHip::check_against_chain(const char* what, const std::vector<double>& c_exec, const std::vector<double>& d_exec,
+                                         const std::vector<std::vector<double>>& tr_exec, const std::vector<double>& c_chain,
+                                         const std::vector<double>& d_chain) {
+    auto same = [](const std::vector<double>& a, const std::vector<double>& b) {
+        return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(double)) == 0);
+    };
+    std::string bad;
+    if (!same(d_exec, d_chain)) bad = "returned delays";
+    else if (!same(c_exec, c_chain)) bad = "returned costs";
+    else if (tr_exec.size() != traces.size()) bad = "number of windows";
+    else
+        for (size_t w = 0; w < traces.size() && bad.empty(); ++w)
+            if (!same(tr_exec[w], traces[w])) bad = "trace of window " + std::to_string(w);
+    if (!bad.empty())
+        panic(std::string("window executor check (") + what + "): the " + bad + " differ from the launch chain's -- a hand-off between "
+              "workgroups delivered a stale value; set RSSYNC_EXECUTOR=0 and report this");
+    executor_checked += 1;
 }
 
 void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl,
@@ -1295,7 +1330,18 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
         // frames of up to 256 tracks: the search, the loop and the final loss of every window as one launch
         sync_exec(begins, ends_incl, initial, search_center, search_radius, 1, kStreamSyncInit + sync_calls, call_stride, costs,
                   delays_out)) {
-        if (call_stride == 1) sync_calls += (uint32_t)W;
+        if (executor_check) { // the same call once more through the launch chain (which advances the call counter itself)
+            const std::vector<double> c_exec = costs, d_exec = delays_out;
+            const std::vector<std::vector<double>> tr_exec = traces;
+            const bool verbose_was = verbose;
+            use_executor = false;
+            verbose = false;
+            std::vector<double> c_chain, d_chain;
+            sync_windows(begins, ends_incl, initial, search_center, search_radius, c_chain, d_chain, call_stride, simplified);
+            use_executor = true;
+            verbose = verbose_was;
+            check_against_chain("sync_windows", c_exec, d_exec, tr_exec, c_chain, d_chain);
+        } else if (call_stride == 1) sync_calls += (uint32_t)W;
         if (verbose && W == 1) { // :330, the lines the host loop would have written
             int conv = 0;
             for (size_t it = 0; it * 6 < traces[0].size(); ++it) {
@@ -1538,6 +1584,9 @@ void SyncProblemHip::sync_points(const std::vector<int64_t>& positions, int64_t 
         presync_windows(initial_delay, positions, ends, presync_step, presync_radius, c, d);
     }
     const uint32_t first_call = sync_calls;
+    std::vector<double> c_exec, d_exec;
+    std::vector<std::vector<double>> tr_exec;
+    bool checking = false;
     if (repeats >= 1 && repeats <= 8) {
         // all repeats of all positions in ONE launch where the executor can run them: a position starts its next
         // call the moment it has finished the previous one
@@ -1546,7 +1595,11 @@ void SyncProblemHip::sync_points(const std::vector<int64_t>& positions, int64_t 
         if (executor_ok(false) && sync_exec(positions, ends, d, initial_delay, radius, repeats, kStreamSyncInit + first_call,
                                             (uint32_t)repeats, costs, delays_out)) {
             sync_calls = first_call + (uint32_t)(W * (size_t)repeats);
-            return;
+            if (!executor_check) return;
+            // RSSYNC_EXECUTOR_CHECK: the chain below runs the same calls; compare, then hand out the (identical) results
+            c_exec = costs; d_exec = delays_out; tr_exec = traces;
+            checking = true;
+            use_executor = false;
         }
     }
     std::vector<std::vector<double>> all(W);
@@ -1560,6 +1613,10 @@ void SyncProblemHip::sync_points(const std::vector<int64_t>& positions, int64_t 
     sync_calls = first_call + (uint32_t)(W * (size_t)std::max(0, repeats));
     traces = all; // every repeat's rows, in order
     delays_out = d;
+    if (checking) {
+        use_executor = true;
+        check_against_chain("sync_points", c_exec, d_exec, tr_exec, costs, delays_out);
+    }
 }
 
 } // namespace
@@ -1717,6 +1774,18 @@ int rssync_ext_exchange_stats(rssync_problem* p, uint64_t* calls, uint64_t* doub
     if (calls) *calls = p->impl->exchange_calls;
     if (doubles) *doubles = p->impl->exchange_doubles;
     return 0;
+}
+
+int rssync_ext_set_executor_check(rssync_problem* p, int on) {
+    p->impl->executor_check = on != 0;
+    return 0;
+}
+int rssync_ext_executor_stats(rssync_problem* p, uint64_t* runs, uint64_t* checked, uint32_t queue[4]) {
+    return guarded([&] {
+        if (runs) *runs = p->impl->executor_runs;
+        if (checked) *checked = p->impl->executor_checked;
+        if (queue) p->impl->executor_queue_stats(queue);
+    });
 }
 
 int rssync_ext_record_init_winners(rssync_problem* p, int on) {

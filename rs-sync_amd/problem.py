@@ -61,6 +61,8 @@ SIGNATURES = {
     "rssync_ext_rccl_shutdown": (C.c_int, [C.c_void_p]),
     "rssync_ext_set_tracks_hint": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rssync_ext_exchange_stats": (C.c_int, [C.c_void_p, _PU64, _PU64]),
+    "rssync_ext_set_executor_check": (C.c_int, [C.c_void_p, C.c_int]),
+    "rssync_ext_executor_stats": (C.c_int, [C.c_void_p, _PU64, _PU64, C.POINTER(C.c_uint32)]),
     "rssync_ext_record_init_winners": (C.c_int, [C.c_void_p, C.c_int]),
     "rssync_ext_last_init_winners": (C.c_int, [C.c_void_p, _PI32, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rssync_ext_set_init_override": (C.c_int, [C.c_void_p, _PI32, C.c_size_t]),
@@ -300,6 +302,16 @@ class SyncProblem:
         a, b = C.c_uint64(), C.c_uint64()
         self._lib.rssync_ext_exchange_stats(self._h, C.byref(a), C.byref(b))
         return a.value, b.value
+
+    def set_executor_check(self, on=True):
+        """debug mode: every call the window executor runs is re-run by the launch chain and must give the same bits"""
+        self._check(self._lib.rssync_ext_set_executor_check(self._h, 1 if on else 0))
+
+    def executor_stats(self):
+        """-> dict(runs, checked, head, tail, ring_cells, waves) of the window executor on this object"""
+        runs, chk, q = C.c_uint64(), C.c_uint64(), (C.c_uint32 * 4)()
+        self._check(self._lib.rssync_ext_executor_stats(self._h, C.byref(runs), C.byref(chk), q))
+        return dict(runs=runs.value, checked=chk.value, head=q[0], tail=q[1], ring_cells=q[2], waves=q[3])
 
     def record_init_winners(self, on=True):
         self._lib.rssync_ext_record_init_winners(self._h, 1 if on else 0)

@@ -131,3 +131,38 @@ def test_the_chain_takes_over_if_the_executor_gives_up(monkeypatch, capfd):
     assert a.Sync(0.036, 0, F - 1, 0.0, 0.2) == b.Sync(0.036, 0, F - 1, 0.0, 0.2)
     err = capfd.readouterr().err
     assert err.count("continuing with the launch chain") == 1
+
+
+def test_check_mode_reruns_every_call_through_the_chain_and_the_queue_ring_wraps(built):
+    """RSSYNC_EXECUTOR_CHECK / set_executor_check: every call the executor runs (at its default eight one-wave
+    workgroups per CU) is run again by the launch chain INSIDE the same call and must give the same bits, or the call
+    panics -- the runtime form of this file's comparisons, for a protocol that is measured, not guaranteed
+    (DESIGN.md section 4).  The same run must have wrapped the queue ring several times: a cell is reused lap after
+    lap (lap-tagged cells, executor.hpp), which a run shorter than the ring would not exercise."""
+    import rssync_amd
+    from rssync_amd import synth
+    F, N, window = 150, 130, 30
+    gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=14)
+    frames = list(synth.make_frames(gyro, 0, F, N, seed=14))
+    p = rssync_amd.SyncProblem(seed=34, max_outer_iters=400)
+    _fill((p,), gyro, frames)
+    p.set_executor_check(True)
+    pos = list(range(0, F - window - 1, 9))
+    c, d = p.sync_points(pos, window, 0.0, 0.002, 0.1)
+    st = p.executor_stats()
+    assert st["runs"] == 1 and st["checked"] == 1, st
+    assert st["waves"] >= 8 * 64 or st["waves"] == len(pos) * (window + 1), st     # (eight per CU, or one per slot)
+    # the ring: every task and end marker ever pushed has a number; the numbers wrapped the ring more than twice
+    assert st["ring_cells"] >= 256 and st["tail"] > 2 * st["ring_cells"], st
+    assert st["head"] >= st["tail"]                                           # every number pushed was claimed
+    # single calls and lock-step windows are checked too
+    r = p.Sync(float(d[0]), 0, 40, 0.0, 0.1)
+    p.sync_windows([0.036, 0.037], [0, 50], [40, 90], 0.0, 0.1)
+    st = p.executor_stats()
+    assert st["runs"] == 3 and st["checked"] == 3, st
+    assert np.isfinite(r[0]) and np.all(np.isfinite(c))
+    # with the check off nothing is re-run
+    p.set_executor_check(False)
+    p.Sync(float(d[0]), 0, 40, 0.0, 0.1)
+    st = p.executor_stats()
+    assert st["runs"] == 4 and st["checked"] == 3, st
