@@ -56,7 +56,21 @@ def main():
     mc, md = q.Sync(0.03, 0, F - 1, 0.0, 0.2)
     mixed = dict(sync=[mc, md], iters=len(q.sync_trace()), calls=hook2.stats["calls"] - init_calls, init_calls=init_calls,
                  M=M.tolist(), k=k.tolist())
-    res = dict(rank=rank, big=big, mixed=mixed, frames=[b, e], presync=[c0, d0], sync=[c1, d1], iters=iters,
+    # BASELINE config 5 with ranks (core_testcode.cpp:184-233): the gyro arrives as rates at timestamps, replicated on
+    # every rank; each orientation is a PreSync over the sharded frames = ONE exchange of its candidate costs
+    F5, N5 = 12, 64
+    g5 = synth.make_gyro(1.0, 1.0 + (F5 + 2) / synth.FPS, seed=77)   # t0 = 0: timestamps must be >= 0
+    b5, e5 = shard(30, 30 + F5, rank, world)
+    names = list(synth.ORIENTATIONS[:4]) + ["XYZ"]
+    r = rssync_amd.SyncProblem(seed=55, _lib=lib)
+    for fr in synth.make_frames(g5, b5, e5, N5, seed=77):
+        r.SetTrackResult(*fr)
+    hook3 = make_reduce_hook("cpu")
+    r.set_reduce_hook(hook3)
+    r.set_tracks_hint(N5)
+    oc, od = r.orientation_sweep(g5.times, g5.rates, names, 0.0, 30, 30 + F5, 0.004, 0.1)
+    sweep = dict(costs=list(map(float, oc)), delays=list(map(float, od)), calls=hook3.stats["calls"], frames=[b5, e5])
+    res = dict(rank=rank, big=big, mixed=mixed, sweep=sweep, frames=[b, e], presync=[c0, d0], sync=[c1, d1], iters=iters,
                presync_exchanges=n_pre, sync_exchanges=n_sync,
                points=[list(map(float, costs)), list(map(float, delays))],
                points_iters=[len(p.window_trace(w)) for w in range(len(pos))])

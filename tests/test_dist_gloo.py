@@ -97,3 +97,20 @@ def test_two_ranks_equal_one(hosttest_lib, tmp_path):
         lone.SetTrackResult(*next(iter(synth.make_frames(gyro, fr, fr + 1, 96, seed=6))))
     _, k_lone = lone.init_motion(0.03, 0, 7)
     assert not np.array_equal(k_lone, k1[:8]) and np.allclose(k_lone, k1[:8], rtol=1e-12)
+    # BASELINE config 5 with ranks: the orientation sweep (gyro as rates, replicated; frames sharded) == one process,
+    # one exchange per orientation (its PreSync's candidate costs), the true orientation first on every rank
+    F5, N5 = 12, 64
+    g5 = synth.make_gyro(1.0, 1.0 + (F5 + 2) / synth.FPS, seed=77)
+    names = list(synth.ORIENTATIONS[:4]) + ["XYZ"]
+    o5 = rssync_amd.SyncProblem(seed=55, _lib=hosttest_lib)
+    for fr in synth.make_frames(g5, 30, 30 + F5, N5, seed=77):
+        o5.SetTrackResult(*fr)
+    oc, od = o5.orientation_sweep(g5.times, g5.rates, names, 0.0, 30, 30 + F5, 0.004, 0.1)
+    assert res[0]["sweep"]["frames"] == [30, 36] and res[1]["sweep"]["frames"] == [36, 42]
+    for r in res:
+        sw = r["sweep"]
+        assert sw["calls"] == len(names)
+        assert sw["delays"] == list(od)
+        assert sw["costs"] == pytest.approx(list(oc), rel=1e-12)
+        assert names[int(np.argmin(sw["costs"]))] == "XYZ"
+    assert res[0]["sweep"]["costs"] == res[1]["sweep"]["costs"]
