@@ -113,6 +113,11 @@ int rssync_ext_set_reduce_hook(rssync_problem* p, rssync_reduce_fn fn, void* use
  * per process, librccl opened at run time).  Rank 0 calls rccl_unique_id (128 bytes), the host
  * hands the bytes to every rank by whatever means it has, every rank calls rccl_init; from then on
  * the sums of PreSync / Sync are all-reduced with ncclAllReduce on the problem's stream. */
+/* preflight: 0 if this process can use RCCL at all (library and entry points resolve; no communication) -- the ranks
+ * agree on the outcome of THIS before any of them enters the collective rccl_init (rs-sync_amd/dist.py);
+ * library: which librccl is used ("... (already loaded in this process)" when the host's own copy was found) */
+int rssync_ext_rccl_preflight(rssync_problem* p);
+const char* rssync_ext_rccl_library(rssync_problem* p);
 int rssync_ext_rccl_unique_id(rssync_problem* p, void* id128);
 int rssync_ext_rccl_init(rssync_problem* p, const void* id128, int rank, int world_size);
 /* leave that communicator (collective: every rank calls it); the problem is a single rank again */

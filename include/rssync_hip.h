@@ -250,6 +250,8 @@ int rship_set_motion(rship_ctx* c, const double* M, const double* k, uint32_t n)
  * (librccl is opened with dlopen on first use: no link-time dependency), one rank per process.
  * unique_id: rank 0 fills 128 bytes, the host distributes them (MPI, torch.distributed, a file...),
  * every rank then calls init.  allreduce sums n doubles in place over all ranks (host buffer). */
+int rship_rccl_preflight(rship_ctx* c);        /* 0 = librccl and every entry point used are there (no communication) */
+const char* rship_rccl_library(rship_ctx* c);   /* which librccl the entry points come from ("" before the first use) */
 int rship_rccl_unique_id(rship_ctx* c, void* id128);
 int rship_rccl_init(rship_ctx* c, const void* id128, int rank, int world);
 int rship_rccl_allreduce(rship_ctx* c, double* buf, uint64_t n);

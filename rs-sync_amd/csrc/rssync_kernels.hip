@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <link.h>
 
 #include <algorithm>
 #include <cmath>
@@ -119,6 +120,7 @@ struct rship_ctx {
     float max_span = 0.f; // widest frame, in knots (frame table)
     // native exchange (RCCL through dlopen)
     void* rccl_lib = nullptr;
+    std::string rccl_path; // which librccl the symbols come from
     void* rccl_comm = nullptr;
     DevBuf rccl_buf;
     DevBuf big_scratch, mo_scratch; // frames of more than 8192 tracks: the LMedS tiles / the motion kernel's rows
@@ -466,11 +468,32 @@ using rccl_init_fn = int (*)(void**, int, RcclId, int);
 using rccl_allreduce_fn = int (*)(const void*, void*, size_t, int, int, void*, hipStream_t);
 using rccl_destroy_fn = int (*)(void*);
 
+using rccl_abort_fn = int (*)(void*);
+
+// librccl: a copy ALREADY MAPPED into this process wins (a host that runs torch.distributed has loaded the librccl its
+// torch build ships, possibly not the system's: two RCCL runtimes in one process would each set up their own
+// transports and IPC handles), found by walking the loaded objects; only otherwise is one opened by name.
 void* rccl_sym(rship_ctx* c, const char* name) {
     if (!c->rccl_lib) {
-        for (const char* lib : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            c->rccl_lib = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
-            if (c->rccl_lib) break;
+        struct Found { std::string path; } found;
+        dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* user) -> int {
+            const char* nm = info->dlpi_name;
+            if (!nm || !*nm) return 0;
+            const char* base = strrchr(nm, '/');
+            base = base ? base + 1 : nm;
+            if (strncmp(base, "librccl.so", 10) != 0) return 0;
+            static_cast<Found*>(user)->path = nm;
+            return 1;
+        }, &found);
+        if (!found.path.empty()) {
+            c->rccl_lib = dlopen(found.path.c_str(), RTLD_NOW | RTLD_NOLOAD);
+            if (c->rccl_lib) c->rccl_path = found.path + " (already loaded in this process)";
+        }
+        if (!c->rccl_lib) {
+            for (const char* lib : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                c->rccl_lib = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+                if (c->rccl_lib) { c->rccl_path = std::string(lib) + " (opened by name)"; break; }
+            }
         }
         if (!c->rccl_lib) {
             set_err(c, std::string("rccl: cannot open librccl: ") + dlerror());
@@ -480,6 +503,17 @@ void* rccl_sym(rship_ctx* c, const char* name) {
     void* f = dlsym(c->rccl_lib, name);
     if (!f) set_err(c, std::string("rccl: missing symbol ") + name);
     return f;
+}
+
+// A local failure while peers may be waiting inside a collective: abort the communicator, so that their pending
+// all-reduces end with an error instead of waiting for this rank for ever.
+void rccl_abort_comm(rship_ctx* c) {
+    if (!c->rccl_comm) return;
+    std::string keep;
+    { std::lock_guard<std::mutex> lock(g_err_mutex); keep = c->err; }
+    if (auto ab = (rccl_abort_fn)rccl_sym(c, "ncclCommAbort")) (void)ab(c->rccl_comm);
+    c->rccl_comm = nullptr;
+    set_err(c, keep + " -- the RCCL communicator was aborted so that the other ranks fail instead of waiting");
 }
 } // namespace
 
@@ -1267,8 +1301,18 @@ static uint32_t loop_groups(const rship_ctx* c, uint32_t n_win) {
     return g < 1 ? 1 : g;
 }
 
+static int sync_run_body(rship_ctx* c, const double* d0, int max_outer, double search_center, double search_radius,
+                         int simplified, double* d_out, int32_t* iters, double* trace);
 int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_center, double search_radius,
                    int simplified, double* d_out, int32_t* iters, double* trace) {
+    const int rc = sync_run_body(c, d0, max_outer, search_center, search_radius, simplified, d_out, iters, trace);
+    // a rank-local failure (an allocation, a launch) in rank mode: the other ranks are, or will be, inside the next
+    // all-reduce of this loop -- abort the communicator so that they fail too instead of waiting for this rank
+    if (rc && c->rccl_comm) rccl_abort_comm(c);
+    return rc;
+}
+static int sync_run_body(rship_ctx* c, const double* d0, int max_outer, double search_center, double search_radius,
+                         int simplified, double* d_out, int32_t* iters, double* trace) {
     DeviceGuard dev_guard(c);
     // Rank mode: the frames are sharded over processes and this context holds the library's RCCL communicator.  The
     // loop is the same; the window sums are all-reduced on the stream between the kernels.  A rank may hold no frame of
@@ -1784,6 +1828,16 @@ int rship_set_motion(rship_ctx* c, const double* M, const double* k, uint32_t n)
     return 0;
 }
 
+// Can this process use RCCL at all?  Resolves the library and every entry point the exchange uses; no communication.
+// (rssync_amd/dist.py: the ranks agree on the outcome of this BEFORE any of them enters the collective
+// ncclCommInitRank, where a rank that cannot follow would leave the others waiting.)
+int rship_rccl_preflight(rship_ctx* c) {
+    for (const char* nm : {"ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclCommDestroy", "ncclCommAbort"})
+        if (!rccl_sym(c, nm)) return 1;
+    return 0;
+}
+const char* rship_rccl_library(rship_ctx* c) { return c->rccl_path.c_str(); }
+
 int rship_rccl_unique_id(rship_ctx* c, void* id128) {
     auto get = (rccl_get_id_fn)rccl_sym(c, "ncclGetUniqueId");
     if (!get) return 1;
@@ -1819,7 +1873,11 @@ int rship_rccl_allreduce(rship_ctx* c, double* buf, uint64_t n) {
     if (ensure(c, c->rccl_buf, (size_t)n * 8)) return 1;
     RS_HIP(hipMemcpyAsync(c->rccl_buf.p, buf, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     const int rc = allreduce(c->rccl_buf.p, c->rccl_buf.p, (size_t)n, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->rccl_comm, c->stream);
-    if (rc) return set_err(c, "rccl: ncclAllReduce failed (" + std::to_string(rc) + ")");
+    if (rc) {
+        set_err(c, "rccl: ncclAllReduce failed (" + std::to_string(rc) + ")");
+        rccl_abort_comm(c);
+        return 1;
+    }
     RS_HIP(hipMemcpyAsync(buf, c->rccl_buf.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
     RS_HIP(hipStreamSynchronize(c->stream));
     return 0;

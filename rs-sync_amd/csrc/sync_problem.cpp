@@ -206,7 +206,21 @@ class SyncProblemHip final : public ISyncProblem {
     void debug_rays(int64_t frame, float* a4, float* b4, size_t cap);
 
     // pieces shared by the public calls and the diagnostics
-    void ensure_device();
+    // collective = false: a rank-local diagnostic (problem_matrix, frame_rays): no exchange with other ranks -- the
+    // kernel shapes agreed by the last collective call stay (or, before any, this rank's own largest frame decides)
+    void ensure_device(bool collective = true);
+    // One agreement on the kernel shapes per PUBLIC call: the entry points that call each other (sync_points ->
+    // presync_windows / sync_windows, orientation_sweep -> PreSync) open a scope, and only the first ensure_device
+    // inside it exchanges (frames cannot change within a call).
+    struct CollectiveCall {
+        SyncProblemHip* s;
+        explicit CollectiveCall(SyncProblemHip* s_) : s(s_) { if (s->coll_depth_++ == 0) s->coll_agreed_ = false; }
+        ~CollectiveCall() { --s->coll_depth_; }
+        CollectiveCall(const CollectiveCall&) = delete;
+        CollectiveCall& operator=(const CollectiveCall&) = delete;
+    };
+    int coll_depth_ = 0;
+    bool coll_agreed_ = false;
     void ensure_spline() { if (spline_dirty_) build_spline(); }
     uint32_t select(int64_t begin, int64_t end_exclusive);
     std::vector<double> sweep(const std::vector<double>& delays, uint32_t stream_base, bool panics,
@@ -310,7 +324,7 @@ class SyncProblemHip final : public ISyncProblem {
     }
     void create_shards(const std::vector<int>& ids);
     void destroy_shards();
-    void agree_on_tracks_hint();
+    void agree_on_tracks_hint(bool exchange);
     // options that live in the device contexts, kept here so that set_devices (new contexts) does not lose them
     int opt_lbfgs_reeval_ = 0, opt_profile_ = 0;
     uint32_t tracks_hint_explicit_ = 0, local_max_tracks_ = 0, applied_hint_ = 0xffffffffu;
@@ -429,7 +443,7 @@ void SyncProblemHip::profile_enable(int on) {
 // threshold the launchers test is one of those), so ranks agree on it with a sum: each adds a one into the slot
 // of its own class and the highest occupied slot wins -- the reduce hook knows neither rank nor world size.
 // One small exchange per collective call, unless the caller has given the number (rssync_ext_set_tracks_hint).
-void SyncProblemHip::agree_on_tracks_hint() {
+void SyncProblemHip::agree_on_tracks_hint(bool exchange) {
     constexpr uint32_t kFine = 128; // classes 0..128: ceil(n / 64)
     auto cls = [](uint32_t n) -> uint32_t {
         if (n <= 64u * kFine) return (n + 63u) / 64u;
@@ -443,7 +457,7 @@ void SyncProblemHip::agree_on_tracks_hint() {
         return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v;
     };
     uint32_t c = cls(tracks_hint_explicit_ ? tracks_hint_explicit_ : local_max_tracks_);
-    if (!tracks_hint_explicit_ && distributed()) {
+    if (!tracks_hint_explicit_ && distributed() && exchange) {
         double slots[kFine + 21] = {};
         slots[c] = 1.0;
         reduce(slots, kFine + 21);
@@ -673,6 +687,7 @@ void SyncProblemHip::orientation_sweep(const double* ts, const double* rates, si
                                        int64_t frame_begin, int64_t frame_end, double search_step,
                                        double search_radius, double* costs, double* delays) {
     if (orientations.empty()) return;
+    CollectiveCall scope(this); // (one PreSync per orientation: the ranks agree on the kernel shapes once)
     for (const std::string& o : orientations) {
         int32_t axis[3];
         double sign[3];
@@ -891,11 +906,18 @@ void SyncProblemHip::combine(size_t rows, size_t n_win, Collect&& collect, doubl
     }
 }
 
-void SyncProblemHip::ensure_device() {
+void SyncProblemHip::ensure_device(bool collective) {
     if (n_knots_ < 2) panic("sync: gyro data was not set");
     if (spline_dirty_) build_spline();
     if (frames_dirty_) pack_frames();
-    agree_on_tracks_hint(); // (an exchange when other ranks take part: every public call is collective then)
+    if (!collective) {
+        // rank-local: never an exchange (a call made on one rank only must not enter a collective)
+        if (!distributed() || tracks_hint_explicit_ || applied_hint_ == 0xffffffffu) agree_on_tracks_hint(false);
+        return;
+    }
+    if (coll_depth_ > 0 && coll_agreed_) return;
+    agree_on_tracks_hint(true); // (an exchange when other ranks take part and no hint was given: the call is collective then)
+    coll_agreed_ = true;
 }
 
 uint32_t SyncProblemHip::get_motion(double* M, double* k, uint32_t cap) {
@@ -1572,6 +1594,7 @@ void SyncProblemHip::presync_windows(double initial_delay, const std::vector<int
 void SyncProblemHip::sync_points(const std::vector<int64_t>& positions, int64_t window, double initial_delay,
                                  bool use_presync, double presync_step, double presync_radius, int repeats,
                                  std::vector<double>& costs, std::vector<double>& delays_out) {
+    CollectiveCall scope(this); // (PreSync of all windows + repeats x Sync: the ranks agree on the kernel shapes once)
     const size_t W = positions.size();
     std::vector<int64_t> ends(W);
     for (size_t w = 0; w < W; ++w) ends[w] = positions[w] + window;
@@ -1748,6 +1771,13 @@ int rssync_ext_set_reduce_hook(rssync_problem* p, rssync_reduce_fn fn, void* use
     return 0;
 }
 
+int rssync_ext_rccl_preflight(rssync_problem* p) {
+    return guarded([&] {
+        if (rship_rccl_preflight(p->impl->dev())) panic(std::string("hip: ") + rship_last_error(p->impl->dev()));
+    });
+}
+const char* rssync_ext_rccl_library(rssync_problem* p) { return rship_rccl_library(p->impl->dev()); }
+
 int rssync_ext_rccl_unique_id(rssync_problem* p, void* id128) {
     return guarded([&] {
         if (rship_rccl_unique_id(p->impl->dev(), id128)) panic(std::string("hip: ") + rship_last_error(p->impl->dev()));
@@ -1860,7 +1890,7 @@ int rssync_ext_problem_matrix(rssync_problem* p, int64_t frame, double delay, fl
                               size_t* n_rows) {
     return guarded([&] {
         SyncProblemHip* s = p->impl;
-        s->ensure_device();
+        s->ensure_device(false); // rank-local: no exchange
         if (!s->has_frame(frame)) panic("problem_matrix: unknown frame");
         s->select(frame, frame + 1);
         s->debug_problem(frame, delay, P, dP, nullptr, nullptr, cap_rows);
@@ -1980,7 +2010,7 @@ int rssync_ext_problem_matrix64(rssync_problem* p, int64_t frame, double delay, 
                                 size_t* n_rows) {
     return guarded([&] {
         SyncProblemHip* s = p->impl;
-        s->ensure_device();
+        s->ensure_device(false); // rank-local: no exchange
         if (!s->has_frame(frame)) panic("problem_matrix: unknown frame");
         s->select(frame, frame + 1);
         s->debug_problem(frame, delay, nullptr, nullptr, P, dP, cap_rows);
@@ -2018,7 +2048,7 @@ int rssync_ext_orientation_sweep(rssync_problem* p, const double* timestamps_s, 
 int rssync_ext_frame_rays(rssync_problem* p, int64_t frame, float* a4, float* b4, size_t cap, size_t* n) {
     return guarded([&] {
         SyncProblemHip* s = p->impl;
-        s->ensure_device();
+        s->ensure_device(false); // rank-local: no exchange
         for (uint32_t i = 0;; ++i) {
             if (i >= s->table_size()) panic("frame_rays: no such frame");
             if (s->table_id(i) != frame) continue;

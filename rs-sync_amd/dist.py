@@ -42,45 +42,38 @@ def use_native_rccl(problem, strict=False):
     """Give `problem` its own RCCL communicator (no Python in the exchange): rank 0's unique id is
     broadcast through the already initialised torch.distributed group, then every rank joins.
 
-    Returns "native-rccl", or -- if any rank could not join (librccl missing, init refused) and `strict` is
-    false -- the first failure's message after every rank has left the communicator again: the caller then
-    installs a reduce hook instead.  The ranks agree on the outcome, so they never end up on different paths.
+    ncclCommInitRank is COLLECTIVE: a rank that cannot follow would leave the others waiting inside it.  So first
+    every rank checks locally that it can use RCCL at all (`rccl_preflight`: library and entry points resolve, rank 0
+    also draws the unique id) and the ranks agree on that (all-reduce MIN) -- only then does anyone call `rccl_init`.
+    Returns "native-rccl"; or, if some rank failed the PREFLIGHT and `strict` is false, that rank's message (no rank
+    has touched RCCL's collective yet: the caller installs a reduce hook instead, the same on every rank).  A failure
+    AFTER the preflight (inside the collective init) is fatal: it raises, the process should exit non-zero.
     """
     import torch
     import torch.distributed as dist
 
     rank, world = dist.get_rank(), dist.get_world_size()
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     err = None
     ids = [None]
-    if rank == 0:
-        try:
+    try:
+        problem.rccl_preflight()
+        if rank == 0:
             ids = [problem.rccl_unique_id()]
-        except Exception as exc:  # noqa: BLE001
-            err = "rank 0: %s" % exc
-    dist.broadcast_object_list(ids, src=0)
-    joined = False
-    if ids[0] is not None:
-        try:
-            problem.rccl_init(ids[0], rank, world)
-            joined = True
-        except Exception as exc:  # noqa: BLE001
-            err = "rank %d: %s" % (rank, exc)
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    ok = torch.tensor([1 if joined else 0], dtype=torch.int32, device=dev)
+    except Exception as exc:  # noqa: BLE001
+        err = "rank %d: %s" % (rank, exc)
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok.item()) == 1:
-        return "native-rccl"
-    errs = [None] * world
-    dist.all_gather_object(errs, err)
-    first = next((e for e in errs if e), "unknown")
-    if joined:
-        try:
-            problem.rccl_shutdown()
-        except Exception:  # noqa: BLE001
-            pass
-    if strict:
-        raise RuntimeError("native RCCL exchange unavailable: " + first)
-    return first
+    if int(ok.item()) != 1:
+        errs = [None] * world
+        dist.all_gather_object(errs, err)
+        first = next((e for e in errs if e), "unknown")
+        if strict:
+            raise RuntimeError("native RCCL exchange unavailable: " + first)
+        return first
+    dist.broadcast_object_list(ids, src=0)
+    problem.rccl_init(ids[0], rank, world)   # collective; a failure here is fatal by design (see above)
+    return "native-rccl"
 
 
 def shard(frame_begin, frame_end, rank, world):

@@ -56,6 +56,8 @@ SIGNATURES = {
     "rssync_ext_set_devices": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     "rssync_ext_device_count": (C.c_int, [C.c_void_p]),
     "rssync_ext_set_reduce_hook": (C.c_int, [C.c_void_p, REDUCE_FN, C.c_void_p]),
+    "rssync_ext_rccl_preflight": (C.c_int, [C.c_void_p]),
+    "rssync_ext_rccl_library": (C.c_char_p, [C.c_void_p]),
     "rssync_ext_rccl_unique_id": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rssync_ext_rccl_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rssync_ext_rccl_shutdown": (C.c_int, [C.c_void_p]),
@@ -275,6 +277,13 @@ class SyncProblem:
 
         self._hook = REDUCE_FN(tramp)  # keep the trampoline alive
         self._lib.rssync_ext_set_reduce_hook(self._h, self._hook, None)
+
+    def rccl_preflight(self):
+        """raises unless this process can use RCCL (library + entry points resolve); no communication"""
+        self._check(self._lib.rssync_ext_rccl_preflight(self._h))
+
+    def rccl_library(self):
+        return (self._lib.rssync_ext_rccl_library(self._h) or b"").decode()
 
     def rccl_unique_id(self):
         """128 opaque bytes from ncclGetUniqueId (call on rank 0, hand them to every rank)."""

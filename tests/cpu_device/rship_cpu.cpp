@@ -344,6 +344,8 @@ int rship_pack_frames(rship_ctx* c, const rship_frame* table, const rship_pack_f
 }
 
 // the native exchange needs a GPU and librccl: not part of the test double
+int rship_rccl_preflight(rship_ctx* c) { return fail(c, "rccl: device only"); }
+const char* rship_rccl_library(rship_ctx*) { return ""; }
 int rship_rccl_unique_id(rship_ctx* c, void*) { return fail(c, "rccl: device only"); }
 int rship_rccl_init(rship_ctx* c, const void*, int, int) { return fail(c, "rccl: device only"); }
 int rship_rccl_allreduce(rship_ctx* c, double*, uint64_t) { return fail(c, "rccl: device only"); }
