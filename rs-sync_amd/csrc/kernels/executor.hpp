@@ -295,7 +295,7 @@ __device__ __forceinline__ void exec_decide(const ExecParams& p, uint32_t w, Exe
                     s.d = d;
                     s.active = 1;
                     s.hit = -1;
-                    s.nf = p.lp.nf_fixed ? p.lp.nf_fixed : kHalfBt;
+                    s.nf = p.lp.nf_fixed ? p.lp.nf_fixed : p.lp.nf_floor;
                     s.x0 = s.d - p.lp.delay_b * s.v;
                     st_m<true>(&p.win_stream[w], p.stream_first + (uint32_t)L->call + w * p.stream_stride);
                     int32_t ikd; float ifd;

@@ -45,6 +45,11 @@ struct SyncLoopParams {
     double c_armijo, delay_b, search_center, search_radius;
     int it, max_outer;
     int nf_fixed;          // 0: adaptive (below); k: always the first k trials first (tests: makes windows wait)
+    // The smallest number of trials a line search's first launch evaluates.  Small windows: kHalfBt -- a trial costs
+    // microseconds there and a window that has to wait for its later trials loses a whole iteration.  Large problems
+    // (a trial launch of 4096 x 2048 ray pairs is 0.06 ms of fp64 work PER TRIAL): 1 -- exactly as many as the later
+    // of the last two searches needed.  Only the batching depends on it, never a result.
+    int nf_floor;
     // Frames sharded over ranks (one process per GPU, the library's RCCL communicator): the window sums of a launch are
     // written to ext_sums[row][window] by sync_sums_kernel, all-reduced over the ranks ON THE STREAM (ncclAllReduce
     // between the kernels, no host round trip), and the decision kernels read them there instead of adding the
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(64) void sync_begin_kernel(SyncLoopParams p) {
 
 // Which trials a launch evaluates for a window.  The ten trials of a line search (backtrack.cpp:7-11) are
 // evaluated in ONE launch per outer iteration: the first nf of them, nf = one more than the larger index at which the window's
-// last two searches stopped, at least five (the step scale barely changes between iterations).  A window whose
+// last two searches stopped, at least nf_floor (the step scale barely changes between iterations).  A window whose
 // search finds nothing among them waits one iteration (phase 1: no motion, no gradient launch for it) in which
 // the launch evaluates the remaining trials; then it steps.  The first trial that satisfies the Armijo test is
 // taken in trial order either way -- what the sequential loop returns.
@@ -260,12 +265,12 @@ __device__ __forceinline__ bool step_decide(const SyncLoopParams& p, SyncWin& s,
         row[0] = s.d; row[1] = step; row[2] = v; row[3] = g; row[4] = t; row[5] = (double)trials;
         s.iters += 1;
         s.phase = 0;
-        // as many as the later of the last two searches needed (at bench size one trial is 0.06 ms of fp64 work:
-        // no blanket margin), at least five
+        // as many as the later of the last two searches needed, at least nf_floor (five for small windows, one where
+        // a trial is expensive: SyncLoopParams)
         const int last = s.hit >= 0 ? s.hit : kMaxBt - 1;
         const int want = (last > s.hit_prev ? last : s.hit_prev) + 1;
         s.hit_prev = last;
-        s.nf = p.nf_fixed ? p.nf_fixed : (want < kHalfBt ? kHalfBt : (want > kMaxBt ? kMaxBt : want));
+        s.nf = p.nf_fixed ? p.nf_fixed : (want < p.nf_floor ? p.nf_floor : (want > kMaxBt ? kMaxBt : want));
         if (step_size < 1e-4) s.conv++; else s.conv = 0;                            // :316-320
         bool stop = s.conv > 5;                                                     // :322-324
         if (!stop && fabs(s.d - p.search_center) > p.search_radius) stop = true;    // :326-328

@@ -1331,6 +1331,13 @@ static int sync_run_body(rship_ctx* c, const double* d0, int max_outer, double s
     c->loop_exchanges = 0;
     int nf_fixed = 0; // test knob: always evaluate exactly this many trials first
     if (const char* e = std::getenv("RSSYNC_LOOP_FIRST_TRIALS")) { const int v = atoi(e); if (v >= 1 && v <= kMaxBt) nf_fixed = v; }
+    // how many trials a search's first launch holds at least (SyncLoopParams::nf_floor): five where a trial is cheap
+    // (the reference's ~130-track frames), one for frames of 1024 tracks and more (dense trackers: every unneeded
+    // trial of 4096 x 2048 ray pairs is 0.06 ms).  Decided from the problem's largest frame over ALL ranks (the agreed
+    // size class): in rank mode every rank must batch its trials alike, the sums of a trial come from all of them.
+    const uint32_t n_all_tracks = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
+    int nf_floor = n_all_tracks >= 1024u ? 1 : kHalfBt;
+    if (const char* e = std::getenv("RSSYNC_LOOP_TRIALS_FLOOR")) { const int v = atoi(e); if (v >= 1 && v <= kMaxBt) nf_floor = v; }
     const int max_launch = 2 * max_outer; // a window whose line search needs its later trials waits one iteration for them
     // one allocation: windows | motion delays | loss delays | trial delays | per-group counters | trace | chunk scratch
     size_t off = 0;
@@ -1359,7 +1366,7 @@ static int sync_run_body(rship_ctx* c, const double* d0, int max_outer, double s
         hw[w].d = d0[w];
         hw[w].active = 1;
         hw[w].hit = -1;
-        hw[w].nf = nf_fixed ? nf_fixed : kHalfBt;
+        hw[w].nf = nf_fixed ? nf_fixed : nf_floor;
     }
     RS_HIP(hipMemcpyAsync(base + o_win, hw.data(), W * sizeof(SyncWin), hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipMemsetAsync(base + o_nact, 0, (size_t)G * nact_stride, c->stream));
@@ -1387,6 +1394,7 @@ static int sync_run_body(rship_ctx* c, const double* d0, int max_outer, double s
     lp.search_radius = search_radius;
     lp.max_outer = max_outer;
     lp.nf_fixed = nf_fixed;
+    lp.nf_floor = nf_floor;
     lp.trace = (double*)(base + o_trace);
     lp.ext_sums = ranked ? (double*)(base + o_ext) : nullptr;
 
@@ -1665,6 +1673,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     ep.lp.search_radius = search_radius;
     ep.lp.max_outer = max_outer;
     ep.lp.nf_fixed = nf_fixed;
+    ep.lp.nf_floor = kHalfBt; // (the executor runs frames of up to 256 tracks: a trial is microseconds)
     ep.win = (ExecWin*)(base + o_win);
     ep.n_win = W;
     ep.n_sel = ns;

@@ -1438,7 +1438,12 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
     }
 
     const double c_armijo = 2e-4, decay = .1, t0 = 1e-3; // :226
-    const int max_bt = 10, half_bt = 5;
+    // the fewest trials a search's first batch holds: five where a trial is cheap, one for frames of 1024 tracks and
+    // more (the largest frame over all ranks -- the agreed size class, so that every rank batches alike; the same rule
+    // as the device loop's SyncLoopParams::nf_floor).  Only the batching depends on it, never a result.
+    const int max_bt = 10;
+    int half_bt = (applied_hint_ != 0xffffffffu && applied_hint_ >= 1024u) ? 1 : 5;
+    if (const char* e = std::getenv("RSSYNC_LOOP_TRIALS_FLOOR")) { const int v = std::atoi(e); if (v >= 1 && v <= max_bt) half_bt = v; }
     const double delay_b = .3; // :260
     const double kOff = std::numeric_limits<double>::quiet_NaN();
     std::vector<double> delay_v(W, 0.0); // :261

@@ -456,3 +456,34 @@ def test_large_frame_kernels_against_the_regular_ones(N, F, step, monkeypatch):
     for key in ("L", "G", "L5", "M1", "k1"):
         np.testing.assert_array_equal(a[key], b[key])
     assert (a["it"], a["ev"]) == (b["it"], b["ev"])
+
+
+def test_trial_batching_floor_changes_nothing_but_the_batching(monkeypatch):
+    """Frames of 1024 tracks and more evaluate, in a line search's first launch, exactly as many trials as the later
+    of the last two searches needed (SyncLoopParams::nf_floor = 1; small frames keep at least five): a trial of
+    4096 x 2048 ray pairs is 0.06 ms.  Only the batching may depend on it: the device loop with the floor at 1 (the
+    default here), at 5 and at 10 (every trial at once) and the host loop return the same bits, trace rows included."""
+    import rssync_amd
+    from rssync_amd import synth
+    F, N = 12, 1100
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=23)
+    frames = list(synth.make_frames(g, 0, F, N, seed=23))
+
+    def run(floor=None, host=False):
+        if floor:
+            monkeypatch.setenv("RSSYNC_LOOP_TRIALS_FLOOR", str(floor))
+        else:
+            monkeypatch.delenv("RSSYNC_LOOP_TRIALS_FLOOR", raising=False)
+        p = rssync_amd.SyncProblem(seed=SEED, max_outer_iters=40)
+        p.SetGyroQuaternions(g.quats, g.fs, g.t0)
+        for fr in frames:
+            p.SetTrackResult(*fr)
+        p.set_host_loop(host)
+        r = p.Sync(0.02, 0, F - 1, 0.0, 0.2)       # far from the optimum: the first searches need several trials
+        return r, p.sync_trace()
+    (r1, t1), (r5, t5), (r10, t10), (rh, th) = run(), run(5), run(10), run(host=True)
+    monkeypatch.delenv("RSSYNC_LOOP_TRIALS_FLOOR", raising=False)
+    assert r1 == r5 == r10 == rh
+    for t in (t5, t10, th):
+        np.testing.assert_array_equal(t1.view(np.uint64), t.view(np.uint64))
+    assert len(t1) >= 5 and t1[:, 5].max() >= 2      # (some search did need more than one trial)

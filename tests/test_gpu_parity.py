@@ -705,6 +705,14 @@ def test_native_rccl_exchange_single_rank(small_case):
     case = dict(small_case, frames=small_case["frames"][:F])
     plain = fill(rssync_amd.SyncProblem(seed=SEED, max_outer_iters=10), case)
     nat = fill(rssync_amd.SyncProblem(seed=SEED, max_outer_iters=10), case)
+    import torch  # noqa: F401  (a host that uses torch.distributed has torch's own librccl mapped already)
+    nat.rccl_preflight()                                  # library + entry points resolve, nothing is communicated
+    lib = nat.rccl_library()
+    assert "librccl" in lib
+    with open("/proc/self/maps") as f:
+        mapped = {line.split()[-1] for line in f if "librccl" in line}
+    assert len(mapped) == 1, mapped                       # never a second RCCL runtime beside the process's own
+    assert "already loaded" in lib or "opened by name" in lib
     uid = nat.rccl_unique_id()
     assert len(uid) == 128 and any(uid)
     nat.rccl_init(uid, 0, 1)
