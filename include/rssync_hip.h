@@ -234,6 +234,10 @@ int rship_exec_supported(rship_ctx* c);
  * every task and end marker ever queued), out[2] cells of the queue ring (the numbers wrap around it), out[3] waves
  * launched; zeros before the first run (and in the CPU test double) */
 int rship_exec_stats(rship_ctx* c, uint32_t out[4]);
+/* the spline windows of the last launches: out[0] widest frame in knots, out[1] knots per fp64 window (dynamic LDS),
+ * out[2] fp32 window of the last PreSync sweep (0 = the 80 knots compiled in, else knots of dynamic LDS), out[3] its
+ * candidates per workgroup, out[4] as out[2] for the last GuessMotion search, out[5] delays per pass of the trials' kernel */
+int rship_window_info(rship_ctx* c, uint32_t out[6]);
 int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream_first, uint32_t stream_stride, uint64_t seed,
                     int max_outer, double search_center, double search_radius, double* d_out, double* cost, int32_t* iters,
                     double* trace, uint32_t trace_rows);

@@ -6,7 +6,9 @@ namespace {
 
 
 constexpr int kBlock = 256;
-constexpr int kWinMax = 80;  // knots of the spline staged in LDS per workgroup (5 KB)
+constexpr int kWinMax = 80;  // knots of the spline window that is a compile-time part of a workgroup's LDS (5 KB fp32 / 10 KB fp64):
+                             // a frame spans 0.044 s x gyro rate knots, so this covers rates up to ~1.7 kHz.  Higher rates run
+                             // the same code with the window in DYNAMIC LDS, sized per problem (CAP = 0 below, Spline::cap).
 constexpr uint32_t kInfBits = 0x7f800000u;
 
 // ---------------------------------------------------------------------------
@@ -102,10 +104,11 @@ __device__ __forceinline__ bool finite_f(float x) { return (__float_as_uint(x) &
 
 struct Spline {
     const f4* __restrict__ g; // global table, 4 f4 per knot
-    const f4* lds;            // [4][kWinMax]
+    const f4* lds;            // [4][capacity]
     int n;                    // knots
     int w0, wlen;             // staged range [w0, w0 + wlen)
     int path;                 // kPathGlobal / kPathLds / kPathInterior, uniform over the workgroup
+    int cap;                  // capacity of the window when it is not a compile-time constant (CAP = 0)
 };
 
 // How a workgroup reads spline coefficients.  The choice is made once per workgroup from the knot
@@ -114,23 +117,25 @@ struct Spline {
 constexpr int kPathGlobal = 0;   // general: any parameter (extrapolation branches included), table read from L2
 constexpr int kPathInterior = 2; // staged in LDS and strictly inside the knots (0 <= idx <= n-2)
 
-// CAP = knots the LDS window holds (a compile-time constant: it is the stride between the four coefficient
-// kinds, folded into the ds_read offsets)
+// CAP = knots the LDS window holds: a compile-time constant (it is the stride between the four coefficient
+// kinds, folded into the ds_read offsets) or 0 = s.cap, set by the caller (a window in dynamic LDS sized for the
+// problem's gyro rate: three more address additions per fetch)
 template <int CAP = kWinMax>
 __device__ __forceinline__ void stage_window(Spline& s, f4* s_win, int lo, int hi, int n_threads = kBlock) {
+    const int cap = CAP ? CAP : s.cap;
     const int n = s.n;
     const bool interior = lo >= 0 && hi <= n - 2;
     lo = lo < 0 ? 0 : (lo > n - 1 ? n - 1 : lo);
     hi = hi < 0 ? 0 : (hi > n - 1 ? n - 1 : hi);
     int wlen = hi - lo + 1;
-    s.path = (wlen <= CAP && interior) ? kPathInterior : kPathGlobal;
-    if (wlen > CAP) wlen = CAP;
+    s.path = (wlen <= cap && interior) ? kPathInterior : kPathGlobal;
+    if (wlen > cap) wlen = cap;
     s.w0 = lo;
     s.wlen = wlen;
     s.lds = s_win;
     for (int e = threadIdx.x; e < wlen * 4; e += n_threads) {
         int knot = e >> 2, kind = e & 3;
-        s_win[kind * CAP + knot] = s.g[(size_t)(lo + knot) * 4 + kind];
+        s_win[kind * cap + knot] = s.g[(size_t)(lo + knot) * 4 + kind];
     }
 }
 
@@ -140,11 +145,12 @@ __device__ __forceinline__ void fetch_coef(const Spline& s, int ci, f4& y, f4& b
         const f4* p = s.g + (size_t)ci * 4;
         y = p[0]; b = p[1]; c = p[2]; d = p[3];
     } else {
+        const int cap = CAP ? CAP : s.cap;
         const int rel = ci - s.w0;
         y = s.lds[rel];
-        b = s.lds[CAP + rel];
-        c = s.lds[2 * CAP + rel];
-        d = s.lds[3 * CAP + rel];
+        b = s.lds[cap + rel];
+        c = s.lds[2 * cap + rel];
+        d = s.lds[3 * cap + rel];
     }
 }
 

@@ -343,19 +343,23 @@ __device__ __forceinline__ void exec_decide(const ExecParams& p, uint32_t w, Exe
 #endif
 }
 
-// LDS of one executor wave: the search's tile and fp32 window, the fp64 window and L-BFGS history; the decisions
-// reuse the fp64 window as staging for a window's per-slot values
+// LDS of one executor wave: the search's tile, the L-BFGS history, a window record -- and, as the launch's dynamic
+// LDS, ONE region of win_cap x 128 bytes that is in turn the search's fp32 spline window, the fp64 spline window of
+// the motion / loss tasks and the decisions' staging area for a window's per-slot values (a task is one of these at
+// a time).  win_cap >= kWinMax is the problem's (rship_sync_exec), so high gyro rates stay on the LDS paths; fewer
+// waves then share a CU.
 template <int RPT>
 struct ExecLds {
-    LmedsSmallLds<RPT> small;
+    LmedsSmallLds<RPT, 0> small;
     MotionLds<1> mo;
     ExecWin win;
 };
-static_assert(sizeof(d4) * 4 * kWinMax >= kExecStage * sizeof(double), "staging area");
+static_assert(sizeof(d4) * 4 * kWinMax >= kExecStage * sizeof(double), "staging area (win_cap >= kWinMax)");
 
 template <int RPT> // rows per lane of the one-wave kernels: frames of up to 64 * RPT tracks
 __global__ __launch_bounds__(64) void sync_exec_kernel(ExecParams p) {
     __shared__ ExecLds<RPT> lds;
+    extern __shared__ d4 s_exec_region[]; // [4 * win_cap] d4 = win_cap x 128 bytes
     const int lane = threadIdx.x;
     for (;;) {
         uint32_t slot;
@@ -370,22 +374,22 @@ __global__ __launch_bounds__(64) void sync_exec_kernel(ExecParams p) {
         const uint32_t w = p.grp[slot];
         EXEC_T0();
         if (ph == kPhInit) {
-            lmeds_small_body<RPT, 1, true>(p.init, slot, 0u, lds.small);
+            lmeds_small_body<RPT, 1, true, 0>(p.init, slot, 0u, lds.small, reinterpret_cast<f4*>(s_exec_region));
         } else if (ph == kPhMotion) {
             // the frame's loss and derivative at x0 with the motion estimate just found (handed over in registers:
             // the values the body has stored)
             double mk[4];
-            opt_motion64_body<RPT, 1, true>(p.mo, slot, lds.mo, mk);
+            opt_motion64_body<RPT, 1, true>(p.mo, slot, lds.mo, s_exec_region, mk);
             const d3 Mv = d3{mk[0], mk[1], mk[2]};
             double Lv, Gv;
-            loss64_wave<true>(p.lo, slot, Mv, mk[3], ld_m<true>(&p.lg_kd[w]), ld_m<true>(&p.lg_fd[w]), lds.mo.win, Lv, Gv);
+            loss64_wave<true>(p.lo, slot, Mv, mk[3], ld_m<true>(&p.lg_kd[w]), ld_m<true>(&p.lg_fd[w]), s_exec_region, Lv, Gv);
             if (lane == 0) { st_m<true>(&p.part[slot], Lv); st_m<true>(&p.part[(size_t)p.n_sel + slot], Gv); }
         } else if (ph == kPhTrials || ph == kPhFinal) {
             const d3 Mv = d3{ld_m<true>(&p.lo.M[3 * slot]), ld_m<true>(&p.lo.M[3 * slot + 1]), ld_m<true>(&p.lo.M[3 * slot + 2])};
             const double kk = ld_m<true>(&p.lo.k[slot]);
             if (ph == kPhFinal) {
                 double Lv, Gv;
-                loss64_wave<false>(p.lo, slot, Mv, kk, ld_m<true>(&p.lg_kd[w]), ld_m<true>(&p.lg_fd[w]), lds.mo.win, Lv, Gv);
+                loss64_wave<false>(p.lo, slot, Mv, kk, ld_m<true>(&p.lg_kd[w]), ld_m<true>(&p.lg_fd[w]), s_exec_region, Lv, Gv);
                 if (lane == 0) st_m<true>(&p.part[slot], Lv);
             } else {
                 // the window's ten trial delays in ONE round trip (lane i fetches trial i; a load past L1 takes ~1.5 us,
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(64) void sync_exec_kernel(ExecParams p) {
                     const double fd = read_lane_d(my_fd, i);
                     if (fd != fd) continue; // not asked for
                     double Lv, Gv;
-                    loss64_wave<false>(p.lo, slot, Mv, kk, __builtin_amdgcn_readlane(my_kd, i), fd, lds.mo.win, Lv, Gv);
+                    loss64_wave<false>(p.lo, slot, Mv, kk, __builtin_amdgcn_readlane(my_kd, i), fd, s_exec_region, Lv, Gv);
                     if (lane == 0) st_m<true>(&p.part[(size_t)i * p.n_sel + slot], Lv);
                 }
             }
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(64) void sync_exec_kernel(ExecParams p) {
         left = uniform_u32(left);
         if (left == 1u) { // the last task of the window's phase: the add has returned, the others' results are there
             EXEC_T0();
-            exec_decide(p, w, &lds.win, (double*)lds.mo.win);
+            exec_decide(p, w, &lds.win, (double*)s_exec_region);
             EXEC_ADD(5, 13);
         }
     }

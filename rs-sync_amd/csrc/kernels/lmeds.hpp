@@ -61,6 +61,9 @@ struct LmedsParams {
     // gridDim.x x scratch_rows x 5 floats
     float* scratch;
     uint32_t scratch_rows;
+    // knots the spline window in DYNAMIC LDS holds (the WIN = 0 / CAP = 0 instantiations: gyro rates whose frames
+    // span more than kWinMax knots); the launch passes win_cap * 64 bytes of dynamic LDS
+    uint32_t win_cap;
 };
 
 // ---- LMedS tile in LDS, struct-of-arrays: unit rows n = safe_normalize(P).  The norms |P|
@@ -370,7 +373,10 @@ constexpr uint32_t kLazyElems = RSSYNC_K2_LAZY_ELEMS;
 #endif
 constexpr int kContCap = 24; // contender records per candidate; beyond that a hypothesis closes its bracket at once
 
-// WIN = knots of the LDS spline window (kWinMax in the product).  Round 2 measured a 28-knot window with a
+// WIN = knots of the LDS spline window: kWinMax, a compile-time part of the workgroup's LDS, or 0 = p.win_cap knots in
+// DYNAMIC LDS (gyro rates above ~1.7 kHz: a frame spans more than kWinMax knots; the host sizes the window for the
+// problem and shortens the candidate chunk so that frame + chunk fit -- fewer workgroups per CU, three more address
+// additions per coefficient fetch, but still the interior path).  Round 2 measured a 28-knot window with a
 // 24-entry direction buffer: 27,088 B of LDS and 80 VGPRs, SIX workgroups per CU instead of five (the occupancy
 // API confirmed it) -- and the same launch time within 0.1 %, while four workgroups per CU had been 12 % slower
 // than five: beyond five waves per SIMD the kernel no longer gains from more resident waves.
@@ -380,7 +386,14 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     constexpr int ROWS = kBlock * RPT;
     constexpr int NR = 4 * RPT; // residual registers per lane: a wave spans the whole tile
     __shared__ __attribute__((aligned(16))) float s_n[3][ROWS];
-    __shared__ f4 s_win[4 * WIN];
+    f4* s_win;
+    if constexpr (WIN != 0) {
+        __shared__ f4 s_win_static[4 * WIN];
+        s_win = s_win_static;
+    } else {
+        extern __shared__ f4 s_win_dynamic[];
+        s_win = s_win_dynamic;
+    }
     __shared__ f4 s_hyp[kHyp];
     __shared__ double s_red[2][4];
     // best (quantile, hypothesis) so far, packed (bits << 32 | h): a 64-bit min is exactly
@@ -431,6 +444,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     Spline sp;
     sp.g = p.coef;
     sp.n = p.n_knots;
+    sp.cap = (int)p.win_cap;
     {
         int kd_lo = p.kd[c0 * p.n_grp + g], kd_hi = kd_lo;
         for (uint32_t c = c0 + 1; c < c1; ++c) {

@@ -20,20 +20,23 @@ namespace {
 constexpr int kSmallMaxRpt = 4; // 256 tracks
 
 // LDS of one wave's work on a (frame, chunk): the kernel below owns one; the window executor (executor.hpp) lends its own
-template <int RPT>
+// CAP = knots of the spline window inside this struct (kWinMax), or 0 = the window lives elsewhere (dynamic LDS sized
+// for the problem's gyro rate; the body is given the pointer and reads the capacity from LmedsParams::win_cap)
+template <int RPT, int CAP = kWinMax>
 struct LmedsSmallLds {
     float n[3][64 * RPT]; // unit rows, for the hypotheses' row pairs
-    f4 win[4 * kWinMax];
+    f4 win[CAP ? 4 * CAP : 1];
     int kd[kMaxChunk];
     float fd[kMaxChunk];
 };
 
 // the work of one wave (64 threads, the whole workgroup) on slot sf, chunk `chunk`
-template <int RPT, int MODE, bool SC1 = false> // SC1: the delays, the stream and the winners are shared with other workgroups of this launch
-__device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t sf, uint32_t chunk, LmedsSmallLds<RPT>& lds) {
+template <int RPT, int MODE, bool SC1 = false, int CAP = kWinMax> // SC1: the delays, the stream and the winners are shared with other workgroups of this launch
+__device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t sf, uint32_t chunk, LmedsSmallLds<RPT, CAP>& lds,
+                                                 f4* dyn_win = nullptr) {
     constexpr int kHyp = kHypBatch;
     float (&s_n)[3][64 * RPT] = lds.n;
-    f4* s_win = lds.win;
+    f4* s_win = CAP ? lds.win : dyn_win;
     int* s_kd = lds.kd;
     float* s_fd = lds.fd;
     const int lane = threadIdx.x;
@@ -56,6 +59,7 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
     Spline sp;
     sp.g = p.coef;
     sp.n = p.n_knots;
+    sp.cap = (int)p.win_cap;
     {
         int kd_lo = ld_m<SC1>(&p.kd[c0 * p.n_grp + g]), kd_hi = kd_lo;
         for (uint32_t c = c0 + 1; c < c1; ++c) {
@@ -63,7 +67,7 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
             kd_lo = v < kd_lo ? v : kd_lo;
             kd_hi = v > kd_hi ? v : kd_hi;
         }
-        stage_window<kWinMax>(sp, s_win, fr.base_knot + (int)floorf(fr.tmin) + kd_lo, fr.base_knot + (int)floorf(fr.tmax) + kd_hi + 1, 64);
+        stage_window<CAP>(sp, s_win, fr.base_knot + (int)floorf(fr.tmin) + kd_lo, fr.base_knot + (int)floorf(fr.tmax) + kd_hi + 1, 64);
     }
     __syncthreads();
 
@@ -89,8 +93,8 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
                 nrm[j] = 0.f;
                 if (row < N) {
                     f3 P, dP;
-                    if (sp.path == kPathInterior) residual_row<false, kPathInterior, MODE == 0, kWinMax, NEWTON>(sp, A, B, base, fd, P, dP, qerr);
-                    else residual_row<false, kPathGlobal, false, kWinMax>(sp, A, B, base, fd, P, dP);
+                    if (sp.path == kPathInterior) residual_row<false, kPathInterior, MODE == 0, CAP, NEWTON>(sp, A, B, base, fd, P, dP, qerr);
+                    else residual_row<false, kPathGlobal, false, CAP>(sp, A, B, base, fd, P, dP);
                     const float n2 = rs::dot(P, P);
                     if (!finite_f(n2)) bad = RSHIP_BAD_P;
                     const bool tiny = n2 < 1e-24f; // safe_normalize (core_private.cpp:35-36)
@@ -211,10 +215,15 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
     }
 }
 
-template <int RPT, int MODE>
+template <int RPT, int MODE, int CAP = kWinMax>
 __global__ __launch_bounds__(64, RPT <= 3 ? 6 : 5) void lmeds_small_kernel(LmedsParams p) {
-    __shared__ LmedsSmallLds<RPT> lds;
-    lmeds_small_body<RPT, MODE>(p, blockIdx.x / p.n_chunks, blockIdx.x % p.n_chunks, lds);
+    __shared__ LmedsSmallLds<RPT, CAP> lds;
+    f4* dyn = nullptr;
+    if constexpr (CAP == 0) {
+        extern __shared__ f4 s_small_win_dynamic[];
+        dyn = s_small_win_dynamic;
+    }
+    lmeds_small_body<RPT, MODE, false, CAP>(p, blockIdx.x / p.n_chunks, blockIdx.x % p.n_chunks, lds, dyn);
 }
 
 } // namespace

@@ -22,14 +22,18 @@ using rs::d3;
 using rs::d4;
 
 // ---------------------------------------------------------------------------
-// fp64 spline window in LDS: [kind][knot] of d4 (32 B), 10 KB at kWinMax = 80 knots
+// fp64 spline window in LDS: [kind][knot] of d4 (32 B), 10 KB at 80 knots.  The window lives in DYNAMIC LDS and its
+// capacity is a launch parameter (Spline64::cap, >= kWinMax): the host sizes it for the problem's widest frame, so
+// that gyro rates above ~1.7 kHz (a frame spans 0.044 s x rate knots) stay on the LDS paths; the stride between the
+// coefficient kinds is then a run-time value -- three integer additions per fetch beside ~150 fp64 instructions.
 
 struct Spline64 {
     const d4* __restrict__ g; // global table, 4 d4 per knot
-    const d4* lds;            // [4][kWinMax]
+    const d4* lds;            // [4][cap]
     int n;
     int w0, wlen;
     int path; // kPathGlobal / kPathLds64 / kPathInterior, uniform over the workgroup
+    int cap;  // knots the window holds (set by the caller before staging)
 };
 
 // the general parameter logic (extrapolation branches) with the coefficients from the LDS window: a delay that puts a
@@ -37,34 +41,38 @@ struct Spline64 {
 // of the CLAMPED range, which is what gets staged (round 3: those delays read the table from L2, 15-35 % slower)
 constexpr int kPathLds64 = 1;
 
+// CAP = compile-time capacity (the stride between the coefficient kinds folds into the ds_read offsets: the five-window
+// loss kernel is at its register limit) or 0 = s.cap
+template <int CAP = 0>
 __device__ __forceinline__ void stage_window64(Spline64& s, d4* s_win, int lo, int hi) {
     const int n = s.n;
     const bool interior = lo >= 0 && hi <= n - 2;
     lo = lo < 0 ? 0 : (lo > n - 1 ? n - 1 : lo);
     hi = hi < 0 ? 0 : (hi > n - 1 ? n - 1 : hi);
     int wlen = hi - lo + 1;
-    s.path = wlen <= kWinMax ? (interior ? kPathInterior : kPathLds64) : kPathGlobal;
-    if (wlen > kWinMax) wlen = kWinMax;
+    const int cap = CAP ? CAP : s.cap;
+    s.path = wlen <= cap ? (interior ? kPathInterior : kPathLds64) : kPathGlobal;
+    if (wlen > cap) wlen = cap;
     s.w0 = lo;
     s.wlen = wlen;
     s.lds = s_win;
     for (int e = threadIdx.x; e < wlen * 4; e += blockDim.x) {
         int knot = e >> 2, kind = e & 3;
-        s_win[kind * kWinMax + knot] = s.g[(size_t)(lo + knot) * 4 + kind];
+        s_win[kind * cap + knot] = s.g[(size_t)(lo + knot) * 4 + kind];
     }
 }
 
-template <int PATH>
+template <int PATH, int CAP = 0>
 __device__ __forceinline__ void fetch_coef64(const Spline64& s, int ci, d4& y, d4& b, d4& c, d4& d) {
     if (PATH == kPathGlobal) {
         const d4* p = s.g + (size_t)ci * 4;
         y = p[0]; b = p[1]; c = p[2]; d = p[3];
     } else {
-        const int rel = ci - s.w0;
+        const int rel = ci - s.w0, cap = CAP ? CAP : s.cap;
         y = s.lds[rel];
-        b = s.lds[kWinMax + rel];
-        c = s.lds[2 * kWinMax + rel];
-        d = s.lds[3 * kWinMax + rel];
+        b = s.lds[cap + rel];
+        c = s.lds[2 * cap + rel];
+        d = s.lds[3 * cap + rel];
     }
 }
 
@@ -77,16 +85,16 @@ struct Rays64 {
 };
 
 // one row of P = ar x br (core_private.cpp:24-28) and, if DERIV, dP/dx (x in knots), in fp64
-template <bool DERIV, int PATH>
+template <bool DERIV, int PATH, int CAP = 0>
 __device__ __forceinline__ void residual_row64(const Spline64& s, double2 X, double2 Y, double2 Z, double2 T, int base, double fd,
                                                d3& P, d3& dP) {
     d4 ya, ba, ca, da, yb, bb, cb, db;
     const rs::KnotT<double> ka = (PATH == kPathInterior) ? rs::spline_locate_interior(T.x, base, fd)
                                                          : rs::spline_locate(T.x, base, fd, s.n);
-    fetch_coef64<PATH>(s, ka.ci, ya, ba, ca, da);
+    fetch_coef64<PATH, CAP>(s, ka.ci, ya, ba, ca, da);
     const rs::KnotT<double> kb = (PATH == kPathInterior) ? rs::spline_locate_interior(T.y, base, fd)
                                                          : rs::spline_locate(T.y, base, fd, s.n);
-    fetch_coef64<PATH>(s, kb.ci, yb, bb, cb, db);
+    fetch_coef64<PATH, CAP>(s, kb.ci, yb, bb, cb, db);
     d3 ar, br, dar, dbr;
     rs::rotate_ray<DERIV>(ya, ba, ca, da, ka, d3{X.x, Y.x, Z.x}, ar, dar);
     rs::rotate_ray<DERIV>(yb, bb, cb, db, kb, d3{X.y, Y.y, Z.y}, br, dbr);
@@ -94,21 +102,23 @@ __device__ __forceinline__ void residual_row64(const Spline64& s, double2 X, dou
     if (DERIV) dP = rs::add(rs::cross(dar, br), rs::cross(ar, dbr));
 }
 
-template <bool DERIV>
-__device__ __forceinline__ void residual_row64(const Spline64& s, double2 X, double2 Y, double2 Z, double2 T, int base, double fd,
-                                               d3& P, d3& dP) {
-    if (s.path == kPathInterior) residual_row64<DERIV, kPathInterior>(s, X, Y, Z, T, base, fd, P, dP);
-    else if (s.path == kPathLds64) residual_row64<DERIV, kPathLds64>(s, X, Y, Z, T, base, fd, P, dP);
-    else residual_row64<DERIV, kPathGlobal>(s, X, Y, Z, T, base, fd, P, dP);
+// (the path is uniform over the workgroup: chosen when the window was staged)
+template <bool DERIV, int CAP = 0>
+__device__ __forceinline__ void residual_row64_auto(const Spline64& s, double2 X, double2 Y, double2 Z, double2 T, int base, double fd,
+                                                    d3& P, d3& dP) {
+    if (s.path == kPathInterior) residual_row64<DERIV, kPathInterior, CAP>(s, X, Y, Z, T, base, fd, P, dP);
+    else if (s.path == kPathLds64) residual_row64<DERIV, kPathLds64, CAP>(s, X, Y, Z, T, base, fd, P, dP);
+    else residual_row64<DERIV, kPathGlobal, CAP>(s, X, Y, Z, T, base, fd, P, dP);
 }
 template <bool DERIV>
 __device__ __forceinline__ void residual_row64(const Spline64& s, const Rays64& r, size_t idx, int base, double fd, d3& P,
                                                d3& dP) {
-    residual_row64<DERIV>(s, r.q0[idx], r.q1[idx], r.q2[idx], r.q3[idx], base, fd, P, dP);
+    residual_row64_auto<DERIV>(s, r.q0[idx], r.q1[idx], r.q2[idx], r.q3[idx], base, fd, P, dP);
 }
 
+template <int CAP = 0>
 __device__ __forceinline__ void frame_window64(Spline64& sp, d4* s_win, const FrameRec& fr, int kd) {
-    stage_window64(sp, s_win, fr.base_knot + (int)floor(fr.tmin64) + kd, fr.base_knot + (int)floor(fr.tmax64) + kd + 1);
+    stage_window64<CAP>(sp, s_win, fr.base_knot + (int)floor(fr.tmin64) + kd, fr.base_knot + (int)floor(fr.tmax64) + kd + 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -137,6 +147,8 @@ struct Loss64Params {
     double* part_loss; // [n_delays][n_sel]
     double* part_grad; // [n_delays][n_sel] (GRAD)
     uint32_t slot0;    // the launch covers slots slot0 .. slot0 + gridDim.x (a group of windows on its own stream)
+    uint32_t win_cap;  // knots per spline window (dynamic LDS: nb_run x win_cap x 128 bytes; one window in the one-wave kernel)
+    uint32_t nb_run;   // delays evaluated per pass over the rows: kLossBatch while their windows fit the LDS, fewer for wide frames
 };
 
 // delays evaluated per pass over the rows: every ray pair is read once for kLossBatch delays (their spline
@@ -144,14 +156,29 @@ struct Loss64Params {
 // 1e-3 .. 1e-12 times the gradient), so the windows cannot be shared; the rays can.  A pass per delay made
 // this kernel HBM/L2-bound (64 B per ray pair per delay: 6.5 TB/s effective at 4096 x 2048).
 constexpr int kLossBatch = 5; // (6, at two workgroups per CU: 5 % slower)
+constexpr int kLossBatchWide = 2; // the same for frames wider than kWinMax knots (windows in dynamic LDS: two up to 200 knots, one beyond)
 
 // RPT = rows per thread the launch covers (the largest frame's); 0 = as many as this frame needs (frames of more
 // than 8192 tracks).  A thread adds its rows in order either way, so a frame's sums do not depend on RPT.
-template <int RPT, bool GRAD, bool SIMPLE>
+// CAP = knots per spline window: kWinMax compiled in (the five-window kernel of the line search's trials, whose
+// registers leave no room for a run-time stride) or 0 = p.win_cap knots in dynamic LDS (the gradient kernel always:
+// one window; the trials' kernel for frames wider than kWinMax knots, with p.nb_run <= kLossBatchWide windows)
+template <int RPT, bool GRAD, bool SIMPLE, int CAP = 0>
 __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
-    constexpr int NB = GRAD ? 1 : kLossBatch;
-    __shared__ d4 s_win[NB][4 * kWinMax];
+    constexpr int NB = GRAD ? 1 : (CAP ? kLossBatch : kLossBatchWide);
+    d4* s_loss_win;
+    uint32_t win_cap;
+    if constexpr (CAP != 0) {
+        __shared__ d4 s_loss_win_static[NB * 4 * CAP];
+        s_loss_win = s_loss_win_static;
+        win_cap = CAP;
+    } else {
+        extern __shared__ d4 s_loss_win_dynamic[]; // [nb_run][4 * win_cap]
+        s_loss_win = s_loss_win_dynamic;
+        win_cap = p.win_cap;
+    }
     __shared__ double s_red[NB][2][4];
+    const uint32_t nb_run = (GRAD || CAP) ? (uint32_t)NB : (p.nb_run < (uint32_t)NB ? (p.nb_run ? p.nb_run : 1u) : (uint32_t)NB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t sf = blockIdx.x + p.slot0;
     const uint32_t g = p.grp ? p.grp[sf] : 0u;
@@ -180,7 +207,7 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
     // r = (P.M) k / |M|  (core_private.cpp:120)  ->  u = (P.M)^2 * inv_s;  SIMPLE: u = |P|^2 k^2
     const double inv_s = rs::loss_inv_s(SIMPLE, kk, Mv);
 
-    for (uint32_t b0 = 0; b0 < p.n_delays; b0 += NB) {
+    for (uint32_t b0 = 0; b0 < p.n_delays; b0 += nb_run) {
         Spline64 sp[NB];
         int base[NB];
         double fdv[NB];
@@ -189,14 +216,14 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const uint32_t b = b0 + q;
-            on[q] = b < p.n_delays;
+            on[q] = (uint32_t)q < nb_run && b < p.n_delays;
             kdv[q] = on[q] ? p.kd[b * p.n_grp + g] : 0;
             fdv[q] = on[q] ? p.fd[b * p.n_grp + g] : 0.0;
             if (fdv[q] != fdv[q]) on[q] = false; // window switched off for this evaluation (workgroup-uniform)
             any_on = any_on || on[q];
         }
         if (!any_on) { // a whole batch of skipped delays
-            if (tid < NB && b0 + tid < p.n_delays) {
+            if ((uint32_t)tid < nb_run && b0 + tid < p.n_delays) {
                 p.part_loss[(size_t)(b0 + tid) * p.n_sel + sf] = 0.0;
                 if (GRAD) p.part_grad[(size_t)(b0 + tid) * p.n_sel + sf] = 0.0;
             }
@@ -207,8 +234,9 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
         for (int q = 0; q < NB; ++q) {
             sp[q].g = p.coef;
             sp[q].n = p.n_knots;
+            sp[q].cap = (int)win_cap;
             base[q] = fr.base_knot + kdv[q];
-            if (on[q]) frame_window64(sp[q], s_win[q], fr, kdv[q]);
+            if (on[q]) frame_window64<CAP>(sp[q], s_loss_win + (size_t)q * 4 * win_cap, fr, kdv[q]);
         }
         __syncthreads();
         double L[NB], G[NB];
@@ -225,7 +253,7 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
                 for (int q = 0; q < NB; ++q) {
                     if (!on[q]) continue;
                     d3 P, dP;
-                    residual_row64<GRAD>(sp[q], X, Y, Z, T, base[q], fdv[q], P, dP);
+                    residual_row64_auto<GRAD, CAP>(sp[q], X, Y, Z, T, base[q], fdv[q], P, dP);
                     rs::loss_row<GRAD, SIMPLE>(P, dP, Mv, inv_s, L[q], G[q]); // core_private.cpp:121-122
                 }
             }
@@ -240,7 +268,7 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
             }
         }
         __syncthreads();
-        if (tid < NB && b0 + tid < p.n_delays) {
+        if ((uint32_t)tid < nb_run && b0 + tid < p.n_delays) {
             const uint32_t b = b0 + tid;
             const double fdb = p.fd[b * p.n_grp + g];
             const bool live = fdb == fdb;
@@ -269,6 +297,7 @@ __device__ __forceinline__ void loss64_wave(const Loss64Params& q, uint32_t sf, 
     Spline64 sp;
     sp.g = q.coef;
     sp.n = q.n_knots;
+    sp.cap = (int)q.win_cap;
     __syncthreads(); // the window's previous users are done
     frame_window64(sp, s_win, fr, kd);
     __syncthreads();
@@ -284,7 +313,7 @@ __device__ __forceinline__ void loss64_wave(const Loss64Params& q, uint32_t sf, 
             if (row < N) {
                 const size_t idx = (size_t)fr.off + row;
                 d3 P, dP;
-                residual_row64<GRAD>(sp, q.rays.q0[idx], q.rays.q1[idx], q.rays.q2[idx], q.rays.q3[idx], base, fd, P, dP);
+                residual_row64_auto<GRAD>(sp, q.rays.q0[idx], q.rays.q1[idx], q.rays.q2[idx], q.rays.q3[idx], base, fd, P, dP);
                 rs::loss_row<GRAD, SIMPLE>(P, dP, Mv, inv_s, L, G);
             }
             Lw[w] = wave_sum_f64(L);
@@ -299,7 +328,7 @@ __device__ __forceinline__ void loss64_wave(const Loss64Params& q, uint32_t sf, 
 // tests/test_gpu_mid_sizes.py::test_one_wave_loss_kernel_equals_the_workgroup_kernel)
 template <bool GRAD, bool SIMPLE>
 __global__ __launch_bounds__(64, 3) void loss64_small_kernel(Loss64Params p) {
-    __shared__ d4 s_win[4 * kWinMax];
+    extern __shared__ d4 s_win[]; // [4 * win_cap]
     const int lane = threadIdx.x;
     const uint32_t sf = blockIdx.x + p.slot0;
     const uint32_t g = p.grp ? p.grp[sf] : 0u;
@@ -366,6 +395,7 @@ struct Motion64Params {
     // n_sel x 3 x scratch_rows doubles (per slot: x, y, z planes; scratch_rows a multiple of the workgroup size)
     double* scratch;
     uint32_t scratch_rows;
+    uint32_t win_cap; // knots of the spline window (dynamic LDS: win_cap x 128 bytes)
 };
 
 // -DRSSYNC_K3_TIMING=1 (with -DRSSYNC_K2_COUNTERS=1, whose counter array it shares): core-clock ticks of wave 0 of
@@ -473,9 +503,9 @@ struct LbfgsHistLds {
 __device__ __forceinline__ double clamp_k(double k) { return rs::clamp_k64(k); } // inline_utils.hpp:50
 
 // LDS of one workgroup's work on a slot: the kernel below owns one; the window executor (executor.hpp) lends its own
+// (the spline window, win_cap x 128 bytes, is the kernel's dynamic LDS and handed to the body separately)
 template <int NW>
 struct MotionLds {
-    d4 win[4 * kWinMax];
     double part[2][NW][4];
     double S[kNB][3], Y[kNB][3];
     // two-loop scratch: every thread writes the same values and reads them back itself;
@@ -486,9 +516,8 @@ struct MotionLds {
 };
 
 template <int RPT, int NW, bool SC1 = false> // SC1: M, k, the pending winners and the delays are written by other workgroups of this launch
-__device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint32_t sf, MotionLds<NW>& lds, double* mk_out = nullptr) {
+__device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint32_t sf, MotionLds<NW>& lds, d4* s_win, double* mk_out = nullptr) {
     constexpr int kThreads = 64 * NW;
-    d4* s_win = lds.win;
     double (*s_part)[NW][4] = lds.part;
     double (*s_S)[3] = lds.S;
     double (*s_Y)[3] = lds.Y;
@@ -517,6 +546,7 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
     Spline64 sp;
     sp.g = p.coef;
     sp.n = p.n_knots;
+    sp.cap = (int)p.win_cap;
     frame_window64(sp, s_win, fr, kd);
     __syncthreads();
 
@@ -625,7 +655,8 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
 template <int RPT, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? (RPT == 0 ? 2 : (RPT <= 8 ? 3 : (RPT == 16 ? 2 : 1))) : (NW == 1 ? (RPT >= 8 ? 3 : 4) : 2)) void opt_motion64_kernel(Motion64Params p) {
     __shared__ MotionLds<NW> lds;
-    opt_motion64_body<RPT, NW>(p, p.order ? p.order[blockIdx.x + p.slot0] : blockIdx.x + p.slot0, lds);
+    extern __shared__ d4 s_motion_win[]; // [4 * win_cap]
+    opt_motion64_body<RPT, NW>(p, p.order ? p.order[blockIdx.x + p.slot0] : blockIdx.x + p.slot0, lds, s_motion_win);
 }
 
 // order[slot0 .. slot0 + count) = the slots slot0 .. slot0 + count sorted by evals[] descending (a counting sort over
@@ -677,6 +708,7 @@ __global__ __launch_bounds__(kBlock) void debug_problem64_kernel(Debug64Params p
     Spline64 sp;
     sp.g = p.coef;
     sp.n = p.n_knots;
+    sp.cap = kWinMax;
     frame_window64(sp, s_win, fr, p.kd);
     __syncthreads();
     for (uint32_t row = blockIdx.x * kBlock + threadIdx.x; row < fr.n; row += gridDim.x * kBlock) {

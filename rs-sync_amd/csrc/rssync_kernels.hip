@@ -24,7 +24,6 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
-#include <link.h>
 
 #include <algorithm>
 #include <cmath>
@@ -111,6 +110,8 @@ struct rship_ctx {
     double fs = 0;
     int lbfgs_reeval = 0; // RSHIP_OPT_LBFGS_REEVAL
     uint32_t tracks_hint = 0; // RSHIP_OPT_TRACKS_HINT
+    bool force_general = false;   // RSSYNC_FORCE_GENERAL_SPLINE=1 (read at creation; tools/gpu_gyro_rate.py's "before" column): no dynamic
+                                  // spline windows -- frames wider than 80 knots take the general path (table from L2), as in rounds 1-3
     bool force_big = false;       // RSSYNC_FORCE_BIG=1 (tests): every frame through the kernels for frames of more than 8192 tracks
     bool no_small_loss = false;   // RSSYNC_NO_SMALL_LOSS=1 (A/B): frames of up to 256 tracks in the four-wave loss kernel
     bool no_motion_order = false; // RSSYNC_NO_MOTION_ORDER=1 (A/B): the motion kernel's workgroups in slot order, not longest-first
@@ -118,6 +119,12 @@ struct rship_ctx {
                                  // selection of every quartile instead of the lazy one (A/B tests: identical results)
     bool no_small_lmeds = false; // RSSYNC_NO_SMALL_LMEDS=1 (read once, at creation): the tile kernel for every frame size (A/B tests)
     float max_span = 0.f; // widest frame, in knots (frame table)
+    // knots the fp64 kernels' spline window holds (dynamic LDS, 128 bytes per knot): the widest frame of the table,
+    // at least kWinMax, at most kCap64Max (beyond that the kernels read the table from L2, as any frame that does not
+    // fit its window does)
+    uint32_t cap64 = 80;
+    int lds_per_cu = 160 * 1024;
+    uint32_t last_lmeds_cap = 0, last_lmeds_chunk = 0, last_init_cap = 0; // rship_window_info: what the last launches used
     // native exchange (RCCL through dlopen)
     void* rccl_lib = nullptr;
     std::string rccl_path; // which librccl the symbols come from
@@ -245,32 +252,147 @@ int rpt_for(uint32_t max_n) {
 uint32_t big_rows(const rship_ctx* c) { return (c->max_n + kBlock - 1) / kBlock * kBlock; }
 int rpt_of(const rship_ctx* c) { return c->force_big ? 0 : rpt_for(c->max_n); }
 
+// ---- spline windows in dynamic LDS (gyro rates above ~1.7 kHz: a frame spans 0.044 s x rate knots) ----
+constexpr uint32_t kCap64Max = 384;                 // 48 KB of fp64 window: one K1 window, three K3 workgroups per CU
+constexpr uint32_t kLossWinBytes = kLossBatch * kWinMax * 128u; // K1's LDS budget for its side-by-side windows (51 KB at 80 knots)
+uint32_t cap64_for(float max_span) {
+    uint32_t need = (uint32_t)std::ceil(std::max(max_span, 0.f)) + 1u;
+    need = (need + 15u) / 16u * 16u;
+    return std::min(std::max(need, (uint32_t)kWinMax), kCap64Max);
+}
+template <class K>
+uint32_t static_lds_of(K kernel) {
+    hipFuncAttributes a{};
+    if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(kernel)) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return (uint32_t)a.sharedSizeBytes;
+}
+template <class K>
+void allow_dynamic_lds(K kernel, size_t bytes) { // (more than 64 KB in all needs the opt-in on some runtimes; harmless otherwise)
+    if (bytes > 32 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        (void)hipGetLastError();
+    }
+}
+
 uint32_t sel_max_n(const rship_ctx* c) {
     uint32_t m = 0;
     for (uint32_t i : c->h_sel) m = c->h_frame_n[i] > m ? c->h_frame_n[i] : m;
     return m;
 }
 
-template <int MODE, int WIN>
-int launch_lmeds(rship_ctx* c, const LmedsParams& p, int rpt, uint32_t grid) {
+// ---- the LMedS kernels' spline window (fp32, 64 bytes per knot) ----
+// A workgroup's window must hold the widest frame plus the knots its chunk of candidate delays spans.  Up to ~1.7 kHz
+// of gyro rate that fits the kWinMax knots compiled into the kernels' LDS (the instantiations the benchmark runs).
+// Beyond, the window moves to DYNAMIC LDS (WIN = 0 instantiations), as large as the problem needs: the plan below picks
+// the largest number of workgroups per CU whose LDS share still holds the frame and a chunk of at least eight
+// candidates, then the longest chunk (<= 32) that fits.  Only when even one workgroup per CU cannot hold it do the
+// kernels fall back to the general path (table from L2).
+struct WinPlan {
+    uint32_t cap = 0;   // 0: the compiled-in kWinMax window; otherwise knots of dynamic LDS
+    uint32_t chunk = 1; // candidates per workgroup
+};
+template <int MODE>
+uint32_t lmeds_dynamic_static_lds(int rpt, bool small) {
+    if (small) {
+        switch (rpt) {
+            case 1: return static_lds_of(lmeds_small_kernel<1, MODE, 0>);
+            case 2: return static_lds_of(lmeds_small_kernel<2, MODE, 0>);
+            case 3: return static_lds_of(lmeds_small_kernel<3, MODE, 0>);
+            default: return static_lds_of(lmeds_small_kernel<4, MODE, 0>);
+        }
+    }
+    switch (rpt) {
+        case 1: return static_lds_of(lmeds_kernel<1, MODE, 0>);
+        case 2: return static_lds_of(lmeds_kernel<2, MODE, 0>);
+        case 4: return static_lds_of(lmeds_kernel<4, MODE, 0>);
+        case 8: return static_lds_of(lmeds_kernel<8, MODE, 0>);
+        case 16: return static_lds_of(lmeds_kernel<16, MODE, 0>);
+        default: return static_lds_of(lmeds_kernel<32, MODE, 0>);
+    }
+}
+// which LMedS kernel family the problem's frames get (decided from the largest frame of the whole PROBLEM, so that a
+// frame's cost does not depend on the selection or the device it is evaluated in)
+enum class LmedsKind { Small, Tile, Big };
+LmedsKind lmeds_kind(const rship_ctx* c) {
+    const uint32_t n_all = c->force_big ? 0xffffffffu : (c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n);
+    if (n_all <= 64u * kSmallMaxRpt && !c->no_small_lmeds) return LmedsKind::Small;
+    if (n_all > (uint32_t)kMaxRpt * kBlock) return LmedsKind::Big;
+    return LmedsKind::Tile;
+}
+uint32_t lmeds_all_tracks(const rship_ctx* c) { return c->force_big ? 0xffffffffu : (c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n); }
+
+template <int MODE>
+WinPlan plan_lmeds_window(rship_ctx* c, double step_knots, uint32_t chunk_want) {
+    WinPlan w;
+    w.chunk = chunk_want;
+    const LmedsKind kind = lmeds_kind(c);
+    if (kind == LmedsKind::Big) return w; // (tiles in global memory, general path throughout)
+    const double span = c->max_span;
+    const uint32_t min_chunk = std::min(8u, chunk_want);
+    auto fit = [&](double cap) -> uint32_t { // candidates whose delays fit a window of `cap` knots next to the widest frame
+        if (cap < span + 1.0) return 0;
+        if (!(step_knots > 0)) return chunk_want;
+        const double n = std::floor((cap - span - 1.0) / step_knots) + 1.0;
+        return n >= (double)chunk_want ? chunk_want : (uint32_t)n;
+    };
+    const uint32_t f80 = fit((double)kWinMax);
+    if (f80 >= min_chunk) { w.chunk = f80; return w; }
+    if (c->force_general) { // rounds 1-3: shorten the chunk down to four candidates, else let the window overflow
+        if (f80 >= 4) w.chunk = f80;
+        return w;
+    }
+    const bool small = kind == LmedsKind::Small;
+    const int rpt = small ? (int)std::max(1u, (lmeds_all_tracks(c) + 63u) / 64u) : rpt_of(c);
+    const uint32_t fixed = lmeds_dynamic_static_lds<MODE>(rpt, small);
+    if (!fixed) return w;
+    const int wg_max = small ? 20 : lmeds_waves(rpt);
+    for (int wg = wg_max; wg >= 1; --wg) {
+        const int share = c->lds_per_cu / wg - 1024; // (allocation granularity, alignment)
+        if (share <= (int)fixed) continue;
+        const uint32_t cap_t = std::min(2048u, ((uint32_t)share - fixed) / 64u / 4u * 4u);
+        const uint32_t f = fit((double)cap_t);
+        if (f < min_chunk) continue;
+        w.chunk = f;
+        const double need = span + 1.0 + (step_knots > 0 ? (f - 1) * step_knots : 0.0);
+        w.cap = std::min(cap_t, ((uint32_t)std::ceil(need) + 3u) / 4u * 4u + 4u);
+        return w;
+    }
+    return w; // does not fit any LDS share: the general path, as before
+}
+
+template <int MODE>
+int launch_lmeds(rship_ctx* c, LmedsParams p, const WinPlan& wp, int rpt, uint32_t grid) {
     ProfScope ps(c, MODE == 1 ? RSHIP_K_INIT : RSHIP_K_LMEDS);
     // Frames of up to 256 tracks (the reference's own data: ~130): one wave per (frame, chunk) instead of a
-    // four-wave workgroup (kernels/lmeds_small.hpp).  Decided from the largest frame of the whole PROBLEM, so that
-    // a frame's cost does not depend on the selection or the device it is evaluated in.
-    const uint32_t n_all = c->force_big ? 0xffffffffu : (c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n);
-    if (n_all <= 64u * kSmallMaxRpt && !c->no_small_lmeds) {
+    // four-wave workgroup (kernels/lmeds_small.hpp).
+    const uint32_t n_all = lmeds_all_tracks(c);
+    const LmedsKind kind = lmeds_kind(c);
+    p.win_cap = wp.cap ? wp.cap : (uint32_t)kWinMax;
+    const size_t dyn = (size_t)wp.cap * 64u;
+    if (kind == LmedsKind::Small) {
         const uint32_t g1 = p.n_sel * p.n_chunks;
-        switch ((n_all + 63u) / 64u) {
-            case 0:
-            case 1: hipLaunchKernelGGL((lmeds_small_kernel<1, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
-            case 2: hipLaunchKernelGGL((lmeds_small_kernel<2, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
-            case 3: hipLaunchKernelGGL((lmeds_small_kernel<3, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
-            default: hipLaunchKernelGGL((lmeds_small_kernel<4, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
+        const uint32_t r = (n_all + 63u) / 64u;
+        if (wp.cap) {
+            switch (r) {
+                case 0:
+                case 1: hipLaunchKernelGGL((lmeds_small_kernel<1, MODE, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break;
+                case 2: hipLaunchKernelGGL((lmeds_small_kernel<2, MODE, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break;
+                case 3: hipLaunchKernelGGL((lmeds_small_kernel<3, MODE, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break;
+                default: hipLaunchKernelGGL((lmeds_small_kernel<4, MODE, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break;
+            }
+        } else {
+            switch (r) {
+                case 0:
+                case 1: hipLaunchKernelGGL((lmeds_small_kernel<1, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
+                case 2: hipLaunchKernelGGL((lmeds_small_kernel<2, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
+                case 3: hipLaunchKernelGGL((lmeds_small_kernel<3, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
+                default: hipLaunchKernelGGL((lmeds_small_kernel<4, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
+            }
         }
         RS_HIP(hipGetLastError());
         return 0;
     }
-    if (n_all > (uint32_t)kMaxRpt * kBlock) {
+    if (kind == LmedsKind::Big) {
         // more than 8192 tracks somewhere in the problem: the slow exact path (kernels/lmeds_big.hpp), tiles in a
         // scratch that a fixed number of workgroups share by walking over the (frame, chunk) items
         const uint32_t rows = big_rows(c);
@@ -287,26 +409,41 @@ int launch_lmeds(rship_ctx* c, const LmedsParams& p, int rpt, uint32_t grid) {
         RS_HIP(hipGetLastError());
         return 0;
     }
+    if (wp.cap) { // the window in dynamic LDS (gyro rates above ~1.7 kHz)
+        switch (rpt) {
+            case 1: hipLaunchKernelGGL((lmeds_kernel<1, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
+            case 2: hipLaunchKernelGGL((lmeds_kernel<2, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
+            case 4: hipLaunchKernelGGL((lmeds_kernel<4, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
+            case 8: hipLaunchKernelGGL((lmeds_kernel<8, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
+            case 16: allow_dynamic_lds(lmeds_kernel<16, MODE, 0>, dyn);
+                     hipLaunchKernelGGL((lmeds_kernel<16, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
+            case 32: allow_dynamic_lds(lmeds_kernel<32, MODE, 0>, dyn);
+                     hipLaunchKernelGGL((lmeds_kernel<32, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
+            default: return set_err(c, "lmeds: unsupported rows-per-thread");
+        }
+        RS_HIP(hipGetLastError());
+        return 0;
+    }
     if (MODE == 0 && c->exact_select) {
         switch (rpt) {
-            case 1: hipLaunchKernelGGL((lmeds_kernel<1, 0, WIN, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-            case 2: hipLaunchKernelGGL((lmeds_kernel<2, 0, WIN, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-            case 4: hipLaunchKernelGGL((lmeds_kernel<4, 0, WIN, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-            case 8: hipLaunchKernelGGL((lmeds_kernel<8, 0, WIN, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-            case 16: hipLaunchKernelGGL((lmeds_kernel<16, 0, WIN, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-            case 32: hipLaunchKernelGGL((lmeds_kernel<32, 0, WIN, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+            case 1: hipLaunchKernelGGL((lmeds_kernel<1, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+            case 2: hipLaunchKernelGGL((lmeds_kernel<2, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+            case 4: hipLaunchKernelGGL((lmeds_kernel<4, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+            case 8: hipLaunchKernelGGL((lmeds_kernel<8, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+            case 16: hipLaunchKernelGGL((lmeds_kernel<16, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+            case 32: hipLaunchKernelGGL((lmeds_kernel<32, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
             default: return set_err(c, "lmeds: unsupported rows-per-thread");
         }
         RS_HIP(hipGetLastError());
         return 0;
     }
     switch (rpt) {
-        case 1: hipLaunchKernelGGL((lmeds_kernel<1, MODE, WIN>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-        case 2: hipLaunchKernelGGL((lmeds_kernel<2, MODE, WIN>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-        case 4: hipLaunchKernelGGL((lmeds_kernel<4, MODE, WIN>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-        case 8: hipLaunchKernelGGL((lmeds_kernel<8, MODE, WIN>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-        case 16: hipLaunchKernelGGL((lmeds_kernel<16, MODE, WIN>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-        case 32: hipLaunchKernelGGL((lmeds_kernel<32, MODE, WIN>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+        case 1: hipLaunchKernelGGL((lmeds_kernel<1, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+        case 2: hipLaunchKernelGGL((lmeds_kernel<2, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+        case 4: hipLaunchKernelGGL((lmeds_kernel<4, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+        case 8: hipLaunchKernelGGL((lmeds_kernel<8, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+        case 16: hipLaunchKernelGGL((lmeds_kernel<16, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+        case 32: hipLaunchKernelGGL((lmeds_kernel<32, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
         default: return set_err(c, "lmeds: unsupported rows-per-thread");
     }
     RS_HIP(hipGetLastError());
@@ -314,28 +451,45 @@ int launch_lmeds(rship_ctx* c, const LmedsParams& p, int rpt, uint32_t grid) {
 }
 
 template <bool GRAD, bool SIMPLE>
-int launch_loss64(rship_ctx* c, const Loss64Params& p, int rpt, hipStream_t st = nullptr, uint32_t count = 0) {
+int launch_loss64(rship_ctx* c, const Loss64Params& p_in, int rpt, hipStream_t st = nullptr, uint32_t count = 0) {
+    Loss64Params p = p_in;
     if (!st) st = c->stream;
     if (!count) count = p.n_sel - p.slot0;
+    // The spline windows.  Trials (no gradient): five delays per pass over the rows, their 80-knot windows compiled into
+    // the kernel's LDS, while the problem's frames fit 80 knots (gyro rates up to ~1.7 kHz); wider frames take the
+    // dynamic-LDS instantiation with cap64 knots per window, two per pass up to 200 knots, one beyond.  The gradient
+    // launch has one window, always in dynamic LDS.
+    p.win_cap = c->cap64;
+    const bool fixed80 = !GRAD && c->cap64 == (uint32_t)kWinMax;
+    p.nb_run = GRAD ? 1u : (fixed80 ? (uint32_t)kLossBatch : std::max(1u, std::min((uint32_t)kLossBatchWide, kLossWinBytes / (c->cap64 * 128u))));
+    const size_t dyn = fixed80 ? 0 : (size_t)p.nb_run * c->cap64 * 128u, dyn_small = (size_t)c->cap64 * 128u;
     ProfScope ps(c, GRAD ? RSHIP_K_LOSS_GRAD : RSHIP_K_LOSS);
     // frames of up to 256 tracks (the reference's own: ~130): one wave per slot instead of a four-wave workgroup that
     // half idles -- the same sums in the same order (loss64_wave), four times as many slots on the chip
     const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
     if (n_all <= 256u && !c->no_small_loss && !c->force_big) {
-        hipLaunchKernelGGL((loss64_small_kernel<GRAD, SIMPLE>), dim3(count), dim3(64), 0, st, p);
+        hipLaunchKernelGGL((loss64_small_kernel<GRAD, SIMPLE>), dim3(count), dim3(64), dyn_small, st, p);
         RS_HIP(hipGetLastError());
         return 0;
     }
+#define RS_LOSS_CASE(R)                                                                                                        \
+    case R:                                                                                                                    \
+        if constexpr (!GRAD) {                                                                                                 \
+            if (fixed80) { hipLaunchKernelGGL((loss64_kernel<R, GRAD, SIMPLE, kWinMax>), dim3(count), dim3(kBlock), 0, st, p); break; } \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((loss64_kernel<R, GRAD, SIMPLE, 0>), dim3(count), dim3(kBlock), dyn, st, p);                        \
+        break;
     switch (rpt) {
-        case 0: hipLaunchKernelGGL((loss64_kernel<0, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
-        case 1: hipLaunchKernelGGL((loss64_kernel<1, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
-        case 2: hipLaunchKernelGGL((loss64_kernel<2, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
-        case 4: hipLaunchKernelGGL((loss64_kernel<4, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
-        case 8: hipLaunchKernelGGL((loss64_kernel<8, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
-        case 16: hipLaunchKernelGGL((loss64_kernel<16, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
-        case 32: hipLaunchKernelGGL((loss64_kernel<32, GRAD, SIMPLE>), dim3(count), dim3(kBlock), 0, st, p); break;
+        RS_LOSS_CASE(0)
+        RS_LOSS_CASE(1)
+        RS_LOSS_CASE(2)
+        RS_LOSS_CASE(4)
+        RS_LOSS_CASE(8)
+        RS_LOSS_CASE(16)
+        RS_LOSS_CASE(32)
         default: return set_err(c, "loss: unsupported rows-per-thread");
     }
+#undef RS_LOSS_CASE
     RS_HIP(hipGetLastError());
     return 0;
 }
@@ -345,9 +499,12 @@ int launch_loss64(rship_ctx* c, const Loss64Params& p, int rpt, hipStream_t st =
 // terms are added, and a frame must get the same sums whichever selection or device it is part of.
 constexpr uint32_t kOrderMinSlots = 512; // fewer workgroups than the chip holds at once: nothing to order
 
-int launch_motion64(rship_ctx* c, const Motion64Params& p, hipStream_t st = nullptr, uint32_t count = 0) {
+int launch_motion64(rship_ctx* c, const Motion64Params& p_in, hipStream_t st = nullptr, uint32_t count = 0) {
+    Motion64Params p = p_in;
     if (!st) st = c->stream;
     if (!count) count = p.n_sel - p.slot0;
+    p.win_cap = c->cap64;
+    const size_t dyn = (size_t)c->cap64 * 128u; // the spline window (used once, for the rows of P)
     ProfScope ps(c, RSHIP_K_MOTION);
     const uint32_t n = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
     // One wave per frame up to 512 tracks: the evaluations of a frame are dominated by their fixed part (five
@@ -358,19 +515,19 @@ int launch_motion64(rship_ctx* c, const Motion64Params& p, hipStream_t st = null
     // bound by the work per evaluation, not by its slowest frame.
     if (c->force_big) {
         if (!p.scratch || p.scratch_rows < c->max_n) return set_err(c, "motion: no scratch for the large-frame kernel");
-        hipLaunchKernelGGL((opt_motion64_kernel<0, 4>), dim3(count), dim3(256), 0, st, p);
-    } else if (n <= 64) hipLaunchKernelGGL((opt_motion64_kernel<1, 1>), dim3(count), dim3(64), 0, st, p);
-    else if (n <= 128) hipLaunchKernelGGL((opt_motion64_kernel<2, 1>), dim3(count), dim3(64), 0, st, p);
-    else if (n <= 192) hipLaunchKernelGGL((opt_motion64_kernel<3, 1>), dim3(count), dim3(64), 0, st, p);
-    else if (n <= 256) hipLaunchKernelGGL((opt_motion64_kernel<4, 1>), dim3(count), dim3(64), 0, st, p);
-    else if (n <= 512) hipLaunchKernelGGL((opt_motion64_kernel<8, 1>), dim3(count), dim3(64), 0, st, p);
-    else if (n <= 1024) hipLaunchKernelGGL((opt_motion64_kernel<4, 4>), dim3(count), dim3(256), 0, st, p);
-    else if (n <= 2048) hipLaunchKernelGGL((opt_motion64_kernel<8, 4>), dim3(count), dim3(256), 0, st, p);
-    else if (n <= 4096) hipLaunchKernelGGL((opt_motion64_kernel<16, 4>), dim3(count), dim3(256), 0, st, p);
-    else if (n <= 8192) hipLaunchKernelGGL((opt_motion64_kernel<32, 4>), dim3(count), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((opt_motion64_kernel<0, 4>), dim3(count), dim3(256), dyn, st, p);
+    } else if (n <= 64) hipLaunchKernelGGL((opt_motion64_kernel<1, 1>), dim3(count), dim3(64), dyn, st, p);
+    else if (n <= 128) hipLaunchKernelGGL((opt_motion64_kernel<2, 1>), dim3(count), dim3(64), dyn, st, p);
+    else if (n <= 192) hipLaunchKernelGGL((opt_motion64_kernel<3, 1>), dim3(count), dim3(64), dyn, st, p);
+    else if (n <= 256) hipLaunchKernelGGL((opt_motion64_kernel<4, 1>), dim3(count), dim3(64), dyn, st, p);
+    else if (n <= 512) hipLaunchKernelGGL((opt_motion64_kernel<8, 1>), dim3(count), dim3(64), dyn, st, p);
+    else if (n <= 1024) hipLaunchKernelGGL((opt_motion64_kernel<4, 4>), dim3(count), dim3(256), dyn, st, p);
+    else if (n <= 2048) hipLaunchKernelGGL((opt_motion64_kernel<8, 4>), dim3(count), dim3(256), dyn, st, p);
+    else if (n <= 4096) hipLaunchKernelGGL((opt_motion64_kernel<16, 4>), dim3(count), dim3(256), dyn, st, p);
+    else if (n <= 8192) hipLaunchKernelGGL((opt_motion64_kernel<32, 4>), dim3(count), dim3(256), dyn, st, p);
     else { // rows of P in global memory (per slot, set up by fill_motion), as many per thread as the frame needs
         if (!p.scratch || p.scratch_rows < c->max_n) return set_err(c, "motion: no scratch for frames of more than 8192 tracks");
-        hipLaunchKernelGGL((opt_motion64_kernel<0, 4>), dim3(count), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((opt_motion64_kernel<0, 4>), dim3(count), dim3(256), dyn, st, p);
     }
     RS_HIP(hipGetLastError());
     // the order of the NEXT launch over these slots, from this one's evaluation counts
@@ -470,30 +627,30 @@ using rccl_destroy_fn = int (*)(void*);
 
 using rccl_abort_fn = int (*)(void*);
 
-// librccl: a copy ALREADY MAPPED into this process wins (a host that runs torch.distributed has loaded the librccl its
-// torch build ships, possibly not the system's: two RCCL runtimes in one process would each set up their own
-// transports and IPC handles), found by walking the loaded objects; only otherwise is one opened by name.
+// WHICH librccl: the one that sits beside the HIP runtime THIS library is bound to.  A process may hold two HIP
+// runtimes -- a PyTorch wheel ships its own libamdhip64 / libhsa-runtime64 / librccl next to the system's ROCm -- and a
+// communicator only works with streams and device pointers of the runtime its librccl was built against: torch's
+// librccl, found "already loaded" in the process, refused this library's stream (ncclCommInitRank -> 1, measured in
+// round 4), the system's beside /opt/rocm/lib/libamdhip64 works; in a process where this library had bound to
+// torch's runtime it would be the other way round.  So: the directory of the libamdhip64 that hipStreamSynchronize
+// resolves to, then the usual names.
 void* rccl_sym(rship_ctx* c, const char* name) {
     if (!c->rccl_lib) {
-        struct Found { std::string path; } found;
-        dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* user) -> int {
-            const char* nm = info->dlpi_name;
-            if (!nm || !*nm) return 0;
-            const char* base = strrchr(nm, '/');
-            base = base ? base + 1 : nm;
-            if (strncmp(base, "librccl.so", 10) != 0) return 0;
-            static_cast<Found*>(user)->path = nm;
-            return 1;
-        }, &found);
-        if (!found.path.empty()) {
-            c->rccl_lib = dlopen(found.path.c_str(), RTLD_NOW | RTLD_NOLOAD);
-            if (c->rccl_lib) c->rccl_path = found.path + " (already loaded in this process)";
+        Dl_info info{};
+        std::string dir, hip_path;
+        if (dladdr(reinterpret_cast<const void*>(&hipStreamSynchronize), &info) && info.dli_fname) {
+            hip_path = info.dli_fname;
+            const size_t cut = hip_path.rfind('/');
+            if (cut != std::string::npos) dir = hip_path.substr(0, cut + 1);
         }
-        if (!c->rccl_lib) {
-            for (const char* lib : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-                c->rccl_lib = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
-                if (c->rccl_lib) { c->rccl_path = std::string(lib) + " (opened by name)"; break; }
-            }
+        std::vector<std::string> tries;
+        if (!dir.empty()) { tries.push_back(dir + "librccl.so.1"); tries.push_back(dir + "librccl.so"); }
+        for (const char* lib : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) tries.push_back(lib);
+        for (size_t i = 0; i < tries.size() && !c->rccl_lib; ++i) {
+            c->rccl_lib = dlopen(tries[i].c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (c->rccl_lib)
+                c->rccl_path = tries[i] + (i < 2 && !dir.empty() ? " (beside the HIP runtime this library is bound to, " + hip_path + ")"
+                                                                 : " (opened by name)");
         }
         if (!c->rccl_lib) {
             set_err(c, std::string("rccl: cannot open librccl: ") + dlerror());
@@ -549,6 +706,7 @@ int rship_create(rship_ctx** out, int device) {
     if (const char* s = std::getenv("RSSYNC_NO_MOTION_ORDER")) c->no_motion_order = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_NO_SMALL_LOSS")) c->no_small_loss = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_FORCE_BIG")) c->force_big = s[0] && s[0] != '0';
+    if (const char* s = std::getenv("RSSYNC_FORCE_GENERAL_SPLINE")) c->force_general = s[0] && s[0] != '0';
     if (device >= 0) {
         e = hipSetDevice(device);
         if (e != hipSuccess) { delete c; return 3; }
@@ -561,6 +719,11 @@ int rship_create(rship_ctx** out, int device) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming);
     if (e != hipSuccess) { delete c; return 4; }
     c->stream = c->own_stream;
+    {
+        int v = 0; // LDS of a compute unit (gfx950: 160 KB): what the dynamic spline windows are planned against
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, c->device) == hipSuccess && v >= 64 * 1024) c->lds_per_cu = v;
+        else (void)hipGetLastError();
+    }
     *out = c;
     return 0;
 }
@@ -837,6 +1000,7 @@ int rship_pack_frames(rship_ctx* c, const rship_frame* table, const rship_pack_f
         const float span = floorf(table[i].tmax) - floorf(table[i].tmin) + 2.f; // knots a frame touches at one delay
         if (table[i].n_rays && span > c->max_span) c->max_span = span;
     }
+    c->cap64 = c->force_general ? (uint32_t)kWinMax : cap64_for(c->max_span);
     const size_t tr = (size_t)total_rays;
     if (ensure(c, c->rays_a, tr ? tr * 16 : 16) || ensure(c, c->rays_b, tr ? tr * 16 : 16) ||
         ensure(c, c->rays64, tr ? tr * 64 : 64))
@@ -1000,16 +1164,12 @@ int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, uint
     if (chunk < 1) chunk = 1;
     if (chunk > (uint32_t)kMaxChunk) chunk = kMaxChunk;
     if (chunk > n_cand) chunk = n_cand;
-    if (n_cand > 1) {
-        // keep the chunk's delays inside what the LDS spline window can hold next to the widest
-        // frame (higher gyro rates: a frame pair spans more knots), as long as chunks stay useful
-        const double step = ((double)kd[n_cand - 1] + fd[n_cand - 1] - (double)kd[0] - fd[0]) / (double)(n_cand - 1);
-        const double room = (double)kWinMax - c->max_span - 1.0;
-        if (step > 0 && room > 0) {
-            const uint32_t fit = (uint32_t)(room / step);
-            if (fit >= 4 && fit < chunk) chunk = fit;
-        }
-    }
+    // keep the chunk's delays inside what the LDS spline window can hold next to the widest frame (higher gyro
+    // rates: a frame pair spans more knots); the window itself grows into dynamic LDS where it has to (plan_lmeds_window)
+    double step_knots = 0.0;
+    if (n_cand > 1) step_knots = std::fabs(((double)kd[n_cand - 1] + fd[n_cand - 1] - (double)kd[0] - fd[0]) / (double)(n_cand - 1));
+    const WinPlan wp = plan_lmeds_window<0>(c, step_knots, chunk);
+    chunk = wp.chunk;
     p.chunk = chunk;
     p.n_chunks = (n_cand + chunk - 1) / chunk;
     p.n_hyp = n_hyp;
@@ -1021,7 +1181,9 @@ int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, uint
     uint32_t groups = (ns + 7) / 8;
     uint64_t grid = (uint64_t)groups * 8 * p.n_chunks;
     if (grid > 0x7fffffffull) return set_err(c, "presync: grid too large");
-    if (launch_lmeds<0, kWinMax>(c, p, rpt_of(c), (uint32_t)grid)) return 1;
+    c->last_lmeds_cap = wp.cap;
+    c->last_lmeds_chunk = chunk;
+    if (launch_lmeds<0>(c, p, wp, rpt_of(c), (uint32_t)grid)) return 1;
     if (launch_plan_sum(c, p.frame_cost, n_cand, ns)) return 1;
     size_t end = 0;
     if (queue_sums_to_host(c, n_cand, 0, &c->pend.off_chunk, &end)) return 1;
@@ -1138,7 +1300,9 @@ int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t
     p.best_h = (int32_t*)c->init_h.p;
     p.flags = (uint32_t*)c->flags.p;
     uint32_t groups = (c->n_sel + 7) / 8;
-    if (launch_lmeds<1, kWinMax>(c, p, rpt_of(c), groups * 8)) return 1;
+    const WinPlan wp_init = plan_lmeds_window<1>(c, 0.0, 1u);
+    c->last_init_cap = wp_init.cap;
+    if (launch_lmeds<1>(c, p, wp_init, rpt_of(c), groups * 8)) return 1;
     c->init_pending = true;
     c->init_seed = seed;
     c->init_stream = stream;
@@ -1595,8 +1759,25 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     if (const char* e = std::getenv("RSSYNC_LOOP_FIRST_TRIALS")) { const int v = atoi(e); if (v >= 1 && v <= kMaxBt) nf_fixed = v; }
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
-    uint32_t per_cu = 8; // what the chip holds at once (LDS: ~19 KB per wave); more would only idle
-    if (const char* s = std::getenv("RSSYNC_EXEC_WAVES_PER_CU")) { const int v = atoi(s); if (v >= 1 && v <= 8) per_cu = (uint32_t)v; }
+    // One dynamic LDS region per wave serves as fp32 window, fp64 window and staging area (executor.hpp): cap64 knots x
+    // 128 bytes -- 10 KB up to ~1.7 kHz of gyro rate, more for wider frames, and then fewer waves share a CU.
+    const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
+    const uint32_t exec_rpt = std::min(4u, std::max(1u, (n_all + 63u) / 64u));
+    const size_t region = (size_t)c->cap64 * 128u;
+    uint32_t fixed_lds = 0;
+    switch (exec_rpt) {
+        case 1: fixed_lds = static_lds_of(sync_exec_kernel<1>); break;
+        case 2: fixed_lds = static_lds_of(sync_exec_kernel<2>); break;
+        case 3: fixed_lds = static_lds_of(sync_exec_kernel<3>); break;
+        default: fixed_lds = static_lds_of(sync_exec_kernel<4>); break;
+    }
+    uint32_t per_cu = 8; // what the chip holds at once (LDS: ~17 KB per wave at 80 knots); more would only idle
+    {
+        const size_t per_wave = fixed_lds + region + 512;
+        const uint32_t fit = (uint32_t)((size_t)c->lds_per_cu / per_wave);
+        if (fit < per_cu) per_cu = fit < 1 ? 1 : fit;
+    }
+    if (const char* s = std::getenv("RSSYNC_EXEC_WAVES_PER_CU")) { const int v = atoi(s); if (v >= 1 && v <= 8 && (uint32_t)v < per_cu) per_cu = (uint32_t)v; }
     uint32_t waves = (uint32_t)n_cu * per_cu;
     if (waves > ns) waves = ns;
     // ring of {lap, slot} cells, several times the entries that can be outstanding (<= ns) plus the numbers idle waves
@@ -1721,6 +1902,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     ep.init.n_grp = W;
     ep.init.best_h = (int32_t*)c->init_h.p;
     ep.init.flags = (uint32_t*)c->flags.p;
+    ep.init.win_cap = c->cap64; // (fp32 knots are half the size: the same count always fits the region)
     // motion
     if (fill_motion(c, ep.mo)) return 1;
     ep.mo.kd = ep.mo_kd;
@@ -1730,6 +1912,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     ep.mo.win_stream = ep.win_stream;
     ep.mo.order = nullptr;
     ep.mo.evals_out = nullptr;
+    ep.mo.win_cap = c->cap64;
     // loss
     ep.lo.rays = rays64_of(c);
     ep.lo.frames = (const FrameRec*)c->frames.p;
@@ -1740,16 +1923,16 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     ep.lo.fs = c->fs;
     ep.lo.M = (const double*)c->M.p;
     ep.lo.k = (const double*)c->k.p;
+    ep.lo.win_cap = c->cap64;
+    ep.lo.nb_run = 1;
 
-    const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
     {
         ProfScope ps(c, RSHIP_K_MOTION);
-        switch ((n_all + 63u) / 64u) {
-            case 0:
-            case 1: hipLaunchKernelGGL((sync_exec_kernel<1>), dim3(waves), dim3(64), 0, c->stream, ep); break;
-            case 2: hipLaunchKernelGGL((sync_exec_kernel<2>), dim3(waves), dim3(64), 0, c->stream, ep); break;
-            case 3: hipLaunchKernelGGL((sync_exec_kernel<3>), dim3(waves), dim3(64), 0, c->stream, ep); break;
-            default: hipLaunchKernelGGL((sync_exec_kernel<4>), dim3(waves), dim3(64), 0, c->stream, ep); break;
+        switch (exec_rpt) {
+            case 1: hipLaunchKernelGGL((sync_exec_kernel<1>), dim3(waves), dim3(64), region, c->stream, ep); break;
+            case 2: hipLaunchKernelGGL((sync_exec_kernel<2>), dim3(waves), dim3(64), region, c->stream, ep); break;
+            case 3: hipLaunchKernelGGL((sync_exec_kernel<3>), dim3(waves), dim3(64), region, c->stream, ep); break;
+            default: hipLaunchKernelGGL((sync_exec_kernel<4>), dim3(waves), dim3(64), region, c->stream, ep); break;
         }
     }
     RS_HIP(hipGetLastError());
@@ -1806,6 +1989,20 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
         if (hw[w].trace_base)
             memcpy(trace + (size_t)w * trace_rows * 6, (const char*)c->pinned + (size_t)w * rows_max * 48, (size_t)hw[w].trace_base * 48);
     }
+    return 0;
+}
+
+// How the spline windows of the last launches were laid out ("gyro rate"): out[0] widest frame in
+// knots, out[1] knots per fp64 window (K1, K3, executor; dynamic LDS), out[2] fp32 window of the last PreSync sweep
+// (0 = the 80 knots compiled into the kernel, else knots of dynamic LDS), out[3] its candidates per workgroup,
+// out[4] the same for the last GuessMotion search, out[5] delays per pass of the trials' loss kernel
+int rship_window_info(rship_ctx* c, uint32_t out[6]) {
+    out[0] = (uint32_t)c->max_span;
+    out[1] = c->cap64;
+    out[2] = c->last_lmeds_cap;
+    out[3] = c->last_lmeds_chunk;
+    out[4] = c->last_init_cap;
+    out[5] = c->cap64 == (uint32_t)kWinMax ? (uint32_t)kLossBatch : std::max(1u, std::min((uint32_t)kLossBatchWide, kLossWinBytes / (c->cap64 * 128u)));
     return 0;
 }
 

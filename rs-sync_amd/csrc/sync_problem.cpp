@@ -1811,6 +1811,13 @@ int rssync_ext_exchange_stats(rssync_problem* p, uint64_t* calls, uint64_t* doub
     return 0;
 }
 
+int rssync_ext_window_info(rssync_problem* p, uint32_t out[6]) {
+    return guarded([&] {
+        for (int i = 0; i < 6; ++i) out[i] = 0;
+        if (rship_window_info(p->impl->dev(), out)) panic(std::string("hip: ") + rship_last_error(p->impl->dev()));
+    });
+}
+
 int rssync_ext_set_executor_check(rssync_problem* p, int on) {
     p->impl->executor_check = on != 0;
     return 0;

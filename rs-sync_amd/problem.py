@@ -63,6 +63,7 @@ SIGNATURES = {
     "rssync_ext_rccl_shutdown": (C.c_int, [C.c_void_p]),
     "rssync_ext_set_tracks_hint": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rssync_ext_exchange_stats": (C.c_int, [C.c_void_p, _PU64, _PU64]),
+    "rssync_ext_window_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "rssync_ext_set_executor_check": (C.c_int, [C.c_void_p, C.c_int]),
     "rssync_ext_executor_stats": (C.c_int, [C.c_void_p, _PU64, _PU64, C.POINTER(C.c_uint32)]),
     "rssync_ext_record_init_winners": (C.c_int, [C.c_void_p, C.c_int]),
@@ -311,6 +312,13 @@ class SyncProblem:
         a, b = C.c_uint64(), C.c_uint64()
         self._lib.rssync_ext_exchange_stats(self._h, C.byref(a), C.byref(b))
         return a.value, b.value
+
+    def window_info(self):
+        """-> dict: how the kernels' LDS spline windows were laid out for this problem's gyro rate"""
+        q = (C.c_uint32 * 6)()
+        self._check(self._lib.rssync_ext_window_info(self._h, q))
+        return dict(frame_span_knots=q[0], fp64_window_knots=q[1], presync_window_knots=q[2] or 80, presync_window_dynamic=bool(q[2]),
+                    presync_chunk=q[3], init_window_knots=q[4] or 80, trial_delays_per_pass=q[5])
 
     def set_executor_check(self, on=True):
         """debug mode: every call the window executor runs is re-run by the launch chain and must give the same bits"""

@@ -487,3 +487,51 @@ def test_trial_batching_floor_changes_nothing_but_the_batching(monkeypatch):
     for t in (t5, t10, th):
         np.testing.assert_array_equal(t1.view(np.uint64), t.view(np.uint64))
     assert len(t1) >= 5 and t1[:, 5].max() >= 2      # (some search did need more than one trial)
+
+
+@pytest.mark.parametrize("N", [130, 600])
+def test_window_capacity_does_not_change_the_fp64_bits(monkeypatch, N):
+    """At 4 kHz a frame spans ~180 knots.  With the spline windows sized for the problem (dynamic LDS) the kernels stay on
+    their LDS paths; RSSYNC_FORCE_GENERAL_SPLINE=1 (rounds 1-3) reads the table from L2 through the general parameter
+    logic.  Where the coefficients come from must not matter: the fp64 kernels give the same bits -- every trace row of
+    Sync, the loss, the residual rows -- and the fp32 sweep, whose interior path rounds the spline parameter once
+    instead of twice, the same delay and nearly always the same winners."""
+    import rssync_amd
+    from rssync_amd import synth
+    F = 16
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, fs=4000.0, seed=29)
+    frames = list(synth.make_frames(g, 0, F, N, seed=29))
+
+    def make(general):
+        if general:
+            monkeypatch.setenv("RSSYNC_FORCE_GENERAL_SPLINE", "1")
+        else:
+            monkeypatch.delenv("RSSYNC_FORCE_GENERAL_SPLINE", raising=False)
+        p = rssync_amd.SyncProblem(seed=SEED, max_outer_iters=15)
+        monkeypatch.delenv("RSSYNC_FORCE_GENERAL_SPLINE", raising=False)
+        p.SetGyroQuaternions(g.quats, g.fs, g.t0)
+        for fr in frames:
+            p.SetTrackResult(*fr)
+        return p
+    a, b = make(False), make(True)
+    da, ca, fa, ba = a.presync_curve(0.0, 0, F, 0.001, 0.1, per_frame=F)
+    db, cb, fb, bb = b.presync_curve(0.0, 0, F, 0.001, 0.1, per_frame=F)
+    assert a.window_info()["presync_window_dynamic"] and not b.window_info()["presync_window_dynamic"]
+    assert a.window_info()["fp64_window_knots"] >= 180 and b.window_info()["fp64_window_knots"] == 80
+    assert (ba == bb).mean() > 0.98 and np.argmin(ca) == np.argmin(cb)
+    np.testing.assert_allclose(ca, cb, rtol=2e-3)
+    np.testing.assert_array_equal(a.problem_matrix64(3, 0.0371, N).view(np.uint64), b.problem_matrix64(3, 0.0371, N).view(np.uint64))
+    d0 = float(da[np.argmin(ca)])
+    # (GuessMotion's fp32 search may pick another winner at a near-tie between the two fp32 spline paths: both start
+    # from a's winners)
+    a.record_init_winners(True)
+    ra = a.Sync(d0, 0, F - 1, 0.0, 0.1)
+    b.set_init_override(a.last_init_winners())
+    rb = b.Sync(d0, 0, F - 1, 0.0, 0.1)
+    assert ra == rb
+    np.testing.assert_array_equal(a.sync_trace().view(np.uint64), b.sync_trace().view(np.uint64))
+    b.set_motion(*a.init_motion(d0, 0, F - 1))
+    Lb, Gb = b.loss([d0, 0.03, 0.0371], grad=True)
+    La2, Ga2 = a.loss([d0, 0.03, 0.0371], grad=True)
+    np.testing.assert_array_equal(np.asarray(La2).view(np.uint64), np.asarray(Lb).view(np.uint64))
+    np.testing.assert_array_equal(np.asarray(Ga2).view(np.uint64), np.asarray(Gb).view(np.uint64))

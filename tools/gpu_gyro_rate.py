@@ -1,21 +1,93 @@
-"""PreSync + Sync time against the gyro sample rate (the LDS spline window holds 64 knots; above
-~900 Hz a frame spans more and the kernels read the table from L2).  GPU box."""
-import os, sys, time, json
+"""Kernel launch times against the gyro sample rate.  A frame pair spans 0.044 s x rate knots of the
+orientation spline; up to ~1.7 kHz that fits the 80-knot window compiled into the kernels' LDS, above it the window
+moves to dynamic LDS sized for the problem (fewer workgroups per CU, shorter candidate chunks) instead of the kernels
+falling back to the table in L2.  Two problems per rate:
+
+  large   F x 2048 tracks (the benchmark's frame size): K2 tile kernel (PreSync, 800 candidates), GuessMotion's search,
+          K3 motion, K1 gradient and trials;
+  small   98 sync points of 61 x 130 (the reference driver's shape): K2s (one wave per frame) and the window executor.
+
+RSSYNC_FORCE_GENERAL_SPLINE=1 (read per launch) gives the old behaviour -- every window 80 knots, wider frames on the
+general path -- for the before / after columns.  GPU box.
+
+    python tools/gpu_gyro_rate.py > profiles/r4_gyro_rate_sweep.json
+"""
+import json
+import os
+import sys
+import time
+
 import numpy as np
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import rssync_amd
-from rssync_amd import synth
-F, N = int(os.environ.get("F", 512)), int(os.environ.get("N", 2048))
-out = {}
-for fs in (400.0, 800.0, 1600.0, 3200.0):
+import rssync_amd  # noqa: E402
+from rssync_amd import synth  # noqa: E402
+
+F, N = int(os.environ.get("F", 1024)), int(os.environ.get("N", 2048))
+RATES = [float(x) for x in os.environ.get("RATES", "400,1000,2000,4000,8000").split(",")]
+
+
+def per_launch(prof):
+    return {k: round(v[1] / v[0], 4) for k, v in prof.items() if v[0]}
+
+
+def large(fs, general):
+    if general:
+        os.environ["RSSYNC_FORCE_GENERAL_SPLINE"] = "1"
+    else:
+        os.environ.pop("RSSYNC_FORCE_GENERAL_SPLINE", None)
     g = synth.make_gyro(0, (F + 2) / synth.FPS, fs=fs, seed=3)
-    h = rssync_amd.SyncProblem(seed=3, max_outer_iters=10)
+    h = rssync_amd.SyncProblem(seed=3, max_outer_iters=10, verbose=False)
     synth.fill(h, g, 0, F, N, seed=3)
     h.upload()
-    h.PreSync(0.0, 0, F, 0.0005, 0.2)
-    t = time.perf_counter(); c, d = h.PreSync(0.0, 0, F, 0.0005, 0.2); t_pre = time.perf_counter() - t
+    c, d = h.PreSync(0.0, 0, F, 0.0005, 0.2)
     h.Sync(d, 0, F - 1, 0.0, 0.2)
-    t = time.perf_counter(); h.Sync(d, 0, F - 1, 0.0, 0.2); t_sync = time.perf_counter() - t
-    out[int(fs)] = {"presync_ms": round(1e3 * t_pre, 2), "sync_ms": round(1e3 * t_sync, 2), "delay": d,
-                    "iters": len(h.sync_trace())}
-print(json.dumps({"frames": F, "tracks": N, "by_gyro_hz": out}))
+    h.profile(True)
+    h.profile_reset()
+    t = time.perf_counter()
+    c, d = h.PreSync(0.0, 0, F, 0.0005, 0.2)
+    t_pre = time.perf_counter() - t
+    t = time.perf_counter()
+    c2, d2 = h.Sync(d, 0, F - 1, 0.0, 0.2)
+    t_sync = time.perf_counter() - t
+    out = {"presync_ms": round(1e3 * t_pre, 3), "sync_ms": round(1e3 * t_sync, 3), "presync_delay": d, "sync_delay": d2,
+           "outer_iterations": len(h.sync_trace()), "ms_per_launch": per_launch(h.profile_get()), "windows": h.window_info()}
+    h.close()
+    return out
+
+
+def small(fs, general):
+    if general:
+        os.environ["RSSYNC_FORCE_GENERAL_SPLINE"] = "1"
+    else:
+        os.environ.pop("RSSYNC_FORCE_GENERAL_SPLINE", None)
+    Fs, Ns, W, D = 3000, 130, 60, 30
+    g = synth.make_gyro(0, (Fs + 2) / synth.FPS, fs=fs, seed=6)
+    h = rssync_amd.SyncProblem(seed=6, verbose=False)
+    synth.fill(h, g, 0, Fs, Ns, seed=6)
+    h.upload()
+    pos = list(range(0, Fs - W - 1, D))
+    h.sync_points(pos, W, 0.0, 0.001, 0.1)
+    t = time.perf_counter()
+    c, d = h.sync_points(pos, W, 0.0, 0.001, 0.1)
+    t_all = time.perf_counter() - t
+    h.profile(True)
+    h.profile_reset()
+    h.pre_sync_windows(0.0, pos, [p + W for p in pos], 0.001, 0.1)
+    prof = per_launch(h.profile_get())
+    out = {"sync_points_s": round(t_all, 4), "positions": len(pos), "presync_windows_kernel_ms": prof.get("lmeds"),
+           "median_abs_err_ms": float(np.median(np.abs(d - synth.D_TRUE)) * 1e3), "executor": h.executor_stats(), "windows": h.window_info()}
+    h.close()
+    return out
+
+
+res = {"what": __doc__.split("\n")[0], "frames": F, "tracks": N, "by_gyro_hz": {}}
+for fs in RATES:
+    row = {"large": large(fs, False), "small": small(fs, False)}
+    if fs * 0.0445 + 2 > 80:   # frames wider than the compiled-in window: the old behaviour beside it
+        row["large_general_path"] = large(fs, True)
+        row["small_general_path"] = small(fs, True)
+    res["by_gyro_hz"][int(fs)] = row
+    print("%g Hz done" % fs, file=sys.stderr, flush=True)
+os.environ.pop("RSSYNC_FORCE_GENERAL_SPLINE", None)
+print(json.dumps(res, indent=1))
