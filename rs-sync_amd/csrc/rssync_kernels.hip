@@ -260,6 +260,18 @@ uint32_t cap64_for(float max_span) {
     need = (need + 15u) / 16u * 16u;
     return std::min(std::max(need, (uint32_t)kWinMax), kCap64Max);
 }
+// The fp64 window the launches use.  Problems of small frames (up to 256 tracks: one WAVE per frame in K1 / K3 / the
+// executor) only gain from a wide window while enough waves still share a CU: a 130-track frame makes 260 coefficient
+// fetches per evaluation, and staging a 190-knot window (24 KB) for them costs more than fetching them from L2 once
+// the window's LDS leaves fewer than six waves per CU.  Measured on 98 sync points of 61 x 130 (profiles/
+// r4_gyro_rate_sweep.json): 2 kHz 21.0 ms with a 96-knot window against 25.0 on the general path; 4 kHz 25.8 ms with
+// 192 knots against 21.6 on the general path.  So such problems keep the 80-knot window beyond kCap64SmallMax knots.
+constexpr uint32_t kCap64SmallMax = 176;
+uint32_t cap64_of(const rship_ctx* c) {
+    const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
+    if (n_all <= 256u && !c->force_big && c->cap64 > kCap64SmallMax) return (uint32_t)kWinMax;
+    return c->cap64;
+}
 template <class K>
 uint32_t static_lds_of(K kernel) {
     hipFuncAttributes a{};
@@ -287,6 +299,7 @@ uint32_t sel_max_n(const rship_ctx* c) {
 // the largest number of workgroups per CU whose LDS share still holds the frame and a chunk of at least eight
 // candidates, then the longest chunk (<= 32) that fits.  Only when even one workgroup per CU cannot hold it do the
 // kernels fall back to the general path (table from L2).
+constexpr uint32_t kSmallWinMax = 128;
 struct WinPlan {
     uint32_t cap = 0;   // 0: the compiled-in kWinMax window; otherwise knots of dynamic LDS
     uint32_t chunk = 1; // candidates per workgroup
@@ -352,9 +365,15 @@ WinPlan plan_lmeds_window(rship_ctx* c, double step_knots, uint32_t chunk_want) 
         const uint32_t cap_t = std::min(2048u, ((uint32_t)share - fixed) / 64u / 4u * 4u);
         const uint32_t f = fit((double)cap_t);
         if (f < min_chunk) continue;
-        w.chunk = f;
         const double need = span + 1.0 + (step_knots > 0 ? (f - 1) * step_knots : 0.0);
-        w.cap = std::min(cap_t, ((uint32_t)std::ceil(need) + 3u) / 4u * 4u + 4u);
+        const uint32_t cap = std::min(cap_t, ((uint32_t)std::ceil(need) + 3u) / 4u * 4u + 4u);
+        // one wave per frame (K2s): a window of more than kSmallWinMax knots costs more in resident waves than the
+        // frame's few hundred coefficient fetches cost from L2 (r4_gyro_rate_sweep.json: 98 x 61 x 130 x 200
+        // candidates, 2 kHz: 1.41 ms with a 112-knot window against 1.54 on the general path; 4 kHz: 1.98 ms with 228
+        // knots against 1.54) -- keep the general path there
+        if (small && cap > kSmallWinMax) break;
+        w.chunk = f;
+        w.cap = cap;
         return w;
     }
     return w; // does not fit any LDS share: the general path, as before
@@ -459,10 +478,11 @@ int launch_loss64(rship_ctx* c, const Loss64Params& p_in, int rpt, hipStream_t s
     // the kernel's LDS, while the problem's frames fit 80 knots (gyro rates up to ~1.7 kHz); wider frames take the
     // dynamic-LDS instantiation with cap64 knots per window, two per pass up to 200 knots, one beyond.  The gradient
     // launch has one window, always in dynamic LDS.
-    p.win_cap = c->cap64;
-    const bool fixed80 = !GRAD && c->cap64 == (uint32_t)kWinMax;
-    p.nb_run = GRAD ? 1u : (fixed80 ? (uint32_t)kLossBatch : std::max(1u, std::min((uint32_t)kLossBatchWide, kLossWinBytes / (c->cap64 * 128u))));
-    const size_t dyn = fixed80 ? 0 : (size_t)p.nb_run * c->cap64 * 128u, dyn_small = (size_t)c->cap64 * 128u;
+    const uint32_t cap64 = cap64_of(c);
+    p.win_cap = cap64;
+    const bool fixed80 = !GRAD && cap64 == (uint32_t)kWinMax;
+    p.nb_run = GRAD ? 1u : (fixed80 ? (uint32_t)kLossBatch : std::max(1u, std::min((uint32_t)kLossBatchWide, kLossWinBytes / (cap64 * 128u))));
+    const size_t dyn = fixed80 ? 0 : (size_t)p.nb_run * cap64 * 128u, dyn_small = (size_t)cap64 * 128u;
     ProfScope ps(c, GRAD ? RSHIP_K_LOSS_GRAD : RSHIP_K_LOSS);
     // frames of up to 256 tracks (the reference's own: ~130): one wave per slot instead of a four-wave workgroup that
     // half idles -- the same sums in the same order (loss64_wave), four times as many slots on the chip
@@ -503,8 +523,8 @@ int launch_motion64(rship_ctx* c, const Motion64Params& p_in, hipStream_t st = n
     Motion64Params p = p_in;
     if (!st) st = c->stream;
     if (!count) count = p.n_sel - p.slot0;
-    p.win_cap = c->cap64;
-    const size_t dyn = (size_t)c->cap64 * 128u; // the spline window (used once, for the rows of P)
+    p.win_cap = cap64_of(c);
+    const size_t dyn = (size_t)p.win_cap * 128u; // the spline window (used once, for the rows of P)
     ProfScope ps(c, RSHIP_K_MOTION);
     const uint32_t n = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
     // One wave per frame up to 512 tracks: the evaluations of a frame are dominated by their fixed part (five
@@ -1763,7 +1783,8 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     // 128 bytes -- 10 KB up to ~1.7 kHz of gyro rate, more for wider frames, and then fewer waves share a CU.
     const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
     const uint32_t exec_rpt = std::min(4u, std::max(1u, (n_all + 63u) / 64u));
-    const size_t region = (size_t)c->cap64 * 128u;
+    const uint32_t cap64 = cap64_of(c);
+    const size_t region = (size_t)cap64 * 128u;
     uint32_t fixed_lds = 0;
     switch (exec_rpt) {
         case 1: fixed_lds = static_lds_of(sync_exec_kernel<1>); break;
@@ -1902,7 +1923,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     ep.init.n_grp = W;
     ep.init.best_h = (int32_t*)c->init_h.p;
     ep.init.flags = (uint32_t*)c->flags.p;
-    ep.init.win_cap = c->cap64; // (fp32 knots are half the size: the same count always fits the region)
+    ep.init.win_cap = cap64; // (fp32 knots are half the size: the same count always fits the region)
     // motion
     if (fill_motion(c, ep.mo)) return 1;
     ep.mo.kd = ep.mo_kd;
@@ -1912,7 +1933,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     ep.mo.win_stream = ep.win_stream;
     ep.mo.order = nullptr;
     ep.mo.evals_out = nullptr;
-    ep.mo.win_cap = c->cap64;
+    ep.mo.win_cap = cap64;
     // loss
     ep.lo.rays = rays64_of(c);
     ep.lo.frames = (const FrameRec*)c->frames.p;
@@ -1923,7 +1944,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     ep.lo.fs = c->fs;
     ep.lo.M = (const double*)c->M.p;
     ep.lo.k = (const double*)c->k.p;
-    ep.lo.win_cap = c->cap64;
+    ep.lo.win_cap = cap64;
     ep.lo.nb_run = 1;
 
     {
@@ -1998,11 +2019,12 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
 // out[4] the same for the last GuessMotion search, out[5] delays per pass of the trials' loss kernel
 int rship_window_info(rship_ctx* c, uint32_t out[6]) {
     out[0] = (uint32_t)c->max_span;
-    out[1] = c->cap64;
+    const uint32_t cap64 = cap64_of(c);
+    out[1] = cap64;
     out[2] = c->last_lmeds_cap;
     out[3] = c->last_lmeds_chunk;
     out[4] = c->last_init_cap;
-    out[5] = c->cap64 == (uint32_t)kWinMax ? (uint32_t)kLossBatch : std::max(1u, std::min((uint32_t)kLossBatchWide, kLossWinBytes / (c->cap64 * 128u)));
+    out[5] = cap64 == (uint32_t)kWinMax ? (uint32_t)kLossBatch : std::max(1u, std::min((uint32_t)kLossBatchWide, kLossWinBytes / (cap64 * 128u)));
     return 0;
 }
 

@@ -489,9 +489,9 @@ def test_trial_batching_floor_changes_nothing_but_the_batching(monkeypatch):
     assert len(t1) >= 5 and t1[:, 5].max() >= 2      # (some search did need more than one trial)
 
 
-@pytest.mark.parametrize("N", [130, 600])
-def test_window_capacity_does_not_change_the_fp64_bits(monkeypatch, N):
-    """At 4 kHz a frame spans ~180 knots.  With the spline windows sized for the problem (dynamic LDS) the kernels stay on
+@pytest.mark.parametrize("fs,N", [(2000.0, 130), (4000.0, 600)])
+def test_window_capacity_does_not_change_the_fp64_bits(monkeypatch, fs, N):
+    """At 4 kHz a frame spans ~180 knots (~90 at 2 kHz).  With the spline windows sized for the problem (dynamic LDS) the kernels stay on
     their LDS paths; RSSYNC_FORCE_GENERAL_SPLINE=1 (rounds 1-3) reads the table from L2 through the general parameter
     logic.  Where the coefficients come from must not matter: the fp64 kernels give the same bits -- every trace row of
     Sync, the loss, the residual rows -- and the fp32 sweep, whose interior path rounds the spline parameter once
@@ -499,7 +499,7 @@ def test_window_capacity_does_not_change_the_fp64_bits(monkeypatch, N):
     import rssync_amd
     from rssync_amd import synth
     F = 16
-    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, fs=4000.0, seed=29)
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, fs=fs, seed=29)
     frames = list(synth.make_frames(g, 0, F, N, seed=29))
 
     def make(general):
@@ -517,9 +517,11 @@ def test_window_capacity_does_not_change_the_fp64_bits(monkeypatch, N):
     da, ca, fa, ba = a.presync_curve(0.0, 0, F, 0.001, 0.1, per_frame=F)
     db, cb, fb, bb = b.presync_curve(0.0, 0, F, 0.001, 0.1, per_frame=F)
     assert a.window_info()["presync_window_dynamic"] and not b.window_info()["presync_window_dynamic"]
-    assert a.window_info()["fp64_window_knots"] >= 180 and b.window_info()["fp64_window_knots"] == 80
+    assert a.window_info()["fp64_window_knots"] >= 0.044 * fs and b.window_info()["fp64_window_knots"] == 80
     assert (ba == bb).mean() > 0.98 and np.argmin(ca) == np.argmin(cb)
-    np.testing.assert_allclose(ca, cb, rtol=2e-3)
+    all_same = (ba == bb).all(axis=1)                 # candidates at which every frame chose the same hypothesis
+    np.testing.assert_allclose(ca[all_same], cb[all_same], rtol=1e-4)
+    np.testing.assert_allclose(ca, cb, rtol=1e-2)     # (a flipped near-tie moves one frame's cost by a few per cent)
     np.testing.assert_array_equal(a.problem_matrix64(3, 0.0371, N).view(np.uint64), b.problem_matrix64(3, 0.0371, N).view(np.uint64))
     d0 = float(da[np.argmin(ca)])
     # (GuessMotion's fp32 search may pick another winner at a near-tie between the two fp32 spline paths: both start
