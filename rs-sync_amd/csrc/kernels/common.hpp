@@ -174,9 +174,6 @@ __device__ __forceinline__ rs::Knot locate_sweep(float t, int base, float fd) {
 // -- and the two v_rcp_f32 (quarter rate) with their clamps become one packed fma.  *qerr collects
 // max |1 - |q|^2| over the rows a thread computes; the caller redoes them without NEWTON if any lane of the
 // wave exceeds kNewtonMaxErr (non-unit knots: the reference normalises whatever it is given, ndspline.cpp:21-27).
-#ifndef RSSYNC_K2_NEWTON
-#define RSSYNC_K2_NEWTON 1
-#endif
 constexpr float kNewtonMaxErr = 2.44140625e-4f; // 2^-12: (2^-12)^2 = 2^-24 relative, half an fp32 ulp
 
 template <bool DERIV, int PATH, bool SWEEP = false, int CAP = kWinMax, bool NEWTON = false>

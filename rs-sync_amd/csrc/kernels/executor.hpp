@@ -112,17 +112,13 @@ __device__ __forceinline__ void split32_dev(double delay, double fs, int32_t* kd
 // with eight waves per CU), and per task that was 20x the task (this file's first version: 232 ms for the workload
 // the launch chain does in 30).
 
-// How an idle wave waits: it re-reads its cell every RSSYNC_EXEC_SLEEP x 64 cycles and looks at the two counters that
-// only atomics change (windows done, abort) every RSSYNC_EXEC_POLL_MASK + 1 reads.  With a thousand idle waves the
+// How an idle wave waits: it re-reads its cell every kExecSleep x 64 cycles and looks at the two counters that
+// only atomics change (windows done, abort) every kExecPollMask + 1 reads.  With a thousand idle waves the
 // atomic reads compete with the working waves' own atomics (the phase counters, the queue's head and tail): every 8th
 // read, 27.6 ms for the 98 sync points; every 16th, 24.1; every 256th, 21.4 (profiles/r3_executor_stats.txt) -- so the
 // "done" counter is not polled at all (end markers, exec_decide) and the abort flag every 1024th read.
-#ifndef RSSYNC_EXEC_POLL_MASK
-#define RSSYNC_EXEC_POLL_MASK 1023
-#endif
-#ifndef RSSYNC_EXEC_SLEEP
-#define RSSYNC_EXEC_SLEEP 16
-#endif
+constexpr uint32_t kExecPollMask = 1023;
+constexpr int kExecSleep = 16;
 __device__ __forceinline__ uint32_t exec_pop(const ExecParams& p) {
     uint32_t idx = 0;
     if (threadIdx.x == 0) idx = __hip_atomic_fetch_add(p.q_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -135,7 +131,7 @@ __device__ __forceinline__ uint32_t exec_pop(const ExecParams& p) {
         const unsigned long long v = ld_m<true>(cell);
         const uint32_t v_lap = uniform_u32((uint32_t)(v >> 32)), v_slot = uniform_u32((uint32_t)v);
         if (v_lap == lap) return v_slot;
-        if ((spins & (uint32_t)RSSYNC_EXEC_POLL_MASK) == (uint32_t)RSSYNC_EXEC_POLL_MASK) {
+        if ((spins & kExecPollMask) == kExecPollMask) {
             // rarely (every ~2 ms): the counters that only atomics change, lanes 0..2 one each in one round trip
             uint32_t v3 = 0;
             if (threadIdx.x < 3)
@@ -155,7 +151,7 @@ __device__ __forceinline__ uint32_t exec_pop(const ExecParams& p) {
                 return 0xffffffffu;
             }
         }
-        __builtin_amdgcn_s_sleep(RSSYNC_EXEC_SLEEP);
+        __builtin_amdgcn_s_sleep(kExecSleep);
     }
 }
 

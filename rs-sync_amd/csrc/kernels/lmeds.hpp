@@ -266,7 +266,6 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
     uint32_t bad = 0;
     const uint32_t voff = threadIdx.x * 16u;
     if (sp.path == kPathInterior) {
-#if RSSYNC_K2_NEWTON
         float qerr = 0.f; // max |1 - |q|^2| over this thread's rows (NaN never raises it: such rows are flagged by their P)
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
@@ -283,13 +282,6 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
                 nrm[j] = t;
             }
         }
-#else
-#pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            const f4 A = load_ray(rays.a, voff, (uint32_t)j * kBlock * 16u), B = load_ray(rays.b, voff, (uint32_t)j * kBlock * 16u);
-            bad |= lmeds_row<kPathInterior, SWEEP, CAP>(sp, A, B, N, j * kBlock + threadIdx.x, base, fd, tile, nrm[j]);
-        }
-#endif
     } else { // rare (ends of the gyro track, wild delays): keep the code small, not fast
         float tmp[RPT];
 #pragma unroll 1
@@ -364,13 +356,7 @@ __device__ __forceinline__ void sweep_tile(const f4* p4x, const f4* p4y, const f
 // stopped, and the packed (quartile, index) minimum decides as before.  The winner is the exact arg-min with the
 // reference's first-wins tie rule either way (tests: identical best_h and costs against the exact selection,
 // RSSYNC_K2_EXACT_SELECT=1, on every (frame, candidate) of full-size sweeps).
-#ifndef RSSYNC_K2_LAZY_ELEMS
-#define RSSYNC_K2_LAZY_ELEMS 16 // round 3 A/B (profiles/r3_k2_ab2.txt), ms per launch: 1 (= closed at once) 45.7, 4: 41.2, 16: 40.2, 48: 41.1
-#endif
-constexpr uint32_t kLazyElems = RSSYNC_K2_LAZY_ELEMS;
-#ifndef RSSYNC_K2_EARLY_REJECT
-#define RSSYNC_K2_EARLY_REJECT 1
-#endif
+constexpr uint32_t kLazyElems = 16; // round 3 A/B (profiles/r3_k2_ab2.txt), ms per launch: 1 (= closed at once) 45.7, 4: 41.2, 16: 40.2, 48: 41.1
 constexpr int kContCap = 24; // contender records per candidate; beyond that a hypothesis closes its bracket at once
 
 // WIN = knots of the LDS spline window: kWinMax, a compile-time part of the workgroup's LDS, or 0 = p.win_cap knots in
@@ -380,6 +366,8 @@ constexpr int kContCap = 24; // contender records per candidate; beyond that a h
 // 24-entry direction buffer: 27,088 B of LDS and 80 VGPRs, SIX workgroups per CU instead of five (the occupancy
 // API confirmed it) -- and the same launch time within 0.1 %, while four workgroups per CU had been 12 % slower
 // than five: beyond five waves per SIMD the kernel no longer gains from more resident waves.
+// LAZY = false is round 2's exact selection of every quartile that beats the bound: instantiated only in the
+// test-variants build (-DRSSYNC_TEST_VARIANTS=1, tests/test_gpu_lazy_select.py), which demands identical winners and costs.
 template <int RPT, int MODE, int WIN, bool LAZY = true> // MODE 0: PreSync cost per candidate; 1: GuessMotion's hypothesis search (Sync start)
 __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsParams p) {
     constexpr int kHyp = kHypBatch;
@@ -565,7 +553,6 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                     // (T is read before the sweep: a bound that has tightened meanwhile only makes this test milder.)
                     const uint32_t T = (uint32_t)(__hip_atomic_load(&s_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32);
                     uint32_t tot;
-#if RSSYNC_K2_EARLY_REJECT
                     if (NR >= 16) {
                         // Four of five hypotheses only have to be turned away, and most of those have a few per cent of
                         // their residuals below T: once all rows but the last 256 are counted and even 256 more could
@@ -577,9 +564,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                         K2_COUNT(9);
                         sweep_tile<NR, GL, GL + 1>(p4x, p4y, p4z, lane, f3{hv.x, hv.y, hv.z}, r2);
                         tot += wave_count_lt<NR, 4 * GL, NR>(r2, T);
-                    } else
-#endif
-                    {
+                    } else {
                         sweep_tile(p4x, p4y, p4z, lane, f3{hv.x, hv.y, hv.z}, r2);
                         tot = wave_count_lt(r2, T);
                     }

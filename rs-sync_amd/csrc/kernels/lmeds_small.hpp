@@ -105,7 +105,6 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
                 s_n[0][row] = nx[j]; s_n[1][row] = ny[j]; s_n[2][row] = nz[j];
             }
         };
-#if RSSYNC_K2_NEWTON
         {
             float qerr = 0.f;
             rows(std::true_type{}, &qerr);
@@ -114,9 +113,6 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
                 rows(std::false_type{}, nullptr);
             }
         }
-#else
-        rows(std::false_type{}, nullptr);
-#endif
         __syncthreads(); // the wave's rows are in LDS
 
         // ---- the hypotheses, in order.  The previous candidate's best quantile (x1.25) is a provisional bound

@@ -740,4 +740,6 @@ __global__ __launch_bounds__(64) void debug_math64_kernel(int op, const double* 
 
 } // namespace
 
+// (this header is only ever part of the HIP translation unit rssync_kernels.hip, whose default -- and whose fp32
+// kernels' assumption -- is -ffp-contract=fast-honor-pragmas: back to it for the headers that follow)
 #pragma clang fp contract(fast)

@@ -35,6 +35,10 @@
 #include <thread>
 #include <vector>
 
+#ifndef RSSYNC_TEST_VARIANTS
+#define RSSYNC_TEST_VARIANTS 0 // 1: also the kernel variants that exist only so that a test can compare the product against them
+#endif
+
 #include "../../include/rssync_hip.h"
 #include "device_math.hpp"
 #include "sync_math.hpp"
@@ -114,9 +118,8 @@ struct rship_ctx {
                                   // spline windows -- frames wider than 80 knots take the general path (table from L2), as in rounds 1-3
     bool force_big = false;       // RSSYNC_FORCE_BIG=1 (tests): every frame through the kernels for frames of more than 8192 tracks
     bool no_small_loss = false;   // RSSYNC_NO_SMALL_LOSS=1 (A/B): frames of up to 256 tracks in the four-wave loss kernel
-    bool no_motion_order = false; // RSSYNC_NO_MOTION_ORDER=1 (A/B): the motion kernel's workgroups in slot order, not longest-first
-    bool exact_select = false;   // RSSYNC_K2_EXACT_SELECT=1 (read once, at creation): PreSync's tile kernel with round 2's exact
-                                 // selection of every quartile instead of the lazy one (A/B tests: identical results)
+    bool exact_select = false;   // RSSYNC_K2_EXACT_SELECT=1 (read once, at creation; only in the -DRSSYNC_TEST_VARIANTS=1 build): PreSync's
+                                 // tile kernel with round 2's exact selection of every quartile instead of the lazy one (tests: identical results)
     bool no_small_lmeds = false; // RSSYNC_NO_SMALL_LMEDS=1 (read once, at creation): the tile kernel for every frame size (A/B tests)
     float max_span = 0.f; // widest frame, in knots (frame table)
     // knots the fp64 kernels' spline window holds (dynamic LDS, 128 bytes per knot): the widest frame of the table,
@@ -443,6 +446,7 @@ int launch_lmeds(rship_ctx* c, LmedsParams p, const WinPlan& wp, int rpt, uint32
         RS_HIP(hipGetLastError());
         return 0;
     }
+#if RSSYNC_TEST_VARIANTS
     if (MODE == 0 && c->exact_select) {
         switch (rpt) {
             case 1: hipLaunchKernelGGL((lmeds_kernel<1, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
@@ -456,6 +460,7 @@ int launch_lmeds(rship_ctx* c, LmedsParams p, const WinPlan& wp, int rpt, uint32
         RS_HIP(hipGetLastError());
         return 0;
     }
+#endif
     switch (rpt) {
         case 1: hipLaunchKernelGGL((lmeds_kernel<1, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
         case 2: hipLaunchKernelGGL((lmeds_kernel<2, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
@@ -551,7 +556,7 @@ int launch_motion64(rship_ctx* c, const Motion64Params& p_in, hipStream_t st = n
     }
     RS_HIP(hipGetLastError());
     // the order of the NEXT launch over these slots, from this one's evaluation counts
-    if (p.evals_out && c->mo_order.p && p.max_iters > 0 && !p.simple_k && count >= kOrderMinSlots && !c->no_motion_order) {
+    if (p.evals_out && c->mo_order.p && p.max_iters > 0 && !p.simple_k && count >= kOrderMinSlots) {
         hipLaunchKernelGGL(motion_order_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)p.evals_out, (uint32_t*)c->mo_order.p, p.slot0, count);
         RS_HIP(hipGetLastError());
     }
@@ -723,7 +728,13 @@ int rship_create(rship_ctx** out, int device) {
     rship_ctx* c = new rship_ctx();
     if (const char* s = std::getenv("RSSYNC_NO_SMALL_LMEDS")) c->no_small_lmeds = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_K2_EXACT_SELECT")) c->exact_select = s[0] && s[0] != '0';
-    if (const char* s = std::getenv("RSSYNC_NO_MOTION_ORDER")) c->no_motion_order = s[0] && s[0] != '0';
+#if !RSSYNC_TEST_VARIANTS
+    if (c->exact_select) { // (a test that asked for the variant must not silently compare the product with itself)
+        fprintf(stderr, "rssync: RSSYNC_K2_EXACT_SELECT needs the test-variants build (tools/k2_build_variant.sh testvariants -DRSSYNC_TEST_VARIANTS=1)\n");
+        delete c;
+        return 5;
+    }
+#endif
     if (const char* s = std::getenv("RSSYNC_NO_SMALL_LOSS")) c->no_small_loss = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_FORCE_BIG")) c->force_big = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_FORCE_GENERAL_SPLINE")) c->force_general = s[0] && s[0] != '0';
@@ -1798,7 +1809,6 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
         const uint32_t fit = (uint32_t)((size_t)c->lds_per_cu / per_wave);
         if (fit < per_cu) per_cu = fit < 1 ? 1 : fit;
     }
-    if (const char* s = std::getenv("RSSYNC_EXEC_WAVES_PER_CU")) { const int v = atoi(s); if (v >= 1 && v <= 8 && (uint32_t)v < per_cu) per_cu = (uint32_t)v; }
     uint32_t waves = (uint32_t)n_cu * per_cu;
     if (waves > ns) waves = ns;
     // ring of {lap, slot} cells, several times the entries that can be outstanding (<= ns) plus the numbers idle waves

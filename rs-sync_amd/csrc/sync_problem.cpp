@@ -398,6 +398,7 @@ void SyncProblemHip::create_shards(const std::vector<int>& ids) {
         int rc = rship_create(&sh.ctx, id);
         if (rc) {
             destroy_shards();
+            if (rc == 5) panic("rssync: RSSYNC_K2_EXACT_SELECT is set but this build has no exact-selection kernels (test-variants build only)");
             panic("rssync: no usable HIP device (rship_create(" + std::to_string(id) + ") failed with " +
                   std::to_string(rc) + "); this library has no CPU fallback");
         }

@@ -1,24 +1,55 @@
 """PreSync's lazy quartile selection (kernels/lmeds.hpp, round 3) against round 2's exact selection of every
-quartile (RSSYNC_K2_EXACT_SELECT=1, read when a problem is created): the arg-min over hypotheses is exact either
-way, so winners and costs must be IDENTICAL for every (frame, candidate) -- including scenes built to produce
-equal quartiles (duplicated tracks, noise-free data), where the reference's first-wins tie rule decides."""
+quartile: the arg-min over hypotheses is exact either way, so winners and costs must be IDENTICAL for every
+(frame, candidate) -- including scenes built to produce equal quartiles (duplicated tracks, noise-free data), where the
+reference's first-wins tie rule decides.
+
+The exact-selection kernels are not part of the product build: they exist in the TEST-VARIANTS build of the same
+sources (-DRSSYNC_TEST_VARIANTS=1 -> rs-sync_amd/_variants/lib_testvariants.so, built by the fixture below when it is
+missing or older than the sources; RSSYNC_K2_EXACT_SELECT=1, read when a problem is created, selects them there and
+is refused by the product build).  The lazy side is the PRODUCT library."""
+import ctypes
 import os
+import subprocess
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-def _two(seed):
+
+@pytest.fixture(scope="module")
+def variants_lib(built):
+    from rssync_amd.problem import bind
+    out = os.path.join(ROOT, "rs-sync_amd", "_variants", "lib_testvariants.so")
+    src_dir = os.path.join(ROOT, "rs-sync_amd", "csrc")
+    deps = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".hpp", ".cpp"))]
+    deps += [os.path.join(src_dir, "kernels", f) for f in os.listdir(os.path.join(src_dir, "kernels"))]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["bash", os.path.join(ROOT, "tools", "k2_build_variant.sh"), "testvariants", "-DRSSYNC_TEST_VARIANTS=1"])
+    return bind(ctypes.CDLL(out))
+
+
+def test_the_product_build_refuses_the_variant_switch(built, monkeypatch):
     import rssync_amd
-    lazy = rssync_amd.SyncProblem(seed=seed)
-    os.environ["RSSYNC_K2_EXACT_SELECT"] = "1"
-    try:
-        exact = rssync_amd.SyncProblem(seed=seed)
-    finally:
-        del os.environ["RSSYNC_K2_EXACT_SELECT"]
-    return lazy, exact
+    monkeypatch.setenv("RSSYNC_K2_EXACT_SELECT", "1")
+    with pytest.raises(rssync_amd.RsSyncError):
+        rssync_amd.SyncProblem(seed=1)
+
+
+@pytest.fixture()
+def _two(variants_lib):
+    def make(seed):
+        import rssync_amd
+        lazy = rssync_amd.SyncProblem(seed=seed)                       # the product library
+        os.environ["RSSYNC_K2_EXACT_SELECT"] = "1"
+        try:
+            exact = rssync_amd.SyncProblem(seed=seed, _lib=variants_lib)   # the same sources + the exact-selection kernels
+        finally:
+            del os.environ["RSSYNC_K2_EXACT_SELECT"]
+        return lazy, exact
+    return make
 
 
 def _curves(p, F, step, radius, d0=0.0):
@@ -33,7 +64,7 @@ def _curves(p, F, step, radius, d0=0.0):
     (6, 5000, 0.002, 0.05, {}),                                    # 32 rows per thread
     (8, 3000, 0.002, 0.05, {"noise": 3e-3, "outliers": 0.3}),      # 16 rows per thread, heavy outliers
 ])
-def test_lazy_selection_equals_exact_selection(built, F, N, step, radius, kw):
+def test_lazy_selection_equals_exact_selection(built, _two, F, N, step, radius, kw):
     from rssync_amd import synth
     gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=70 + F)
     frames = list(synth.make_frames(gyro, 0, F, N, seed=70 + F, **kw))
@@ -50,7 +81,7 @@ def test_lazy_selection_equals_exact_selection(built, F, N, step, radius, kw):
     assert lazy.PreSync(0.0, 0, F, step, radius) == exact.PreSync(0.0, 0, F, step, radius)
 
 
-def test_ties_go_to_the_earlier_hypothesis_either_way(built):
+def test_ties_go_to_the_earlier_hypothesis_either_way(built, _two):
     """tracks duplicated many times over: different row pairs give the SAME direction and so the same quartile, bit
     for bit; the first of them must win (core_private.cpp:53 strict <) under both selections"""
     from rssync_amd import synth
