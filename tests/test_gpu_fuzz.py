@@ -1,4 +1,4 @@
-"""Randomised differential cases, HIP against the CPU restatement: gyro rate, number of frames, ragged track
+"""Randomised differential cases, HIP against the CPU restatement: gyro rate (200 Hz .. 6.4 kHz), number of frames, ragged track
 counts (2 .. 700: every rows-per-thread instantiation, frames of one wave and of four), sparse frame ids, sweep
 step / radius / centre all drawn per seed.  What is compared is what does not depend on rounding noise: the fp64
 rows, the fp64 loss and its analytic gradient, PreSync's per-frame costs where both sides chose the same
@@ -14,7 +14,7 @@ from oracle.oracle import OracleProblem
 
 pytestmark = pytest.mark.gpu
 
-RATES = [200.0, 400.0, 500.0, 800.0, 1000.0, 1600.0]
+RATES = [200.0, 400.0, 500.0, 800.0, 1000.0, 1600.0, 2000.0, 3200.0, 4000.0, 6400.0]   # (above ~1.7 kHz: spline windows in dynamic LDS)
 # RSSYNC_FUZZ_CASES=200 widens the seed ranges for a one-off soak; the committed default keeps the suite short
 EXTRA = int(os.environ.get("RSSYNC_FUZZ_CASES", "0"))
 

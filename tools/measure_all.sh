@@ -8,4 +8,8 @@ run orientation_sweep_c5.json python tools/gpu_orientations.py
 run pixels_kernel.json python tests/measure/gpu_pixels.py
 run gyro_device.json python tests/measure/gpu_gyro.py
 run config2_parity.json python tests/measure/gpu_config2_parity.py
-run fullsize_sync_parity.txt python tests/measure/gpu_fullsize_parity.py
+run fullsize_sync_parity.json python tests/measure/gpu_fullsize_parity.py
+run gyro_rate_sweep.json python tools/gpu_gyro_rate.py
+run quality_drift_noisy.json python tests/measure/gpu_quality.py
+[ -x tools/ubench/_build/handoff_probe ] && run handoff_probe.json tools/ubench/_build/handoff_probe 400
+[ -x tools/ubench/_build/stagec_mfma ] && run k2_mfma_raw.txt tools/ubench/_build/stagec_mfma
