@@ -433,10 +433,14 @@ int launch_lmeds(rship_ctx* c, LmedsParams p, const WinPlan& wp, int rpt, uint32
     }
     if (wp.cap) { // the window in dynamic LDS (gyro rates above ~1.7 kHz)
         switch (rpt) {
-            case 1: hipLaunchKernelGGL((lmeds_kernel<1, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
-            case 2: hipLaunchKernelGGL((lmeds_kernel<2, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
-            case 4: hipLaunchKernelGGL((lmeds_kernel<4, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
-            case 8: hipLaunchKernelGGL((lmeds_kernel<8, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
+            case 1: allow_dynamic_lds(lmeds_kernel<1, MODE, 0>, dyn);
+                    hipLaunchKernelGGL((lmeds_kernel<1, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
+            case 2: allow_dynamic_lds(lmeds_kernel<2, MODE, 0>, dyn);
+                    hipLaunchKernelGGL((lmeds_kernel<2, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
+            case 4: allow_dynamic_lds(lmeds_kernel<4, MODE, 0>, dyn);
+                    hipLaunchKernelGGL((lmeds_kernel<4, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
+            case 8: allow_dynamic_lds(lmeds_kernel<8, MODE, 0>, dyn);
+                    hipLaunchKernelGGL((lmeds_kernel<8, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
             case 16: allow_dynamic_lds(lmeds_kernel<16, MODE, 0>, dyn);
                      hipLaunchKernelGGL((lmeds_kernel<16, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
             case 32: allow_dynamic_lds(lmeds_kernel<32, MODE, 0>, dyn);
@@ -1933,7 +1937,15 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     ep.init.n_grp = W;
     ep.init.best_h = (int32_t*)c->init_h.p;
     ep.init.flags = (uint32_t*)c->flags.p;
-    ep.init.win_cap = cap64; // (fp32 knots are half the size: the same count always fits the region)
+    // The search's fp32 window must put every frame on the SAME spline path as the launch chain's search kernel does
+    // (interior and general path round differently in fp32: a near-tie between hypotheses could fall the other way and
+    // the executor would no longer return the chain's bits -- caught by RSSYNC_EXECUTOR_CHECK on a randomised case at
+    // 3.2 kHz in round 4): the capacity the chain's planner chooses, 80 knots where it keeps the compiled-in window.
+    {
+        const WinPlan wp_init = plan_lmeds_window<1>(c, 0.0, 1u);
+        ep.init.win_cap = wp_init.cap ? wp_init.cap : (uint32_t)kWinMax;
+        if ((size_t)ep.init.win_cap * 64u > region) return set_err(c, "sync_exec: the search's window does not fit the wave's LDS region");
+    }
     // motion
     if (fill_motion(c, ep.mo)) return 1;
     ep.mo.kd = ep.mo_kd;

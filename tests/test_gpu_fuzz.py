@@ -82,7 +82,7 @@ def test_random_noisy_case(seed):
         np.testing.assert_allclose(fch[:, big][same], fco[:, big][same], rtol=3e-3)
         cbh, cbo = fch[:, big].sum(axis=1), fco[:, big].sum(axis=1)
         rel = np.abs(cbh - cbo) / cbo   # a candidate where one frame's near-tie went the other way moves by a few %
-        assert np.mean(rel <= 3e-3) > 0.9 and rel.max() < 0.1
+        assert np.sum(rel > 3e-3) <= max(1, 0.1 * len(rel)) and rel.max() < 0.1   # (one flip allowed however few candidates a case has)
         srt = np.sort(cbo)
         if len(srt) > 1 and srt[1] - srt[0] > 0.08 * srt[0]:   # a clear minimum: the same candidate wins
             assert int(np.argmin(cbh)) == int(np.argmin(cbo))
