@@ -44,6 +44,7 @@
 #include "sync_math.hpp"
 #include "lens_math.hpp"
 #include "gyro_math.hpp"
+#include "window_plan.hpp"
 
 using rs::f3;
 using rs::f4;
@@ -256,24 +257,18 @@ uint32_t big_rows(const rship_ctx* c) { return (c->max_n + kBlock - 1) / kBlock 
 int rpt_of(const rship_ctx* c) { return c->force_big ? 0 : rpt_for(c->max_n); }
 
 // ---- spline windows in dynamic LDS (gyro rates above ~1.7 kHz: a frame spans 0.044 s x rate knots) ----
-constexpr uint32_t kCap64Max = 384;                 // 48 KB of fp64 window: one K1 window, three K3 workgroups per CU
 constexpr uint32_t kLossWinBytes = kLossBatch * kWinMax * 128u; // K1's LDS budget for its side-by-side windows (51 KB at 80 knots)
-uint32_t cap64_for(float max_span) {
-    uint32_t need = (uint32_t)std::ceil(std::max(max_span, 0.f)) + 1u;
-    need = (need + 15u) / 16u * 16u;
-    return std::min(std::max(need, (uint32_t)kWinMax), kCap64Max);
-}
-// The fp64 window the launches use.  Problems of small frames (up to 256 tracks: one WAVE per frame in K1 / K3 / the
-// executor) only gain from a wide window while enough waves still share a CU: a 130-track frame makes 260 coefficient
-// fetches per evaluation, and staging a 190-knot window (24 KB) for them costs more than fetching them from L2 once
-// the window's LDS leaves fewer than six waves per CU.  Measured on 98 sync points of 61 x 130 (profiles/
-// r4_gyro_rate_sweep.json): 2 kHz 21.0 ms with a 96-knot window against 25.0 on the general path; 4 kHz 25.8 ms with
-// 192 knots against 21.6 on the general path.  So such problems keep the 80-knot window beyond kCap64SmallMax knots.
-constexpr uint32_t kCap64SmallMax = 176;
+using rs::WinPlan;
+static_assert(rs::kPlanWinStatic == (uint32_t)kWinMax, "window_plan.hpp and kernels/common.hpp disagree on the compiled-in window");
+// The fp64 window the launches use (window_plan.hpp: cap64_for, cap64_used).  Problems of small frames (up to 256
+// tracks: one WAVE per frame in K1 / K3 / the executor) only gain from a wide window while enough waves still share a CU:
+// a 130-track frame makes 260 coefficient fetches per evaluation, and staging a 190-knot window (24 KB) for them costs
+// more than fetching them from L2 once the window's LDS leaves fewer than six waves per CU.  Measured on 98 sync points
+// of 61 x 130 (profiles/r4_gyro_rate_sweep.json): 2 kHz 20.6 ms with a 96-knot window against 24.4 on the general path;
+// 4 kHz 25.8 ms with 192 knots against 21.6 on the general path.
 uint32_t cap64_of(const rship_ctx* c) {
     const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
-    if (n_all <= 256u && !c->force_big && c->cap64 > kCap64SmallMax) return (uint32_t)kWinMax;
-    return c->cap64;
+    return rs::cap64_used(c->cap64, n_all, c->force_big);
 }
 template <class K>
 uint32_t static_lds_of(K kernel) {
@@ -302,11 +297,6 @@ uint32_t sel_max_n(const rship_ctx* c) {
 // the largest number of workgroups per CU whose LDS share still holds the frame and a chunk of at least eight
 // candidates, then the longest chunk (<= 32) that fits.  Only when even one workgroup per CU cannot hold it do the
 // kernels fall back to the general path (table from L2).
-constexpr uint32_t kSmallWinMax = 128;
-struct WinPlan {
-    uint32_t cap = 0;   // 0: the compiled-in kWinMax window; otherwise knots of dynamic LDS
-    uint32_t chunk = 1; // candidates per workgroup
-};
 template <int MODE>
 uint32_t lmeds_dynamic_static_lds(int rpt, bool small) {
     if (small) {
@@ -339,47 +329,18 @@ uint32_t lmeds_all_tracks(const rship_ctx* c) { return c->force_big ? 0xffffffff
 
 template <int MODE>
 WinPlan plan_lmeds_window(rship_ctx* c, double step_knots, uint32_t chunk_want) {
-    WinPlan w;
-    w.chunk = chunk_want;
     const LmedsKind kind = lmeds_kind(c);
-    if (kind == LmedsKind::Big) return w; // (tiles in global memory, general path throughout)
-    const double span = c->max_span;
-    const uint32_t min_chunk = std::min(8u, chunk_want);
-    auto fit = [&](double cap) -> uint32_t { // candidates whose delays fit a window of `cap` knots next to the widest frame
-        if (cap < span + 1.0) return 0;
-        if (!(step_knots > 0)) return chunk_want;
-        const double n = std::floor((cap - span - 1.0) / step_knots) + 1.0;
-        return n >= (double)chunk_want ? chunk_want : (uint32_t)n;
-    };
-    const uint32_t f80 = fit((double)kWinMax);
-    if (f80 >= min_chunk) { w.chunk = f80; return w; }
-    if (c->force_general) { // rounds 1-3: shorten the chunk down to four candidates, else let the window overflow
-        if (f80 >= 4) w.chunk = f80;
+    if (kind == LmedsKind::Big) { // (tiles in global memory, general path throughout)
+        WinPlan w;
+        w.chunk = chunk_want;
         return w;
     }
     const bool small = kind == LmedsKind::Small;
-    const int rpt = small ? (int)std::max(1u, (lmeds_all_tracks(c) + 63u) / 64u) : rpt_of(c);
-    const uint32_t fixed = lmeds_dynamic_static_lds<MODE>(rpt, small);
-    if (!fixed) return w;
-    const int wg_max = small ? 20 : lmeds_waves(rpt);
-    for (int wg = wg_max; wg >= 1; --wg) {
-        const int share = c->lds_per_cu / wg - 1024; // (allocation granularity, alignment)
-        if (share <= (int)fixed) continue;
-        const uint32_t cap_t = std::min(2048u, ((uint32_t)share - fixed) / 64u / 4u * 4u);
-        const uint32_t f = fit((double)cap_t);
-        if (f < min_chunk) continue;
-        const double need = span + 1.0 + (step_knots > 0 ? (f - 1) * step_knots : 0.0);
-        const uint32_t cap = std::min(cap_t, ((uint32_t)std::ceil(need) + 3u) / 4u * 4u + 4u);
-        // one wave per frame (K2s): a window of more than kSmallWinMax knots costs more in resident waves than the
-        // frame's few hundred coefficient fetches cost from L2 (r4_gyro_rate_sweep.json: 98 x 61 x 130 x 200
-        // candidates, 2 kHz: 1.41 ms with a 112-knot window against 1.54 on the general path; 4 kHz: 1.98 ms with 228
-        // knots against 1.54) -- keep the general path there
-        if (small && cap > kSmallWinMax) break;
-        w.chunk = f;
-        w.cap = cap;
-        return w;
-    }
-    return w; // does not fit any LDS share: the general path, as before
+    const int rpt = small ? (int)std::max(1u, std::min(4u, (lmeds_all_tracks(c) + 63u) / 64u)) : rpt_of(c);
+    // (the kernel's LDS footprint is only asked for when the compiled-in window does not do: plan_window's first test)
+    const bool fits80 = rs::plan_fit((double)kWinMax, c->max_span, step_knots, chunk_want) >= std::min(8u, chunk_want);
+    const uint32_t fixed = (fits80 || c->force_general) ? 0u : lmeds_dynamic_static_lds<MODE>(rpt, small);
+    return rs::plan_window(c->max_span, step_knots, chunk_want, small, small ? 20 : lmeds_waves(rpt), fixed, c->lds_per_cu, c->force_general);
 }
 
 template <int MODE>
@@ -1035,7 +996,7 @@ int rship_pack_frames(rship_ctx* c, const rship_frame* table, const rship_pack_f
         const float span = floorf(table[i].tmax) - floorf(table[i].tmin) + 2.f; // knots a frame touches at one delay
         if (table[i].n_rays && span > c->max_span) c->max_span = span;
     }
-    c->cap64 = c->force_general ? (uint32_t)kWinMax : cap64_for(c->max_span);
+    c->cap64 = c->force_general ? (uint32_t)kWinMax : rs::cap64_for(c->max_span);
     const size_t tr = (size_t)total_rays;
     if (ensure(c, c->rays_a, tr ? tr * 16 : 16) || ensure(c, c->rays_b, tr ? tr * 16 : 16) ||
         ensure(c, c->rays64, tr ? tr * 64 : 64))

@@ -1,0 +1,121 @@
+"""The host arithmetic that sizes the kernels' LDS spline windows for a problem's gyro rate (rs-sync_amd/csrc/
+window_plan.hpp; DESIGN.md section 3 "Gyro rate").  It is plain C++ without HIP, so it is compiled here with g++ behind a
+three-function C shim and checked on the CPU: the benchmark's shape keeps the compiled-in window, every plan holds the
+widest frame plus its chunk, no plan exceeds its share of the CU's LDS, and the rules for small frames.
+Reference for what the window must hold: core_private.cpp:19-20 (x = (ts - start + delay) * sample_rate)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = r'''
+#include "window_plan.hpp"
+extern "C" {
+void plan(double span, double step, unsigned want, int small_, int wg_max, unsigned fixed, int lds, int legacy, unsigned* out) {
+    const rs::WinPlan w = rs::plan_window(span, step, want, small_ != 0, wg_max, fixed, lds, legacy != 0);
+    out[0] = w.cap; out[1] = w.chunk;
+}
+unsigned cap64_for(float span) { return rs::cap64_for(span); }
+unsigned cap64_used(unsigned cap64, unsigned n_all, int force_big) { return rs::cap64_used(cap64, n_all, force_big != 0); }
+}
+'''
+LDS = 160 * 1024
+TILE8 = 26432      # static LDS of lmeds_kernel<8, 0, 0, true> (2048 tracks), of the one-wave kernel for 130 tracks
+SMALL3 = 2600
+
+
+@pytest.fixture(scope="module")
+def lib(tmp_path_factory):
+    d = tmp_path_factory.mktemp("plan")
+    src = d / "shim.cpp"
+    src.write_text(SHIM)
+    out = d / "libplan.so"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "rs-sync_amd", "csrc"), "-o", str(out), str(src)])
+    L = ctypes.CDLL(str(out))
+    L.plan.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.c_int,
+                       ctypes.POINTER(ctypes.c_uint)]
+    L.cap64_for.argtypes = [ctypes.c_float]
+    L.cap64_for.restype = ctypes.c_uint
+    L.cap64_used.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_int]
+    L.cap64_used.restype = ctypes.c_uint
+    return L
+
+
+def plan(L, span, step, want=32, small=False, wg_max=5, fixed=TILE8, lds=LDS, legacy=False):
+    out = (ctypes.c_uint * 2)()
+    L.plan(span, step, want, int(small), wg_max, fixed, lds, int(legacy), out)
+    return int(out[0]), int(out[1])
+
+
+def span_of(fs):      # a frame pair of the synthetic camera: 1/30 s + 11.1 ms of readout, + 2 knots
+    return np.floor(0.0444 * fs) + 2
+
+
+def test_the_benchmark_shape_keeps_the_compiled_in_window(lib):
+    # 400 Hz, candidates 0.5 ms = 0.2 knots apart, chunks of 32: 19.8 + 6.2 + 1 knots of 80
+    assert plan(lib, span_of(400), 0.2) == (0, 32)
+    assert plan(lib, span_of(1000), 0.5) == (0, 32)
+    # close to the edge the chunk shortens before the window grows (at least eight candidates)
+    cap, chunk = plan(lib, 70.0, 0.8)
+    assert cap == 0 and 8 <= chunk < 32 and 70 + (chunk - 1) * 0.8 + 1 <= 80
+
+
+def fit(cap, span, step, want):
+    if cap < span + 1:
+        return 0
+    return want if step <= 0 else int(min(want, np.floor((cap - span - 1) / step) + 1))
+
+
+@pytest.mark.parametrize("fs", [1800, 2000, 3200, 4000, 6400, 8000, 12000, 20000])
+@pytest.mark.parametrize("fixed,wg_max", [(TILE8, 5), (14144, 5), (50000, 2), (99000, 1)])
+def test_dynamic_plans_hold_the_frame_and_fit_the_lds(lib, fs, fixed, wg_max):
+    span, step = span_of(fs), 0.0005 * fs
+    cap, chunk = plan(lib, span, step, fixed=fixed, wg_max=wg_max)
+    # the rule, restated: the most workgroups per CU whose LDS share holds the widest frame and eight candidates, then
+    # the longest chunk that share holds, then no more knots than that chunk needs
+    want = None
+    for wg in range(wg_max, 0, -1):
+        share = LDS // wg - 1024
+        if share <= fixed:
+            continue
+        cap_t = min(2048, (share - fixed) // 64 // 4 * 4)
+        f = fit(cap_t, span, step, 32)
+        if f >= 8:
+            want = (wg, cap_t, f)
+            break
+    if want is None:
+        assert (cap, chunk) == (0, 32)            # nothing holds it: the compiled-in window, general path
+        return
+    wg, cap_t, f = want
+    assert chunk == f and 8 <= chunk <= 32
+    assert span + 1 + (chunk - 1) * step <= cap <= cap_t          # the widest frame and the whole chunk, within the share
+    assert cap <= span + 1 + (chunk - 1) * step + 8               # ... and no more LDS than that needs
+    assert fixed + cap * 64 + 1024 <= LDS // wg
+
+
+def test_small_frames_keep_the_general_path_beyond_128_knots(lib):
+    assert plan(lib, span_of(2000), 1.0, want=32, small=True, wg_max=20, fixed=SMALL3)[0] in range(92, 129)
+    cap, chunk = plan(lib, span_of(4000), 2.0, want=32, small=True, wg_max=20, fixed=SMALL3)
+    assert (cap, chunk) == (0, 32)
+    # GuessMotion's search: one candidate per workgroup
+    cap, chunk = plan(lib, span_of(2000), 0.0, want=1, small=True, wg_max=20, fixed=SMALL3)
+    assert chunk == 1 and span_of(2000) + 1 <= cap <= span_of(2000) + 9
+    assert plan(lib, span_of(4000), 0.0, want=1, small=True, wg_max=20, fixed=SMALL3) == (0, 1)
+
+
+def test_legacy_switch_never_grows_the_window(lib):
+    for fs in (400, 2000, 8000):
+        cap, chunk = plan(lib, span_of(fs), 0.0005 * fs, legacy=True)
+        assert cap == 0
+    assert plan(lib, 74.0, 0.8, legacy=True)[1] in range(4, 9)
+
+
+def test_fp64_window_capacity(lib):
+    assert lib.cap64_for(20.0) == 80 and lib.cap64_for(79.0) == 80 and lib.cap64_for(80.0) == 96
+    assert lib.cap64_for(180.0) == 192 and lib.cap64_for(358.0) == 368 and lib.cap64_for(5000.0) == 384
+    # problems of small frames keep 80 knots beyond 176; a forced large-frame run does not count as small
+    assert lib.cap64_used(96, 130, 0) == 96 and lib.cap64_used(176, 256, 0) == 176
+    assert lib.cap64_used(192, 130, 0) == 80 and lib.cap64_used(192, 257, 0) == 192 and lib.cap64_used(192, 130, 1) == 192
