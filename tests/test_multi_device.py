@@ -14,9 +14,9 @@ import pytest
 F, N = 200, 40
 
 
-def _case():
+def _case(fs=400.0):
     from rssync_amd import synth
-    gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=11)
+    gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, fs=fs, seed=11)
     frames = list(synth.make_frames(gyro, 0, F, N, seed=11))
     # ragged: a few frames with other track counts, sparse ids at the end
     out = []
@@ -99,6 +99,20 @@ def test_several_contexts_on_the_gpu_equal_one(tmp_path):
         p = rssync_amd.SyncProblem(seed=5, max_outer_iters=12)
         p.set_devices(ids)
         _check(one, _run(_fill(p, case)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fs", [2000.0, 4000.0])
+def test_several_contexts_at_high_gyro_rates(fs):
+    """Above ~1.7 kHz every context plans its own spline windows (capacity, candidates per workgroup) from the frames
+    IT holds; which path a frame's rows take must not depend on that, or the sums of a sharded object would no longer be
+    the single-device run's bits."""
+    import rssync_amd
+    case = _case(fs)
+    one = _run(_fill(rssync_amd.SyncProblem(seed=5, max_outer_iters=12), case))
+    p = rssync_amd.SyncProblem(seed=5, max_outer_iters=12)
+    p.set_devices([0, 0, 0])
+    _check(one, _run(_fill(p, case)))
 
 
 def _gyro_routes(make, device_lists):
