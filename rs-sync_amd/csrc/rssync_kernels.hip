@@ -1735,6 +1735,7 @@ static int sync_run_body(rship_ctx* c, const double* d0, int max_outer, double s
 // trace[W][trace_rows][6] (trace_rows >= repeats * max_outer).  Window w samples call r with stream_first + r + w * stride.
 int rship_exec_supported(rship_ctx* c) {
     const uint32_t n = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
+    if (c->force_big) return 0; // (RSSYNC_FORCE_BIG: every frame through the large-frame kernels, whose association the one-wave tasks do not have)
     return n >= 2 && n <= 64u * kSmallMaxRpt && c->n_sel < (1u << 24) ? 1 : 0; // (a queue cell holds the slot in 24 bits)
 }
 
