@@ -137,8 +137,9 @@ int rssync_ext_set_executor_check(rssync_problem* p, int on);
 /* diagnostics: how the kernels' LDS spline windows were laid out for this problem's gyro rate (first device):
  * out = {widest frame in knots, knots per fp64 window, fp32 window of the last PreSync sweep (0 = the 80 knots compiled
  * into the kernel, else knots of dynamic LDS), its candidates per workgroup, the same window for the last GuessMotion
- * search, delays per pass of the line-search trials' kernel} */
-int rssync_ext_window_info(rssync_problem* p, uint32_t out[6]);
+ * search, delays per pass of the line-search trials' kernel, widest frame counting only the two ends' ranges of each
+ * pair (what the dynamic windows stage where that is fewer knots), 0} */
+int rssync_ext_window_info(rssync_problem* p, uint32_t out[8]);
 int rssync_ext_executor_stats(rssync_problem* p, uint64_t* runs, uint64_t* checked, uint32_t queue[4]);
 /* Diagnostics of the bit-exactness tests (tests/test_gpu_bitexact.py).  GuessMotion's 200-hypothesis search runs
  * in fp32 and leaves one winning hypothesis index per slot (window-major, frames ascending); with recording on,

@@ -32,15 +32,23 @@ extern "C" {
 
 typedef struct rship_ctx rship_ctx;
 
-/* one record of the device frame table (48 bytes) */
+/* one record of the device frame table (56 bytes) */
+#define RSHIP_NO_SPLIT 0xffffffffu
 typedef struct rship_frame {
     uint32_t ray_offset; /* first ray of the frame in the packed streams */
     uint32_t n_rays;
     int32_t base_knot; /* floor(min over rays of (ts - start) * fs) */
     float tmin, tmax;  /* min / max of the per-ray offsets ta, tb as the fp32 streams hold them */
-    uint32_t reserved;
+    /* The two ENDS of a frame pair cover far fewer knots than the pair: ts_a lies within one read-out time of the
+     * current frame, ts_b of the next (core_testcode.cpp:144-145), a frame interval apart.  range_a / range_b: the
+     * knots the a-end / b-end offsets touch at delay 0, relative to base_knot, as lo | hi << 16 (hi inclusive =
+     * floor of the end's largest offset); RSHIP_NO_SPLIT = not known or not representable (the kernels then stage
+     * the whole span tmin .. tmax, which is always valid). */
+    uint32_t range_a;
     int64_t id;            /* caller's frame number (keys the hypothesis sampler) */
     double tmin64, tmax64; /* the same bounds as the fp64 streams hold them */
+    uint32_t range_b;
+    uint32_t reserved;
 } rship_frame;
 
 /* status bits reported by the LMedS kernel; the host turns them into the
@@ -236,8 +244,9 @@ int rship_exec_supported(rship_ctx* c);
 int rship_exec_stats(rship_ctx* c, uint32_t out[4]);
 /* the spline windows of the last launches: out[0] widest frame in knots, out[1] knots per fp64 window (dynamic LDS),
  * out[2] fp32 window of the last PreSync sweep (0 = the 80 knots compiled in, else knots of dynamic LDS), out[3] its
- * candidates per workgroup, out[4] as out[2] for the last GuessMotion search, out[5] delays per pass of the trials' kernel */
-int rship_window_info(rship_ctx* c, uint32_t out[6]);
+ * candidates per workgroup, out[4] as out[2] for the last GuessMotion search, out[5] delays per pass of the trials' kernel,
+ * out[6] widest frame counting only the two ends' ranges of each pair (= out[0] where the table does not know them), out[7] 0 */
+int rship_window_info(rship_ctx* c, uint32_t out[8]);
 int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream_first, uint32_t stream_stride, uint64_t seed,
                     int max_outer, double search_center, double search_radius, double* d_out, double* cost, int32_t* iters,
                     double* trace, uint32_t trace_rows);

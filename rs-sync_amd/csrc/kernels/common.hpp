@@ -98,6 +98,38 @@ __device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)
 
 __device__ __forceinline__ bool finite_f(float x) { return (__float_as_uint(x) & kInfBits) != kInfBits; }
 
+struct FrameRec { // == rship_frame
+    uint32_t off, n;
+    int32_t base_knot;
+    float tmin, tmax;
+    uint32_t range_a; // knots the a-end touches at delay 0, relative to base_knot: lo | hi << 16 (RSHIP_NO_SPLIT: unknown)
+    int64_t id;
+    double tmin64, tmax64;
+    uint32_t range_b;
+    uint32_t reserved;
+};
+static_assert(sizeof(FrameRec) == sizeof(rship_frame), "frame record layout");
+
+// The knots a frame's spline window must hold while the integer parts of the delays span [kd_lo, kd_hi]: the whole
+// pair [lo, hi] (the caller's, from tmin / tmax) and -- where the table knows them -- the two ENDS' ranges.  ts_a lies
+// within one read-out time of the current frame and ts_b of the next (core_testcode.cpp:144-145), a frame interval
+// apart: at high gyro rates the two ends together cover half the knots of the pair or fewer.
+struct FrameKnots {
+    int lo, hi;
+    int a_lo, a_hi, b_lo, b_hi;
+    bool split;
+};
+__device__ __forceinline__ FrameKnots frame_knots(const FrameRec& fr, int lo, int hi, int kd_lo, int kd_hi) {
+    FrameKnots k;
+    k.lo = lo; k.hi = hi;
+    k.split = fr.range_a != RSHIP_NO_SPLIT && fr.range_b != RSHIP_NO_SPLIT;
+    k.a_lo = fr.base_knot + (int)(fr.range_a & 0xffffu) + kd_lo;
+    k.a_hi = fr.base_knot + (int)(fr.range_a >> 16) + kd_hi + 1; // (+1: the delay's fraction can carry into the next knot)
+    k.b_lo = fr.base_knot + (int)(fr.range_b & 0xffffu) + kd_lo;
+    k.b_hi = fr.base_knot + (int)(fr.range_b >> 16) + kd_hi + 1;
+    return k;
+}
+
 // ---------------------------------------------------------------------------
 // spline window in LDS: SoA by coefficient kind so that neighbouring knots
 // fall into different banks (ds_read_b128 of kind k, knot j at (k*kWinMax + j) * 16 B).
@@ -109,6 +141,9 @@ struct Spline {
     int w0, wlen;             // staged range [w0, w0 + wlen)
     int path;                 // kPathGlobal / kPathLds / kPathInterior, uniform over the workgroup
     int cap;                  // capacity of the window when it is not a compile-time constant (CAP = 0)
+    bool whole_pair;          // CAP = 0 only: never stage the two ends separately (set by the caller; false = allowed)
+    int w0b;                  // CAP = 0 only: knot index that maps to window slot 0 for the B END's fetches (two ranges
+                              // staged one after the other: stage_window_ends); = w0 where one range is staged
 };
 
 // How a workgroup reads spline coefficients.  The choice is made once per workgroup from the knot
@@ -131,6 +166,7 @@ __device__ __forceinline__ void stage_window(Spline& s, f4* s_win, int lo, int h
     s.path = (wlen <= cap && interior) ? kPathInterior : kPathGlobal;
     if (wlen > cap) wlen = cap;
     s.w0 = lo;
+    s.w0b = lo;
     s.wlen = wlen;
     s.lds = s_win;
     for (int e = threadIdx.x; e < wlen * 4; e += n_threads) {
@@ -139,14 +175,43 @@ __device__ __forceinline__ void stage_window(Spline& s, f4* s_win, int lo, int h
     }
 }
 
-template <int PATH, int CAP = kWinMax>
+// The window of the dynamic-LDS instantiations (CAP = 0): where the frame table knows the two ends' ranges, they are
+// disjoint and interior and together fit the capacity, the a-end's knots go to slots [0, lenA) and the b-end's to
+// [lenA, lenA + lenB) -- fetches of the b end subtract w0b instead of w0 -- and the knots between them are not staged at
+// all; in every other case the whole pair, exactly as stage_window does.  Compile-time windows (the 80-knot kernels the
+// benchmark runs) always take the whole pair: their code does not change.
+template <int CAP>
+__device__ __forceinline__ void stage_window_ends(Spline& s, f4* s_win, const FrameKnots& k, int n_threads = kBlock) {
+    if constexpr (CAP == 0) {
+        const int cap = s.cap, n = s.n;
+        const int lenA = k.a_hi - k.a_lo + 1, lenB = k.b_hi - k.b_lo + 1;
+        const bool disjoint = k.b_lo > k.a_hi + 1 || k.a_lo > k.b_hi + 1;
+        const bool interior = k.a_lo >= 0 && k.b_lo >= 0 && k.a_hi <= n - 2 && k.b_hi <= n - 2;
+        if (k.split && !s.whole_pair && disjoint && interior && lenA + lenB <= cap && lenA + lenB < k.hi - k.lo + 1) {
+            s.path = kPathInterior;
+            s.w0 = k.a_lo;
+            s.w0b = k.b_lo - lenA;
+            s.wlen = lenA + lenB;
+            s.lds = s_win;
+            for (int e = threadIdx.x; e < (lenA + lenB) * 4; e += n_threads) {
+                const int slot = e >> 2, kind = e & 3;
+                const int knot = slot < lenA ? k.a_lo + slot : k.b_lo + (slot - lenA);
+                s_win[kind * cap + slot] = s.g[(size_t)knot * 4 + kind];
+            }
+            return;
+        }
+    }
+    stage_window<CAP>(s, s_win, k.lo, k.hi, n_threads);
+}
+
+template <int PATH, int CAP = kWinMax, bool END_B = false>
 __device__ __forceinline__ void fetch_coef(const Spline& s, int ci, f4& y, f4& b, f4& c, f4& d) {
     if (PATH == kPathGlobal) {
         const f4* p = s.g + (size_t)ci * 4;
         y = p[0]; b = p[1]; c = p[2]; d = p[3];
     } else {
         const int cap = CAP ? CAP : s.cap;
-        const int rel = ci - s.w0;
+        const int rel = ci - ((CAP == 0 && END_B) ? s.w0b : s.w0);
         y = s.lds[rel];
         b = s.lds[cap + rel];
         c = s.lds[2 * cap + rel];
@@ -184,7 +249,7 @@ __device__ __forceinline__ void residual_row(const Spline& s, f4 A, f4 B, int ba
     fetch_coef<PATH, CAP>(s, ka.ci, ya, ba, ca, da);
     rs::Knot kb = (PATH == kPathInterior) ? (SWEEP ? locate_sweep(B.w, base, fd) : rs::spline_locate_interior(B.w, base, fd))
                                           : rs::spline_locate(B.w, base, fd, s.n);
-    fetch_coef<PATH, CAP>(s, kb.ci, yb, bb, cb, db);
+    fetch_coef<PATH, CAP, true>(s, kb.ci, yb, bb, cb, db);
     if (!DERIV && PATH == kPathInterior) {
         // hot path, all in packed fp32.  Horner per end on the component pairs (w,x), (y,z) exactly as
         // ds_read_b128 delivers them (same fma chain per component as rs::horner, so the values are
@@ -224,15 +289,5 @@ __device__ __forceinline__ void residual_row(const Spline& s, f4 A, f4 B, int ba
         if (DERIV) dP = rs::add(rs::cross(dar, br), rs::cross(ar, dbr));
     }
 }
-
-struct FrameRec { // == rship_frame
-    uint32_t off, n;
-    int32_t base_knot;
-    float tmin, tmax;
-    uint32_t reserved;
-    int64_t id;
-    double tmin64, tmax64;
-};
-static_assert(sizeof(FrameRec) == sizeof(rship_frame), "frame record layout");
 
 } // namespace

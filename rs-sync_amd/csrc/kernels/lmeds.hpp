@@ -64,6 +64,8 @@ struct LmedsParams {
     // knots the spline window in DYNAMIC LDS holds (the WIN = 0 / CAP = 0 instantiations: gyro rates whose frames
     // span more than kWinMax knots); the launch passes win_cap * 64 bytes of dynamic LDS
     uint32_t win_cap;
+    uint32_t win_whole_pair; // 1: a dynamic window behaves like the compiled-in one -- whole pairs only (the window executor's
+                             // search where the launch chain's search kernel uses the compiled-in window)
 };
 
 // ---- LMedS tile in LDS, struct-of-arrays: unit rows n = safe_normalize(P).  The norms |P|
@@ -433,6 +435,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     sp.g = p.coef;
     sp.n = p.n_knots;
     sp.cap = (int)p.win_cap;
+    sp.whole_pair = p.win_whole_pair != 0;
     {
         int kd_lo = p.kd[c0 * p.n_grp + g], kd_hi = kd_lo;
         for (uint32_t c = c0 + 1; c < c1; ++c) {
@@ -440,8 +443,8 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
             kd_lo = v < kd_lo ? v : kd_lo;
             kd_hi = v > kd_hi ? v : kd_hi;
         }
-        stage_window<WIN>(sp, s_win, fr.base_knot + (int)floorf(fr.tmin) + kd_lo,
-                     fr.base_knot + (int)floorf(fr.tmax) + kd_hi + 1);
+        stage_window_ends<WIN>(sp, s_win, frame_knots(fr, fr.base_knot + (int)floorf(fr.tmin) + kd_lo,
+                                                       fr.base_knot + (int)floorf(fr.tmax) + kd_hi + 1, kd_lo, kd_hi));
     }
 #pragma unroll
     for (int j = 0; j < RPT; ++j) { // rows beyond N: NaN once, never rewritten

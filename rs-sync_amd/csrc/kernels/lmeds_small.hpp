@@ -60,6 +60,7 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
     sp.g = p.coef;
     sp.n = p.n_knots;
     sp.cap = (int)p.win_cap;
+    sp.whole_pair = p.win_whole_pair != 0;
     {
         int kd_lo = ld_m<SC1>(&p.kd[c0 * p.n_grp + g]), kd_hi = kd_lo;
         for (uint32_t c = c0 + 1; c < c1; ++c) {
@@ -67,7 +68,8 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
             kd_lo = v < kd_lo ? v : kd_lo;
             kd_hi = v > kd_hi ? v : kd_hi;
         }
-        stage_window<CAP>(sp, s_win, fr.base_knot + (int)floorf(fr.tmin) + kd_lo, fr.base_knot + (int)floorf(fr.tmax) + kd_hi + 1, 64);
+        stage_window_ends<CAP>(sp, s_win, frame_knots(fr, fr.base_knot + (int)floorf(fr.tmin) + kd_lo,
+                                                       fr.base_knot + (int)floorf(fr.tmax) + kd_hi + 1, kd_lo, kd_hi), 64);
     }
     __syncthreads();
 

@@ -34,6 +34,8 @@ struct Spline64 {
     int w0, wlen;
     int path; // kPathGlobal / kPathLds64 / kPathInterior, uniform over the workgroup
     int cap;  // knots the window holds (set by the caller before staging)
+    int w0b;  // run-time capacity only: the knot that maps to slot 0 for the B END's fetches (two ranges staged one after
+              // the other, common.hpp: stage_window_ends); = w0 where the whole pair is staged
 };
 
 // the general parameter logic (extrapolation branches) with the coefficients from the LDS window: a delay that puts a
@@ -54,6 +56,7 @@ __device__ __forceinline__ void stage_window64(Spline64& s, d4* s_win, int lo, i
     s.path = wlen <= cap ? (interior ? kPathInterior : kPathLds64) : kPathGlobal;
     if (wlen > cap) wlen = cap;
     s.w0 = lo;
+    s.w0b = lo;
     s.wlen = wlen;
     s.lds = s_win;
     for (int e = threadIdx.x; e < wlen * 4; e += blockDim.x) {
@@ -62,13 +65,13 @@ __device__ __forceinline__ void stage_window64(Spline64& s, d4* s_win, int lo, i
     }
 }
 
-template <int PATH, int CAP = 0>
+template <int PATH, int CAP = 0, bool END_B = false>
 __device__ __forceinline__ void fetch_coef64(const Spline64& s, int ci, d4& y, d4& b, d4& c, d4& d) {
     if (PATH == kPathGlobal) {
         const d4* p = s.g + (size_t)ci * 4;
         y = p[0]; b = p[1]; c = p[2]; d = p[3];
     } else {
-        const int rel = ci - s.w0, cap = CAP ? CAP : s.cap;
+        const int rel = ci - ((CAP == 0 && END_B) ? s.w0b : s.w0), cap = CAP ? CAP : s.cap;
         y = s.lds[rel];
         b = s.lds[cap + rel];
         c = s.lds[2 * cap + rel];
@@ -94,7 +97,7 @@ __device__ __forceinline__ void residual_row64(const Spline64& s, double2 X, dou
     fetch_coef64<PATH, CAP>(s, ka.ci, ya, ba, ca, da);
     const rs::KnotT<double> kb = (PATH == kPathInterior) ? rs::spline_locate_interior(T.y, base, fd)
                                                          : rs::spline_locate(T.y, base, fd, s.n);
-    fetch_coef64<PATH, CAP>(s, kb.ci, yb, bb, cb, db);
+    fetch_coef64<PATH, CAP, true>(s, kb.ci, yb, bb, cb, db);
     d3 ar, br, dar, dbr;
     rs::rotate_ray<DERIV>(ya, ba, ca, da, ka, d3{X.x, Y.x, Z.x}, ar, dar);
     rs::rotate_ray<DERIV>(yb, bb, cb, db, kb, d3{X.y, Y.y, Z.y}, br, dbr);
@@ -116,9 +119,32 @@ __device__ __forceinline__ void residual_row64(const Spline64& s, const Rays64& 
     residual_row64_auto<DERIV>(s, r.q0[idx], r.q1[idx], r.q2[idx], r.q3[idx], base, fd, P, dP);
 }
 
+// the frame's window at one delay: the two ends' knot ranges one after the other where the table knows them and the
+// capacity is a run-time value (the same rule as stage_window_ends of the fp32 kernels), else the whole pair
 template <int CAP = 0>
 __device__ __forceinline__ void frame_window64(Spline64& sp, d4* s_win, const FrameRec& fr, int kd) {
-    stage_window64<CAP>(sp, s_win, fr.base_knot + (int)floor(fr.tmin64) + kd, fr.base_knot + (int)floor(fr.tmax64) + kd + 1);
+    const int lo = fr.base_knot + (int)floor(fr.tmin64) + kd, hi = fr.base_knot + (int)floor(fr.tmax64) + kd + 1;
+    if constexpr (CAP == 0) {
+        const FrameKnots k = frame_knots(fr, lo, hi, kd, kd);
+        const int cap = sp.cap, n = sp.n;
+        const int lenA = k.a_hi - k.a_lo + 1, lenB = k.b_hi - k.b_lo + 1;
+        const bool disjoint = k.b_lo > k.a_hi + 1 || k.a_lo > k.b_hi + 1;
+        const bool interior = k.a_lo >= 0 && k.b_lo >= 0 && k.a_hi <= n - 2 && k.b_hi <= n - 2;
+        if (k.split && disjoint && interior && lenA + lenB <= cap && lenA + lenB < hi - lo + 1) {
+            sp.path = kPathInterior;
+            sp.w0 = k.a_lo;
+            sp.w0b = k.b_lo - lenA;
+            sp.wlen = lenA + lenB;
+            sp.lds = s_win;
+            for (int e = threadIdx.x; e < (lenA + lenB) * 4; e += blockDim.x) {
+                const int slot = e >> 2, kind = e & 3;
+                const int knot = slot < lenA ? k.a_lo + slot : k.b_lo + (slot - lenA);
+                s_win[kind * cap + slot] = sp.g[(size_t)knot * 4 + kind];
+            }
+            return;
+        }
+    }
+    stage_window64<CAP>(sp, s_win, lo, hi);
 }
 
 // ---------------------------------------------------------------------------

@@ -123,6 +123,7 @@ struct rship_ctx {
                                  // tile kernel with round 2's exact selection of every quartile instead of the lazy one (tests: identical results)
     bool no_small_lmeds = false; // RSSYNC_NO_SMALL_LMEDS=1 (read once, at creation): the tile kernel for every frame size (A/B tests)
     float max_span = 0.f; // widest frame, in knots (frame table)
+    float max_ends = 0.f; // the same counting only the two ends' ranges of each pair (rship_frame::range_a / range_b)
     // knots the fp64 kernels' spline window holds (dynamic LDS, 128 bytes per knot): the widest frame of the table,
     // at least kWinMax, at most kCap64Max (beyond that the kernels read the table from L2, as any frame that does not
     // fit its window does)
@@ -340,7 +341,7 @@ WinPlan plan_lmeds_window(rship_ctx* c, double step_knots, uint32_t chunk_want) 
     // (the kernel's LDS footprint is only asked for when the compiled-in window does not do: plan_window's first test)
     const bool fits80 = rs::plan_fit((double)kWinMax, c->max_span, step_knots, chunk_want) >= std::min(8u, chunk_want);
     const uint32_t fixed = (fits80 || c->force_general) ? 0u : lmeds_dynamic_static_lds<MODE>(rpt, small);
-    return rs::plan_window(c->max_span, step_knots, chunk_want, small, small ? 20 : lmeds_waves(rpt), fixed, c->lds_per_cu, c->force_general);
+    return rs::plan_window(c->max_span, c->max_ends, step_knots, chunk_want, small, small ? 20 : lmeds_waves(rpt), fixed, c->lds_per_cu, c->force_general);
 }
 
 template <int MODE>
@@ -450,7 +451,9 @@ int launch_loss64(rship_ctx* c, const Loss64Params& p_in, int rpt, hipStream_t s
     // launch has one window, always in dynamic LDS.
     const uint32_t cap64 = cap64_of(c);
     p.win_cap = cap64;
-    const bool fixed80 = !GRAD && cap64 == (uint32_t)kWinMax;
+    // (the compiled-in windows hold whole pairs only: where the 80 knots are enough just because the two ends are staged
+    // separately, the dynamic instantiation runs)
+    const bool fixed80 = !GRAD && cap64 == (uint32_t)kWinMax && (c->max_span + 1.f <= (float)kWinMax || c->force_general);
     p.nb_run = GRAD ? 1u : (fixed80 ? (uint32_t)kLossBatch : std::max(1u, std::min((uint32_t)kLossBatchWide, kLossWinBytes / (cap64 * 128u))));
     const size_t dyn = fixed80 ? 0 : (size_t)p.nb_run * cap64 * 128u, dyn_small = (size_t)cap64 * 128u;
     ProfScope ps(c, GRAD ? RSHIP_K_LOSS_GRAD : RSHIP_K_LOSS);
@@ -982,6 +985,7 @@ int rship_pack_frames(rship_ctx* c, const rship_frame* table, const rship_pack_f
     c->h_sel.clear();
     c->h_frame_n.assign(n_frames, 0);
     c->max_span = 0.f;
+    c->max_ends = 0.f;
     uint32_t max_n = 0;
     for (uint32_t i = 0; i < n_frames; ++i) {
         if ((uint64_t)table[i].ray_offset + table[i].n_rays > total_rays) return set_err(c, "frame table exceeds ray buffer");
@@ -995,15 +999,30 @@ int rship_pack_frames(rship_ctx* c, const rship_frame* table, const rship_pack_f
         max_n = std::max(max_n, table[i].n_rays);
         const float span = floorf(table[i].tmax) - floorf(table[i].tmin) + 2.f; // knots a frame touches at one delay
         if (table[i].n_rays && span > c->max_span) c->max_span = span;
+        float ends = span;
+        if (table[i].range_a != RSHIP_NO_SPLIT && table[i].range_b != RSHIP_NO_SPLIT) {
+            const int a_lo = (int)(table[i].range_a & 0xffffu), a_hi = (int)(table[i].range_a >> 16) + 1;
+            const int b_lo = (int)(table[i].range_b & 0xffffu), b_hi = (int)(table[i].range_b >> 16) + 1;
+            if (b_lo > a_hi + 1 || a_lo > b_hi + 1) ends = std::min(span, (float)((a_hi - a_lo + 1) + (b_hi - b_lo + 1)));
+        }
+        if (table[i].n_rays && ends > c->max_ends) c->max_ends = ends;
     }
-    c->cap64 = c->force_general ? (uint32_t)kWinMax : rs::cap64_for(c->max_span);
+    c->cap64 = c->force_general ? (uint32_t)kWinMax : rs::cap64_for(c->max_span, c->max_ends);
     const size_t tr = (size_t)total_rays;
     if (ensure(c, c->rays_a, tr ? tr * 16 : 16) || ensure(c, c->rays_b, tr ? tr * 16 : 16) ||
         ensure(c, c->rays64, tr ? tr * 64 : 64))
         return 1;
     if (ensure(c, c->frames, (size_t)n_frames * sizeof(rship_frame) + 64)) return 1;
     c->total_rays = total_rays;
-    if (n_frames) RS_HIP(hipMemcpyAsync(c->frames.p, table, (size_t)n_frames * sizeof(rship_frame), hipMemcpyHostToDevice, c->stream));
+    if (n_frames && c->force_general) {
+        // RSSYNC_FORCE_GENERAL_SPLINE (rounds 1-3, the sweep's "before" column): whole pairs only, 80-knot windows
+        std::vector<rship_frame> legacy(table, table + n_frames);
+        for (rship_frame& r : legacy) r.range_a = r.range_b = RSHIP_NO_SPLIT;
+        c->max_ends = c->max_span;
+        RS_HIP(hipMemcpy(c->frames.p, legacy.data(), (size_t)n_frames * sizeof(rship_frame), hipMemcpyHostToDevice));
+    } else if (n_frames) {
+        RS_HIP(hipMemcpyAsync(c->frames.p, table, (size_t)n_frames * sizeof(rship_frame), hipMemcpyHostToDevice, c->stream));
+    }
     uint32_t nb = 0;
     if (n_frames && max_n) {
         TempBuf dpk, dbad;
@@ -1906,6 +1925,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     {
         const WinPlan wp_init = plan_lmeds_window<1>(c, 0.0, 1u);
         ep.init.win_cap = wp_init.cap ? wp_init.cap : (uint32_t)kWinMax;
+        ep.init.win_whole_pair = wp_init.cap ? 0u : 1u; // (the compiled-in window stages whole pairs: so must this one, or tiny frames take another path)
         if ((size_t)ep.init.win_cap * 64u > region) return set_err(c, "sync_exec: the search's window does not fit the wave's LDS region");
     }
     // motion
@@ -2000,15 +2020,18 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
 // How the spline windows of the last launches were laid out ("gyro rate"): out[0] widest frame in
 // knots, out[1] knots per fp64 window (K1, K3, executor; dynamic LDS), out[2] fp32 window of the last PreSync sweep
 // (0 = the 80 knots compiled into the kernel, else knots of dynamic LDS), out[3] its candidates per workgroup,
-// out[4] the same for the last GuessMotion search, out[5] delays per pass of the trials' loss kernel
-int rship_window_info(rship_ctx* c, uint32_t out[6]) {
+// out[4] the same for the last GuessMotion search, out[5] delays per pass of the trials' loss kernel, out[6] the widest
+// frame counting only the two ends' ranges of each pair
+int rship_window_info(rship_ctx* c, uint32_t out[8]) {
     out[0] = (uint32_t)c->max_span;
+    out[6] = (uint32_t)c->max_ends;
+    out[7] = 0;
     const uint32_t cap64 = cap64_of(c);
     out[1] = cap64;
     out[2] = c->last_lmeds_cap;
     out[3] = c->last_lmeds_chunk;
     out[4] = c->last_init_cap;
-    out[5] = cap64 == (uint32_t)kWinMax ? (uint32_t)kLossBatch : std::max(1u, std::min((uint32_t)kLossBatchWide, kLossWinBytes / (cap64 * 128u)));
+    out[5] = (cap64 == (uint32_t)kWinMax && (c->max_span + 1.f <= (float)kWinMax || c->force_general)) ? (uint32_t)kLossBatch : std::max(1u, std::min((uint32_t)kLossBatchWide, kLossWinBytes / (cap64 * 128u)));
     return 0;
 }
 

@@ -150,7 +150,8 @@ class Arena {
 struct HostFrame {
     uint64_t raw_off = 0; // arena offset of the record: rays = ts_a[n] ts_b[n] rays_a[3n] rays_b[3n]; pixels = {xa,ya,xb,yb}[n]
     uint32_t n = 0;
-    double ts_min = 0, ts_max = 0; // over ts_a and ts_b: all the frame table needs from the data
+    double ts_min = 0, ts_max = 0; // over ts_a and ts_b: all the frame table needs from the data ...
+    double a_min = 0, a_max = 0, b_min = 0, b_max = 0; // ... and per end (the kernels' spline windows stage the two ends separately)
     // frames given as tracked pixels (rssync_ext_set_track_pixels): the packing kernel undistorts
     bool from_pixels = false;
     double time_a = 0, time_b = 0, rows = 0;
@@ -592,11 +593,14 @@ void SyncProblemHip::SetTrackResult(int64_t frame, const double* ts_a, const dou
     std::memcpy(rec + 2 * count, rays_a, 3 * count * 8);
     std::memcpy(rec + 5 * count, rays_b, 3 * count * 8);
     if (count) {
-        f.ts_min = f.ts_max = ts_a[0];
+        f.a_min = f.a_max = ts_a[0];
+        f.b_min = f.b_max = ts_b[0];
         for (size_t i = 0; i < count; ++i) {
-            f.ts_min = std::min(f.ts_min, std::min(ts_a[i], ts_b[i]));
-            f.ts_max = std::max(f.ts_max, std::max(ts_a[i], ts_b[i]));
+            f.a_min = std::min(f.a_min, ts_a[i]); f.a_max = std::max(f.a_max, ts_a[i]);
+            f.b_min = std::min(f.b_min, ts_b[i]); f.b_max = std::max(f.b_max, ts_b[i]);
         }
+        f.ts_min = std::min(f.a_min, f.b_min);
+        f.ts_max = std::max(f.a_max, f.b_max);
     }
     frames_[frame] = f;
     frames_dirty_ = true;
@@ -629,9 +633,13 @@ void SyncProblemHip::SetTrackPixels(int64_t frame, double time_a, double time_b,
         rec[4 * i + 2] = px_b[2 * i]; rec[4 * i + 3] = px_b[2 * i + 1];
         const double tsa = time_a + lens[0] * (px_a[2 * i + 1] / image_rows); // :144
         const double tsb = time_b + lens[0] * (px_b[2 * i + 1] / image_rows); // :145
-        if (i == 0) f.ts_min = f.ts_max = tsa;
-        f.ts_min = std::min(f.ts_min, std::min(tsa, tsb));
-        f.ts_max = std::max(f.ts_max, std::max(tsa, tsb));
+        if (i == 0) { f.a_min = f.a_max = tsa; f.b_min = f.b_max = tsb; }
+        f.a_min = std::min(f.a_min, tsa); f.a_max = std::max(f.a_max, tsa);
+        f.b_min = std::min(f.b_min, tsb); f.b_max = std::max(f.b_max, tsb);
+    }
+    if (count) {
+        f.ts_min = std::min(f.a_min, f.b_min);
+        f.ts_max = std::max(f.a_max, f.b_max);
     }
     frames_[frame] = f;
     frames_dirty_ = true;
@@ -746,6 +754,28 @@ void SyncProblemHip::pack_frames() {
             rec.tmax = std::nextafterf(rec.tmax, std::numeric_limits<float>::infinity());
             rec.tmin64 = std::nextafter(rec.tmin64, -std::numeric_limits<double>::infinity());
             rec.tmax64 = std::nextafter(rec.tmax64, std::numeric_limits<double>::infinity());
+        }
+        // the knots each END of the pair touches at delay 0, relative to base_knot (rship_frame::range_a / range_b):
+        // floors of the end's smallest / largest offset, taken both on the fp64 value and on its fp32 rounding (the
+        // fp32 stream's offset may round up across a knot), with the same one-ulp slack for pixel frames
+        rec.range_a = rec.range_b = RSHIP_NO_SPLIT;
+        if (n) {
+            auto range = [&](double tlo, double thi) -> uint32_t {
+                double lo64 = (tlo - start_) * fs_ - base, hi64 = (thi - start_) * fs_ - base;
+                float lo32 = (float)lo64, hi32 = (float)hi64;
+                if (f.from_pixels) {
+                    lo64 = std::nextafter(lo64, -std::numeric_limits<double>::infinity());
+                    hi64 = std::nextafter(hi64, std::numeric_limits<double>::infinity());
+                    lo32 = std::nextafterf(lo32, -std::numeric_limits<float>::infinity());
+                    hi32 = std::nextafterf(hi32, std::numeric_limits<float>::infinity());
+                }
+                const double lo = std::min(std::floor(lo64), (double)std::floor(lo32));
+                const double hi = std::max(std::floor(hi64), (double)std::floor(hi32));
+                if (!(lo >= 0.0) || !(hi >= lo) || !(hi <= 65000.0)) return RSHIP_NO_SPLIT;
+                return (uint32_t)lo | ((uint32_t)hi << 16);
+            };
+            const uint32_t ra = range(f.a_min, f.a_max), rb = range(f.b_min, f.b_max);
+            if (ra != RSHIP_NO_SPLIT && rb != RSHIP_NO_SPLIT) { rec.range_a = ra; rec.range_b = rb; }
         }
         rship_pack_frame pf{};
         pf.raw_offset = f.raw_off;
@@ -1812,9 +1842,9 @@ int rssync_ext_exchange_stats(rssync_problem* p, uint64_t* calls, uint64_t* doub
     return 0;
 }
 
-int rssync_ext_window_info(rssync_problem* p, uint32_t out[6]) {
+int rssync_ext_window_info(rssync_problem* p, uint32_t out[8]) {
     return guarded([&] {
-        for (int i = 0; i < 6; ++i) out[i] = 0;
+        for (int i = 0; i < 8; ++i) out[i] = 0;
         if (rship_window_info(p->impl->dev(), out)) panic(std::string("hip: ") + rship_last_error(p->impl->dev()));
     });
 }

@@ -23,9 +23,11 @@ struct WinPlan {
     uint32_t chunk = 1; // candidates per workgroup
 };
 
-// knots the fp64 kernels' window holds for a table whose widest frame touches `max_span` knots at one delay
-inline uint32_t cap64_for(float max_span) {
-    uint32_t need = (uint32_t)std::ceil(std::max(max_span, 0.f)) + 1u;
+// knots the fp64 kernels' window holds for a table whose widest frame touches `max_span` knots at one delay -- or
+// `max_ends` knots where only the two ends of each pair are staged (a frame's a-end and b-end ranges one after the
+// other: kernels/common.hpp stage_window_ends; max_ends = max_span for a table without that information)
+inline uint32_t cap64_for(float max_span, float max_ends) {
+    uint32_t need = (uint32_t)std::ceil(std::max(std::min(max_span, max_ends), 0.f)) + 1u;
     need = (need + 15u) / 16u * 16u;
     return std::min(std::max(need, kPlanWinStatic), kPlanCap64Max);
 }
@@ -43,16 +45,26 @@ inline uint32_t plan_fit(double cap, double span, double step_knots, uint32_t ch
     const double n = std::floor((cap - span - 1.0) / step_knots) + 1.0;
     return n >= (double)chunk_want ? chunk_want : (uint32_t)n;
 }
+// the same where the two ends of a pair are staged one after the other (`ends` knots at one delay, both ends' carry
+// knots included): every candidate of the chunk widens BOTH ranges
+inline uint32_t plan_fit_ends(double cap, double ends, double step_knots, uint32_t chunk_want) {
+    if (cap < ends + 2.0) return 0;
+    if (!(step_knots > 0)) return chunk_want;
+    const double n = std::floor((cap - ends - 2.0) / (2.0 * step_knots)) + 1.0;
+    return n >= (double)chunk_want ? chunk_want : (uint32_t)n;
+}
 
 // The fp32 window of an LMedS launch (PreSync sweep or GuessMotion's search).
 //   span        widest frame of the table, knots touched at one delay
+//   ends        the same counting only the two ends' ranges of each pair (= span where the table does not know them):
+//               the dynamic-window kernels stage the ends separately where that is fewer knots
 //   step_knots  distance between neighbouring candidate delays (0: one candidate per workgroup)
 //   chunk_want  candidates per workgroup the launch would like (<= 32)
 //   small       the one-wave kernels (frames of up to 256 tracks); wg_max: most workgroups per CU the kernel runs at
 //   fixed_lds   static LDS of the dynamic-window instantiation, lds_per_cu the CU's LDS
 //   legacy      rounds 1-3: never a dynamic window (RSSYNC_FORCE_GENERAL_SPLINE)
 // -> cap == 0: the compiled-in window (if the chunk's frames do not fit it, their workgroups take the general path)
-inline WinPlan plan_window(double span, double step_knots, uint32_t chunk_want, bool small, int wg_max, uint32_t fixed_lds,
+inline WinPlan plan_window(double span, double ends, double step_knots, uint32_t chunk_want, bool small, int wg_max, uint32_t fixed_lds,
                            int lds_per_cu, bool legacy) {
     WinPlan w;
     w.chunk = chunk_want;
@@ -67,16 +79,18 @@ inline WinPlan plan_window(double span, double step_knots, uint32_t chunk_want, 
     for (int wg = wg_max; wg >= 1; --wg) {
         const int share = lds_per_cu / wg - 1024; // (allocation granularity, alignment)
         if (share <= (int)fixed_lds) continue;
-        const uint32_t cap_t = std::min(2048u, ((uint32_t)share - fixed_lds) / 64u / 4u * 4u);
-        const uint32_t f = plan_fit((double)cap_t, span, step_knots, chunk_want);
-        if (f < min_chunk) continue;
-        const double need = span + 1.0 + (step_knots > 0 ? (f - 1) * step_knots : 0.0);
-        const uint32_t cap = std::min(cap_t, ((uint32_t)std::ceil(need) + 3u) / 4u * 4u + 4u);
+        uint32_t cap_t = std::min(2048u, ((uint32_t)share - fixed_lds) / 64u / 4u * 4u);
         // one wave per frame (K2s): a window of more than kPlanSmallWinMax knots costs more in resident waves than the
-        // frame's few hundred coefficient fetches cost from L2 (profiles/r4_gyro_rate_sweep.json: 98 x 61 x 130 x 200
-        // candidates, 2 kHz: 1.39 ms with a 112-knot window against 1.56 on the general path; 4 kHz: 1.98 ms with 228
-        // knots against 1.54) -- keep the general path there
-        if (small && cap > kPlanSmallWinMax) break;
+        // frame's few hundred coefficient fetches cost from L2 (profiles/r4_gyro_rate_sweep.json: a 228-knot window 1.98 ms
+        // against 1.54 on the general path) -- never more than that; if even eight candidates do not fit it, the general path
+        if (small) cap_t = std::min(cap_t, kPlanSmallWinMax);
+        const uint32_t f1 = plan_fit((double)cap_t, span, step_knots, chunk_want);
+        const uint32_t f2 = ends < span ? plan_fit_ends((double)cap_t, ends, step_knots, chunk_want) : 0u;
+        const uint32_t f = std::max(f1, f2);
+        if (f < min_chunk) continue;
+        const double cs = step_knots > 0 ? (f - 1) * step_knots : 0.0;
+        const double need = std::min(f1 >= f ? span + 1.0 + cs : 1e30, f2 >= f ? ends + 2.0 + 2.0 * cs : 1e30);
+        const uint32_t cap = std::min(cap_t, ((uint32_t)std::ceil(need) + 3u) / 4u * 4u + 4u);
         w.chunk = f;
         w.cap = cap;
         return w;

@@ -315,10 +315,10 @@ class SyncProblem:
 
     def window_info(self):
         """-> dict: how the kernels' LDS spline windows were laid out for this problem's gyro rate"""
-        q = (C.c_uint32 * 6)()
+        q = (C.c_uint32 * 8)()
         self._check(self._lib.rssync_ext_window_info(self._h, q))
         return dict(frame_span_knots=q[0], fp64_window_knots=q[1], presync_window_knots=q[2] or 80, presync_window_dynamic=bool(q[2]),
-                    presync_chunk=q[3], init_window_knots=q[4] or 80, trial_delays_per_pass=q[5])
+                    presync_chunk=q[3], init_window_knots=q[4] or 80, trial_delays_per_pass=q[5], frame_ends_knots=q[6])
 
     def set_executor_check(self, on=True):
         """debug mode: every call the window executor runs is re-run by the launch chain and must give the same bits"""

@@ -670,15 +670,21 @@ def test_gyro_rates_against_the_oracle(fs, N):
     co, do = o.PreSync(0.0, 0, F, 0.002, 0.1)
     assert dh == do and ch == pytest.approx(co, rel=5e-3)
     w = h.window_info()
-    span = w["frame_span_knots"]
+    span, ends = w["frame_span_knots"], w["frame_ends_knots"]
     assert abs(span - (0.0444 * fs + 2)) <= 3
-    small = N <= 256    # one wave per frame: wide windows only while enough waves still share a CU (rssync_kernels.hip: cap64_of, kSmallWinMax)
+    # the two ends of a pair (11 ms of read-out each) cover about half the knots of the pair (44 ms): what the dynamic
+    # windows stage
+    assert ends <= span and (span <= 24 or ends <= 0.62 * span + 8)
+    need = min(span, ends)
+    small = N <= 256    # one wave per frame: wide windows only while enough waves still share a CU (window_plan.hpp)
+    want64 = max(80, (need + 1 + 15) // 16 * 16)
     if span <= 70:
         assert not w["presync_window_dynamic"] and w["fp64_window_knots"] == 80 and w["trial_delays_per_pass"] == 5
-    elif span <= 384 and not small:                           # the window grew instead of the kernels leaving the LDS path
-        assert w["presync_window_dynamic"] and w["presync_window_knots"] >= span and w["fp64_window_knots"] >= span
+    elif need + 1 <= 384 and not small:                       # the window grew instead of the kernels leaving the LDS path
+        assert w["presync_window_dynamic"] and w["presync_window_knots"] >= need and w["fp64_window_knots"] == want64
     elif small:
-        assert w["presync_window_dynamic"] == (span + 1 <= 128) and w["fp64_window_knots"] == (80 if span > 176 else (span + 15) // 16 * 16)
+        assert w["presync_window_dynamic"] == (need + 3 <= 128), w
+        assert w["fp64_window_knots"] == (80 if want64 > 176 else want64), w
     else:
         assert w["fp64_window_knots"] == 384                  # wider than any window: the table from L2 (still correct)
     Mh, kh = h.init_motion(dh, 0, F - 1)

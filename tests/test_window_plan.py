@@ -14,11 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = r'''
 #include "window_plan.hpp"
 extern "C" {
-void plan(double span, double step, unsigned want, int small_, int wg_max, unsigned fixed, int lds, int legacy, unsigned* out) {
-    const rs::WinPlan w = rs::plan_window(span, step, want, small_ != 0, wg_max, fixed, lds, legacy != 0);
+void plan(double span, double ends, double step, unsigned want, int small_, int wg_max, unsigned fixed, int lds, int legacy, unsigned* out) {
+    const rs::WinPlan w = rs::plan_window(span, ends, step, want, small_ != 0, wg_max, fixed, lds, legacy != 0);
     out[0] = w.cap; out[1] = w.chunk;
 }
-unsigned cap64_for(float span) { return rs::cap64_for(span); }
+unsigned cap64_for(float span, float ends) { return rs::cap64_for(span, ends); }
 unsigned cap64_used(unsigned cap64, unsigned n_all, int force_big) { return rs::cap64_used(cap64, n_all, force_big != 0); }
 }
 '''
@@ -35,18 +35,18 @@ def lib(tmp_path_factory):
     out = d / "libplan.so"
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "rs-sync_amd", "csrc"), "-o", str(out), str(src)])
     L = ctypes.CDLL(str(out))
-    L.plan.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.c_int,
+    L.plan.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.c_int,
                        ctypes.POINTER(ctypes.c_uint)]
-    L.cap64_for.argtypes = [ctypes.c_float]
+    L.cap64_for.argtypes = [ctypes.c_float, ctypes.c_float]
     L.cap64_for.restype = ctypes.c_uint
     L.cap64_used.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_int]
     L.cap64_used.restype = ctypes.c_uint
     return L
 
 
-def plan(L, span, step, want=32, small=False, wg_max=5, fixed=TILE8, lds=LDS, legacy=False):
+def plan(L, span, step, want=32, small=False, wg_max=5, fixed=TILE8, lds=LDS, legacy=False, ends=None):
     out = (ctypes.c_uint * 2)()
-    L.plan(span, step, want, int(small), wg_max, fixed, lds, int(legacy), out)
+    L.plan(span, span if ends is None else ends, step, want, int(small), wg_max, fixed, lds, int(legacy), out)
     return int(out[0]), int(out[1])
 
 
@@ -114,8 +114,31 @@ def test_legacy_switch_never_grows_the_window(lib):
 
 
 def test_fp64_window_capacity(lib):
-    assert lib.cap64_for(20.0) == 80 and lib.cap64_for(79.0) == 80 and lib.cap64_for(80.0) == 96
-    assert lib.cap64_for(180.0) == 192 and lib.cap64_for(358.0) == 368 and lib.cap64_for(5000.0) == 384
+    c64 = lambda span, ends=None: lib.cap64_for(span, span if ends is None else ends)
+    assert c64(20.0) == 80 and c64(79.0) == 80 and c64(80.0) == 96
+    assert c64(180.0) == 192 and c64(358.0) == 368 and c64(5000.0) == 384
+    # where the table knows the two ends' ranges the window holds those: a 4 kHz pair (180 knots) needs 2 x 46
+    assert c64(180.0, 92.0) == 96 and c64(91.0, 48.0) == 80 and c64(358.0, 182.0) == 192
     # problems of small frames keep 80 knots beyond 176; a forced large-frame run does not count as small
     assert lib.cap64_used(96, 130, 0) == 96 and lib.cap64_used(176, 256, 0) == 176
     assert lib.cap64_used(192, 130, 0) == 80 and lib.cap64_used(192, 257, 0) == 192 and lib.cap64_used(192, 130, 1) == 192
+
+
+def ends_of(fs):     # the two ends of such a pair: 11.1 ms of read-out each, + the carry knot and the partial knot per end
+    return 2 * (np.floor(0.0111 * fs) + 3)
+
+
+@pytest.mark.parametrize("fs", [2000, 3200, 4000, 8000])
+def test_staging_the_two_ends_needs_fewer_knots(lib, fs):
+    span, ends, step = span_of(fs), ends_of(fs), 0.0005 * fs
+    cap1, chunk1 = plan(lib, span, step)
+    cap2, chunk2 = plan(lib, span, step, ends=ends)
+    assert cap2 and cap2 <= cap1 and chunk2 >= 8
+    # whichever form the plan counted on, its capacity holds it: the pair and the chunk, or the two ends, each widened by the chunk
+    cs = (chunk2 - 1) * step
+    assert cap2 >= min(span + 1 + cs, ends + 2 + 2 * cs)
+    wg1 = next(w for w in range(5, 0, -1) if TILE8 + cap1 * 64 + 1024 <= LDS // w)
+    wg2 = next(w for w in range(5, 0, -1) if TILE8 + cap2 * 64 + 1024 <= LDS // w)
+    assert wg2 >= wg1
+    if fs == 2000:
+        assert wg2 == 5 and wg1 == 4          # 2 kHz: five workgroups per CU again
