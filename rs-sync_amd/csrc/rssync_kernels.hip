@@ -262,11 +262,12 @@ constexpr uint32_t kLossWinBytes = kLossBatch * kWinMax * 128u; // K1's LDS budg
 using rs::WinPlan;
 static_assert(rs::kPlanWinStatic == (uint32_t)kWinMax, "window_plan.hpp and kernels/common.hpp disagree on the compiled-in window");
 // The fp64 window the launches use (window_plan.hpp: cap64_for, cap64_used).  Problems of small frames (up to 256
-// tracks: one WAVE per frame in K1 / K3 / the executor) only gain from a wide window while enough waves still share a CU:
-// a 130-track frame makes 260 coefficient fetches per evaluation, and staging a 190-knot window (24 KB) for them costs
-// more than fetching them from L2 once the window's LDS leaves fewer than six waves per CU.  Measured on 98 sync points
-// of 61 x 130 (profiles/r4_gyro_rate_sweep.json): 2 kHz 20.6 ms with a 96-knot window against 24.4 on the general path;
-// 4 kHz 25.8 ms with 192 knots against 21.6 on the general path.
+// tracks: one WAVE per frame in K1 / K3 / the executor) stage a window PER EVALUATION for a frame's 260 coefficient
+// fetches: beyond ~4 kHz that staging (cap64 x 128 bytes from a table that no longer fits the L2s) is what the workload
+// costs, and beyond kPlanCap64SmallMax knots the general path (260 x 128 bytes from L2) is cheaper again.  Measured on 98
+// sync points of 61 x 130 with the two ends of a pair staged separately (profiles/r4_gyro_rate_small_frames.json):
+// 4 kHz 18.1 ms with 96 knots against 21.8 on the general path; 6 kHz 54 (144 knots) against 61; 8 kHz 59 (192)
+// against 61; 12 kHz 69 (272) against 58.5.
 uint32_t cap64_of(const rship_ctx* c) {
     const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
     return rs::cap64_used(c->cap64, n_all, c->force_big);

@@ -16,7 +16,7 @@ namespace rs {
 constexpr uint32_t kPlanWinStatic = 80;   // knots compiled into the kernels' LDS (kernels/common.hpp: kWinMax)
 constexpr uint32_t kPlanSmallWinMax = 128; // one wave per frame (K2s): no dynamic window beyond this many knots
 constexpr uint32_t kPlanCap64Max = 384;   // fp64 windows: 48 KB
-constexpr uint32_t kPlanCap64SmallMax = 176; // problems of small frames: the 80-knot window beyond this
+constexpr uint32_t kPlanCap64SmallMax = 208; // problems of small frames: the 80-knot window beyond this (measured: below)
 
 struct WinPlan {
     uint32_t cap = 0;   // 0: the compiled-in 80-knot window; otherwise knots of dynamic LDS (64 bytes each)

@@ -119,9 +119,9 @@ def test_fp64_window_capacity(lib):
     assert c64(180.0) == 192 and c64(358.0) == 368 and c64(5000.0) == 384
     # where the table knows the two ends' ranges the window holds those: a 4 kHz pair (180 knots) needs 2 x 46
     assert c64(180.0, 92.0) == 96 and c64(91.0, 48.0) == 80 and c64(358.0, 182.0) == 192
-    # problems of small frames keep 80 knots beyond 176; a forced large-frame run does not count as small
-    assert lib.cap64_used(96, 130, 0) == 96 and lib.cap64_used(176, 256, 0) == 176
-    assert lib.cap64_used(192, 130, 0) == 80 and lib.cap64_used(192, 257, 0) == 192 and lib.cap64_used(192, 130, 1) == 192
+    # problems of small frames keep 80 knots beyond 208; a forced large-frame run does not count as small
+    assert lib.cap64_used(96, 130, 0) == 96 and lib.cap64_used(208, 256, 0) == 208
+    assert lib.cap64_used(224, 130, 0) == 80 and lib.cap64_used(224, 257, 0) == 224 and lib.cap64_used(224, 130, 1) == 224
 
 
 def ends_of(fs):     # the two ends of such a pair: 11.1 ms of read-out each, + the carry knot and the partial knot per end
