@@ -182,7 +182,7 @@ struct Loss64Params {
 // 1e-3 .. 1e-12 times the gradient), so the windows cannot be shared; the rays can.  A pass per delay made
 // this kernel HBM/L2-bound (64 B per ray pair per delay: 6.5 TB/s effective at 4096 x 2048).
 constexpr int kLossBatch = 5; // (6, at two workgroups per CU: 5 % slower)
-constexpr int kLossBatchWide = 2; // the same for frames wider than kWinMax knots (windows in dynamic LDS: two up to 200 knots, one beyond)
+constexpr int kLossBatchWide = 3; // the same with the windows in dynamic LDS (run-time stride: 167 VGPRs at three; as many of them as 51 KB hold)
 
 // RPT = rows per thread the launch covers (the largest frame's); 0 = as many as this frame needs (frames of more
 // than 8192 tracks).  A thread adds its rows in order either way, so a frame's sums do not depend on RPT.
@@ -191,7 +191,7 @@ constexpr int kLossBatchWide = 2; // the same for frames wider than kWinMax knot
 // one window; the trials' kernel for frames wider than kWinMax knots, with p.nb_run <= kLossBatchWide windows)
 template <int RPT, bool GRAD, bool SIMPLE, int CAP = 0>
 __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
-    constexpr int NB = GRAD ? 1 : (CAP ? kLossBatch : kLossBatchWide);
+    constexpr int NB = GRAD ? 1 : (CAP ? kLossBatch : (RPT == 0 ? 2 : kLossBatchWide)); // (RPT = 0, frames of more than 8192 tracks: three windows spill)
     d4* s_loss_win;
     uint32_t win_cap;
     if constexpr (CAP != 0) {

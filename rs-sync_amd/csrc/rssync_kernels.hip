@@ -448,7 +448,7 @@ int launch_loss64(rship_ctx* c, const Loss64Params& p_in, int rpt, hipStream_t s
     if (!count) count = p.n_sel - p.slot0;
     // The spline windows.  Trials (no gradient): five delays per pass over the rows, their 80-knot windows compiled into
     // the kernel's LDS, while the problem's frames fit 80 knots (gyro rates up to ~1.7 kHz); wider frames take the
-    // dynamic-LDS instantiation with cap64 knots per window, two per pass up to 200 knots, one beyond.  The gradient
+    // dynamic-LDS instantiation with cap64 knots per window, as many per pass as 51 KB hold (at most three).  The gradient
     // launch has one window, always in dynamic LDS.
     const uint32_t cap64 = cap64_of(c);
     p.win_cap = cap64;

@@ -25,6 +25,7 @@ from rssync_amd import synth  # noqa: E402
 
 F, N = int(os.environ.get("F", 1024)), int(os.environ.get("N", 2048))
 RATES = [float(x) for x in os.environ.get("RATES", "400,1000,2000,4000,8000").split(",")]
+REPS = int(os.environ.get("REPS", 4))
 
 
 def per_launch(prof):
@@ -43,15 +44,20 @@ def large(fs, general):
     c, d = h.PreSync(0.0, 0, F, 0.0005, 0.2)
     h.Sync(d, 0, F - 1, 0.0, 0.2)
     h.profile(True)
-    h.profile_reset()
-    t = time.perf_counter()
-    c, d = h.PreSync(0.0, 0, F, 0.0005, 0.2)
-    t_pre = time.perf_counter() - t
-    t = time.perf_counter()
-    c2, d2 = h.Sync(d, 0, F - 1, 0.0, 0.2)
-    t_sync = time.perf_counter() - t
-    out = {"presync_ms": round(1e3 * t_pre, 3), "sync_ms": round(1e3 * t_sync, 3), "presync_delay": d, "sync_delay": d2,
-           "outer_iterations": len(h.sync_trace()), "ms_per_launch": per_launch(h.profile_get()), "windows": h.window_info()}
+    best = None
+    for rep in range(REPS):       # the fastest of REPS passes per kernel: a box's clock wanders by a few per cent
+        h.profile_reset()
+        t = time.perf_counter()
+        c, d = h.PreSync(0.0, 0, F, 0.0005, 0.2)
+        t_pre = time.perf_counter() - t
+        t = time.perf_counter()
+        c2, d2 = h.Sync(d, 0, F - 1, 0.0, 0.2)
+        t_sync = time.perf_counter() - t
+        cur = per_launch(h.profile_get())
+        cur["_presync_ms"], cur["_sync_ms"] = 1e3 * t_pre, 1e3 * t_sync
+        best = cur if best is None else {k: min(best[k], cur[k]) for k in cur}
+    out = {"presync_ms": round(best.pop("_presync_ms"), 3), "sync_ms": round(best.pop("_sync_ms"), 3), "presync_delay": d, "sync_delay": d2,
+           "outer_iterations": len(h.sync_trace()), "ms_per_launch": best, "passes": REPS, "windows": h.window_info()}
     h.close()
     return out
 
