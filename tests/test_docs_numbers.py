@@ -11,3 +11,24 @@ def test_baseline_table_is_what_the_profiles_give():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_baseline_tables.py"), "r4", "--check"],
                        cwd=ROOT, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_design_quotes_the_committed_kernel_statistics():
+    """the figures DESIGN.md quotes for the two rooflines and the step are the ones profiles/r4_* give (three rounds in a
+    row a csv was re-collected and the prose was not)"""
+    import csv
+    import json
+    prof = os.path.join(ROOT, "profiles")
+    stats = list(csv.DictReader(open(os.path.join(prof, "r4_bench_kernel_stats.csv"))))
+    k2 = [r for r in stats if "lmeds_kernel<8, 0, 80, true>" in r["Name"]][0]
+    k1 = [r for r in stats if "loss64_kernel<8, true, false" in r["Name"]][0]
+    bench = json.load(open(os.path.join(prof, "r4_bench.json")))
+    k2_ms, k1_us = float(k2["AverageNs"]) / 1e6, float(k1["AverageNs"]) / 1e3
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    want = ["**%.2f ms**" % k2_ms,                                                  # K2's mean launch time
+            "**%.3f** of 8 TB/s" % (4096 * 2048 * 800 * 32 / k2_ms / 1e9 / 8),      # its contract roofline
+            "mean **%.1f µs**" % k1_us,                                              # K1's gradient launch
+            "%.3f of 8 TB/s" % (4096 * 2048 * 64 / k1_us / 1e6 / 8),
+            "**%.2f ms = " % bench["ms_per_step"]]                                   # the step of the committed bench line
+    missing = [w for w in want if w not in design]
+    assert not missing, missing
