@@ -232,7 +232,7 @@ int rship_sync_run(rship_ctx* c, const double* d0, int max_outer, double search_
 /* The WINDOW EXECUTOR (kernels/executor.hpp): Sync for the W windows of the selection, `repeats` chained calls each
  * (the reference driver runs four per sync point, core_testcode.cpp:314), in ONE launch scheduled on the device --
  * tasks (window, phase, frame) pulled from a queue by persistent one-wave workgroups; windows advance
- * independently.  Frames of up to 256 tracks (rship_exec_supported), every window non-empty.  Call after
+ * independently.  Frames of up to 512 tracks (rship_exec_supported), every window non-empty.  Call after
  * rship_select_slots + rship_set_plan (no rship_init_motion: the search is the executor's first phase).  Window w
  * samples its call r with stream_first + r + w * stream_stride.  Out: d_out[W], cost[W] = loss at the returned
  * delay, iters[W][repeats], trace[W][trace_rows][6] with the rows of a window's calls back to back

@@ -353,7 +353,7 @@ struct ExecLds {
 static_assert(sizeof(d4) * 4 * kWinMax >= kExecStage * sizeof(double), "staging area (win_cap >= kWinMax)");
 
 template <int RPT> // rows per lane of the one-wave kernels: frames of up to 64 * RPT tracks
-__global__ __launch_bounds__(64) void sync_exec_kernel(ExecParams p) {
+__global__ __launch_bounds__(64, RPT == 8 ? 2 : 1) void sync_exec_kernel(ExecParams p) { // (RPT = 8: 256 VGPRs, two waves per SIMD; the others fit anyway)
     __shared__ ExecLds<RPT> lds;
     extern __shared__ d4 s_exec_region[]; // [4 * win_cap] d4 = win_cap x 128 bytes
     const int lane = threadIdx.x;

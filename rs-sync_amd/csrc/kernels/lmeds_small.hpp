@@ -1,4 +1,4 @@
-// lmeds_small.hpp -- K2 for frames of up to 256 tracks: ONE WAVE per (frame, chunk of candidate delays).
+// lmeds_small.hpp -- K2 for frames of up to 512 tracks: ONE WAVE per (frame, chunk of candidate delays).
 // Part of the single HIP translation unit rssync_kernels.hip (included there, after lmeds.hpp).
 //
 // The reference's own data has ~130 tracks per frame.  The tile kernel (lmeds.hpp) spends a four-wave
@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr int kSmallMaxRpt = 4; // 256 tracks
+constexpr int kSmallMaxRpt = 8; // 512 tracks (instantiated: 1, 2, 3, 4 rows per lane, and 8 for 257 .. 512 tracks)
 
 // LDS of one wave's work on a (frame, chunk): the kernel below owns one; the window executor (executor.hpp) lends its own
 // CAP = knots of the spline window inside this struct (kWinMax), or 0 = the window lives elsewhere (dynamic LDS sized
@@ -214,7 +214,7 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
 }
 
 template <int RPT, int MODE, int CAP = kWinMax>
-__global__ __launch_bounds__(64, RPT <= 3 ? 6 : 5) void lmeds_small_kernel(LmedsParams p) {
+__global__ __launch_bounds__(64, RPT <= 3 ? 6 : (RPT == 4 ? 5 : 3)) void lmeds_small_kernel(LmedsParams p) {
     __shared__ LmedsSmallLds<RPT, CAP> lds;
     f4* dyn = nullptr;
     if constexpr (CAP == 0) {

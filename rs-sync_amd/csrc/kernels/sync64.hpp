@@ -308,8 +308,8 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
 }
 
 // FrameState::Loss (and its analytic d/d-delay) of one slot at one delay by ONE wave, in the association of
-// loss64_kernel for frames of up to 256 tracks: thread t of that kernel's four waves holds row t, each wave is
-// summed by wave_sum_f64, the four wave sums are added left to right.  Mv, kk: the slot's motion estimate.
+// loss64_kernel: thread t of that kernel's four waves holds rows t, t + 256, ... (one row up to 256 tracks, two up to
+// 512) and adds them in that order, each wave is summed by wave_sum_f64, the four wave sums are added left to right.  Mv, kk: the slot's motion estimate.
 // (A frame of 130 tracks leaves two of the four waves of loss64_kernel's workgroup idle, and the workgroup holds its
 // registers all the same: three per CU.  One wave per slot puts four times as many slots on the chip; the window
 // executor evaluates its loss tasks this way too.)
@@ -334,9 +334,8 @@ __device__ __forceinline__ void loss64_wave(const Loss64Params& q, uint32_t sf, 
         Lw[w] = 0.0;
         Gw[w] = 0.0;
         if ((uint32_t)w * 64u < N) { // (a wave without rows sums zeros to zero)
-            const uint32_t row = (uint32_t)w * 64u + lane;
             double L = 0.0, G = 0.0;
-            if (row < N) {
+            for (uint32_t row = (uint32_t)w * 64u + lane; row < N; row += kBlock) { // (the four-wave kernel's rows j * 256 + tid of this thread)
                 const size_t idx = (size_t)fr.off + row;
                 d3 P, dP;
                 residual_row64_auto<GRAD>(sp, q.rays.q0[idx], q.rays.q1[idx], q.rays.q2[idx], q.rays.q3[idx], base, fd, P, dP);
@@ -350,7 +349,7 @@ __device__ __forceinline__ void loss64_wave(const Loss64Params& q, uint32_t sf, 
     G_out = GRAD ? (Gw[0] + Gw[1] + Gw[2] + Gw[3]) * q.fs : 0.0;
 }
 
-// K1 for frames of up to 256 tracks: one WAVE per slot, the delays one after the other (same bits as loss64_kernel:
+// K1 for frames of up to 512 tracks: one WAVE per slot, the delays one after the other (same bits as loss64_kernel:
 // tests/test_gpu_mid_sizes.py::test_one_wave_loss_kernel_equals_the_workgroup_kernel)
 template <bool GRAD, bool SIMPLE>
 __global__ __launch_bounds__(64, 3) void loss64_small_kernel(Loss64Params p) {

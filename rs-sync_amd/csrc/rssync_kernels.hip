@@ -6,7 +6,7 @@
 //                      matrix P into an LDS tile, LMedS hypothesis search with an exact
 //                      lower-quartile selection, robust PreSync cost.  The same kernel
 //                      in INIT mode is Sync's GuessMotion/GuessK.
-//   lmeds_small_kernel the same for frames of up to 256 tracks: one wave per (frame, chunk), rows in registers.
+//   lmeds_small_kernel the same for frames of up to 512 tracks: one wave per (frame, chunk), rows in registers.
 //   loss64_kernel      one workgroup per frame: residual + robust loss (+ analytic
 //                      d/d-delay) for a batch of delays, fp64 (the reference's arithmetic).
 //   opt_motion64_kernel one workgroup per frame: P in registers (fp64), restated L-BFGS on the
@@ -117,8 +117,9 @@ struct rship_ctx {
     uint32_t tracks_hint = 0; // RSHIP_OPT_TRACKS_HINT
     bool force_general = false;   // RSSYNC_FORCE_GENERAL_SPLINE=1 (read at creation; tools/gpu_gyro_rate.py's "before" column): no dynamic
                                   // spline windows -- frames wider than 80 knots take the general path (table from L2), as in rounds 1-3
+    uint32_t one_wave_max = 512;  // frames of up to this many tracks run the one-wave kernels (K2s, loss64_small, the executor); RSSYNC_ONE_WAVE_MAX (tests, A/B)
     bool force_big = false;       // RSSYNC_FORCE_BIG=1 (tests): every frame through the kernels for frames of more than 8192 tracks
-    bool no_small_loss = false;   // RSSYNC_NO_SMALL_LOSS=1 (A/B): frames of up to 256 tracks in the four-wave loss kernel
+    bool no_small_loss = false;   // RSSYNC_NO_SMALL_LOSS=1 (A/B): frames of up to 512 tracks in the four-wave loss kernel
     bool exact_select = false;   // RSSYNC_K2_EXACT_SELECT=1 (read once, at creation; only in the -DRSSYNC_TEST_VARIANTS=1 build): PreSync's
                                  // tile kernel with round 2's exact selection of every quartile instead of the lazy one (tests: identical results)
     bool no_small_lmeds = false; // RSSYNC_NO_SMALL_LMEDS=1 (read once, at creation): the tile kernel for every frame size (A/B tests)
@@ -261,7 +262,7 @@ int rpt_of(const rship_ctx* c) { return c->force_big ? 0 : rpt_for(c->max_n); }
 constexpr uint32_t kLossWinBytes = kLossBatch * kWinMax * 128u; // K1's LDS budget for its side-by-side windows (51 KB at 80 knots)
 using rs::WinPlan;
 static_assert(rs::kPlanWinStatic == (uint32_t)kWinMax, "window_plan.hpp and kernels/common.hpp disagree on the compiled-in window");
-// The fp64 window the launches use (window_plan.hpp: cap64_for, cap64_used).  Problems of small frames (up to 256
+// The fp64 window the launches use (window_plan.hpp: cap64_for, cap64_used).  Problems of small frames (up to 512
 // tracks: one WAVE per frame in K1 / K3 / the executor) stage a window PER EVALUATION for a frame's 260 coefficient
 // fetches: beyond ~4 kHz that staging (cap64 x 128 bytes from a table that no longer fits the L2s) is what the workload
 // costs, and beyond kPlanCap64SmallMax knots the general path (260 x 128 bytes from L2) is cheaper again.  Measured on 98
@@ -270,7 +271,7 @@ static_assert(rs::kPlanWinStatic == (uint32_t)kWinMax, "window_plan.hpp and kern
 // against 61; 12 kHz 69 (272) against 58.5.
 uint32_t cap64_of(const rship_ctx* c) {
     const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
-    return rs::cap64_used(c->cap64, n_all, c->force_big);
+    return rs::cap64_used(c->cap64, n_all <= c->one_wave_max ? std::min(n_all, 256u) : n_all, c->force_big);
 }
 template <class K>
 uint32_t static_lds_of(K kernel) {
@@ -306,7 +307,8 @@ uint32_t lmeds_dynamic_static_lds(int rpt, bool small) {
             case 1: return static_lds_of(lmeds_small_kernel<1, MODE, 0>);
             case 2: return static_lds_of(lmeds_small_kernel<2, MODE, 0>);
             case 3: return static_lds_of(lmeds_small_kernel<3, MODE, 0>);
-            default: return static_lds_of(lmeds_small_kernel<4, MODE, 0>);
+            case 4: return static_lds_of(lmeds_small_kernel<4, MODE, 0>);
+            default: return static_lds_of(lmeds_small_kernel<8, MODE, 0>);
         }
     }
     switch (rpt) {
@@ -321,9 +323,12 @@ uint32_t lmeds_dynamic_static_lds(int rpt, bool small) {
 // which LMedS kernel family the problem's frames get (decided from the largest frame of the whole PROBLEM, so that a
 // frame's cost does not depend on the selection or the device it is evaluated in)
 enum class LmedsKind { Small, Tile, Big };
+// rows per lane of the one-wave kernels: 1 .. 4 up to 256 tracks, 8 for 257 .. 512 (rows beyond the frame contribute
+// exact zeros, so one instantiation serves them all with the same bits)
+int small_rpt(uint32_t n_all) { const uint32_t r = std::max(1u, (n_all + 63u) / 64u); return r <= 4u ? (int)r : 8; }
 LmedsKind lmeds_kind(const rship_ctx* c) {
     const uint32_t n_all = c->force_big ? 0xffffffffu : (c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n);
-    if (n_all <= 64u * kSmallMaxRpt && !c->no_small_lmeds) return LmedsKind::Small;
+    if (n_all <= c->one_wave_max && !c->no_small_lmeds) return LmedsKind::Small;
     if (n_all > (uint32_t)kMaxRpt * kBlock) return LmedsKind::Big;
     return LmedsKind::Tile;
 }
@@ -338,7 +343,7 @@ WinPlan plan_lmeds_window(rship_ctx* c, double step_knots, uint32_t chunk_want) 
         return w;
     }
     const bool small = kind == LmedsKind::Small;
-    const int rpt = small ? (int)std::max(1u, std::min(4u, (lmeds_all_tracks(c) + 63u) / 64u)) : rpt_of(c);
+    const int rpt = small ? small_rpt(lmeds_all_tracks(c)) : rpt_of(c);
     // (the kernel's LDS footprint is only asked for when the compiled-in window does not do: plan_window's first test)
     const bool fits80 = rs::plan_fit((double)kWinMax, c->max_span, step_knots, chunk_want) >= std::min(8u, chunk_want);
     const uint32_t fixed = (fits80 || c->force_general) ? 0u : lmeds_dynamic_static_lds<MODE>(rpt, small);
@@ -348,7 +353,7 @@ WinPlan plan_lmeds_window(rship_ctx* c, double step_knots, uint32_t chunk_want) 
 template <int MODE>
 int launch_lmeds(rship_ctx* c, LmedsParams p, const WinPlan& wp, int rpt, uint32_t grid) {
     ProfScope ps(c, MODE == 1 ? RSHIP_K_INIT : RSHIP_K_LMEDS);
-    // Frames of up to 256 tracks (the reference's own data: ~130): one wave per (frame, chunk) instead of a
+    // Frames of up to 512 tracks (the reference's own data: ~130): one wave per (frame, chunk) instead of a
     // four-wave workgroup (kernels/lmeds_small.hpp).
     const uint32_t n_all = lmeds_all_tracks(c);
     const LmedsKind kind = lmeds_kind(c);
@@ -356,22 +361,22 @@ int launch_lmeds(rship_ctx* c, LmedsParams p, const WinPlan& wp, int rpt, uint32
     const size_t dyn = (size_t)wp.cap * 64u;
     if (kind == LmedsKind::Small) {
         const uint32_t g1 = p.n_sel * p.n_chunks;
-        const uint32_t r = (n_all + 63u) / 64u;
+        const int r = small_rpt(n_all);
         if (wp.cap) {
             switch (r) {
-                case 0:
                 case 1: hipLaunchKernelGGL((lmeds_small_kernel<1, MODE, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break;
                 case 2: hipLaunchKernelGGL((lmeds_small_kernel<2, MODE, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break;
                 case 3: hipLaunchKernelGGL((lmeds_small_kernel<3, MODE, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break;
-                default: hipLaunchKernelGGL((lmeds_small_kernel<4, MODE, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break;
+                case 4: hipLaunchKernelGGL((lmeds_small_kernel<4, MODE, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break;
+                default: hipLaunchKernelGGL((lmeds_small_kernel<8, MODE, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break;
             }
         } else {
             switch (r) {
-                case 0:
                 case 1: hipLaunchKernelGGL((lmeds_small_kernel<1, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
                 case 2: hipLaunchKernelGGL((lmeds_small_kernel<2, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
                 case 3: hipLaunchKernelGGL((lmeds_small_kernel<3, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
-                default: hipLaunchKernelGGL((lmeds_small_kernel<4, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
+                case 4: hipLaunchKernelGGL((lmeds_small_kernel<4, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
+                default: hipLaunchKernelGGL((lmeds_small_kernel<8, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
             }
         }
         RS_HIP(hipGetLastError());
@@ -458,10 +463,10 @@ int launch_loss64(rship_ctx* c, const Loss64Params& p_in, int rpt, hipStream_t s
     p.nb_run = GRAD ? 1u : (fixed80 ? (uint32_t)kLossBatch : std::max(1u, std::min((uint32_t)kLossBatchWide, kLossWinBytes / (cap64 * 128u))));
     const size_t dyn = fixed80 ? 0 : (size_t)p.nb_run * cap64 * 128u, dyn_small = (size_t)cap64 * 128u;
     ProfScope ps(c, GRAD ? RSHIP_K_LOSS_GRAD : RSHIP_K_LOSS);
-    // frames of up to 256 tracks (the reference's own: ~130): one wave per slot instead of a four-wave workgroup that
+    // frames of up to 512 tracks (the reference's own: ~130): one wave per slot instead of a four-wave workgroup that
     // half idles -- the same sums in the same order (loss64_wave), four times as many slots on the chip
     const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
-    if (n_all <= 256u && !c->no_small_loss && !c->force_big) {
+    if (n_all <= c->one_wave_max && !c->no_small_loss && !c->force_big) {
         hipLaunchKernelGGL((loss64_small_kernel<GRAD, SIMPLE>), dim3(count), dim3(64), dyn_small, st, p);
         RS_HIP(hipGetLastError());
         return 0;
@@ -707,6 +712,7 @@ int rship_create(rship_ctx** out, int device) {
     if (const char* s = std::getenv("RSSYNC_NO_SMALL_LOSS")) c->no_small_loss = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_FORCE_BIG")) c->force_big = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_FORCE_GENERAL_SPLINE")) c->force_general = s[0] && s[0] != '0';
+    if (const char* s = std::getenv("RSSYNC_ONE_WAVE_MAX")) { const int v = atoi(s); if (v >= 64 && v <= 64 * kSmallMaxRpt) c->one_wave_max = (uint32_t)v; }
     if (device >= 0) {
         e = hipSetDevice(device);
         if (e != hipSuccess) { delete c; return 3; }
@@ -1750,13 +1756,13 @@ static int sync_run_body(rship_ctx* c, const double* d0, int max_outer, double s
 }
 
 // Sync for the W windows of the selection, `repeats` chained calls each (the reference driver's four, core_testcode.cpp:
-// 314), in ONE launch of the window executor (kernels/executor.hpp): frames of up to 256 tracks.  d0[W] in; d_out[W],
+// 314), in ONE launch of the window executor (kernels/executor.hpp): frames of up to 512 tracks.  d0[W] in; d_out[W],
 // cost[W] (loss at the returned delay), iters[W][repeats], and the trace rows of all calls of a window back to back,
 // trace[W][trace_rows][6] (trace_rows >= repeats * max_outer).  Window w samples call r with stream_first + r + w * stride.
 int rship_exec_supported(rship_ctx* c) {
     const uint32_t n = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
     if (c->force_big) return 0; // (RSSYNC_FORCE_BIG: every frame through the large-frame kernels, whose association the one-wave tasks do not have)
-    return n >= 2 && n <= 64u * kSmallMaxRpt && c->n_sel < (1u << 24) ? 1 : 0; // (a queue cell holds the slot in 24 bits)
+    return n >= 2 && n <= c->one_wave_max && c->n_sel < (1u << 24) ? 1 : 0; // (a queue cell holds the slot in 24 bits)
 }
 
 int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream_first, uint32_t stream_stride, uint64_t seed,
@@ -1765,7 +1771,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     DeviceGuard dev_guard(c);
     if (check_ready(c)) return 1;
     const uint32_t W = c->n_grp, ns = c->n_sel;
-    if (!rship_exec_supported(c)) return set_err(c, "sync_exec: frames of more than 256 tracks");
+    if (!rship_exec_supported(c)) return set_err(c, "sync_exec: frames too large for the one-wave kernels (512 tracks, RSSYNC_ONE_WAVE_MAX)");
     if (c->plan_wins != W || c->plan_has_idx || c->plan_len != ns) return set_err(c, "sync_exec: the plan must be the selection's groups");
     if (max_outer <= 0 || repeats < 1 || repeats > kExecMaxCalls) return set_err(c, "sync_exec: bad iteration or call count");
     if (trace_rows < (uint32_t)repeats * (uint32_t)max_outer) return set_err(c, "sync_exec: trace too small");
@@ -1779,7 +1785,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     // One dynamic LDS region per wave serves as fp32 window, fp64 window and staging area (executor.hpp): cap64 knots x
     // 128 bytes -- 10 KB up to ~1.7 kHz of gyro rate, more for wider frames, and then fewer waves share a CU.
     const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
-    const uint32_t exec_rpt = std::min(4u, std::max(1u, (n_all + 63u) / 64u));
+    const uint32_t exec_rpt = (uint32_t)small_rpt(n_all);
     const uint32_t cap64 = cap64_of(c);
     const size_t region = (size_t)cap64 * 128u;
     uint32_t fixed_lds = 0;
@@ -1787,7 +1793,8 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
         case 1: fixed_lds = static_lds_of(sync_exec_kernel<1>); break;
         case 2: fixed_lds = static_lds_of(sync_exec_kernel<2>); break;
         case 3: fixed_lds = static_lds_of(sync_exec_kernel<3>); break;
-        default: fixed_lds = static_lds_of(sync_exec_kernel<4>); break;
+        case 4: fixed_lds = static_lds_of(sync_exec_kernel<4>); break;
+        default: fixed_lds = static_lds_of(sync_exec_kernel<8>); break;
     }
     uint32_t per_cu = 8; // what the chip holds at once (LDS: ~17 KB per wave at 80 knots); more would only idle
     {
@@ -1871,7 +1878,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     ep.lp.search_radius = search_radius;
     ep.lp.max_outer = max_outer;
     ep.lp.nf_fixed = nf_fixed;
-    ep.lp.nf_floor = kHalfBt; // (the executor runs frames of up to 256 tracks: a trial is microseconds)
+    ep.lp.nf_floor = kHalfBt; // (the executor runs frames of up to 512 tracks: a trial is microseconds)
     ep.win = (ExecWin*)(base + o_win);
     ep.n_win = W;
     ep.n_sel = ns;
@@ -1958,7 +1965,8 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
             case 1: hipLaunchKernelGGL((sync_exec_kernel<1>), dim3(waves), dim3(64), region, c->stream, ep); break;
             case 2: hipLaunchKernelGGL((sync_exec_kernel<2>), dim3(waves), dim3(64), region, c->stream, ep); break;
             case 3: hipLaunchKernelGGL((sync_exec_kernel<3>), dim3(waves), dim3(64), region, c->stream, ep); break;
-            default: hipLaunchKernelGGL((sync_exec_kernel<4>), dim3(waves), dim3(64), region, c->stream, ep); break;
+            case 4: hipLaunchKernelGGL((sync_exec_kernel<4>), dim3(waves), dim3(64), region, c->stream, ep); break;
+            default: hipLaunchKernelGGL((sync_exec_kernel<8>), dim3(waves), dim3(64), region, c->stream, ep); break;
         }
     }
     RS_HIP(hipGetLastError());

@@ -277,7 +277,7 @@ class SyncProblemHip final : public ISyncProblem {
     std::vector<int32_t> last_init_winners, init_override;
     void exchange_init_winners();
     uint32_t sync_calls = 0;
-    // Frames of up to 256 tracks run Sync's calls of all windows as ONE device-scheduled launch (kernels/executor.hpp)
+    // Frames of up to 512 tracks run Sync's calls of all windows as ONE device-scheduled launch (kernels/executor.hpp)
     // instead of the chain of launches: the same bits, 21 ms against 30-35 on the reference's workload
     // (profiles/r3_syncpoints.json).  RSSYNC_EXECUTOR=0 keeps the chain.  If the executor ever gives up (its
     // watchdog), the call is redone by the chain -- same values -- and this object stays with the chain.
@@ -1303,7 +1303,7 @@ void SyncProblemHip::select_windows(const std::vector<int64_t>& begins, const st
 //    sequential loop returns;
 //  * P is computed once per motion optimisation, not three times per evaluation (:94-97).
 // Can the window executor (kernels/executor.hpp) run the current selection?  One device holding every frame, nobody
-// else in the sums, frames of up to 256 tracks, no empty window.
+// else in the sums, frames of up to 512 tracks, no empty window.
 bool SyncProblemHip::executor_ok(bool simplified) {
     if (!use_executor || simplified || shards_.size() != 1 || distributed() || host_loop || max_outer <= 0 || sel_.empty()) return false;
     if (!rship_has_device_loop() || !rship_exec_supported(shards_[0].ctx)) return false;
@@ -1380,7 +1380,7 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
     const size_t W = begins.size();
     select_windows(begins, ends_incl);
     if (executor_ok(simplified) &&
-        // frames of up to 256 tracks: the search, the loop and the final loss of every window as one launch
+        // frames of up to 512 tracks: the search, the loop and the final loss of every window as one launch
         sync_exec(begins, ends_incl, initial, search_center, search_radius, 1, kStreamSyncInit + sync_calls, call_stride, costs,
                   delays_out)) {
         if (executor_check) { // the same call once more through the launch chain (which advances the call counter itself)

@@ -31,7 +31,8 @@ inline uint32_t cap64_for(float max_span, float max_ends) {
     need = (need + 15u) / 16u * 16u;
     return std::min(std::max(need, kPlanWinStatic), kPlanCap64Max);
 }
-// ... and what the launches of a problem whose largest frame has `n_all` tracks actually use
+// ... and what the launches of a problem whose largest frame has `n_all` tracks actually use (n_all <= 256 stands for "the
+// one-wave kernels": rssync_kernels.hip cap64_of passes min(n, 256) for every problem they run, up to 512 tracks)
 inline uint32_t cap64_used(uint32_t cap64, uint32_t n_all, bool force_big) {
     if (n_all <= 256u && !force_big && cap64 > kPlanCap64SmallMax) return kPlanWinStatic;
     return cap64;
@@ -60,7 +61,7 @@ inline uint32_t plan_fit_ends(double cap, double ends, double step_knots, uint32
 //               the dynamic-window kernels stage the ends separately where that is fewer knots
 //   step_knots  distance between neighbouring candidate delays (0: one candidate per workgroup)
 //   chunk_want  candidates per workgroup the launch would like (<= 32)
-//   small       the one-wave kernels (frames of up to 256 tracks); wg_max: most workgroups per CU the kernel runs at
+//   small       the one-wave kernels (frames of up to 512 tracks); wg_max: most workgroups per CU the kernel runs at
 //   fixed_lds   static LDS of the dynamic-window instantiation, lds_per_cu the CU's LDS
 //   legacy      rounds 1-3: never a dynamic window (RSSYNC_FORCE_GENERAL_SPLINE)
 // -> cap == 0: the compiled-in window (if the chunk's frames do not fit it, their workgroups take the general path)

@@ -1,4 +1,4 @@
-"""The window executor (kernels/executor.hpp: Sync for frames of up to 256 tracks as ONE device-scheduled launch --
+"""The window executor (kernels/executor.hpp: Sync for frames of up to 512 tracks as ONE device-scheduled launch --
 tasks (window, phase, frame) pulled from a queue by persistent waves, windows advancing independently, a sync
 point's four calls chained per window; the default for such frames, RSSYNC_EXECUTOR=0 -- read when a problem is
 created -- keeps the chain) against the chain of launches: the same task bodies, sums and decisions, so the SAME BITS -- delays, costs, every trace row."""
@@ -32,7 +32,7 @@ def _fill(ps, gyro, frames):
             p.SetTrackResult(*fr)
 
 
-@pytest.mark.parametrize("N", [256, 130, 64, 40])
+@pytest.mark.parametrize("N", [512, 300, 256, 130, 64, 40])
 def test_single_sync_call(built, N):
     from rssync_amd import synth
     F = 48
@@ -168,19 +168,22 @@ def test_check_mode_reruns_every_call_through_the_chain_and_the_queue_ring_wraps
     assert st["runs"] == 4 and st["checked"] == 3, st
 
 
-@pytest.mark.parametrize("fs", [2000.0, 3200.0, 4000.0, 8000.0])
-def test_executor_equals_the_chain_at_high_gyro_rates(built, fs):
+@pytest.mark.parametrize("fs,n_top", [(2000.0, 130), (3200.0, 130), (4000.0, 130), (8000.0, 130), (2000.0, 300), (4000.0, 512),
+                                      (8000.0, 400)])
+def test_executor_equals_the_chain_at_high_gyro_rates(built, fs, n_top):
     """Above ~1.7 kHz the spline windows are sized per problem, and for small frames the planner keeps the search on
     the general path beyond 128 knots: the executor's search must make the same choice as the launch chain's kernel
     (interior and general path round differently in fp32), or a near-tie between hypotheses falls the other way.  Ragged
-    tiny frames make near-ties likely (a randomised 3.2 kHz case found exactly this in round 4)."""
+    tiny frames make near-ties likely (a randomised 3.2 kHz case found exactly this in round 4).  n_top: the largest
+    frame, which picks the instantiation (eight rows per lane from 257 tracks on)."""
     from rssync_amd import synth
     F = 24
     gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, fs=fs, seed=113)
     rng = np.random.default_rng(113)
     frames = []
     for fr in range(F):
-        n = int(rng.choice([2, 4, 5, 7, 13, 16, 20, 23, 40, 130]))
+        n = int(rng.choice([2, 4, 5, 7, 13, 16, 20, 23, 40, n_top]))
+        n = n_top if fr == 3 else n
         frames += list(synth.make_frames(gyro, fr, fr + 1, n, seed=113, noise=0.0, outliers=0.0))
     ex, ch = _two(seed=113, max_outer_iters=60)
     _fill((ex, ch), gyro, frames)

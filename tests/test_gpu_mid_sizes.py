@@ -3,7 +3,9 @@
 The kernels are instantiated per rows-per-thread (rssync_kernels.hip:rpt_for): 1 row for <= 256
 tracks, 2 for <= 512, 4 for <= 1024, 8 for <= 2048.  tests/test_gpu_parity.py covers <1> and <8>;
 these cases dispatch lmeds/loss/opt_motion <2> and <4>, including ragged tails (N not a multiple of
-256: NaN-padded tile rows, partially filled last row tile).  Reference: core_private.cpp:15-32
+256: NaN-padded tile rows, partially filled last row tile).  Since round 4 frames of up to 512 tracks run in the
+one-wave kernels by default: every test here runs a second time with RSSYNC_ONE_WAVE_MAX=256 (the `kernel_family`
+fixture) so that the <2> instantiations of the four-wave kernels stay covered.  Reference: core_private.cpp:15-32
 (P), :34-59 + :61-90 (PreSync), :92-133 (loss, init), :211-334 (Sync).
 """
 import os
@@ -15,6 +17,19 @@ pytestmark = pytest.mark.gpu
 
 SEED = 123
 THREADS = min(os.cpu_count() or 1, 16)
+
+
+@pytest.fixture(autouse=True, params=["default", "four-wave kernels from 257 tracks"])
+def kernel_family(request, monkeypatch):
+    """Frames of up to 512 tracks run the one-wave kernels (K2s, loss64_small, the executor) since round 4; the tile /
+    four-wave kernels' instantiations for 257 .. 512 tracks stay reachable with RSSYNC_ONE_WAVE_MAX=256 (read when a
+    problem is created): every test of this file with such an N runs both ways."""
+    if request.param == "default":
+        return
+    N = getattr(request.node, "callspec", None) and request.node.callspec.params.get("N")
+    if not isinstance(N, int) or not 256 < N <= 512:
+        pytest.skip("the same kernels either way")
+    monkeypatch.setenv("RSSYNC_ONE_WAVE_MAX", "256")
 
 
 def _pair(F, N, seed, noise=1e-3, outliers=0.10, **kw):
@@ -300,7 +315,7 @@ def test_track_limit_is_an_indexing_bound():
 
 
 def test_one_wave_kernel_for_small_frames_agrees_with_the_tile_kernel(monkeypatch):
-    """Frames of up to 256 tracks run PreSync / GuessMotion in lmeds_small_kernel (one wave per frame, rows in
+    """Frames of up to 512 tracks run PreSync / GuessMotion in lmeds_small_kernel (one wave per frame, rows in
     registers, hypotheses in order); RSSYNC_NO_SMALL_LMEDS=1 sends them through the four-wave tile kernel.  Same
     rows, same directions, same exact selection: the winning hypothesis of every (frame, candidate) is identical,
     the costs agree to the order of their summation, GuessMotion's winners are the same."""
@@ -308,7 +323,7 @@ def test_one_wave_kernel_for_small_frames_agrees_with_the_tile_kernel(monkeypatc
     from rssync_amd import synth
     F = 14
     g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=17)
-    for n_max in (5, 64, 65, 130, 192, 200, 256):
+    for n_max in (5, 64, 65, 130, 192, 200, 256, 300, 512):
         frames = list(synth.make_frames(g, 0, F, n_max, seed=17))
         counts = [max(2, n_max - 7 * (i % 3)) for i in range(F)]   # ragged, the largest frame decides the kernel
         counts[3] = n_max
@@ -374,9 +389,9 @@ def test_one_wave_kernel_with_several_candidates_per_chunk(monkeypatch):
     assert d[int(np.argmin(c))] == do[int(np.argmin(co))]
 
 
-@pytest.mark.parametrize("N", [40, 130, 256])
+@pytest.mark.parametrize("N", [40, 130, 256, 257, 300, 512])
 def test_one_wave_loss_kernel_equals_the_workgroup_kernel(N, monkeypatch):
-    """Frames of up to 256 tracks: loss64_small_kernel evaluates a slot's loss / derivative with ONE wave in the
+    """Frames of up to 512 tracks: loss64_small_kernel evaluates a slot's loss / derivative with ONE wave in the
     four-wave kernel's association (four times as many slots on the chip); RSSYNC_NO_SMALL_LOSS=1 keeps
     loss64_kernel.  Loss, derivative, the five-delay batch with switched-off windows, simplified mode and whole Sync
     traces: the same bits."""

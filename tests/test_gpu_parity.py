@@ -63,7 +63,7 @@ def test_residual_matrix_outside_the_gyro_span(hip_small, ora_small, small_case)
 
 
 def _hip_with_kernel(small_case, kernel, monkeypatch):
-    """a fresh problem on the GPU whose <= 256-track frames run PreSync / GuessMotion in the one-wave kernel (the
+    """a fresh problem on the GPU whose <= 512-track frames run PreSync / GuessMotion in the one-wave kernel (the
     default) or in the four-wave tile kernel's one-row-per-thread instantiation, lmeds_kernel<1, .> (VERDICT r2,
     next #7: compared with the oracle directly, not only with the one-wave kernel).  The switch is read when the
     device context is created."""

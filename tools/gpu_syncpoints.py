@@ -43,7 +43,7 @@ bat.profile(True); bat.profile_reset()
 t = time.perf_counter(); bat.sync_points(pos, WINDOW, 0.0, 0.001, 0.1); t_prof = time.perf_counter() - t
 prof = bat.profile_get()
 del os.environ["RSSYNC_EXECUTOR"]
-execp = problem()                      # the window executor (default for frames of up to 256 tracks)
+execp = problem()                      # the window executor (default for frames of up to 512 tracks)
 os.environ["RSSYNC_EXECUTOR"] = "0"
 execp.sync_points(pos, WINDOW, 0.0, 0.001, 0.1)
 t = time.perf_counter(); _, de = execp.sync_points(pos, WINDOW, 0.0, 0.001, 0.1); t_exec = time.perf_counter() - t
