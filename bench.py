@@ -191,6 +191,10 @@ def run(args):
     prob = rssync_amd.SyncProblem(seed=0x5EED0003, max_outer_iters=args.outer_iters, verbose=False, _lib=lib)
     if inproc and n_dev > 1:
         prob.set_devices(list(range(n_dev)))
+    elif on_gpu and not inproc:
+        # a rank names its GPU explicitly: the library's default is "the calling thread's current device" of the HIP
+        # runtime IT is bound to, which is torch's only while both resolve libamdhip64 to the same copy
+        prob.set_devices([dev])
     # host side of the boundary, outside the timed region: generate the frames, then hand them over with the
     # reference's calls (SetTrackResult copies into pinned staging and starts the upload)
     t_gen = time.time()
