@@ -269,7 +269,8 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
 #pragma unroll
         for (int q = 0; q < NB; ++q) L[q] = G[q] = 0.0;
         const int rpt = RPT ? RPT : (int)((N + kBlock - 1) / kBlock);
-#pragma unroll 1 // (unroll 2 measured in round 3: the gradient launch stays at 0.122 ms)
+#pragma unroll 1 // (unroll 2 measured in round 3: the gradient launch stays at 0.122 ms; round 4: the next row's 64 bytes requested
+                 // before this row's arithmetic, 158 VGPRs: 1.03 against 1.00 ms per bench step, profiles/r4_k1_prefetch_ab.txt)
         for (int j = 0; j < rpt; ++j) {
             const uint32_t row = j * kBlock + tid;
             if (row < N) {
