@@ -264,11 +264,12 @@ using rs::WinPlan;
 static_assert(rs::kPlanWinStatic == (uint32_t)kWinMax, "window_plan.hpp and kernels/common.hpp disagree on the compiled-in window");
 // The fp64 window the launches use (window_plan.hpp: cap64_for, cap64_used).  Problems of small frames (up to 512
 // tracks: one WAVE per frame in K1 / K3 / the executor) stage a window PER EVALUATION for a frame's 260 coefficient
-// fetches: beyond ~4 kHz that staging (cap64 x 128 bytes from a table that no longer fits the L2s) is what the workload
-// costs, and beyond kPlanCap64SmallMax knots the general path (260 x 128 bytes from L2) is cheaper again.  Measured on 98
-// sync points of 61 x 130 with the two ends of a pair staged separately (profiles/r4_gyro_rate_small_frames.json):
-// 4 kHz 18.1 ms with 96 knots against 21.8 on the general path; 6 kHz 54 (144 knots) against 61; 8 kHz 59 (192)
-// against 61; 12 kHz 69 (272) against 58.5.
+// fetches, and every knot of it is LDS that another wave of the CU cannot have: 96 knots leave the executor its eight
+// waves per CU, 144 seven, 192 five, 272 four.  Beyond kPlanCap64SmallMax knots the general path (260 x 128 bytes from
+// L2, eight waves) is cheaper again.  Measured on 98 sync points of 61 x 130, two ends of a pair staged separately,
+// outer iterations capped at 25 per call so that rates compare (profiles/r4_gyro_rate_small_frames.json, a build that
+// allows 384 knots): 4 kHz 17.5 ms with 96 knots against 20.5 on the general path; 6 kHz 20.0 (144 knots) against 21.1;
+// 8 kHz 25.5 (192) against 21.4; 12 kHz 33.6 (272) against 21.9.
 uint32_t cap64_of(const rship_ctx* c) {
     const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
     return rs::cap64_used(c->cap64, n_all <= c->one_wave_max ? std::min(n_all, 256u) : n_all, c->force_big);

@@ -16,7 +16,10 @@ namespace rs {
 constexpr uint32_t kPlanWinStatic = 80;   // knots compiled into the kernels' LDS (kernels/common.hpp: kWinMax)
 constexpr uint32_t kPlanSmallWinMax = 128; // one wave per frame (K2s): no dynamic window beyond this many knots
 constexpr uint32_t kPlanCap64Max = 384;   // fp64 windows: 48 KB
-constexpr uint32_t kPlanCap64SmallMax = 208; // problems of small frames: the 80-knot window beyond this (measured: below)
+#ifndef RSSYNC_PLAN_CAP64_SMALL_MAX   // (a measurement build sets 384: tools/gpu_gyro_rate.py's small-frame sweep beyond the rule)
+#define RSSYNC_PLAN_CAP64_SMALL_MAX 144
+#endif
+constexpr uint32_t kPlanCap64SmallMax = RSSYNC_PLAN_CAP64_SMALL_MAX; // problems of small frames: the 80-knot window beyond this (measured: below)
 
 struct WinPlan {
     uint32_t cap = 0;   // 0: the compiled-in 80-knot window; otherwise knots of dynamic LDS (64 bytes each)

@@ -684,7 +684,7 @@ def test_gyro_rates_against_the_oracle(fs, N):
         assert w["presync_window_dynamic"] and w["presync_window_knots"] >= need and w["fp64_window_knots"] == want64
     elif small:
         assert w["presync_window_dynamic"] == (need + 3 <= 128), w
-        assert w["fp64_window_knots"] == (80 if want64 > 208 else want64), w
+        assert w["fp64_window_knots"] == (80 if want64 > 144 else want64), w
     else:
         assert w["fp64_window_knots"] == 384                  # wider than any window: the table from L2 (still correct)
     Mh, kh = h.init_motion(dh, 0, F - 1)

@@ -119,8 +119,8 @@ def test_fp64_window_capacity(lib):
     assert c64(180.0) == 192 and c64(358.0) == 368 and c64(5000.0) == 384
     # where the table knows the two ends' ranges the window holds those: a 4 kHz pair (180 knots) needs 2 x 46
     assert c64(180.0, 92.0) == 96 and c64(91.0, 48.0) == 80 and c64(358.0, 182.0) == 192
-    # problems of small frames keep 80 knots beyond 208; a forced large-frame run does not count as small
-    assert lib.cap64_used(96, 130, 0) == 96 and lib.cap64_used(208, 256, 0) == 208
+    # problems of small frames keep 80 knots beyond 144; a forced large-frame run does not count as small
+    assert lib.cap64_used(96, 130, 0) == 96 and lib.cap64_used(144, 256, 0) == 144 and lib.cap64_used(160, 256, 0) == 80
     assert lib.cap64_used(224, 130, 0) == 80 and lib.cap64_used(224, 257, 0) == 224 and lib.cap64_used(224, 130, 1) == 224
 
 

@@ -11,5 +11,7 @@ run config2_parity.json python tests/measure/gpu_config2_parity.py
 run fullsize_sync_parity.json python tests/measure/gpu_fullsize_parity.py
 run gyro_rate_sweep.json python tools/gpu_gyro_rate.py
 run quality_drift_noisy.json python tests/measure/gpu_quality.py
+# (needs the measurement build: bash tools/k2_build_variant.sh cap384 -DRSSYNC_PLAN_CAP64_SMALL_MAX=384)
+[ -f rs-sync_amd/_variants/lib_cap384.so ] && run gyro_rate_small_frames.json env RSSYNC_LIB=$PWD/rs-sync_amd/_variants/lib_cap384.so SMALL_ONLY=1 RATES=4000,6000,8000,12000 python tools/gpu_gyro_rate.py
 [ -x tools/ubench/_build/handoff_probe ] && run handoff_probe.json tools/ubench/_build/handoff_probe 400
 [ -x tools/ubench/_build/stagec_mfma ] && run k2_mfma_raw.txt tools/ubench/_build/stagec_mfma
