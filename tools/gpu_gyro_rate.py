@@ -67,7 +67,7 @@ def large(fs, general):
 def small(fs, general, bounded=None):
     """bounded: outer iterations per Sync call capped (every window's four calls then take at most 4 x bounded
     iterations: the run's length no longer follows ONE window that the reference's loop does not converge on -- at 6 and
-    8 kHz this scene has such a window, 480 iterations in its last call against ~100-130 elsewhere -- and rates compare)"""
+    8 kHz this scene has such a window, 460-510 iterations over its four calls against ~55 on average -- and rates compare)"""
     if general:
         os.environ["RSSYNC_FORCE_GENERAL_SPLINE"] = "1"
     else:
@@ -88,7 +88,7 @@ def small(fs, general, bounded=None):
     if bounded:
         iters = [len(h.window_trace(w)) for w in range(len(pos))]
         out = {"sync_points_s": round(t_all, 4), "outer_iterations_cap_per_call": bounded,
-               "last_call_outer_iterations": {"mean": round(float(np.mean(iters)), 2), "max": int(np.max(iters))},
+               "outer_iterations_per_position": {"mean": round(float(np.mean(iters)), 2), "max": int(np.max(iters))},
                "executor_tasks": h.executor_stats()["head"], "executor_waves": h.executor_stats()["waves"]}
         h.close()
         return out
@@ -96,9 +96,9 @@ def small(fs, general, bounded=None):
     h.profile_reset()
     h.pre_sync_windows(0.0, pos, [p + W for p in pos], 0.001, 0.1)
     prof = per_launch(h.profile_get())
-    iters = [len(h.window_trace(w)) for w in range(len(pos))]   # outer iterations of each position's last Sync call
+    iters = [len(h.window_trace(w)) for w in range(len(pos))]   # outer iterations of each position's four Sync calls together
     out = {"sync_points_s": round(t_all, 4), "positions": len(pos), "presync_windows_kernel_ms": prof.get("lmeds"),
-           "last_call_outer_iterations": {"mean": round(float(np.mean(iters)), 2), "max": int(np.max(iters))},
+           "outer_iterations_per_position": {"mean": round(float(np.mean(iters)), 2), "max": int(np.max(iters))},
            "median_abs_err_ms": float(np.median(np.abs(d - synth.D_TRUE)) * 1e3), "executor": h.executor_stats(), "windows": h.window_info()}
     h.close()
     return out
