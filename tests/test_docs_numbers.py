@@ -32,3 +32,25 @@ def test_design_quotes_the_committed_kernel_statistics():
             "**%.2f ms = " % bench["ms_per_step"]]                                   # the step of the committed bench line
     missing = [w for w in want if w not in design]
     assert not missing, missing
+
+
+def test_design_gyro_rate_table_is_the_committed_sweep():
+    """DESIGN.md section 3's gyro-rate table and its small-frame paragraph against profiles/r4_gyro_rate_sweep.json and
+    r4_gyro_rate_small_frames.json (the table was once left behind by a re-collection within the hour)"""
+    import json
+    prof = os.path.join(ROOT, "profiles")
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    sweep = json.load(open(os.path.join(prof, "r4_gyro_rate_sweep.json")))["by_gyro_hz"]
+    want = []
+    for hz, row in sweep.items():
+        want.append("%.2f" % row["large"]["ms_per_launch"]["lmeds"])                      # K2 per launch
+        if "large_general_path" in row:
+            want.append("[%.2f = " % row["large_general_path"]["ms_per_launch"]["lmeds"])
+        if int(hz) in (400, 4000):
+            want.append("%.1f" % (1e3 * row["small_bounded"]["sync_points_s"]))           # 98 sync points, iterations capped
+    small = json.load(open(os.path.join(prof, "r4_gyro_rate_small_frames.json")))["by_gyro_hz"]
+    for hz, row in small.items():
+        want.append("%.1f" % (1e3 * row["small_bounded"]["sync_points_s"]))
+        want.append("%.1f" % (1e3 * row["small_general_path_bounded"]["sync_points_s"]))
+    missing = [w for w in want if w not in design]
+    assert not missing, missing
