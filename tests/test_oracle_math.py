@@ -377,3 +377,65 @@ def test_timestamped_gyro_is_resampled_like_the_reference():
         bad = ts_us.copy()
         bad[10], bad[11] = bad[11], bad[10]
         o.SetGyroQuaternionsTimestamped(bad, q)
+
+
+def _sync_in_python(o, frames, initial_delay, search_center, search_radius, stream, max_outer=400):
+    """core_private.cpp:211-334 with backtrack.cpp:3-13 written out in Python on the oracle's per-frame primitives
+    (GuessMotion's search, one frame's L-BFGS, one frame's loss and central-difference derivative): the outer loop's
+    control flow, transcribed a second time."""
+    d = initial_delay
+    M, k = {}, {}
+    for f in frames:                                                    # :218-223
+        M[f] = o.guess_motion(f, d, 200, stream)[0]                     # GuessMotion (:125-128)
+        pm = o.problem_matrix(f, d) @ M[f]
+        k[f] = float(np.clip(1.0 / np.sqrt(sum(x * x for x in pm)) * 1e2, 10.0, 1000.0))   # GuessK (:130-133)
+    c_armijo, decay, t0, max_bt, delay_b = 2e-4, 0.1, 1e-3, 10, 0.3     # :226, :260
+    v_mom, converge, rows = 0.0, 0, []
+    for _ in range(max_outer):                                          # :309
+        for f in frames:                                                # do_opt_motion (:262-296)
+            M[f] = o.lbfgs_motion(f, d, M[f], k[f])[0]
+        x0 = d - delay_b * v_mom                                        # do_opt_delay (:298-305) -> Backtrack::Step
+        v = g = 0.0
+        for f in frames:
+            L, dn, _, _ = o.loss(f, x0, M[f], k[f])
+            v, g = v + L, g + dn
+        m, t, trials = g * g, t0, 0
+        for _i in range(max_bt):
+            v1 = 0.0
+            for f in frames:
+                v1 += o.loss(f, x0 - t * g, M[f], k[f])[0]
+            trials += 1
+            if v - v1 >= t * c_armijo * m:
+                break
+            t *= decay
+        step = -t * g
+        v_mom = delay_b * v_mom + step                                  # :301
+        d += v_mom                                                      # :302
+        rows.append([d, step, v, g, t, trials])
+        converge = converge + 1 if abs(step) < 1e-4 else 0              # :316-320
+        if converge > 5 or abs(d - search_center) > search_radius:      # :322-328
+            break
+    cost = 0.0
+    for f in frames:
+        cost += o.loss(f, d, M[f], k[f])[0]                             # :333
+    return cost, d, np.array(rows)
+
+
+@pytest.mark.parametrize("case_name,d0", [("clean", 0.03), ("noisy", 0.0355)])
+def test_sync_loop_equals_its_python_transcription(small_case, clean_case, case_name, d0):
+    """the C oracle's Sync (ora_sync_trace) against the loop written out in Python on the same per-frame primitives: the
+    same decisions, trial counts, delays and costs in every outer iteration, bit for bit (both add the frames in order)"""
+    from tests.conftest import fill
+    case = clean_case if case_name == "clean" else small_case
+    F = 12
+    sub = dict(gyro=case["gyro"], frames=case["frames"][:F])
+    a = fill(OracleProblem(seed=31, threads=1, faithful=True, max_outer_iters=60), sub)
+    b = fill(OracleProblem(seed=31, threads=1, faithful=True, max_outer_iters=60), sub)
+    cost_c, delay_c, trace_c = a.sync_trace(d0, 0, F - 1, 0.0, 0.1)
+    cost_p, delay_p, trace_p = _sync_in_python(b, list(range(F)), d0, 0.0, 0.1, 0x80000000, max_outer=60)
+    assert len(trace_c) == len(trace_p) >= 6
+    np.testing.assert_array_equal(trace_c[:, 5], trace_p[:, 5])          # trials per line search
+    np.testing.assert_array_equal(trace_c, trace_p)
+    # (the final loss: ora_loss evaluates value and gradient together, whose value can differ in the last bit from the
+    # value-only routine the C loop ends with)
+    assert delay_c == delay_p and cost_c == pytest.approx(cost_p, rel=1e-14)
