@@ -251,7 +251,11 @@ constexpr int kMaxRpt = 32; // 8192 tracks per frame in registers / LDS; larger 
 // kernels' runtime-length variants (loss64_kernel<0>, opt_motion64_kernel<0, 4>, lmeds_big_kernel)
 int rpt_for(uint32_t max_n) {
     if (max_n > (uint32_t)kMaxRpt * kBlock) return 0;
-    int rpt = 1;
+    // (at least four: frames of up to 512 tracks run in the one-wave kernels, and where a switch sends them here all the
+    // same -- RSSYNC_NO_SMALL_LMEDS / _LOSS, RSSYNC_ONE_WAVE_MAX, the tests' cross-checks of the two families -- the
+    // 1024-row instantiation gives the bits a 256- or 512-row one would: a thread adds its rows in order, rows beyond
+    // the frame add nothing.  Rounds 1-4 carried 20 kernels for those two sizes that no unswitched run could reach.)
+    int rpt = 4;
     while ((uint32_t)rpt * kBlock < max_n) rpt *= 2;
     return rpt;
 }
@@ -313,8 +317,6 @@ uint32_t lmeds_dynamic_static_lds(int rpt, bool small) {
         }
     }
     switch (rpt) {
-        case 1: return static_lds_of(lmeds_kernel<1, MODE, 0>);
-        case 2: return static_lds_of(lmeds_kernel<2, MODE, 0>);
         case 4: return static_lds_of(lmeds_kernel<4, MODE, 0>);
         case 8: return static_lds_of(lmeds_kernel<8, MODE, 0>);
         case 16: return static_lds_of(lmeds_kernel<16, MODE, 0>);
@@ -402,10 +404,6 @@ int launch_lmeds(rship_ctx* c, LmedsParams p, const WinPlan& wp, int rpt, uint32
     }
     if (wp.cap) { // the window in dynamic LDS (gyro rates above ~1.7 kHz)
         switch (rpt) {
-            case 1: allow_dynamic_lds(lmeds_kernel<1, MODE, 0>, dyn);
-                    hipLaunchKernelGGL((lmeds_kernel<1, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
-            case 2: allow_dynamic_lds(lmeds_kernel<2, MODE, 0>, dyn);
-                    hipLaunchKernelGGL((lmeds_kernel<2, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
             case 4: allow_dynamic_lds(lmeds_kernel<4, MODE, 0>, dyn);
                     hipLaunchKernelGGL((lmeds_kernel<4, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
             case 8: allow_dynamic_lds(lmeds_kernel<8, MODE, 0>, dyn);
@@ -422,8 +420,6 @@ int launch_lmeds(rship_ctx* c, LmedsParams p, const WinPlan& wp, int rpt, uint32
 #if RSSYNC_TEST_VARIANTS
     if (MODE == 0 && c->exact_select) {
         switch (rpt) {
-            case 1: hipLaunchKernelGGL((lmeds_kernel<1, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-            case 2: hipLaunchKernelGGL((lmeds_kernel<2, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
             case 4: hipLaunchKernelGGL((lmeds_kernel<4, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
             case 8: hipLaunchKernelGGL((lmeds_kernel<8, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
             case 16: hipLaunchKernelGGL((lmeds_kernel<16, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
@@ -435,8 +431,6 @@ int launch_lmeds(rship_ctx* c, LmedsParams p, const WinPlan& wp, int rpt, uint32
     }
 #endif
     switch (rpt) {
-        case 1: hipLaunchKernelGGL((lmeds_kernel<1, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-        case 2: hipLaunchKernelGGL((lmeds_kernel<2, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
         case 4: hipLaunchKernelGGL((lmeds_kernel<4, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
         case 8: hipLaunchKernelGGL((lmeds_kernel<8, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
         case 16: hipLaunchKernelGGL((lmeds_kernel<16, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
@@ -481,8 +475,6 @@ int launch_loss64(rship_ctx* c, const Loss64Params& p_in, int rpt, hipStream_t s
         break;
     switch (rpt) {
         RS_LOSS_CASE(0)
-        RS_LOSS_CASE(1)
-        RS_LOSS_CASE(2)
         RS_LOSS_CASE(4)
         RS_LOSS_CASE(8)
         RS_LOSS_CASE(16)

@@ -1,11 +1,11 @@
 """HIP path vs the oracle at 256 < tracks <= 1024 per frame (BASELINE config 2's 1024-track shape).
 
-The kernels are instantiated per rows-per-thread (rssync_kernels.hip:rpt_for): 1 row for <= 256
-tracks, 2 for <= 512, 4 for <= 1024, 8 for <= 2048.  tests/test_gpu_parity.py covers <1> and <8>;
-these cases dispatch lmeds/loss/opt_motion <2> and <4>, including ragged tails (N not a multiple of
-256: NaN-padded tile rows, partially filled last row tile).  Since round 4 frames of up to 512 tracks run in the
-one-wave kernels by default: every test here runs a second time with RSSYNC_ONE_WAVE_MAX=256 (the `kernel_family`
-fixture) so that the <2> instantiations of the four-wave kernels stay covered.  Reference: core_private.cpp:15-32
+The four-wave kernels are instantiated per rows-per-thread (rssync_kernels.hip:rpt_for): 4 rows for <= 1024 tracks,
+8 for <= 2048, ...; frames of up to 512 tracks run in the one-wave kernels (1 .. 4 and 8 rows per lane).
+tests/test_gpu_parity.py covers the one-wave kernels and <8>; these cases cover the sizes in between, including ragged
+tails (N not a multiple of 256: NaN-padded tile rows, partially filled last row tile).  Every test here with 256 < N <= 512
+runs a second time with RSSYNC_ONE_WAVE_MAX=256 (the `kernel_family` fixture): the tile / four-wave family on frames the
+one-wave family takes by default (through the 1024-row instantiations: same bits as narrower ones would give).  Reference: core_private.cpp:15-32
 (P), :34-59 + :61-90 (PreSync), :92-133 (loss, init), :211-334 (Sync).
 """
 import os
@@ -21,9 +21,9 @@ THREADS = min(os.cpu_count() or 1, 16)
 
 @pytest.fixture(autouse=True, params=["default", "four-wave kernels from 257 tracks"])
 def kernel_family(request, monkeypatch):
-    """Frames of up to 512 tracks run the one-wave kernels (K2s, loss64_small, the executor) since round 4; the tile /
-    four-wave kernels' instantiations for 257 .. 512 tracks stay reachable with RSSYNC_ONE_WAVE_MAX=256 (read when a
-    problem is created): every test of this file with such an N runs both ways."""
+    """Frames of up to 512 tracks run the one-wave kernels (K2s, loss64_small, the executor) since round 4; with
+    RSSYNC_ONE_WAVE_MAX=256 (read when a problem is created) frames of 257 .. 512 tracks go through the tile /
+    four-wave family instead: every test of this file with such an N runs both ways."""
     if request.param == "default":
         return
     N = getattr(request.node, "callspec", None) and request.node.callspec.params.get("N")
