@@ -276,7 +276,7 @@ static_assert(rs::kPlanWinStatic == (uint32_t)kWinMax, "window_plan.hpp and kern
 // 8 kHz 25.5 (192) against 21.3; 12 kHz 33.4 (272) against 22.0.
 uint32_t cap64_of(const rship_ctx* c) {
     const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
-    return rs::cap64_used(c->cap64, n_all <= c->one_wave_max ? std::min(n_all, 256u) : n_all, c->force_big);
+    return rs::cap64_used(c->cap64, n_all <= c->one_wave_max && !c->force_big);
 }
 template <class K>
 uint32_t static_lds_of(K kernel) {

@@ -34,10 +34,10 @@ inline uint32_t cap64_for(float max_span, float max_ends) {
     need = (need + 15u) / 16u * 16u;
     return std::min(std::max(need, kPlanWinStatic), kPlanCap64Max);
 }
-// ... and what the launches of a problem whose largest frame has `n_all` tracks actually use (n_all <= 256 stands for "the
-// one-wave kernels": rssync_kernels.hip cap64_of passes min(n, 256) for every problem they run, up to 512 tracks)
-inline uint32_t cap64_used(uint32_t cap64, uint32_t n_all, bool force_big) {
-    if (n_all <= 256u && !force_big && cap64 > kPlanCap64SmallMax) return kPlanWinStatic;
+// ... and what the launches of a problem actually use: `one_wave` = its frames run in the one-wave kernels (K1 / K3 in
+// their one-wave shapes, the window executor), which stage a window per evaluation of a few hundred fetches
+inline uint32_t cap64_used(uint32_t cap64, bool one_wave) {
+    if (one_wave && cap64 > kPlanCap64SmallMax) return kPlanWinStatic;
     return cap64;
 }
 

@@ -19,7 +19,7 @@ void plan(double span, double ends, double step, unsigned want, int small_, int 
     out[0] = w.cap; out[1] = w.chunk;
 }
 unsigned cap64_for(float span, float ends) { return rs::cap64_for(span, ends); }
-unsigned cap64_used(unsigned cap64, unsigned n_all, int force_big) { return rs::cap64_used(cap64, n_all, force_big != 0); }
+unsigned cap64_used(unsigned cap64, int one_wave) { return rs::cap64_used(cap64, one_wave != 0); }
 }
 '''
 LDS = 160 * 1024
@@ -39,7 +39,7 @@ def lib(tmp_path_factory):
                        ctypes.POINTER(ctypes.c_uint)]
     L.cap64_for.argtypes = [ctypes.c_float, ctypes.c_float]
     L.cap64_for.restype = ctypes.c_uint
-    L.cap64_used.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_int]
+    L.cap64_used.argtypes = [ctypes.c_uint, ctypes.c_int]
     L.cap64_used.restype = ctypes.c_uint
     return L
 
@@ -119,9 +119,9 @@ def test_fp64_window_capacity(lib):
     assert c64(180.0) == 192 and c64(358.0) == 368 and c64(5000.0) == 384
     # where the table knows the two ends' ranges the window holds those: a 4 kHz pair (180 knots) needs 2 x 46
     assert c64(180.0, 92.0) == 96 and c64(91.0, 48.0) == 80 and c64(358.0, 182.0) == 192
-    # problems of small frames keep 80 knots beyond 144; a forced large-frame run does not count as small
-    assert lib.cap64_used(96, 130, 0) == 96 and lib.cap64_used(144, 256, 0) == 144 and lib.cap64_used(160, 256, 0) == 80
-    assert lib.cap64_used(224, 130, 0) == 80 and lib.cap64_used(224, 257, 0) == 224 and lib.cap64_used(224, 130, 1) == 224
+    # problems whose frames run in the one-wave kernels keep 80 knots beyond 144
+    assert lib.cap64_used(96, 1) == 96 and lib.cap64_used(144, 1) == 144 and lib.cap64_used(160, 1) == 80
+    assert lib.cap64_used(224, 1) == 80 and lib.cap64_used(224, 0) == 224 and lib.cap64_used(384, 0) == 384
 
 
 def ends_of(fs):     # the two ends of such a pair: 11.1 ms of read-out each, + the carry knot and the partial knot per end
