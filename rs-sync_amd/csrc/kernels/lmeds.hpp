@@ -683,20 +683,25 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         kf = (kf < 10.f) ? 10.f : ((1000.f < kf) ? 1000.f : kf);
         {
             float sc = kf * rs::rsqrt_fast(rs::dot(Mv, Mv)); // core_private.cpp:80
-            // a non-finite r or rho (core_private.cpp:81,83) makes the sums non-finite: NaN propagates
-            // and all terms are >= 0, so the checks are made once on the sums, not per row
-            float acc = 0.f, rsum = 0.f;
+            // a non-finite r or rho (core_private.cpp:81,83) makes the sum non-finite (NaN and inf propagate through r^2,
+            // log1p and sqrt, and all terms are >= 0): the check is made once on the sum, and only if it fires does the
+            // thread look which of the reference's two checks would have been first (round 4: the per-row |r| sum that
+            // answered this beforehand cost 0.15 ms per launch, profiles/r4_k2_norsum_ab.txt)
+            float acc = 0.f;
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
                 const float r = pm[j] * sc;
-                rsum += fabsf(r);
                 const float rho = rs::log1p_pos_fast(r * r); // core_private.cpp:82
                 // v_sqrt_f32 directly (1 ulp): libm's sqrtf adds range scaling for denormal inputs,
                 // whose square roots (< 1e-19) cannot change a sum of O(1) terms in fp32
                 acc += __builtin_amdgcn_sqrtf(rho);
             }
-            if (!finite_f(rsum)) bad |= RSHIP_BAD_R;
-            else if (!finite_f(acc)) bad |= RSHIP_BAD_RHO;
+            if (!finite_f(acc)) {
+                float rsum = 0.f;
+#pragma unroll
+                for (int j = 0; j < RPT; ++j) rsum += fabsf(pm[j] * sc);
+                bad |= finite_f(rsum) ? RSHIP_BAD_RHO : RSHIP_BAD_R;
+            }
             double acc_tot;
             K2_TIMED(3, acc_tot = block_sum(acc, s_red[1]));
             if (tid == 0) {

@@ -193,15 +193,18 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
         kf = (kf < 10.f) ? 10.f : ((1000.f < kf) ? 1000.f : kf);
         {
             const float sc = kf * rs::rsqrt_fast(rs::dot(Mv, Mv));
-            float acc = 0.f, rsum = 0.f;
+            float acc = 0.f;
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
                 const float r = pm[q] * sc;
-                rsum += fabsf(r);
                 acc += __builtin_amdgcn_sqrtf(rs::log1p_pos_fast(r * r));
             }
-            if (!finite_f(rsum)) bad |= RSHIP_BAD_R;
-            else if (!finite_f(acc)) bad |= RSHIP_BAD_RHO;
+            if (!finite_f(acc)) { // (as in the tile kernel: which of the reference's two checks fires first, looked up only then)
+                float rsum = 0.f;
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) rsum += fabsf(pm[q] * sc);
+                bad |= finite_f(rsum) ? RSHIP_BAD_RHO : RSHIP_BAD_R;
+            }
             const double acc_tot = (double)wave_sum_f32(acc);
             if (lane == 0) {
                 p.frame_cost[(size_t)c * p.n_sel + sf] = sqrt(acc_tot);
