@@ -243,21 +243,39 @@ __device__ __forceinline__ f4 load_ray(__amdgpu_buffer_rsrc_t rs_, uint32_t voff
 // stage A of the LMedS kernel: this thread's rows of P for one delay, written to the LDS tile as
 // unit rows, norms kept in nrm[]; returns RSHIP_BAD_P if a row is not finite.  Rows >= N are not
 // touched: the kernel fills them with NaN once (their residuals compare above every threshold).
-template <int PATH, bool SWEEP, int CAP, bool NEWTON = false>
+// what a thread's hot-path rows leave behind instead of per-row checks: the largest |1 - |q|^2| (residual_row's NEWTON),
+// the smallest |P|^2 and the sum of the norms |P| -- a row below safe_normalize's 1e-12 or a quaternion off unit length
+// sends the wave through the careful form of the rows again, a non-finite sum is a non-finite P (inf and NaN both end
+// as NaN norms: rsqrt(inf) = 0, inf x 0)
+struct RowWatch {
+    float qerr = 0.f, n2min = 3.0e38f, nsum = 0.f;
+};
+
+template <int PATH, bool SWEEP, int CAP, bool FAST = false>
 __device__ __forceinline__ uint32_t lmeds_row(const Spline& sp, f4 A, f4 B, uint32_t N, uint32_t row, int base, float fd,
-                                              const Tile& tile, float& nrm, float* qerr = nullptr) {
+                                              const Tile& tile, float& nrm, RowWatch* watch = nullptr) {
     uint32_t bad = 0;
     nrm = 0.f;
     if (row < N) {
         f3 P, dP;
-        residual_row<false, PATH, SWEEP, CAP, NEWTON>(sp, A, B, base, fd, P, dP, qerr);
+        residual_row<false, PATH, SWEEP, CAP, FAST>(sp, A, B, base, fd, P, dP, FAST ? &watch->qerr : nullptr);
         const float n2 = rs::dot(P, P);
-        if (!finite_f(n2)) bad = RSHIP_BAD_P;
-        // safe_normalize (core_private.cpp:35-36): rows with |P| < 1e-12 stay as they are
-        const bool tiny = n2 < 1e-24f;
-        const float inv = tiny ? 1.f : rs::rsqrt_fast(n2);
-        tile.nx[row] = P.x * inv; tile.ny[row] = P.y * inv; tile.nz[row] = P.z * inv;
-        nrm = tiny ? 1.f : n2 * inv;
+        if (FAST) {
+            // (round 4: five instructions per row -- a class test and an OR for non-finite rows, a compare and two selects
+            // for safe_normalize's rule -- became a minimum and an addition; profiles/r4_k2_rowwatch_ab.txt)
+            const float inv = rs::rsqrt_fast(n2);
+            tile.nx[row] = P.x * inv; tile.ny[row] = P.y * inv; tile.nz[row] = P.z * inv;
+            nrm = n2 * inv;
+            watch->n2min = fminf(watch->n2min, n2);
+            watch->nsum += nrm;
+        } else {
+            if (!finite_f(n2)) bad = RSHIP_BAD_P;
+            // safe_normalize (core_private.cpp:35-36): rows with |P| < 1e-12 stay as they are
+            const bool tiny = n2 < 1e-24f;
+            const float inv = tiny ? 1.f : rs::rsqrt_fast(n2);
+            tile.nx[row] = P.x * inv; tile.ny[row] = P.y * inv; tile.nz[row] = P.z * inv;
+            nrm = tiny ? 1.f : n2 * inv;
+        }
     }
     return bad;
 }
@@ -268,13 +286,16 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
     uint32_t bad = 0;
     const uint32_t voff = threadIdx.x * 16u;
     if (sp.path == kPathInterior) {
-        float qerr = 0.f; // max |1 - |q|^2| over this thread's rows (NaN never raises it: such rows are flagged by their P)
+        RowWatch watch;
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const f4 A = load_ray(rays.a, voff, (uint32_t)j * kBlock * 16u), B = load_ray(rays.b, voff, (uint32_t)j * kBlock * 16u);
-            bad |= lmeds_row<kPathInterior, SWEEP, CAP, true>(sp, A, B, N, j * kBlock + threadIdx.x, base, fd, tile, nrm[j], &qerr);
+            (void)lmeds_row<kPathInterior, SWEEP, CAP, true>(sp, A, B, N, j * kBlock + threadIdx.x, base, fd, tile, nrm[j], &watch);
         }
-        if (__builtin_amdgcn_ballot_w64(qerr >= kNewtonMaxErr) != 0) { // never, for orientations: redo with the reciprocal
+        if (!finite_f(watch.nsum)) bad = RSHIP_BAD_P;
+        // never, for orientations and rays that move: redo the wave's rows with the reciprocal and safe_normalize's select
+        // (a non-finite row keeps its flag either way: the careful form tests it per row)
+        if (__builtin_amdgcn_ballot_w64(watch.qerr >= kNewtonMaxErr || watch.n2min < 1e-24f) != 0) {
             bad = 0;
             // (not unrolled: rare code kept small -- except for two rows per thread, where hipcc answered the run-time
             // index with a copy of nrm[] in scratch memory that the hot path then used as well)

@@ -84,8 +84,8 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
         float nx[RPT], ny[RPT], nz[RPT], nrm[RPT];
         // (the tile kernel's stage A, operation for operation -- including its reciprocal-free normalisation of the
         // interpolated quaternions and the fallback when they are not near unit length: common.hpp, NEWTON)
-        auto rows = [&](auto newton_tag, float* qerr) {
-            constexpr bool NEWTON = decltype(newton_tag)::value;
+        auto rows = [&](auto fast_tag, RowWatch* watch) {
+            constexpr bool FAST = decltype(fast_tag)::value; // (lmeds.hpp, lmeds_row: the hot form and the careful form)
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
                 const uint32_t row = j * 64 + lane;
@@ -95,25 +95,36 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
                 nrm[j] = 0.f;
                 if (row < N) {
                     f3 P, dP;
-                    if (sp.path == kPathInterior) residual_row<false, kPathInterior, MODE == 0, CAP, NEWTON>(sp, A, B, base, fd, P, dP, qerr);
+                    if (sp.path == kPathInterior) residual_row<false, kPathInterior, MODE == 0, CAP, FAST>(sp, A, B, base, fd, P, dP, FAST ? &watch->qerr : nullptr);
                     else residual_row<false, kPathGlobal, false, CAP>(sp, A, B, base, fd, P, dP);
                     const float n2 = rs::dot(P, P);
-                    if (!finite_f(n2)) bad = RSHIP_BAD_P;
-                    const bool tiny = n2 < 1e-24f; // safe_normalize (core_private.cpp:35-36)
-                    const float inv = tiny ? 1.f : rs::rsqrt_fast(n2);
-                    nx[j] = P.x * inv; ny[j] = P.y * inv; nz[j] = P.z * inv;
-                    nrm[j] = tiny ? 1.f : n2 * inv;
+                    if (FAST) {
+                        const float inv = rs::rsqrt_fast(n2);
+                        nx[j] = P.x * inv; ny[j] = P.y * inv; nz[j] = P.z * inv;
+                        nrm[j] = n2 * inv;
+                        watch->n2min = fminf(watch->n2min, n2);
+                        watch->nsum += nrm[j];
+                    } else {
+                        if (!finite_f(n2)) bad = RSHIP_BAD_P;
+                        const bool tiny = n2 < 1e-24f; // safe_normalize (core_private.cpp:35-36)
+                        const float inv = tiny ? 1.f : rs::rsqrt_fast(n2);
+                        nx[j] = P.x * inv; ny[j] = P.y * inv; nz[j] = P.z * inv;
+                        nrm[j] = tiny ? 1.f : n2 * inv;
+                    }
                 }
                 s_n[0][row] = nx[j]; s_n[1][row] = ny[j]; s_n[2][row] = nz[j];
             }
         };
-        {
-            float qerr = 0.f;
-            rows(std::true_type{}, &qerr);
-            if (__builtin_amdgcn_ballot_w64(qerr >= kNewtonMaxErr) != 0) {
+        if (sp.path == kPathInterior) {
+            RowWatch watch;
+            rows(std::true_type{}, &watch);
+            if (!finite_f(watch.nsum)) bad = RSHIP_BAD_P;
+            if (__builtin_amdgcn_ballot_w64(watch.qerr >= kNewtonMaxErr || watch.n2min < 1e-24f) != 0) {
                 bad = 0;
                 rows(std::false_type{}, nullptr);
             }
+        } else {
+            rows(std::false_type{}, nullptr);
         }
         __syncthreads(); // the wave's rows are in LDS
 

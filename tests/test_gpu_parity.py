@@ -927,3 +927,38 @@ def test_ranked_device_loop_with_two_ranks(tmp_path):
     for key in ("sync", "trace", "cw", "dw", "wtr", "one", "one_trace", "simplified"):
         assert res[0]["device"][key] == res[1]["device"][key], key               # both ranks took the same decisions
     assert len(res[1]["device"]["one_trace"]) >= 3                               # (rank 1 held none of that window's frames)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_rows_below_safe_normalizes_threshold_and_the_non_finite_r_panic(kernel, monkeypatch):
+    """Rows of P that are exactly zero (here: tracks whose two rays are the zero vector) are below the 1e-12 of
+    safe_normalize (core_private.cpp:35-36, inline_utils.hpp:5-11) and stay as they are; a hypothesis drawn from such a row
+    is the zero vector, with it M = 0, k = 100 / 0 -> clamp, r = P M k / |M| = NaN: the reference panics on r (:81), before
+    rho.  The kernels' hot path carries neither the per-row threshold test nor a per-row |r| check (a minimum of |P|^2 per
+    thread sends the wave through the careful form of the rows; a non-finite cost sum looks up which check fires first):
+    the same panic as the oracle, with every row zero and with three zero rows per frame among ordinary ones.
+    (Rays that merely coincide after the rotation do not make zero rows here: the fp32 cross product's fused
+    multiply-adds leave 1e-9 of rounding, which is normalised like any other row.)"""
+    import rssync_amd
+    from rssync_amd import synth
+    from oracle.oracle import OracleProblem, OracleError
+    F, N = 6, 200
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=8)
+    frames = list(synth.make_frames(g, 0, F, N, seed=8))
+    for zero_rows in (slice(None), [3, 77, 150]):
+        if kernel == "tile":
+            monkeypatch.setenv("RSSYNC_NO_SMALL_LMEDS", "1")
+        h = rssync_amd.SyncProblem(seed=SEED)
+        monkeypatch.delenv("RSSYNC_NO_SMALL_LMEDS", raising=False)
+        o = OracleProblem(seed=SEED, threads=4, faithful=False)
+        for p in (h, o):
+            p.SetGyroQuaternions(g.quats, g.fs, g.t0)
+            for fr, ta, tb, ra, rb in frames:
+                ra, rb = ra.copy(), rb.copy()
+                ra[zero_rows] = 0.0
+                rb[zero_rows] = 0.0
+                p.SetTrackResult(fr, ta, tb, ra, rb)
+        with pytest.raises(OracleError, match="pre-sync: non-finite r"):
+            o.PreSync(0.0, 0, F, 0.002, 0.02)
+        with pytest.raises(rssync_amd.RsSyncError, match="pre-sync: non-finite r"):
+            h.PreSync(0.0, 0, F, 0.002, 0.02)
