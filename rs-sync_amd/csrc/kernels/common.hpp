@@ -98,6 +98,16 @@ __device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)
 
 __device__ __forceinline__ bool finite_f(float x) { return (__float_as_uint(x) & kInfBits) != kInfBits; }
 
+// a * b where a zero factor wins over NaN and infinity (v_mul_legacy_f32, the DX9 rule; every other product is
+// v_mul_f32's, bit for bit: tools/ubench/mul_legacy.hip).  Stage D of the LMedS kernels multiplies a row's norm -- 0 for
+// the rows beyond the frame -- with a dot product that is NaN for exactly those rows (their tile entries are NaN so
+// that they never count below a threshold): one instruction instead of a product, a compare and a select.
+__device__ __forceinline__ float mul_zero_wins(float a, float b) {
+    float r;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 struct FrameRec { // == rship_frame
     uint32_t off, n;
     int32_t base_knot;

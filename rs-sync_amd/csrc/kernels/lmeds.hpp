@@ -287,6 +287,9 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
     const uint32_t voff = threadIdx.x * 16u;
     if (sp.path == kPathInterior) {
         RowWatch watch;
+        // (round 4, measured and dropped: the groups of 256 rows that lie inside the frame altogether -- all of them at 2048
+        // tracks -- without the per-lane `row < N`, by a scalar test on N; three instructions fewer per row, but the kernel
+        // sits at its 96 registers: the build spilled two values and ran 0.6 ms per launch SLOWER, profiles/r4_k2_allrows_ab.txt)
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const f4 A = load_ray(rays.a, voff, (uint32_t)j * kBlock * 16u), B = load_ray(rays.b, voff, (uint32_t)j * kBlock * 16u);
@@ -686,15 +689,14 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         }
 
         // ---- stage D: k = clamp(100 / |P M|), cost = sqrt(sum sqrt(log1p(r^2))) ----
-        // Branch-free over the rows: a row beyond N has nrm = 0 but a NaN tile entry, so its
-        // product is replaced by 0 with one select; zeros then contribute nothing below.
+        // Branch-free over the rows: a row beyond N has nrm = 0 but a NaN tile entry: the product in which a zero factor
+        // wins (mul_zero_wins) makes it 0, and zeros contribute nothing below.
         float pm[RPT];
         float ss = 0.f;
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const uint32_t row = j * kBlock + tid;
-            const float v = nrm[j] * rs::dot(f3{tile.nx[row], tile.ny[row], tile.nz[row]}, Mv);
-            pm[j] = row < N ? v : 0.f;
+            pm[j] = mul_zero_wins(nrm[j], rs::dot(f3{tile.nx[row], tile.ny[row], tile.nz[row]}, Mv));
             ss = fmaf(pm[j], pm[j], ss);
         }
         double ss_tot;

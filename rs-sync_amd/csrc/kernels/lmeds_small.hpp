@@ -194,9 +194,7 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
         float ss = 0.f;
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            const uint32_t row = q * 64 + lane;
-            const float v = nrm[q] * rs::dot(f3{nx[q], ny[q], nz[q]}, Mv);
-            pm[q] = row < N ? v : 0.f;
+            pm[q] = mul_zero_wins(nrm[q], rs::dot(f3{nx[q], ny[q], nz[q]}, Mv)); // (rows beyond N: norm 0, NaN entries)
             ss = fmaf(pm[q], pm[q], ss);
         }
         const double ss_tot = (double)wave_sum_f32(ss);
