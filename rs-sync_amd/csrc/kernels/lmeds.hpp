@@ -248,7 +248,10 @@ __device__ __forceinline__ f4 load_ray(__amdgpu_buffer_rsrc_t rs_, uint32_t voff
 // sends the wave through the careful form of the rows again, a non-finite sum is a non-finite P (inf and NaN both end
 // as NaN norms: rsqrt(inf) = 0, inf x 0)
 struct RowWatch {
-    float qerr = 0.f, n2min = 3.0e38f, nsum = 0.f;
+    float qerr = 0.f, nsum = 0.f;
+    uint32_t n2min = 0x7f000000u; // bit pattern of the smallest |P|^2: non-negative floats order like their patterns, a NaN's
+                                  // lies above them all (and an integer minimum needs no canonicalising v_max before it)
+    __device__ __forceinline__ bool below_safe_normalize() const { return n2min < __float_as_uint(1e-24f); }
 };
 
 template <int PATH, bool SWEEP, int CAP, bool FAST = false>
@@ -266,7 +269,7 @@ __device__ __forceinline__ uint32_t lmeds_row(const Spline& sp, f4 A, f4 B, uint
             const float inv = rs::rsqrt_fast(n2);
             tile.nx[row] = P.x * inv; tile.ny[row] = P.y * inv; tile.nz[row] = P.z * inv;
             nrm = n2 * inv;
-            watch->n2min = fminf(watch->n2min, n2);
+            watch->n2min = min(watch->n2min, __float_as_uint(n2));
             watch->nsum += nrm;
         } else {
             if (!finite_f(n2)) bad = RSHIP_BAD_P;
@@ -298,7 +301,7 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
         if (!finite_f(watch.nsum)) bad = RSHIP_BAD_P;
         // never, for orientations and rays that move: redo the wave's rows with the reciprocal and safe_normalize's select
         // (a non-finite row keeps its flag either way: the careful form tests it per row)
-        if (__builtin_amdgcn_ballot_w64(watch.qerr >= kNewtonMaxErr || watch.n2min < 1e-24f) != 0) {
+        if (__builtin_amdgcn_ballot_w64(watch.qerr >= kNewtonMaxErr || watch.below_safe_normalize()) != 0) {
             bad = 0;
             // (not unrolled: rare code kept small -- except for two rows per thread, where hipcc answered the run-time
             // index with a copy of nrm[] in scratch memory that the hot path then used as well)

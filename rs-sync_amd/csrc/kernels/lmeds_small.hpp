@@ -102,7 +102,7 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
                         const float inv = rs::rsqrt_fast(n2);
                         nx[j] = P.x * inv; ny[j] = P.y * inv; nz[j] = P.z * inv;
                         nrm[j] = n2 * inv;
-                        watch->n2min = fminf(watch->n2min, n2);
+                        watch->n2min = min(watch->n2min, __float_as_uint(n2));
                         watch->nsum += nrm[j];
                     } else {
                         if (!finite_f(n2)) bad = RSHIP_BAD_P;
@@ -119,7 +119,7 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
             RowWatch watch;
             rows(std::true_type{}, &watch);
             if (!finite_f(watch.nsum)) bad = RSHIP_BAD_P;
-            if (__builtin_amdgcn_ballot_w64(watch.qerr >= kNewtonMaxErr || watch.n2min < 1e-24f) != 0) {
+            if (__builtin_amdgcn_ballot_w64(watch.qerr >= kNewtonMaxErr || watch.below_safe_normalize()) != 0) {
                 bad = 0;
                 rows(std::false_type{}, nullptr);
             }
