@@ -272,8 +272,8 @@ static_assert(rs::kPlanWinStatic == (uint32_t)kWinMax, "window_plan.hpp and kern
 // waves per CU, 144 seven, 192 five, 272 four.  Beyond kPlanCap64SmallMax knots the general path (260 x 128 bytes from
 // L2, eight waves) is cheaper again.  Measured on 98 sync points of 61 x 130, two ends of a pair staged separately,
 // outer iterations capped at 25 per call so that rates compare (profiles/r4_gyro_rate_small_frames.json, a build that
-// allows 384 knots): 4 kHz 16.9 ms with 96 knots against 20.7 on the general path; 6 kHz 19.8 (144 knots) against 20.9;
-// 8 kHz 25.5 (192) against 21.3; 12 kHz 33.4 (272) against 22.0.
+// allows 384 knots): 4 kHz 17.4 ms with 96 knots against 20.4 on the general path; 6 kHz 20.0 (144 knots) against 20.8;
+// 8 kHz 25.4 (192) against 21.4; 12 kHz 33.6 (272) against 21.7.
 uint32_t cap64_of(const rship_ctx* c) {
     const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
     return rs::cap64_used(c->cap64, n_all <= c->one_wave_max && !c->force_big);
