@@ -122,10 +122,11 @@ int rssync_ext_rccl_unique_id(rssync_problem* p, void* id128);
 int rssync_ext_rccl_init(rssync_problem* p, const void* id128, int rank, int world_size);
 /* leave that communicator (collective: every rank calls it); the problem is a single rank again */
 int rssync_ext_rccl_shutdown(rssync_problem* p);
-/* Ranks must pick the same kernel shapes, which follow the largest per-frame track count of the WHOLE problem
- * (a frame's sums must not depend on which rank holds it).  Give that count here (0 = not given, the default)
- * or let the ranks agree on it themselves: then every collective call (PreSync, Sync, ...) starts with one
- * extra exchange of ~150 doubles. */
+/* A NO-OP since round 5, kept so that callers written against rounds 2-4 still link.  (Then the kernel shapes followed
+ * the largest per-frame track count of the whole problem and ranks had to agree on it.  Now a frame's kernels -- and the
+ * order of its sums -- follow the frame's OWN track count, as the reference evaluates every frame on its own,
+ * core_private.cpp:73-86, :231-238, :263-295: a frame's result is the same on any rank, in any window, without an
+ * exchange.) */
 int rssync_ext_set_tracks_hint(rssync_problem* p, uint32_t max_tracks_all_ranks);
 /* exchanges with other ranks so far (reduce hook or native RCCL): calls and doubles summed */
 int rssync_ext_exchange_stats(rssync_problem* p, uint64_t* calls, uint64_t* doubles);

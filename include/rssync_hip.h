@@ -82,9 +82,11 @@ int rship_max_tracks(void); /* largest per-frame track count accepted: 2^24, an 
  * best step is not its last -- 0 (default): iterate at the best step, value and gradient as the last
  * trial left them (the published LineSearch); 1: evaluate once more at the best step. */
 #define RSHIP_OPT_LBFGS_REEVAL 1
-/* RSHIP_OPT_TRACKS_HINT: the largest per-frame track count of the WHOLE problem (all devices).  Kernels whose
- * workgroup shape fixes the order of a frame's sums pick the shape from it, so that a frame gets the same sums
- * on any device and in any selection. */
+/* RSHIP_OPT_TRACKS_HINT: accepted and ignored since round 5.  (Rounds 2-4: the largest per-frame track count of the
+ * whole problem, from which the kernels whose workgroup shape fixes the order of a frame's sums picked the shape.  The
+ * shape now follows each frame's OWN track count -- size classes, rssync_kernels.hip -- as the reference evaluates each
+ * frame on its own, core_private.cpp:73-86, :231-238, :263-295: a frame's sums are the same on any device, in any
+ * selection and on any rank without anybody agreeing on anything.) */
 #define RSHIP_OPT_TRACKS_HINT 2
 int rship_set_option(rship_ctx* c, int option, int value);
 
@@ -158,6 +160,11 @@ typedef struct rship_pack_frame {
  * reference checks the rays it is handed, core_private.cpp:199-200). */
 int rship_pack_frames(rship_ctx* c, const rship_frame* table, const rship_pack_frame* pack, uint32_t n_frames,
                       uint64_t total_rays, double start, double fs, uint32_t* bad);
+
+/* One object over several devices (optional): the frame-table records of ALL frames of the problem (only n_rays, tmin,
+ * tmax, range_a, range_b are read), so that every shard plans its LDS spline windows from the same frames as a single
+ * device holding everything would.  Call after rship_pack_frames (which forgets an earlier list). */
+int rship_set_problem_frames(rship_ctx* c, const rship_frame* table_all, uint32_t n_all);
 
 /* the frames a PreSync/Sync call works on (indices into the table; replaces the
  * frame filters at core_private.cpp:65-68, :218-219, :340-343) */

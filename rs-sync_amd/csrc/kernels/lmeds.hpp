@@ -43,6 +43,11 @@ struct LmedsParams {
     const FrameRec* frames;
     const uint32_t* sel;
     uint32_t n_sel;
+    // The slots THIS launch works on: entry i of the launch is slot slots[i] (null: i itself), i < n_slots.  A launch covers
+    // the slots of one SIZE CLASS of the selection (rssync_kernels.hip: a frame's kernel family follows its own track
+    // count, whatever else the problem holds); results are indexed by slot (stride n_sel) as before.
+    const uint32_t* slots;
+    uint32_t n_slots;
     const f4* coef;
     int n_knots;
     const int32_t* kd;
@@ -434,9 +439,10 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
     // frame on one XCD so its rays are fetched into one L2 only
     const uint32_t per = 8u * p.n_chunks;
     const uint32_t grp = blockIdx.x / per, within = blockIdx.x % per;
-    const uint32_t sf = grp * 8u + (within & 7u);
+    const uint32_t entry = grp * 8u + (within & 7u);
     const uint32_t chunk = within >> 3;
-    if (sf >= p.n_sel) return;
+    if (entry >= p.n_slots) return;
+    const uint32_t sf = p.slots ? p.slots[entry] : entry;
     const uint32_t fi = p.sel[sf];
     const FrameRec fr = p.frames[fi];
     const uint32_t N = fr.n;

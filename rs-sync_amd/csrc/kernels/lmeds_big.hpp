@@ -47,9 +47,10 @@ __global__ __launch_bounds__(kBlock) void lmeds_big_kernel(LmedsParams p) {
     sp.w0 = sp.wlen = 0;
     sp.path = kPathGlobal; // any parameter, table from L2
 
-    const uint32_t total = p.n_sel * p.n_chunks;
+    const uint32_t total = p.n_slots * p.n_chunks;
     for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
-        const uint32_t sf = item / p.n_chunks, chunk = item % p.n_chunks;
+        const uint32_t entry = item / p.n_chunks, chunk = item % p.n_chunks;
+        const uint32_t sf = p.slots ? p.slots[entry] : entry;
         const uint32_t fi = p.sel[sf];
         const FrameRec fr = p.frames[fi];
         const uint32_t N = fr.n;

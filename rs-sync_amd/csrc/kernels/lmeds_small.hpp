@@ -11,8 +11,8 @@
 // in scalar registers, and nothing waits for another wave.  Arithmetic per row and per hypothesis is the tile
 // kernel's, operation for operation (same P rows, same directions, same residual fma chain, same exact
 // selection); only the order in which a frame's cost terms are added differs (one wave sum instead of four).
-// Which of the two kernels a frame gets is fixed per PROBLEM (largest frame of all devices), like the motion
-// kernel's shape, so that a frame's cost does not depend on the selection it is part of.
+// Which of the two kernels a frame gets follows from the FRAME's own track count (up to 512: this one), like the motion
+// kernel's shape, so that a frame's cost does not depend on the selection, the device or the rank it is evaluated in.
 #pragma once
 
 namespace {
@@ -233,7 +233,8 @@ __global__ __launch_bounds__(64, RPT <= 3 ? 6 : (RPT == 4 ? 5 : 3)) void lmeds_s
         extern __shared__ f4 s_small_win_dynamic[];
         dyn = s_small_win_dynamic;
     }
-    lmeds_small_body<RPT, MODE, false, CAP>(p, blockIdx.x / p.n_chunks, blockIdx.x % p.n_chunks, lds, dyn);
+    const uint32_t entry = blockIdx.x / p.n_chunks; // (the launch has n_slots x n_chunks workgroups)
+    lmeds_small_body<RPT, MODE, false, CAP>(p, p.slots ? p.slots[entry] : entry, blockIdx.x % p.n_chunks, lds, dyn);
 }
 
 } // namespace

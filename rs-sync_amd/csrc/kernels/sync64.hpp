@@ -172,7 +172,8 @@ struct Loss64Params {
     const double* k;
     double* part_loss; // [n_delays][n_sel]
     double* part_grad; // [n_delays][n_sel] (GRAD)
-    uint32_t slot0;    // the launch covers slots slot0 .. slot0 + gridDim.x (a group of windows on its own stream)
+    uint32_t slot0;    // the launch covers slots slot0 .. slot0 + gridDim.x (a group of windows on its own stream) ...
+    const uint32_t* slots; // ... or, if not null, the slots slots[0 .. gridDim.x): the frames of one size class (rssync_kernels.hip)
     uint32_t win_cap;  // knots per spline window (dynamic LDS: nb_run x win_cap x 128 bytes; one window in the one-wave kernel)
     uint32_t nb_run;   // delays evaluated per pass over the rows: kLossBatch while their windows fit the LDS, fewer for wide frames
 };
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
     __shared__ double s_red[NB][2][4];
     const uint32_t nb_run = (GRAD || CAP) ? (uint32_t)NB : (p.nb_run < (uint32_t)NB ? (p.nb_run ? p.nb_run : 1u) : (uint32_t)NB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t sf = blockIdx.x + p.slot0;
+    const uint32_t sf = p.slots ? p.slots[blockIdx.x] : blockIdx.x + p.slot0;
     const uint32_t g = p.grp ? p.grp[sf] : 0u;
     {
         // nothing to evaluate for this slot's window (a finished window, a line search that has already
@@ -356,7 +357,7 @@ template <bool GRAD, bool SIMPLE>
 __global__ __launch_bounds__(64, 3) void loss64_small_kernel(Loss64Params p) {
     extern __shared__ d4 s_win[]; // [4 * win_cap]
     const int lane = threadIdx.x;
-    const uint32_t sf = blockIdx.x + p.slot0;
+    const uint32_t sf = p.slots ? p.slots[blockIdx.x] : blockIdx.x + p.slot0;
     const uint32_t g = p.grp ? p.grp[sf] : 0u;
     const d3 Mv = SIMPLE ? d3{0.0, 0.0, 0.0} : d3{p.M[3 * sf], p.M[3 * sf + 1], p.M[3 * sf + 2]};
     const double kk = p.k[sf];
@@ -409,18 +410,21 @@ struct Motion64Params {
     uint32_t stream_base, stream_stride; // sampler stream = base + group * stride
     const uint32_t* win_stream;          // or, if not null (window executor): win_stream[group]
     int simple_k; // 1: k = clamp(100 / sqrt(sum |P_j|^2)) only (no-translation variant), no M, no optimisation
-    uint32_t slot0; // the launch covers slots slot0 .. slot0 + gridDim.x
+    uint32_t slot0; // the launch covers slots slot0 .. slot0 + gridDim.x, or (order != null) the entries order[slot0 + b]
     // Longest first: workgroup b of the launch takes slot order[slot0 + b] (null: slot0 + b), a permutation of the
-    // launch's slots sorted by how many evaluations each needed in the previous launch (motion_order_kernel); a
+    // launch's slots -- the slots of one size class inside one stream group's range -- sorted by how many evaluations each needed in the previous launch (motion_order_kernel); a
     // launch is as long as its slowest frame plus whatever is queued behind it, and the frames that need 60
     // evaluations instead of 20 are the same ones from one outer iteration to the next.  Which workgroup computes a
     // slot changes nothing in the slot's result.
     const uint32_t* order;
     uint32_t* evals_out; // [n_sel]: evaluations of this launch per slot (input of the next ordering), or null
     // frames of more than 8192 tracks (RPT = 0): the rows of P per workgroup in global memory instead of registers,
-    // n_sel x 3 x scratch_rows doubles (per slot: x, y, z planes; scratch_rows a multiple of the workgroup size)
+    // 3 x scratch_rows doubles (x, y, z planes; scratch_rows a multiple of the workgroup size) per ENTRY of the class's
+    // slot list -- workgroup b of the launch uses entry scratch0 + b (launches of several stream groups run side by
+    // side on disjoint ranges of the list)
     double* scratch;
     uint32_t scratch_rows;
+    uint32_t scratch0;
     uint32_t win_cap; // knots of the spline window (dynamic LDS: win_cap x 128 bytes)
 };
 
@@ -542,7 +546,8 @@ struct MotionLds {
 };
 
 template <int RPT, int NW, bool SC1 = false> // SC1: M, k, the pending winners and the delays are written by other workgroups of this launch
-__device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint32_t sf, MotionLds<NW>& lds, d4* s_win, double* mk_out = nullptr) {
+__device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint32_t sf, MotionLds<NW>& lds, d4* s_win, double* mk_out = nullptr,
+                                                  uint32_t scratch_entry = 0) {
     constexpr int kThreads = 64 * NW;
     double (*s_part)[NW][4] = lds.part;
     double (*s_S)[3] = lds.S;
@@ -593,7 +598,7 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
             ev.P[j] = P; // zero rows contribute log1p(0) = 0 and no gradient
         }
     } else { // the same rows, kept in this workgroup's scratch (only this thread reads what it writes)
-        double* gp = p.scratch + (size_t)sf * 3 * p.scratch_rows; // per SLOT: launches of several stream groups run side by side
+        double* gp = p.scratch + (size_t)scratch_entry * 3 * p.scratch_rows;
         ev.gP = gp;
         ev.g_rows = p.scratch_rows;
         ev.rpt = (int)((N + kThreads - 1) / kThreads);
@@ -682,19 +687,20 @@ template <int RPT, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? (RPT == 0 ? 2 : (RPT <= 8 ? 3 : (RPT == 16 ? 2 : 1))) : (NW == 1 ? (RPT >= 8 ? 3 : 4) : 2)) void opt_motion64_kernel(Motion64Params p) {
     __shared__ MotionLds<NW> lds;
     extern __shared__ d4 s_motion_win[]; // [4 * win_cap]
-    opt_motion64_body<RPT, NW>(p, p.order ? p.order[blockIdx.x + p.slot0] : blockIdx.x + p.slot0, lds, s_motion_win);
+    opt_motion64_body<RPT, NW>(p, p.order ? p.order[blockIdx.x + p.slot0] : blockIdx.x + p.slot0, lds, s_motion_win, nullptr,
+                               p.scratch0 + blockIdx.x);
 }
 
-// order[slot0 .. slot0 + count) = the slots slot0 .. slot0 + count sorted by evals[] descending (a counting sort over
-// min(evals, 255) in one workgroup; the order among equal counts is whatever the atomics give -- it only decides
-// which workgroup computes which slot)
-__global__ __launch_bounds__(1024) void motion_order_kernel(const uint32_t* __restrict__ evals, uint32_t* __restrict__ order,
-                                                            uint32_t slot0, uint32_t count) {
+// order[pos0 .. pos0 + count) = the slots list[pos0 .. pos0 + count) (the slots of one size class inside one stream
+// group's range, ascending) sorted by evals[slot] descending (a counting sort over min(evals, 255) in one workgroup; the
+// order among equal counts is whatever the atomics give -- it only decides which workgroup computes which slot)
+__global__ __launch_bounds__(1024) void motion_order_kernel(const uint32_t* __restrict__ evals, const uint32_t* __restrict__ list,
+                                                            uint32_t* __restrict__ order, uint32_t pos0, uint32_t count) {
     __shared__ uint32_t s_bin[256];
     for (uint32_t b = threadIdx.x; b < 256; b += blockDim.x) s_bin[b] = 0;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
-        const uint32_t e = evals[slot0 + i];
+        const uint32_t e = evals[list[pos0 + i]];
         atomicAdd(&s_bin[e < 255u ? e : 255u], 1u);
     }
     __syncthreads();
@@ -708,9 +714,10 @@ __global__ __launch_bounds__(1024) void motion_order_kernel(const uint32_t* __re
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
-        const uint32_t e = evals[slot0 + i];
+        const uint32_t s = list[pos0 + i];
+        const uint32_t e = evals[s];
         const uint32_t pos = atomicAdd(&s_bin[e < 255u ? e : 255u], 1u);
-        order[slot0 + pos] = slot0 + i;
+        order[pos0 + pos] = s;
     }
 }
 

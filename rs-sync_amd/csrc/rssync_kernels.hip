@@ -77,6 +77,8 @@ struct TempBuf : DevBuf {
     }
 };
 
+constexpr int kNumClasses = 6; // size classes of frames (rship_ctx::cls_slots)
+
 struct rship_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -114,7 +116,22 @@ struct rship_ctx {
     uint64_t total_rays = 0;
     double fs = 0;
     int lbfgs_reeval = 0; // RSHIP_OPT_LBFGS_REEVAL
-    uint32_t tracks_hint = 0; // RSHIP_OPT_TRACKS_HINT
+    // SIZE CLASSES (round 5).  Which kernel family a frame runs in -- and with it the association of its sums -- follows
+    // from the frame's OWN track count: class 0 = up to one_wave_max tracks (the one-wave kernels), 1 .. 4 = the four-wave
+    // kernels with 4 / 8 / 16 / 32 rows per thread (up to 1024 / 2048 / 4096 / 8192 tracks), 5 = more than 8192 (rows in
+    // global memory).  A selection is cut into one slot list per class (cls_slots, ascending slots inside a class) and
+    // every launch covers one class; the plan of the sums indexes by slot and does not notice.  The reference evaluates
+    // each frame in its own lambda (core_private.cpp:73-86, :231-238, :263-295): a frame's result must not depend on what
+    // else the problem, the window, the device or the rank holds.
+    DevBuf cls_slots;                    // [n_sel] slots sorted by (class, slot)
+    std::vector<uint32_t> h_cls_slots;
+    uint32_t cls_off[kNumClasses + 1] = {};   // class k = h_cls_slots[cls_off[k] .. cls_off[k + 1])
+    uint32_t cls_max_n[kNumClasses] = {};     // largest frame of the class IN THE SELECTION (rows per lane of the one-wave kernels, scratch rows)
+    int cls_used = 0;                         // classes with slots
+    // what the spline windows are planned from: the frames of this context's table, or -- rship_set_problem_frames: one
+    // object over several devices -- of the whole problem, so that every shard plans like the single-device run
+    std::vector<rs::FrameDims> own_dims, problem_dims;
+    uint32_t cls_cap64[kNumClasses] = {80, 80, 80, 80, 80, 80}; // knots of the fp64 window per class (window_plan.hpp: cap64_frames)
     bool force_general = false;   // RSSYNC_FORCE_GENERAL_SPLINE=1 (read at creation; tools/gpu_gyro_rate.py's "before" column): no dynamic
                                   // spline windows -- frames wider than 80 knots take the general path (table from L2), as in rounds 1-3
     uint32_t one_wave_max = 512;  // frames of up to this many tracks run the one-wave kernels (K2s, loss64_small, the executor); RSSYNC_ONE_WAVE_MAX (tests, A/B)
@@ -125,10 +142,6 @@ struct rship_ctx {
     bool no_small_lmeds = false; // RSSYNC_NO_SMALL_LMEDS=1 (read once, at creation): the tile kernel for every frame size (A/B tests)
     float max_span = 0.f; // widest frame, in knots (frame table)
     float max_ends = 0.f; // the same counting only the two ends' ranges of each pair (rship_frame::range_a / range_b)
-    // knots the fp64 kernels' spline window holds (dynamic LDS, 128 bytes per knot): the widest frame of the table,
-    // at least kWinMax, at most kCap64Max (beyond that the kernels read the table from L2, as any frame that does not
-    // fit its window does)
-    uint32_t cap64 = 80;
     int lds_per_cu = 160 * 1024;
     uint32_t last_lmeds_cap = 0, last_lmeds_chunk = 0, last_init_cap = 0; // rship_window_info: what the last launches used
     // native exchange (RCCL through dlopen)
@@ -136,7 +149,7 @@ struct rship_ctx {
     std::string rccl_path; // which librccl the symbols come from
     void* rccl_comm = nullptr;
     DevBuf rccl_buf;
-    DevBuf big_scratch, mo_scratch; // frames of more than 8192 tracks: the LMedS tiles / the motion kernel's rows
+    DevBuf big_scratch, mo_scratch; // frames of more than 8192 tracks: the LMedS tiles / the motion kernel's rows (per entry of class 5's slot list)
     rship_loop_exchange_fn loop_xchg = nullptr; // host exchange for the device-driven loop (rship_set_loop_exchange)
     void* loop_xchg_user = nullptr;
     uint64_t loop_exchanges = 0; // all-reduces the last rship_sync_run enqueued on the stream (rank mode)
@@ -247,36 +260,115 @@ int sync_stream(rship_ctx* c) {
 
 constexpr int kMaxRpt = 32; // 8192 tracks per frame in registers / LDS; larger frames take the kernels' slow paths
 
-// rows per thread of a 256-thread workgroup that cover max_n tracks (a power of two); 0 = more than kMaxRpt: the
-// kernels' runtime-length variants (loss64_kernel<0>, opt_motion64_kernel<0, 4>, lmeds_big_kernel)
+// ---- size classes ---------------------------------------------------------------------------------------------
+// class of a frame of n tracks (rship_ctx::cls_slots): 0 one wave per frame, 1 .. 4 four waves with 4 / 8 / 16 / 32 rows
+// per thread, 5 rows in global memory.  A thread adds its rows in order and rows beyond the frame add exact zeros, so a
+// frame's sums do not depend on the rows-per-thread instantiation INSIDE a family (one wave / four waves): the classes
+// 1 .. 4 differ in speed only (registers, workgroups per CU), 0 and 5 in the association (0) and the fp32 spline path (5).
+int class_of(const rship_ctx* c, uint32_t n) {
+    if (c->force_big) return 5;
+    if (n <= c->one_wave_max) return 0;
+    if (n <= 4u * kBlock) return 1;
+    if (n <= 8u * kBlock) return 2;
+    if (n <= 16u * kBlock) return 3;
+    if (n <= (uint32_t)kMaxRpt * kBlock) return 4;
+    return 5;
+}
+// track counts of class k (both ends inclusive)
+void class_bounds(const rship_ctx* c, int k, uint32_t* lo, uint32_t* hi) {
+    if (c->force_big) { *lo = k == 5 ? 0u : 1u; *hi = k == 5 ? 0xffffffffu : 0u; return; }
+    const uint32_t top[6] = {c->one_wave_max, 4u * kBlock, 8u * kBlock, 16u * kBlock, (uint32_t)kMaxRpt * kBlock, 0xffffffffu};
+    *hi = top[k];
+    *lo = k == 0 ? 0u : top[k - 1] + 1u;
+}
+// rows per thread of the four-wave kernels of class k (0 = as many as the frame needs: class 5)
+int class_rpt(int k) { return k == 5 ? 0 : (4 << (k - 1)); }
+// rows per lane of the one-wave kernels: 1 .. 4 up to 256 tracks, 8 for 257 .. 512 (rows beyond the frame contribute
+// exact zeros, so one instantiation serves them all with the same bits)
+int small_rpt(uint32_t n_all) { const uint32_t r = std::max(1u, (n_all + 63u) / 64u); return r <= 4u ? (int)r : 8; }
+// rows per thread of a 256-thread workgroup that cover max_n tracks (a power of two, at least four): the four-wave
+// kernels on frames of class 0 (RSSYNC_NO_SMALL_LMEDS / _LOSS: the tests' cross-checks of the two families)
 int rpt_for(uint32_t max_n) {
     if (max_n > (uint32_t)kMaxRpt * kBlock) return 0;
-    // (at least four: frames of up to 512 tracks run in the one-wave kernels, and where a switch sends them here all the
-    // same -- RSSYNC_NO_SMALL_LMEDS / _LOSS, RSSYNC_ONE_WAVE_MAX, the tests' cross-checks of the two families -- the
-    // 1024-row instantiation gives the bits a 256- or 512-row one would: a thread adds its rows in order, rows beyond
-    // the frame add nothing.  Rounds 1-4 carried 20 kernels for those two sizes that no unswitched run could reach.)
     int rpt = 4;
     while ((uint32_t)rpt * kBlock < max_n) rpt *= 2;
     return rpt;
 }
-uint32_t big_rows(const rship_ctx* c) { return (c->max_n + kBlock - 1) / kBlock * kBlock; }
-int rpt_of(const rship_ctx* c) { return c->force_big ? 0 : rpt_for(c->max_n); }
+uint32_t big_rows(uint32_t max_n) { return (max_n + kBlock - 1) / kBlock * kBlock; }
+
+// the frames the windows are planned from (rship_ctx::own_dims / problem_dims)
+const std::vector<rs::FrameDims>& plan_dims(const rship_ctx* c) { return c->problem_dims.empty() ? c->own_dims : c->problem_dims; }
+void update_class_caps(rship_ctx* c) {
+    const std::vector<rs::FrameDims>& d = plan_dims(c);
+    for (int k = 0; k < kNumClasses; ++k) {
+        uint32_t lo, hi;
+        class_bounds(c, k, &lo, &hi);
+        c->cls_cap64[k] = c->force_general ? (uint32_t)rs::kPlanWinStatic : rs::cap64_frames(d.data(), d.size(), lo, hi, k == 0);
+    }
+}
+
+// One launch's share of the selection: the entries [pos0, pos0 + count) of the class-sorted slot list -- all of class k.
+// list == nullptr: the selection is ONE class and the list is the identity (entry = slot): kernels then take
+// slot0 + blockIdx.x, exactly as before there were classes (the benchmark's launches are unchanged).
+struct ClassRange {
+    int k;
+    uint32_t pos0, count;
+    const uint32_t* list; // device: c->cls_slots + pos0, or null
+};
+// the classes' shares of the slots [slot0, slot0 + count) (count = 0: the whole selection)
+std::vector<ClassRange> class_ranges(const rship_ctx* c, uint32_t slot0 = 0, uint32_t count = 0) {
+    std::vector<ClassRange> out;
+    if (!count) { slot0 = 0; count = c->n_sel; }
+    const uint32_t* L = c->h_cls_slots.data();
+    for (int k = 0; k < kNumClasses; ++k) {
+        const uint32_t* a = L + c->cls_off[k];
+        const uint32_t* b = L + c->cls_off[k + 1];
+        if (a == b) continue;
+        const uint32_t* lo = std::lower_bound(a, b, slot0);
+        const uint32_t* hi = std::lower_bound(a, b, slot0 + count);
+        if (lo == hi) continue;
+        const uint32_t pos0 = (uint32_t)(lo - L);
+        out.push_back(ClassRange{k, pos0, (uint32_t)(hi - lo), c->cls_used > 1 ? (const uint32_t*)c->cls_slots.p + pos0 : nullptr});
+    }
+    return out;
+}
+// the class most slots of the selection belong to (what rship_window_info reports, what a one-class problem has)
+int main_class(const rship_ctx* c) {
+    int best = 0;
+    uint32_t most = 0;
+    for (int k = 0; k < kNumClasses; ++k) {
+        const uint32_t n = c->cls_off[k + 1] - c->cls_off[k];
+        if (n > most) { most = n; best = k; }
+    }
+    if (!most) { // no selection yet: the class of the table's largest frame
+        uint32_t mx = 0;
+        for (const rs::FrameDims& d : c->own_dims) mx = std::max(mx, d.n);
+        best = class_of(c, mx);
+    }
+    return best;
+}
 
 // ---- spline windows in dynamic LDS (gyro rates above ~1.7 kHz: a frame spans 0.044 s x rate knots) ----
 constexpr uint32_t kLossWinBytes = kLossBatch * kWinMax * 128u; // K1's LDS budget for its side-by-side windows (51 KB at 80 knots)
 using rs::WinPlan;
 static_assert(rs::kPlanWinStatic == (uint32_t)kWinMax, "window_plan.hpp and kernels/common.hpp disagree on the compiled-in window");
-// The fp64 window the launches use (window_plan.hpp: cap64_for, cap64_used).  Problems of small frames (up to 512
-// tracks: one WAVE per frame in K1 / K3 / the executor) stage a window PER EVALUATION for a frame's 260 coefficient
-// fetches, and every knot of it is LDS that another wave of the CU cannot have: 96 knots leave the executor its eight
-// waves per CU, 144 seven, 192 five, 272 four.  Beyond kPlanCap64SmallMax knots the general path (260 x 128 bytes from
-// L2, eight waves) is cheaper again.  Measured on 98 sync points of 61 x 130, two ends of a pair staged separately,
-// outer iterations capped at 25 per call so that rates compare (profiles/r4_gyro_rate_small_frames.json, a build that
-// allows 384 knots): 4 kHz 17.4 ms with 96 knots against 20.4 on the general path; 6 kHz 20.0 (144 knots) against 20.8;
-// 8 kHz 25.4 (192) against 21.4; 12 kHz 33.6 (272) against 21.7.
-uint32_t cap64_of(const rship_ctx* c) {
-    const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
-    return rs::cap64_used(c->cap64, n_all <= c->one_wave_max && !c->force_big);
+// The fp64 window a class's launches use (window_plan.hpp: cap64_frames).  The one-wave kernels (class 0: K1 / K3 in their
+// one-wave shapes, the executor) stage a window PER EVALUATION for a frame's 260 coefficient fetches, and every knot of
+// it is LDS that another wave of the CU cannot have: 96 knots leave the executor its eight waves per CU, 144 seven, 192
+// five, 272 four.  Beyond kPlanCap64SmallMax knots the general path (260 x 128 bytes from L2, eight waves) is cheaper
+// again.  Measured on 98 sync points of 61 x 130, two ends of a pair staged separately, outer iterations capped at 25 per
+// call so that rates compare (profiles/r4_gyro_rate_small_frames.json, a build that allows 384 knots): 4 kHz 17.4 ms with
+// 96 knots against 20.4 on the general path; 6 kHz 20.0 (144 knots) against 20.8; 8 kHz 25.4 (192) against 21.4; 12 kHz
+// 33.6 (272) against 21.7.
+uint32_t cap64_of(const rship_ctx* c, int k) { return c->cls_cap64[k]; }
+// widest whole pair of class k among the frames the windows are planned from
+float class_span(const rship_ctx* c, int k) {
+    uint32_t lo, hi;
+    class_bounds(c, k, &lo, &hi);
+    float m = 0.f;
+    for (const rs::FrameDims& d : plan_dims(c))
+        if (d.n && d.n >= lo && d.n <= hi) m = std::max(m, d.span);
+    return m;
 }
 template <class K>
 uint32_t static_lds_of(K kernel) {
@@ -292,19 +384,13 @@ void allow_dynamic_lds(K kernel, size_t bytes) { // (more than 64 KB in all need
     }
 }
 
-uint32_t sel_max_n(const rship_ctx* c) {
-    uint32_t m = 0;
-    for (uint32_t i : c->h_sel) m = c->h_frame_n[i] > m ? c->h_frame_n[i] : m;
-    return m;
-}
-
 // ---- the LMedS kernels' spline window (fp32, 64 bytes per knot) ----
-// A workgroup's window must hold the widest frame plus the knots its chunk of candidate delays spans.  Up to ~1.7 kHz
+// A workgroup's window must hold its frame plus the knots its chunk of candidate delays spans.  Up to ~1.7 kHz
 // of gyro rate that fits the kWinMax knots compiled into the kernels' LDS (the instantiations the benchmark runs).
-// Beyond, the window moves to DYNAMIC LDS (WIN = 0 instantiations), as large as the problem needs: the plan below picks
-// the largest number of workgroups per CU whose LDS share still holds the frame and a chunk of at least eight
-// candidates, then the longest chunk (<= 32) that fits.  Only when even one workgroup per CU cannot hold it do the
-// kernels fall back to the general path (table from L2).
+// Beyond, the window moves to DYNAMIC LDS (WIN = 0 instantiations), as large as the class's frames need: the plan picks
+// the largest number of workgroups per CU whose LDS share still holds the widest ELIGIBLE frame (window_plan.hpp:
+// plan_window_frames) and a chunk of at least eight candidates, then the longest chunk (<= 32) that fits.  A frame that
+// no window can hold takes the general path (table from L2), alone or in company.
 template <int MODE>
 uint32_t lmeds_dynamic_static_lds(int rpt, bool small) {
     if (small) {
@@ -323,50 +409,61 @@ uint32_t lmeds_dynamic_static_lds(int rpt, bool small) {
         default: return static_lds_of(lmeds_kernel<32, MODE, 0>);
     }
 }
-// which LMedS kernel family the problem's frames get (decided from the largest frame of the whole PROBLEM, so that a
-// frame's cost does not depend on the selection or the device it is evaluated in)
+// which LMedS kernel the frames of class k get
 enum class LmedsKind { Small, Tile, Big };
-// rows per lane of the one-wave kernels: 1 .. 4 up to 256 tracks, 8 for 257 .. 512 (rows beyond the frame contribute
-// exact zeros, so one instantiation serves them all with the same bits)
-int small_rpt(uint32_t n_all) { const uint32_t r = std::max(1u, (n_all + 63u) / 64u); return r <= 4u ? (int)r : 8; }
-LmedsKind lmeds_kind(const rship_ctx* c) {
-    const uint32_t n_all = c->force_big ? 0xffffffffu : (c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n);
-    if (n_all <= c->one_wave_max && !c->no_small_lmeds) return LmedsKind::Small;
-    if (n_all > (uint32_t)kMaxRpt * kBlock) return LmedsKind::Big;
+LmedsKind lmeds_kind(const rship_ctx* c, int k) {
+    if (k == 5) return LmedsKind::Big;
+    if (k == 0 && !c->no_small_lmeds) return LmedsKind::Small;
     return LmedsKind::Tile;
 }
-uint32_t lmeds_all_tracks(const rship_ctx* c) { return c->force_big ? 0xffffffffu : (c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n); }
+// rows per thread / per lane of class k's LMedS kernel in the current selection
+int lmeds_rpt(const rship_ctx* c, int k) {
+    const LmedsKind kind = lmeds_kind(c, k);
+    if (kind == LmedsKind::Small) return small_rpt(c->cls_max_n[0]);
+    if (kind == LmedsKind::Big) return 0;
+    return k == 0 ? rpt_for(c->cls_max_n[0]) : class_rpt(k);
+}
 
 template <int MODE>
-WinPlan plan_lmeds_window(rship_ctx* c, double step_knots, uint32_t chunk_want) {
-    const LmedsKind kind = lmeds_kind(c);
+WinPlan plan_lmeds_window(rship_ctx* c, int k, double step_knots, uint32_t chunk_want) {
+    const LmedsKind kind = lmeds_kind(c, k);
     if (kind == LmedsKind::Big) { // (tiles in global memory, general path throughout)
         WinPlan w;
         w.chunk = chunk_want;
         return w;
     }
     const bool small = kind == LmedsKind::Small;
-    const int rpt = small ? small_rpt(lmeds_all_tracks(c)) : rpt_of(c);
+    const int rpt = lmeds_rpt(c, k);
+    uint32_t lo, hi;
+    class_bounds(c, k, &lo, &hi);
+    const std::vector<rs::FrameDims>& d = plan_dims(c);
     // (the kernel's LDS footprint is only asked for when the compiled-in window does not do: plan_window's first test)
-    const bool fits80 = rs::plan_fit((double)kWinMax, c->max_span, step_knots, chunk_want) >= std::min(8u, chunk_want);
+    const bool fits80 = rs::plan_fit((double)kWinMax, class_span(c, k), step_knots, chunk_want) >= std::min(8u, chunk_want);
     const uint32_t fixed = (fits80 || c->force_general) ? 0u : lmeds_dynamic_static_lds<MODE>(rpt, small);
-    return rs::plan_window(c->max_span, c->max_ends, step_knots, chunk_want, small, small ? 20 : lmeds_waves(rpt), fixed, c->lds_per_cu, c->force_general);
+    return rs::plan_window_frames(d.data(), d.size(), lo, hi, step_knots, chunk_want, small, small ? 20 : lmeds_waves(rpt), fixed, c->lds_per_cu,
+                                  c->force_general);
 }
 
+// one class's part of an LMedS launch: p.slots / p.n_slots / p.chunk / p.n_chunks are set here
 template <int MODE>
-int launch_lmeds(rship_ctx* c, LmedsParams p, const WinPlan& wp, int rpt, uint32_t grid) {
-    ProfScope ps(c, MODE == 1 ? RSHIP_K_INIT : RSHIP_K_LMEDS);
-    // Frames of up to 512 tracks (the reference's own data: ~130): one wave per (frame, chunk) instead of a
-    // four-wave workgroup (kernels/lmeds_small.hpp).
-    const uint32_t n_all = lmeds_all_tracks(c);
-    const LmedsKind kind = lmeds_kind(c);
+int launch_lmeds_class(rship_ctx* c, LmedsParams p, const ClassRange& r, const WinPlan& wp) {
+    const int k = r.k;
+    const LmedsKind kind = lmeds_kind(c, k);
+    const int rpt = lmeds_rpt(c, k);
+    p.slots = r.list;
+    p.n_slots = r.count;
+    p.chunk = wp.chunk;
+    p.n_chunks = (p.n_cand + wp.chunk - 1) / wp.chunk;
     p.win_cap = wp.cap ? wp.cap : (uint32_t)kWinMax;
     const size_t dyn = (size_t)wp.cap * 64u;
     if (kind == LmedsKind::Small) {
-        const uint32_t g1 = p.n_sel * p.n_chunks;
-        const int r = small_rpt(n_all);
+        // Frames of up to 512 tracks (the reference's own data: ~130): one wave per (frame, chunk) instead of a
+        // four-wave workgroup (kernels/lmeds_small.hpp).
+        const uint64_t g64 = (uint64_t)r.count * p.n_chunks;
+        if (g64 > 0x7fffffffull) return set_err(c, "lmeds: grid too large");
+        const uint32_t g1 = (uint32_t)g64;
         if (wp.cap) {
-            switch (r) {
+            switch (rpt) {
                 case 1: hipLaunchKernelGGL((lmeds_small_kernel<1, MODE, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break;
                 case 2: hipLaunchKernelGGL((lmeds_small_kernel<2, MODE, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break;
                 case 3: hipLaunchKernelGGL((lmeds_small_kernel<3, MODE, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break;
@@ -374,7 +471,7 @@ int launch_lmeds(rship_ctx* c, LmedsParams p, const WinPlan& wp, int rpt, uint32
                 default: hipLaunchKernelGGL((lmeds_small_kernel<8, MODE, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break;
             }
         } else {
-            switch (r) {
+            switch (rpt) {
                 case 1: hipLaunchKernelGGL((lmeds_small_kernel<1, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
                 case 2: hipLaunchKernelGGL((lmeds_small_kernel<2, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
                 case 3: hipLaunchKernelGGL((lmeds_small_kernel<3, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
@@ -386,22 +483,25 @@ int launch_lmeds(rship_ctx* c, LmedsParams p, const WinPlan& wp, int rpt, uint32
         return 0;
     }
     if (kind == LmedsKind::Big) {
-        // more than 8192 tracks somewhere in the problem: the slow exact path (kernels/lmeds_big.hpp), tiles in a
-        // scratch that a fixed number of workgroups share by walking over the (frame, chunk) items
-        const uint32_t rows = big_rows(c);
-        const uint64_t total = (uint64_t)p.n_sel * p.n_chunks;
+        // more than 8192 tracks: the slow exact path (kernels/lmeds_big.hpp), tiles in a scratch that a fixed number of
+        // workgroups share by walking over the (frame, chunk) items of the class
+        const uint32_t rows = big_rows(c->cls_max_n[k]);
+        const uint64_t total = (uint64_t)r.count * p.n_chunks;
         uint64_t g1 = total < 2048 ? total : 2048;
         const uint64_t per_wg = (uint64_t)rows * kBigScratchFloats * 4;
         const uint64_t fit = ((uint64_t)4 << 30) / per_wg; // at most 4 GB of tiles
         if (g1 > fit) g1 = fit ? fit : 1;
         if (ensure(c, c->big_scratch, (size_t)(g1 * per_wg))) return 1;
-        LmedsParams q = p;
-        q.scratch = (float*)c->big_scratch.p;
-        q.scratch_rows = rows;
-        hipLaunchKernelGGL((lmeds_big_kernel<MODE>), dim3((uint32_t)g1), dim3(kBlock), 0, c->stream, q);
+        p.scratch = (float*)c->big_scratch.p;
+        p.scratch_rows = rows;
+        hipLaunchKernelGGL((lmeds_big_kernel<MODE>), dim3((uint32_t)g1), dim3(kBlock), 0, c->stream, p);
         RS_HIP(hipGetLastError());
         return 0;
     }
+    // the tile kernel: blocks b and b + 8 share an XCD, the chunks of one frame stay on one XCD (kernels/lmeds.hpp)
+    const uint64_t grid64 = (uint64_t)((r.count + 7) / 8) * 8 * p.n_chunks;
+    if (grid64 > 0x7fffffffull) return set_err(c, "lmeds: grid too large");
+    const uint32_t grid = (uint32_t)grid64;
     if (wp.cap) { // the window in dynamic LDS (gyro rates above ~1.7 kHz)
         switch (rpt) {
             case 4: allow_dynamic_lds(lmeds_kernel<4, MODE, 0>, dyn);
@@ -441,91 +541,127 @@ int launch_lmeds(rship_ctx* c, LmedsParams p, const WinPlan& wp, int rpt, uint32
     return 0;
 }
 
-template <bool GRAD, bool SIMPLE>
-int launch_loss64(rship_ctx* c, const Loss64Params& p_in, int rpt, hipStream_t st = nullptr, uint32_t count = 0) {
-    Loss64Params p = p_in;
-    if (!st) st = c->stream;
-    if (!count) count = p.n_sel - p.slot0;
-    // The spline windows.  Trials (no gradient): five delays per pass over the rows, their 80-knot windows compiled into
-    // the kernel's LDS, while the problem's frames fit 80 knots (gyro rates up to ~1.7 kHz); wider frames take the
-    // dynamic-LDS instantiation with cap64 knots per window, as many per pass as 51 KB hold (at most three).  The gradient
-    // launch has one window, always in dynamic LDS.
-    const uint32_t cap64 = cap64_of(c);
-    p.win_cap = cap64;
-    // (the compiled-in windows hold whole pairs only: where the 80 knots are enough just because the two ends are staged
-    // separately, the dynamic instantiation runs)
-    const bool fixed80 = !GRAD && cap64 == (uint32_t)kWinMax && (c->max_span + 1.f <= (float)kWinMax || c->force_general);
-    p.nb_run = GRAD ? 1u : (fixed80 ? (uint32_t)kLossBatch : std::max(1u, std::min((uint32_t)kLossBatchWide, kLossWinBytes / (cap64 * 128u))));
-    const size_t dyn = fixed80 ? 0 : (size_t)p.nb_run * cap64 * 128u, dyn_small = (size_t)cap64 * 128u;
-    ProfScope ps(c, GRAD ? RSHIP_K_LOSS_GRAD : RSHIP_K_LOSS);
-    // frames of up to 512 tracks (the reference's own: ~130): one wave per slot instead of a four-wave workgroup that
-    // half idles -- the same sums in the same order (loss64_wave), four times as many slots on the chip
-    const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
-    if (n_all <= c->one_wave_max && !c->no_small_loss && !c->force_big) {
-        hipLaunchKernelGGL((loss64_small_kernel<GRAD, SIMPLE>), dim3(count), dim3(64), dyn_small, st, p);
-        RS_HIP(hipGetLastError());
-        return 0;
+// The LMedS launches of one call: every size class of the selection with its own kernel, window plan and chunking (the
+// results are indexed by candidate and slot, so the classes' chunkings do not meet).  main_cap / main_chunk: what the
+// class with the most slots used (rship_window_info).
+template <int MODE>
+int launch_lmeds(rship_ctx* c, const LmedsParams& p, double step_knots, uint32_t chunk_want, uint32_t* main_cap, uint32_t* main_chunk) {
+    ProfScope ps(c, MODE == 1 ? RSHIP_K_INIT : RSHIP_K_LMEDS);
+    const int mk = main_class(c);
+    for (const ClassRange& r : class_ranges(c)) {
+        const WinPlan wp = plan_lmeds_window<MODE>(c, r.k, step_knots, chunk_want);
+        if (r.k == mk) {
+            if (main_cap) *main_cap = wp.cap;
+            if (main_chunk) *main_chunk = wp.chunk;
+        }
+        if (launch_lmeds_class<MODE>(c, p, r, wp)) return 1;
     }
-#define RS_LOSS_CASE(R)                                                                                                        \
-    case R:                                                                                                                    \
-        if constexpr (!GRAD) {                                                                                                 \
-            if (fixed80) { hipLaunchKernelGGL((loss64_kernel<R, GRAD, SIMPLE, kWinMax>), dim3(count), dim3(kBlock), 0, st, p); break; } \
-        }                                                                                                                      \
-        hipLaunchKernelGGL((loss64_kernel<R, GRAD, SIMPLE, 0>), dim3(count), dim3(kBlock), dyn, st, p);                        \
-        break;
-    switch (rpt) {
-        RS_LOSS_CASE(0)
-        RS_LOSS_CASE(4)
-        RS_LOSS_CASE(8)
-        RS_LOSS_CASE(16)
-        RS_LOSS_CASE(32)
-        default: return set_err(c, "loss: unsupported rows-per-thread");
-    }
-#undef RS_LOSS_CASE
-    RS_HIP(hipGetLastError());
     return 0;
 }
 
-// The workgroup shape of the motion kernel follows the LARGEST frame of the whole problem (all devices:
-// RSHIP_OPT_TRACKS_HINT), not of the selection at hand: the shape fixes the order in which a frame's row
-// terms are added, and a frame must get the same sums whichever selection or device it is part of.
+// does class k's trial kernel use its compiled-in five windows of 80 knots? (whole pairs only: where the 80 knots are
+// enough just because the two ends are staged separately, the dynamic instantiation runs)
+bool loss_fixed80(const rship_ctx* c, int k) {
+    return c->cls_cap64[k] == (uint32_t)kWinMax && (class_span(c, k) + 1.f <= (float)kWinMax || c->force_general);
+}
+uint32_t loss_nb_run(const rship_ctx* c, int k) {
+    return loss_fixed80(c, k) ? (uint32_t)kLossBatch : std::max(1u, std::min((uint32_t)kLossBatchWide, kLossWinBytes / (c->cls_cap64[k] * 128u)));
+}
+
+// K1 over the slots [slot0, slot0 + count) of the selection (count = 0: all), one launch per size class
+template <bool GRAD, bool SIMPLE>
+int launch_loss64(rship_ctx* c, const Loss64Params& p_in, hipStream_t st = nullptr, uint32_t slot0 = 0, uint32_t count = 0) {
+    if (!st) st = c->stream;
+    ProfScope ps(c, GRAD ? RSHIP_K_LOSS_GRAD : RSHIP_K_LOSS);
+    for (const ClassRange& r : class_ranges(c, slot0, count)) {
+        Loss64Params p = p_in;
+        const int k = r.k;
+        p.slots = r.list;
+        p.slot0 = r.list ? 0u : c->h_cls_slots[r.pos0]; // (one class: the list is the identity and entry = slot)
+        // The spline windows.  Trials (no gradient): five delays per pass over the rows, their 80-knot windows compiled into
+        // the kernel's LDS, while the class's frames fit 80 knots (gyro rates up to ~1.7 kHz); wider frames take the
+        // dynamic-LDS instantiation with cap64 knots per window, as many per pass as 51 KB hold (at most three).  The gradient
+        // launch has one window, always in dynamic LDS.
+        const uint32_t cap64 = cap64_of(c, k);
+        p.win_cap = cap64;
+        const bool fixed80 = !GRAD && loss_fixed80(c, k);
+        p.nb_run = GRAD ? 1u : loss_nb_run(c, k);
+        const size_t dyn = fixed80 ? 0 : (size_t)p.nb_run * cap64 * 128u, dyn_small = (size_t)cap64 * 128u;
+        // frames of up to 512 tracks (the reference's own: ~130): one wave per slot instead of a four-wave workgroup that
+        // half idles -- the same sums in the same order (loss64_wave), four times as many slots on the chip
+        if (k == 0 && !c->no_small_loss) {
+            hipLaunchKernelGGL((loss64_small_kernel<GRAD, SIMPLE>), dim3(r.count), dim3(64), dyn_small, st, p);
+            RS_HIP(hipGetLastError());
+            continue;
+        }
+        const int rpt = k == 0 ? rpt_for(c->cls_max_n[0]) : class_rpt(k);
+#define RS_LOSS_CASE(R)                                                                                                        \
+    case R:                                                                                                                    \
+        if constexpr (!GRAD) {                                                                                                 \
+            if (fixed80) { hipLaunchKernelGGL((loss64_kernel<R, GRAD, SIMPLE, kWinMax>), dim3(r.count), dim3(kBlock), 0, st, p); break; } \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((loss64_kernel<R, GRAD, SIMPLE, 0>), dim3(r.count), dim3(kBlock), dyn, st, p);                      \
+        break;
+        switch (rpt) {
+            RS_LOSS_CASE(0)
+            RS_LOSS_CASE(4)
+            RS_LOSS_CASE(8)
+            RS_LOSS_CASE(16)
+            RS_LOSS_CASE(32)
+            default: return set_err(c, "loss: unsupported rows-per-thread");
+        }
+#undef RS_LOSS_CASE
+        RS_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+// The workgroup shape of the motion kernel fixes the order in which a frame's row terms are added; it follows the frame's
+// own size class (one wave up to 512 tracks, four above), so that a frame gets the same sums whichever selection, device or
+// rank it is part of.
 constexpr uint32_t kOrderMinSlots = 512; // fewer workgroups than the chip holds at once: nothing to order
 
-int launch_motion64(rship_ctx* c, const Motion64Params& p_in, hipStream_t st = nullptr, uint32_t count = 0) {
-    Motion64Params p = p_in;
+// K3 over the slots [slot0, slot0 + count) of the selection (count = 0: all), one launch per size class; p.order is the
+// class-sorted launch order (c->mo_order: entry e of the launch list is slot order[e])
+int launch_motion64(rship_ctx* c, const Motion64Params& p_in, hipStream_t st = nullptr, uint32_t slot0 = 0, uint32_t count = 0) {
     if (!st) st = c->stream;
-    if (!count) count = p.n_sel - p.slot0;
-    p.win_cap = cap64_of(c);
-    const size_t dyn = (size_t)p.win_cap * 128u; // the spline window (used once, for the rows of P)
     ProfScope ps(c, RSHIP_K_MOTION);
-    const uint32_t n = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
-    // One wave per frame up to 512 tracks: the evaluations of a frame are dominated by their fixed part (five
-    // wave reductions, the uniform L-BFGS bookkeeping) which every wave of a workgroup repeats, and a one-wave
-    // frame needs no LDS exchange or barrier at all -- the reference's own workload (~130 tracks) ran 3x as
-    // many frames per CU this way.  Above that, four waves: with 8 / 16 waves (4 / 2 rows per thread at 2048
-    // tracks) the launch took 7.8 / 12.4 ms per bench step instead of 4.75, and with two waves 5.15: the kernel is
-    // bound by the work per evaluation, not by its slowest frame.
-    if (c->force_big) {
-        if (!p.scratch || p.scratch_rows < c->max_n) return set_err(c, "motion: no scratch for the large-frame kernel");
-        hipLaunchKernelGGL((opt_motion64_kernel<0, 4>), dim3(count), dim3(256), dyn, st, p);
-    } else if (n <= 64) hipLaunchKernelGGL((opt_motion64_kernel<1, 1>), dim3(count), dim3(64), dyn, st, p);
-    else if (n <= 128) hipLaunchKernelGGL((opt_motion64_kernel<2, 1>), dim3(count), dim3(64), dyn, st, p);
-    else if (n <= 192) hipLaunchKernelGGL((opt_motion64_kernel<3, 1>), dim3(count), dim3(64), dyn, st, p);
-    else if (n <= 256) hipLaunchKernelGGL((opt_motion64_kernel<4, 1>), dim3(count), dim3(64), dyn, st, p);
-    else if (n <= 512) hipLaunchKernelGGL((opt_motion64_kernel<8, 1>), dim3(count), dim3(64), dyn, st, p);
-    else if (n <= 1024) hipLaunchKernelGGL((opt_motion64_kernel<4, 4>), dim3(count), dim3(256), dyn, st, p);
-    else if (n <= 2048) hipLaunchKernelGGL((opt_motion64_kernel<8, 4>), dim3(count), dim3(256), dyn, st, p);
-    else if (n <= 4096) hipLaunchKernelGGL((opt_motion64_kernel<16, 4>), dim3(count), dim3(256), dyn, st, p);
-    else if (n <= 8192) hipLaunchKernelGGL((opt_motion64_kernel<32, 4>), dim3(count), dim3(256), dyn, st, p);
-    else { // rows of P in global memory (per slot, set up by fill_motion), as many per thread as the frame needs
-        if (!p.scratch || p.scratch_rows < c->max_n) return set_err(c, "motion: no scratch for frames of more than 8192 tracks");
-        hipLaunchKernelGGL((opt_motion64_kernel<0, 4>), dim3(count), dim3(256), dyn, st, p);
-    }
-    RS_HIP(hipGetLastError());
-    // the order of the NEXT launch over these slots, from this one's evaluation counts
-    if (p.evals_out && c->mo_order.p && p.max_iters > 0 && !p.simple_k && count >= kOrderMinSlots) {
-        hipLaunchKernelGGL(motion_order_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)p.evals_out, (uint32_t*)c->mo_order.p, p.slot0, count);
+    for (const ClassRange& r : class_ranges(c, slot0, count)) {
+        Motion64Params p = p_in;
+        const int k = r.k;
+        p.slot0 = r.pos0; // (an index into order[]; with one class the list is the identity and this is the first slot)
+        p.win_cap = cap64_of(c, k);
+        const size_t dyn = (size_t)p.win_cap * 128u; // the spline window (used once, for the rows of P)
+        const uint32_t cnt = r.count;
+        // One wave per frame up to 512 tracks: the evaluations of a frame are dominated by their fixed part (five
+        // wave reductions, the uniform L-BFGS bookkeeping) which every wave of a workgroup repeats, and a one-wave
+        // frame needs no LDS exchange or barrier at all -- the reference's own workload (~130 tracks) ran 3x as
+        // many frames per CU this way.  Above that, four waves: with 8 / 16 waves (4 / 2 rows per thread at 2048
+        // tracks) the launch took 7.8 / 12.4 ms per bench step instead of 4.75, and with two waves 5.15: the kernel is
+        // bound by the work per evaluation, not by its slowest frame.
+        if (k == 0) {
+            const uint32_t n = c->cls_max_n[0];
+            if (n <= 64) hipLaunchKernelGGL((opt_motion64_kernel<1, 1>), dim3(cnt), dim3(64), dyn, st, p);
+            else if (n <= 128) hipLaunchKernelGGL((opt_motion64_kernel<2, 1>), dim3(cnt), dim3(64), dyn, st, p);
+            else if (n <= 192) hipLaunchKernelGGL((opt_motion64_kernel<3, 1>), dim3(cnt), dim3(64), dyn, st, p);
+            else if (n <= 256) hipLaunchKernelGGL((opt_motion64_kernel<4, 1>), dim3(cnt), dim3(64), dyn, st, p);
+            else hipLaunchKernelGGL((opt_motion64_kernel<8, 1>), dim3(cnt), dim3(64), dyn, st, p);
+        } else if (k == 1) hipLaunchKernelGGL((opt_motion64_kernel<4, 4>), dim3(cnt), dim3(256), dyn, st, p);
+        else if (k == 2) hipLaunchKernelGGL((opt_motion64_kernel<8, 4>), dim3(cnt), dim3(256), dyn, st, p);
+        else if (k == 3) hipLaunchKernelGGL((opt_motion64_kernel<16, 4>), dim3(cnt), dim3(256), dyn, st, p);
+        else if (k == 4) hipLaunchKernelGGL((opt_motion64_kernel<32, 4>), dim3(cnt), dim3(256), dyn, st, p);
+        else { // rows of P in global memory (per entry of the class's list, set up by fill_motion), as many per thread as the frame needs
+            if (!p.scratch || p.scratch_rows < c->cls_max_n[5]) return set_err(c, "motion: no scratch for frames of more than 8192 tracks");
+            p.scratch0 = r.pos0 - c->cls_off[5];
+            hipLaunchKernelGGL((opt_motion64_kernel<0, 4>), dim3(cnt), dim3(256), dyn, st, p);
+        }
         RS_HIP(hipGetLastError());
+        // the order of the NEXT launch over these slots, from this one's evaluation counts
+        if (p.evals_out && p.order && c->mo_order.p && p.max_iters > 0 && !p.simple_k && cnt >= kOrderMinSlots) {
+            hipLaunchKernelGGL(motion_order_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)p.evals_out, (const uint32_t*)c->cls_slots.p,
+                               (uint32_t*)c->mo_order.p, r.pos0, cnt);
+            RS_HIP(hipGetLastError());
+        }
     }
     return 0;
 }
@@ -759,7 +895,7 @@ const char* rship_last_error(const rship_ctx* c) { return c ? c->err.c_str() : "
 int rship_set_option(rship_ctx* c, int option, int value) {
     switch (option) {
         case RSHIP_OPT_LBFGS_REEVAL: c->lbfgs_reeval = value != 0; return 0;
-        case RSHIP_OPT_TRACKS_HINT: c->tracks_hint = value > 0 ? (uint32_t)value : 0u; return 0;
+        case RSHIP_OPT_TRACKS_HINT: return 0; // (rounds 2-4: the kernel shapes followed the problem's largest frame; they follow each frame's own size now)
         default: return set_err(c, "set_option: unknown option");
     }
 }
@@ -986,6 +1122,12 @@ int rship_pack_frames(rship_ctx* c, const rship_frame* table, const rship_pack_f
     c->h_frame_n.assign(n_frames, 0);
     c->max_span = 0.f;
     c->max_ends = 0.f;
+    c->own_dims.assign(n_frames, rs::FrameDims{0u, 0.f, 0.f});
+    c->problem_dims.clear(); // (the host gives them again after packing: rship_set_problem_frames)
+    memset(c->cls_off, 0, sizeof(c->cls_off));
+    memset(c->cls_max_n, 0, sizeof(c->cls_max_n));
+    c->cls_used = 0;
+    c->h_cls_slots.clear();
     uint32_t max_n = 0;
     for (uint32_t i = 0; i < n_frames; ++i) {
         if ((uint64_t)table[i].ray_offset + table[i].n_rays > total_rays) return set_err(c, "frame table exceeds ray buffer");
@@ -997,17 +1139,14 @@ int rship_pack_frames(rship_ctx* c, const rship_frame* table, const rship_pack_f
             return set_err(c, "frame has more tracks than the kernels accept (" + std::to_string(rship_max_tracks()) + ")");
         c->h_frame_n[i] = table[i].n_rays;
         max_n = std::max(max_n, table[i].n_rays);
-        const float span = floorf(table[i].tmax) - floorf(table[i].tmin) + 2.f; // knots a frame touches at one delay
+        const float span = rs::frame_span(table[i].tmin, table[i].tmax); // knots a frame touches at one delay
         if (table[i].n_rays && span > c->max_span) c->max_span = span;
-        float ends = span;
-        if (table[i].range_a != RSHIP_NO_SPLIT && table[i].range_b != RSHIP_NO_SPLIT) {
-            const int a_lo = (int)(table[i].range_a & 0xffffu), a_hi = (int)(table[i].range_a >> 16) + 1;
-            const int b_lo = (int)(table[i].range_b & 0xffffu), b_hi = (int)(table[i].range_b >> 16) + 1;
-            if (b_lo > a_hi + 1 || a_lo > b_hi + 1) ends = std::min(span, (float)((a_hi - a_lo + 1) + (b_hi - b_lo + 1)));
-        }
+        // (RSSYNC_FORCE_GENERAL_SPLINE, rounds 1-3: whole pairs only)
+        const float ends = c->force_general ? span : rs::frame_ends(table[i].range_a, table[i].range_b, span);
         if (table[i].n_rays && ends > c->max_ends) c->max_ends = ends;
+        c->own_dims[i] = rs::FrameDims{table[i].n_rays, span, ends};
     }
-    c->cap64 = c->force_general ? (uint32_t)kWinMax : rs::cap64_for(c->max_span, c->max_ends);
+    update_class_caps(c);
     const size_t tr = (size_t)total_rays;
     if (ensure(c, c->rays_a, tr ? tr * 16 : 16) || ensure(c, c->rays_b, tr ? tr * 16 : 16) ||
         ensure(c, c->rays64, tr ? tr * 64 : 64))
@@ -1063,6 +1202,21 @@ int rship_pack_frames(rship_ctx* c, const rship_frame* table, const rship_pack_f
     return 0;
 }
 
+// One object over several devices: the track count and the knot spans (tmin / tmax / range_a / range_b of the frame
+// table) of ALL frames of the problem, so that this context plans its spline windows from the same frames as every other
+// shard -- and as a single device holding everything would (window_plan.hpp: plan_window_frames).  Optional: without it
+// the context's own table is what it plans from.
+int rship_set_problem_frames(rship_ctx* c, const rship_frame* table_all, uint32_t n_all) {
+    c->problem_dims.assign(n_all, rs::FrameDims{0u, 0.f, 0.f});
+    for (uint32_t i = 0; i < n_all; ++i) {
+        const float span = rs::frame_span(table_all[i].tmin, table_all[i].tmax);
+        const float ends = c->force_general ? span : rs::frame_ends(table_all[i].range_a, table_all[i].range_b, span);
+        c->problem_dims[i] = rs::FrameDims{table_all[i].n_rays, span, ends};
+    }
+    update_class_caps(c);
+    return 0;
+}
+
 // Selection = list of slots.  A slot names a frame of the table; with groups (batched windows)
 // the same frame may appear in several slots, slots of one group are contiguous, and the
 // per-frame Sync state (M, k) is kept per slot.
@@ -1094,12 +1248,33 @@ int rship_select_slots(rship_ctx* c, const uint32_t* idx, uint32_t n, const uint
     RS_HIP(hipMemsetAsync(c->M.p, 0, (size_t)n * 24 + 24, c->stream));
     RS_HIP(hipMemsetAsync(c->k.p, 0, (size_t)n * 8 + 8, c->stream));
     RS_HIP(hipMemsetD32Async((hipDeviceptr_t)c->init_h.p, kInitNone, (size_t)n + 1, c->stream));
-    {   // launch order of the motion kernel: identity until a launch has left evaluation counts
-        std::vector<uint32_t> ident(n + 1);
-        for (uint32_t i = 0; i <= n; ++i) ident[i] = i;
-        RS_HIP(hipMemcpyAsync(c->mo_order.p, ident.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    // the slot list of every size class (ascending slots inside a class), and -- until a launch has left evaluation
+    // counts -- the motion kernel's launch order = that list
+    {
+        std::vector<uint32_t> cnt(kNumClasses + 1, 0);
+        uint32_t mx[kNumClasses] = {};
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t fn = c->h_frame_n[idx[i]];
+            const int k = class_of(c, fn);
+            cnt[k + 1] += 1;
+            mx[k] = std::max(mx[k], fn);
+        }
+        c->cls_used = 0;
+        for (int k = 0; k < kNumClasses; ++k) {
+            if (cnt[k + 1]) c->cls_used += 1;
+            c->cls_max_n[k] = mx[k];
+            c->cls_off[k] = cnt[k];
+            cnt[k + 1] += cnt[k];
+        }
+        c->cls_off[kNumClasses] = n;
+        c->h_cls_slots.assign((size_t)n + 1, n);
+        uint32_t at[kNumClasses];
+        for (int k = 0; k < kNumClasses; ++k) at[k] = c->cls_off[k];
+        for (uint32_t i = 0; i < n; ++i) c->h_cls_slots[at[class_of(c, c->h_frame_n[idx[i]])]++] = i;
+        if (ensure(c, c->cls_slots, (size_t)n * 4 + 4)) return 1;
+        RS_HIP(hipMemcpyAsync(c->cls_slots.p, c->h_cls_slots.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+        RS_HIP(hipMemcpyAsync(c->mo_order.p, c->h_cls_slots.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, c->stream));
         RS_HIP(hipMemsetAsync(c->mo_evals.p, 0, (size_t)n * 4 + 4, c->stream));
-        RS_HIP(hipStreamSynchronize(c->stream)); // ident goes out of scope
         c->mo_identity = true;
         c->mo_ranges.clear();
     }
@@ -1108,7 +1283,8 @@ int rship_select_slots(rship_ctx* c, const uint32_t* idx, uint32_t n, const uint
     c->h_grp_off = off;
     c->n_sel = n;
     c->n_grp = n_grp;
-    c->max_n = sel_max_n(c);
+    c->max_n = 0;
+    for (int k = 0; k < kNumClasses; ++k) c->max_n = std::max(c->max_n, c->cls_max_n[k]);
     return 0;
 }
 
@@ -1180,25 +1356,17 @@ int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, uint
     if (chunk > (uint32_t)kMaxChunk) chunk = kMaxChunk;
     if (chunk > n_cand) chunk = n_cand;
     // keep the chunk's delays inside what the LDS spline window can hold next to the widest frame (higher gyro
-    // rates: a frame pair spans more knots); the window itself grows into dynamic LDS where it has to (plan_lmeds_window)
+    // rates: a frame pair spans more knots); the window itself grows into dynamic LDS where it has to (plan_lmeds_window,
+    // per size class)
     double step_knots = 0.0;
     if (n_cand > 1) step_knots = std::fabs(((double)kd[n_cand - 1] + fd[n_cand - 1] - (double)kd[0] - fd[0]) / (double)(n_cand - 1));
-    const WinPlan wp = plan_lmeds_window<0>(c, step_knots, chunk);
-    chunk = wp.chunk;
-    p.chunk = chunk;
-    p.n_chunks = (n_cand + chunk - 1) / chunk;
     p.n_hyp = n_hyp;
     p.stream_base = stream_base;
     p.seed = seed;
     p.frame_cost = (double*)c->frame_cost.p;
     p.best_h = want_best_h ? (int32_t*)c->best_h.p : nullptr;
     p.flags = (uint32_t*)c->flags.p;
-    uint32_t groups = (ns + 7) / 8;
-    uint64_t grid = (uint64_t)groups * 8 * p.n_chunks;
-    if (grid > 0x7fffffffull) return set_err(c, "presync: grid too large");
-    c->last_lmeds_cap = wp.cap;
-    c->last_lmeds_chunk = chunk;
-    if (launch_lmeds<0>(c, p, wp, rpt_of(c), (uint32_t)grid)) return 1;
+    if (launch_lmeds<0>(c, p, step_knots, chunk, &c->last_lmeds_cap, &c->last_lmeds_chunk)) return 1;
     if (launch_plan_sum(c, p.frame_cost, n_cand, ns)) return 1;
     size_t end = 0;
     if (queue_sums_to_host(c, n_cand, 0, &c->pend.off_chunk, &end)) return 1;
@@ -1238,10 +1406,10 @@ namespace {
 int fill_motion(rship_ctx* c, Motion64Params& p) {
     p.scratch = nullptr;
     p.scratch_rows = 0;
-    const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
-    if (n_all > (uint32_t)kMaxRpt * kBlock || c->force_big) {
-        const uint32_t rows = big_rows(c);
-        if (ensure(c, c->mo_scratch, (size_t)(c->n_sel ? c->n_sel : 1) * 3 * rows * 8)) return 1;
+    p.scratch0 = 0;
+    if (c->cls_off[5] != c->cls_off[6]) { // frames of more than 8192 tracks: their rows of P live in global memory, per entry of the class's list
+        const uint32_t rows = big_rows(c->cls_max_n[5]);
+        if (ensure(c, c->mo_scratch, (size_t)(c->cls_off[6] - c->cls_off[5]) * 3 * rows * 8)) return 1;
         p.scratch = (double*)c->mo_scratch.p;
         p.scratch_rows = rows;
     }
@@ -1269,13 +1437,12 @@ int fill_motion(rship_ctx* c, Motion64Params& p) {
 }
 
 // Before a call launches the motion kernel over the slot ranges `ranges` (one per stream group): the launch order
-// left by earlier launches is only usable if it was built for the same ranges; otherwise back to the identity.
+// left by earlier launches is only usable if it was built for the same ranges (a class's share of a range is a segment
+// of the class-sorted list, permuted in place); otherwise back to the list itself.
 int prepare_order(rship_ctx* c, const std::vector<std::pair<uint32_t, uint32_t>>& ranges) {
     if (!c->mo_identity && ranges != c->mo_ranges) {
-        std::vector<uint32_t> ident(c->n_sel + 1);
-        for (uint32_t i = 0; i <= c->n_sel; ++i) ident[i] = i;
         RS_HIP(hipStreamSynchronize(c->stream));
-        RS_HIP(hipMemcpy(c->mo_order.p, ident.data(), (size_t)(c->n_sel + 1) * 4, hipMemcpyHostToDevice));
+        RS_HIP(hipMemcpy(c->mo_order.p, c->h_cls_slots.data(), (size_t)(c->n_sel + 1) * 4, hipMemcpyHostToDevice));
     }
     c->mo_identity = false;
     c->mo_ranges = ranges;
@@ -1314,10 +1481,7 @@ int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t
     p.n_grp = c->n_grp;
     p.best_h = (int32_t*)c->init_h.p;
     p.flags = (uint32_t*)c->flags.p;
-    uint32_t groups = (c->n_sel + 7) / 8;
-    const WinPlan wp_init = plan_lmeds_window<1>(c, 0.0, 1u);
-    c->last_init_cap = wp_init.cap;
-    if (launch_lmeds<1>(c, p, wp_init, rpt_of(c), groups * 8)) return 1;
+    if (launch_lmeds<1>(c, p, 0.0, 1u, &c->last_init_cap, nullptr)) return 1;
     c->init_pending = true;
     c->init_seed = seed;
     c->init_stream = stream;
@@ -1426,10 +1590,9 @@ int rship_loss_enqueue(rship_ctx* c, const int32_t* kd, const double* fd, uint32
     p.k = (const double*)c->k.p;
     p.part_loss = (double*)c->part.p;
     p.part_grad = p.part_loss + (size_t)n_delays * ns;
-    const int rpt = rpt_of(c);
     int rc;
-    if (simple) rc = want_grad ? launch_loss64<true, true>(c, p, rpt) : launch_loss64<false, true>(c, p, rpt);
-    else rc = want_grad ? launch_loss64<true, false>(c, p, rpt) : launch_loss64<false, false>(c, p, rpt);
+    if (simple) rc = want_grad ? launch_loss64<true, true>(c, p) : launch_loss64<false, true>(c, p);
+    else rc = want_grad ? launch_loss64<true, false>(c, p) : launch_loss64<false, false>(c, p);
     if (rc) return 1;
     // rows [0, n_delays) = loss, [n_delays, 2 n_delays) = d loss / d delay
     const uint32_t rows = want_grad ? 2 * n_delays : n_delays;
@@ -1512,10 +1675,10 @@ static int sync_run_body(rship_ctx* c, const double* d0, int max_outer, double s
     if (const char* e = std::getenv("RSSYNC_LOOP_FIRST_TRIALS")) { const int v = atoi(e); if (v >= 1 && v <= kMaxBt) nf_fixed = v; }
     // how many trials a search's first launch holds at least (SyncLoopParams::nf_floor): five where a trial is cheap
     // (the reference's ~130-track frames), one for frames of 1024 tracks and more (dense trackers: every unneeded
-    // trial of 4096 x 2048 ray pairs is 0.06 ms).  Decided from the problem's largest frame over ALL ranks (the agreed
-    // size class): in rank mode every rank must batch its trials alike, the sums of a trial come from all of them.
-    const uint32_t n_all_tracks = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
-    int nf_floor = n_all_tracks >= 1024u ? 1 : kHalfBt;
+    // trial of 4096 x 2048 ray pairs is 0.06 ms).  Only the batching depends on it, never a result.  In rank mode every
+    // rank must batch its trials alike -- the sums of a trial come from all of them -- and no rank knows the others'
+    // frames: always five there (at the benchmark's size every search needs six trials anyway).
+    int nf_floor = (!ranked && c->max_n >= 1024u) ? 1 : kHalfBt;
     if (const char* e = std::getenv("RSSYNC_LOOP_TRIALS_FLOOR")) { const int v = atoi(e); if (v >= 1 && v <= kMaxBt) nf_floor = v; }
     const int max_launch = 2 * max_outer; // a window whose line search needs its later trials waits one iteration for them
     // one allocation: windows | motion delays | loss delays | trial delays | per-group counters | trace | chunk scratch
@@ -1594,7 +1757,6 @@ static int sync_run_body(rship_ctx* c, const double* d0, int max_outer, double s
     qp.M = (const double*)c->M.p;
     qp.k = (const double*)c->k.p;
     qp.part_loss = (double*)c->part.p;
-    const int rpt = rpt_of(c);
 
     // the groups: windows [w0, w1) = slots [s0, s1), balanced by slots
     struct Group {
@@ -1628,8 +1790,10 @@ static int sync_run_body(rship_ctx* c, const double* d0, int max_outer, double s
         }
     }
     {
-        std::vector<std::pair<uint32_t, uint32_t>> ranges;
-        for (const Group& gr : groups) ranges.emplace_back(gr.s0, gr.s1 - gr.s0);
+        std::vector<std::pair<uint32_t, uint32_t>> ranges; // (segments of the class-sorted list: one per group and class)
+        for (const Group& gr : groups)
+            if (gr.s1 > gr.s0)
+                for (const ClassRange& r : class_ranges(c, gr.s0, gr.s1 - gr.s0)) ranges.emplace_back(r.pos0, r.count);
         if (prepare_order(c, ranges)) return 1;
     }
     if (G > 1) { // what the context's stream has queued (selection, GuessMotion, the copies above) comes first
@@ -1644,19 +1808,16 @@ static int sync_run_body(rship_ctx* c, const double* d0, int max_outer, double s
         const uint32_t nw = gr.w1 - gr.w0, cnt = gr.s1 - gr.s0;
         const dim3 ctl_block(nw > 64 ? 64 : kBlock);
         Loss64Params q = qp;
-        q.slot0 = gr.s0;
         auto loss_launch = [&](bool grad) -> int {
-            if (simplified) return grad ? launch_loss64<true, true>(c, q, rpt, gr.st, cnt) : launch_loss64<false, true>(c, q, rpt, gr.st, cnt);
-            return grad ? launch_loss64<true, false>(c, q, rpt, gr.st, cnt) : launch_loss64<false, false>(c, q, rpt, gr.st, cnt);
+            if (simplified) return grad ? launch_loss64<true, true>(c, q, gr.st, gr.s0, cnt) : launch_loss64<false, true>(c, q, gr.st, gr.s0, cnt);
+            return grad ? launch_loss64<true, false>(c, q, gr.st, gr.s0, cnt) : launch_loss64<false, false>(c, q, gr.st, gr.s0, cnt);
         };
         if (gr.it == 0) {
             hipLaunchKernelGGL(sync_begin_kernel, dim3((nw + 63) / 64), dim3(64), 0, gr.st, l);
             RS_HIP(hipGetLastError());
         }
         if (!simplified && cnt) {
-            Motion64Params m = mp;
-            m.slot0 = gr.s0;
-            if (launch_motion64(c, m, gr.st, cnt)) return 1; // :311 (finishes a pending GuessMotion on its first launch)
+            if (launch_motion64(c, mp, gr.st, gr.s0, cnt)) return 1; // :311 (finishes a pending GuessMotion on its first launch)
         }
         // loss + gradient at x0 (:298-299 -> backtrack.cpp:4)
         q.kd = l.lg_kd; q.fd = l.lg_fd; q.n_delays = 1;
@@ -1753,9 +1914,10 @@ static int sync_run_body(rship_ctx* c, const double* d0, int max_outer, double s
 // cost[W] (loss at the returned delay), iters[W][repeats], and the trace rows of all calls of a window back to back,
 // trace[W][trace_rows][6] (trace_rows >= repeats * max_outer).  Window w samples call r with stream_first + r + w * stride.
 int rship_exec_supported(rship_ctx* c) {
-    const uint32_t n = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
-    if (c->force_big) return 0; // (RSSYNC_FORCE_BIG: every frame through the large-frame kernels, whose association the one-wave tasks do not have)
-    return n >= 2 && n <= c->one_wave_max && c->n_sel < (1u << 24) ? 1 : 0; // (a queue cell holds the slot in 24 bits)
+    // every slot of the selection in the one-wave class (RSSYNC_FORCE_BIG: none is -- every frame goes through the
+    // large-frame kernels, whose association the one-wave tasks do not have)
+    const uint32_t n0 = c->cls_off[1] - c->cls_off[0];
+    return c->n_sel && n0 == c->n_sel && c->cls_max_n[0] >= 2 && c->n_sel < (1u << 24) ? 1 : 0; // (a queue cell holds the slot in 24 bits)
 }
 
 int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream_first, uint32_t stream_stride, uint64_t seed,
@@ -1777,9 +1939,8 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
     // One dynamic LDS region per wave serves as fp32 window, fp64 window and staging area (executor.hpp): cap64 knots x
     // 128 bytes -- 10 KB up to ~1.7 kHz of gyro rate, more for wider frames, and then fewer waves share a CU.
-    const uint32_t n_all = c->tracks_hint > c->max_n ? c->tracks_hint : c->max_n;
-    const uint32_t exec_rpt = (uint32_t)small_rpt(n_all);
-    const uint32_t cap64 = cap64_of(c);
+    const uint32_t exec_rpt = (uint32_t)small_rpt(c->cls_max_n[0]);
+    const uint32_t cap64 = cap64_of(c, 0);
     const size_t region = (size_t)cap64 * 128u;
     uint32_t fixed_lds = 0;
     switch (exec_rpt) {
@@ -1907,6 +2068,8 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     ep.init.frames = (const FrameRec*)c->frames.p;
     ep.init.sel = (const uint32_t*)c->sel.p;
     ep.init.n_sel = ns;
+    ep.init.slots = nullptr;
+    ep.init.n_slots = ns;
     ep.init.coef = (const f4*)c->coef.p;
     ep.init.n_knots = (int)c->n_knots;
     ep.init.kd = ep.in_kd;
@@ -1924,7 +2087,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     // the executor would no longer return the chain's bits -- caught by RSSYNC_EXECUTOR_CHECK on a randomised case at
     // 3.2 kHz in round 4): the capacity the chain's planner chooses, 80 knots where it keeps the compiled-in window.
     {
-        const WinPlan wp_init = plan_lmeds_window<1>(c, 0.0, 1u);
+        const WinPlan wp_init = plan_lmeds_window<1>(c, 0, 0.0, 1u);
         ep.init.win_cap = wp_init.cap ? wp_init.cap : (uint32_t)kWinMax;
         ep.init.win_whole_pair = wp_init.cap ? 0u : 1u; // (the compiled-in window stages whole pairs: so must this one, or tiny frames take another path)
         if ((size_t)ep.init.win_cap * 64u > region) return set_err(c, "sync_exec: the search's window does not fit the wave's LDS region");
@@ -2028,12 +2191,12 @@ int rship_window_info(rship_ctx* c, uint32_t out[8]) {
     out[0] = (uint32_t)c->max_span;
     out[6] = (uint32_t)c->max_ends;
     out[7] = 0;
-    const uint32_t cap64 = cap64_of(c);
-    out[1] = cap64;
+    const int mk = main_class(c); // (of the class most slots of the selection belong to)
+    out[1] = cap64_of(c, mk);
     out[2] = c->last_lmeds_cap;
     out[3] = c->last_lmeds_chunk;
     out[4] = c->last_init_cap;
-    out[5] = (cap64 == (uint32_t)kWinMax && (c->max_span + 1.f <= (float)kWinMax || c->force_general)) ? (uint32_t)kLossBatch : std::max(1u, std::min((uint32_t)kLossBatchWide, kLossWinBytes / (cap64 * 128u)));
+    out[5] = loss_nb_run(c, mk);
     return 0;
 }
 

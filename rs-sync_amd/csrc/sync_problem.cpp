@@ -207,21 +207,10 @@ class SyncProblemHip final : public ISyncProblem {
     void debug_rays(int64_t frame, float* a4, float* b4, size_t cap);
 
     // pieces shared by the public calls and the diagnostics
-    // collective = false: a rank-local diagnostic (problem_matrix, frame_rays): no exchange with other ranks -- the
-    // kernel shapes agreed by the last collective call stay (or, before any, this rank's own largest frame decides)
-    void ensure_device(bool collective = true);
-    // One agreement on the kernel shapes per PUBLIC call: the entry points that call each other (sync_points ->
-    // presync_windows / sync_windows, orientation_sweep -> PreSync) open a scope, and only the first ensure_device
-    // inside it exchanges (frames cannot change within a call).
-    struct CollectiveCall {
-        SyncProblemHip* s;
-        explicit CollectiveCall(SyncProblemHip* s_) : s(s_) { if (s->coll_depth_++ == 0) s->coll_agreed_ = false; }
-        ~CollectiveCall() { --s->coll_depth_; }
-        CollectiveCall(const CollectiveCall&) = delete;
-        CollectiveCall& operator=(const CollectiveCall&) = delete;
-    };
-    int coll_depth_ = 0;
-    bool coll_agreed_ = false;
+    // (Rounds 2-4: ranks first agreed on the problem's largest frame here, one exchange per public call, because the
+    // kernel shapes followed it.  Since round 5 a frame's kernels follow its OWN track count -- size classes in the device
+    // context -- and nobody has to agree on anything: no exchange, in collective calls or diagnostics.)
+    void ensure_device();
     void ensure_spline() { if (spline_dirty_) build_spline(); }
     uint32_t select(int64_t begin, int64_t end_exclusive);
     std::vector<double> sweep(const std::vector<double>& delays, uint32_t stream_base, bool panics,
@@ -254,9 +243,8 @@ class SyncProblemHip final : public ISyncProblem {
     bool distributed() const { return native_exchange || reduce_fn; }
     uint64_t exchange_calls = 0, exchange_doubles = 0; // sums exchanged with other ranks so far
     void rccl_shutdown();
-    // The largest per-frame track count over ALL ranks, given by the caller (0 = not given: the ranks agree on
-    // it with one small exchange per call, agree_on_tracks_hint).
-    void set_tracks_hint(uint32_t n) { tracks_hint_explicit_ = n; }
+    // (rounds 2-4: the largest per-frame track count over all ranks; a no-op since the kernels follow each frame's own size)
+    void set_tracks_hint(uint32_t) {}
     void reduce(double* buf, size_t n) {
         if (distributed()) { exchange_calls += 1; exchange_doubles += n; }
         if (native_exchange) hip_check(shards_[0], rship_rccl_allreduce(shards_[0].ctx, buf, n), "rccl all-reduce");
@@ -325,10 +313,8 @@ class SyncProblemHip final : public ISyncProblem {
     }
     void create_shards(const std::vector<int>& ids);
     void destroy_shards();
-    void agree_on_tracks_hint(bool exchange);
     // options that live in the device contexts, kept here so that set_devices (new contexts) does not lose them
     int opt_lbfgs_reeval_ = 0, opt_profile_ = 0;
-    uint32_t tracks_hint_explicit_ = 0, local_max_tracks_ = 0, applied_hint_ = 0xffffffffu;
     // slots (table indices, window-major; off = window offsets or empty for one ungrouped window) -> per-shard
     // selections; plan windows = the given lists of slot positions (plan_off/plan_pos) or, if empty, the groups
     void apply_selection(const std::vector<uint32_t>& slots, const std::vector<uint32_t>& grp_off,
@@ -406,7 +392,6 @@ void SyncProblemHip::create_shards(const std::vector<int>& ids) {
         shards_.push_back(sh);
     }
     // what the caller had switched on applies to the new contexts as well
-    applied_hint_ = 0xffffffffu;
     if (opt_lbfgs_reeval_) set_option(RSHIP_OPT_LBFGS_REEVAL, opt_lbfgs_reeval_);
     if (opt_profile_) profile_enable(opt_profile_);
 }
@@ -437,40 +422,6 @@ void SyncProblemHip::set_option(int option, int value) {
 void SyncProblemHip::profile_enable(int on) {
     opt_profile_ = on != 0;
     for (Shard& sh : shards_) hip_check(sh, rship_profile_enable(sh.ctx, on), "profile");
-}
-
-// Kernels whose workgroup shape fixes the order of a frame's sums pick the shape from the largest frame of the
-// whole PROBLEM (RSHIP_OPT_TRACKS_HINT), so that a frame gets the same sums on any device, in any selection and
-// on any rank.  Only the size CLASS matters (multiples of 64 tracks up to 8192, powers of two above: every
-// threshold the launchers test is one of those), so ranks agree on it with a sum: each adds a one into the slot
-// of its own class and the highest occupied slot wins -- the reduce hook knows neither rank nor world size.
-// One small exchange per collective call, unless the caller has given the number (rssync_ext_set_tracks_hint).
-void SyncProblemHip::agree_on_tracks_hint(bool exchange) {
-    constexpr uint32_t kFine = 128; // classes 0..128: ceil(n / 64)
-    auto cls = [](uint32_t n) -> uint32_t {
-        if (n <= 64u * kFine) return (n + 63u) / 64u;
-        uint32_t c = kFine;
-        for (uint64_t cap = 64ull * kFine; cap < n; cap *= 2) ++c;
-        return c;
-    };
-    auto bound = [](uint32_t c) -> uint32_t {
-        if (c <= kFine) return 64u * c;
-        const uint64_t v = (64ull * kFine) << (c - kFine);
-        return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v;
-    };
-    uint32_t c = cls(tracks_hint_explicit_ ? tracks_hint_explicit_ : local_max_tracks_);
-    if (!tracks_hint_explicit_ && distributed() && exchange) {
-        double slots[kFine + 21] = {};
-        slots[c] = 1.0;
-        reduce(slots, kFine + 21);
-        for (uint32_t i = 0; i < kFine + 21; ++i)
-            if (slots[i] > 0) c = i;
-    }
-    const uint32_t hint = bound(c);
-    if (hint != applied_hint_) {
-        set_option(RSHIP_OPT_TRACKS_HINT, (int)std::min<uint32_t>(hint, 0x7fffffffu));
-        applied_hint_ = hint;
-    }
 }
 
 void SyncProblemHip::rccl_shutdown() {
@@ -696,7 +647,6 @@ void SyncProblemHip::orientation_sweep(const double* ts, const double* rates, si
                                        int64_t frame_begin, int64_t frame_end, double search_step,
                                        double search_radius, double* costs, double* delays) {
     if (orientations.empty()) return;
-    CollectiveCall scope(this); // (one PreSync per orientation: the ranks agree on the kernel shapes once)
     for (const std::string& o : orientations) {
         int32_t axis[3];
         double sign[3];
@@ -807,8 +757,6 @@ void SyncProblemHip::pack_frames() {
         cut[d] = best;
     }
     if (S == 1) upload_new_records();
-    local_max_tracks_ = 0;
-    for (size_t i = 0; i < nf; ++i) local_max_tracks_ = std::max(local_max_tracks_, table[i].n_rays);
     uint32_t bad = 0;
     for (size_t d = 0; d < S; ++d) {
         Shard& sh = shards_[d];
@@ -849,6 +797,10 @@ void SyncProblemHip::pack_frames() {
         bad += b;
     }
     if (bad) panic("set-track-result: non-finite numbers in rays (" + std::to_string(bad) + " tracks; lens parameters?)");
+    // several devices: every shard plans its LDS spline windows from the frames of the WHOLE problem, as the single
+    // device would (window_plan.hpp: plan_window_frames), so that a frame takes the same spline path wherever it lives
+    if (S > 1)
+        for (Shard& sh : shards_) hip_check(sh, rship_set_problem_frames(sh.ctx, table.data(), (uint32_t)nf), "problem frames");
     sel_.clear();
     window_key_.clear();
     frames_dirty_ = false;
@@ -937,18 +889,10 @@ void SyncProblemHip::combine(size_t rows, size_t n_win, Collect&& collect, doubl
     }
 }
 
-void SyncProblemHip::ensure_device(bool collective) {
+void SyncProblemHip::ensure_device() {
     if (n_knots_ < 2) panic("sync: gyro data was not set");
     if (spline_dirty_) build_spline();
     if (frames_dirty_) pack_frames();
-    if (!collective) {
-        // rank-local: never an exchange (a call made on one rank only must not enter a collective)
-        if (!distributed() || tracks_hint_explicit_ || applied_hint_ == 0xffffffffu) agree_on_tracks_hint(false);
-        return;
-    }
-    if (coll_depth_ > 0 && coll_agreed_) return;
-    agree_on_tracks_hint(true); // (an exchange when other ranks take part and no hint was given: the call is collective then)
-    coll_agreed_ = true;
 }
 
 uint32_t SyncProblemHip::get_motion(double* M, double* k, uint32_t cap) {
@@ -1469,11 +1413,13 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
     }
 
     const double c_armijo = 2e-4, decay = .1, t0 = 1e-3; // :226
-    // the fewest trials a search's first batch holds: five where a trial is cheap, one for frames of 1024 tracks and
-    // more (the largest frame over all ranks -- the agreed size class, so that every rank batches alike; the same rule
-    // as the device loop's SyncLoopParams::nf_floor).  Only the batching depends on it, never a result.
+    // the fewest trials a search's first batch holds: five where a trial is cheap, one where the selection has frames
+    // of 1024 tracks and more -- but always five with ranks, which must batch alike without knowing each other's frames
+    // (the same rule as the device loop's SyncLoopParams::nf_floor).  Only the batching depends on it, never a result.
     const int max_bt = 10;
-    int half_bt = (applied_hint_ != 0xffffffffu && applied_hint_ >= 1024u) ? 1 : 5;
+    uint32_t sel_max_tracks = 0;
+    for (uint32_t i : sel_) sel_max_tracks = std::max(sel_max_tracks, frames_.at(table_ids_[i]).n);
+    int half_bt = (!distributed() && sel_max_tracks >= 1024u) ? 1 : 5;
     if (const char* e = std::getenv("RSSYNC_LOOP_TRIALS_FLOOR")) { const int v = std::atoi(e); if (v >= 1 && v <= max_bt) half_bt = v; }
     const double delay_b = .3; // :260
     const double kOff = std::numeric_limits<double>::quiet_NaN();
@@ -1630,7 +1576,6 @@ void SyncProblemHip::presync_windows(double initial_delay, const std::vector<int
 void SyncProblemHip::sync_points(const std::vector<int64_t>& positions, int64_t window, double initial_delay,
                                  bool use_presync, double presync_step, double presync_radius, int repeats,
                                  std::vector<double>& costs, std::vector<double>& delays_out) {
-    CollectiveCall scope(this); // (PreSync of all windows + repeats x Sync: the ranks agree on the kernel shapes once)
     const size_t W = positions.size();
     std::vector<int64_t> ends(W);
     for (size_t w = 0; w < W; ++w) ends[w] = positions[w] + window;
@@ -1933,7 +1878,7 @@ int rssync_ext_problem_matrix(rssync_problem* p, int64_t frame, double delay, fl
                               size_t* n_rows) {
     return guarded([&] {
         SyncProblemHip* s = p->impl;
-        s->ensure_device(false); // rank-local: no exchange
+        s->ensure_device();
         if (!s->has_frame(frame)) panic("problem_matrix: unknown frame");
         s->select(frame, frame + 1);
         s->debug_problem(frame, delay, P, dP, nullptr, nullptr, cap_rows);
@@ -2053,7 +1998,7 @@ int rssync_ext_problem_matrix64(rssync_problem* p, int64_t frame, double delay, 
                                 size_t* n_rows) {
     return guarded([&] {
         SyncProblemHip* s = p->impl;
-        s->ensure_device(false); // rank-local: no exchange
+        s->ensure_device();
         if (!s->has_frame(frame)) panic("problem_matrix: unknown frame");
         s->select(frame, frame + 1);
         s->debug_problem(frame, delay, nullptr, nullptr, P, dP, cap_rows);
@@ -2091,7 +2036,7 @@ int rssync_ext_orientation_sweep(rssync_problem* p, const double* timestamps_s, 
 int rssync_ext_frame_rays(rssync_problem* p, int64_t frame, float* a4, float* b4, size_t cap, size_t* n) {
     return guarded([&] {
         SyncProblemHip* s = p->impl;
-        s->ensure_device(false); // rank-local: no exchange
+        s->ensure_device();
         for (uint32_t i = 0;; ++i) {
             if (i >= s->table_size()) panic("frame_rays: no such frame");
             if (s->table_id(i) != frame) continue;

@@ -102,4 +102,76 @@ inline WinPlan plan_window(double span, double ends, double step_knots, uint32_t
     return w; // does not fit any LDS share: the general path
 }
 
+// ---- per-FRAME planning (round 5) -----------------------------------------------------------------------------
+// The reference evaluates every frame on its own (core_private.cpp:73-86, :231-238, :263-295): nothing about frame i
+// knows frame j.  Rounds 1-4 planned a launch's window from the WIDEST frame of the table, so that one frame too wide
+// for any LDS window sent every other frame of its problem to the general spline path (other fp32 roundings), and a
+// shard that did not hold that frame planned differently from the single-device run.  Now a launch is planned from the
+// frames that CAN have a window at all -- a frame is ELIGIBLE if its own knots (whole pair, or its two ends) plus the
+// shortest chunk of candidates fit the largest window the kernel can run with; the others read the table from L2, as
+// they would alone -- so whether a frame takes the interior path follows from the frame, not from its neighbours.
+struct FrameDims {
+    uint32_t n;  // tracks
+    float span;  // knots the pair touches at one delay
+    float ends;  // the same counting only the two ends' ranges (= span where unknown or not fewer)
+};
+inline float frame_span(float tmin, float tmax) { return std::floor(tmax) - std::floor(tmin) + 2.f; }
+// range_a / range_b as rship_frame holds them (lo | hi << 16, 0xffffffff = unknown)
+inline float frame_ends(uint32_t range_a, uint32_t range_b, float span) {
+    if (range_a == 0xffffffffu || range_b == 0xffffffffu) return span;
+    const int a_lo = (int)(range_a & 0xffffu), a_hi = (int)(range_a >> 16) + 1;
+    const int b_lo = (int)(range_b & 0xffffu), b_hi = (int)(range_b >> 16) + 1;
+    if (b_lo > a_hi + 1 || a_lo > b_hi + 1) return std::min(span, (float)((a_hi - a_lo + 1) + (b_hi - b_lo + 1)));
+    return span;
+}
+// the largest dynamic window (knots) a kernel with `fixed_lds` bytes of static LDS can be launched with
+inline uint32_t plan_cap_limit(bool small, uint32_t fixed_lds, int lds_per_cu) {
+    const int share = lds_per_cu - 1024;
+    if (share <= (int)fixed_lds) return 0;
+    uint32_t cap_t = std::min(2048u, ((uint32_t)share - fixed_lds) / 64u / 4u * 4u);
+    if (small) cap_t = std::min(cap_t, kPlanSmallWinMax);
+    return cap_t;
+}
+// The fp32 window of an LMedS launch over the frames f[0 .. nf) whose track count lies in [n_lo, n_hi] (one size class).
+// Same result as plan_window(span, ends, ...) of the class's widest frame whenever every frame of the class is eligible.
+inline WinPlan plan_window_frames(const FrameDims* f, size_t nf, uint32_t n_lo, uint32_t n_hi, double step_knots, uint32_t chunk_want,
+                                  bool small, int wg_max, uint32_t fixed_lds, int lds_per_cu, bool legacy) {
+    WinPlan w;
+    w.chunk = chunk_want;
+    const uint32_t min_chunk = std::min(8u, chunk_want);
+    double span_all = 0.0, ends_all = 0.0;
+    for (size_t i = 0; i < nf; ++i)
+        if (f[i].n >= n_lo && f[i].n <= n_hi && f[i].n) { span_all = std::max(span_all, (double)f[i].span); ends_all = std::max(ends_all, (double)f[i].ends); }
+    const uint32_t f80 = plan_fit((double)kPlanWinStatic, span_all, step_knots, chunk_want);
+    if (f80 >= min_chunk || legacy || !fixed_lds) return plan_window(span_all, ends_all, step_knots, chunk_want, small, wg_max, fixed_lds, lds_per_cu, legacy);
+    const double limit = (double)plan_cap_limit(small, fixed_lds, lds_per_cu);
+    double span_e = 0.0, ends_e = 0.0;
+    bool any = false;
+    for (size_t i = 0; i < nf; ++i) {
+        if (f[i].n < n_lo || f[i].n > n_hi || !f[i].n) continue;
+        const bool fits = plan_fit(limit, f[i].span, step_knots, min_chunk) >= min_chunk ||
+                          (f[i].ends < f[i].span && plan_fit_ends(limit, f[i].ends, step_knots, min_chunk) >= min_chunk);
+        if (!fits) continue;
+        any = true;
+        span_e = std::max(span_e, (double)f[i].span);
+        ends_e = std::max(ends_e, (double)f[i].ends);
+    }
+    if (!any) return w; // nobody can have a window: the compiled-in one (its frames take the general path)
+    return plan_window(span_e, ends_e, step_knots, chunk_want, small, wg_max, fixed_lds, lds_per_cu, legacy);
+}
+// knots of the fp64 window for the frames of one size class: the widest frame that a window of at most `limit` knots
+// (kPlanCap64Max; kPlanCap64SmallMax for the one-wave kernels, above which a knot of window costs more in resident waves
+// than the general path's fetches from L2) can hold; wider frames read the table from L2 -- the same bits either way
+inline uint32_t cap64_frames(const FrameDims* f, size_t nf, uint32_t n_lo, uint32_t n_hi, bool one_wave) {
+    const uint32_t limit = one_wave ? kPlanCap64SmallMax : kPlanCap64Max;
+    uint32_t need = kPlanWinStatic;
+    for (size_t i = 0; i < nf; ++i) {
+        if (f[i].n < n_lo || f[i].n > n_hi || !f[i].n) continue;
+        uint32_t k = (uint32_t)std::ceil(std::max(std::min(f[i].span, f[i].ends), 0.f)) + 1u;
+        k = (k + 15u) / 16u * 16u;
+        if (k <= limit && k > need) need = k;
+    }
+    return need;
+}
+
 } // namespace rs

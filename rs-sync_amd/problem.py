@@ -304,7 +304,8 @@ class SyncProblem:
         self._check(self._lib.rssync_ext_rccl_shutdown(self._h))
 
     def set_tracks_hint(self, max_tracks_all_ranks):
-        """Largest per-frame track count over all ranks (0: the ranks agree on it with an exchange per call)."""
+        """A no-op since round 5 (kept for callers written against round 4, when the kernel shapes followed the problem's
+        largest frame and ranks had to agree on it): a frame's kernels follow its own track count."""
         self._lib.rssync_ext_set_tracks_hint(self._h, int(max_tracks_all_ranks))
 
     def exchange_stats(self):

@@ -50,7 +50,6 @@ struct rship_ctx {
     std::vector<uint32_t> sel, grp, grp_off; // slots, slot -> window, window offsets
     std::vector<double> M, k;                // per slot
     int lbfgs_reeval = 0;
-    uint32_t tracks_hint = 0;
     // reduction plan and the results of the last *_enqueue
     std::vector<uint32_t> plan_idx, plan_chunk_off, plan_win_off;
     bool plan_has_idx = false;
@@ -163,7 +162,7 @@ void rship_destroy(rship_ctx* c) { delete c; }
 const char* rship_last_error(const rship_ctx* c) { return c->err.c_str(); }
 int rship_set_stream(rship_ctx*, void*) { return 0; }
 int rship_set_option(rship_ctx* c, int option, int value) {
-    if (option == RSHIP_OPT_TRACKS_HINT) { c->tracks_hint = value > 0 ? (uint32_t)value : 0u; return 0; } // K3's workgroup shape
+    if (option == RSHIP_OPT_TRACKS_HINT) return 0; // (ignored since round 5: a frame's shape follows its own track count)
     if (option != RSHIP_OPT_LBFGS_REEVAL) return fail(c, "set_option: unknown option");
     c->lbfgs_reeval = value != 0;
     return 0;
@@ -343,6 +342,8 @@ int rship_pack_frames(rship_ctx* c, const rship_frame* table, const rship_pack_f
     return 0;
 }
 
+int rship_set_problem_frames(rship_ctx*, const rship_frame*, uint32_t) { return 0; } // (window planning: nothing to plan here)
+
 // the native exchange needs a GPU and librccl: not part of the test double
 int rship_rccl_preflight(rship_ctx* c) { return fail(c, "rccl: device only"); }
 const char* rship_rccl_library(rship_ctx*) { return ""; }
@@ -504,10 +505,10 @@ double wave_sum_order(const double* lanes) {
     return (v[63] + v[47]) + (v[31] + v[15]);
 }
 
-// the workgroup shape launch_motion64 picks (rows per thread, waves) from the largest frame of the problem
-void motion_shape(const rship_ctx* c, int& rpt, int& nw) {
-    uint32_t n = c->tracks_hint;
-    for (uint32_t i : c->sel) n = std::max(n, c->frames[i].n_rays);
+// the workgroup shape launch_motion64 picks (rows per thread, waves) for a frame of n tracks: its size class, whatever
+// else the problem holds (a thread adds its rows in order and rows beyond the frame add zeros, so inside the one-wave /
+// four-wave family the sums do not depend on the rows per thread)
+void motion_shape(uint32_t n, int& rpt, int& nw) {
     if (n <= 64) { rpt = 1; nw = 1; }
     else if (n <= 128) { rpt = 2; nw = 1; }
     else if (n <= 192) { rpt = 3; nw = 1; }
@@ -601,9 +602,9 @@ struct LbfgsHistCpu {
 // opt_motion64_kernel, one slot after the other
 void motion_pass(rship_ctx* c, const int32_t* kdv, const double* fdv, int max_iters, bool simple_k, uint64_t* stats) {
     uint64_t tot_it = 0, tot_ev = 0, tot_bnl = 0;
-    int rpt = 1, nw = 1;
-    motion_shape(c, rpt, nw);
     for (size_t sl = 0; sl < c->sel.size(); ++sl) {
+        int rpt = 1, nw = 1;
+        motion_shape(c->frames[c->sel[sl]].n_rays, rpt, nw);
         const uint32_t grp = c->grp[sl];
         const int32_t kd = kdv[grp];
         const double fd = fdv[grp];

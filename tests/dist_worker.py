@@ -27,7 +27,6 @@ def main():
     synth.fill(p, gyro, b, e, N, seed=6, noise=0.0, outliers=0.0)
     hook = make_reduce_hook("cpu")
     p.set_reduce_hook(hook)
-    p.set_tracks_hint(N)  # every rank holds N-track frames: no exchange needed to agree on the kernel shapes
     c0, d0 = p.PreSync(0.0, 0, F, 0.004, 0.1)
     n_pre = hook.stats["calls"]
     c1, d1 = p.Sync(d0, 0, F - 1, 0.0, 0.2)
@@ -41,9 +40,9 @@ def main():
     wc, wd = p.pre_sync_windows(0.02, [0, 3, 6, 9], [6, 9, 12, 15], 0.0001, 0.105)
     big = dict(costs=list(map(float, wc)), delays=list(map(float, wd)), calls=hook.stats["calls"] - n_before,
                doubles=hook.stats["doubles"])
-    # ranks with DIFFERENT largest frames (rank 0: 96 tracks, rank 1: 600) and no hint given: every call starts
-    # with one small exchange in which the ranks agree on the size class that fixes the kernels' shapes, so a
-    # frame's sums are the same bits whichever rank holds it
+    # ranks with DIFFERENT largest frames (rank 0: 96 tracks, rank 1: 600): a frame's kernels -- and with them the order
+    # of its sums -- follow the frame's OWN track count, so a frame's sums are the same bits whichever rank holds it and
+    # whatever the other ranks hold, without any exchange to agree on anything
     n_of = lambda fr: 96 if fr < 8 else 600
     q = rssync_amd.SyncProblem(seed=321, max_outer_iters=6, _lib=lib)
     q.SetGyroQuaternions(gyro.quats, gyro.fs, gyro.t0)
@@ -51,7 +50,7 @@ def main():
         q.SetTrackResult(*next(iter(synth.make_frames(gyro, fr, fr + 1, n_of(fr), seed=6))))
     hook2 = make_reduce_hook("cpu")
     q.set_reduce_hook(hook2)
-    M, k = q.init_motion(0.03, 0, F - 1)  # GuessMotion + GuessK of this rank's frames (collective: the agreement)
+    M, k = q.init_motion(0.03, 0, F - 1)  # GuessMotion + GuessK of this rank's frames (rank-local: no exchange)
     init_calls = hook2.stats["calls"]
     mc, md = q.Sync(0.03, 0, F - 1, 0.0, 0.2)
     mixed = dict(sync=[mc, md], iters=len(q.sync_trace()), calls=hook2.stats["calls"] - init_calls, init_calls=init_calls,
@@ -67,7 +66,6 @@ def main():
         r.SetTrackResult(*fr)
     hook3 = make_reduce_hook("cpu")
     r.set_reduce_hook(hook3)
-    r.set_tracks_hint(N5)
     oc, od = r.orientation_sweep(g5.times, g5.rates, names, 0.0, 30, 30 + F5, 0.004, 0.1)
     sweep = dict(costs=list(map(float, oc)), delays=list(map(float, od)), calls=hook3.stats["calls"], frames=[b5, e5])
     res = dict(rank=rank, big=big, mixed=mixed, sweep=sweep, frames=[b, e], presync=[c0, d0], sync=[c1, d1], iters=iters,

@@ -1,6 +1,7 @@
 """One rank of the 2-rank GPU test (both ranks share the box's one GPU; gloo carries the sums): rank 0 holds frames
-of 96 tracks, rank 1 frames of 600 tracks.  Without agreement on the problem-wide size class rank 0 would run its
-frames through the one-wave kernels and the single-process run through the tile kernels: other summation orders."""
+of 96 tracks, rank 1 frames of 600 tracks.  A frame's kernels follow its OWN track count (size classes, round 5): rank 0
+runs its frames through the one-wave kernels, and so does the single-process run that holds both kinds -- the same bits,
+with no exchange to agree on anything (rounds 2-4: one exchange per call so that both took the tile kernels)."""
 import json
 import os
 import sys

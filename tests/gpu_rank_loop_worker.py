@@ -31,7 +31,6 @@ def main():
         p.SetGyroQuaternions(gyro.quats, gyro.fs, gyro.t0)
         for fr in range(b, e):
             p.SetTrackResult(*next(iter(synth.make_frames(gyro, fr, fr + 1, N, seed=8))))
-        p.set_tracks_hint(N)
         p.set_reduce_hook(make_reduce_hook("cpu"))
         p.set_hook_device_loop(mode == "device")
         x0 = p.exchange_stats()[0]

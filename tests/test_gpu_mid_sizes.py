@@ -287,8 +287,10 @@ def test_more_than_8192_tracks_per_frame(N):
 
 
 def test_large_and_small_frames_in_one_problem():
-    """one frame of 9000 tracks among frames of 300: the whole problem takes the large-frame kernels (the kernel
-    choice follows the problem's largest frame), every frame still matches the oracle"""
+    """one frame of 9000 tracks among frames of 300: the large frame takes the large-frame kernels, the others the
+    one-wave kernels they would take alone (round 5: size classes -- rounds 3-4 sent the whole problem through the slow
+    exact kernels) -- every frame's PreSync costs, winners and GuessK are, bit for bit, those of the same frame in a
+    problem of its own class only, and the whole still matches the oracle"""
     import rssync_amd
     from rssync_amd import synth
     from oracle.oracle import OracleProblem
@@ -302,6 +304,24 @@ def test_large_and_small_frames_in_one_problem():
         for fr in range(F):
             p.SetTrackResult(*next(iter(synth.make_frames(g, fr, fr + 1, n_of(fr), seed=17, noise=3e-4, outliers=0.05))))
     _check_large_frames(h, o, F, n_of, "mixed_9000_300", n_cand_step=0.02)
+    # single-class problems: the 300-track frames without the large one, the large one alone
+    def only(frs):
+        q = rssync_amd.SyncProblem(seed=SEED, max_outer_iters=12)
+        q.SetGyroQuaternions(g.quats, g.fs, g.t0)
+        for fr in frs:
+            q.SetTrackResult(*next(iter(synth.make_frames(g, fr, fr + 1, n_of(fr), seed=17, noise=3e-4, outliers=0.05))))
+        return q
+    mixed = only(range(F))
+    _, _, fc, bh = mixed.presync_curve(0.0, 0, F, 0.02, 0.1, per_frame=F)
+    M, k = mixed.init_motion(0.036, 0, F - 1)
+    for frs in ([0, 1, 3, 4], [2]):
+        q = only(frs)
+        _, _, fc1, bh1 = q.presync_curve(0.0, 0, F, 0.02, 0.1, per_frame=len(frs))
+        M1, k1 = q.init_motion(0.036, 0, F - 1)
+        np.testing.assert_array_equal(fc1, fc[:, frs])
+        np.testing.assert_array_equal(bh1, bh[:, frs])
+        np.testing.assert_array_equal(M1, M[frs])
+        np.testing.assert_array_equal(k1, k[frs])
 
 
 def test_track_limit_is_an_indexing_bound():

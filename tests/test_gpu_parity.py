@@ -625,12 +625,13 @@ def test_rccl_reduce_hook_on_the_device(tmp_path):
     for k in ("_trace", "_windows"):
         assert r["plain" + k] == r["rccl" + k] == r["native" + k] == r["native_host" + k], k
     its = r["native"][4]
-    # the size-class agreement + the final loss, and in between -- device loop: two all-reduces per ENQUEUED iteration
-    # (a block of eight, then blocks of four); host loop: one per launch
-    assert r["native_sync_exchanges"] == 1 + 2 * _enqueued(its) + 1
-    assert 1 + 2 * its + 1 <= r["native_host_sync_exchanges"] <= 1 + 3 * its + 1
-    # PreSync: the size-class agreement + the sweep; Sync: the agreement + 2 per outer iteration + the final loss
-    assert r["rccl_sync_exchanges"] == 1 + 2 * r["rccl"][4] + 1 and r["exchanges"] > r["rccl_sync_exchanges"]
+    # the final loss, and before it -- device loop: two all-reduces per ENQUEUED iteration (a block of eight, then blocks
+    # of four); host loop: one per launch.  Nothing else: since round 5 the ranks agree on no kernel shape (a frame's
+    # kernels follow its own track count), which rounds 2-4 paid one more exchange per call for.
+    assert r["native_sync_exchanges"] == 2 * _enqueued(its) + 1
+    assert 2 * its + 1 <= r["native_host_sync_exchanges"] <= 3 * its + 1
+    # PreSync: the sweep; Sync: 2 per outer iteration + the final loss
+    assert r["rccl_sync_exchanges"] == 2 * r["rccl"][4] + 1 and r["exchanges"] > r["rccl_sync_exchanges"]
 
 
 @pytest.mark.parametrize("fs,N", [(50.0, 600), (100.0, 200), (400.0, 200), (2000.0, 200), (2000.0, 400), (4000.0, 200), (2000.0, 600),
@@ -923,7 +924,7 @@ def test_ranked_device_loop_with_two_ranks(tmp_path):
             assert r["host"][key] == r["device"][key], key
         assert len(r["device"]["trace"]) >= 5
         its = len(r["device"]["trace"])
-        assert r["device"]["exchanges"] == 2 * _enqueued(its) + 1     # (explicit hint: no agreement exchange)
+        assert r["device"]["exchanges"] == 2 * _enqueued(its) + 1     # (and no exchange to agree on kernel shapes: size classes)
     for key in ("sync", "trace", "cw", "dw", "wtr", "one", "one_trace", "simplified"):
         assert res[0]["device"][key] == res[1]["device"][key], key               # both ranks took the same decisions
     assert len(res[1]["device"]["one_trace"]) >= 3                               # (rank 1 held none of that window's frames)

@@ -1,0 +1,145 @@
+"""A frame's bits and speed depend on its OWN track count only (round 5: size classes).
+
+The reference evaluates every frame in its own lambda (core_private.cpp:73-86 PreSync, :231-238 / :245-250 the loss
+sums, :263-295 the per-frame L-BFGS): nothing about frame i knows frame j's track count.  Rounds 2-4 picked the kernel
+family -- and with it the order of a frame's sums -- from the LARGEST frame of the whole problem.  Now a selection is cut
+into one slot list per size class ({<= 512 tracks: one wave per frame}, {<= 1024, 2048, 4096, 8192: four waves with 4 / 8
+/ 16 / 32 rows per thread}, {more: rows in global memory}) and every class runs its own kernels
+(rssync_kernels.hip: class_of, class_ranges).  These tests demand, bit for bit, that a frame gives the same PreSync
+costs and winners, the same GuessMotion / GuessK, the same loss and derivative and the same Sync trace whether it is
+evaluated ALONE in a problem or among frames of every other class -- and that the whole still matches the oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 123
+THREADS = min(os.cpu_count() or 1, 16)
+# one frame of every class: one wave (96, 300), four waves with 4 / 8 / 16 / 32 rows per thread, rows in global memory
+COUNTS = [96, 300, 600, 1500, 3000, 5000, 9000]
+
+
+def _frames(gyro, counts, seed, **kw):
+    from rssync_amd import synth
+    return [next(iter(synth.make_frames(gyro, fr, fr + 1, n, seed=seed, **kw))) for fr, n in enumerate(counts)]
+
+
+def _problem(gyro, frames, **kw):
+    import rssync_amd
+    p = rssync_amd.SyncProblem(seed=SEED, verbose=False, **kw)
+    p.SetGyroQuaternions(gyro.quats, gyro.fs, gyro.t0)
+    for f in frames:
+        p.SetTrackResult(*f)
+    return p
+
+
+def test_a_frames_bits_do_not_depend_on_its_neighbours():
+    from rssync_amd import synth
+    F = len(COUNTS)
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=31)
+    frames = _frames(g, COUNTS, seed=31, noise=5e-4, outliers=0.08)
+    mixed = _problem(g, frames, max_outer_iters=8)
+    d, c, fc, bh = mixed.presync_curve(0.03, 0, F, 0.001, 0.012, per_frame=F)       # 24 candidates x 7 frames
+    M, k = mixed.init_motion(0.0362, 0, F - 1)
+    L, G = mixed.loss([0.0362, 0.03, 0.041], grad=True)
+    per_frame_loss = []
+    for fr in range(F):
+        lone = _problem(g, [frames[fr]], max_outer_iters=8)
+        d1, c1, fc1, bh1 = lone.presync_curve(0.03, 0, F, 0.001, 0.012, per_frame=1)
+        np.testing.assert_array_equal(d1, d)
+        np.testing.assert_array_equal(bh1[:, 0], bh[:, fr], err_msg="PreSync winners of the %d-track frame" % COUNTS[fr])
+        np.testing.assert_array_equal(fc1[:, 0], fc[:, fr], err_msg="PreSync costs of the %d-track frame" % COUNTS[fr])
+        M1, k1 = lone.init_motion(0.0362, 0, F - 1)
+        np.testing.assert_array_equal(M1[0], M[fr], err_msg="GuessMotion of the %d-track frame" % COUNTS[fr])
+        np.testing.assert_array_equal(k1[0], k[fr], err_msg="GuessK of the %d-track frame" % COUNTS[fr])
+        per_frame_loss.append(lone.loss([0.0362, 0.03, 0.041], grad=True))
+        # Sync of the frame's own one-frame window: the mixed problem's table holds six other classes, the lone one none
+        ca, da = lone.Sync(0.036, fr, fr, 0.0, 0.2)
+        tra = lone.sync_trace()
+        other = _problem(g, frames, max_outer_iters=8)
+        other.init_motion(0.0362, 0, F - 1)        # (the lone problem has made one Sync-side call before: same sampler stream)
+        cb, db = other.Sync(0.036, fr, fr, 0.0, 0.2)
+        assert (ca, da) == (cb, db), COUNTS[fr]
+        np.testing.assert_array_equal(tra, other.sync_trace())
+    # the window sums of the mixed problem are the sequential sums of the frames' own values (one chunk of the plan)
+    for j in range(3):
+        acc_l = acc_g = 0.0
+        for fr in range(F):
+            acc_l += per_frame_loss[fr][0][j]
+            acc_g += per_frame_loss[fr][1][j]
+        assert L[j] == acc_l and G[j] == acc_g
+
+
+def test_every_class_in_one_problem_against_the_oracle():
+    """the same mixed problem against the CPU restatement: rows, PreSync winners and costs, GuessK, loss, Sync"""
+    from rssync_amd import synth
+    from oracle.oracle import OracleProblem
+    from oracle import oracle as ora
+    F = len(COUNTS)
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=31)
+    frames = _frames(g, COUNTS, seed=31, noise=3e-4, outliers=0.05)
+    h = _problem(g, frames, max_outer_iters=10)
+    o = OracleProblem(seed=SEED, threads=THREADS, faithful=False, max_outer_iters=10)
+    o.SetGyroQuaternions(g.quats, g.fs, g.t0)
+    for f in frames:
+        o.SetTrackResult(*f)
+    dh, ch, fch, bhh = h.presync_curve(0.03, 0, F, 0.001, 0.012, per_frame=F)
+    do, co, fco, bho = o.presync_curve(0.03, 0, F, 0.001, 0.012, per_frame=F)
+    np.testing.assert_array_equal(dh, do)
+    same = bhh == bho
+    assert same.mean() > 0.97, same.mean()
+    rel = np.abs(fch - fco) / fco
+    assert rel[same].max() < 1e-3 and np.median(rel[same]) < 2e-6
+    assert np.argmin(ch) == np.argmin(co)
+    Mh, kh = h.init_motion(0.0362, 0, F - 1)
+    agree = 0
+    for f in range(F):
+        Mo, _, _ = o.guess_motion(f, 0.0362, 200, ora.STREAM_SYNC_INIT + 0)
+        if np.abs(Mh[f] - Mo).max() < 1e-12:
+            agree += 1
+            ko = np.clip(100 / np.linalg.norm(o.problem_matrix(f, 0.0362) @ Mo), 10, 1000)
+            assert kh[f] == pytest.approx(ko, rel=1e-12)
+    assert agree >= F - 1                          # the fp32 search may flip one near-tie
+    Lh, Gh = h.loss([0.0362, 0.03], grad=True)
+    for j, dd in enumerate((0.0362, 0.03)):
+        per = [o.loss(f, dd, Mh[f], kh[f]) for f in range(F)]
+        assert Lh[j] == pytest.approx(sum(p[0] for p in per), rel=1e-12)
+        assert Gh[j] == pytest.approx(sum(p[2] for p in per), rel=1e-10, abs=1e-10 * abs(Lh[j]))
+    # Sync from the oracle's GuessMotion winners (the fp32 search may flip a near-tie; the optimisation is what is compared)
+    co2, do2, tro = o.sync_trace(0.036, 0, F - 1, 0.0, 0.2)
+    h2 = _problem(g, frames, max_outer_iters=10)
+    h2.set_init_override(o.last_init_winners())
+    ch2, dh2 = h2.Sync(0.036, 0, F - 1, 0.0, 0.2)
+    assert abs(dh2 - do2) < 1e-6 and ch2 == pytest.approx(co2, rel=1e-8)
+    assert len(h2.sync_trace()) == len(tro)
+
+
+def test_batched_windows_of_mixed_classes_equal_the_sequential_calls():
+    """sync_windows / sync_points over windows that hold frames of several classes (the launch chain: the executor only
+    takes windows of one-wave frames) == the same windows one Sync call after the other, bit for bit; and the batched
+    PreSync of overlapping windows == PreSync per window"""
+    from rssync_amd import synth
+    counts = [130, 130, 600, 130, 96, 130, 1100, 130, 130, 300, 130, 130]
+    F = len(counts)
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=44)
+    frames = _frames(g, counts, seed=44, noise=5e-4, outliers=0.05)
+    wins = [(0, 5), (3, 8), (6, 11), (7, 11)]                    # 2nd and 3rd hold two classes each, the 4th one class... and 1100
+    seq = _problem(g, frames, max_outer_iters=10)
+    want = [seq.Sync(0.036, b, e, 0.0, 0.2) for (b, e) in wins]
+    want_tr = []
+    seq2 = _problem(g, frames, max_outer_iters=10)
+    for (b, e) in wins:
+        seq2.Sync(0.036, b, e, 0.0, 0.2)
+        want_tr.append(seq2.sync_trace().copy())
+    bat = _problem(g, frames, max_outer_iters=10)
+    costs, delays = bat.sync_windows([0.036] * len(wins), [w[0] for w in wins], [w[1] for w in wins], 0.0, 0.2)
+    for w in range(len(wins)):
+        assert (costs[w], delays[w]) == want[w], w
+        np.testing.assert_array_equal(bat.window_trace(w), want_tr[w])
+    pc, pd = bat.pre_sync_windows(0.03, [w[0] for w in wins], [w[1] + 1 for w in wins], 0.002, 0.02)
+    for w, (b, e) in enumerate(wins):
+        c1, d1 = seq.PreSync(0.03, b, e + 1, 0.002, 0.02)
+        assert pd[w] == d1 and pc[w] == pytest.approx(c1, rel=1e-14)

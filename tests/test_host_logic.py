@@ -131,11 +131,11 @@ def test_reduce_hook_is_called_twice_per_outer_iteration(host, tiny_case):
     calls = []
     h.set_reduce_hook(lambda a: calls.append(len(a)))
     h.PreSync(0.0, 0, F, 0.01, 0.05)
-    # without a hint the ranks first agree on the size class of the largest frame (149 slots), then the sweep:
-    # candidate costs + 4 status flags in one exchange
-    assert calls == [149, 10 + 4]
+    # the sweep: candidate costs + 4 status flags in ONE exchange -- and nothing else: a frame's kernels follow its own
+    # track count (size classes), the ranks agree on nothing (rounds 2-4 began every call with a 149-double exchange)
+    assert calls == [10 + 4]
     calls.clear()
-    h.set_tracks_hint(tiny_case["N"])                  # given by the caller: no agreement exchange
+    h.set_tracks_hint(tiny_case["N"])                  # (accepted and ignored: kept for callers written against round 4)
     h.PreSync(0.0, 0, F, 0.01, 0.05)
     assert calls == [10 + 4]
     calls.clear()
@@ -281,7 +281,6 @@ def test_pre_sync_windows_equal_separate_presync_calls(host, tiny_case):
         assert costs[w] == pytest.approx(c, rel=1e-14, abs=0)
     calls = []
     h.set_reduce_hook(lambda a: calls.append(len(a)))
-    h.set_tracks_hint(tiny_case["N"])                 # (otherwise every call starts with the size-class agreement)
     h.pre_sync_windows(0.03, b, e, 0.004, 0.04)
     assert calls == [20 * len(b) + 4]                 # one exchange for all windows
     calls.clear()
