@@ -43,6 +43,10 @@ __device__ unsigned long long g_exec_tlast[4096]; // 0-4 task phases, 5 decide, 
 
 constexpr int kExecMaxCalls = 8;
 enum : int { kPhInit = 0, kPhMotion = 1, kPhGrad = 2, kPhTrials = 3, kPhFinal = 4, kPhDone = 5 };
+// a queue cell's phase byte kPhOneTrial + i: ONE line-search trial (i) of a frame of more than 512 tracks -- such a
+// frame's trials are a task each (for a one-wave frame all ten are one task of ~16 us; a 600-track frame's would be ~40 us
+// in a row, the longest task of its window's phase)
+constexpr int kPhOneTrial = 16;
 
 struct ExecWin {
     SyncWin s;               // the loop state of the current call
@@ -54,6 +58,17 @@ struct ExecWin {
     int pad2;
     double cost;             // loss at the returned delay (core_private.cpp:333), after the last call
     int iters_call[kExecMaxCalls];
+};
+
+struct ExecBig {
+    const uint32_t* win_big_off; // [W + 1]: window w's frames of more than 512 tracks = big_list[win_big_off[w] .. [w + 1])
+    const uint32_t* big_list;    // their slots
+    const uint32_t* slot_info;
+    float* big_tile;
+    double* big_P;
+    uint32_t big_rows;
+    uint32_t init_whole; // bit k: class k stages whole pairs only
+    uint32_t init_cap[6];
 };
 
 struct ExecParams {
@@ -85,8 +100,22 @@ struct ExecParams {
     uint32_t* done;                  // windows finished
     uint32_t* abort_flag;
     // (head, tail, done and abort each sit on a 128-byte line of their own: rship_sync_exec)
+    // Frames of more than 512 tracks (exec_big.hpp): slot_info[slot] = 0 for a one-wave frame, else (entry + 1) << 3 | size
+    // class; entry indexes the big frames' scratch -- big_tile (fp32 tile of the search: big_rows x 5 floats per entry)
+    // and mo.scratch (the rows of P in fp64).  init_cap / init_whole: the fp32 window the launch chain's search kernel
+    // gives each class (knots; whole pairs only), so that a frame takes the spline path it takes there.  Null: none.
+    // (in a record of its own in global memory: the kernel is at its registers' limit, and a selection of one-wave frames
+    // only -- the reference's workload -- pays nothing for it)
+    const struct ExecBig* big;
     unsigned long long watchdog_ticks; // s_memrealtime ticks (100 MHz) without a push by anybody before a waiting wave gives up
 };
+
+// a pointer read from a record in memory (ExecBig) is GLOBAL memory; say so, or every access through it is a flat
+// instruction (both wait counters, no clustering) -- the kernel's own arguments are known to be global
+template <class T>
+__device__ __forceinline__ T* as_global(T* p) {
+    return (T*)(__attribute__((address_space(1))) T*)p;
+}
 
 // host split_delay (sync_problem.cpp) on the device: delay * fs = kd + fd, fd in [0, 1) as fp32
 __device__ __forceinline__ void split32_dev(double delay, double fs, int32_t* kd, float* fd) {
@@ -158,17 +187,47 @@ __device__ __forceinline__ uint32_t exec_pop(const ExecParams& p) {
 // the window's slots as tasks of its (already stored) next phase
 // (a cell's low word: the task's phase in the top byte -- the consumer need not fetch the window's record to learn
 // it -- and the slot below; slots are < 2^24, checked by the launcher)
-__device__ __forceinline__ void exec_push(const ExecParams& p, uint32_t w, uint32_t slot0, uint32_t n_slots, int phase) {
-    if (threadIdx.x == 0) st_m<true>(&p.win[w].remaining, n_slots);
+// BIG: in the trial phase a frame of more than 512 tracks gets one task PER TRIAL the window wants (kPhOneTrial + i);
+// `s` is the window's loop state (which trials it wants).
+template <bool BIG>
+__device__ __forceinline__ void exec_push(const ExecParams& p, uint32_t w, uint32_t slot0, uint32_t n_slots, int phase, const SyncWin& s) {
+    uint32_t extra = 0, per_big = 0, tmask = 0, b0 = 0;
+    if constexpr (BIG) {
+        if (phase == kPhTrials) {
+            b0 = as_global(p.big->win_big_off)[w];
+            const uint32_t nb = as_global(p.big->win_big_off)[w + 1] - b0;
+            if (nb) {
+                for (int i = 0; i < kMaxBt; ++i) tmask |= trial_wanted(s, i) ? (1u << i) : 0u;
+                const uint32_t nwant = (uint32_t)__builtin_popcount(tmask);
+                if (nwant > 1u) { per_big = nwant - 1u; extra = nb * per_big; }
+                else tmask = 0; // (one trial or none: the ordinary task does)
+            }
+        }
+    }
+    if (threadIdx.x == 0) st_m<true>(&p.win[w].remaining, n_slots + extra);
     // the numbers of the new entries are reserved while the window's new state, its delays and its counter drain:
     // one wait for both, and only then the cells
     uint32_t base = 0;
-    if (threadIdx.x == 0) base = __hip_atomic_fetch_add(p.q_tail, n_slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) base = __hip_atomic_fetch_add(p.q_tail, n_slots + extra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     wait_stores();
     base = uniform_u32(base);
     for (uint32_t i = threadIdx.x; i < n_slots; i += 64) {
         const uint32_t e = base + i;
-        st_m<true>(p.q + (e & p.q_mask), ((unsigned long long)((e >> p.q_shift) + 1u) << 32) | ((uint32_t)phase << 24) | (slot0 + i));
+        uint32_t ph = (uint32_t)phase;
+        if constexpr (BIG) {
+            if (tmask && as_global(p.big->slot_info)[slot0 + i]) ph = (uint32_t)kPhOneTrial + (uint32_t)__builtin_ctz(tmask); // its first wanted trial
+        }
+        st_m<true>(p.q + (e & p.q_mask), ((unsigned long long)((e >> p.q_shift) + 1u) << 32) | (ph << 24) | (slot0 + i));
+    }
+    if constexpr (BIG) {
+        for (uint32_t x = threadIdx.x; x < extra; x += 64) { // the big frames' further trials
+            const uint32_t b = x / per_big, r = x % per_big + 1u; // the (r + 1)-th wanted trial
+            uint32_t m = tmask;
+            for (uint32_t q = 0; q < r; ++q) m &= m - 1u;
+            const uint32_t e = base + n_slots + x;
+            st_m<true>(p.q + (e & p.q_mask), ((unsigned long long)((e >> p.q_shift) + 1u) << 32) |
+                                                 (((uint32_t)kPhOneTrial + (uint32_t)__builtin_ctz(m)) << 24) | as_global(p.big->big_list)[b0 + b]);
+        }
     }
 }
 
@@ -224,6 +283,7 @@ __device__ __forceinline__ void exec_store_win(ExecWin* dst, const ExecWin* lds_
 }
 
 // the decisions of window w after the last task of its phase; executed by one whole wave
+template <bool BIG>
 __device__ __forceinline__ void exec_decide(const ExecParams& p, uint32_t w, ExecWin* L, double* stage) {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x;
@@ -333,7 +393,7 @@ __device__ __forceinline__ void exec_decide(const ExecParams& p, uint32_t w, Exe
         }
         return;
     }
-    exec_push(p, w, slot0, n_slots, L->phase);
+    exec_push<BIG>(p, w, slot0, n_slots, L->phase, L->s);
 #if RSSYNC_EXEC_STATS
     if (lane == 0 && w < 4096u) st_m<true>(&g_exec_tlast[w], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
@@ -352,8 +412,12 @@ struct ExecLds {
 };
 static_assert(sizeof(d4) * 4 * kWinMax >= kExecStage * sizeof(double), "staging area (win_cap >= kWinMax)");
 
-template <int RPT> // rows per lane of the one-wave kernels: frames of up to 64 * RPT tracks
-__global__ __launch_bounds__(64, RPT == 8 ? 2 : 1) void sync_exec_kernel(ExecParams p) { // (RPT = 8: 256 VGPRs, two waves per SIMD; the others fit anyway)
+// RPT = rows per lane of the one-wave kernels: frames of up to 64 * RPT tracks.  BIG = the selection also holds frames of
+// more than 512 tracks (exec_big.hpp: p.big) -- an instantiation of its own, so that the reference's workload (one-wave
+// frames only) runs the very code it ran before there were size classes.
+template <int RPT, bool BIG = false>
+__global__ __launch_bounds__(64, (RPT == 8 && !BIG) ? 2 : 1) void sync_exec_kernel(ExecParams p) { // (RPT = 8: 256 VGPRs, two waves per SIMD; the others fit anyway;
+                                                                                                     //  RPT = 8 with BIG would spill at 256: one wave per SIMD there)
     __shared__ ExecLds<RPT> lds;
     extern __shared__ d4 s_exec_region[]; // [4 * win_cap] d4 = win_cap x 128 bytes
     const int lane = threadIdx.x;
@@ -365,17 +429,34 @@ __global__ __launch_bounds__(64, RPT == 8 ? 2 : 1) void sync_exec_kernel(ExecPar
             EXEC_ADD(6, 14);
         }
         if (slot == 0xffffffffu) break;
-        const int ph = (int)(slot >> 24); // (the cell carries the phase: exec_push)
+        int ph = (int)(slot >> 24); // (the cell carries the phase: exec_push)
         slot &= 0x00ffffffu;
+        int one_trial = -1; // BIG: this task is ONE trial of a frame of more than 512 tracks
+        if (BIG && ph >= kPhOneTrial) { one_trial = ph - kPhOneTrial; ph = kPhTrials; }
         const uint32_t w = p.grp[slot];
+        // a frame of more than 512 tracks: one wave in the four-wave kernels' association (exec_big.hpp); the table is
+        // written before the launch and never changes
+        uint32_t info = 0u;
+        if constexpr (BIG) info = uniform_u32(as_global(p.big->slot_info)[slot]);
+        const uint32_t big_k = info & 7u, big_entry = (info >> 3) - 1u;
         EXEC_T0();
         if (ph == kPhInit) {
-            lmeds_small_body<RPT, 1, true, 0>(p.init, slot, 0u, lds.small, reinterpret_cast<f4*>(s_exec_region));
+            if (BIG && info)
+                exec_big_init<true>(p.init, slot, as_global(p.big->big_tile) + (size_t)big_entry * p.big->big_rows * kExecBigFloats, p.big->big_rows,
+                                    reinterpret_cast<f4*>(s_exec_region), p.lo.win_cap * 128u, p.big->init_cap[big_k],
+                                    ((p.big->init_whole >> big_k) & 1u) != 0, big_k == 5u);
+            else
+                lmeds_small_body<RPT, 1, true, 0>(p.init, slot, 0u, lds.small, reinterpret_cast<f4*>(s_exec_region));
         } else if (ph == kPhMotion) {
             // the frame's loss and derivative at x0 with the motion estimate just found (handed over in registers:
             // the values the body has stored)
             double mk[4];
-            opt_motion64_body<RPT, 1, true>(p.mo, slot, lds.mo, s_exec_region, mk);
+            if (BIG && info) {
+                Motion64Params mb = p.mo; // (the rows of P of the big entries: not part of the one-wave frames' parameters)
+                mb.scratch = as_global(p.big->big_P);
+                mb.scratch_rows = p.big->big_rows;
+                opt_motion64_body<0, 1, true, true>(mb, slot, lds.mo, s_exec_region, mk, big_entry);
+            } else opt_motion64_body<RPT, 1, true>(p.mo, slot, lds.mo, s_exec_region, mk);
             const d3 Mv = d3{mk[0], mk[1], mk[2]};
             double Lv, Gv;
             loss64_wave<true>(p.lo, slot, Mv, mk[3], ld_m<true>(&p.lg_kd[w]), ld_m<true>(&p.lg_fd[w]), s_exec_region, Lv, Gv);
@@ -387,6 +468,11 @@ __global__ __launch_bounds__(64, RPT == 8 ? 2 : 1) void sync_exec_kernel(ExecPar
                 double Lv, Gv;
                 loss64_wave<false>(p.lo, slot, Mv, kk, ld_m<true>(&p.lg_kd[w]), ld_m<true>(&p.lg_fd[w]), s_exec_region, Lv, Gv);
                 if (lane == 0) st_m<true>(&p.part[slot], Lv);
+            } else if (BIG && one_trial >= 0) {
+                double Lv, Gv;
+                loss64_wave<false>(p.lo, slot, Mv, kk, ld_m<true>(&p.tr_kd[(size_t)one_trial * p.n_win + w]),
+                                   ld_m<true>(&p.tr_fd[(size_t)one_trial * p.n_win + w]), s_exec_region, Lv, Gv);
+                if (lane == 0) st_m<true>(&p.part[(size_t)one_trial * p.n_sel + slot], Lv);
             } else {
                 // the window's ten trial delays in ONE round trip (lane i fetches trial i; a load past L1 takes ~1.5 us,
                 // and ten of them one after the other were most of a trial task)
@@ -412,7 +498,7 @@ __global__ __launch_bounds__(64, RPT == 8 ? 2 : 1) void sync_exec_kernel(ExecPar
         left = uniform_u32(left);
         if (left == 1u) { // the last task of the window's phase: the add has returned, the others' results are there
             EXEC_T0();
-            exec_decide(p, w, &lds.win, (double*)s_exec_region);
+            exec_decide<BIG>(p, w, &lds.win, (double*)s_exec_region);
             EXEC_ADD(5, 13);
         }
     }

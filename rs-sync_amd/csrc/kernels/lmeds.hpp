@@ -75,18 +75,21 @@ struct LmedsParams {
 
 // ---- LMedS tile in LDS, struct-of-arrays: unit rows n = safe_normalize(P).  The norms |P|
 // stay in the registers of the thread that owns the row (only stage D needs them).
-struct Tile {
-    float* nx;
-    float* ny;
-    float* nz;
+template <class P> // pointer to float: generic (the kernels' LDS or global tiles), or address-space qualified (exec_big.hpp)
+struct TileP {
+    P nx;
+    P ny;
+    P nz;
 };
+using Tile = TileP<float*>;
 
 // hypothesis direction v = safe_normalize(P[i0] x P[i1]) (core_private.cpp:45-46).  The tile
 // holds unit rows, and P[i0] x P[i1] is a positive multiple of n[i0] x n[i1], so the direction is
 // the same; the "leave it un-normalised below 1e-12" rule of safe_normalize (inline_utils.hpp:5-11)
 // is applied to |n[i0] x n[i1]| instead of |P[i0] x P[i1]| (it only fires for rows parallel to
 // within 1e-12 rad, where the hypothesis is noise either way).
-__device__ __forceinline__ f3 hypothesis(const Tile& t, uint64_t seed, int64_t frame, uint32_t stream, uint32_t h,
+template <class P>
+__device__ __forceinline__ f3 hypothesis(const TileP<P>& t, uint64_t seed, int64_t frame, uint32_t stream, uint32_t h,
                                          uint32_t n) {
     uint32_t i0, i1;
     rs::sample_pair(seed, frame, stream, h, n, i0, i1);

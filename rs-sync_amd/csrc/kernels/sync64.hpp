@@ -450,12 +450,22 @@ constexpr int kInitNone = (int)0x80000000;
 constexpr int kNB = rs::kLbfgsBasis; // numBasis (ens::L_BFGS default)
 
 // NW = waves per workgroup (4 in the product: measured fastest, see launch_motion64)
-template <int RPT, int NW>
+// EMU4 (with RPT = 0, NW = 1): ONE wave evaluates the FOUR-wave kernel's association -- thread t of that kernel's four
+// waves holds rows t, t + 256, ...; lane l walks the rows of threads l, 64 + l, 128 + l, 192 + l in turn ("virtual waves"),
+// sums each virtual wave with wave_sum_f64 and adds the four wave sums left to right, exactly as the workgroup does
+// through LDS.  The window executor runs frames of more than 512 tracks this way (executor.hpp): the bits of
+// opt_motion64_kernel<R, 4>, whatever R (a thread adds its rows in order, rows beyond the frame are zeros).
+template <int RPT, int NW, bool EMU4 = false>
 struct MotionEval64 {
+    static_assert(!EMU4 || (RPT == 0 && NW == 1), "the emulation reads its rows from global memory, one wave");
     d3 P[RPT ? RPT : 1];
     const double* gP; // RPT == 0: the rows in global memory, plane stride g_rows, rpt rows per thread (zero beyond the frame)
     uint32_t g_rows;
-    int rpt;
+    int rpt;          // rows per thread (EMU4: per thread of the emulated four-wave workgroup)
+    // EMU4: the same rows in the wave's LDS region where they fit (planes of n_lds rows, 24 bytes per row; rows beyond the
+    // frame are not stored: they are zeros) -- an L-BFGS reads them ~30 times
+    const __attribute__((address_space(3))) double* lP = nullptr;
+    uint32_t n_lds = 0;
     double (*part)[NW][4]; // [2][NW][4] LDS, double-buffered
     int buf;
     double k2;
@@ -470,6 +480,29 @@ struct MotionEval64 {
         K3_T0();
         double inv_xx;
         const double inv_s = rs::motion_inv_s(x, k2, &inv_xx);
+        double t[4];
+        if constexpr (EMU4) {
+#pragma unroll 1
+            for (int vw = 0; vw < 4; ++vw) {
+                double L = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+                if (n_lds) {
+                    for (int j = 0; j < rpt; ++j) {
+                        const uint32_t i = (uint32_t)j * 256u + (uint32_t)vw * 64u + threadIdx.x;
+                        const bool in = i < n_lds;
+                        const uint32_t q = in ? i : 0u;
+                        const d3 Pi = d3{in ? lP[q] : 0.0, in ? lP[n_lds + q] : 0.0, in ? lP[2u * n_lds + q] : 0.0};
+                        rs::motion_row(Pi, x, inv_s, L, a0, a1, a2);
+                    }
+                } else
+                for (int j = 0; j < rpt; ++j) {
+                    const size_t i = (size_t)j * 256 + (size_t)vw * 64 + threadIdx.x;
+                    rs::motion_row(d3{gP[i], gP[g_rows + i], gP[2 * (size_t)g_rows + i]}, x, inv_s, L, a0, a1, a2);
+                }
+                const double r0 = wave_sum_f64(L), r1 = wave_sum_f64(a0), r2 = wave_sum_f64(a1), r3 = wave_sum_f64(a2);
+                if (vw == 0) { t[0] = r0; t[1] = r1; t[2] = r2; t[3] = r3; }
+                else { t[0] += r0; t[1] += r1; t[2] += r2; t[3] += r3; }
+            }
+        } else {
         double L = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
         if constexpr (RPT != 0) {
 #pragma unroll
@@ -481,7 +514,7 @@ struct MotionEval64 {
             }
         }
         double r0 = wave_sum_f64(L), r1 = wave_sum_f64(a0), r2 = wave_sum_f64(a1), r3 = wave_sum_f64(a2);
-        double t[4] = {r0, r1, r2, r3};
+        t[0] = r0; t[1] = r1; t[2] = r2; t[3] = r3;
         if (NW > 1) { // the waves' sums through LDS; a one-wave frame has them already
             const int wave = threadIdx.x >> 6;
             if ((threadIdx.x & 63) == 0) {
@@ -497,6 +530,7 @@ struct MotionEval64 {
                 t[q] = acc;
             }
             buf ^= 1;
+        }
         }
         ++evals;
         const double fv = rs::motion_finish(x, inv_xx, t, g);
@@ -545,7 +579,7 @@ struct MotionLds {
     double red[NW];
 };
 
-template <int RPT, int NW, bool SC1 = false> // SC1: M, k, the pending winners and the delays are written by other workgroups of this launch
+template <int RPT, int NW, bool SC1 = false, bool EMU4 = false> // SC1: M, k, the pending winners and the delays are written by other workgroups of this launch; EMU4: MotionEval64
 __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint32_t sf, MotionLds<NW>& lds, d4* s_win, double* mk_out = nullptr,
                                                   uint32_t scratch_entry = 0) {
     constexpr int kThreads = 64 * NW;
@@ -581,7 +615,7 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
     frame_window64(sp, s_win, fr, kd);
     __syncthreads();
 
-    MotionEval64<RPT, NW> ev;
+    MotionEval64<RPT, NW, EMU4> ev;
     ev.part = s_part;
     ev.buf = 0;
     ev.evals = 0;
@@ -601,13 +635,14 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
         double* gp = p.scratch + (size_t)scratch_entry * 3 * p.scratch_rows;
         ev.gP = gp;
         ev.g_rows = p.scratch_rows;
-        ev.rpt = (int)((N + kThreads - 1) / kThreads);
-        for (int j = 0; j < ev.rpt; ++j) {
-            const uint32_t row = j * kThreads + tid;
+        constexpr int kGroup = EMU4 ? 256 : kThreads; // threads of the workgroup whose association is evaluated
+        ev.rpt = (int)((N + kGroup - 1) / kGroup);
+        for (uint32_t row = tid; row < (uint32_t)ev.rpt * kGroup; row += kThreads) {
             d3 P = d3{0, 0, 0}, dP;
             if (row < N) residual_row64<false>(sp, p.rays, (size_t)fr.off + row, base, fd, P, dP);
             gp[row] = P.x; gp[p.scratch_rows + row] = P.y; gp[2 * (size_t)p.scratch_rows + row] = P.z;
         }
+        // (EMU4 as well: lane l writes the rows = l mod 64 and reads exactly those -- only this thread reads what it writes)
     }
 
     double x[3];
@@ -625,6 +660,21 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
             const double nn = sqrt(rs::dot(Mv, Mv));
             if (!(nn < 1e-12)) Mv = rs::scale(Mv, 1.0 / nn); // safe_normalize, inline_utils.hpp:5-11
         }
+        double tot;
+        if constexpr (EMU4) { // the four virtual waves' sums, added left to right
+            tot = 0.0;
+            for (int vw = 0; vw < 4; ++vw) {
+                double ss = 0.0;
+                for (int j = 0; j < ev.rpt; ++j) {
+                    const size_t i = (size_t)j * 256 + (size_t)vw * 64 + tid;
+                    const d3 Pj = d3{ev.gP[i], ev.gP[ev.g_rows + i], ev.gP[2 * (size_t)ev.g_rows + i]};
+                    const double pm = p.simple_k ? sqrt(rs::dot(Pj, Pj)) : rs::dot(Pj, Mv);
+                    ss = fma(pm, pm, ss);
+                }
+                const double sw = wave_sum_f64(ss);
+                tot = vw == 0 ? sw : tot + sw;
+            }
+        } else {
         double ss = 0.0;
         if constexpr (RPT != 0) {
 #pragma unroll
@@ -643,9 +693,10 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
         const double sw = wave_sum_f64(ss);
         if ((tid & 63) == 0) s_red[tid >> 6] = sw;
         __syncthreads();
-        double tot = s_red[0];
+        tot = s_red[0];
 #pragma unroll
         for (int w = 1; w < NW; ++w) tot += s_red[w];
+        }
         kk = clamp_k(100.0 / sqrt(tot)); // :132; tot = 0 gives +inf -> 1000
         x[0] = Mv.x; x[1] = Mv.y; x[2] = Mv.z;
         if (tid == 0) {
@@ -660,6 +711,21 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
     if (mk_out) { mk_out[0] = x[0]; mk_out[1] = x[1]; mk_out[2] = x[2]; mk_out[3] = kk; }
     if (p.max_iters <= 0 || p.simple_k) return;
     ev.k2 = kk * kk;
+    if constexpr (EMU4) {
+        // the spline window has done its work: the rows of P take its place where they fit (a lane copies the rows it wrote)
+        if ((size_t)N * 24u <= (size_t)p.win_cap * 128u) {
+            __syncthreads();
+            __attribute__((address_space(3))) double* l = (__attribute__((address_space(3))) double*)reinterpret_cast<double*>(s_win);
+            for (uint32_t row = tid; row < N; row += kThreads) {
+                l[row] = ev.gP[row];
+                l[N + row] = ev.gP[ev.g_rows + row];
+                l[2 * N + row] = ev.gP[2 * (size_t)ev.g_rows + row];
+            }
+            __syncthreads();
+            ev.lP = l;
+            ev.n_lds = N;
+        }
+    }
 
     LbfgsHistLds hist{s_S, s_Y, s_inv_ys, s_rho, s_alpha};
     int best_not_last = 0;

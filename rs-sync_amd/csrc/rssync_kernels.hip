@@ -57,6 +57,7 @@ using rs::f4;
 #include "kernels/support.hpp"
 #include "kernels/sync64.hpp"
 #include "kernels/syncloop.hpp"
+#include "kernels/exec_big.hpp"
 #include "kernels/executor.hpp"
 #include "kernels/gyro.hpp"
 
@@ -135,6 +136,9 @@ struct rship_ctx {
     bool force_general = false;   // RSSYNC_FORCE_GENERAL_SPLINE=1 (read at creation; tools/gpu_gyro_rate.py's "before" column): no dynamic
                                   // spline windows -- frames wider than 80 knots take the general path (table from L2), as in rounds 1-3
     uint32_t one_wave_max = 512;  // frames of up to this many tracks run the one-wave kernels (K2s, loss64_small, the executor); RSSYNC_ONE_WAVE_MAX (tests, A/B)
+    uint32_t exec_big_max = 2048; // the window executor takes selections whose largest frame has up to this many tracks (RSSYNC_EXEC_BIG_MAX): a larger
+                                  // frame's tasks, serial in ONE wave, would be the whole call (one 9000-track frame among 130-track ones: 170 ms
+                                  // in the executor, 94 ms through the chain of launches, profiles/r5_syncpoints_mixed.json)
     bool force_big = false;       // RSSYNC_FORCE_BIG=1 (tests): every frame through the kernels for frames of more than 8192 tracks
     bool no_small_loss = false;   // RSSYNC_NO_SMALL_LOSS=1 (A/B): frames of up to 512 tracks in the four-wave loss kernel
     bool exact_select = false;   // RSSYNC_K2_EXACT_SELECT=1 (read once, at creation; only in the -DRSSYNC_TEST_VARIANTS=1 build): PreSync's
@@ -841,6 +845,7 @@ int rship_create(rship_ctx** out, int device) {
     if (const char* s = std::getenv("RSSYNC_NO_SMALL_LOSS")) c->no_small_loss = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_FORCE_BIG")) c->force_big = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_FORCE_GENERAL_SPLINE")) c->force_general = s[0] && s[0] != '0';
+    if (const char* s = std::getenv("RSSYNC_EXEC_BIG_MAX")) { const int v = atoi(s); if (v >= 0) c->exec_big_max = (uint32_t)v; }
     if (const char* s = std::getenv("RSSYNC_ONE_WAVE_MAX")) { const int v = atoi(s); if (v >= 64 && v <= 64 * kSmallMaxRpt) c->one_wave_max = (uint32_t)v; }
     if (device >= 0) {
         e = hipSetDevice(device);
@@ -1913,11 +1918,31 @@ static int sync_run_body(rship_ctx* c, const double* d0, int max_outer, double s
 // 314), in ONE launch of the window executor (kernels/executor.hpp): frames of up to 512 tracks.  d0[W] in; d_out[W],
 // cost[W] (loss at the returned delay), iters[W][repeats], and the trace rows of all calls of a window back to back,
 // trace[W][trace_rows][6] (trace_rows >= repeats * max_outer).  Window w samples call r with stream_first + r + w * stride.
+namespace {
+// the LDS region of an executor wave: the one-wave class's fp64 window, and at least the fp32 window the launch chain's
+// search kernel gives every other class of the selection (exec_big.hpp stages it there)
+size_t exec_region_bytes(rship_ctx* c) {
+    size_t region = (size_t)cap64_of(c, 0) * 128u;
+    // with frames of more than 512 tracks: 16 KB at least -- the search of such a frame keeps its unit rows (12 bytes each)
+    // and keys there, its L-BFGS the rows of P (24 bytes each); with ~3.6 KB of static LDS eight waves still share a CU
+    if (c->n_sel != c->cls_off[1] - c->cls_off[0]) region = std::max(region, (size_t)16 * 1024);
+    for (int k = 1; k < 5; ++k)
+        if (c->cls_off[k + 1] != c->cls_off[k]) {
+            const WinPlan wp = plan_lmeds_window<1>(c, k, 0.0, 1u);
+            region = std::max(region, (size_t)(wp.cap ? wp.cap : (uint32_t)kWinMax) * 64u);
+        }
+    return region;
+}
+} // namespace
 int rship_exec_supported(rship_ctx* c) {
-    // every slot of the selection in the one-wave class (RSSYNC_FORCE_BIG: none is -- every frame goes through the
-    // large-frame kernels, whose association the one-wave tasks do not have)
-    const uint32_t n0 = c->cls_off[1] - c->cls_off[0];
-    return c->n_sel && n0 == c->n_sel && c->cls_max_n[0] >= 2 && c->n_sel < (1u << 24) ? 1 : 0; // (a queue cell holds the slot in 24 bits)
+    // any frame size: frames of up to 512 tracks are one-wave tasks, larger ones are evaluated by one wave in their own
+    // class's (four-wave) association (kernels/exec_big.hpp).  Not with RSSYNC_FORCE_BIG (every frame through the
+    // large-frame kernels: a test mode of the launch chain) and not where a class's search window outgrows a wave's LDS.
+    if (c->force_big || !c->n_sel || c->n_sel >= (1u << 24)) return 0; // (a queue cell holds the slot in 24 bits)
+    for (uint32_t i : c->h_sel)
+        if (c->h_frame_n[i] < 2) return 0;
+    if (c->max_n > c->one_wave_max && c->max_n > c->exec_big_max) return 0; // (a frame that large is better off with four waves: the chain of launches)
+    return exec_region_bytes(c) <= 48u * 1024u ? 1 : 0;
 }
 
 int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream_first, uint32_t stream_stride, uint64_t seed,
@@ -1926,7 +1951,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     DeviceGuard dev_guard(c);
     if (check_ready(c)) return 1;
     const uint32_t W = c->n_grp, ns = c->n_sel;
-    if (!rship_exec_supported(c)) return set_err(c, "sync_exec: frames too large for the one-wave kernels (512 tracks, RSSYNC_ONE_WAVE_MAX)");
+    if (!rship_exec_supported(c)) return set_err(c, "sync_exec: this selection is not for the executor (RSSYNC_FORCE_BIG, a frame of fewer than 2 tracks, a search window beyond a wave's LDS)");
     if (c->plan_wins != W || c->plan_has_idx || c->plan_len != ns) return set_err(c, "sync_exec: the plan must be the selection's groups");
     if (max_outer <= 0 || repeats < 1 || repeats > kExecMaxCalls) return set_err(c, "sync_exec: bad iteration or call count");
     if (trace_rows < (uint32_t)repeats * (uint32_t)max_outer) return set_err(c, "sync_exec: trace too small");
@@ -1940,28 +1965,42 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     // One dynamic LDS region per wave serves as fp32 window, fp64 window and staging area (executor.hpp): cap64 knots x
     // 128 bytes -- 10 KB up to ~1.7 kHz of gyro rate, more for wider frames, and then fewer waves share a CU.
     const uint32_t exec_rpt = (uint32_t)small_rpt(c->cls_max_n[0]);
-    const uint32_t cap64 = cap64_of(c, 0);
-    const size_t region = (size_t)cap64 * 128u;
-    uint32_t fixed_lds = 0;
-    switch (exec_rpt) {
-        case 1: fixed_lds = static_lds_of(sync_exec_kernel<1>); break;
-        case 2: fixed_lds = static_lds_of(sync_exec_kernel<2>); break;
-        case 3: fixed_lds = static_lds_of(sync_exec_kernel<3>); break;
-        case 4: fixed_lds = static_lds_of(sync_exec_kernel<4>); break;
-        default: fixed_lds = static_lds_of(sync_exec_kernel<8>); break;
-    }
-    uint32_t per_cu = 8; // what the chip holds at once (LDS: ~17 KB per wave at 80 knots); more would only idle
+    const size_t region = exec_region_bytes(c);
+    const uint32_t cap64 = (uint32_t)(region / 128u); // knots of fp64 window the region holds (>= the one-wave class's plan)
+    const bool with_big = ns != c->cls_off[1] - c->cls_off[0]; // frames of more than 512 tracks in the selection
+    // what the chip holds at once: eight waves per CU at most (more would only idle), fewer where the LDS (~17 KB per wave
+    // at 80 knots) or the registers (RPT = 8 with big frames: one wave per SIMD) say so
+    uint32_t per_cu = 8;
     {
-        const size_t per_wave = fixed_lds + region + 512;
+        int occ = 0;
+        uint32_t fixed_lds = 0;
+        hipError_t e = hipSuccess;
+#define RS_EXEC_OCC(R)                                                                                                                  \
+    case R:                                                                                                                             \
+        fixed_lds = with_big ? static_lds_of(sync_exec_kernel<R, true>) : static_lds_of(sync_exec_kernel<R, false>);                    \
+        e = with_big ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sync_exec_kernel<R, true>, 64, region)                        \
+                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sync_exec_kernel<R, false>, 64, region);                      \
+        break;
+        switch (exec_rpt) {
+            RS_EXEC_OCC(1)
+            RS_EXEC_OCC(2)
+            RS_EXEC_OCC(3)
+            RS_EXEC_OCC(4)
+            default: RS_EXEC_OCC(8)
+        }
+#undef RS_EXEC_OCC
+        if (e != hipSuccess) { (void)hipGetLastError(); occ = 0; }
+        const size_t per_wave = fixed_lds + region + 512; // (the LDS bound, as rounds 3-4 computed it)
         const uint32_t fit = (uint32_t)((size_t)c->lds_per_cu / per_wave);
         if (fit < per_cu) per_cu = fit < 1 ? 1 : fit;
+        if (occ >= 1 && (uint32_t)occ < per_cu) per_cu = (uint32_t)occ; // (and what the registers allow)
     }
     uint32_t waves = (uint32_t)n_cu * per_cu;
     if (waves > ns) waves = ns;
     // ring of {lap, slot} cells, several times the entries that can be outstanding (<= ns) plus the numbers idle waves
     // have claimed ahead (<= waves)
     uint32_t q_cap = 256, q_shift = 8;
-    while (q_cap < 4 * (ns + waves)) { q_cap *= 2; ++q_shift; }
+    while (q_cap < 4 * (ns + 9 * (ns - (c->cls_off[1] - c->cls_off[0])) + waves)) { q_cap *= 2; ++q_shift; } // (a big frame's trials are up to ten tasks)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t o_win = take(W * sizeof(ExecWin));
@@ -1975,8 +2014,34 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     constexpr size_t kCtlStride = 128;
     const size_t o_q = take((size_t)q_cap * 8), o_ctl = take(4 * kCtlStride);
     const size_t o_trace = take((size_t)W * trace_rows * 48);
+    // frames of more than 512 tracks: the table slot -> (entry, class) and the entries' scratch (kernels/exec_big.hpp)
+    const uint32_t n_big = ns - (c->cls_off[1] - c->cls_off[0]);
+    uint32_t big_rows_n = 0;
+    for (int k = 1; k < kNumClasses; ++k) big_rows_n = std::max(big_rows_n, c->cls_max_n[k]);
+    big_rows_n = big_rows(big_rows_n);
+    const size_t o_info = take(n_big ? (size_t)ns * 4 : 0), o_big = take(n_big ? sizeof(ExecBig) : 0);
+    const size_t o_wboff = take(n_big ? (size_t)(W + 1) * 4 : 0), o_blist = take(n_big ? (size_t)n_big * 4 : 0);
     if (ensure(c, c->loop_state, off) || ensure(c, c->part, (size_t)2 * kMaxBt * ns * 8) || ensure(c, c->flags, 16)) return 1;
+    if (n_big && (ensure(c, c->big_scratch, (size_t)n_big * big_rows_n * kExecBigFloats * 4) ||
+                  ensure(c, c->mo_scratch, (size_t)n_big * 3 * big_rows_n * 8)))
+        return 1;
     char* base = (char*)c->loop_state.p;
+    std::vector<uint32_t> slot_info, win_big_off, big_list;
+    if (n_big) {
+        slot_info.assign(ns, 0u);
+        uint32_t entry = 0;
+        for (int k = 1; k < kNumClasses; ++k)
+            for (uint32_t e = c->cls_off[k]; e < c->cls_off[k + 1]; ++e) slot_info[c->h_cls_slots[e]] = ((entry++ + 1u) << 3) | (uint32_t)k;
+        win_big_off.assign(W + 1, 0u); // the big frames of every window (their trials are a task each: executor.hpp)
+        for (uint32_t w = 0; w < W; ++w) {
+            for (uint32_t j = c->h_grp_off[w]; j < c->h_grp_off[w + 1]; ++j)
+                if (slot_info[j]) big_list.push_back(j);
+            win_big_off[w + 1] = (uint32_t)big_list.size();
+        }
+        RS_HIP(hipMemcpyAsync(base + o_info, slot_info.data(), (size_t)ns * 4, hipMemcpyHostToDevice, c->stream));
+        RS_HIP(hipMemcpyAsync(base + o_wboff, win_big_off.data(), (size_t)(W + 1) * 4, hipMemcpyHostToDevice, c->stream));
+        RS_HIP(hipMemcpyAsync(base + o_blist, big_list.data(), (size_t)n_big * 4, hipMemcpyHostToDevice, c->stream));
+    }
 
     // host-side initial state: every window in its first call, its slots queued for the search
     std::vector<ExecWin> hw(W);
@@ -2092,6 +2157,27 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
         ep.init.win_whole_pair = wp_init.cap ? 0u : 1u; // (the compiled-in window stages whole pairs: so must this one, or tiny frames take another path)
         if ((size_t)ep.init.win_cap * 64u > region) return set_err(c, "sync_exec: the search's window does not fit the wave's LDS region");
     }
+    ExecBig hb{};
+    ep.big = nullptr;
+    if (n_big) {
+        hb.slot_info = (const uint32_t*)(base + o_info);
+        hb.win_big_off = (const uint32_t*)(base + o_wboff);
+        hb.big_list = (const uint32_t*)(base + o_blist);
+        hb.big_tile = (float*)c->big_scratch.p;
+        hb.big_P = (double*)c->mo_scratch.p; // (per entry of the table above, not of class 5's list)
+        hb.big_rows = big_rows_n;
+        hb.init_whole = 0;
+        for (int k = 0; k < kNumClasses; ++k) {
+            hb.init_cap[k] = (uint32_t)kWinMax;
+            if (k >= 1 && k <= 4 && c->cls_off[k + 1] != c->cls_off[k]) {
+                const WinPlan wp = plan_lmeds_window<1>(c, k, 0.0, 1u);
+                hb.init_cap[k] = wp.cap ? wp.cap : (uint32_t)kWinMax;
+                if (!wp.cap) hb.init_whole |= 1u << k; // (the compiled-in window stages whole pairs)
+            }
+        }
+        RS_HIP(hipMemcpyAsync(base + o_big, &hb, sizeof(hb), hipMemcpyHostToDevice, c->stream));
+        ep.big = (const ExecBig*)(base + o_big);
+    }
     // motion
     if (fill_motion(c, ep.mo)) return 1;
     ep.mo.kd = ep.mo_kd;
@@ -2117,13 +2203,19 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
 
     {
         ProfScope ps(c, RSHIP_K_MOTION);
+#define RS_EXEC_LAUNCH(R)                                                                                            \
+    case R:                                                                                                          \
+        if (with_big) hipLaunchKernelGGL((sync_exec_kernel<R, true>), dim3(waves), dim3(64), region, c->stream, ep);  \
+        else hipLaunchKernelGGL((sync_exec_kernel<R, false>), dim3(waves), dim3(64), region, c->stream, ep);         \
+        break;
         switch (exec_rpt) {
-            case 1: hipLaunchKernelGGL((sync_exec_kernel<1>), dim3(waves), dim3(64), region, c->stream, ep); break;
-            case 2: hipLaunchKernelGGL((sync_exec_kernel<2>), dim3(waves), dim3(64), region, c->stream, ep); break;
-            case 3: hipLaunchKernelGGL((sync_exec_kernel<3>), dim3(waves), dim3(64), region, c->stream, ep); break;
-            case 4: hipLaunchKernelGGL((sync_exec_kernel<4>), dim3(waves), dim3(64), region, c->stream, ep); break;
-            default: hipLaunchKernelGGL((sync_exec_kernel<8>), dim3(waves), dim3(64), region, c->stream, ep); break;
+            RS_EXEC_LAUNCH(1)
+            RS_EXEC_LAUNCH(2)
+            RS_EXEC_LAUNCH(3)
+            RS_EXEC_LAUNCH(4)
+            default: RS_EXEC_LAUNCH(8)
         }
+#undef RS_EXEC_LAUNCH
     }
     RS_HIP(hipGetLastError());
     c->init_pending = false;

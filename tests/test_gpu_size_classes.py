@@ -117,11 +117,13 @@ def test_every_class_in_one_problem_against_the_oracle():
     assert len(h2.sync_trace()) == len(tro)
 
 
-def test_batched_windows_of_mixed_classes_equal_the_sequential_calls():
-    """sync_windows / sync_points over windows that hold frames of several classes (the launch chain: the executor only
-    takes windows of one-wave frames) == the same windows one Sync call after the other, bit for bit; and the batched
-    PreSync of overlapping windows == PreSync per window"""
+@pytest.mark.parametrize("executor", ["1", "0"])
+def test_batched_windows_of_mixed_classes_equal_the_sequential_calls(executor, monkeypatch):
+    """sync_windows over windows that hold frames of several classes == the same windows one Sync call after the other,
+    bit for bit -- through the window executor and through the launch chain (RSSYNC_EXECUTOR=0: one launch per class and
+    step); and the batched PreSync of overlapping windows == PreSync per window"""
     from rssync_amd import synth
+    monkeypatch.setenv("RSSYNC_EXECUTOR", executor)
     counts = [130, 130, 600, 130, 96, 130, 1100, 130, 130, 300, 130, 130]
     F = len(counts)
     g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=44)
@@ -143,3 +145,53 @@ def test_batched_windows_of_mixed_classes_equal_the_sequential_calls():
     for w, (b, e) in enumerate(wins):
         c1, d1 = seq.PreSync(0.03, b, e + 1, 0.002, 0.02)
         assert pd[w] == d1 and pc[w] == pytest.approx(c1, rel=1e-14)
+
+
+@pytest.mark.parametrize("counts_at", [{7: 600, 19: 1100}, {7: 600, 19: 1100, 25: 300, 31: 9000}])
+def test_the_executor_takes_windows_with_frames_of_any_class(counts_at, monkeypatch):
+    """The window executor (one launch, tasks run by single waves) used to need every frame of the selection to be a
+    one-wave frame: one 513-track frame sent every window of a clip to the chain of launches (21 -> 34 ms on the driver
+    workload).  Now a larger frame's tasks are run by one wave in the FOUR-wave kernels' association
+    (kernels/exec_big.hpp, MotionEval64<0, 1, EMU4>), so the executor's results stay the launch chain's bit for bit:
+    the check mode re-runs every call through the chain and panics on any difference; and a problem that never uses
+    the executor returns the same values.  Second case: 257 .. 512-track one-wave frames (eight rows per lane) together
+    with larger ones -- the instantiation that runs one wave per SIMD -- and a frame of more than 8192 tracks (general
+    spline path in the search, as lmeds_big_kernel)."""
+    from rssync_amd import synth
+    F = 40
+    counts = [130 - 3 * (fr % 5) for fr in range(F)]
+    for fr, n in counts_at.items():
+        counts[fr] = n
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=52)
+    frames = _frames(g, counts, seed=52, noise=5e-4, outliers=0.05)
+    pos = [0, 6, 12, 18, 24]
+    monkeypatch.delenv("RSSYNC_EXECUTOR", raising=False)
+    monkeypatch.setenv("RSSYNC_EXEC_BIG_MAX", "16384")   # (by default the executor leaves selections with frames of more than 2048 tracks to the chain)
+    ex = _problem(g, frames, max_outer_iters=12)
+    ex.set_executor_check(True)
+    c_ex, d_ex = ex.sync_points(pos, 12, 0.0, 0.002, 0.04, repeats=3)
+    st = ex.executor_stats()
+    assert st["runs"] == 1 and st["checked"] == 1, st
+    tr_ex = [ex.window_trace(w) for w in range(len(pos))]
+    monkeypatch.setenv("RSSYNC_EXECUTOR", "0")
+    ch = _problem(g, frames, max_outer_iters=12)
+    c_ch, d_ch = ch.sync_points(pos, 12, 0.0, 0.002, 0.04, repeats=3)
+    assert ch.executor_stats()["runs"] == 0
+    np.testing.assert_array_equal(d_ex, d_ch)
+    np.testing.assert_array_equal(c_ex, c_ch)
+    for w in range(len(pos)):
+        np.testing.assert_array_equal(tr_ex[w], ch.window_trace(w))
+    # a single Sync call of a mixed window through the executor as well
+    monkeypatch.delenv("RSSYNC_EXECUTOR", raising=False)
+    one = _problem(g, frames, max_outer_iters=12)
+    one.set_executor_check(True)
+    c1, d1 = one.Sync(0.036, 4, 22, 0.0, 0.2)
+    st = one.executor_stats()
+    assert (st["runs"], st["checked"]) == (1, 1), st
+    assert abs(d1 - synth.D_TRUE) < 2e-3
+    if max(counts) > 2048:       # the default policy: such a selection goes through the chain of launches
+        monkeypatch.delenv("RSSYNC_EXEC_BIG_MAX", raising=False)
+        dflt = _problem(g, frames, max_outer_iters=12)
+        c2, d2 = dflt.sync_points(pos, 12, 0.0, 0.002, 0.04, repeats=3)
+        assert dflt.executor_stats()["runs"] == 0
+        np.testing.assert_array_equal(d2, d_ex)

@@ -68,7 +68,7 @@ def test_no_scratch_memory_and_no_matrix_instructions(code_object, kernels):
     # One kernel reserves a private segment it never touches (8 SGPRs parked in a frame slot that the final code keeps
     # in VGPR lanes, plus one dword): known, harmless, and pinned so that it does not grow unnoticed.
     private = {n: k["private"] for n, k in kernels.items() if k["private"]}
-    assert set(private) <= {"sync_exec_kernel<1>"} and all(v <= 64 for v in private.values()), private
+    assert set(private) <= {"sync_exec_kernel<1, false>"} and all(v <= 64 for v in private.values()), private
 
 
 def _waves_per_simd(vgpr):
@@ -87,10 +87,13 @@ def test_occupancy_the_design_relies_on(kernels):
     k3 = kernels["opt_motion64_kernel<8, 4>"]
     assert _waves_per_simd(k3["vgpr"]) >= 3, k3
     # the window executor: one-wave workgroups; up to 256 tracks two waves per SIMD (8 per CU), the 512-track
-    # instantiation uses every register a wave can have and still runs two
+    # instantiation uses every register a wave can have and still runs two.  The instantiations that also take frames of
+    # more than 512 tracks (<., true>: kernels/exec_big.hpp) keep two waves per SIMD up to 256 tracks; with 257 .. 512-track
+    # one-wave frames AND larger ones in one selection the kernel runs one wave per SIMD rather than spill.
     for rpt in (1, 2, 3, 4):
-        assert _waves_per_simd(kernels["sync_exec_kernel<%d>" % rpt]["vgpr"]) >= 2
-    assert kernels["sync_exec_kernel<8>"]["vgpr"] <= 256
+        assert _waves_per_simd(kernels["sync_exec_kernel<%d, false>" % rpt]["vgpr"]) >= 2
+        assert _waves_per_simd(kernels["sync_exec_kernel<%d, true>" % rpt]["vgpr"]) >= 2
+    assert kernels["sync_exec_kernel<8, false>"]["vgpr"] <= 256
     # one-wave LMedS kernels: at least three waves per SIMD (RPT <= 3: six, 4: five by their launch bounds)
     for rpt, need in ((1, 6), (2, 6), (3, 6), (4, 5), (8, 3)):
         k = kernels["lmeds_small_kernel<%d, 0, 80>" % rpt]
@@ -107,7 +110,7 @@ def test_every_instantiation_the_launchers_name_is_in_the_binary(kernels):
     # family cross-checks run them through the 1024-row ones: same bits)
     assert not [n for n in have if re.match(r"(lmeds_kernel|loss64_kernel)<[12],", n)]
     for rpt in (1, 2, 3, 4, 8):
-        assert "sync_exec_kernel<%d>" % rpt in have
+        assert "sync_exec_kernel<%d, false>" % rpt in have and "sync_exec_kernel<%d, true>" % rpt in have
         for mode in (0, 1):
             for cap in (80, 0):
                 assert "lmeds_small_kernel<%d, %d, %d>" % (rpt, mode, cap) in have
