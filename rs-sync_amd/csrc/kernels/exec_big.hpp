@@ -62,6 +62,7 @@ __device__ __forceinline__ void exec_big_init(const LmedsParams& p, uint32_t sf,
     __syncthreads();
 
     // ---- stage A: unit rows and norms -> the tile, as the tile kernel's four waves compute them ----
+    uint32_t n2min = 0x7f000000u; // the smallest |P|^2 of the frame (hypothesis(): smin2)
     if (sp.path == kPathInterior) {
         for (uint32_t vw = 0; vw < 4u; ++vw) { // virtual wave vw of lmeds_kernel: rows 256 j + 64 vw + lane
             RowWatch watch;
@@ -80,14 +81,24 @@ __device__ __forceinline__ void exec_big_init(const LmedsParams& p, uint32_t sf,
                 }
             }
             bad |= vbad;
+            n2min = min(n2min, watch.n2min);
         }
     } else {
+        RowWatch watch;
         for (uint32_t row = lane; row < N; row += 64u) {
             float nrm;
-            bad |= lmeds_row<kPathGlobal, false, 0>(sp, ra[row], rb[row], N, row, base, fd, tile, nrm);
+            bad |= lmeds_row<kPathGlobal, false, 0>(sp, ra[row], rb[row], N, row, base, fd, tile, nrm, &watch);
             g_nrm[row] = nrm;
         }
+        n2min = watch.n2min;
     }
+    // hypothesis(): as the kernel of the frame's class has it -- the tile kernel's bound and recomputed norms (lmeds.hpp),
+    // or, for a frame of more than 8192 tracks, the stored norms directly (lmeds_big.hpp)
+    const float smin2 = general ? 0.f : smin2_of(wave_min_u32(n2min));
+    auto row_scale = [&](uint32_t row) -> float {
+        if (general) return g_nrm[row];
+        return row_scale_general(p.coef, p.n_knots, ra[row], rb[row], base, fd);
+    };
     __syncthreads(); // (one wave: the tile's stores are ordered before the loads below)
 
     // ---- stage C: hypotheses in order; (T, bH) = best (quartile, index) so far, strict < (core_private.cpp:53) ----
@@ -104,7 +115,7 @@ __device__ __forceinline__ void exec_big_init(const LmedsParams& p, uint32_t sf,
             // the directions of up to 64 hypotheses at once, one per lane (the sampler's hash is ~100 instructions), then
             // taken in order with v_readlane -- as lmeds_small_body does
             f3 v = f3{0, 0, 0};
-            if ((uint32_t)lane < nb) v = hypothesis(t, p.seed, fr.id, stream, batch + lane, N);
+            if ((uint32_t)lane < nb) v = hypothesis(t, p.seed, fr.id, stream, batch + lane, N, smin2, row_scale);
             for (uint32_t jh = 0; jh < nb; ++jh) {
                 const f3 hv = f3{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), jh)),
                                  __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), jh)),

@@ -83,23 +83,72 @@ struct TileP {
 };
 using Tile = TileP<float*>;
 
-// hypothesis direction v = safe_normalize(P[i0] x P[i1]) (core_private.cpp:45-46).  The tile
-// holds unit rows, and P[i0] x P[i1] is a positive multiple of n[i0] x n[i1], so the direction is
-// the same; the "leave it un-normalised below 1e-12" rule of safe_normalize (inline_utils.hpp:5-11)
-// is applied to |n[i0] x n[i1]| instead of |P[i0] x P[i1]| (it only fires for rows parallel to
-// within 1e-12 rad, where the hypothesis is noise either way).
-template <class P>
+// hypothesis direction v = safe_normalize(P[i0] x P[i1]) (core_private.cpp:45-46, inline_utils.hpp:5-11) on the
+// UN-NORMALISED rows, as the reference has it: |P[i0] x P[i1]| < 1e-12 leaves v as it is -- a tiny vector whose residuals
+// are scaled down with it and which therefore WINS the LMedS outright (a near-static camera: |P| ~ 1e-6).  The tile
+// holds unit rows n_i with P_i = s_i n_i (s_i = |P_i|, or 1 for a row safe_normalize left alone), so
+// P[i0] x P[i1] = s0 s1 (n0 x n1) and the rule reads  s0 s1 |n0 x n1| < 1e-12.  (Rounds 1-4 applied the threshold to
+// |n0 x n1|: deviation 5 of DESIGN.md, gone.)  The norms stay in the registers of the threads that own the rows, so:
+//   * smin2 = a lower bound of s_i s_j over ALL rows of the frame (0.999 x the smallest |P|^2 of stage A, 0 if any row is
+//     below safe_normalize's threshold); nn smin2 >= 1e-12 decides the common case -- every hypothesis of an ordinary
+//     scene -- with one multiplication;
+//   * otherwise the two rows' norms are recomputed from the rays (scale(row) = row_scale_general below: the general form of
+//     the row with the coefficients from the table, the same in every kernel family and on every spline path, so that
+//     they all take the same decision) and the reference's rule is applied exactly.
+template <class P, class ScaleFn>
 __device__ __forceinline__ f3 hypothesis(const TileP<P>& t, uint64_t seed, int64_t frame, uint32_t stream, uint32_t h,
-                                         uint32_t n) {
+                                         uint32_t n, float smin2, ScaleFn&& scale) {
     uint32_t i0, i1;
+    // (the frame's part of the sampler's hash is the same for every candidate and hypothesis: left alone, the compiler
+    // computes it once and keeps a register pair alive through the whole tile kernel, which has none to spare -- two
+    // 64-bit multiplications per call are cheaper than that pair's spill)
+    asm volatile("" : "+s"(seed));
     rs::sample_pair(seed, frame, stream, h, n, i0, i1);
     f3 v = rs::cross(f3{t.nx[i0], t.ny[i0], t.nz[i0]}, f3{t.nx[i1], t.ny[i1], t.nz[i1]});
     float nn = sqrtf(rs::dot(v, v));
-    if (!(nn < 1e-12f)) {
+    if (nn * smin2 >= 1e-12f) { // |P[i0] x P[i1]| >= 1e-12 for certain
         float inv = 1.0f / nn;
         v = rs::scale(v, inv);
+    } else {
+        // (one row after the other, not unrolled: the two recomputations side by side would cost the tile kernel -- at
+        // its 96 registers -- spills around this rare branch)
+        float ss = 1.f;
+#pragma unroll 1
+        for (int e = 0; e < 2; ++e) ss *= scale(e == 0 ? i0 : i1);
+        if (!(ss * nn < 1e-12f)) { // (a NaN is "normalised", as the reference's strict < does)
+            float inv = 1.0f / nn;
+            v = rs::scale(v, inv);
+        } else {
+            v = rs::scale(v, ss); // P[i0] x P[i1] itself
+        }
     }
     return v;
+}
+// |P_row| as safe_normalize sees it (1 for a row it leaves alone)
+__device__ __forceinline__ float row_scale_of(f3 P) {
+    const float n2 = rs::dot(P, P);
+    return n2 < 1e-24f ? 1.f : n2 * rs::rsqrt_fast(n2);
+}
+// ... of the row with rays A = {ax,bx,ay,by}, B = {az,bz,ta,tb}: the general form of the row (any parameter, coefficients
+// from the table in L2), one END after the other and not unrolled -- this runs inside the tile kernel, which sits at its
+// 96 registers, on a branch an ordinary scene takes once in a million hypotheses
+__device__ __forceinline__ float row_scale_general(const f4* __restrict__ coef, int n_knots, f4 A, f4 B, int base, float fd) {
+    f3 ar = f3{0, 0, 0}, br = f3{0, 0, 0};
+#pragma unroll 1
+    for (int e = 0; e < 2; ++e) {
+        const float t = e ? B.w : B.z;
+        const f3 ray = e ? f3{A.y, A.w, B.y} : f3{A.x, A.z, B.x};
+        const rs::Knot k = rs::spline_locate(t, base, fd, n_knots);
+        const f4* q = coef + (size_t)k.ci * 4;
+        f3 r, d;
+        rs::rotate_ray<false>(q[0], q[1], q[2], q[3], k, ray, r, d);
+        if (e) br = r; else ar = r;
+    }
+    return row_scale_of(rs::cross(ar, br));
+}
+// the bound smin2 of hypothesis() from the smallest |P|^2 (bit pattern) over the frame's rows
+__device__ __forceinline__ float smin2_of(uint32_t n2min_bits) {
+    return n2min_bits < __float_as_uint(1e-24f) ? 0.f : __uint_as_float(n2min_bits) * 0.999f;
 }
 
 // wave-wide count of |r[]| < pivot (pivot: bit pattern of a non-negative float, uniform).
@@ -286,14 +335,16 @@ __device__ __forceinline__ uint32_t lmeds_row(const Spline& sp, f4 A, f4 B, uint
             const float inv = tiny ? 1.f : rs::rsqrt_fast(n2);
             tile.nx[row] = P.x * inv; tile.ny[row] = P.y * inv; tile.nz[row] = P.z * inv;
             nrm = tiny ? 1.f : n2 * inv;
+            if (watch) watch->n2min = min(watch->n2min, __float_as_uint(n2)); // (hypothesis(): the smallest |P|^2 of the frame)
         }
     }
     return bad;
 }
 
+// n2min: the smallest |P|^2 (bit pattern) of this thread's rows, for hypothesis()'s bound
 template <int RPT, bool SWEEP, int CAP>
 __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& rays, uint32_t N, int base, float fd,
-                                               const Tile& tile, float (&nrm)[RPT]) {
+                                               const Tile& tile, float (&nrm)[RPT], uint32_t& n2min) {
     uint32_t bad = 0;
     const uint32_t voff = threadIdx.x * 16u;
     if (sp.path == kPathInterior) {
@@ -321,15 +372,18 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
                 nrm[j] = t;
             }
         }
+        n2min = watch.n2min; // (of the hot form: a row below the threshold shows there too)
     } else { // rare (ends of the gyro track, wild delays): keep the code small, not fast
         float tmp[RPT];
+        RowWatch watch;
 #pragma unroll 1
         for (int j = 0; j < RPT; ++j) {
             const f4 A = load_ray(rays.a, voff, (uint32_t)j * kBlock * 16u), B = load_ray(rays.b, voff, (uint32_t)j * kBlock * 16u);
-            bad |= lmeds_row<kPathGlobal, false, CAP>(sp, A, B, N, j * kBlock + threadIdx.x, base, fd, tile, tmp[j]);
+            bad |= lmeds_row<kPathGlobal, false, CAP>(sp, A, B, N, j * kBlock + threadIdx.x, base, fd, tile, tmp[j], &watch);
         }
 #pragma unroll
         for (int j = 0; j < RPT; ++j) nrm[j] = tmp[j];
+        n2min = watch.n2min;
     }
     return bad;
 }
@@ -433,6 +487,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         s_cchi[LAZY ? kContCap : 1];
     __shared__ uint32_t s_ncont;
     __shared__ unsigned long long s_exact;
+    __shared__ uint32_t s_min2[4]; // per wave: the smallest |P|^2 (bit pattern) of the candidate's rows (hypothesis(): smin2)
     const int tid = threadIdx.x, lane = tid & 63;
 #if RSSYNC_K2_TIMING && RSSYNC_K2_COUNTERS
     long long k2_bar = 0, k2_by[4] = {0, 0, 0, 0};
@@ -503,7 +558,24 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         uint32_t bad = 0;
         // ---- stage A: rows of P -> LDS tile as unit rows; norms stay in registers ----
         float nrm[RPT];
-        bad |= lmeds_rows<RPT, MODE == 0, WIN>(sp, rays, N, base, fd, tile, nrm);
+        uint32_t n2min;
+        bad |= lmeds_rows<RPT, MODE == 0, WIN>(sp, rays, N, base, fd, tile, nrm, n2min);
+        {   // (written before the "tile written" barrier below, read by the hypotheses' lanes after it; the next
+            // candidate's write comes after this candidate's last barrier)
+            const uint32_t wmin = wave_min_u32(n2min);
+            if (lane == 0) s_min2[tid >> 6] = wmin;
+        }
+        // |P_row| for hypothesis(), from the rays
+        auto row_scale = [&](uint32_t row) -> float {
+            return row_scale_general(p.coef, p.n_knots, load_ray(rays.a, row * 16u, 0u), load_ray(rays.b, row * 16u, 0u), base, fd);
+        };
+        auto frame_smin2 = [&]() -> float {
+            uint32_t m = s_min2[0];
+            m = s_min2[1] < m ? s_min2[1] : m;
+            m = s_min2[2] < m ? s_min2[2] : m;
+            m = s_min2[3] < m ? s_min2[3] : m;
+            return smin2_of(m);
+        };
 
         // ---- stage C: the hypotheses.  The best quantile of the previous candidate (x1.25: between
         // neighbouring candidates it moves by -20..+26 %, 1st..99th percentile) serves as a
@@ -523,7 +595,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                 const uint32_t nb = (p.n_hyp - batch < (uint32_t)kHyp) ? p.n_hyp - batch : (uint32_t)kHyp;
                 __syncthreads(); // tile written / previous batch consumed
                 if ((uint32_t)tid < nb) {
-                    const f3 v = hypothesis(tile, p.seed, fr.id, stream, batch + tid, N);
+                    const f3 v = hypothesis(tile, p.seed, fr.id, stream, batch + tid, N, frame_smin2(), row_scale);
                     s_hyp[tid] = f4{v.x, v.y, v.z, 0.f};
                 }
                 if (tid == 0) s_next = 0;
@@ -576,7 +648,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                 const uint32_t nb = (p.n_hyp - batch < (uint32_t)kHyp) ? p.n_hyp - batch : (uint32_t)kHyp;
                 K2_SYNC(0); // tile written / previous batch consumed
                 if ((uint32_t)tid < nb) {
-                    const f3 v = hypothesis(tile, p.seed, fr.id, stream, batch + tid, N);
+                    const f3 v = hypothesis(tile, p.seed, fr.id, stream, batch + tid, N, frame_smin2(), row_scale);
                     s_hyp[tid] = f4{v.x, v.y, v.z, 0.f};
                 }
                 if (tid == 0) s_next = 0;
@@ -670,12 +742,13 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                 if (!(s_clo[j] < m_hi)) continue;
                 K2_COUNT(8);
                 const uint32_t h = s_ch[j];
-                const f3 v = hypothesis(tile, p.seed, fr.id, stream, h, N);
+                const f3 v = hypothesis(tile, p.seed, fr.id, stream, h, N, frame_smin2(), row_scale);
                 uint32_t r2[NR];
                 sweep_tile(p4x, p4y, p4z, lane, v, r2);
                 Bracket b{s_clo[j], s_cclo[j], s_chi[j], s_cchi[j]};
                 narrow_kth(r2, kq, b, 0u, 0u);
-                if (lane == 0) atomicMin(&s_exact, ((unsigned long long)b.lo << 32) | h);
+                // (the index is read again rather than kept across the sweep: the kernel has no register to spare here)
+                if (lane == 0) atomicMin(&s_exact, ((unsigned long long)b.lo << 32) | s_ch[j]);
             }
             __syncthreads();
             const unsigned long long best = s_exact; // smaller quartile wins, ties go to the earlier hypothesis (core_private.cpp:53)
@@ -691,7 +764,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
                 const f4 hv = s_hyp[bH];
                 Mv = f3{hv.x, hv.y, hv.z};
             } else {
-                Mv = hypothesis(tile, p.seed, fr.id, stream, (uint32_t)bH, N);
+                Mv = hypothesis(tile, p.seed, fr.id, stream, (uint32_t)bH, N, frame_smin2(), row_scale);
             }
         }
         if (!(finite_f(Mv.x) && finite_f(Mv.y) && finite_f(Mv.z))) bad |= RSHIP_BAD_M;

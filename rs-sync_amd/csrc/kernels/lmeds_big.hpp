@@ -80,7 +80,8 @@ __global__ __launch_bounds__(kBlock) void lmeds_big_kernel(LmedsParams p) {
             int bH = -1;
             f3 Mv = f3{0, 0, 0};
             for (uint32_t h = 0; h < p.n_hyp; ++h) {
-                const f3 hv = hypothesis(tile, p.seed, fr.id, stream, h, N); // (uniform: every thread computes it)
+                // (uniform: every thread computes it; the rows' norms are at hand: no bound, the reference's rule directly)
+                const f3 hv = hypothesis(tile, p.seed, fr.id, stream, h, N, 0.f, [&](uint32_t row) -> float { return g_nrm[row]; });
                 for (uint32_t row = tid; row < N; row += kBlock) {
                     const float r = fmaf(tile.nz[row], hv.z, fmaf(tile.ny[row], hv.y, tile.nx[row] * hv.x)); // :48, as sweep_tile
                     const uint32_t a = __float_as_uint(r) & 0x7fffffffu;

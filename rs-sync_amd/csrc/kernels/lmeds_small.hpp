@@ -110,13 +110,14 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
                         const float inv = tiny ? 1.f : rs::rsqrt_fast(n2);
                         nx[j] = P.x * inv; ny[j] = P.y * inv; nz[j] = P.z * inv;
                         nrm[j] = tiny ? 1.f : n2 * inv;
+                        if (watch) watch->n2min = min(watch->n2min, __float_as_uint(n2));
                     }
                 }
                 s_n[0][row] = nx[j]; s_n[1][row] = ny[j]; s_n[2][row] = nz[j];
             }
         };
+        RowWatch watch;
         if (sp.path == kPathInterior) {
-            RowWatch watch;
             rows(std::true_type{}, &watch);
             if (!finite_f(watch.nsum)) bad = RSHIP_BAD_P;
             if (__builtin_amdgcn_ballot_w64(watch.qerr >= kNewtonMaxErr || watch.below_safe_normalize()) != 0) {
@@ -124,9 +125,14 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
                 rows(std::false_type{}, nullptr);
             }
         } else {
-            rows(std::false_type{}, nullptr);
+            rows(std::false_type{}, &watch);
         }
         __syncthreads(); // the wave's rows are in LDS
+        // hypothesis(): the bound from the frame's smallest |P|^2, and |P_row| from the rays (the tile kernel's values, lmeds.hpp)
+        const float smin2 = smin2_of(wave_min_u32(watch.n2min));
+        auto row_scale = [&](uint32_t row) -> float {
+            return row_scale_general(p.coef, p.n_knots, load_ray(rays.a, row * 16u, 0u), load_ray(rays.b, row * 16u, 0u), base, fd);
+        };
 
         // ---- the hypotheses, in order.  The previous candidate's best quantile (x1.25) is a provisional bound
         // as in the tile kernel; if nothing beats it the candidate is redone without it. ----
@@ -142,7 +148,7 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
             for (uint32_t batch = 0; batch < p.n_hyp; batch += kHyp) {
                 const uint32_t nb = (p.n_hyp - batch < (uint32_t)kHyp) ? p.n_hyp - batch : (uint32_t)kHyp;
                 f3 v = f3{0, 0, 0};
-                if ((uint32_t)lane < nb) v = hypothesis(tile, p.seed, fr.id, stream, batch + lane, N);
+                if ((uint32_t)lane < nb) v = hypothesis(tile, p.seed, fr.id, stream, batch + lane, N, smin2, row_scale);
                 for (uint32_t j = 0; j < nb; ++j) {
                     const float hx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), j));
                     const float hy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), j));

@@ -139,6 +139,7 @@ struct rship_ctx {
     uint32_t exec_big_max = 2048; // the window executor takes selections whose largest frame has up to this many tracks (RSSYNC_EXEC_BIG_MAX): a larger
                                   // frame's tasks, serial in ONE wave, would be the whole call (one 9000-track frame among 130-track ones: 170 ms
                                   // in the executor, 94 ms through the chain of launches, profiles/r5_syncpoints_mixed.json)
+    uint32_t exec_big_share = 8;  // ... and in which at most one slot in this many holds a frame of more than 512 tracks (RSSYNC_EXEC_BIG_SHARE; 1 = any)
     bool force_big = false;       // RSSYNC_FORCE_BIG=1 (tests): every frame through the kernels for frames of more than 8192 tracks
     bool no_small_loss = false;   // RSSYNC_NO_SMALL_LOSS=1 (A/B): frames of up to 512 tracks in the four-wave loss kernel
     bool exact_select = false;   // RSSYNC_K2_EXACT_SELECT=1 (read once, at creation; only in the -DRSSYNC_TEST_VARIANTS=1 build): PreSync's
@@ -846,6 +847,7 @@ int rship_create(rship_ctx** out, int device) {
     if (const char* s = std::getenv("RSSYNC_FORCE_BIG")) c->force_big = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_FORCE_GENERAL_SPLINE")) c->force_general = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_EXEC_BIG_MAX")) { const int v = atoi(s); if (v >= 0) c->exec_big_max = (uint32_t)v; }
+    if (const char* s = std::getenv("RSSYNC_EXEC_BIG_SHARE")) { const int v = atoi(s); if (v >= 1) c->exec_big_share = (uint32_t)v; }
     if (const char* s = std::getenv("RSSYNC_ONE_WAVE_MAX")) { const int v = atoi(s); if (v >= 64 && v <= 64 * kSmallMaxRpt) c->one_wave_max = (uint32_t)v; }
     if (device >= 0) {
         e = hipSetDevice(device);
@@ -1942,6 +1944,10 @@ int rship_exec_supported(rship_ctx* c) {
     for (uint32_t i : c->h_sel)
         if (c->h_frame_n[i] < 2) return 0;
     if (c->max_n > c->one_wave_max && c->max_n > c->exec_big_max) return 0; // (a frame that large is better off with four waves: the chain of launches)
+    // ... and so is a selection in which the larger frames are not the exception: a one-wave task in the four-wave
+    // association is ~4x a one-wave frame's (BASELINE config 3, every frame 2048 tracks: 30 ms in the executor against
+    // 9.8 ms through the chain).  Stragglers only: at most one slot in eight.
+    if ((uint64_t)(c->n_sel - (c->cls_off[1] - c->cls_off[0])) * c->exec_big_share > c->n_sel) return 0;
     return exec_region_bytes(c) <= 48u * 1024u ? 1 : 0;
 }
 

@@ -127,9 +127,12 @@ Rows unit_rows(const rship_ctx* c, const rship_frame& fr, int32_t kd, float fd) 
 f3 hypothesis(const Rows& t, uint64_t seed, int64_t frame, uint32_t stream, uint32_t h) {
     uint32_t i0, i1;
     rs::sample_pair(seed, frame, stream, h, (uint32_t)t.n.size(), i0, i1);
+    // safe_normalize on the UN-NORMALISED cross product (core_private.cpp:45-46): P_i = nrm_i n_i
     f3 v = rs::cross(t.n[i0], t.n[i1]);
     float nn = std::sqrt(rs::dot(v, v));
-    if (!(nn < 1e-12f)) v = rs::scale(v, 1.0f / nn);
+    const float ss = t.nrm[i0] * t.nrm[i1];
+    if (!(ss * nn < 1e-12f)) v = rs::scale(v, 1.0f / nn);
+    else v = rs::scale(v, ss);
     return v;
 }
 

@@ -963,3 +963,59 @@ def test_rows_below_safe_normalizes_threshold_and_the_non_finite_r_panic(kernel,
             o.PreSync(0.0, 0, F, 0.002, 0.02)
         with pytest.raises(rssync_amd.RsSyncError, match="pre-sync: non-finite r"):
             h.PreSync(0.0, 0, F, 0.002, 0.02)
+
+
+def test_near_static_camera_the_hypothesis_rule_on_unnormalised_rows():
+    """core_private.cpp:45-46: v = safe_normalize(cross(P[i0], P[i1])) -- the 1e-12 threshold of inline_utils.hpp:5-11
+    applies to |P[i0] x P[i1]| of the UN-normalised rows.  For a near-static camera (|P| ~ translation / depth ~ 1e-6 at the
+    true delay) that product is below the threshold for most pairs: the reference leaves v tiny, its residuals shrink
+    with it and such a hypothesis wins the LMedS outright.  Rounds 1-4 applied the threshold to the unit rows' cross
+    product and normalised those directions (DESIGN.md deviation 5, now gone): on this scene the device would then pick
+    another winner wherever the oracle's is an un-normalised direction -- about half of the (frame, candidate) pairs.
+    What limits the agreement now is the fp32 rounding of the rows themselves (6e-8 absolute on rows of 2e-6: 3 %,
+    tests/measure/gpu_near_static.py -> profiles/r5_near_static.json: 100 % identical winners at |P| ~ 2e-3, 91 % at
+    1e-5, 84 % at 2e-6), so the bounds here are what that measurement supports, not the 99.5 % of ordinary scenes."""
+    import rssync_amd
+    from rssync_amd import synth
+    from oracle.oracle import OracleProblem
+    F, N = 12, 600
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=9)
+    # frames 0 .. 7 near-static (5e-5 m per frame at 2 .. 50 m: |P| ~ 2e-6, ray noise in proportion), 8 .. 11 ordinary
+    frames = list(synth.make_frames(g, 0, 8, N, seed=9, noise=1e-6, outliers=0.1, translation=5e-5))
+    frames += list(synth.make_frames(g, 8, F, N, seed=9, noise=1e-3, outliers=0.1))
+    h = rssync_amd.SyncProblem(seed=SEED)
+    o = OracleProblem(seed=SEED, threads=min(os.cpu_count() or 1, 16), faithful=False)
+    for p in (h, o):
+        p.SetGyroQuaternions(g.quats, g.fs, g.t0)
+        for fr in frames:
+            p.SetTrackResult(*fr)
+    dh, ch, fch, bhh = h.presync_curve(synth.D_TRUE, 0, F, 2e-6, 2e-5, per_frame=F)   # 20 candidates within 20 us of the truth
+    do, co, fco, bho = o.presync_curve(synth.D_TRUE, 0, F, 2e-6, 2e-5, per_frame=F)
+    np.testing.assert_array_equal(dh, do)
+    # which of the oracle's winners are un-normalised directions (|M| far below 1)
+    unn = np.array([[np.linalg.norm(o.guess_motion(f, float(do[c]), 20, c)[0]) < 0.5 for f in range(F)] for c in range(len(do))])
+    assert 0.25 < unn[:, :8].mean() < 0.9, unn[:, :8].mean()      # the scene is in the regime the rule is about ...
+    assert not unn[:, 8:].any()                                   # ... and the ordinary frames are not
+    same = bhh == bho
+    assert same[:, 8:].mean() > 0.99                              # ordinary frames beside them: as everywhere else
+    assert same[:, :8][unn[:, :8]].mean() > 0.7, same[:, :8][unn[:, :8]].mean()     # (the old rule: ~0 here)
+    assert same[:, :8].mean() > 0.75, same[:, :8].mean()
+    rel = np.abs(fch - fco) / fco
+    assert np.median(rel[same]) < 2e-3
+    np.testing.assert_allclose(ch, co, rtol=0.06)
+    # the one-wave kernels take the same decisions as the tile kernel on the same data (every family recomputes the two
+    # rows' norms with the same routine, lmeds.hpp: row_scale_general)
+    small = list(synth.make_frames(g, 0, 8, 130, seed=9, noise=1e-6, outliers=0.1, translation=5e-5))
+    res = {}
+    for tile in ("0", "1"):
+        os.environ["RSSYNC_NO_SMALL_LMEDS"] = tile
+        try:
+            q = rssync_amd.SyncProblem(seed=SEED)
+        finally:
+            del os.environ["RSSYNC_NO_SMALL_LMEDS"]
+        q.SetGyroQuaternions(g.quats, g.fs, g.t0)
+        for fr in small:
+            q.SetTrackResult(*fr)
+        res[tile] = q.presync_curve(synth.D_TRUE, 0, 8, 2e-6, 2e-5, per_frame=8)
+    np.testing.assert_array_equal(res["0"][3], res["1"][3])        # winners: one wave per frame == four-wave tile kernel
+    np.testing.assert_allclose(res["0"][2], res["1"][2], rtol=2e-6)

@@ -124,6 +124,7 @@ def test_batched_windows_of_mixed_classes_equal_the_sequential_calls(executor, m
     step); and the batched PreSync of overlapping windows == PreSync per window"""
     from rssync_amd import synth
     monkeypatch.setenv("RSSYNC_EXECUTOR", executor)
+    monkeypatch.setenv("RSSYNC_EXEC_BIG_SHARE", "1")     # (two larger frames among twelve: by default the chain's, not the executor's)
     counts = [130, 130, 600, 130, 96, 130, 1100, 130, 130, 300, 130, 130]
     F = len(counts)
     g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=44)
@@ -166,7 +167,8 @@ def test_the_executor_takes_windows_with_frames_of_any_class(counts_at, monkeypa
     frames = _frames(g, counts, seed=52, noise=5e-4, outliers=0.05)
     pos = [0, 6, 12, 18, 24]
     monkeypatch.delenv("RSSYNC_EXECUTOR", raising=False)
-    monkeypatch.setenv("RSSYNC_EXEC_BIG_MAX", "16384")   # (by default the executor leaves selections with frames of more than 2048 tracks to the chain)
+    monkeypatch.setenv("RSSYNC_EXEC_BIG_MAX", "16384")   # (by default the executor leaves selections with frames of more than 2048 tracks to the chain ...
+    monkeypatch.setenv("RSSYNC_EXEC_BIG_SHARE", "1")     #  ... and those in which more than one slot in eight holds a larger frame)
     ex = _problem(g, frames, max_outer_iters=12)
     ex.set_executor_check(True)
     c_ex, d_ex = ex.sync_points(pos, 12, 0.0, 0.002, 0.04, repeats=3)
@@ -191,6 +193,7 @@ def test_the_executor_takes_windows_with_frames_of_any_class(counts_at, monkeypa
     assert abs(d1 - synth.D_TRUE) < 2e-3
     if max(counts) > 2048:       # the default policy: such a selection goes through the chain of launches
         monkeypatch.delenv("RSSYNC_EXEC_BIG_MAX", raising=False)
+        monkeypatch.delenv("RSSYNC_EXEC_BIG_SHARE", raising=False)
         dflt = _problem(g, frames, max_outer_iters=12)
         c2, d2 = dflt.sync_points(pos, 12, 0.0, 0.002, 0.04, repeats=3)
         assert dflt.executor_stats()["runs"] == 0
