@@ -44,7 +44,16 @@ BYTES_PER_RR = 32      # 8 fp32 per ray pair read per (frame, de
 BYTES_PER_RR_F64 = 64  # the Sync kernels read the fp64 streams: 8 doubles per ray pair per evaluation
 FLOP_PER_RR_PRESYNC = 390       # ~230 flop per residual row + 20 hypotheses x ~8
 FP32_VECTOR_PEAK_TF = 157.3     # MI355X_MICROARCH.md: peak FP32 (vector)
-PMC_SUMMARIES = ("r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json")
+PMC_SUMMARIES = ("r5_pmc_summary.json", "r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json")
+N_SIMD = 1024                   # 256 CUs x 4 SIMDs
+# cycles a gfx950 SIMD needs per fp64 wave-instruction with >= 2 waves resident: measured 4.2 - 4.4 (v_fma_f64,
+# tools/ubench/valu_rate.hip -> profiles/r2_valu_rate.txt); MI355X_MICROARCH.md states no fp64 vector peak
+FP64_CYCLES_PER_WAVE_INSTR = 4.3
+# parity asserted in the driver's own run (north star: delay within 1e-4 s, per-iteration loss to a stated tolerance)
+# (the sweep's curve: fp32 frame costs agree to ~1e-7 where both sides pick the same hypothesis; a near-tie that falls the
+# other way moves ONE frame's cost by per cent, i.e. the sum over the sample's 192 frames by ~1e-4 -- measured 9.5e-5 on the
+# default sample, 1.3e-5 on all 4096 frames, profiles/r4_config3_presync_parity.json; deterministic, box-independent)
+PARITY_TOL = {"delay_s": 1e-4, "loss_rel": 2e-4, "presync_curve_rel": 3e-4}
 
 
 def parse_args(argv=None):
@@ -61,10 +70,13 @@ def parse_args(argv=None):
     ap.add_argument("--mode", default="ranks", choices=["ranks", "inproc"],
                     help="ranks: one process per GPU (self-spawned unless WORLD_SIZE is set); inproc: one object "
                          "driving all GPUs of this process")
-    ap.add_argument("--hook-device-loop", action="store_true",
-                    help="with --exchange torch: keep Sync's loop on the device and call the hook on the window sums "
-                         "between the kernels (the structure of the native RCCL path with a host transport; default: "
-                         "the host loop, one hook call per launch)")
+    ap.add_argument("--hook-device-loop", dest="hook_device_loop", action="store_true", default=True,
+                    help="with --exchange torch (default ON since round 5): keep Sync's loop on the device and call the "
+                         "hook on the window sums between the kernels -- the structure of the native RCCL path with a "
+                         "host transport; bit-identical to the host loop (tests/test_gpu_parity.py, two ranks)")
+    ap.add_argument("--no-hook-device-loop", dest="hook_device_loop", action="store_false",
+                    help="with --exchange torch: Sync's loop on the host, one hook call per launch")
+    ap.add_argument("--no-parity", action="store_true", help="skip the untimed HIP-vs-oracle comparison on the CPU sample")
     ap.add_argument("--exchange", default="torch", choices=["native", "torch"],
                     help="multi-rank sums: torch.distributed all_reduce through a reduce hook (default: the path every "
                          "multi-rank test exercises), or the library's own RCCL communicator with Sync's loop on the "
@@ -323,11 +335,14 @@ def run(args):
             avg_ms = ms_l / n_l
             alg_bytes = F * N * n_cand * BYTES_PER_RR
             ach = alg_bytes / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "lmeds_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            roof = {"bound": "hbm-equivalent (contract: 32 B per ray-residual)", "kernel": "lmeds_kernel",
+                    "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "valu_busy": None,
                     "avg_launch_ms": round(avg_ms, 4), "launches": n_l,
-                    "note": "equivalent bandwidth: 32 B per nominal ray-residual; the kernel reuses each ray "
-                            "across the candidates of a chunk and is VALU/LDS-bound (DESIGN.md)"}
+                    "note": "NOT a physical bandwidth: SURVEY 8(d)'s contract figure, 32 B per nominal ray-residual / live "
+                            "launch time.  The kernel reuses each ray across the candidates of a chunk -- `traffic` is "
+                            "what it really moves -- and is bound by VALU issue (`valu_busy`) with the CU's scalar unit "
+                            "saturated by the counting idiom (DESIGN.md section 3)"}
             # nominal arithmetic of the same launches: ~390 flop per PreSync ray-residual (230
             # for the residual row + 20 hypotheses x 8) against the fp32 vector peak, from this run's HIP events
             flops = F * N * n_cand * FLOP_PER_RR_PRESYNC
@@ -352,6 +367,12 @@ def run(args):
                     roof["traffic"] = round((2 * ctr["FETCH_SIZE"]["mean_per_launch_KiB"] +
                                              ctr["WRITE_SIZE"]["mean_per_launch_KiB"]) * 1024 / 1e9, 4)
                     roof["traffic_unit"] = "GB per launch, from profiles/%s (a separate rocprofv3 --pmc run, not this one)" % name
+                    if "SQ_ACTIVE_INST_VALU" in ctr and "GRBM_GUI_ACTIVE" in ctr:
+                        # fraction of the SIMDs' cycles in which a VALU instruction was executing: the guide's formula,
+                        # SQ_ACTIVE_INST_VALU x 4 / (SIMDs x cycles of one XCD's GRBM_GUI_ACTIVE share)
+                        roof["valu_busy"] = round(ctr["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] * 4 /
+                                                  (N_SIMD * ctr["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8), 3)
+                        roof["valu_busy_unit"] = "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), same file"
                     break
         # second roofline: K1's loss + analytic-gradient launch (one delay per window, every fp64 ray pair of the
         # GPU's frames read once: 64 B per ray pair), the HBM-bound kernel of the Sync phase, from its own events
@@ -363,10 +384,42 @@ def run(args):
             roof_k1 = {"bound": "hbm", "kernel": "loss64_kernel<.,GRAD>", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_ms, 4),
                        "launches": n_g, "note": "64 B (fp64 streams) x frames x tracks of one GPU / live launch time"}
+        # third roofline: K3, the per-frame motion L-BFGS -- Sync's largest kernel, on-chip (P in registers) and bound by
+        # fp64 VALU issue.  The guide states no fp64 peak, so the "peak" is this chip's MEASURED fp64 issue rate: one
+        # wave-instruction per FP64_CYCLES_PER_WAVE_INSTR cycles and SIMD.  achieved = the kernel's VALU wave-
+        # instructions per launch (PMC, its own rocprofv3 pass) / the launch's cycles; both from the committed summary,
+        # the live launch time of THIS run beside them.
+        n_m, ms_m = prof["motion"]
+        roof_k3 = None
+        if n_m and (F, N, n_cand) == (4096, 2048, 800):
+            for name in PMC_SUMMARIES:
+                pmc_path = os.path.join(ROOT, "profiles", name)
+                if not os.path.exists(pmc_path):
+                    continue
+                raw = json.load(open(pmc_path))
+                key = [k for k in raw if k.startswith("opt_motion64_kernel<8, 4>")]
+                if key and "SQ_INSTS_VALU" in raw[key[0]] and "GRBM_GUI_ACTIVE" in raw[key[0]]:
+                    ctr = raw[key[0]]
+                    insts = ctr["SQ_INSTS_VALU"]["mean_per_launch"]
+                    cycles = ctr["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8
+                    ach = insts / (N_SIMD * cycles)                 # wave-instructions per SIMD and cycle
+                    peak = 1.0 / FP64_CYCLES_PER_WAVE_INSTR
+                    roof_k3 = {"bound": "fp64 VALU issue (measured rate: no fp64 peak in MI355X_MICROARCH.md)",
+                               "kernel": "opt_motion64_kernel<8, 4>", "achieved": round(ach, 4), "peak": round(peak, 4),
+                               "unit": "wave-instructions / SIMD / cycle", "frac": round(ach / peak, 3),
+                               "avg_launch_ms": round(ms_m / n_m, 4), "launches": n_m,
+                               "valu_wave_instructions_per_launch": insts,
+                               "note": "SQ_INSTS_VALU per launch / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) from profiles/%s; peak = 1 / %.1f "
+                                       "cycles per fp64 wave-instruction (profiles/r2_valu_rate.txt: 4.2 - 4.4 with >= 2 waves "
+                                       "per SIMD); avg_launch_ms is this run's (HIP events)" % (name, FP64_CYCLES_PER_WAVE_INSTR)}
+                    break
         kernels = {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in prof.items()}
-        cpu = None
+        cpu = parity = None
         if n_gpus == 1 and args.cpu_frames > 0 and not c5:
             cpu = cpu_baseline(gyro, min(args.cpu_frames, F), N, args)
+            if not args.no_parity and not rehearsal:
+                parity = parity_check(gyro, min(args.cpu_frames, F), N, args, cpu.pop("_oracle"))
+            cpu.pop("_oracle", None)
         out = {
             "metric": "ray-residuals/sec (PreSync sweep + Sync iter), 4096 frames x 2048 tracks",
             "value": value, "unit": "ray-residuals/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -383,8 +436,11 @@ def run(args):
                        "parallelism": "frames sharded x%d (%s)" % (n_gpus, "one object, in-process" if inproc else
                                                                    "one process per GPU")},
             "multi_gpu": {"mode": args.mode, "launcher": launcher, "processes": world, "devices_per_process": n_dev,
-                          "exchange": exchange, "rccl_ranks": world if exchange == "native-rccl" else 0,
-                          "rccl_library": prob.rccl_library() if exchange == "native-rccl" else None,
+                          # RCCL carries the sums whenever the backend is nccl -- through the library's own communicator
+                          # ("native-rccl") or through torch.distributed behind the reduce hook ("torch-nccl-hook")
+                          "exchange": exchange, "rccl_ranks": world if (world > 1 and (exchange == "native-rccl" or backend == "nccl")) else 0,
+                          "rccl_library": prob.rccl_library() if exchange == "native-rccl" else
+                                          ("torch.distributed's (backend nccl)" if world > 1 and backend == "nccl" else None),
                           "exchanges_per_step": x_calls / max(args.steps, 1),
                           "doubles_per_step": x_doubles / max(args.steps, 1),
                           "sync_loop": ("device, window sums all-reduced on the stream (ncclAllReduce between the kernels)"
@@ -394,7 +450,8 @@ def run(args):
                                         "host, one exchange per launch"),
                           "note": "exchange = how the sums over frames cross process boundaries (none within one "
                                   "process: --mode inproc adds the devices' chunk sums on the host)"},
-            "roofline": roof, "roofline_flop": roof_flop, "roofline_k1": roof_k1, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roof, "roofline_flop": roof_flop, "roofline_k1": roof_k1, "roofline_k3": roof_k3, "cpu_baseline": cpu,
+            "parity": parity, "kernels": kernels,
             "presync_ms_per_step": t_pre / args.steps * 1e3,
             "result": result, "host": {"gen_s": round(t_gen, 2), "set_track_result_s": round(t_set, 3), "pack_upload_s": round(t_up, 3),
                      "note": "set_track_result_s = the SetTrackResult loop over all frames (checks + copy into pinned "
@@ -407,6 +464,9 @@ def run(args):
             # reported for context only: the roofline fraction, not this ratio, says how good the kernels are
             out["gpu_over_cpu"] = round(value / n_gpus / cpu["value"], 1)
         print(json.dumps(out), flush=True)
+        if parity is not None and not parity["ok"]:
+            print("bench: PARITY FAILED on the CPU sample: %s" % json.dumps(parity), file=sys.stderr)
+            sys.exit(3)
     if world > 1:
         dist.barrier()
         if exchange == "native-rccl":
@@ -453,7 +513,39 @@ def cpu_baseline(gyro, frames, tracks, args):
     return {"value": rr / (t_pre + t_sync), "unit": "ray-residuals/s", "cores": cores, "kind": "port",
             "sample": "%d frames x %d tracks, %d candidates + %d Sync outer iterations (same inputs, "
                       "first frames of the window)" % (frames, tracks, len(delays), len(tr)),
-            "presync_s": round(t_pre, 2), "sync_s": round(t_sync, 2), "presync_delay": d0, "sync_delay": d1}
+            "presync_s": round(t_pre, 2), "sync_s": round(t_sync, 2), "presync_delay": d0, "sync_delay": d1,
+            "note": "the SAMPLE's results (first %d frames): compare with `parity`, not with `result` (all frames)" % frames,
+            "_oracle": {"delays": delays, "costs": costs, "d0": d0, "sync_cost": c1, "sync_delay": d1, "trace": tr}}
+
+
+def parity_check(gyro, frames, tracks, args, ora):
+    """Like for like, in the driver's own run: the HIP path once more (untimed) on EXACTLY the sample the oracle was timed
+    on -- the first `frames` frames, the same candidates, Sync from the oracle's PreSync delay -- against the oracle's
+    results: same PreSync arg-min, cost curve, returned delay (north star: 1e-4 s), per-iteration loss."""
+    import rssync_amd
+    from rssync_amd import synth
+
+    h = rssync_amd.SyncProblem(seed=0x5EED0003, max_outer_iters=args.outer_iters, verbose=False)
+    synth.fill(h, gyro, 0, frames, tracks, seed=0x5EED0003)
+    delays, costs = h.presync_curve(0.0, 0, frames, args.search_step, args.search_radius)
+    same_delays = len(delays) == len(ora["delays"]) and bool(np.array_equal(delays, ora["delays"]))
+    curve_rel = float(np.abs(costs - ora["costs"]).max() / np.abs(ora["costs"]).max()) if same_delays else float("inf")
+    c1, d1 = h.Sync(ora["d0"], 0, frames - 1, 0.0, args.search_radius)
+    tr = h.sync_trace()
+    n = min(len(tr), len(ora["trace"]))
+    loss_rel = float(np.max(np.abs(tr[:n, 2] - np.asarray(ora["trace"])[:n, 2]) / np.abs(np.asarray(ora["trace"])[:n, 2]))) if n else float("inf")
+    out = {"sample": "%d frames x %d tracks, %d candidates (the cpu_baseline's sample)" % (frames, tracks, len(delays)),
+           "presync_same_index": bool(same_delays and int(np.argmin(costs)) == int(np.argmin(ora["costs"]))),
+           "presync_index": int(np.argmin(costs)), "presync_curve_rel_max": curve_rel,
+           "sync_delay_hip": float(d1), "sync_delay_oracle": float(ora["sync_delay"]),
+           "sync_delay_abs_diff_s": float(abs(d1 - ora["sync_delay"])),
+           "sync_cost_rel_diff": float(abs(c1 - ora["sync_cost"]) / abs(ora["sync_cost"])),
+           "sync_outer_iters": [int(len(tr)), int(len(ora["trace"]))],
+           "sync_loss_rel_max_per_iter": loss_rel, "tolerance": PARITY_TOL}
+    out["ok"] = bool(out["presync_same_index"] and curve_rel <= PARITY_TOL["presync_curve_rel"] and
+                     out["sync_delay_abs_diff_s"] <= PARITY_TOL["delay_s"] and len(tr) == len(ora["trace"]) and
+                     loss_rel <= PARITY_TOL["loss_rel"])
+    return out
 
 
 if __name__ == "__main__":

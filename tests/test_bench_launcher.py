@@ -97,3 +97,40 @@ def test_baseline_config_is_named_and_config5_runs_with_ranks(hosttest_lib):
     sys.path.insert(0, ROOT)
     import bench
     assert bench.parse_args([]).exchange == "torch" and bench.parse_args([]).frames == 4096
+
+
+def test_eight_ranks_rehearsed_on_the_cpu_stand_in(hosttest_lib):
+    """What the driver's first SCALE run will execute -- `bench.py --gpus 8`, one rank per GPU -- rehearsed with eight gloo
+    ranks on the CPU stand-in (tiny frames): one JSON line, the config named, the exchange named, and the exchanges per
+    step within the budget DESIGN.md section 4 writes down: 1 for PreSync + 2 per outer iteration (3 when a line search
+    needs its later trials) + 1 for the final loss.  (The stand-in has no device loop: this is the host loop's count; the
+    device loop's -- two per ENQUEUED iteration -- is asserted on the GPU, tests/test_gpu_parity.py.)"""
+    lib = _lib(hosttest_lib)
+    rc, out, err = _run([sys.executable, "bench.py", "--gpus", "8", "--frames", "4", "--rehearse-cpu", lib] + SMALL, timeout=900)
+    assert rc == 0 and len(out) == 1, err[-2000:]
+    d = json.loads(out[0])
+    assert d["n_gpus"] == 8 and d["multi_gpu"]["processes"] == 8 and d["multi_gpu"]["launcher"] == "self-spawned"
+    assert d["multi_gpu"]["exchange"].startswith("torch-gloo-hook")
+    assert d["multi_gpu"]["rccl_ranks"] == 0                   # gloo here; with the nccl backend the line says 8 (below)
+    assert d["config"]["baseline_config"].startswith("none (4 frames") and d["config"]["frames_per_gpu"] == 4
+    its = max(d["config"]["sync_outer_iters"])
+    assert 1 + 2 * min(d["config"]["sync_outer_iters"]) + 1 <= d["multi_gpu"]["exchanges_per_step"] <= 1 + 3 * its + 1
+    # the same 32-frame window in one process: same arg-min, same refinement
+    rc, one, err = _run([sys.executable, "bench.py", "--gpus", "1", "--frames", "32", "--rehearse-cpu", lib] + SMALL)
+    assert rc == 0, err[-2000:]
+    a = json.loads(one[0])
+    assert d["result"]["presync_delay"] == a["result"]["presync_delay"]
+    assert d["result"]["sync_delay"] == pytest.approx(a["result"]["sync_delay"], abs=1e-9)
+
+
+def test_the_line_names_rccl_whenever_the_backend_is_nccl():
+    """`rccl_ranks` = the world size whenever RCCL carries the sums -- through the library's own communicator or through
+    torch.distributed behind the reduce hook (the default): round 4's line said 0 for an 8-rank RCCL run through the hook.
+    (Source-level: a run with the nccl backend needs GPUs; the expression is what the line prints.)"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"rccl_ranks": world if (world > 1 and (exchange == "native-rccl" or backend == "nccl")) else 0' in src
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args([])
+    assert a.hook_device_loop is True and bench.parse_args(["--no-hook-device-loop"]).hook_device_loop is False
+    assert a.exchange == "torch"          # (native stays opt-in until it has run with two real ranks: DESIGN.md section 4)
