@@ -135,6 +135,10 @@ int rssync_ext_exchange_stats(rssync_problem* p, uint64_t* calls, uint64_t* doub
  * (a debug mode, also RSSYNC_EXECUTOR_CHECK=1).  stats: calls the executor completed, of those verified against the
  * chain, and queue[4] of the last run = {numbers claimed, numbers pushed, cells of the ring, waves launched}. */
 int rssync_ext_set_executor_check(rssync_problem* p, int on);
+/* With the check mode off, one executor call in `every` (counted over all objects of the process; default 256, also
+ * RSSYNC_EXECUTOR_CHECK_EVERY; 0 = never) is verified the same way: the executor's cross-workgroup hand-offs are a
+ * measured protocol, not an architectural guarantee, and this keeps a tripwire in production at < 1 % of its time. */
+int rssync_ext_set_executor_check_every(rssync_problem* p, uint32_t every);
 /* diagnostics: how the kernels' LDS spline windows were laid out for this problem's gyro rate (first device):
  * out = {widest frame in knots, knots per fp64 window, fp32 window of the last PreSync sweep (0 = the 80 knots compiled
  * into the kernel, else knots of dynamic LDS), its candidates per workgroup, the same window for the last GuessMotion

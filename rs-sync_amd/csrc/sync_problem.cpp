@@ -17,6 +17,7 @@
 #include "../../include/rssync_hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cmath>
 #include <cstdio>
@@ -277,7 +278,22 @@ class SyncProblemHip final : public ISyncProblem {
     // call panics.  A debug mode (it doubles the work): the executor's cross-workgroup hand-offs are a measured
     // protocol, not an architectural guarantee, and a stale word would otherwise be silent.
     bool executor_check = false;
+    // Without the check mode, ONE executor call in executor_check_every (process-wide count; RSSYNC_EXECUTOR_CHECK_EVERY,
+    // default 256, 0 = never) is verified the same way: a tripwire for the hand-off protocol in production at < 1 % of the
+    // executor's time (a verified call costs about 2.5 calls: profiles/r5_syncpoints.json).
+    uint32_t executor_check_every = 256;
+    bool check_this_call();
     uint64_t executor_runs = 0, executor_checked = 0; // calls the executor completed / of those, verified against the chain
+    // the chain re-run of a checked call runs with the executor and the progress lines off: restored on every way out,
+    // exceptions (a panic of the chain run in throwing mode) included
+    struct ChainRerun {
+        SyncProblemHip* s;
+        bool exec_was, verbose_was;
+        explicit ChainRerun(SyncProblemHip* s_) : s(s_), exec_was(s_->use_executor), verbose_was(s_->verbose) { s->use_executor = false; s->verbose = false; }
+        ~ChainRerun() { s->use_executor = exec_was; s->verbose = verbose_was; }
+        ChainRerun(const ChainRerun&) = delete;
+        ChainRerun& operator=(const ChainRerun&) = delete;
+    };
     void check_against_chain(const char* what, const std::vector<double>& c_exec, const std::vector<double>& d_exec,
                              const std::vector<std::vector<double>>& tr_exec, const std::vector<double>& c_chain,
                              const std::vector<double>& d_chain);
@@ -354,6 +370,7 @@ SyncProblemHip::SyncProblemHip() {
     if (const char* s = std::getenv("RSSYNC_EXECUTOR")) use_executor = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_EXECUTOR_FAIL")) executor_test_fail_ = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_EXECUTOR_CHECK")) executor_check = s[0] && s[0] != '0';
+    if (const char* s = std::getenv("RSSYNC_EXECUTOR_CHECK_EVERY")) { const long v = std::atol(s); if (v >= 0) executor_check_every = (uint32_t)v; }
     // RSSYNC_GPUS: how many GPUs this object spreads its frames over ("4" = devices 0..3) or which
     // ("0,2,5"); default: the calling thread's current device only
     std::vector<int> ids;
@@ -1296,6 +1313,15 @@ bool SyncProblemHip::sync_exec(const std::vector<int64_t>& begins, const std::ve
     return true;
 }
 
+// is this executor call one that gets verified?  (the check mode: every call; otherwise one in executor_check_every,
+// counted over all objects of the process -- a service that syncs one clip per object still samples)
+bool SyncProblemHip::check_this_call() {
+    if (executor_check) return true;
+    if (!executor_check_every) return false;
+    static std::atomic<uint64_t> calls{0};
+    return (calls.fetch_add(1, std::memory_order_relaxed) + 1) % executor_check_every == 0;
+}
+
 // RSSYNC_EXECUTOR_CHECK: the executor's results against the launch chain's for the same call (`traces` holds the chain's)
 void SyncProblemHip::check_against_chain(const char* what, const std::vector<double>& c_exec, const std::vector<double>& d_exec,
                                          const std::vector<std::vector<double>>& tr_exec, const std::vector<double>& c_chain,
@@ -1327,16 +1353,14 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
         // frames of up to 512 tracks: the search, the loop and the final loss of every window as one launch
         sync_exec(begins, ends_incl, initial, search_center, search_radius, 1, kStreamSyncInit + sync_calls, call_stride, costs,
                   delays_out)) {
-        if (executor_check) { // the same call once more through the launch chain (which advances the call counter itself)
+        if (check_this_call()) { // the same call once more through the launch chain (which advances the call counter itself)
             const std::vector<double> c_exec = costs, d_exec = delays_out;
             const std::vector<std::vector<double>> tr_exec = traces;
-            const bool verbose_was = verbose;
-            use_executor = false;
-            verbose = false;
             std::vector<double> c_chain, d_chain;
-            sync_windows(begins, ends_incl, initial, search_center, search_radius, c_chain, d_chain, call_stride, simplified);
-            use_executor = true;
-            verbose = verbose_was;
+            {
+                ChainRerun scope(this);
+                sync_windows(begins, ends_incl, initial, search_center, search_radius, c_chain, d_chain, call_stride, simplified);
+            }
             check_against_chain("sync_windows", c_exec, d_exec, tr_exec, c_chain, d_chain);
         } else if (call_stride == 1) sync_calls += (uint32_t)W;
         if (verbose && W == 1) { // :330, the lines the host loop would have written
@@ -1599,13 +1623,15 @@ void SyncProblemHip::sync_points(const std::vector<int64_t>& positions, int64_t 
         if (executor_ok(false) && sync_exec(positions, ends, d, initial_delay, radius, repeats, kStreamSyncInit + first_call,
                                             (uint32_t)repeats, costs, delays_out)) {
             sync_calls = first_call + (uint32_t)(W * (size_t)repeats);
-            if (!executor_check) return;
-            // RSSYNC_EXECUTOR_CHECK: the chain below runs the same calls; compare, then hand out the (identical) results
+            if (!check_this_call()) return;
+            // verified call (RSSYNC_EXECUTOR_CHECK, or this one's turn): the chain below runs the same calls; compare, then
+            // hand out the (identical) results
             c_exec = costs; d_exec = delays_out; tr_exec = traces;
             checking = true;
-            use_executor = false;
         }
     }
+    std::unique_ptr<ChainRerun> rerun;
+    if (checking) rerun.reset(new ChainRerun(this));
     std::vector<std::vector<double>> all(W);
     for (int r = 0; r < repeats; ++r) { // :314 (Sync's range is end-inclusive: window + 1 frames)
         sync_calls = first_call + (uint32_t)r;
@@ -1618,7 +1644,7 @@ void SyncProblemHip::sync_points(const std::vector<int64_t>& positions, int64_t 
     traces = all; // every repeat's rows, in order
     delays_out = d;
     if (checking) {
-        use_executor = true;
+        rerun.reset();
         check_against_chain("sync_points", c_exec, d_exec, tr_exec, costs, delays_out);
     }
 }
@@ -1796,6 +1822,10 @@ int rssync_ext_window_info(rssync_problem* p, uint32_t out[8]) {
 
 int rssync_ext_set_executor_check(rssync_problem* p, int on) {
     p->impl->executor_check = on != 0;
+    return 0;
+}
+int rssync_ext_set_executor_check_every(rssync_problem* p, uint32_t every) {
+    p->impl->executor_check_every = every;
     return 0;
 }
 int rssync_ext_executor_stats(rssync_problem* p, uint64_t* runs, uint64_t* checked, uint32_t queue[4]) {

@@ -65,6 +65,7 @@ SIGNATURES = {
     "rssync_ext_exchange_stats": (C.c_int, [C.c_void_p, _PU64, _PU64]),
     "rssync_ext_window_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "rssync_ext_set_executor_check": (C.c_int, [C.c_void_p, C.c_int]),
+    "rssync_ext_set_executor_check_every": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rssync_ext_executor_stats": (C.c_int, [C.c_void_p, _PU64, _PU64, C.POINTER(C.c_uint32)]),
     "rssync_ext_record_init_winners": (C.c_int, [C.c_void_p, C.c_int]),
     "rssync_ext_last_init_winners": (C.c_int, [C.c_void_p, _PI32, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -324,6 +325,10 @@ class SyncProblem:
     def set_executor_check(self, on=True):
         """debug mode: every call the window executor runs is re-run by the launch chain and must give the same bits"""
         self._check(self._lib.rssync_ext_set_executor_check(self._h, 1 if on else 0))
+
+    def set_executor_check_every(self, every):
+        """with the check mode off: verify one executor call in `every` against the launch chain (process-wide count; 0 = never)"""
+        self._lib.rssync_ext_set_executor_check_every(self._h, int(every))
 
     def executor_stats(self):
         """-> dict(runs, checked, head, tail, ring_cells, waves) of the window executor on this object"""

@@ -91,7 +91,7 @@ def _check_product(h, gold):
     # Sync from the stored PreSync result against the stored trace (24 x 128, noise + outliers).  A noisy scene: the
     # optimiser amplifies rounding differences.  What the device computes is bit-identical to the CPU stand-in in
     # device order (tests/test_gpu_bitexact.py); stand-in and reference-order oracle differ by the reassociation
-    # scatter measured per scene in profiles/r4_reassociation.json -- on THIS scene 1.8e-5 s, so the north-star
+    # scatter measured per scene in profiles/r5_reassociation.json -- on THIS scene 1.8e-5 s, so the north-star
     # 1e-4 s is what is asserted (tests/noisy_scenes.py).  Both start from the oracle's GuessMotion winners.
     import noisy_scenes as ns
     scene = ns.golden_noisy()

@@ -192,3 +192,32 @@ def test_executor_equals_the_chain_at_high_gyro_rates(built, fs, n_top):
         np.testing.assert_array_equal(_bits(ex.sync_trace()), _bits(ch.sync_trace()))
         assert r1 == r2
     assert ex.executor_stats()["runs"] == 2
+
+
+def test_one_call_in_n_is_verified_in_production():
+    """RSSYNC_EXECUTOR_CHECK is a debug mode (every call twice).  Without it the product still re-runs ONE executor call
+    in N (default 256, here 3) through the launch chain and panics on a difference -- a tripwire for the cross-workgroup
+    hand-off protocol (measured, not guaranteed: DESIGN.md section 4) at < 1 % of the executor's time.  The count is
+    process-wide, so of any 6 consecutive calls with N = 3 exactly 2 are verified, whichever object makes them."""
+    import rssync_amd
+    from rssync_amd import synth
+    F, N = 40, 130
+    gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=15)
+    frames = list(synth.make_frames(gyro, 0, F, N, seed=15))
+    checked = runs = 0
+    for _ in range(2):                 # two objects: the sample is over the process, not per object
+        p = rssync_amd.SyncProblem(seed=35, max_outer_iters=40)
+        _fill((p,), gyro, frames)
+        p.set_executor_check_every(3)
+        for call in range(3):
+            p.Sync(0.036, 0, 30, 0.0, 0.1)
+        st = p.executor_stats()
+        runs += st["runs"]
+        checked += st["checked"]
+    assert runs == 6 and checked == 2, (runs, checked)
+    q = rssync_amd.SyncProblem(seed=35, max_outer_iters=40)
+    _fill((q,), gyro, frames)
+    q.set_executor_check_every(0)      # off
+    for call in range(4):
+        q.Sync(0.036, 0, 30, 0.0, 0.1)
+    assert q.executor_stats()["checked"] == 0

@@ -263,7 +263,7 @@ def _check_large_frames(h, o, F, N_of, scene_name, n_cand_step=0.01):
     L5 = h.loss([0.036, 0.03, 0.035, 0.0371, 0.04])       # the five-delay batch kernel
     assert L5[0] == pytest.approx(Lh[0], rel=1e-13) and L5[1] == pytest.approx(Lh[1], rel=1e-13)
     # Sync on fresh problems from the oracle's GuessMotion winners: a handful of noisy frames, 12 iterations.  The
-    # tolerance is this scene's own (tests/noisy_scenes.py, profiles/r4_reassociation.json: ~1e-11 s measured, the
+    # tolerance is this scene's own (tests/noisy_scenes.py, profiles/r5_reassociation.json: ~1e-11 s measured, the
     # north-star 1e-4 s asserted); the fp64 evaluations themselves are compared bit for bit with the
     # device-association oracle in test_gpu_bitexact.py (3 x 9000)
     import noisy_scenes as ns

@@ -237,7 +237,7 @@ def test_sync_on_noisy_data_differs_from_the_cpu_solver_by_reassociation_only():
     that sums in the device's order (tests/test_gpu_bitexact.py), and that stand-in differs from the reference-order
     oracle only by rounding (tests/test_reassociation.py: the per-frame L-BFGS works on a loss that does not depend on
     |M| (core_private.cpp:120), so rounding moves its iterates along that direction and some frames end in another
-    basin).  The tolerance is THIS scene's (tests/noisy_scenes.py, profiles/r4_reassociation.json: measured 3.2e-5 s,
+    basin).  The tolerance is THIS scene's (tests/noisy_scenes.py, profiles/r5_reassociation.json: measured 3.2e-5 s,
     so the north-star 1e-4 s is asserted), and the device must land where the stand-in landed."""
     import noisy_scenes as ns
     scene = ns.config1_noisy()

@@ -115,6 +115,51 @@ def test_several_contexts_at_high_gyro_rates(fs):
     _check(one, _run(_fill(p, case)))
 
 
+def _case_mixed_spans(fs):
+    """as _case, but the frames' knot spans differ: most frames keep only the tracks of the first 40 % of the read-out
+    (narrow: their two ends fit a one-wave kernel's LDS window), the frames from 150 on keep all rows (at 6 kHz: two ends
+    of 11 ms x 6 kHz = 66 knots each, more than the 128 knots such a window may have)"""
+    from rssync_amd import synth
+    gyro, frames = _case(fs)
+    out = []
+    for fr, ta, tb, ra, rb in frames:
+        if fr < 150:
+            f0 = fr if fr < 1000 else fr - 1000
+            keep = (ta - f0 / synth.FPS <= 0.4 * synth.READOUT) & (tb - (f0 + 1) / synth.FPS <= 0.4 * synth.READOUT)
+            if keep.sum() >= 4:
+                ta, tb, ra, rb = ta[keep], tb[keep], ra[keep], rb[keep]
+        out.append((fr, ta, tb, ra, rb))
+    return gyro, out
+
+
+@pytest.mark.gpu
+def test_several_contexts_with_frames_wider_than_any_window():
+    """in the cap-limited regime (one-wave kernels, a frame wider than the 128 knots their LDS window may have) a
+    shard that did not hold the wide frames planned a window from its own widest frame and put an 80 .. 128-knot frame on the
+    interior path, while the single-device run -- planning from the widest frame of all -- fell back to the general path
+    for the same frame: other fp32 roundings, the sharded object no longer the single-device run's bits.  Now every context
+    plans from the frames of the WHOLE problem (rship_set_problem_frames) and a launch's window is planned from the frames
+    that can have one at all (window_plan.hpp: plan_window_frames), so that which path a frame takes follows from the
+    frame.  The wide frames live in the last shard only."""
+    import rssync_amd
+    case = _case_mixed_spans(6000.0)
+    one_p = _fill(rssync_amd.SyncProblem(seed=5, max_outer_iters=12), case)
+    one = _run(one_p)
+    info = one_p.window_info()
+    assert info["frame_ends_knots"] > 128, info   # the widest frame's two ends: beyond a one-wave kernel's window
+    p = rssync_amd.SyncProblem(seed=5, max_outer_iters=12)
+    p.set_devices([0, 0, 0])
+    _check(one, _run(_fill(p, case)))
+    # and the narrow frames take the interior path although wide ones exist: alone in a problem they give the same bits
+    g, frames = case
+    narrow = [f for f in frames if f[0] < 64]
+    a = _fill(rssync_amd.SyncProblem(seed=5, max_outer_iters=12), (g, narrow))
+    d1, c1, fc1, bh1 = a.presync_curve(0.0, 0, 64, 0.01, 0.05, per_frame=len(narrow))
+    d2, c2, fc2, bh2 = one_p.presync_curve(0.0, 0, 64, 0.01, 0.05, per_frame=len(narrow))
+    np.testing.assert_array_equal(fc1, fc2)
+    np.testing.assert_array_equal(bh1, bh2)
+
+
 def _gyro_routes(make, device_lists):
     """the gyro routes that run on the device (timestamped samples, angular rates, orientation sweep): every
     device of the object builds the table itself, and a change of devices rebuilds it from the knots"""

@@ -8,7 +8,7 @@ On noise-free data that is 1e-11 s; on noisy windows the per-frame L-BFGS amplif
 
 Every tolerance is the scene's own (tests/noisy_scenes.py: `bound_s(scene)` = the north-star 1e-4 s where that
 scene's measured maximum is below it, 2.5 x its measured maximum otherwise; measured by tests/measure/reassociation.py
-into profiles/r4_reassociation.json), the file is checked to be current, and the claim "no worse than the algorithm's
+into profiles/r5_reassociation.json), the file is checked to be current, and the claim "no worse than the algorithm's
 own scatter" is asserted on the distribution: median and 90th percentile against the control (the reference-order
 oracle started 1e-9 s away from itself).
 """
@@ -45,7 +45,7 @@ def test_noisy_windows_scatter_like_the_algorithm_itself(hosttest_lib):
 @pytest.mark.parametrize("name", ["config1_noisy", "golden_noisy", "big_8193"])
 def test_single_call_scenes_and_the_measurement_file_is_current(hosttest_lib, name):
     """The scenes the GPU tests assert with `bound_s`: recomputed here with the stand-in, they must give the numbers
-    of profiles/r4_reassociation.json (a change of the arithmetic that was not re-measured fails HERE, on the CPU),
+    of profiles/r5_reassociation.json (a change of the arithmetic that was not re-measured fails HERE, on the CPU),
     and the north-star 1e-4 s holds on each of them."""
     scene = ns.SCENES[name]()
     (r,) = ns.run_scene(scene, scene.device(hosttest_lib), scene.oracle())
@@ -67,3 +67,31 @@ def test_noise_free_windows_agree_to_1e_9_s(hosttest_lib):
     np.testing.assert_allclose(trd[:, 2], tro[:, 2], rtol=1e-5, atol=1e-9)   # (the loss is ~0 here: it is all L-BFGS stopping slack)
     np.testing.assert_array_equal(trd[:, 5], tro[:, 5])
     assert abs(r["d_dev"] - synth.D_TRUE) < 1e-4
+
+
+def test_the_stated_miss_on_205_windows_over_five_clips(hosttest_lib):
+    """Round 4 stated the one miss -- the north star's 1e-4 s on the reference's own workload shape WITH noise -- from 24
+    overlapping windows of one clip.  Round 5: 5 independent clips x 41 windows half a window apart (the reference
+    driver's spacing) = 205 windows (tests/measure/reassociation.py -> "pooled_reference_workload_noisy").  Asserted:
+    the committed numbers are this build's (one clip recomputed here), the device-order scatter is no larger than the
+    reference-order algorithm's own (control: the oracle started 1e-9 s away) at the median, the 90th percentile and the
+    maximum, on the pooled sample and on every clip's median; and what fraction of the windows IS within 1e-4 s."""
+    import json
+    pooled = json.load(open(ns.MEASURED_FILE))["pooled_reference_workload_noisy"]
+    assert pooled["windows"] == len(ns.POOLED_SEEDS) * ns.POOLED_WINDOWS_PER_SEED >= 200 and len(ns.POOLED_SEEDS) >= 5
+    # (1) current: clip 33 recomputed
+    scene = ns.reference_workload_noisy_clip(33)
+    recs = ns.run_scene(scene, scene.device(hosttest_lib), scene.oracle(), control=scene.oracle())
+    m = pooled["per_seed"]["33"]
+    np.testing.assert_allclose([r["d_dev"] for r in recs], m["delays_s"]["device_order"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose([r["d_ora"] for r in recs], m["delays_s"]["reference_order"], rtol=0, atol=1e-9)
+    # (2) the distribution: rounding in another order moves a window no further than the algorithm's own chaos does
+    dev, ctl = pooled["device_order_minus_reference_order_s"], pooled["control_reference_order_started_1e-9_s_away_s"]
+    for q in ("median", "p90", "max"):
+        assert dev[q] <= SCATTER_FACTOR * ctl[q], (q, dev[q], ctl[q])
+    for sd in ns.POOLED_SEEDS:
+        a = pooled["per_seed"][str(sd)]
+        assert a["device_order_minus_reference_order_s"]["median"] <= SCATTER_FACTOR * a["control_reference_order_started_1e-9_s_away_s"]["median"], sd
+    # (3) the miss, in numbers: most windows are within the north star, the worst is not (BASELINE.md states both)
+    assert 0.75 < pooled["fraction_within_north_star_1e-4_s"] < 1.0
+    assert dev["max"] > ns.NORTH_STAR_S and dev["median"] < ns.NORTH_STAR_S
