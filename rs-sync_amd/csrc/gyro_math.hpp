@@ -134,6 +134,25 @@ RS_HD void spline_segment(double y0, double y1, double c0, double c1, double* b,
     *d = (c1 - c0) / 3.0;
     *b = (y1 - y0) - (2.0 * c0 + c1) / 3.0;
 }
+// x / 3.0, correctly rounded, in three instructions instead of an IEEE division (~35 on gfx950): q = x * RN(1/3) is within
+// one ulp, r = x - 3 q is exact in an fma, and q + r * RN(1/3) rounds to RN(x / 3) (Markstein's theorem for a correctly
+// rounded reciprocal; 3's significand is not all ones).  Exact for every double whose quotient is a normal number; the
+// spline's coefficients are O(1) and their differences far above 1e-290.  tests/test_gpu_gyro.py compares it with the
+// division on the device and on the host.
+RS_HD double div3_exact(double x) {
+#pragma clang fp contract(off)
+    const double third = 0.33333333333333331482961625624739;
+    const double q = x * third;
+    const double r = fma(-3.0, q, x);
+    return fma(r, third, q);
+}
+// spline_segment with that division: THE SAME BITS (compact fp64 windows, kernels/sync64.hpp: only y and c of a knot are
+// kept in LDS, b and d are rebuilt per fetch)
+RS_HD void spline_segment_fast(double y0, double y1, double c0, double c1, double* b, double* d) {
+#pragma clang fp contract(off)
+    *d = div3_exact(c1 - c0);
+    *b = (y1 - y0) - div3_exact(2.0 * c0 + c1);
+}
 // the last knot's coefficients, used by the extrapolation (minispline.cpp:43-44)
 RS_HD void spline_tail(double b_prev, double d_prev, double c_prev, double* b, double* d) {
 #pragma clang fp contract(off)

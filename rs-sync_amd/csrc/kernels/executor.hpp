@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64, (RPT == 8 && !BIG) ? 2 : 1) void sync_exec_kern
         if (ph == kPhInit) {
             if (BIG && info)
                 exec_big_init<true>(p.init, slot, as_global(p.big->big_tile) + (size_t)big_entry * p.big->big_rows * kExecBigFloats, p.big->big_rows,
-                                    reinterpret_cast<f4*>(s_exec_region), p.lo.win_cap * 128u, p.big->init_cap[big_k],
+                                    reinterpret_cast<f4*>(s_exec_region), p.mo.win_bytes, p.big->init_cap[big_k],
                                     ((p.big->init_whole >> big_k) & 1u) != 0, big_k == 5u);
             else
                 lmeds_small_body<RPT, 1, true, 0>(p.init, slot, 0u, lds.small, reinterpret_cast<f4*>(s_exec_region));

@@ -362,9 +362,8 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
         // (a non-finite row keeps its flag either way: the careful form tests it per row)
         if (__builtin_amdgcn_ballot_w64(watch.qerr >= kNewtonMaxErr || watch.below_safe_normalize()) != 0) {
             bad = 0;
-            // (not unrolled: rare code kept small -- except for two rows per thread, where hipcc answered the run-time
-            // index with a copy of nrm[] in scratch memory that the hot path then used as well)
-#pragma unroll RPT <= 2 ? RPT : 1
+            // (not unrolled: rare code kept small)
+#pragma unroll 1
             for (int j = 0; j < RPT; ++j) {
                 const f4 A = load_ray(rays.a, voff, (uint32_t)j * kBlock * 16u), B = load_ray(rays.b, voff, (uint32_t)j * kBlock * 16u);
                 float t;

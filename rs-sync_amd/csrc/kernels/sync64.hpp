@@ -36,6 +36,13 @@ struct Spline64 {
     int cap;  // knots the window holds (set by the caller before staging)
     int w0b;  // run-time capacity only: the knot that maps to slot 0 for the B END's fetches (two ranges staged one after
               // the other, common.hpp: stage_window_ends); = w0 where the whole pair is staged
+    // COMPACT (run-time capacity only; round 5): the window holds y and c of a knot only -- [2][cap] d4, 64 bytes per knot
+    // instead of 128 -- and b, d are rebuilt per fetch from the knot and its successor with the expressions the table was
+    // built with (rs::spline_segment_fast: the same bits).  The one-wave kernels stage a window per evaluation for ~260
+    // fetches and every knot of it is LDS another wave of the CU cannot have; at 8 kHz a 130-track frame's two ends are
+    // 182 knots: 23 KB as full records (five waves per CU: slower than reading the table from L2), 12 KB compact.  A
+    // staged range then includes the knot after its last one.  Interior frames only (others read the table from L2).
+    int compact;
 };
 
 // the general parameter logic (extrapolation branches) with the coefficients from the LDS window: a delay that puts a
@@ -53,6 +60,21 @@ __device__ __forceinline__ void stage_window64(Spline64& s, d4* s_win, int lo, i
     hi = hi < 0 ? 0 : (hi > n - 1 ? n - 1 : hi);
     int wlen = hi - lo + 1;
     const int cap = CAP ? CAP : s.cap;
+    if constexpr (CAP == 0) {
+        if (s.compact) { // y and c of the knots lo .. hi + 1 (interior: hi + 1 <= n - 1 exists)
+            s.w0 = lo;
+            s.w0b = lo;
+            s.lds = s_win;
+            if (!interior || wlen + 1 > cap) { s.path = kPathGlobal; s.wlen = 0; return; }
+            s.path = kPathInterior;
+            s.wlen = wlen + 1;
+            for (int e = threadIdx.x; e < (wlen + 1) * 2; e += blockDim.x) {
+                const int knot = e >> 1, kind = e & 1;
+                s_win[kind * cap + knot] = s.g[(size_t)(lo + knot) * 4 + 2 * kind];
+            }
+            return;
+        }
+    }
     s.path = wlen <= cap ? (interior ? kPathInterior : kPathLds64) : kPathGlobal;
     if (wlen > cap) wlen = cap;
     s.w0 = lo;
@@ -72,6 +94,18 @@ __device__ __forceinline__ void fetch_coef64(const Spline64& s, int ci, d4& y, d
         y = p[0]; b = p[1]; c = p[2]; d = p[3];
     } else {
         const int rel = ci - ((CAP == 0 && END_B) ? s.w0b : s.w0), cap = CAP ? CAP : s.cap;
+        if constexpr (CAP == 0) {
+            if (s.compact) { // b and d from this knot and the next, as spline_finish_kernel computed them (the same bits)
+                y = s.lds[rel];
+                c = s.lds[cap + rel];
+                const d4 y1 = s.lds[rel + 1], c1 = s.lds[cap + rel + 1];
+                rs::spline_segment_fast(y.x, y1.x, c.x, c1.x, &b.x, &d.x);
+                rs::spline_segment_fast(y.y, y1.y, c.y, c1.y, &b.y, &d.y);
+                rs::spline_segment_fast(y.z, y1.z, c.z, c1.z, &b.z, &d.z);
+                rs::spline_segment_fast(y.w, y1.w, c.w, c1.w, &b.w, &d.w);
+                return;
+            }
+        }
         y = s.lds[rel];
         b = s.lds[cap + rel];
         c = s.lds[2 * cap + rel];
@@ -130,7 +164,22 @@ __device__ __forceinline__ void frame_window64(Spline64& sp, d4* s_win, const Fr
         const int lenA = k.a_hi - k.a_lo + 1, lenB = k.b_hi - k.b_lo + 1;
         const bool disjoint = k.b_lo > k.a_hi + 1 || k.a_lo > k.b_hi + 1;
         const bool interior = k.a_lo >= 0 && k.b_lo >= 0 && k.a_hi <= n - 2 && k.b_hi <= n - 2;
-        if (k.split && disjoint && interior && lenA + lenB <= cap && lenA + lenB < hi - lo + 1) {
+        if (sp.compact) {
+            // each end's range and the knot after it: slots [0, lenA + 1) and [lenA + 1, lenA + lenB + 2)
+            if (k.split && disjoint && interior && lenA + lenB + 2 <= cap && lenA + lenB + 2 < hi - lo + 2) {
+                sp.path = kPathInterior;
+                sp.w0 = k.a_lo;
+                sp.w0b = k.b_lo - (lenA + 1);
+                sp.wlen = lenA + lenB + 2;
+                sp.lds = s_win;
+                for (int e = threadIdx.x; e < (lenA + lenB + 2) * 2; e += blockDim.x) {
+                    const int slot = e >> 1, kind = e & 1;
+                    const int knot = slot <= lenA ? k.a_lo + slot : k.b_lo + (slot - lenA - 1);
+                    s_win[kind * cap + slot] = sp.g[(size_t)knot * 4 + 2 * kind];
+                }
+                return;
+            }
+        } else if (k.split && disjoint && interior && lenA + lenB <= cap && lenA + lenB < hi - lo + 1) {
             sp.path = kPathInterior;
             sp.w0 = k.a_lo;
             sp.w0b = k.b_lo - lenA;
@@ -175,6 +224,7 @@ struct Loss64Params {
     uint32_t slot0;    // the launch covers slots slot0 .. slot0 + gridDim.x (a group of windows on its own stream) ...
     const uint32_t* slots; // ... or, if not null, the slots slots[0 .. gridDim.x): the frames of one size class (rssync_kernels.hip)
     uint32_t win_cap;  // knots per spline window (dynamic LDS: nb_run x win_cap x 128 bytes; one window in the one-wave kernel)
+    uint32_t win_compact; // 1: the window holds y and c only, 64 bytes per knot (Spline64::compact; the one-wave kernels at high gyro rates)
     uint32_t nb_run;   // delays evaluated per pass over the rows: kLossBatch while their windows fit the LDS, fewer for wide frames
 };
 
@@ -262,6 +312,7 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
             sp[q].g = p.coef;
             sp[q].n = p.n_knots;
             sp[q].cap = (int)win_cap;
+            sp[q].compact = CAP ? 0 : (int)p.win_compact;
             base[q] = fr.base_knot + kdv[q];
             if (on[q]) frame_window64<CAP>(sp[q], s_loss_win + (size_t)q * 4 * win_cap, fr, kdv[q]);
         }
@@ -326,6 +377,7 @@ __device__ __forceinline__ void loss64_wave(const Loss64Params& q, uint32_t sf, 
     sp.g = q.coef;
     sp.n = q.n_knots;
     sp.cap = (int)q.win_cap;
+    sp.compact = (int)q.win_compact;
     __syncthreads(); // the window's previous users are done
     frame_window64(sp, s_win, fr, kd);
     __syncthreads();
@@ -425,7 +477,9 @@ struct Motion64Params {
     double* scratch;
     uint32_t scratch_rows;
     uint32_t scratch0;
-    uint32_t win_cap; // knots of the spline window (dynamic LDS: win_cap x 128 bytes)
+    uint32_t win_cap; // knots of the spline window (dynamic LDS: win_cap x 128 bytes, or x 64 with win_compact)
+    uint32_t win_compact; // 1: Spline64::compact
+    uint32_t win_bytes;   // bytes of that LDS region (EMU4: once the window has done its work the rows of P live there)
 };
 
 // -DRSSYNC_K3_TIMING=1 (with -DRSSYNC_K2_COUNTERS=1, whose counter array it shares): core-clock ticks of wave 0 of
@@ -612,6 +666,7 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
     sp.g = p.coef;
     sp.n = p.n_knots;
     sp.cap = (int)p.win_cap;
+    sp.compact = (int)p.win_compact;
     frame_window64(sp, s_win, fr, kd);
     __syncthreads();
 
@@ -713,7 +768,7 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
     ev.k2 = kk * kk;
     if constexpr (EMU4) {
         // the spline window has done its work: the rows of P take its place where they fit (a lane copies the rows it wrote)
-        if ((size_t)N * 24u <= (size_t)p.win_cap * 128u) {
+        if ((size_t)N * 24u <= (size_t)p.win_bytes) {
             __syncthreads();
             __attribute__((address_space(3))) double* l = (__attribute__((address_space(3))) double*)reinterpret_cast<double*>(s_win);
             for (uint32_t row = tid; row < N; row += kThreads) {
@@ -808,6 +863,7 @@ __global__ __launch_bounds__(kBlock) void debug_problem64_kernel(Debug64Params p
     sp.g = p.coef;
     sp.n = p.n_knots;
     sp.cap = kWinMax;
+    sp.compact = 0;
     frame_window64(sp, s_win, fr, p.kd);
     __syncthreads();
     for (uint32_t row = blockIdx.x * kBlock + threadIdx.x; row < fr.n; row += gridDim.x * kBlock) {
@@ -820,7 +876,7 @@ __global__ __launch_bounds__(kBlock) void debug_problem64_kernel(Debug64Params p
 
 // debug: the fp64 building blocks whose bits the CPU stand-in must reproduce (tests/test_gpu_bitexact.py names
 // the operation if one ever differs): op 0 a / b, 1 sqrt(a), 2 log1p_rcp_f64(a) -> {value, 1/(1+a)},
-// 3 fma(a, b, a), 4 the wave sum of each block of 64 values of a (out[block])
+// 3 fma(a, b, a), 4 the wave sum of each block of 64 values of a (out[block]), 5 a / 3 by rs::div3_exact (the compact spline windows)
 __global__ __launch_bounds__(64) void debug_math64_kernel(int op, const double* __restrict__ a, const double* __restrict__ b,
                                                           double* __restrict__ out, uint32_t n) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
@@ -834,6 +890,7 @@ __global__ __launch_bounds__(64) void debug_math64_kernel(int op, const double* 
     if (op == 0) out[i] = x / y;
     else if (op == 1) out[i] = sqrt(x);
     else if (op == 2) { double rc; out[2 * i] = rs::log1p_rcp_f64(x, &rc); out[2 * i + 1] = rc; }
+    else if (op == 5) out[i] = rs::div3_exact(x);
     else out[i] = fma(x, y, x);
 }
 

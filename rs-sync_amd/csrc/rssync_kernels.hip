@@ -133,6 +133,8 @@ struct rship_ctx {
     // object over several devices -- of the whole problem, so that every shard plans like the single-device run
     std::vector<rs::FrameDims> own_dims, problem_dims;
     uint32_t cls_cap64[kNumClasses] = {80, 80, 80, 80, 80, 80}; // knots of the fp64 window per class (window_plan.hpp: cap64_frames)
+    bool cls_compact = false;     // class 0's fp64 window is COMPACT: y and c only, 64 bytes per knot (kernels/sync64.hpp: Spline64::compact)
+    bool no_compact = false;      // RSSYNC_NO_COMPACT_WINDOW=1 (A/B, the bits test): round 4's rule -- full records up to 144 knots, beyond that the table from L2
     bool force_general = false;   // RSSYNC_FORCE_GENERAL_SPLINE=1 (read at creation; tools/gpu_gyro_rate.py's "before" column): no dynamic
                                   // spline windows -- frames wider than 80 knots take the general path (table from L2), as in rounds 1-3
     uint32_t one_wave_max = 512;  // frames of up to this many tracks run the one-wave kernels (K2s, loss64_small, the executor); RSSYNC_ONE_WAVE_MAX (tests, A/B)
@@ -308,7 +310,10 @@ void update_class_caps(rship_ctx* c) {
     for (int k = 0; k < kNumClasses; ++k) {
         uint32_t lo, hi;
         class_bounds(c, k, &lo, &hi);
-        c->cls_cap64[k] = c->force_general ? (uint32_t)rs::kPlanWinStatic : rs::cap64_frames(d.data(), d.size(), lo, hi, k == 0);
+        bool comp = false;
+        const bool may_compact = k == 0 && !c->no_compact && !c->no_small_loss && !c->force_general;
+        c->cls_cap64[k] = c->force_general ? (uint32_t)rs::kPlanWinStatic : rs::cap64_frames(d.data(), d.size(), lo, hi, k == 0, may_compact ? &comp : nullptr);
+        if (k == 0) c->cls_compact = comp;
     }
 }
 
@@ -366,6 +371,8 @@ static_assert(rs::kPlanWinStatic == (uint32_t)kWinMax, "window_plan.hpp and kern
 // 96 knots against 20.4 on the general path; 6 kHz 20.0 (144 knots) against 20.8; 8 kHz 25.4 (192) against 21.4; 12 kHz
 // 33.6 (272) against 21.7.
 uint32_t cap64_of(const rship_ctx* c, int k) { return c->cls_cap64[k]; }
+bool compact_of(const rship_ctx* c, int k) { return k == 0 && c->cls_compact; }
+size_t win64_bytes(const rship_ctx* c, int k) { return (size_t)c->cls_cap64[k] * (compact_of(c, k) ? 64u : 128u); } // one fp64 window of class k
 // widest whole pair of class k among the frames the windows are planned from
 float class_span(const rship_ctx* c, int k) {
     uint32_t lo, hi;
@@ -589,9 +596,10 @@ int launch_loss64(rship_ctx* c, const Loss64Params& p_in, hipStream_t st = nullp
         // launch has one window, always in dynamic LDS.
         const uint32_t cap64 = cap64_of(c, k);
         p.win_cap = cap64;
+        p.win_compact = compact_of(c, k) ? 1u : 0u;
         const bool fixed80 = !GRAD && loss_fixed80(c, k);
         p.nb_run = GRAD ? 1u : loss_nb_run(c, k);
-        const size_t dyn = fixed80 ? 0 : (size_t)p.nb_run * cap64 * 128u, dyn_small = (size_t)cap64 * 128u;
+        const size_t dyn = fixed80 ? 0 : (size_t)p.nb_run * cap64 * 128u, dyn_small = win64_bytes(c, k);
         // frames of up to 512 tracks (the reference's own: ~130): one wave per slot instead of a four-wave workgroup that
         // half idles -- the same sums in the same order (loss64_wave), four times as many slots on the chip
         if (k == 0 && !c->no_small_loss) {
@@ -636,7 +644,9 @@ int launch_motion64(rship_ctx* c, const Motion64Params& p_in, hipStream_t st = n
         const int k = r.k;
         p.slot0 = r.pos0; // (an index into order[]; with one class the list is the identity and this is the first slot)
         p.win_cap = cap64_of(c, k);
-        const size_t dyn = (size_t)p.win_cap * 128u; // the spline window (used once, for the rows of P)
+        p.win_compact = compact_of(c, k) ? 1u : 0u;
+        const size_t dyn = win64_bytes(c, k); // the spline window (used once, for the rows of P)
+        p.win_bytes = (uint32_t)dyn;
         const uint32_t cnt = r.count;
         // One wave per frame up to 512 tracks: the evaluations of a frame are dominated by their fixed part (five
         // wave reductions, the uniform L-BFGS bookkeeping) which every wave of a workgroup repeats, and a one-wave
@@ -846,6 +856,7 @@ int rship_create(rship_ctx** out, int device) {
     if (const char* s = std::getenv("RSSYNC_NO_SMALL_LOSS")) c->no_small_loss = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_FORCE_BIG")) c->force_big = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_FORCE_GENERAL_SPLINE")) c->force_general = s[0] && s[0] != '0';
+    if (const char* s = std::getenv("RSSYNC_NO_COMPACT_WINDOW")) c->no_compact = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_EXEC_BIG_MAX")) { const int v = atoi(s); if (v >= 0) c->exec_big_max = (uint32_t)v; }
     if (const char* s = std::getenv("RSSYNC_EXEC_BIG_SHARE")) { const int v = atoi(s); if (v >= 1) c->exec_big_share = (uint32_t)v; }
     if (const char* s = std::getenv("RSSYNC_ONE_WAVE_MAX")) { const int v = atoi(s); if (v >= 64 && v <= 64 * kSmallMaxRpt) c->one_wave_max = (uint32_t)v; }
@@ -1924,7 +1935,7 @@ namespace {
 // the LDS region of an executor wave: the one-wave class's fp64 window, and at least the fp32 window the launch chain's
 // search kernel gives every other class of the selection (exec_big.hpp stages it there)
 size_t exec_region_bytes(rship_ctx* c) {
-    size_t region = (size_t)cap64_of(c, 0) * 128u;
+    size_t region = win64_bytes(c, 0);
     // with frames of more than 512 tracks: 16 KB at least -- the search of such a frame keeps its unit rows (12 bytes each)
     // and keys there, its L-BFGS the rows of P (24 bytes each); with ~3.6 KB of static LDS eight waves still share a CU
     if (c->n_sel != c->cls_off[1] - c->cls_off[0]) region = std::max(region, (size_t)16 * 1024);
@@ -1972,7 +1983,8 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     // 128 bytes -- 10 KB up to ~1.7 kHz of gyro rate, more for wider frames, and then fewer waves share a CU.
     const uint32_t exec_rpt = (uint32_t)small_rpt(c->cls_max_n[0]);
     const size_t region = exec_region_bytes(c);
-    const uint32_t cap64 = (uint32_t)(region / 128u); // knots of fp64 window the region holds (>= the one-wave class's plan)
+    const bool compact = compact_of(c, 0);
+    const uint32_t cap64 = (uint32_t)(region / (compact ? 64u : 128u)); // knots of fp64 window the region holds (>= the one-wave class's plan)
     const bool with_big = ns != c->cls_off[1] - c->cls_off[0]; // frames of more than 512 tracks in the selection
     // what the chip holds at once: eight waves per CU at most (more would only idle), fewer where the LDS (~17 KB per wave
     // at 80 knots) or the registers (RPT = 8 with big frames: one wave per SIMD) say so
@@ -2194,6 +2206,8 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     ep.mo.order = nullptr;
     ep.mo.evals_out = nullptr;
     ep.mo.win_cap = cap64;
+    ep.mo.win_compact = compact ? 1u : 0u;
+    ep.mo.win_bytes = (uint32_t)region;
     // loss
     ep.lo.rays = rays64_of(c);
     ep.lo.frames = (const FrameRec*)c->frames.p;
@@ -2205,6 +2219,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     ep.lo.M = (const double*)c->M.p;
     ep.lo.k = (const double*)c->k.p;
     ep.lo.win_cap = cap64;
+    ep.lo.win_compact = compact ? 1u : 0u;
     ep.lo.nb_run = 1;
 
     {
@@ -2288,7 +2303,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
 int rship_window_info(rship_ctx* c, uint32_t out[8]) {
     out[0] = (uint32_t)c->max_span;
     out[6] = (uint32_t)c->max_ends;
-    out[7] = 0;
+    out[7] = c->cls_compact ? 1u : 0u; // the one-wave kernels' fp64 window is compact (64 bytes per knot)
     const int mk = main_class(c); // (of the class most slots of the selection belong to)
     out[1] = cap64_of(c, mk);
     out[2] = c->last_lmeds_cap;
@@ -2474,7 +2489,7 @@ int rship_debug_problem64(rship_ctx* c, uint32_t sel_index, int32_t kd, double f
 
 int rship_debug_math64(rship_ctx* c, int op, const double* a, const double* b, double* out, uint32_t n) {
     DeviceGuard dev_guard(c);
-    if (op < 0 || op > 4 || !n) return set_err(c, "debug_math64: bad arguments");
+    if (op < 0 || op > 5 || !n) return set_err(c, "debug_math64: bad arguments");
     const uint32_t blocks = (n + 63) / 64;
     const size_t n_out = op == 2 ? 2 * (size_t)n : (op == 4 ? blocks : n);
     TempBuf da, db, dout;

@@ -162,15 +162,32 @@ inline WinPlan plan_window_frames(const FrameDims* f, size_t nf, uint32_t n_lo, 
 // knots of the fp64 window for the frames of one size class: the widest frame that a window of at most `limit` knots
 // (kPlanCap64Max; kPlanCap64SmallMax for the one-wave kernels, above which a knot of window costs more in resident waves
 // than the general path's fetches from L2) can hold; wider frames read the table from L2 -- the same bits either way
-inline uint32_t cap64_frames(const FrameDims* f, size_t nf, uint32_t n_lo, uint32_t n_hi, bool one_wave) {
-    const uint32_t limit = one_wave ? kPlanCap64SmallMax : kPlanCap64Max;
+// One-wave kernels (round 5): beyond kPlanCompactFrom knots the window is COMPACT -- y and c of a knot only, 64 bytes
+// instead of 128, b and d rebuilt per fetch with the table's own expressions (kernels/sync64.hpp: Spline64::compact) -- so
+// that up to kPlanCompactMax knots still leave a CU its eight one-wave workgroups (8 kHz: a 130-track frame's two
+// ends are 182 knots = 12 KB compact, eight waves per CU; as full records 23 KB, five waves: slower than the table from
+// L2).  Up to kPlanCompactFrom knots (4 kHz) full records already leave eight waves per CU and cost no arithmetic.
+constexpr uint32_t kPlanCompactFrom = 96;
+// measured on 98 sync points of 61 x 130, iterations capped at 25 per call (profiles/r5_gyro_rate_small_frames.json), compact
+// against round 4's rule (full records to 144 knots, then the table from L2): 6 kHz 19.0 ms against 20.2; 8 kHz (192 knots,
+// 12 KB: eight waves per CU) 19.4 against 21.6; 12 kHz (288 knots, 18 KB: seven waves) 22.4 against 22.1 -- the rebuilt
+// coefficients (~90 more fp64 instructions per row) eat what the window saves there.  So: compact up to 208 knots (13 KB,
+// the most that leaves the executor its eight waves per CU), the table from L2 beyond.
+constexpr uint32_t kPlanCompactMax = 208;
+// (a compact range also holds the knot after its last one, per end: + 2)
+inline uint32_t cap64_frames(const FrameDims* f, size_t nf, uint32_t n_lo, uint32_t n_hi, bool one_wave, bool* compact = nullptr) {
+    const uint32_t limit = one_wave ? (compact ? kPlanCompactMax : kPlanCap64SmallMax) : kPlanCap64Max;
     uint32_t need = kPlanWinStatic;
+    bool comp = false;
     for (size_t i = 0; i < nf; ++i) {
         if (f[i].n < n_lo || f[i].n > n_hi || !f[i].n) continue;
-        uint32_t k = (uint32_t)std::ceil(std::max(std::min(f[i].span, f[i].ends), 0.f)) + 1u;
-        k = (k + 15u) / 16u * 16u;
-        if (k <= limit && k > need) need = k;
+        const uint32_t raw = (uint32_t)std::ceil(std::max(std::min(f[i].span, f[i].ends), 0.f)) + 1u;
+        const bool c = one_wave && compact && raw > kPlanCompactFrom;
+        uint32_t k = ((c ? raw + 2u : raw) + 15u) / 16u * 16u;
+        if (k <= limit && k > need) { need = k; }
+        if (c && k <= limit) comp = true;
     }
+    if (compact) *compact = comp;
     return need;
 }
 

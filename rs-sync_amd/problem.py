@@ -320,7 +320,8 @@ class SyncProblem:
         q = (C.c_uint32 * 8)()
         self._check(self._lib.rssync_ext_window_info(self._h, q))
         return dict(frame_span_knots=q[0], fp64_window_knots=q[1], presync_window_knots=q[2] or 80, presync_window_dynamic=bool(q[2]),
-                    presync_chunk=q[3], init_window_knots=q[4] or 80, trial_delays_per_pass=q[5], frame_ends_knots=q[6])
+                    presync_chunk=q[3], init_window_knots=q[4] or 80, trial_delays_per_pass=q[5], frame_ends_knots=q[6],
+                    fp64_window_compact=bool(q[7]))
 
     def set_executor_check(self, on=True):
         """debug mode: every call the window executor runs is re-run by the launch chain and must give the same bits"""
@@ -353,7 +354,7 @@ class SyncProblem:
         self._lib.rssync_ext_set_init_override(self._h, _p(w, _PI32), w.size)
 
     def debug_math64(self, op, a, b=None):
-        """The Sync kernels' fp64 building blocks on arrays: 0 a/b, 1 sqrt, 2 (log1p, 1/(1+a)), 3 fma(a,b,a), 4 wave sums."""
+        """The Sync kernels' fp64 building blocks on arrays: 0 a/b, 1 sqrt, 2 (log1p, 1/(1+a)), 3 fma(a,b,a), 4 wave sums, 5 a/3 (div3_exact)."""
         a = _d(a)
         b = _d(b) if b is not None else None
         n = a.size

@@ -757,7 +757,7 @@ int rship_debug_problem64(rship_ctx* c, uint32_t sel_index, int32_t kd, double f
 }
 
 int rship_debug_math64(rship_ctx* c, int op, const double* a, const double* b, double* out, uint32_t n) {
-    if (op < 0 || op > 4 || !n) return fail(c, "debug_math64: bad arguments");
+    if (op < 0 || op > 5 || !n) return fail(c, "debug_math64: bad arguments");
     if (op == 4) {
         for (uint32_t blk = 0; blk < (n + 63) / 64; ++blk) {
             double lanes[64];
@@ -771,6 +771,7 @@ int rship_debug_math64(rship_ctx* c, int op, const double* a, const double* b, d
         if (op == 0) out[i] = x / y;
         else if (op == 1) out[i] = std::sqrt(x);
         else if (op == 2) { double rc; out[2 * i] = rs::log1p_rcp_f64(x, &rc); out[2 * i + 1] = rc; }
+        else if (op == 5) out[i] = rs::div3_exact(x);
         else out[i] = std::fma(x, y, x);
     }
     return 0;

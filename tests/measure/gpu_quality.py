@@ -15,58 +15,82 @@ from oracle.oracle import OracleProblem
 
 F = int(os.environ.get("F", 600)); N = int(os.environ.get("N", 130))
 WINDOW = int(os.environ.get("WINDOW", 60)); DIST = int(os.environ.get("DIST", 30))
-DRIFT = float(os.environ.get("DRIFT", 2e-4)); SEED = 0x5EED0007
+DRIFT = float(os.environ.get("DRIFT", 2e-4))
 NOISE = float(os.environ.get("NOISE", 1e-3)); OUTL = float(os.environ.get("OUTLIERS", 0.1))
-g = synth.make_gyro(0, (F + 2) / synth.FPS, seed=SEED)
-frames = list(synth.make_frames(g, 0, F, N, seed=SEED, drift=DRIFT, noise=NOISE, outliers=OUTL))
+# round 5: the scene on several independent clips (round 4's figures rested on the first seed alone)
+SEEDS = [0x5EED0007 + i for i in range(int(os.environ.get("SEEDS", 5)))]
 pos = quality.sync_points_auto(0, F, WINDOW, DIST)
 threads = os.cpu_count() or 1
 
 
-def fill(p):
-    p.SetGyroQuaternions(g.quats, g.fs, g.t0)
-    for fr in frames:
-        p.SetTrackResult(*fr)
-    return p
+def run(SEED):
+    g = synth.make_gyro(0, (F + 2) / synth.FPS, seed=SEED)
+    frames = list(synth.make_frames(g, 0, F, N, seed=SEED, drift=DRIFT, noise=NOISE, outliers=OUTL))
+
+    def fill(p):
+        p.SetGyroQuaternions(g.quats, g.fs, g.t0)
+        for fr in frames:
+            p.SetTrackResult(*fr)
+        return p
+
+    def oracle_chain(eps=0.0):
+        o = fill(OracleProblem(seed=SEED, threads=threads, faithful=False))
+        out, pre = [], []
+        for p0 in pos:
+            d = o.PreSync(0.0, p0, p0 + WINDOW, 0.001, 0.1)[1]
+            pre.append(d)
+            d += eps
+            for _ in range(4):
+                d = o.Sync(d, p0, p0 + WINDOW, 0.0, 0.1)[1]
+            out.append(d)
+        return np.array(out), np.array(pre)
+
+    h = fill(rssync_amd.SyncProblem(seed=SEED))
+    t = time.perf_counter(); _, dh = h.sync_points(pos, WINDOW, 0.0, 0.001, 0.1); th = time.perf_counter() - t
+    t = time.perf_counter(); do, pre_o = oracle_chain(); to = time.perf_counter() - t
+    do_eps, _ = oracle_chain(1e-9)
+    # one Sync call per sync point, both sides from the oracle's PreSync delay, fresh objects (call counter 0)
+    h1 = fill(rssync_amd.SyncProblem(seed=SEED))
+    o1 = fill(OracleProblem(seed=SEED, threads=threads, faithful=False))
+    first = []
+    for p0, d0 in zip(pos, pre_o):
+        first.append(h1.Sync(float(d0), p0, p0 + WINDOW, 0.0, 0.1)[1] - o1.Sync(float(d0), p0, p0 + WINDOW, 0.0, 0.1)[1])
+    first = np.array(first)
+    mid = (np.array(pos) + WINDOW / 2) / synth.FPS
+    truth = synth.D_TRUE + DRIFT * mid
+    sh, ih, rh = quality.linear_fit_rmse(pos, 1e3 * dh)
+    so, io, ro = quality.linear_fit_rmse(pos, 1e3 * do)
+    return {"seed": SEED,
+            "hip": {"slope": sh, "intercept": ih, "rmse_ms": rh, "max_err_vs_truth_ms": float(1e3 * np.abs(dh - truth).max()), "s": round(th, 3)},
+            "oracle": {"slope": so, "intercept": io, "rmse_ms": ro, "max_err_vs_truth_ms": float(1e3 * np.abs(do - truth).max()), "s": round(to, 3)},
+            "first_sync_max_abs_hip_minus_oracle_ms": float(1e3 * np.abs(first).max()),
+            "first_sync_median_abs_hip_minus_oracle_ms": float(1e3 * np.median(np.abs(first))),
+            "chain_max_abs_hip_minus_oracle_ms": float(1e3 * np.abs(dh - do).max()),
+            "chain_median_abs_hip_minus_oracle_ms": float(1e3 * np.median(np.abs(dh - do))),
+            "oracle_self_max_abs_ms_after_1e-9_s_perturbation": float(1e3 * np.abs(do_eps - do).max()),
+            "oracle_self_median_abs_ms_after_1e-9_s_perturbation": float(1e3 * np.median(np.abs(do_eps - do)))}
 
 
-def oracle_chain(eps=0.0):
-    o = fill(OracleProblem(seed=SEED, threads=threads, faithful=False))
-    out, pre = [], []
-    for p0 in pos:
-        d = o.PreSync(0.0, p0, p0 + WINDOW, 0.001, 0.1)[1]
-        pre.append(d)
-        d += eps
-        for _ in range(4):
-            d = o.Sync(d, p0, p0 + WINDOW, 0.0, 0.1)[1]
-        out.append(d)
-    return np.array(out), np.array(pre)
+per_seed = []
+for sd in SEEDS:
+    per_seed.append(run(sd))
+    print("seed %#x: rmse hip %.3f ms, oracle %.3f ms" % (sd, per_seed[-1]["hip"]["rmse_ms"], per_seed[-1]["oracle"]["rmse_ms"]), file=sys.stderr, flush=True)
 
 
-h = fill(rssync_amd.SyncProblem(seed=SEED))
-t = time.perf_counter(); _, dh = h.sync_points(pos, WINDOW, 0.0, 0.001, 0.1); th = time.perf_counter() - t
-t = time.perf_counter(); do, pre_o = oracle_chain(); to = time.perf_counter() - t
-do_eps, _ = oracle_chain(1e-9)
+def spread(get):
+    v = np.array([get(r) for r in per_seed])
+    return {"mean": float(v.mean()), "std": float(v.std()), "min": float(v.min()), "max": float(v.max())}
 
-# one Sync call per sync point, both sides from the oracle's PreSync delay, fresh objects (call counter 0)
-h1 = fill(rssync_amd.SyncProblem(seed=SEED))
-o1 = fill(OracleProblem(seed=SEED, threads=threads, faithful=False))
-first = []
-for p0, d0 in zip(pos, pre_o):
-    first.append(h1.Sync(float(d0), p0, p0 + WINDOW, 0.0, 0.1)[1] - o1.Sync(float(d0), p0, p0 + WINDOW, 0.0, 0.1)[1])
-first = np.array(first)
 
-mid = (np.array(pos) + WINDOW / 2) / synth.FPS
-truth = synth.D_TRUE + DRIFT * mid
-sh, ih, rh = quality.linear_fit_rmse(pos, 1e3 * dh)
-so, io, ro = quality.linear_fit_rmse(pos, 1e3 * do)
-print(json.dumps({"frames": F, "tracks": N, "window": WINDOW, "positions": len(pos), "drift_ms_per_frame": 1e3 * DRIFT / synth.FPS,
-                  "noise_rad": NOISE, "outliers": OUTL,
-                  "hip": {"slope": sh, "intercept": ih, "rmse_ms": rh, "max_err_vs_truth_ms": float(1e3 * np.abs(dh - truth).max()), "s": round(th, 3)},
-                  "oracle": {"slope": so, "intercept": io, "rmse_ms": ro, "max_err_vs_truth_ms": float(1e3 * np.abs(do - truth).max()), "s": round(to, 3)},
-                  "first_sync_max_abs_hip_minus_oracle_ms": float(1e3 * np.abs(first).max()),
-                  "first_sync_median_abs_hip_minus_oracle_ms": float(1e3 * np.median(np.abs(first))),
-                  "chain_max_abs_hip_minus_oracle_ms": float(1e3 * np.abs(dh - do).max()),
-                  "chain_median_abs_hip_minus_oracle_ms": float(1e3 * np.median(np.abs(dh - do))),
-                  "oracle_self_max_abs_ms_after_1e-9_s_perturbation": float(1e3 * np.abs(do_eps - do).max()),
-                  "oracle_self_median_abs_ms_after_1e-9_s_perturbation": float(1e3 * np.median(np.abs(do_eps - do)))}))
+out = dict(per_seed[0])          # (the first seed's figures at the top level, as round 4's file had them)
+out.update({"frames": F, "tracks": N, "window": WINDOW, "positions": len(pos), "drift_ms_per_frame": 1e3 * DRIFT / synth.FPS,
+            "noise_rad": NOISE, "outliers": OUTL, "seeds": len(SEEDS),
+            "over_seeds": {"rmse_ms_hip": spread(lambda r: r["hip"]["rmse_ms"]), "rmse_ms_oracle": spread(lambda r: r["oracle"]["rmse_ms"]),
+                           "rmse_ms_hip_minus_oracle": spread(lambda r: r["hip"]["rmse_ms"] - r["oracle"]["rmse_ms"]),
+                           "slope_ms_per_frame_hip": spread(lambda r: r["hip"]["slope"]), "slope_ms_per_frame_oracle": spread(lambda r: r["oracle"]["slope"]),
+                           "first_sync_median_abs_hip_minus_oracle_ms": spread(lambda r: r["first_sync_median_abs_hip_minus_oracle_ms"]),
+                           "first_sync_max_abs_hip_minus_oracle_ms": spread(lambda r: r["first_sync_max_abs_hip_minus_oracle_ms"]),
+                           "chain_median_abs_hip_minus_oracle_ms": spread(lambda r: r["chain_median_abs_hip_minus_oracle_ms"]),
+                           "oracle_self_median_abs_ms_after_1e-9_s_perturbation": spread(lambda r: r["oracle_self_median_abs_ms_after_1e-9_s_perturbation"])},
+            "per_seed": per_seed})
+print(json.dumps(out))

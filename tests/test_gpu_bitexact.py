@@ -59,6 +59,11 @@ def test_fp64_building_blocks(hosttest_lib):
     with np.errstate(over="ignore", under="ignore"):
         np.testing.assert_array_equal(gpu.debug_math64(0, a, b), a / b)
     np.testing.assert_array_equal(gpu.debug_math64(1, a), np.sqrt(a))
+    # x / 3 in three instructions (rs::div3_exact: the compact spline windows rebuild b and d of a knot with it) IS the
+    # correctly rounded division, on the device and on the host, over the whole range of normal quotients
+    t = np.concatenate([s, a[: n // 2], -a[n // 2:], [3.0, 1.0, 2.0 ** -1000, 2.0 ** 1000, 1.0 + 2.0 ** -52, 0.0]])
+    np.testing.assert_array_equal(_bits(gpu.debug_math64(5, t)), _bits(t / 3.0))
+    np.testing.assert_array_equal(_bits(cpu.debug_math64(5, t)), _bits(t / 3.0))
     # and the routine is log1p to a few ulp
     lg = gpu.debug_math64(2, u)
     np.testing.assert_allclose(lg[:, 0], np.log1p(u), rtol=1e-15, atol=0)

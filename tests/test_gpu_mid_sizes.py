@@ -572,3 +572,59 @@ def test_window_capacity_does_not_change_the_fp64_bits(monkeypatch, fs, N):
     La2, Ga2 = a.loss([d0, 0.03, 0.0371], grad=True)
     np.testing.assert_array_equal(np.asarray(La2).view(np.uint64), np.asarray(Lb).view(np.uint64))
     np.testing.assert_array_equal(np.asarray(Ga2).view(np.uint64), np.asarray(Gb).view(np.uint64))
+
+
+@pytest.mark.parametrize("fs,N,compact", [(4000.0, 130, False), (6000.0, 130, True), (8000.0, 130, True), (12000.0, 200, False), (8000.0, 400, True)])
+def test_compact_fp64_windows_do_not_change_a_bit(monkeypatch, fs, N, compact):
+    """Round 5: beyond 96 knots the one-wave kernels' fp64 window keeps only y and c of a knot (64 bytes instead of 128) and
+    rebuilds b and d per fetch with the expressions the table was built with (minispline.cpp:38-41 as spline_finish_kernel
+    has them; the division by 3 as rs::div3_exact, correctly rounded): 8 kHz (a 130-track frame's two ends: 182 knots)
+    stays on the LDS path -- round 4 read the table from L2 there (12 kHz, 272 knots, still does: measured no faster
+    compact, profiles/r5_gyro_rate_small_frames.json).  The same bits as full records
+    (RSSYNC_NO_COMPACT_WINDOW=1: round 4's rule) and as the general path (RSSYNC_FORCE_GENERAL_SPLINE=1): rows, loss,
+    derivative, every trace row of Sync through the executor and through the launch chain."""
+    import rssync_amd
+    from rssync_amd import synth
+    F = 14
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, fs=fs, seed=61)
+    frames = list(synth.make_frames(g, 0, F, N, seed=61))
+
+    def make(env):
+        for k in ("RSSYNC_NO_COMPACT_WINDOW", "RSSYNC_FORCE_GENERAL_SPLINE", "RSSYNC_EXECUTOR"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        p = rssync_amd.SyncProblem(seed=SEED, max_outer_iters=15)
+        p.SetGyroQuaternions(g.quats, g.fs, g.t0)
+        for fr in frames:
+            p.SetTrackResult(*fr)
+        p.upload()
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+        return p
+    a = make({})
+    a.record_init_winners(True)
+    ra = a.Sync(0.0355, 0, F - 1, 0.0, 0.1)
+    wi = a.window_info()
+    if N > int(os.environ.get("RSSYNC_ONE_WAVE_MAX", 512)):
+        compact = False                      # (the `kernel_family` fixture: these frames in the four-wave kernels, whose windows are full records)
+    assert bool(wi.get("fp64_window_compact")) == compact, wi
+    if compact:
+        assert wi["fp64_window_knots"] >= wi["frame_ends_knots"] + 2 > 98      # the window holds the frame: no fallback to L2
+    ta = a.sync_trace()
+    win = a.last_init_winners()
+    Pa = a.problem_matrix64(3, 0.0371, N)
+    Ma, ka = a.init_motion(0.0355, 0, F - 1)
+    La, Ga = a.loss([0.0355, 0.03, 0.0371], grad=True)
+    for env in ({"RSSYNC_NO_COMPACT_WINDOW": "1"}, {"RSSYNC_FORCE_GENERAL_SPLINE": "1"}, {"RSSYNC_EXECUTOR": "0"},
+                {"RSSYNC_EXECUTOR": "0", "RSSYNC_NO_COMPACT_WINDOW": "1"}):
+        b = make(env)
+        b.set_init_override(win)             # (the fp32 search may flip a near-tie between its two spline paths)
+        assert b.Sync(0.0355, 0, F - 1, 0.0, 0.1) == ra, env
+        np.testing.assert_array_equal(b.sync_trace().view(np.uint64), ta.view(np.uint64), err_msg=str(env))
+        np.testing.assert_array_equal(b.problem_matrix64(3, 0.0371, N).view(np.uint64), Pa.view(np.uint64))
+        b.init_motion(0.0355, 0, F - 1)
+        b.set_motion(Ma, ka)
+        Lb, Gb = b.loss([0.0355, 0.03, 0.0371], grad=True)
+        np.testing.assert_array_equal(np.asarray(Lb).view(np.uint64), np.asarray(La).view(np.uint64), err_msg=str(env))
+        np.testing.assert_array_equal(np.asarray(Gb).view(np.uint64), np.asarray(Ga).view(np.uint64), err_msg=str(env))

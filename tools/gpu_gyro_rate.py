@@ -64,7 +64,7 @@ def large(fs, general):
     return out
 
 
-def small(fs, general, bounded=None):
+def small(fs, general, bounded=None, no_compact=False):
     """bounded: outer iterations per Sync call capped (every window's four calls then take at most 4 x bounded
     iterations: the run's length no longer follows ONE window that the reference's loop does not converge on -- at 6 and
     8 kHz this scene has such a window, 460-510 iterations over its four calls against ~55 on average -- and rates compare)"""
@@ -72,6 +72,10 @@ def small(fs, general, bounded=None):
         os.environ["RSSYNC_FORCE_GENERAL_SPLINE"] = "1"
     else:
         os.environ.pop("RSSYNC_FORCE_GENERAL_SPLINE", None)
+    if no_compact:   # round 4's rule for the one-wave kernels' fp64 window: full records up to 144 knots, beyond that the table from L2
+        os.environ["RSSYNC_NO_COMPACT_WINDOW"] = "1"
+    else:
+        os.environ.pop("RSSYNC_NO_COMPACT_WINDOW", None)
     Fs, Ns, W, D = 3000, 130, 60, 30
     g = synth.make_gyro(0, (Fs + 2) / synth.FPS, fs=fs, seed=6)
     h = rssync_amd.SyncProblem(seed=6, verbose=False, **({"max_outer_iters": bounded} if bounded else {}))
@@ -87,7 +91,7 @@ def small(fs, general, bounded=None):
         t_all = dt if t_all is None else min(t_all, dt)
     if bounded:
         iters = [len(h.window_trace(w)) for w in range(len(pos))]
-        out = {"sync_points_s": round(t_all, 4), "outer_iterations_cap_per_call": bounded,
+        out = {"sync_points_s": round(t_all, 4), "outer_iterations_cap_per_call": bounded, "windows": h.window_info(),
                "outer_iterations_per_position": {"mean": round(float(np.mean(iters)), 2), "max": int(np.max(iters))},
                "executor_tasks": h.executor_stats()["head"], "executor_waves": h.executor_stats()["waves"]}
         h.close()
@@ -114,7 +118,9 @@ for fs in RATES:
             row["large_general_path"] = large(fs, True)
         row["small_general_path"] = small(fs, True)
         row["small_general_path_bounded"] = small(fs, True, BOUND)
+        row["small_round4_window_rule_bounded"] = small(fs, False, BOUND, no_compact=True)
     res["by_gyro_hz"][int(fs)] = row
     print("%g Hz done" % fs, file=sys.stderr, flush=True)
 os.environ.pop("RSSYNC_FORCE_GENERAL_SPLINE", None)
+os.environ.pop("RSSYNC_NO_COMPACT_WINDOW", None)
 print(json.dumps(res, indent=1))
