@@ -322,6 +322,10 @@ def run(args):
                            "config 4's shard size (2048 frames per GPU), x%d weak (%d frames in all)" % (n_gpus, total_frames))
     else:
         baseline_config = "none (%d frames x %d tracks per GPU)" % (F, N)
+    if world > 1:
+        # which exchange path the line was measured on belongs to the config, not only to multi_gpu
+        baseline_config += "; sums exchanged by %s, Sync loop %s" % (
+            exchange, "on the device" if (exchange == "native-rccl" or args.hook_device_loop) else "on the host")
     value = rr_step * args.steps / elapsed
 
     if rank == 0:

@@ -82,6 +82,11 @@ def test_random_noisy_case(seed):
         np.testing.assert_allclose(fch[:, big][same], fco[:, big][same], rtol=3e-3)
         cbh, cbo = fch[:, big].sum(axis=1), fco[:, big].sum(axis=1)
         rel = np.abs(cbh - cbo) / cbo   # a candidate where one frame's near-tie went the other way moves by a few %
+        # A TOLERANCE WIDENED TO PASS, on the record: until round 4 this read "> 90 % of the candidates within 3e-3".  Soak
+        # case 360 (gpurun_out/r4l_fuzz_check.log: a sweep of FOUR candidates, one frame's near-tie between two hypotheses
+        # fell the other way in fp32 at one of them: 1 of 4 = 25 % outside) failed that form without anything being wrong --
+        # a single flip is the fp32 search's stated behaviour -- so the count allowed is now
+        # max(1, 10 %): one flip however few candidates a case draws, and never a move above 10 %.
         assert np.sum(rel > 3e-3) <= max(1, 0.1 * len(rel)) and rel.max() < 0.1   # (one flip allowed however few candidates a case has)
         srt = np.sort(cbo)
         if len(srt) > 1 and srt[1] - srt[0] > 0.08 * srt[0]:   # a clear minimum: the same candidate wins
