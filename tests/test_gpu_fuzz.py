@@ -1,5 +1,6 @@
 """Randomised differential cases, HIP against the CPU restatement: gyro rate (200 Hz .. 6.4 kHz), number of frames, ragged track
-counts (2 .. 700: every rows-per-thread instantiation, frames of one wave and of four), sparse frame ids, sweep
+counts (2 .. 2300: frames of one wave and of four with 4 / 8 / 16 rows per thread -- up to four SIZE CLASSES in one problem,
+round 5), sparse frame ids, sweep
 step / radius / centre all drawn per seed.  What is compared is what does not depend on rounding noise: the fp64
 rows, the fp64 loss and its analytic gradient, PreSync's per-frame costs where both sides chose the same
 hypothesis, the arg-min of the sweep, and Sync on noise-free scenes."""
@@ -10,7 +11,7 @@ import pytest
 
 import rssync_amd
 from rssync_amd import synth
-from oracle.oracle import OracleProblem
+from oracle.oracle import OracleProblem, sample_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -19,13 +20,24 @@ RATES = [200.0, 400.0, 500.0, 800.0, 1000.0, 1600.0, 2000.0, 3200.0, 4000.0, 640
 EXTRA = int(os.environ.get("RSSYNC_FUZZ_CASES", "0"))
 
 
+def lower_quartile_fp64(P, i0, i1):
+    """core_private.cpp:35-52 in numpy fp64: the N/4-th smallest squared residual of the hypothesis drawn as rows (i0, i1)"""
+    nrm = np.linalg.norm(P, axis=1)
+    nP = P / np.where(nrm < 1e-12, 1.0, nrm)[:, None]
+    v = np.cross(P[i0], P[i1])
+    nv = np.linalg.norm(v)
+    if nv >= 1e-12:
+        v = v / nv
+    return float(np.sort((nP @ v) ** 2)[len(P) // 4])
+
+
 def draw_case(seed, clean):
     rng = np.random.default_rng(1000 + seed)
     fs = RATES[int(rng.integers(len(RATES)))]
     F = int(rng.integers(3, 15))
     first = int(rng.integers(0, 40))
     ids = first + np.sort(rng.choice(3 * F, size=F, replace=False))
-    n_max = int(rng.choice([40, 130, 256, 300, 520, 700]))
+    n_max = int(rng.choice([40, 130, 256, 300, 520, 700, 1100, 2300], p=[.15, .15, .15, .15, .15, .15, .05, .05]))
     counts = [int(rng.integers(2, n_max + 1)) for _ in range(F)]
     counts[int(rng.integers(F))] = n_max
     g = synth.make_gyro(first / synth.FPS, (int(ids[-1]) + 2) / synth.FPS, fs=fs, seed=seed)
@@ -86,8 +98,18 @@ def test_random_noisy_case(seed):
         # case 360 (gpurun_out/r4l_fuzz_check.log: a sweep of FOUR candidates, one frame's near-tie between two hypotheses
         # fell the other way in fp32 at one of them: 1 of 4 = 25 % outside) failed that form without anything being wrong --
         # a single flip is the fp32 search's stated behaviour -- so the count allowed is now
-        # max(1, 10 %): one flip however few candidates a case draws, and never a move above 10 %.
-        assert np.sum(rel > 3e-3) <= max(1, 0.1 * len(rel)) and rel.max() < 0.1   # (one flip allowed however few candidates a case has)
+        # max(1, 10 %): one flip however few candidates a case draws.
+        assert np.sum(rel > 3e-3) <= max(1, 0.1 * len(rel))
+        # ... and HOW FAR a flip moves a candidate's cost says nothing (round 5, soak case 230: the only flip of the case, on
+        # one of three frames, moved that candidate by 16 % and failed the blanket "< 10 %" that stood here).  What makes a
+        # flip legitimate is that the two hypotheses TIE in the reference's own arithmetic: their lower quartiles, recomputed
+        # here in fp64 from the oracle's rows, must agree to 1e-2 (case 230: 2e-5; a winner chosen wrongly would be off by
+        # O(1): quartiles of unrelated hypotheses differ by factors).
+        flips = [(c, j) for c, j in zip(*np.nonzero(bhh != bho)) if big[j] and bhh[c, j] >= 0 and bho[c, j] >= 0]
+        for c, j in flips[:12]:
+            P = o.problem_matrix(ids[j], float(do[c]))
+            q = [lower_quartile_fp64(P, *sample_pair(seed, ids[j], int(c), int(w), counts[j])) for w in (bhh[c, j], bho[c, j])]
+            assert abs(q[0] - q[1]) <= 1e-2 * max(q[1], 1e-300), (seed, int(c), int(ids[j]), q)
         srt = np.sort(cbo)
         if len(srt) > 1 and srt[1] - srt[0] > 0.08 * srt[0]:   # a clear minimum: the same candidate wins
             assert int(np.argmin(cbh)) == int(np.argmin(cbo))
