@@ -102,14 +102,26 @@ def test_random_noisy_case(seed):
         assert np.sum(rel > 3e-3) <= max(1, 0.1 * len(rel))
         # ... and HOW FAR a flip moves a candidate's cost says nothing (round 5, soak case 230: the only flip of the case, on
         # one of three frames, moved that candidate by 16 % and failed the blanket "< 10 %" that stood here).  What makes a
-        # flip legitimate is that the two hypotheses TIE in the reference's own arithmetic: their lower quartiles, recomputed
-        # here in fp64 from the oracle's rows, must agree to 1e-2 (case 230: 2e-5; a winner chosen wrongly would be off by
-        # O(1): quartiles of unrelated hypotheses differ by factors).
+        # flip legitimate is that the two hypotheses TIE in the reference's own arithmetic as far as the fp32 search can
+        # tell: their lower-quartile residuals, recomputed here in fp64 from the oracle's rows, differ by no more than the
+        # fp32 rows' error can move either of them.  A direction v = P[i0] x P[i1] built from rows known to 5e-7 absolute
+        # (profiles/r4_config2_parity.json) is off by up to err_v = 5e-7 (1/|P[i0]| + 1/|P[i1]|) / sin(angle) radians, and a
+        # residual n.v by as much.  Allowed: 0.2 err_v (of the worse-conditioned of the two) + 0.5 % of the residual.
+        # Measured on 6000 soaked cases (profiles/r5_fuzz_soak.txt): 10 flips above 1 % of the quartile, every one with a
+        # defining row below 1.3e-4 or a pair within 0.6 degrees of parallel, the largest at 0.066 err_v; well-conditioned
+        # pairs flip at <= 1e-4.  A winner chosen WRONGLY would be off by O(1): quartiles of unrelated hypotheses differ by
+        # factors.
         flips = [(c, j) for c, j in zip(*np.nonzero(bhh != bho)) if big[j] and bhh[c, j] >= 0 and bho[c, j] >= 0]
         for c, j in flips[:12]:
             P = o.problem_matrix(ids[j], float(do[c]))
-            q = [lower_quartile_fp64(P, *sample_pair(seed, ids[j], int(c), int(w), counts[j])) for w in (bhh[c, j], bho[c, j])]
-            assert abs(q[0] - q[1]) <= 1e-2 * max(q[1], 1e-300), (seed, int(c), int(ids[j]), q)
+            nr = np.linalg.norm(P, axis=1)
+            rq, err_v = [], 0.0
+            for w in (bhh[c, j], bho[c, j]):
+                i0, i1 = sample_pair(seed, ids[j], int(c), int(w), counts[j])
+                rq.append(np.sqrt(lower_quartile_fp64(P, i0, i1)))
+                sin_a = np.linalg.norm(np.cross(P[i0], P[i1])) / max(nr[i0] * nr[i1], 1e-300)
+                err_v = max(err_v, 5e-7 * (1.0 / max(nr[i0], 1e-300) + 1.0 / max(nr[i1], 1e-300)) / max(sin_a, 1e-300))
+            assert abs(rq[0] - rq[1]) <= 0.2 * err_v + 5e-3 * rq[1], (seed, int(c), int(ids[j]), rq, err_v)
         srt = np.sort(cbo)
         if len(srt) > 1 and srt[1] - srt[0] > 0.08 * srt[0]:   # a clear minimum: the same candidate wins
             assert int(np.argmin(cbh)) == int(np.argmin(cbo))
@@ -141,7 +153,9 @@ def test_random_clean_case_sync(seed):
     co, do = o.Sync(start, lo, hi, 0.0, 0.5)
     # the two solvers agree far better than either agrees with the truth (a few frames, capped iterations)
     assert abs(dh - do) < 2e-6, (dh, do)
-    assert abs(dh - synth.D_TRUE) < 1e-3, (dh, do)
+    # (how near the truth both end is a property of the ALGORITHM on the draw -- a few frames, 60 capped iterations --, not of
+    # the device: 1 of 3000 soaked draws, seed 983, ends 1.6 ms away ON BOTH SIDES, the two 2e-10 s apart)
+    assert abs(dh - synth.D_TRUE) < (1e-3 if seed < 200 else 3e-3), (dh, do)
     assert ch == pytest.approx(co, rel=1e-3, abs=1e-9)
 
 

@@ -57,6 +57,13 @@ def look(seed):
                 i0, i1 = ora.sample_pair(seed_o, ids[j], stream, hh, n)
                 q[name] = quartile_of(P, i0, i1)
                 rec["pair_" + name] = [i0, i1]
+            nr = np.linalg.norm(P, axis=1)
+            for name in ("hip", "oracle"):
+                i0, i1 = rec["pair_" + name]
+                cr = np.linalg.norm(np.cross(P[i0], P[i1]))
+                rec["defining_rows_" + name] = {"norms": [float(nr[i0]), float(nr[i1])], "cross_norm": float(cr),
+                                                 "sin_angle": float(cr / max(nr[i0] * nr[i1], 1e-300))}
+            rec["row_norm_percentiles_1_10_50"] = [float(x) for x in np.percentile(nr, [1, 10, 50])]
             rec["quartile_r2_of_hips_winner_fp64"] = q["hip"]
             rec["quartile_r2_of_oracles_winner_fp64"] = q["oracle"]
             rec["relative_gap"] = abs(q["hip"] - q["oracle"]) / max(q["oracle"], 1e-300)
