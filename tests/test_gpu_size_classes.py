@@ -198,3 +198,55 @@ def test_the_executor_takes_windows_with_frames_of_any_class(counts_at, monkeypa
         c2, d2 = dflt.sync_points(pos, 12, 0.0, 0.002, 0.04, repeats=3)
         assert dflt.executor_stats()["runs"] == 0
         np.testing.assert_array_equal(d2, d_ex)
+
+
+def test_every_route_through_the_library_on_a_problem_of_mixed_classes():
+    """Size classes cut EVERY launch of the library, not only PreSync / Sync of one object on one device: the host loop,
+    two device contexts sharing the frames (contiguous blocks cut inside the table), DebugPreSync's candidate generator and
+    the thesis' simplified mode all see the same per-class slot lists.  One problem with a frame of every class: each route
+    gives the plain route's bits, and the simplified mode agrees with the oracle."""
+    from rssync_amd import synth
+    from oracle.oracle import OracleProblem
+    counts = [96, 600, 300, 1500, 130, 3000, 5000, 9000, 200, 2048]       # classes interleaved along the table
+    F = len(counts)
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=37)
+    frames = _frames(g, counts, seed=37, noise=4e-4, outliers=0.06)
+
+    def run(p):
+        out = {}
+        out["presync"] = p.PreSync(0.03, 0, F, 0.001, 0.012)
+        out["debug"] = p.DebugPreSync(0.03, 0, F, 0.012, 9)
+        out["sync"] = p.Sync(out["presync"][1], 0, F - 1, 0.0, 0.2)
+        out["trace"] = np.array(p.sync_trace())
+        out["simple"] = p.SyncSimplified(out["presync"][1], 0, F - 1, 0.0, 0.2)
+        out["strace"] = np.array(p.sync_trace())
+        out["windows"] = p.sync_windows([0.036, 0.0362, 0.0358], [0, 2, 5], [4, 7, F - 1], 0.0, 0.2)
+        return out
+
+    base = run(_problem(g, frames, max_outer_iters=8))
+    host = _problem(g, frames, max_outer_iters=8)
+    host.set_host_loop(True)
+    two = _problem(g, frames, max_outer_iters=8)
+    two.set_devices([0, 0])
+    three = _problem(g, frames, max_outer_iters=8)
+    three.set_devices([0, 0, 0])
+    for name, p in (("host loop", host), ("two contexts", two), ("three contexts", three)):
+        got = run(p)
+        for key in base:
+            a, b = base[key], got[key]
+            if isinstance(a, tuple) and len(a) == 2 and np.ndim(a[0]) == 0:
+                assert a == b, (name, key, a, b)
+            else:
+                for x, y in zip(a if isinstance(a, tuple) else (a,), b if isinstance(b, tuple) else (b,)):
+                    np.testing.assert_array_equal(np.asarray(x), np.asarray(y), err_msg="%s: %s" % (name, key))
+    # DebugPreSync's end points are PreSync's candidate values where the grids coincide (core_private.cpp:345: both ends)
+    dd, dc = base["debug"]
+    assert len(dd) == 9 and dd[0] == pytest.approx(0.03 - 0.012) and dd[-1] == pytest.approx(0.03 + 0.012)
+    # the simplified mode against the oracle's restatement on the same mixed problem
+    o = OracleProblem(seed=SEED, threads=THREADS, faithful=False, max_outer_iters=8)
+    o.SetGyroQuaternions(g.quats, g.fs, g.t0)
+    for f in frames:
+        o.SetTrackResult(*f)
+    cs, ds, tro = o.sync_simplified_trace(base["presync"][1], 0, F - 1, 0.0, 0.2)
+    assert abs(base["simple"][1] - ds) < 1e-9 and base["simple"][0] == pytest.approx(cs, rel=1e-9)
+    assert len(base["strace"]) == len(tro)
