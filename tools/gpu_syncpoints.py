@@ -47,6 +47,15 @@ execp = problem()                      # the window executor (default for frames
 os.environ["RSSYNC_EXECUTOR"] = "0"
 execp.sync_points(pos, WINDOW, 0.0, 0.001, 0.1)
 t = time.perf_counter(); _, de = execp.sync_points(pos, WINDOW, 0.0, 0.001, 0.1); t_exec = time.perf_counter() - t
+# the production tripwire (round 5): one executor call in RSSYNC_EXECUTOR_CHECK_EVERY (default 256) is re-run through the
+# launch chain inside the call and compared bit for bit.  What a VERIFIED call costs: every call verified (every = 1).
+del os.environ["RSSYNC_EXECUTOR"]
+checked = problem()
+checked.set_executor_check_every(1)
+checked.sync_points(pos, WINDOW, 0.0, 0.001, 0.1)
+t = time.perf_counter(); _, dc = checked.sync_points(pos, WINDOW, 0.0, 0.001, 0.1); t_checked = time.perf_counter() - t
+stats_checked = checked.executor_stats()
+os.environ["RSSYNC_EXECUTOR"] = "0"
 hostloop = problem(); hostloop.set_host_loop(True)
 hostloop.sync_points(pos, WINDOW, 0.0, 0.001, 0.1)
 t = time.perf_counter(); _, dh = hostloop.sync_points(pos, WINDOW, 0.0, 0.001, 0.1); t_host = time.perf_counter() - t
@@ -55,6 +64,10 @@ print(json.dumps({"frames": F, "tracks": N, "window": WINDOW, "positions": len(p
                   "sequential_s": round(t_seq, 4), "batched_s": round(t_bat, 4), "speedup": round(t_seq / t_bat, 2),
                   "batched_host_loop_s": round(t_host, 4), "batched_executor_s": round(t_exec, 4),
                   "executor_identical": bool(np.array_equal(de, db)), "batched_profiled_s": round(t_prof, 4),
+                  "executor_check": {"every_call_verified_s": round(t_checked, 4), "identical": bool(np.array_equal(dc, de)),
+                                     "a_verified_call_costs_x": round(t_checked / t_exec, 2),
+                                     "average_overhead_at_one_in_256": round((t_checked - t_exec) / t_exec / 256, 5),
+                                     "stats": stats_checked},
                   "identical": bool(np.array_equal(ds, db)), "max_abs_diff": float(np.abs(ds - db).max()),
                   "host_loop_identical": bool(np.array_equal(dh, db)),
                   "delay_err_vs_truth_ms": {"median": float(np.median(np.abs(db - synth.D_TRUE)) * 1e3),
