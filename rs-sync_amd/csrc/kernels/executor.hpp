@@ -420,6 +420,12 @@ __global__ __launch_bounds__(64, (RPT == 8 && !BIG) ? 2 : 1) void sync_exec_kern
                                                                                                      //  RPT = 8 with BIG would spill at 256: one wave per SIMD there)
     __shared__ ExecLds<RPT> lds;
     extern __shared__ d4 s_exec_region[]; // [4 * win_cap] d4 = win_cap x 128 bytes
+#ifndef RSSYNC_EXEC_PRELOAD   // (-DRSSYNC_EXEC_PRELOAD=0: the loads where the rows need them, for the A/B of profiles/r5_exec_preload_ab.txt)
+#define RSSYNC_EXEC_PRELOAD 1
+#endif
+    // rows per lane whose rays a loss task requests up-front (sync64.hpp: RowRays); three where a fourth would cost the
+    // instantiation its second wave per SIMD (tests/test_kernel_resources.py)
+    constexpr int kPre = RSSYNC_EXEC_PRELOAD ? (RPT < 4 ? RPT : ((BIG && RPT == 4) ? 3 : 4)) : 0;
     const int lane = threadIdx.x;
     for (;;) {
         uint32_t slot;
@@ -459,14 +465,14 @@ __global__ __launch_bounds__(64, (RPT == 8 && !BIG) ? 2 : 1) void sync_exec_kern
             } else opt_motion64_body<RPT, 1, true>(p.mo, slot, lds.mo, s_exec_region, mk);
             const d3 Mv = d3{mk[0], mk[1], mk[2]};
             double Lv, Gv;
-            loss64_wave<true>(p.lo, slot, Mv, mk[3], ld_m<true>(&p.lg_kd[w]), ld_m<true>(&p.lg_fd[w]), s_exec_region, Lv, Gv);
+            loss64_wave<true, false, kPre>(p.lo, slot, Mv, mk[3], ld_m<true>(&p.lg_kd[w]), ld_m<true>(&p.lg_fd[w]), s_exec_region, Lv, Gv);
             if (lane == 0) { st_m<true>(&p.part[slot], Lv); st_m<true>(&p.part[(size_t)p.n_sel + slot], Gv); }
         } else if (ph == kPhTrials || ph == kPhFinal) {
             const d3 Mv = d3{ld_m<true>(&p.lo.M[3 * slot]), ld_m<true>(&p.lo.M[3 * slot + 1]), ld_m<true>(&p.lo.M[3 * slot + 2])};
             const double kk = ld_m<true>(&p.lo.k[slot]);
             if (ph == kPhFinal) {
                 double Lv, Gv;
-                loss64_wave<false>(p.lo, slot, Mv, kk, ld_m<true>(&p.lg_kd[w]), ld_m<true>(&p.lg_fd[w]), s_exec_region, Lv, Gv);
+                loss64_wave<false, false, kPre>(p.lo, slot, Mv, kk, ld_m<true>(&p.lg_kd[w]), ld_m<true>(&p.lg_fd[w]), s_exec_region, Lv, Gv);
                 if (lane == 0) st_m<true>(&p.part[slot], Lv);
             } else if (BIG && one_trial >= 0) {
                 double Lv, Gv;
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(64, (RPT == 8 && !BIG) ? 2 : 1) void sync_exec_kern
                     const double fd = read_lane_d(my_fd, i);
                     if (fd != fd) continue; // not asked for
                     double Lv, Gv;
-                    loss64_wave<false>(p.lo, slot, Mv, kk, __builtin_amdgcn_readlane(my_kd, i), fd, s_exec_region, Lv, Gv);
+                    loss64_wave<false, false, kPre>(p.lo, slot, Mv, kk, __builtin_amdgcn_readlane(my_kd, i), fd, s_exec_region, Lv, Gv);
                     if (lane == 0) st_m<true>(&p.part[(size_t)i * p.n_sel + slot], Lv);
                 }
             }

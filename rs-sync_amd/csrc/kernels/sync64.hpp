@@ -366,9 +366,31 @@ __global__ __launch_bounds__(kBlock, 3) void loss64_kernel(Loss64Params p) {
 // (A frame of 130 tracks leaves two of the four waves of loss64_kernel's workgroup idle, and the workgroup holds its
 // registers all the same: three per CU.  One wave per slot puts four times as many slots on the chip; the window
 // executor evaluates its loss tasks this way too.)
-template <bool GRAD, bool SIMPLE = false>
+// The rays of a lane's FIRST row of each of the first NPRE "waves" (rows w * 64 + lane), requested in one go.  Round 5: the
+// loop below fetched a row's 64 bytes where it needed them -- one round trip past L1 per wave of rows, one after the other,
+// after the round trip in which the spline window is staged.  Requested before the window's loads they arrive in the same
+// round trip (loads return in order).  Only the order of the loads changes: the same values enter the same arithmetic in the
+// same order.  (Holding them across a line search's ten evaluations instead -- one request per TASK -- was tried: +64 live
+// registers through the whole task took the executor from two waves per SIMD to one.)
+template <int NPRE>
+struct RowRays {
+    double2 X[NPRE ? NPRE : 1], Y[NPRE ? NPRE : 1], Z[NPRE ? NPRE : 1], T[NPRE ? NPRE : 1];
+};
+template <int NPRE>
+__device__ __forceinline__ void load_row_rays(const Rays64& r, const FrameRec& fr, RowRays<NPRE>& o) {
+#pragma unroll
+    for (int w = 0; w < NPRE; ++w) {
+        const uint32_t row = (uint32_t)w * 64u + threadIdx.x;
+        if (row < fr.n) {
+            const size_t idx = (size_t)fr.off + row;
+            o.X[w] = r.q0[idx]; o.Y[w] = r.q1[idx]; o.Z[w] = r.q2[idx]; o.T[w] = r.q3[idx];
+        }
+    }
+}
+
+template <bool GRAD, bool SIMPLE = false, int NPRE = 0>
 __device__ __forceinline__ void loss64_wave(const Loss64Params& q, uint32_t sf, d3 Mv, double kk, int kd, double fd, d4* s_win,
-                                            double& L_out, double& G_out) {
+                                            double& L_out, double& G_out, const RowRays<NPRE>* given = nullptr) {
     const int lane = threadIdx.x;
     const FrameRec fr = q.frames[q.sel[sf]];
     const uint32_t N = fr.n;
@@ -379,6 +401,9 @@ __device__ __forceinline__ void loss64_wave(const Loss64Params& q, uint32_t sf, 
     sp.cap = (int)q.win_cap;
     sp.compact = (int)q.win_compact;
     __syncthreads(); // the window's previous users are done
+    RowRays<NPRE> mine;
+    if (NPRE && !given) load_row_rays<NPRE>(q.rays, fr, mine); // (before the window's loads: they return in order, one round trip for both)
+    const RowRays<NPRE>& pre = given ? *given : mine;
     frame_window64(sp, s_win, fr, kd);
     __syncthreads();
     const int base = fr.base_knot + kd;
@@ -389,7 +414,16 @@ __device__ __forceinline__ void loss64_wave(const Loss64Params& q, uint32_t sf, 
         Gw[w] = 0.0;
         if ((uint32_t)w * 64u < N) { // (a wave without rows sums zeros to zero)
             double L = 0.0, G = 0.0;
-            for (uint32_t row = (uint32_t)w * 64u + lane; row < N; row += kBlock) { // (the four-wave kernel's rows j * 256 + tid of this thread)
+            uint32_t row = (uint32_t)w * 64u + lane; // (the four-wave kernel's rows j * 256 + tid of this thread)
+            if (w < NPRE) {
+                if (row < N) {
+                    d3 P, dP;
+                    residual_row64_auto<GRAD>(sp, pre.X[w], pre.Y[w], pre.Z[w], pre.T[w], base, fd, P, dP);
+                    rs::loss_row<GRAD, SIMPLE>(P, dP, Mv, inv_s, L, G);
+                }
+                row += kBlock;
+            }
+            for (; row < N; row += kBlock) {
                 const size_t idx = (size_t)fr.off + row;
                 d3 P, dP;
                 residual_row64_auto<GRAD>(sp, q.rays.q0[idx], q.rays.q1[idx], q.rays.q2[idx], q.rays.q3[idx], base, fd, P, dP);
