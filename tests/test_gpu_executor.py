@@ -201,6 +201,8 @@ def test_one_call_in_n_is_verified_in_production():
     process-wide, so of any 6 consecutive calls with N = 3 exactly 2 are verified, whichever object makes them."""
     import rssync_amd
     from rssync_amd import synth
+    if os.environ.get("RSSYNC_EXECUTOR_CHECK", "0") not in ("", "0"):
+        pytest.skip("the suite is being run in the check mode itself: every call is verified, there is no sample to count")
     F, N = 40, 130
     gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=15)
     frames = list(synth.make_frames(gyro, 0, F, N, seed=15))
