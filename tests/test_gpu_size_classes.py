@@ -250,3 +250,44 @@ def test_every_route_through_the_library_on_a_problem_of_mixed_classes():
     cs, ds, tro = o.sync_simplified_trace(base["presync"][1], 0, F - 1, 0.0, 0.2)
     assert abs(base["simple"][1] - ds) < 1e-9 and base["simple"][0] == pytest.approx(cs, rel=1e-9)
     assert len(base["strace"]) == len(tro)
+
+
+def test_resetting_a_frame_moves_it_to_its_new_class():
+    """core_private.cpp:192-203: SetTrackResult on a frame that exists overwrites it (:194) -- with another track count the
+    frame changes its size class between two calls of the same object.  After every overwrite the object must give what a
+    fresh object holding the final frames gives, bit for bit (slot lists, window plans and staging follow the table, not
+    the history), and the overwritten frame's old rows must be gone."""
+    from rssync_amd import synth
+    from oracle.oracle import OracleProblem
+    counts = [130, 200, 130, 600, 130, 96]
+    F = len(counts)
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=41)
+    frames = _frames(g, counts, seed=41, noise=4e-4, outliers=0.06)
+    p = _problem(g, frames, max_outer_iters=8)
+    first = (p.PreSync(0.03, 0, F, 0.001, 0.012), p.Sync(0.036, 0, F - 1, 0.0, 0.2))
+    # frame 2: 130 -> 700 tracks (one wave -> four waves); frame 3: 600 -> 40 (four waves -> one); frame 5: 96 -> 3000
+    steps = [(2, 700), (3, 40), (5, 3000), (2, 130)]
+    for n_done, (fr, n) in enumerate(steps, 1):
+        new = next(iter(synth.make_frames(g, fr, fr + 1, n, seed=100 + n_done, noise=4e-4, outliers=0.06)))
+        frames[fr] = new
+        p.SetTrackResult(*new)
+        got = (p.PreSync(0.03, 0, F, 0.001, 0.012), p.Sync(0.036, 0, F - 1, 0.0, 0.2), np.array(p.sync_trace()))
+        fresh = _problem(g, frames, max_outer_iters=8)
+        for _ in range(n_done):                          # (the sampler's stream of a Sync call advances with the object's calls)
+            fresh.Sync(0.036, 0, F - 1, 0.0, 0.2)
+        want = (fresh.PreSync(0.03, 0, F, 0.001, 0.012), fresh.Sync(0.036, 0, F - 1, 0.0, 0.2), np.array(fresh.sync_trace()))
+        assert got[0] == want[0], (fr, n, got[0], want[0])
+        assert got[1] == want[1], (fr, n, got[1], want[1])
+        np.testing.assert_array_equal(got[2], want[2])
+    assert first[0] != got[0]
+    # and the final state against the oracle (PreSync arg-min and Sync from the same GuessMotion winners)
+    o = OracleProblem(seed=SEED, threads=THREADS, faithful=False, max_outer_iters=8)
+    o.SetGyroQuaternions(g.quats, g.fs, g.t0)
+    for f in frames:
+        o.SetTrackResult(*f)
+    assert p.PreSync(0.03, 0, F, 0.001, 0.012)[1] == o.PreSync(0.03, 0, F, 0.001, 0.012)[1]
+    co, do, tro = o.sync_trace(0.036, 0, F - 1, 0.0, 0.2)
+    q = _problem(g, frames, max_outer_iters=8)
+    q.set_init_override(o.last_init_winners())
+    cq, dq = q.Sync(0.036, 0, F - 1, 0.0, 0.2)
+    assert abs(dq - do) < 1e-6 and len(q.sync_trace()) == len(tro)
