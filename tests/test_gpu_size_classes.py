@@ -291,3 +291,25 @@ def test_resetting_a_frame_moves_it_to_its_new_class():
     q.set_init_override(o.last_init_winners())
     cq, dq = q.Sync(0.036, 0, F - 1, 0.0, 0.2)
     assert abs(dq - do) < 1e-6 and len(q.sync_trace()) == len(tro)
+
+
+def test_orientation_sweep_over_frames_of_mixed_classes():
+    """core_testcode.cpp:186-224 on a clip whose frames fall into four size classes: the batched sweep (gyro as rates,
+    re-integrated and re-splined on the device per orientation, tracks kept) equals per-orientation set_gyro_rates + PreSync
+    calls bit for bit, and the true orientation comes out first."""
+    from rssync_amd import synth
+    counts = [130, 600, 96, 1500, 300, 2500, 130, 700, 200, 130, 1100, 64]
+    F = len(counts)
+    g = synth.make_gyro(1.0, 1.0 + (F + 2) / synth.FPS, seed=43)
+    frames = [next(iter(synth.make_frames(g, 30 + i, 31 + i, n, seed=43))) for i, n in enumerate(counts)]
+    names = ["XYZ", "XZY", "yXZ", "Zxy", "xyz"]
+    p = _problem(g, frames)
+    costs, delays = p.orientation_sweep(g.times, g.rates, names, 0.0, 30, 30 + F, 0.004, 0.08)
+    q = _problem(g, frames)
+    for k, name in enumerate(names):
+        q.set_gyro_rates(g.times, g.rates, name)
+        c, d = q.PreSync(0.0, 30, 30 + F, 0.004, 0.08)
+        assert (c, d) == (costs[k], delays[k]), (name, c, d, costs[k], delays[k])
+    order = np.argsort(costs)
+    assert names[order[0]] == "XYZ" and costs[order[0]] < 0.97 * costs[order[1]]
+    assert abs(delays[order[0]] - synth.D_TRUE) <= 0.004
