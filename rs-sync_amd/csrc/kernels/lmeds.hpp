@@ -391,7 +391,10 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
 // (8 per thread) the 24 KB tile lets five workgroups share a CU; 4096 / 8192 rows (16 / 32 per thread, 48 /
 // 96 KB of tile, 64 / 128 residual registers per lane) run at two / one -- slower per row, but a frame of a
 // dense tracker is accepted instead of refused.
-__host__ __device__ constexpr int lmeds_waves(int rpt) { return rpt <= 8 ? 5 : (rpt == 16 ? 2 : 1); }
+#ifndef RSSYNC_K2_WAVES4   // (waves per SIMD the 1024-row instantiation is compiled for: A/B of profiles/r5_k2_waves4_ab.txt)
+#define RSSYNC_K2_WAVES4 6
+#endif
+__host__ __device__ constexpr int lmeds_waves(int rpt) { return rpt == 4 ? RSSYNC_K2_WAVES4 : (rpt <= 8 ? 5 : (rpt == 16 ? 2 : 1)); }
 __host__ __device__ constexpr int loss_waves(int rpt, bool grad) { return (grad || rpt >= 8) ? 3 : 4; }
 
 constexpr int kMaxChunk = 32; // candidates per workgroup (rship: chunk <= kMaxChunk); 64 and 100 measured: no change
