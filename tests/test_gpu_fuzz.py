@@ -31,6 +31,31 @@ def lower_quartile_fp64(P, i0, i1):
     return float(np.sort((nP @ v) ** 2)[len(P) // 4])
 
 
+def flip_interval(P, i0, i1):
+    """-> (lo, hi, rq): where the fp32 search's lower-quartile |residual| of hypothesis (i0, i1) can lie, given rows known
+    to 5e-7 absolute (profiles/r4_config2_parity.json).  The direction v = P[i0] x P[i1] is off by up to
+    err_v = 5e-7 (1/|P[i0]| + 1/|P[i1]|) / sin(angle) radians -- 0.2 of that is taken, the largest fraction a soak of 6000
+    cases showed was 0.066 --; a residual n_i.v by that plus its own row's 5e-7 / |P_i|; the rows whose residual lies within
+    their error of the quartile value may change sides, and the quartile moves by as many order statistics."""
+    nr = np.linalg.norm(P, axis=1)
+    nP = P / np.where(nr < 1e-12, 1.0, nr)[:, None]
+    v = np.cross(P[i0], P[i1])
+    nv = np.linalg.norm(v)
+    if nv >= 1e-12:
+        v = v / nv
+    r = np.abs(nP @ v)
+    sin_a = nv / max(nr[i0] * nr[i1], 1e-300) if nv >= 1e-12 else 1.0
+    err_v = 5e-7 * (1.0 / max(nr[i0], 1e-300) + 1.0 / max(nr[i1], 1e-300)) / max(sin_a, 1e-300)
+    e = 0.2 * err_v * np.linalg.norm(v) + 5e-7 / np.maximum(nr, 1e-300)
+    order = np.argsort(r)
+    kq = len(P) // 4
+    rq = r[order[kq]]
+    m = int(np.sum(np.abs(r - rq) <= e)) - 1            # rows (other than the quartile's own) that may change sides
+    m = max(m, 0)
+    lo_k, hi_k = max(kq - m, 0), min(kq + m, len(P) - 1)
+    return float(r[order[lo_k]] - e[order[lo_k]]), float(r[order[hi_k]] + e[order[hi_k]]), float(rq)
+
+
 def draw_case(seed, clean):
     rng = np.random.default_rng(1000 + seed)
     fs = RATES[int(rng.integers(len(RATES)))]
@@ -111,17 +136,17 @@ def test_random_noisy_case(seed):
         # defining row below 1.3e-4 or a pair within 0.6 degrees of parallel, the largest at 0.066 err_v; well-conditioned
         # pairs flip at <= 1e-4.  A winner chosen WRONGLY would be off by O(1): quartiles of unrelated hypotheses differ by
         # factors.
+        # And the quartile is an ORDER STATISTIC of residuals that each carry the error of their own row: a row of norm |P_i|
+        # is off by up to 5e-7 / |P_i| in direction, so residuals within that of the quartile value may change sides, and
+        # with m such rows the fp32 quartile is any of the order statistics kq - m .. kq + m (at 50 tracks neighbouring
+        # order statistics at the quartile lie ~7 % apart: soak cases 3809 and 3963 of run 5, 2.2 % and 0.6 %).  So what is
+        # compared is the INTERVAL each hypothesis' quartile can lie in: flip_interval() below.
         flips = [(c, j) for c, j in zip(*np.nonzero(bhh != bho)) if big[j] and bhh[c, j] >= 0 and bho[c, j] >= 0]
         for c, j in flips[:12]:
             P = o.problem_matrix(ids[j], float(do[c]))
-            nr = np.linalg.norm(P, axis=1)
-            rq, err_v = [], 0.0
-            for w in (bhh[c, j], bho[c, j]):
-                i0, i1 = sample_pair(seed, ids[j], int(c), int(w), counts[j])
-                rq.append(np.sqrt(lower_quartile_fp64(P, i0, i1)))
-                sin_a = np.linalg.norm(np.cross(P[i0], P[i1])) / max(nr[i0] * nr[i1], 1e-300)
-                err_v = max(err_v, 5e-7 * (1.0 / max(nr[i0], 1e-300) + 1.0 / max(nr[i1], 1e-300)) / max(sin_a, 1e-300))
-            assert abs(rq[0] - rq[1]) <= 0.2 * err_v + 5e-3 * rq[1], (seed, int(c), int(ids[j]), rq, err_v)
+            iv = [flip_interval(P, *sample_pair(seed, ids[j], int(c), int(w), counts[j])) for w in (bhh[c, j], bho[c, j])]
+            gap = max(iv[0][0], iv[1][0]) - min(iv[0][1], iv[1][1])        # > 0: the intervals do not meet
+            assert gap <= 5e-3 * iv[1][2], (seed, int(c), int(ids[j]), iv)
         srt = np.sort(cbo)
         if len(srt) > 1 and srt[1] - srt[0] > 0.08 * srt[0]:   # a clear minimum: the same candidate wins
             assert int(np.argmin(cbh)) == int(np.argmin(cbo))

@@ -63,6 +63,8 @@ def look(seed):
                 cr = np.linalg.norm(np.cross(P[i0], P[i1]))
                 rec["defining_rows_" + name] = {"norms": [float(nr[i0]), float(nr[i1])], "cross_norm": float(cr),
                                                  "sin_angle": float(cr / max(nr[i0] * nr[i1], 1e-300))}
+            rec["quartile_interval_hip"] = fz.flip_interval(P, *rec["pair_hip"])
+            rec["quartile_interval_oracle"] = fz.flip_interval(P, *rec["pair_oracle"])
             rec["row_norm_percentiles_1_10_50"] = [float(x) for x in np.percentile(nr, [1, 10, 50])]
             rec["quartile_r2_of_hips_winner_fp64"] = q["hip"]
             rec["quartile_r2_of_oracles_winner_fp64"] = q["oracle"]
