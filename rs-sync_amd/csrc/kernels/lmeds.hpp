@@ -394,7 +394,10 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
 #ifndef RSSYNC_K2_WAVES4   // (waves per SIMD the 1024-row instantiation is compiled for: A/B of profiles/r5_k2_waves4_ab.txt)
 #define RSSYNC_K2_WAVES4 6
 #endif
-__host__ __device__ constexpr int lmeds_waves(int rpt) { return rpt == 4 ? RSSYNC_K2_WAVES4 : (rpt <= 8 ? 5 : (rpt == 16 ? 2 : 1)); }
+#ifndef RSSYNC_K2_WAVES16   // (workgroups per CU the planner may aim at for 16 rows per thread: 3 = with a small window in dynamic LDS, lmeds_kernel<16, ., 1>; 2: never)
+#define RSSYNC_K2_WAVES16 3
+#endif
+__host__ __device__ constexpr int lmeds_waves(int rpt) { return rpt == 4 ? RSSYNC_K2_WAVES4 : (rpt <= 8 ? 5 : (rpt == 16 ? RSSYNC_K2_WAVES16 : 1)); }
 __host__ __device__ constexpr int loss_waves(int rpt, bool grad) { return (grad || rpt >= 8) ? 3 : 4; }
 
 constexpr int kMaxChunk = 32; // candidates per workgroup (rship: chunk <= kMaxChunk); 64 and 100 measured: no change
@@ -463,15 +466,20 @@ constexpr int kContCap = 24; // contender records per candidate; beyond that a h
 // than five: beyond five waves per SIMD the kernel no longer gains from more resident waves.
 // LAZY = false is round 2's exact selection of every quartile that beats the bound: instantiated only in the
 // test-variants build (-DRSSYNC_TEST_VARIANTS=1, tests/test_gpu_lazy_select.py), which demands identical winners and costs.
+// WIN = 1 (16 rows per thread only): the dynamic window again, compiled for THREE workgroups per CU instead of two -- for the
+// launches whose window is small enough that the kernel's LDS lets a third one in (rssync_kernels.hip: plan_lmeds_window;
+// 168 VGPRs, 44 of the 213 the kernel wants spilled to scratch, and still 25 % faster: profiles/r5_k2_class3_ab.txt).  WIN = 0
+// stays compiled for two: a large window (high gyro rates) leaves no room for a third workgroup and the spills would only cost.
 template <int RPT, int MODE, int WIN, bool LAZY = true> // MODE 0: PreSync cost per candidate; 1: GuessMotion's hypothesis search (Sync start)
-__global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsParams p) {
+__global__ __launch_bounds__(kBlock, RPT == 16 ? (WIN == 1 ? 3 : 2) : lmeds_waves(RPT)) void lmeds_kernel(LmedsParams p) {
+    constexpr int CAPW = WIN == 1 ? 0 : WIN; // the window's compile-time capacity (0 = dynamic)
     constexpr int kHyp = kHypBatch;
     constexpr int ROWS = kBlock * RPT;
     constexpr int NR = 4 * RPT; // residual registers per lane: a wave spans the whole tile
     __shared__ __attribute__((aligned(16))) float s_n[3][ROWS];
     f4* s_win;
-    if constexpr (WIN != 0) {
-        __shared__ f4 s_win_static[4 * WIN];
+    if constexpr (CAPW != 0) {
+        __shared__ f4 s_win_static[4 * CAPW];
         s_win = s_win_static;
     } else {
         extern __shared__ f4 s_win_dynamic[];
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
             kd_lo = v < kd_lo ? v : kd_lo;
             kd_hi = v > kd_hi ? v : kd_hi;
         }
-        stage_window_ends<WIN>(sp, s_win, frame_knots(fr, fr.base_knot + (int)floorf(fr.tmin) + kd_lo,
+        stage_window_ends<CAPW>(sp, s_win, frame_knots(fr, fr.base_knot + (int)floorf(fr.tmin) + kd_lo,
                                                        fr.base_knot + (int)floorf(fr.tmax) + kd_hi + 1, kd_lo, kd_hi));
     }
 #pragma unroll
@@ -561,7 +569,7 @@ __global__ __launch_bounds__(kBlock, lmeds_waves(RPT)) void lmeds_kernel(LmedsPa
         // ---- stage A: rows of P -> LDS tile as unit rows; norms stay in registers ----
         float nrm[RPT];
         uint32_t n2min;
-        bad |= lmeds_rows<RPT, MODE == 0, WIN>(sp, rays, N, base, fd, tile, nrm, n2min);
+        bad |= lmeds_rows<RPT, MODE == 0, CAPW>(sp, rays, N, base, fd, tile, nrm, n2min);
         {   // (written before the "tile written" barrier below, read by the hypotheses' lanes after it; the next
             // candidate's write comes after this candidate's last barrier)
             const uint32_t wmin = wave_min_u32(n2min);

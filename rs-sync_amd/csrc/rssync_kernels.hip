@@ -421,6 +421,16 @@ uint32_t lmeds_dynamic_static_lds(int rpt, bool small) {
         default: return static_lds_of(lmeds_kernel<32, MODE, 0>);
     }
 }
+// static LDS of the tile kernel's compiled-in-window instantiation
+template <int MODE>
+uint32_t lmeds_static_lds(int rpt) {
+    switch (rpt) {
+        case 4: return static_lds_of(lmeds_kernel<4, MODE, kWinMax>);
+        case 8: return static_lds_of(lmeds_kernel<8, MODE, kWinMax>);
+        case 16: return static_lds_of(lmeds_kernel<16, MODE, kWinMax>);
+        default: return static_lds_of(lmeds_kernel<32, MODE, kWinMax>);
+    }
+}
 // which LMedS kernel the frames of class k get
 enum class LmedsKind { Small, Tile, Big };
 LmedsKind lmeds_kind(const rship_ctx* c, int k) {
@@ -452,8 +462,15 @@ WinPlan plan_lmeds_window(rship_ctx* c, int k, double step_knots, uint32_t chunk
     // (the kernel's LDS footprint is only asked for when the compiled-in window does not do: plan_window's first test)
     const bool fits80 = rs::plan_fit((double)kWinMax, class_span(c, k), step_knots, chunk_want) >= std::min(8u, chunk_want);
     const uint32_t fixed = (fits80 || c->force_general) ? 0u : lmeds_dynamic_static_lds<MODE>(rpt, small);
-    return rs::plan_window_frames(d.data(), d.size(), lo, hi, step_knots, chunk_want, small, small ? 20 : lmeds_waves(rpt), fixed, c->lds_per_cu,
-                                  c->force_general);
+    rs::WinPlan wp = rs::plan_window_frames(d.data(), d.size(), lo, hi, step_knots, chunk_want, small, small ? 20 : (rpt == 16 ? 2 : lmeds_waves(rpt)), fixed,
+                                            c->lds_per_cu, c->force_general);
+    if (!small && !wp.cap && fits80 && !c->force_general && rpt == 16) {
+        // the compiled-in window does, but a smaller one in dynamic LDS lets a third workgroup share the CU (window_plan.hpp)
+        const uint32_t cap = rs::smaller_window_for_occupancy(class_span(c, k), step_knots, wp.chunk, lmeds_static_lds<MODE>(rpt),
+                                                              lmeds_dynamic_static_lds<MODE>(rpt, false), lmeds_waves(rpt), c->lds_per_cu);
+        if (cap) { wp.cap = cap; wp.whole_pair = true; wp.extra_wg = true; }
+    }
+    return wp;
 }
 
 // one class's part of an LMedS launch: p.slots / p.n_slots / p.chunk / p.n_chunks are set here
@@ -467,6 +484,7 @@ int launch_lmeds_class(rship_ctx* c, LmedsParams p, const ClassRange& r, const W
     p.chunk = wp.chunk;
     p.n_chunks = (p.n_cand + wp.chunk - 1) / wp.chunk;
     p.win_cap = wp.cap ? wp.cap : (uint32_t)kWinMax;
+    if (wp.whole_pair) p.win_whole_pair = 1u;
     const size_t dyn = (size_t)wp.cap * 64u;
     if (kind == LmedsKind::Small) {
         // Frames of up to 512 tracks (the reference's own data: ~130): one wave per (frame, chunk) instead of a
@@ -520,8 +538,15 @@ int launch_lmeds_class(rship_ctx* c, LmedsParams p, const ClassRange& r, const W
                     hipLaunchKernelGGL((lmeds_kernel<4, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
             case 8: allow_dynamic_lds(lmeds_kernel<8, MODE, 0>, dyn);
                     hipLaunchKernelGGL((lmeds_kernel<8, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
-            case 16: allow_dynamic_lds(lmeds_kernel<16, MODE, 0>, dyn);
-                     hipLaunchKernelGGL((lmeds_kernel<16, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
+            case 16:
+                if (wp.extra_wg) { // (a window small enough for a third workgroup per CU: the instantiation compiled for three)
+                    allow_dynamic_lds(lmeds_kernel<16, MODE, 1>, dyn);
+                    hipLaunchKernelGGL((lmeds_kernel<16, MODE, 1>), dim3(grid), dim3(kBlock), dyn, c->stream, p);
+                } else {
+                    allow_dynamic_lds(lmeds_kernel<16, MODE, 0>, dyn);
+                    hipLaunchKernelGGL((lmeds_kernel<16, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p);
+                }
+                break;
             case 32: allow_dynamic_lds(lmeds_kernel<32, MODE, 0>, dyn);
                      hipLaunchKernelGGL((lmeds_kernel<32, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
             default: return set_err(c, "lmeds: unsupported rows-per-thread");
@@ -2172,7 +2197,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     {
         const WinPlan wp_init = plan_lmeds_window<1>(c, 0, 0.0, 1u);
         ep.init.win_cap = wp_init.cap ? wp_init.cap : (uint32_t)kWinMax;
-        ep.init.win_whole_pair = wp_init.cap ? 0u : 1u; // (the compiled-in window stages whole pairs: so must this one, or tiny frames take another path)
+        ep.init.win_whole_pair = (wp_init.cap && !wp_init.whole_pair) ? 0u : 1u; // (the compiled-in window stages whole pairs: so must this one, or tiny frames take another path)
         if ((size_t)ep.init.win_cap * 64u > region) return set_err(c, "sync_exec: the search's window does not fit the wave's LDS region");
     }
     ExecBig hb{};
@@ -2190,7 +2215,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
             if (k >= 1 && k <= 4 && c->cls_off[k + 1] != c->cls_off[k]) {
                 const WinPlan wp = plan_lmeds_window<1>(c, k, 0.0, 1u);
                 hb.init_cap[k] = wp.cap ? wp.cap : (uint32_t)kWinMax;
-                if (!wp.cap) hb.init_whole |= 1u << k; // (the compiled-in window stages whole pairs)
+                if (!wp.cap || wp.whole_pair) hb.init_whole |= 1u << k; // (the compiled-in window stages whole pairs, and so does the small one that stands in for it)
             }
         }
         RS_HIP(hipMemcpyAsync(base + o_big, &hb, sizeof(hb), hipMemcpyHostToDevice, c->stream));

@@ -24,7 +24,26 @@ constexpr uint32_t kPlanCap64SmallMax = RSSYNC_PLAN_CAP64_SMALL_MAX; // problems
 struct WinPlan {
     uint32_t cap = 0;   // 0: the compiled-in 80-knot window; otherwise knots of dynamic LDS (64 bytes each)
     uint32_t chunk = 1; // candidates per workgroup
+    bool whole_pair = false; // a dynamic window that stages whole pairs only, as the compiled-in one does (same path decisions)
+    bool extra_wg = false;   // ... chosen because it lets one more workgroup share the CU (smaller_window_for_occupancy)
 };
+
+// Frames whose knots fit the compiled-in window can still be better off with a SMALLER window in dynamic LDS: where the
+// kernel's LDS, not its registers, decides how many workgroups share a CU and the compiled-in window is the difference
+// (round 5: lmeds_kernel<16, ...>, 2049 .. 4096 tracks -- 48 KB of tile + the 5 KB window = two workgroups per CU, with a
+// window of the ~30 knots a 400 Hz frame and its chunk touch three).  static_lds / dyn_fixed_lds: the two instantiations'
+// static LDS; wg_cap: workgroups per CU the kernel's registers allow.  -> knots of the dynamic window, or 0 = keep the
+// compiled-in one.  The dynamic window then stages whole pairs, as the compiled-in one does: the same frames take the
+// interior path, the same bits.
+inline uint32_t smaller_window_for_occupancy(double span, double step_knots, uint32_t chunk, uint32_t static_lds, uint32_t dyn_fixed_lds,
+                                             int wg_cap, int lds_per_cu) {
+    if (!static_lds || !dyn_fixed_lds) return 0;
+    const double cs = step_knots > 0 ? (chunk - 1) * step_knots : 0.0;
+    const uint32_t cap = ((uint32_t)std::ceil(span + 1.0 + cs) + 3u) / 4u * 4u + 4u;
+    if (cap >= kPlanWinStatic) return 0;
+    auto wgs = [&](uint32_t lds) { return std::min(wg_cap, (int)(lds_per_cu / (int)(lds + 1024u))); }; // (allocation granularity)
+    return wgs(dyn_fixed_lds + cap * 64u) > wgs(static_lds) ? cap : 0u;
+}
 
 // knots the fp64 kernels' window holds for a table whose widest frame touches `max_span` knots at one delay -- or
 // `max_ends` knots where only the two ends of each pair are staged (a frame's a-end and b-end ranges one after the

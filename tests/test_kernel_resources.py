@@ -60,15 +60,25 @@ def test_no_scratch_memory_and_no_matrix_instructions(code_object, kernels):
     dense contraction; the one candidate, stage C, was measured 1.57x slower there: profiles/r4_k2_mfma.txt)"""
     dis = subprocess.run([_tool("llvm-objdump"), "-d", code_object], check=True, capture_output=True, text=True).stdout
     assert len(dis) > 1000000
-    assert not re.search(r"\bscratch_(load|store)", dis), "a kernel uses scratch memory"
-    assert not re.search(r"\bbuffer_(load|store)\w* .*\boffen\b.*\bs\[0:3\]", dis)  # (the other form of a private access)
+    # ONE deliberate exception (round 5): lmeds_kernel<16, ., 1> -- the PreSync / GuessMotion tile kernel for frames of 2049 ..
+    # 4096 tracks when its spline window is small enough for a THIRD workgroup per CU -- is compiled for three waves per SIMD,
+    # 168 VGPRs, and spills 44 (32) of the 213 (194) registers it wants to scratch: measured 25 % FASTER than the spill-free
+    # two-workgroup instantiation (profiles/r5_k2_class3_ab.txt), which stays for the large windows of high gyro rates.
+    allowed = re.compile(r"lmeds_kernelILi16ELi[01]ELi1ELb1EEE")
+    funcs = re.split(r"^[0-9a-f]+ <(\S+)>:$", dis, flags=re.M)      # [preamble, name, body, name, body, ...]
+    assert len(funcs) > 100
+    for name, body in zip(funcs[1::2], funcs[2::2]):
+        if allowed.search(name):
+            continue
+        assert not re.search(r"\bscratch_(load|store)", body), "kernel %s uses scratch memory" % name
+        assert not re.search(r"\bbuffer_(load|store)\w* .*\boffen\b.*\bs\[0:3\]", body), name  # (the other form of a private access)
     assert "v_mfma" not in dis
-    for name, k in kernels.items():
-        assert k["vgpr_spills"] == 0, (name, k)   # (accumulation registers are part of gfx950's unified file: not a spill)
+    spilling = {n: k["vgpr_spills"] for n, k in kernels.items() if k["vgpr_spills"]}   # (accumulation registers are part of gfx950's unified file: not a spill)
+    assert set(spilling) <= {"lmeds_kernel<16, 0, 1, true>", "lmeds_kernel<16, 1, 1, true>"} and all(v <= 48 for v in spilling.values()), spilling
     # An executor instantiation may reserve a private segment it never touches (8 SGPRs parked in a frame slot that the final
     # code keeps in VGPR lanes, plus one dword; which instantiation it hits moves with the build): known, harmless -- no
     # scratch instruction exists in the binary (asserted above) -- and pinned so that it does not grow unnoticed.
-    private = {n: k["private"] for n, k in kernels.items() if k["private"]}
+    private = {n: k["private"] for n, k in kernels.items() if k["private"] and n not in spilling}
     assert all(re.match(r"sync_exec_kernel<\d, (true|false)>$", n) for n in private) and all(v <= 64 for v in private.values()), private
     assert len(private) <= 2, private
 
@@ -106,7 +116,7 @@ def test_every_instantiation_the_launchers_name_is_in_the_binary(kernels):
     have = set(kernels)
     for rpt in (4, 8, 16, 32):
         for mode in (0, 1):
-            for win in (80, 0):
+            for win in (80, 0) + ((1,) if rpt == 16 else ()):
                 assert "lmeds_kernel<%d, %d, %d, true>" % (rpt, mode, win) in have
     # frames of up to 512 tracks belong to the one-wave kernels: no four-wave instantiations for 256 / 512 rows (the tests'
     # family cross-checks run them through the 1024-row ones: same bits)
