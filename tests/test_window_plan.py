@@ -18,6 +18,9 @@ void plan(double span, double ends, double step, unsigned want, int small_, int 
     const rs::WinPlan w = rs::plan_window(span, ends, step, want, small_ != 0, wg_max, fixed, lds, legacy != 0);
     out[0] = w.cap; out[1] = w.chunk;
 }
+unsigned smaller(double span, double step, unsigned chunk, unsigned static_lds, unsigned dyn_fixed, int wg_cap, int lds) {
+    return rs::smaller_window_for_occupancy(span, step, chunk, static_lds, dyn_fixed, wg_cap, lds);
+}
 unsigned cap64_for(float span, float ends) { return rs::cap64_for(span, ends); }
 unsigned cap64_used(unsigned cap64, int one_wave) { return rs::cap64_used(cap64, one_wave != 0); }
 }
@@ -37,6 +40,8 @@ def lib(tmp_path_factory):
     L = ctypes.CDLL(str(out))
     L.plan.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.c_int,
                        ctypes.POINTER(ctypes.c_uint)]
+    L.smaller.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_int, ctypes.c_int]
+    L.smaller.restype = ctypes.c_uint
     L.cap64_for.argtypes = [ctypes.c_float, ctypes.c_float]
     L.cap64_for.restype = ctypes.c_uint
     L.cap64_used.argtypes = [ctypes.c_uint, ctypes.c_int]
@@ -142,3 +147,25 @@ def test_staging_the_two_ends_needs_fewer_knots(lib, fs):
     assert wg2 >= wg1
     if fs == 2000:
         assert wg2 == 5 and wg1 == 4          # 2 kHz: five workgroups per CU again
+
+
+def test_a_smaller_window_where_it_buys_a_workgroup_per_cu(lib):
+    """round 5 (profiles/r5_k2_class3_ab.txt): frames of 2049 .. 4096 tracks -- 56 136 B of LDS with the compiled-in window,
+    51 024 B + the window in dynamic LDS, registers for three workgroups per CU.  At 400 Hz the frames and their chunk touch
+    28 knots: a 32-knot window (2 KB) lets the third workgroup in; from ~600 Hz on the window they need does not, and the
+    compiled-in one stays; a kernel compiled for two workgroups, or one whose tile leaves no room either way, never switches."""
+    S16, D16 = 56136, 51024          # lmeds_kernel<16, 0, 80> / <16, 0, 0>
+    assert lib.smaller(span_of(400), 0.2, 32, S16, D16, 3, LDS) == 32
+    assert lib.smaller(span_of(400), 0.2, 32, S16, D16, 2, LDS) == 0          # (never more workgroups than the registers allow)
+    assert lib.smaller(span_of(800), 0.4, 32, S16, D16, 3, LDS) == 0          # 38 + 12.4 + 1 knots: 56 of dynamic window do not fit three times
+    assert lib.smaller(span_of(2000), 1.0, 15, S16, D16, 3, LDS) == 0         # (wider than the compiled-in window anyway)
+    # whatever it returns holds the frames and the chunk, and is smaller than the compiled-in window
+    for fs in (100, 200, 400, 500, 600):
+        span, step = span_of(fs), 0.0005 * fs
+        cap = lib.smaller(span, step, 32, S16, D16, 3, LDS)
+        if cap:
+            assert span + 1 + 31 * step <= cap < 80 and (D16 + 64 * cap + 1024) * 3 <= LDS
+    # the benchmark's kernel (31 560 B / 26 432 B, five workgroups by its registers) and the 8192-row one (105 288 / 100 176, one)
+    assert lib.smaller(span_of(400), 0.2, 32, 31560, TILE8, 5, LDS) == 0
+    assert lib.smaller(span_of(400), 0.2, 32, 105288, 100176, 1, LDS) == 0
+    assert lib.smaller(span_of(400), 0.2, 32, 0, D16, 3, LDS) == 0            # (no footprint given: no opinion)
