@@ -231,7 +231,7 @@ __device__ __forceinline__ void exec_push(const ExecParams& p, uint32_t w, uint3
     }
 }
 
-constexpr uint32_t kExecStage = 1280; // doubles of LDS the decisions may use for a window's per-slot values (10 KB)
+constexpr uint32_t kExecStage = rs::kPlanExecStage; // doubles of LDS the decisions may use for a window's per-slot values (10 KB; window_plan.hpp sizes the region)
 
 // The window's sums of rows [0, rows) of part[] (only those in `mask`) in the plan's order (window_sums /
 // plan_sum_kernel: a chunk sequentially, then the chunks in order); out[r] valid in every lane.  The values are
@@ -410,7 +410,7 @@ struct ExecLds {
     MotionLds<1> mo;
     ExecWin win;
 };
-static_assert(sizeof(d4) * 4 * kWinMax >= kExecStage * sizeof(double), "staging area (win_cap >= kWinMax)");
+// (the region is at least kExecStage doubles: rssync_kernels.hip, exec_region_bytes -- checked again by rship_sync_exec)
 
 // RPT = rows per lane of the one-wave kernels: frames of up to 64 * RPT tracks.  BIG = the selection also holds frames of
 // more than 512 tracks (exec_big.hpp: p.big) -- an instantiation of its own, so that the reference's workload (one-wave

@@ -1960,7 +1960,13 @@ namespace {
 // the LDS region of an executor wave: the one-wave class's fp64 window, and at least the fp32 window the launch chain's
 // search kernel gives every other class of the selection (exec_big.hpp stages it there)
 size_t exec_region_bytes(rship_ctx* c) {
-    size_t region = win64_bytes(c, 0);
+    // window_plan.hpp, exec_region_for: the one-wave class's fp64 window, the fp32 window the launch chain's search kernel
+    // gives that class, and never less than the decisions' staging area (compact fp64 windows had let the
+    // region shrink to 7-9 KB at 4.3-6.5 kHz on small frames, below the 10 KB a window of ~90-128 one-wave frames stages
+    // in its trial phase and below a 116-knot search window; eight waves per CU still fit ~3.5 KB of static LDS + 10 KB)
+    uint32_t search_cap = 0;
+    if (c->cls_off[1] != c->cls_off[0]) search_cap = plan_lmeds_window<1>(c, 0, 0.0, 1u).cap;
+    size_t region = rs::exec_region_for(c->cls_cap64[0], compact_of(c, 0), search_cap);
     // with frames of more than 512 tracks: 16 KB at least -- the search of such a frame keeps its unit rows (12 bytes each)
     // and keys there, its L-BFGS the rows of P (24 bytes each); with ~3.6 KB of static LDS eight waves still share a CU
     if (c->n_sel != c->cls_off[1] - c->cls_off[0]) region = std::max(region, (size_t)16 * 1024);
@@ -2008,6 +2014,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     // 128 bytes -- 10 KB up to ~1.7 kHz of gyro rate, more for wider frames, and then fewer waves share a CU.
     const uint32_t exec_rpt = (uint32_t)small_rpt(c->cls_max_n[0]);
     const size_t region = exec_region_bytes(c);
+    if (region < (size_t)kExecStage * sizeof(double)) return set_err(c, "sync_exec: the wave's LDS region is smaller than the decisions' staging area");
     const bool compact = compact_of(c, 0);
     const uint32_t cap64 = (uint32_t)(region / (compact ? 64u : 128u)); // knots of fp64 window the region holds (>= the one-wave class's plan)
     const bool with_big = ns != c->cls_off[1] - c->cls_off[0]; // frames of more than 512 tracks in the selection

@@ -210,4 +210,19 @@ inline uint32_t cap64_frames(const FrameDims* f, size_t nf, uint32_t n_lo, uint3
     return need;
 }
 
+// ---- the window executor's per-wave LDS region (kernels/executor.hpp) -------------------------------------------
+// ONE region of dynamic LDS per wave is in turn the search's fp32 spline window, the fp64 window of the motion / loss tasks
+// and the decisions' staging area.  It must therefore hold the largest of the three:
+//   * the one-wave class's fp64 window (cap64 knots at 128 bytes, 64 if compact),
+//   * the fp32 window the launch chain's search kernel would use for the same frames (`search_cap` knots at 64 bytes,
+//     0 = the compiled-in 80: the executor's search must take the chain's spline path, or near-ties fall the other way),
+//   * kPlanExecStage doubles of staging (exec_window_sums: a window's per-slot values, rows x slots <= kPlanExecStage).
+// Round 5's compact windows had let the first term fall to 7-9 KB (4.3-6.5 kHz on small frames) -- below both others.
+constexpr uint32_t kPlanExecStage = 1280;
+inline size_t exec_region_for(uint32_t cap64, bool compact, uint32_t search_cap) {
+    const size_t win64 = (size_t)cap64 * (compact ? 64u : 128u);
+    const size_t win32 = (size_t)(search_cap ? search_cap : kPlanWinStatic) * 64u;
+    return std::max(std::max(win64, win32), (size_t)kPlanExecStage * 8u);
+}
+
 } // namespace rs

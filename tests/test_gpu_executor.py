@@ -194,6 +194,28 @@ def test_executor_equals_the_chain_at_high_gyro_rates(built, fs, n_top):
     assert ex.executor_stats()["runs"] == 2
 
 
+@pytest.mark.parametrize("fs,F", [(4400.0, 100), (5000.0, 128), (6000.0, 120), (6400.0, 128)])
+def test_large_windows_with_compact_fp64_windows_equal_the_chain(built, fs, F):
+    """at 4.3-6.5 kHz a 130-track frame's two ends span 100-140 knots, the one-wave class's fp64 window is
+    COMPACT (64 bytes per knot: 7-9 KB), and the executor's per-wave LDS region had shrunk with it -- below the 10 KB
+    exec_window_sums stages for a window of ~90-128 frames in its trial phase (10 rows x slots doubles): stores past the
+    workgroup's LDS are dropped, loads return 0, the line search decides on wrong sums.  No test reached it (compact tests
+    had 14 frames, measurements 61-slot windows).  One window of 100-128 frames of 130 tracks, executor against the chain of
+    launches: every trace row, delay and cost the same bits, and the executor really ran with a compact window."""
+    from rssync_amd import synth
+    gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, fs=fs, seed=77)
+    frames = list(synth.make_frames(gyro, 0, F, 130, seed=77))
+    ex, ch = _two(seed=77, max_outer_iters=12)
+    _fill((ex, ch), gyro, frames)
+    for d0 in (0.0362, 0.0375):
+        r1, r2 = ex.Sync(d0, 0, F - 1, 0.0, 0.1), ch.Sync(d0, 0, F - 1, 0.0, 0.1)
+        np.testing.assert_array_equal(_bits(ex.sync_trace()), _bits(ch.sync_trace()))
+        assert r1 == r2
+    assert ex.executor_stats()["runs"] == 2
+    info = ex.window_info()
+    assert info["fp64_window_compact"] and 96 < info["fp64_window_knots"] <= 208, info     # (the regime the finding is about)
+
+
 def test_one_call_in_n_is_verified_in_production():
     """RSSYNC_EXECUTOR_CHECK is a debug mode (every call twice).  Without it the product still re-runs ONE executor call
     in N (default 256, here 3) through the launch chain and panics on a difference -- a tripwire for the cross-workgroup

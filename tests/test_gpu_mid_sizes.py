@@ -582,7 +582,10 @@ def test_compact_fp64_windows_do_not_change_a_bit(monkeypatch, fs, N, compact):
     stays on the LDS path -- round 4 read the table from L2 there (12 kHz, 272 knots, still does: measured no faster
     compact, profiles/r5_gyro_rate_small_frames.json).  The same bits as full records
     (RSSYNC_NO_COMPACT_WINDOW=1: round 4's rule) and as the general path (RSSYNC_FORCE_GENERAL_SPLINE=1): rows, loss,
-    derivative, every trace row of Sync through the executor and through the launch chain."""
+    derivative, every trace row of Sync through the chain of launches.  (NOT through the executor, as this docstring
+    claimed until round 6: `record_init_winners` / `set_init_override` keep a problem out of it, sync_problem.cpp:
+    executor_ok.  The executor with compact windows against the chain, bit for bit, on windows large enough to matter:
+    tests/test_gpu_executor.py::test_large_windows_with_compact_fp64_windows_equal_the_chain.)"""
     import rssync_amd
     from rssync_amd import synth
     F = 14

@@ -23,6 +23,15 @@ unsigned smaller(double span, double step, unsigned chunk, unsigned static_lds, 
 }
 unsigned cap64_for(float span, float ends) { return rs::cap64_for(span, ends); }
 unsigned cap64_used(unsigned cap64, int one_wave) { return rs::cap64_used(cap64, one_wave != 0); }
+// the one-wave class's fp64 window for ONE frame of n tracks (out[0] knots, out[1] compact) and the executor's region for it
+void one_wave_window(unsigned n, float span, float ends, int may_compact, unsigned* out) {
+    const rs::FrameDims f{n, span, ends};
+    bool comp = false;
+    out[0] = rs::cap64_frames(&f, 1, 0u, 512u, true, may_compact ? &comp : nullptr);
+    out[1] = comp ? 1u : 0u;
+}
+unsigned long exec_region(unsigned cap64, int compact, unsigned search_cap) { return (unsigned long)rs::exec_region_for(cap64, compact != 0, search_cap); }
+unsigned exec_stage() { return rs::kPlanExecStage; }
 }
 '''
 LDS = 160 * 1024
@@ -46,6 +55,10 @@ def lib(tmp_path_factory):
     L.cap64_for.restype = ctypes.c_uint
     L.cap64_used.argtypes = [ctypes.c_uint, ctypes.c_int]
     L.cap64_used.restype = ctypes.c_uint
+    L.one_wave_window.argtypes = [ctypes.c_uint, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.POINTER(ctypes.c_uint)]
+    L.exec_region.argtypes = [ctypes.c_uint, ctypes.c_int, ctypes.c_uint]
+    L.exec_region.restype = ctypes.c_ulong
+    L.exec_stage.restype = ctypes.c_uint
     return L
 
 
@@ -169,3 +182,34 @@ def test_a_smaller_window_where_it_buys_a_workgroup_per_cu(lib):
     assert lib.smaller(span_of(400), 0.2, 32, 31560, TILE8, 5, LDS) == 0
     assert lib.smaller(span_of(400), 0.2, 32, 105288, 100176, 1, LDS) == 0
     assert lib.smaller(span_of(400), 0.2, 32, 0, D16, 3, LDS) == 0            # (no footprint given: no opinion)
+
+
+def test_the_executors_region_holds_the_staging_area_and_the_search_window(lib):
+    """ADVICE r5 (high + medium): with round 5's COMPACT fp64 windows (64 bytes per knot) the window executor's per-wave LDS
+    region -- which is in turn the search's fp32 window, the fp64 window and the staging area of a window's decisions
+    (kernels/executor.hpp) -- had shrunk to 7168 / 9216 bytes for frames whose two ends span ~100-140 knots (4.3-6.5 kHz on
+    130-track frames): below the 10 240 bytes exec_window_sums stages for a window of 90-128 frames in its trial phase, and
+    below the 116-knot fp32 window the launch chain's search kernel plans for the same frames (107-109 knots of ends).
+    The region is now the largest of the three, for every width (window_plan.hpp: exec_region_for)."""
+    stage_bytes = lib.exec_stage() * 8
+    assert stage_bytes == 10240
+    seen_compact_below_stage = False
+    for ends in range(90, 211):
+        for span in (ends, 2 * ends - 6):                  # the two ends as the planner counts them; the whole pair
+            out = (ctypes.c_uint * 2)()
+            lib.one_wave_window(130, float(span), float(ends), 1, out)
+            cap64, compact = int(out[0]), bool(out[1])
+            # the search's fp32 window as plan_lmeds_window<1> asks for it: one candidate per workgroup, one-wave kernel
+            cap32, chunk = plan(lib, float(span), 0.0, want=1, small=True, wg_max=20, fixed=SMALL3, ends=float(ends))
+            region = lib.exec_region(cap64, int(compact), cap32)
+            win64 = cap64 * (64 if compact else 128)
+            seen_compact_below_stage |= compact and win64 < stage_bytes
+            assert region >= win64 and region >= stage_bytes and region >= (cap32 or 80) * 64, (span, ends, cap64, compact, cap32, region)
+            # eight one-wave workgroups per CU wherever the fp64 window alone allowed them (~3.6 KB of static LDS + 512 B)
+            if win64 <= stage_bytes:
+                assert LDS // (region + 3600 + 512) >= 8
+    assert seen_compact_below_stage                          # (the sweep does cover the case the finding is about)
+    # the cases the finding names: compact 112 / 144 knots; a 116-knot search window beside a 7168-byte fp64 window
+    assert lib.exec_region(112, 1, 0) == 10240 and lib.exec_region(144, 1, 0) == 10240
+    assert lib.exec_region(112, 1, 116) == 10240 and lib.exec_region(112, 1, 128) == 10240
+    assert lib.exec_region(80, 0, 0) == 10240 and lib.exec_region(144, 0, 0) == 144 * 128 and lib.exec_region(208, 1, 0) == 208 * 64
