@@ -298,6 +298,7 @@ def run(args):
     x_doubles -= x_doubles0
     prof = prob.profile_get()
     prob.profile(False)
+    near_static = prob.near_static_stats()  # (frame, candidate) pairs the sweep recomputed with fp64 rows: 0 on this scene
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -456,6 +457,10 @@ def run(args):
                                   "process: --mode inproc adds the devices' chunk sums on the host)"},
             "roofline": roof, "roofline_flop": roof_flop, "roofline_k1": roof_k1, "roofline_k3": roof_k3, "cpu_baseline": cpu,
             "parity": parity, "kernels": kernels,
+            "near_static": {"fp64_row_pairs": near_static["pairs"], "sweeps": near_static["sweeps"],
+                            "note": "PreSync recomputes near-static (frame, candidate) pairs -- a quarter of a frame's first 64 rows "
+                                    "with |P| < 2e-4 -- from the fp64 streams (core_private.cpp:19-28 is double); an ordinary "
+                                    "scene like this one never does: both counters must be 0 for the timed steps to be the fp32 sweep"},
             "presync_ms_per_step": t_pre / args.steps * 1e3,
             "result": result, "host": {"gen_s": round(t_gen, 2), "set_track_result_s": round(t_set, 3), "pack_upload_s": round(t_up, 3),
                      "note": "set_track_result_s = the SetTrackResult loop over all frames (checks + copy into pinned "

@@ -146,6 +146,12 @@ int rssync_ext_set_executor_check_every(rssync_problem* p, uint32_t every);
  * pair (what the dynamic windows stage where that is fewer knots), 0} */
 int rssync_ext_window_info(rssync_problem* p, uint32_t out[8]);
 int rssync_ext_executor_stats(rssync_problem* p, uint64_t* runs, uint64_t* checked, uint32_t queue[4]);
+/* Near-static footage (a camera on a tripod, a slow pan: rows of the residual matrix below ~2e-4).  The reference computes
+ * rows, norms and the safe_normalize decisions in double (core_private.cpp:19-28,45-46, inline_utils.hpp:5-11); PreSync's
+ * fp32 sweep recomputes exactly those (frame, candidate) pairs from the fp64 streams.  *pairs = pairs recomputed so far on
+ * this object, *sweeps = sweeps (PreSync / DebugPreSync / curve calls, per slice) that needed it.  Both stay 0 on ordinary
+ * footage; RSSYNC_NO_FP64_ROWS=1 (read when a problem is created) switches the mechanism off. */
+int rssync_ext_near_static_stats(rssync_problem* p, uint64_t* pairs, uint64_t* sweeps);
 /* Diagnostics of the bit-exactness tests (tests/test_gpu_bitexact.py).  GuessMotion's 200-hypothesis search runs
  * in fp32 and leaves one winning hypothesis index per slot (window-major, frames ascending); with recording on,
  * the winners of the last Sync / sync_windows / sync_simplified call can be read back, and set_init_override

@@ -57,6 +57,10 @@ typedef struct rship_frame {
 #define RSHIP_BAD_M 2u
 #define RSHIP_BAD_R 4u
 #define RSHIP_BAD_RHO 8u
+/* not an error: the PreSync sweep met (frame, candidate) pairs whose rows are too small for its fp32 inputs (a near-static
+ * camera: |P| below ~2e-4) and flagged them; rship_presync_collect recomputes those pairs from the fp64 streams before
+ * it returns (kernels/lmeds.hpp, "fp64 rows"; reference: core_private.cpp:19-28,45-46 are double throughout) */
+#define RSHIP_NEAR_STATIC 16u
 
 /* kernel kinds for rship_profile_get */
 #define RSHIP_K_LMEDS 0  /* PreSync tile kernel */
@@ -189,12 +193,17 @@ int rship_set_plan(rship_ctx* c, const uint32_t* plan_idx, uint32_t plan_len, co
  * opt_compute_problem + opt_guess_translational_motion(P, n_hyp) + cost
  * (core_private.cpp:75-85), then the sums of the plan.  enqueue returns at once (several devices work
  * concurrently); collect waits: win_costs[n_cand][n_win], chunk_costs[n_cand][n_chunks] (either may be
- * NULL), status bits, and the debug matrices frame_costs / best_h [n_cand][n_sel] if asked for. */
-int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand,
-                          uint32_t n_hyp, uint32_t stream_base, uint64_t seed, int want_frame_costs,
+ * NULL), status bits, and the debug matrices frame_costs / best_h [n_cand][n_sel] if asked for.
+ * kd64 / fd64 (or NULL: the fp32 split, widened): the same delays split in fp64, for the pairs whose rows the sweep
+ * recomputes from the fp64 streams -- near-static frames, |P| below ~2e-4, where fp32 inputs are not enough to follow
+ * the reference's double arithmetic (core_private.cpp:19-28,45-46); collect does that before it returns. */
+int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, const int32_t* kd64, const double* fd64,
+                          uint32_t n_cand, uint32_t n_hyp, uint32_t stream_base, uint64_t seed, int want_frame_costs,
                           int want_best_h);
 int rship_presync_collect(rship_ctx* c, uint32_t n_cand, double* win_costs, double* chunk_costs,
                           uint32_t* flags, double* frame_costs, int32_t* best_h);
+/* out[0] = (frame, candidate) pairs recomputed with fp64 rows so far on this context, out[1] = sweeps that needed it */
+int rship_near_static_stats(rship_ctx* c, uint64_t out[2]);
 
 /* FrameState::GuessMotion (core_private.cpp:125-128): the 200-hypothesis LMedS search for every selected
  * slot, in the fp32 tile kernel; kd/fd hold one delay per window (fp32 split), window w samples with

@@ -71,7 +71,37 @@ struct LmedsParams {
     uint32_t win_cap;
     uint32_t win_whole_pair; // 1: a dynamic window behaves like the compiled-in one -- whole pairs only (the window executor's
                              // search where the launch chain's search kernel uses the compiled-in window)
+    // ---- NEAR-STATIC frames: rows in fp64 (round 6; MODE 0 only, "fp64 rows" below) ----
+    // redo_mask (or null: the watch is off): one bit per (slot, candidate), word slot * mask_words + (c >> 5), bit c & 31.
+    // The fp32 sweep SETS the bit of a pair whose rows are too small for fp32 inputs; the R64 instantiations -- launched
+    // over the same grid once the host has seen RSHIP_NEAR_STATIC -- recompute exactly those pairs from the fp64 streams
+    // (src64, delays kd64 / fd64 [n_cand]), overwrite frame_cost / best_h, and clear the bits they served.
+    uint32_t* redo_mask;
+    uint32_t mask_words;
+    Rows64Src src64;
+    const int32_t* kd64;
+    const double* fd64;
+    unsigned long long* redo_count; // pairs recomputed in fp64 so far (debug ABI: rship_near_static_stats)
 };
+
+// fp64 ROWS FOR NEAR-STATIC FRAMES (round 6).  The reference computes the rows of P, their norms and the safe_normalize
+// decisions in double (core_private.cpp:19-28,45-46, inline_utils.hpp:5-11).  The sweep's inputs are fp32 -- a ray
+// component carries 6e-8 absolute -- which is 3e-5 of an ordinary row (|P| ~ 2e-3: translation / depth) but 3 % of a row
+// of 2e-6: for a camera on a tripod or in a slow pan the fp32 sweep picked another LMedS winner than the reference in up to
+// 19 % of the (frame, candidate) pairs (profiles/r5_near_static.json).  The fp64 streams that Sync reads are resident
+// anyway.  So the sweep WATCHES for such pairs -- of the frame's first 64 rows, a quarter or more with |P|^2 below
+// kNearStatic2: one v_cmp and one s_bcnt1 per wave and candidate in the hot kernel, nothing per row -- and flags them; the
+// host, when it collects the sweep and sees the flag, launches the R64 form of the same kernels, which recompute only the
+// flagged pairs: rows from the fp64 streams and the fp64 table (rows64.hpp: row64_unit -- norm, unit row and the
+// safe_normalize test in double), rounded ONCE to the fp32 tile and fp32 norms; hypotheses (with the rows' fp64 norms in
+// the hypothesis rule), sweeps, selection and stage D are the fp32 code, untouched.  An ordinary scene never sets a bit
+// and never sees the second launch (rship_near_static_stats counts the pairs; the tests assert 0 on ordinary scenes).
+// The sample is the first min(N, 64) rows in every kernel family, so the decision is the frame's and the candidate's.
+#ifndef RSSYNC_NEAR_WATCH   // (-DRSSYNC_NEAR_WATCH=0: the sweep kernels without the watch -- round 5's code -- for the A/B of profiles/r6_k2_rows64_ab.txt)
+#define RSSYNC_NEAR_WATCH 1
+#endif
+constexpr float kNearStatic2 = 4e-8f; // |P| < 2e-4: where profiles/r5_near_static.json first falls below 99 % (median |P| 1.2e-4)
+__device__ __forceinline__ bool near_static_fires(uint32_t near, uint32_t N) { return 4u * near >= (N < 64u ? N : 64u); }
 
 // ---- LMedS tile in LDS, struct-of-arrays: unit rows n = safe_normalize(P).  The norms |P|
 // stay in the registers of the thread that owns the row (only stage D needs them).
@@ -308,18 +338,21 @@ struct RowWatch {
     float qerr = 0.f, nsum = 0.f;
     uint32_t n2min = 0x7f000000u; // bit pattern of the smallest |P|^2: non-negative floats order like their patterns, a NaN's
                                   // lies above them all (and an integer minimum needs no canonicalising v_max before it)
+    uint32_t near = 0; // wave-uniform: how many of the wave's FIRST rows (j = 0: rows 0 .. 63 in wave 0) have |P|^2 < kNearStatic2
     __device__ __forceinline__ bool below_safe_normalize() const { return n2min < __float_as_uint(1e-24f); }
 };
 
 template <int PATH, bool SWEEP, int CAP, bool FAST = false>
 __device__ __forceinline__ uint32_t lmeds_row(const Spline& sp, f4 A, f4 B, uint32_t N, uint32_t row, int base, float fd,
-                                              const Tile& tile, float& nrm, RowWatch* watch = nullptr) {
+                                              const Tile& tile, float& nrm, RowWatch* watch = nullptr, bool first = false) {
     uint32_t bad = 0;
     nrm = 0.f;
     if (row < N) {
         f3 P, dP;
         residual_row<false, PATH, SWEEP, CAP, FAST>(sp, A, B, base, fd, P, dP, FAST ? &watch->qerr : nullptr);
         const float n2 = rs::dot(P, P);
+        // the near-static watch (above): of the wave's first rows -- the lanes active here -- how many are tiny
+        if (RSSYNC_NEAR_WATCH && first && watch) watch->near = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(n2 < kNearStatic2));
         if (FAST) {
             // (round 4: five instructions per row -- a class test and an OR for non-finite rows, a compare and two selects
             // for safe_normalize's rule -- became a minimum and an addition; profiles/r4_k2_rowwatch_ab.txt)
@@ -344,7 +377,7 @@ __device__ __forceinline__ uint32_t lmeds_row(const Spline& sp, f4 A, f4 B, uint
 // n2min: the smallest |P|^2 (bit pattern) of this thread's rows, for hypothesis()'s bound
 template <int RPT, bool SWEEP, int CAP>
 __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& rays, uint32_t N, int base, float fd,
-                                               const Tile& tile, float (&nrm)[RPT], uint32_t& n2min) {
+                                               const Tile& tile, float (&nrm)[RPT], uint32_t& n2min, uint32_t& near) {
     uint32_t bad = 0;
     const uint32_t voff = threadIdx.x * 16u;
     if (sp.path == kPathInterior) {
@@ -355,7 +388,7 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const f4 A = load_ray(rays.a, voff, (uint32_t)j * kBlock * 16u), B = load_ray(rays.b, voff, (uint32_t)j * kBlock * 16u);
-            (void)lmeds_row<kPathInterior, SWEEP, CAP, true>(sp, A, B, N, j * kBlock + threadIdx.x, base, fd, tile, nrm[j], &watch);
+            (void)lmeds_row<kPathInterior, SWEEP, CAP, true>(sp, A, B, N, j * kBlock + threadIdx.x, base, fd, tile, nrm[j], &watch, j == 0);
         }
         if (!finite_f(watch.nsum)) bad = RSHIP_BAD_P;
         // never, for orientations and rays that move: redo the wave's rows with the reciprocal and safe_normalize's select
@@ -372,17 +405,42 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
             }
         }
         n2min = watch.n2min; // (of the hot form: a row below the threshold shows there too)
+        near = watch.near;
     } else { // rare (ends of the gyro track, wild delays): keep the code small, not fast
         float tmp[RPT];
         RowWatch watch;
 #pragma unroll 1
         for (int j = 0; j < RPT; ++j) {
             const f4 A = load_ray(rays.a, voff, (uint32_t)j * kBlock * 16u), B = load_ray(rays.b, voff, (uint32_t)j * kBlock * 16u);
-            bad |= lmeds_row<kPathGlobal, false, CAP>(sp, A, B, N, j * kBlock + threadIdx.x, base, fd, tile, tmp[j], &watch);
+            bad |= lmeds_row<kPathGlobal, false, CAP>(sp, A, B, N, j * kBlock + threadIdx.x, base, fd, tile, tmp[j], &watch, j == 0);
         }
 #pragma unroll
         for (int j = 0; j < RPT; ++j) nrm[j] = tmp[j];
         n2min = watch.n2min;
+        near = watch.near;
+    }
+    return bad;
+}
+
+// stage A in its fp64 form (R64 instantiations: "fp64 rows" above): this thread's rows from the fp64 streams, unit rows to
+// the tile, norms to s_nrm (LDS, so that the loop need not be unrolled and hypothesis() can look any row's norm up)
+template <int RPT>
+__device__ __forceinline__ uint32_t lmeds_rows64(const Rows64Src& src, uint32_t off, uint32_t N, int base, double fd, const Tile& tile,
+                                                 float* s_nrm, uint32_t& n2min) {
+    uint32_t bad = 0;
+    n2min = 0x7f000000u;
+#pragma unroll 1
+    for (int j = 0; j < RPT; ++j) {
+        const uint32_t row = j * kBlock + threadIdx.x;
+        if (row < N) {
+            const Row64 r = row64_unit(src, (size_t)off + row, base, fd);
+            if (!r.finite) bad = RSHIP_BAD_P;
+            tile.nx[row] = r.n.x; tile.ny[row] = r.n.y; tile.nz[row] = r.n.z;
+            s_nrm[row] = r.nrm;
+            n2min = min(n2min, __float_as_uint(r.n2));
+        } else {
+            s_nrm[row] = 0.f;
+        }
     }
     return bad;
 }
@@ -470,8 +528,12 @@ constexpr int kContCap = 24; // contender records per candidate; beyond that a h
 // launches whose window is small enough that the kernel's LDS lets a third one in (rssync_kernels.hip: plan_lmeds_window;
 // 168 VGPRs, 44 of the 213 the kernel wants spilled to scratch, and still 25 % faster: profiles/r5_k2_class3_ab.txt).  WIN = 0
 // stays compiled for two: a large window (high gyro rates) leaves no room for a third workgroup and the spills would only cost.
-template <int RPT, int MODE, int WIN, bool LAZY = true> // MODE 0: PreSync cost per candidate; 1: GuessMotion's hypothesis search (Sync start)
-__global__ __launch_bounds__(kBlock, RPT == 16 ? (WIN == 1 ? 3 : 2) : lmeds_waves(RPT)) void lmeds_kernel(LmedsParams p) {
+// R64 = the fp64-rows form ("fp64 rows" above; MODE 0, WIN 0): the same grid, but a workgroup leaves at once unless the
+// fp32 launch has flagged candidates of its (frame, chunk), and evaluates only those -- stage A from the fp64 streams.
+// Not a hot kernel: compiled without an occupancy target.
+template <int RPT, int MODE, int WIN, bool LAZY = true, bool R64 = false> // MODE 0: PreSync cost per candidate; 1: GuessMotion's hypothesis search (Sync start)
+__global__ __launch_bounds__(kBlock, R64 ? 1 : (RPT == 16 ? (WIN == 1 ? 3 : 2) : lmeds_waves(RPT))) void lmeds_kernel(LmedsParams p) {
+    static_assert(!R64 || (MODE == 0 && WIN == 0 && LAZY), "the fp64-rows form exists for the PreSync sweep only");
     constexpr int CAPW = WIN == 1 ? 0 : WIN; // the window's compile-time capacity (0 = dynamic)
     constexpr int kHyp = kHypBatch;
     constexpr int ROWS = kBlock * RPT;
@@ -498,6 +560,7 @@ __global__ __launch_bounds__(kBlock, RPT == 16 ? (WIN == 1 ? 3 : 2) : lmeds_wave
     __shared__ uint32_t s_ncont;
     __shared__ unsigned long long s_exact;
     __shared__ uint32_t s_min2[4]; // per wave: the smallest |P|^2 (bit pattern) of the candidate's rows (hypothesis(): smin2)
+    __shared__ float s_nrm[R64 ? ROWS : 1]; // R64: the rows' norms (fp64, rounded once)
     const int tid = threadIdx.x, lane = tid & 63;
 #if RSSYNC_K2_TIMING && RSSYNC_K2_COUNTERS
     long long k2_bar = 0, k2_by[4] = {0, 0, 0, 0};
@@ -525,6 +588,17 @@ __global__ __launch_bounds__(kBlock, RPT == 16 ? (WIN == 1 ? 3 : 2) : lmeds_wave
     const uint32_t c0 = chunk * p.chunk;
     const uint32_t c1 = (c0 + p.chunk < p.n_cand) ? c0 + p.chunk : p.n_cand;
     if (c0 >= c1) return;
+    // R64: the candidates of this chunk the fp32 launch flagged (bit i <-> candidate c0 + i); none: nothing to do
+    uint32_t redo = 0;
+    if constexpr (R64) {
+        const uint32_t* mw = p.redo_mask + (size_t)sf * p.mask_words;
+        const uint32_t w0 = c0 >> 5, w1 = (c1 - 1u) >> 5;
+        const unsigned long long both = (unsigned long long)mw[w0] | (w1 != w0 ? (unsigned long long)mw[w1] << 32 : 0ull);
+        redo = (uint32_t)(both >> (c0 & 31u));
+        if (c1 - c0 < 32u) redo &= (1u << (c1 - c0)) - 1u;
+        redo = uniform_u32(redo);
+        if (!redo) return;
+    }
 
     // the chunk's delays, staged once: a scalar load per candidate would put an L2 round trip at
     // the head of every stage A
@@ -539,7 +613,7 @@ __global__ __launch_bounds__(kBlock, RPT == 16 ? (WIN == 1 ? 3 : 2) : lmeds_wave
     sp.n = p.n_knots;
     sp.cap = (int)p.win_cap;
     sp.whole_pair = p.win_whole_pair != 0;
-    {
+    if constexpr (!R64) { // (the fp64 rows read the fp64 table from L2: no window)
         int kd_lo = p.kd[c0 * p.n_grp + g], kd_hi = kd_lo;
         for (uint32_t c = c0 + 1; c < c1; ++c) {
             int v = p.kd[c * p.n_grp + g];
@@ -555,6 +629,15 @@ __global__ __launch_bounds__(kBlock, RPT == 16 ? (WIN == 1 ? 3 : 2) : lmeds_wave
         if (row >= N) s_n[0][row] = s_n[1][row] = s_n[2][row] = __uint_as_float(0x7fc00000u);
     }
     __syncthreads();
+    if constexpr (R64) { // every thread has read the chunk's bits: they are served, clear them (other chunks share the words)
+        if (tid == 0) {
+            const uint32_t w0 = c0 >> 5, w1 = (c1 - 1u) >> 5;
+            uint32_t* mw = p.redo_mask + (size_t)sf * p.mask_words;
+            atomicAnd(&mw[w0], ~(redo << (c0 & 31u)));
+            if (w1 != w0) atomicAnd(&mw[w1], ~(uint32_t)((unsigned long long)redo >> (32u - (c0 & 31u))));
+            atomicAdd(p.redo_count, (unsigned long long)__builtin_popcount(redo));
+        }
+    }
 
     const f4* p4x = reinterpret_cast<const f4*>(tile.nx);
     const f4* p4y = reinterpret_cast<const f4*>(tile.ny);
@@ -562,6 +645,9 @@ __global__ __launch_bounds__(kBlock, RPT == 16 ? (WIN == 1 ? 3 : 2) : lmeds_wave
     uint32_t prev_best = kInfBits; // winning quantile of the previous candidate of this chunk
 
     for (uint32_t c = c0; c < c1; ++c) {
+        if constexpr (R64) {
+            if (!((redo >> (c - c0)) & 1u)) continue;
+        }
         const int base = fr.base_knot + s_kd[c - c0];
         const float fd = s_fd[c - c0];
         const uint32_t stream = p.stream_base + c + g * p.stream_stride; // g != 0 only for batched GuessMotion
@@ -569,15 +655,28 @@ __global__ __launch_bounds__(kBlock, RPT == 16 ? (WIN == 1 ? 3 : 2) : lmeds_wave
         // ---- stage A: rows of P -> LDS tile as unit rows; norms stay in registers ----
         float nrm[RPT];
         uint32_t n2min;
-        bad |= lmeds_rows<RPT, MODE == 0, CAPW>(sp, rays, N, base, fd, tile, nrm, n2min);
+        if constexpr (R64) {
+            bad |= lmeds_rows64<RPT>(p.src64, fr.off, N, fr.base_knot + p.kd64[c], p.fd64[c], tile, s_nrm, n2min);
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) nrm[j] = s_nrm[j * kBlock + tid]; // (this thread's own stores)
+        } else {
+            uint32_t near;
+            bad |= lmeds_rows<RPT, MODE == 0, CAPW>(sp, rays, N, base, fd, tile, nrm, n2min, near);
+            // the near-static watch ("fp64 rows" above): thread 0's wave has counted the frame's first 64 rows
+            if (RSSYNC_NEAR_WATCH && MODE == 0 && p.redo_mask && tid == 0 && near_static_fires(near, N)) {
+                atomicOr(&p.redo_mask[(size_t)sf * p.mask_words + (c >> 5)], 1u << (c & 31u));
+                bad |= RSHIP_NEAR_STATIC;
+            }
+        }
         {   // (written before the "tile written" barrier below, read by the hypotheses' lanes after it; the next
             // candidate's write comes after this candidate's last barrier)
             const uint32_t wmin = wave_min_u32(n2min);
             if (lane == 0) s_min2[tid >> 6] = wmin;
         }
-        // |P_row| for hypothesis(), from the rays
+        // |P_row| for hypothesis(), from the rays (R64: the norms of stage A, in LDS -- read after the "tile written" barrier)
         auto row_scale = [&](uint32_t row) -> float {
-            return row_scale_general(p.coef, p.n_knots, load_ray(rays.a, row * 16u, 0u), load_ray(rays.b, row * 16u, 0u), base, fd);
+            if constexpr (R64) return s_nrm[row];
+            else return row_scale_general(p.coef, p.n_knots, load_ray(rays.a, row * 16u, 0u), load_ray(rays.b, row * 16u, 0u), base, fd);
         };
         auto frame_smin2 = [&]() -> float {
             uint32_t m = s_min2[0];

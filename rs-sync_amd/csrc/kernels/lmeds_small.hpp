@@ -31,9 +31,12 @@ struct LmedsSmallLds {
 };
 
 // the work of one wave (64 threads, the whole workgroup) on slot sf, chunk `chunk`
-template <int RPT, int MODE, bool SC1 = false, int CAP = kWinMax> // SC1: the delays, the stream and the winners are shared with other workgroups of this launch
+// R64 = the fp64-rows form of the sweep (lmeds.hpp, "fp64 rows"; MODE 0, CAP 0): only the candidates of this (frame, chunk)
+// that the fp32 launch flagged, their rows from the fp64 streams; s_nrm = 64 * RPT floats of LDS for the rows' norms
+template <int RPT, int MODE, bool SC1 = false, int CAP = kWinMax, bool R64 = false> // SC1: the delays, the stream and the winners are shared with other workgroups of this launch
 __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t sf, uint32_t chunk, LmedsSmallLds<RPT, CAP>& lds,
-                                                 f4* dyn_win = nullptr) {
+                                                 f4* dyn_win = nullptr, float* s_nrm = nullptr) {
+    static_assert(!R64 || (MODE == 0 && !SC1 && CAP == 0), "the fp64-rows form exists for the PreSync sweep only");
     constexpr int kHyp = kHypBatch;
     float (&s_n)[3][64 * RPT] = lds.n;
     f4* s_win = CAP ? lds.win : dyn_win;
@@ -52,6 +55,22 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
     const uint32_t c0 = chunk * p.chunk;
     const uint32_t c1 = (c0 + p.chunk < p.n_cand) ? c0 + p.chunk : p.n_cand;
     if (c0 >= c1) return;
+    uint32_t redo = 0; // R64: the flagged candidates of this chunk (bit i <-> candidate c0 + i)
+    if constexpr (R64) {
+        uint32_t* mw = p.redo_mask + (size_t)sf * p.mask_words;
+        const uint32_t w0 = c0 >> 5, w1 = (c1 - 1u) >> 5;
+        const unsigned long long both = (unsigned long long)mw[w0] | (w1 != w0 ? (unsigned long long)mw[w1] << 32 : 0ull);
+        redo = (uint32_t)(both >> (c0 & 31u));
+        if (c1 - c0 < 32u) redo &= (1u << (c1 - c0)) - 1u;
+        redo = uniform_u32(redo);
+        if (!redo) return;
+        __syncthreads(); // (one wave: every lane has its copy before the bits are cleared)
+        if (lane == 0) {
+            atomicAnd(&mw[w0], ~(redo << (c0 & 31u)));
+            if (w1 != w0) atomicAnd(&mw[w1], ~(uint32_t)((unsigned long long)redo >> (32u - (c0 & 31u))));
+            atomicAdd(p.redo_count, (unsigned long long)__builtin_popcount(redo));
+        }
+    }
     if ((uint32_t)lane < c1 - c0) {
         s_kd[lane] = ld_m<SC1>(&p.kd[(c0 + lane) * p.n_grp + g]);
         s_fd[lane] = ld_m<SC1>(&p.fd[(c0 + lane) * p.n_grp + g]);
@@ -61,7 +80,8 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
     sp.n = p.n_knots;
     sp.cap = (int)p.win_cap;
     sp.whole_pair = p.win_whole_pair != 0;
-    {
+    sp.path = kPathGlobal;
+    if constexpr (!R64) { // (the fp64 rows read the fp64 table from L2: no window)
         int kd_lo = ld_m<SC1>(&p.kd[c0 * p.n_grp + g]), kd_hi = kd_lo;
         for (uint32_t c = c0 + 1; c < c1; ++c) {
             const int v = ld_m<SC1>(&p.kd[c * p.n_grp + g]);
@@ -76,6 +96,9 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
     uint32_t prev_best = kInfBits;
     const uint32_t voff = (uint32_t)lane * 16u;
     for (uint32_t c = c0; c < c1; ++c) {
+        if constexpr (R64) {
+            if (!((redo >> (c - c0)) & 1u)) continue;
+        }
         const int base = fr.base_knot + s_kd[c - c0];
         const float fd = s_fd[c - c0];
         const uint32_t stream = p.win_stream ? ld_m<SC1>(&p.win_stream[g]) + c : p.stream_base + c + g * p.stream_stride;
@@ -98,6 +121,8 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
                     if (sp.path == kPathInterior) residual_row<false, kPathInterior, MODE == 0, CAP, FAST>(sp, A, B, base, fd, P, dP, FAST ? &watch->qerr : nullptr);
                     else residual_row<false, kPathGlobal, false, CAP>(sp, A, B, base, fd, P, dP);
                     const float n2 = rs::dot(P, P);
+                    // the near-static watch (lmeds.hpp): of the frame's first 64 rows -- the lanes active here -- how many are tiny
+                    if (RSSYNC_NEAR_WATCH && MODE == 0 && j == 0 && watch) watch->near = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(n2 < kNearStatic2));
                     if (FAST) {
                         const float inv = rs::rsqrt_fast(n2);
                         nx[j] = P.x * inv; ny[j] = P.y * inv; nz[j] = P.z * inv;
@@ -117,7 +142,27 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
             }
         };
         RowWatch watch;
-        if (sp.path == kPathInterior) {
+        if constexpr (R64) {
+            // the fp64 form of the rows (rows64.hpp: row64_unit): unit rows and norms from the fp64 streams, rounded once
+            const int base64 = fr.base_knot + p.kd64[c];
+            const double fd64 = p.fd64[c];
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                const uint32_t row = j * 64 + lane;
+                const float nan = __uint_as_float(0x7fc00000u);
+                nx[j] = ny[j] = nz[j] = nan;
+                nrm[j] = 0.f;
+                if (row < N) {
+                    const Row64 r = row64_unit(p.src64, (size_t)fr.off + row, base64, fd64);
+                    if (!r.finite) bad = RSHIP_BAD_P;
+                    nx[j] = r.n.x; ny[j] = r.n.y; nz[j] = r.n.z;
+                    nrm[j] = r.nrm;
+                    watch.n2min = min(watch.n2min, __float_as_uint(r.n2));
+                }
+                s_n[0][row] = nx[j]; s_n[1][row] = ny[j]; s_n[2][row] = nz[j];
+                s_nrm[row] = nrm[j];
+            }
+        } else if (sp.path == kPathInterior) {
             rows(std::true_type{}, &watch);
             if (!finite_f(watch.nsum)) bad = RSHIP_BAD_P;
             if (__builtin_amdgcn_ballot_w64(watch.qerr >= kNewtonMaxErr || watch.below_safe_normalize()) != 0) {
@@ -127,11 +172,20 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
         } else {
             rows(std::false_type{}, &watch);
         }
+        if constexpr (!R64) { // the near-static watch ("fp64 rows", lmeds.hpp): flag the pair for the fp64 form
+            if (RSSYNC_NEAR_WATCH && MODE == 0 && p.redo_mask && near_static_fires(watch.near, N)) {
+                if (lane == 0) { // (one lane: the flag word is an atomic per lane that carries a bit)
+                    atomicOr(&p.redo_mask[(size_t)sf * p.mask_words + (c >> 5)], 1u << (c & 31u));
+                    bad |= RSHIP_NEAR_STATIC;
+                }
+            }
+        }
         __syncthreads(); // the wave's rows are in LDS
         // hypothesis(): the bound from the frame's smallest |P|^2, and |P_row| from the rays (the tile kernel's values, lmeds.hpp)
         const float smin2 = smin2_of(wave_min_u32(watch.n2min));
         auto row_scale = [&](uint32_t row) -> float {
-            return row_scale_general(p.coef, p.n_knots, load_ray(rays.a, row * 16u, 0u), load_ray(rays.b, row * 16u, 0u), base, fd);
+            if constexpr (R64) return s_nrm[row]; // (the norms of the fp64 rows)
+            else return row_scale_general(p.coef, p.n_knots, load_ray(rays.a, row * 16u, 0u), load_ray(rays.b, row * 16u, 0u), base, fd);
         };
 
         // ---- the hypotheses, in order.  The previous candidate's best quantile (x1.25) is a provisional bound
@@ -231,16 +285,17 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
     }
 }
 
-template <int RPT, int MODE, int CAP = kWinMax>
-__global__ __launch_bounds__(64, RPT <= 3 ? 6 : (RPT == 4 ? 5 : 3)) void lmeds_small_kernel(LmedsParams p) {
+template <int RPT, int MODE, int CAP = kWinMax, bool R64 = false>
+__global__ __launch_bounds__(64, R64 ? 1 : (RPT <= 3 ? 6 : (RPT == 4 ? 5 : 3))) void lmeds_small_kernel(LmedsParams p) {
     __shared__ LmedsSmallLds<RPT, CAP> lds;
+    __shared__ float s_nrm[R64 ? 64 * RPT : 1];
     f4* dyn = nullptr;
     if constexpr (CAP == 0) {
         extern __shared__ f4 s_small_win_dynamic[];
         dyn = s_small_win_dynamic;
     }
     const uint32_t entry = blockIdx.x / p.n_chunks; // (the launch has n_slots x n_chunks workgroups)
-    lmeds_small_body<RPT, MODE, false, CAP>(p, p.slots ? p.slots[entry] : entry, blockIdx.x % p.n_chunks, lds, dyn);
+    lmeds_small_body<RPT, MODE, false, CAP, R64>(p, p.slots ? p.slots[entry] : entry, blockIdx.x % p.n_chunks, lds, dyn, s_nrm);
 }
 
 } // namespace

@@ -51,6 +51,7 @@ using rs::f4;
 
 // the kernels, one header per kernel, all in this translation unit
 #include "kernels/common.hpp"
+#include "kernels/rows64.hpp"
 #include "kernels/lmeds.hpp"
 #include "kernels/lmeds_small.hpp"
 #include "kernels/lmeds_big.hpp"
@@ -167,6 +168,16 @@ struct rship_ctx {
     const float* d_fd = nullptr;    // device address of the fd half of the last upload
     DevBuf kd64;                    // kd[n] (int32) then fd[n] (double) for the fp64 kernels
     const double* d_fd64 = nullptr;
+    // NEAR-STATIC frames: rows in fp64 (kernels/lmeds.hpp, "fp64 rows").  redo_mask: one bit per (slot, candidate), all zero
+    // between calls (the R64 kernels clear what they serve); redo_count: pairs recomputed (device counter);
+    // what the last presync enqueue left for a redo at collect time
+    DevBuf redo_mask, redo_delays, redo_count;
+    bool no_fp64_rows = false;  // RSSYNC_NO_FP64_ROWS=1 (read at creation; the "before" column of profiles/r6_near_static.json): the watch is off
+    bool redo_dirty = true;     // the mask may hold bits (fresh allocation, a call that failed half-way): cleared before the next sweep
+    uint64_t near_launches = 0; // sweeps that went through the fp64 form
+    struct PendRedo { bool armed = false; LmedsParams p{}; double step_knots = 0; uint32_t chunk = 1; bool uploaded = false; } pend_redo;
+    std::vector<int32_t> h_kd64r;
+    std::vector<double> h_fd64r;
     // scratch
     DevBuf kd, frame_cost, best_h, costs, part, flags, stats;
     void* pinned = nullptr;
@@ -596,6 +607,47 @@ int launch_lmeds(rship_ctx* c, const LmedsParams& p, double step_knots, uint32_t
     return 0;
 }
 
+// The fp64-rows form of a PreSync sweep (kernels/lmeds.hpp, "fp64 rows"): per size class the SAME grid and chunking as the
+// fp32 launch (the plan is a function of the context's state, which has not changed since), R64 instantiations; a
+// workgroup whose (frame, chunk) has no flagged candidate leaves at once.  Class 5 has taken its fp64 rows in the first
+// launch already (kernels/lmeds_big.hpp).
+int launch_lmeds_redo(rship_ctx* c, const LmedsParams& p_in, double step_knots, uint32_t chunk_want) {
+    ProfScope ps(c, RSHIP_K_LMEDS);
+    for (const ClassRange& r : class_ranges(c)) {
+        const LmedsKind kind = lmeds_kind(c, r.k);
+        if (kind == LmedsKind::Big) continue;
+        const WinPlan wp = plan_lmeds_window<0>(c, r.k, step_knots, chunk_want);
+        const int rpt = lmeds_rpt(c, r.k);
+        LmedsParams p = p_in;
+        p.slots = r.list;
+        p.n_slots = r.count;
+        p.chunk = wp.chunk;
+        p.n_chunks = (p.n_cand + wp.chunk - 1) / wp.chunk;
+        if (kind == LmedsKind::Small) {
+            const uint32_t g1 = (uint32_t)((uint64_t)r.count * p.n_chunks); // (the fp32 launch has checked the size)
+            switch (rpt) {
+                case 1: hipLaunchKernelGGL((lmeds_small_kernel<1, 0, 0, true>), dim3(g1), dim3(64), 0, c->stream, p); break;
+                case 2: hipLaunchKernelGGL((lmeds_small_kernel<2, 0, 0, true>), dim3(g1), dim3(64), 0, c->stream, p); break;
+                case 3: hipLaunchKernelGGL((lmeds_small_kernel<3, 0, 0, true>), dim3(g1), dim3(64), 0, c->stream, p); break;
+                case 4: hipLaunchKernelGGL((lmeds_small_kernel<4, 0, 0, true>), dim3(g1), dim3(64), 0, c->stream, p); break;
+                default: hipLaunchKernelGGL((lmeds_small_kernel<8, 0, 0, true>), dim3(g1), dim3(64), 0, c->stream, p); break;
+            }
+        } else {
+            const uint32_t grid = (uint32_t)((uint64_t)((r.count + 7) / 8) * 8 * p.n_chunks);
+            switch (rpt) {
+                case 4: hipLaunchKernelGGL((lmeds_kernel<4, 0, 0, true, true>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+                case 8: hipLaunchKernelGGL((lmeds_kernel<8, 0, 0, true, true>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+                case 16: hipLaunchKernelGGL((lmeds_kernel<16, 0, 0, true, true>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+                case 32: allow_dynamic_lds(lmeds_kernel<32, 0, 0, true, true>, 0);
+                         hipLaunchKernelGGL((lmeds_kernel<32, 0, 0, true, true>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+                default: return set_err(c, "lmeds (fp64 rows): unsupported rows-per-thread");
+            }
+        }
+        RS_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
 // does class k's trial kernel use its compiled-in five windows of 80 knots? (whole pairs only: where the 80 knots are
 // enough just because the two ends are staged separately, the dynamic instantiation runs)
 bool loss_fixed80(const rship_ctx* c, int k) {
@@ -882,6 +934,7 @@ int rship_create(rship_ctx** out, int device) {
     if (const char* s = std::getenv("RSSYNC_FORCE_BIG")) c->force_big = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_FORCE_GENERAL_SPLINE")) c->force_general = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_NO_COMPACT_WINDOW")) c->no_compact = s[0] && s[0] != '0';
+    if (const char* s = std::getenv("RSSYNC_NO_FP64_ROWS")) c->no_fp64_rows = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_EXEC_BIG_MAX")) { const int v = atoi(s); if (v >= 0) c->exec_big_max = (uint32_t)v; }
     if (const char* s = std::getenv("RSSYNC_EXEC_BIG_SHARE")) { const int v = atoi(s); if (v >= 1) c->exec_big_share = (uint32_t)v; }
     if (const char* s = std::getenv("RSSYNC_ONE_WAVE_MAX")) { const int v = atoi(s); if (v >= 64 && v <= 64 * kSmallMaxRpt) c->one_wave_max = (uint32_t)v; }
@@ -919,7 +972,7 @@ void rship_destroy(rship_ctx* c) {
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     DevBuf* bufs[] = {&c->coef, &c->coef64, &c->raw, &c->rays_a, &c->rays_b, &c->rays64, &c->frames, &c->sel, &c->M, &c->k, &c->grp, &c->grp_off,
                       &c->plan_idx, &c->plan_chunk_off, &c->plan_win_off, &c->chunk_out, &c->win_out, &c->loop_state, &c->kd, &c->kd64, &c->init_h,
-                      &c->frame_cost, &c->best_h, &c->costs, &c->part, &c->flags, &c->stats,
+                      &c->frame_cost, &c->best_h, &c->costs, &c->part, &c->flags, &c->stats, &c->redo_mask, &c->redo_delays, &c->redo_count,
                       &c->big_scratch, &c->mo_scratch, &c->mo_evals, &c->mo_order,
                       &c->g_ts, &c->g_rates, &c->g_us, &c->g_dq, &c->g_q, &c->g_knots, &c->g_cf, &c->g_status};
     for (DevBuf* b : bufs)
@@ -1364,10 +1417,11 @@ int rship_set_plan(rship_ctx* c, const uint32_t* plan_idx, uint32_t plan_len, co
 
 // pre_sync's per-frame body (core_private.cpp:75-85) for every (selected slot, candidate delay), then the
 // sums of the current plan.  Asynchronous: rship_presync_collect waits and hands the results over.
-int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand, uint32_t n_hyp,
+int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, const int32_t* kd64, const double* fd64, uint32_t n_cand, uint32_t n_hyp,
                           uint32_t stream_base, uint64_t seed, int want_frame_costs, int want_best_h) {
     DeviceGuard dev_guard(c);
     c->pend = rship_ctx::Pend{};
+    c->pend_redo = rship_ctx::PendRedo{};
     if (!c->n_knots) return set_err(c, "no gyro spline uploaded");
     if (c->n_grp != 1) return set_err(c, "presync: the selection must not be grouped");
     const uint32_t ns = c->n_sel;
@@ -1409,7 +1463,47 @@ int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, uint
     p.frame_cost = (double*)c->frame_cost.p;
     p.best_h = want_best_h ? (int32_t*)c->best_h.p : nullptr;
     p.flags = (uint32_t*)c->flags.p;
+    // the near-static watch (kernels/lmeds.hpp, "fp64 rows"): a bit per (slot, candidate) for the pairs whose rows are too
+    // small for fp32 inputs; rship_presync_collect launches the fp64 form for them.  The candidates' delays split in fp64
+    // (kd64 / fd64; without them the fp32 split, widened) are kept on the host until then -- except where the selection
+    // holds frames of more than 8192 tracks, whose kernel takes the fp64 rows in place.
+    if (!c->no_fp64_rows && c->rays64.p && c->coef64.p) {
+        const uint32_t words = (n_cand + 31u) / 32u;
+        const size_t mask_bytes = (size_t)ns * words * 4;
+        const void* before = c->redo_mask.p;
+        const void* cnt_before = c->redo_count.p;
+        if (ensure(c, c->redo_mask, mask_bytes) || ensure(c, c->redo_count, 8)) return 1;
+        if (c->redo_mask.p != before || c->redo_dirty) {
+            RS_HIP(hipMemsetAsync(c->redo_mask.p, 0, c->redo_mask.cap, c->stream));
+            c->redo_dirty = false;
+        }
+        if (c->redo_count.p != cnt_before) RS_HIP(hipMemsetAsync(c->redo_count.p, 0, 8, c->stream));
+        c->h_kd64r.assign(n_cand, 0);
+        c->h_fd64r.assign(n_cand, 0.0);
+        for (uint32_t i = 0; i < n_cand; ++i) {
+            c->h_kd64r[i] = kd64 ? kd64[i] : kd[i];
+            c->h_fd64r[i] = fd64 ? fd64[i] : (double)fd[i];
+        }
+        p.redo_mask = (uint32_t*)c->redo_mask.p;
+        p.mask_words = words;
+        p.src64 = Rows64Src{rays64_of(c), (const d4*)c->coef64.p, (int)c->n_knots};
+        p.redo_count = (unsigned long long*)c->redo_count.p;
+        c->pend_redo.uploaded = false;
+        if (c->cls_off[5] != c->cls_off[6]) { // (frames of more than 8192 tracks: their kernel needs the fp64 delays now)
+            const size_t pad = (n_cand + 1) / 2 * 2;
+            if (ensure(c, c->redo_delays, pad * 4 + (size_t)n_cand * 8)) return 1;
+            RS_HIP(hipMemcpyAsync(c->redo_delays.p, c->h_kd64r.data(), (size_t)n_cand * 4, hipMemcpyHostToDevice, c->stream));
+            RS_HIP(hipMemcpyAsync((char*)c->redo_delays.p + pad * 4, c->h_fd64r.data(), (size_t)n_cand * 8, hipMemcpyHostToDevice, c->stream));
+            c->pend_redo.uploaded = true;
+            p.kd64 = (const int32_t*)c->redo_delays.p;
+            p.fd64 = (const double*)((const char*)c->redo_delays.p + pad * 4);
+        }
+        c->pend_redo.armed = true;
+        c->pend_redo.step_knots = step_knots;
+        c->pend_redo.chunk = chunk;
+    }
     if (launch_lmeds<0>(c, p, step_knots, chunk, &c->last_lmeds_cap, &c->last_lmeds_chunk)) return 1;
+    c->pend_redo.p = p;
     if (launch_plan_sum(c, p.frame_cost, n_cand, ns)) return 1;
     size_t end = 0;
     if (queue_sums_to_host(c, n_cand, 0, &c->pend.off_chunk, &end)) return 1;
@@ -1435,6 +1529,35 @@ int rship_presync_collect(rship_ctx* c, uint32_t n_cand, double* win_costs, doub
     if (n_cand != c->pend.rows) return set_err(c, "presync_collect: candidate count differs from the enqueue");
     if (sync_stream(c)) return 1;
     const uint32_t ns = c->n_sel;
+    {
+        // NEAR-STATIC pairs (kernels/lmeds.hpp, "fp64 rows"): the sweep has flagged (frame, candidate) pairs whose rows are
+        // too small for its fp32 inputs.  Their costs are recomputed from the fp64 streams by the R64 form of the same
+        // kernels, the sums are taken again, and only then does the caller see anything.  An ordinary scene never gets here.
+        uint32_t fl = 0;
+        memcpy(&fl, (char*)c->pinned + c->pend.off_flags, 4);
+        if ((fl & RSHIP_NEAR_STATIC) && c->pend_redo.armed) {
+            c->redo_dirty = true; // (until the fp64 launches have been enqueued: an error below leaves bits behind)
+            LmedsParams p = c->pend_redo.p;
+            const size_t pad = ((size_t)n_cand + 1) / 2 * 2;
+            if (!c->pend_redo.uploaded) {
+                if (ensure(c, c->redo_delays, pad * 4 + (size_t)n_cand * 8)) return 1;
+                RS_HIP(hipMemcpyAsync(c->redo_delays.p, c->h_kd64r.data(), (size_t)n_cand * 4, hipMemcpyHostToDevice, c->stream));
+                RS_HIP(hipMemcpyAsync((char*)c->redo_delays.p + pad * 4, c->h_fd64r.data(), (size_t)n_cand * 8, hipMemcpyHostToDevice, c->stream));
+            }
+            p.kd64 = (const int32_t*)c->redo_delays.p;
+            p.fd64 = (const double*)((const char*)c->redo_delays.p + pad * 4);
+            if (launch_lmeds_redo(c, p, c->pend_redo.step_knots, c->pend_redo.chunk)) return 1;
+            c->redo_dirty = false;
+            c->near_launches += 1;
+            if (launch_plan_sum(c, p.frame_cost, n_cand, ns)) return 1;
+            size_t end = 0;
+            if (queue_sums_to_host(c, n_cand, 0, &c->pend.off_chunk, &end)) return 1;
+            c->pend.off_flags = end;
+            RS_HIP(hipMemcpyAsync((char*)c->pinned + end, c->flags.p, 4, hipMemcpyDeviceToHost, c->stream));
+            if (sync_stream(c)) return 1;
+        }
+        c->pend_redo.armed = false;
+    }
     if (win_costs) memcpy(win_costs, c->pinned, (size_t)n_cand * c->plan_wins * 8);
     if (chunk_costs) memcpy(chunk_costs, (char*)c->pinned + c->pend.off_chunk, (size_t)n_cand * c->plan_chunks * 8);
     if (flags) memcpy(flags, (char*)c->pinned + c->pend.off_flags, 4);
@@ -2345,6 +2468,20 @@ int rship_window_info(rship_ctx* c, uint32_t out[8]) {
     return 0;
 }
 
+// out[0]: (frame, candidate) pairs of PreSync sweeps recomputed with fp64 rows so far (near-static frames: kernels/lmeds.hpp,
+// "fp64 rows"); out[1]: sweeps that went through the fp64 form.  Zero on ordinary scenes.
+int rship_near_static_stats(rship_ctx* c, uint64_t out[2]) {
+    DeviceGuard dev_guard(c);
+    out[0] = out[1] = 0;
+    if (c->redo_count.p) {
+        RS_HIP(hipStreamSynchronize(c->stream));
+        unsigned long long v = 0;
+        RS_HIP(hipMemcpy(&v, c->redo_count.p, 8, hipMemcpyDeviceToHost));
+        out[0] = v;
+    }
+    out[1] = c->near_launches;
+    return 0;
+}
 int rship_exec_stats(rship_ctx* c, uint32_t out[4]) {
     for (int i = 0; i < 4; ++i) out[i] = c->exec_last[i];
     return 0;

@@ -302,6 +302,17 @@ class SyncProblemHip final : public ISyncProblem {
         out[0] = out[1] = out[2] = out[3] = 0;
         if (shards_.size() == 1 && shards_[0].ctx) (void)rship_exec_stats(shards_[0].ctx, out);
     }
+    // (frame, candidate) pairs of PreSync sweeps recomputed with fp64 rows / sweeps that needed it, over this object's devices
+    void near_static_stats(uint64_t out[2]) {
+        out[0] = out[1] = 0;
+        for (Shard& sh : shards_)
+            if (sh.ctx) {
+                uint64_t v[2] = {0, 0};
+                (void)rship_near_static_stats(sh.ctx, v);
+                out[0] += v[0];
+                out[1] = std::max(out[1], v[1]);
+            }
+    }
     bool sync_exec(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl, const std::vector<double>& initial,
                    double search_center, double search_radius, int repeats, uint32_t stream_first, uint32_t stream_stride,
                    std::vector<double>& costs, std::vector<double>& delays_out);
@@ -1002,12 +1013,18 @@ void SyncProblemHip::sweep_windows(const std::vector<double>& delays, uint32_t s
     std::fill(out, out + n * W, 0.0);
     uint32_t flags = 0;
     if (ns && n) {
-        std::vector<int32_t> kd(n);
+        std::vector<int32_t> kd(n), kd64(n);
         std::vector<float> fd(n);
+        std::vector<double> fd64(n);
         for (size_t i = 0; i < n; ++i) {
             DelaySplit sp = split_delay(delays[i], fs_);
             kd[i] = sp.kd;
             fd[i] = sp.fd;
+            // ... and in full precision, for the pairs whose rows the sweep takes from the fp64 streams (near-static frames:
+            // the reference's arithmetic is double throughout, core_private.cpp:19-28,45-46)
+            DelaySplit64 sp64 = split_delay64(delays[i], fs_);
+            kd64[i] = sp64.kd;
+            fd64[i] = sp64.fd;
         }
         // the devices keep a [candidates][frames] fp64 matrix: sweep very long candidate lists in
         // slices (the sampler stream is the global candidate index, so slicing changes nothing)
@@ -1017,7 +1034,7 @@ void SyncProblemHip::sweep_windows(const std::vector<double>& delays, uint32_t s
         for (size_t b = 0; b < n; b += slice) {
             const size_t m = std::min(slice, n - b);
             for (Shard& sh : shards_) // every device starts its part ...
-                hip_check(sh, rship_presync_enqueue(sh.ctx, kd.data() + b, fd.data() + b, (uint32_t)m, 20 /* core_private.cpp:77 */,
+                hip_check(sh, rship_presync_enqueue(sh.ctx, kd.data() + b, fd.data() + b, kd64.data() + b, fd64.data() + b, (uint32_t)m, 20 /* core_private.cpp:77 */,
                                                     stream_base + (uint32_t)b, seed, frame_costs != nullptr, best_h != nullptr),
                           "presync");
             combine(m, W, [&](Shard& sh, double* win, double* chunk) { // ... and is waited for in turn
@@ -1833,6 +1850,15 @@ int rssync_ext_executor_stats(rssync_problem* p, uint64_t* runs, uint64_t* check
         if (runs) *runs = p->impl->executor_runs;
         if (checked) *checked = p->impl->executor_checked;
         if (queue) p->impl->executor_queue_stats(queue);
+    });
+}
+
+int rssync_ext_near_static_stats(rssync_problem* p, uint64_t* pairs, uint64_t* sweeps) {
+    return guarded([&] {
+        uint64_t v[2];
+        p->impl->near_static_stats(v);
+        if (pairs) *pairs = v[0];
+        if (sweeps) *sweeps = v[1];
     });
 }
 

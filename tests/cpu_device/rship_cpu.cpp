@@ -418,7 +418,7 @@ void plan_sum(rship_ctx* c, const std::vector<double>& in, uint32_t rows, size_t
 }
 } // namespace
 
-int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_cand, uint32_t n_hyp,
+int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, const int32_t* /*kd64*/, const double* /*fd64*/, uint32_t n_cand, uint32_t n_hyp,
                           uint32_t stream_base, uint64_t seed, int, int) {
     uint32_t fl = 0;
     c->pend_rows = 0;
@@ -703,6 +703,7 @@ int rship_loss_collect(rship_ctx* c, uint32_t n_delays, double* win_loss, double
 
 int rship_exec_supported(rship_ctx*) { return 0; } // the window executor is a device scheduler: nothing to stand in for
 int rship_exec_stats(rship_ctx*, uint32_t out[4]) { out[0] = out[1] = out[2] = out[3] = 0; return 0; }
+int rship_near_static_stats(rship_ctx*, uint64_t out[2]) { out[0] = out[1] = 0; return 0; } // (the stand-in's sweep is its own sequential fp32 search)
 int rship_window_info(rship_ctx*, uint32_t out[8]) { for (int i = 0; i < 8; ++i) out[i] = 0; return 0; }
 int rship_sync_exec(rship_ctx* c, const double*, int, uint32_t, uint32_t, uint64_t, int, double, double, double*, double*, int32_t*,
                     double*, uint32_t) {
