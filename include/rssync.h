@@ -47,10 +47,11 @@ class ISyncProblem {
     // interleaved, lens already undistorted) and the capture time of each ray's
     // image row.  Setting a frame again replaces it.
     // Any count, as in the reference (core_private.cpp:192-203), up to the indexing bound
-    // of 2^24 tracks per frame (rship_max_tracks() in rssync_hip.h).  Frames of more than
-    // 8192 tracks run slower, exact variants of the kernels -- a correctness path, not a tuned
-    // one -- and ONE such frame sends every frame of the problem through them (the kernel
-    // family follows the problem's largest frame: DESIGN.md section 3).
+    // of 2^24 tracks per frame (rship_max_tracks() in rssync_hip.h).  A frame's kernels follow
+    // from ITS OWN track count (size classes): up to 512 tracks one wave per
+    // frame, up to 8192 four waves; only the frames of more than 8192 tracks themselves run the
+    // slower, exact variants of the kernels -- a correctness path, not a tuned one -- whatever
+    // else the problem holds, and a frame's results do not depend on its neighbours.
     virtual void SetTrackResult(int64_t frame, const double* ts_a, const double* ts_b,
                                 const double* rays_a, const double* rays_b, size_t count) = 0;
     // Brute-force sweep of the delay over initial_delay +- search_radius in

@@ -60,3 +60,24 @@ def test_design_gyro_rate_table_is_the_committed_sweep():
             want.append("%.1f" % (1e3 * row["small_round4_window_rule_bounded"]["sync_points_s"]))
     missing = [w for w in want if w not in design]
     assert not missing, missing
+
+
+def test_public_headers_do_not_claim_what_size_classes_retired():
+    """Until round 5 the kernel family -- and with it a frame's bits -- followed the LARGEST frame of the whole problem: one
+    frame above 8192 tracks sent every frame through the slow exact kernels, one above 512 sent a clip out of the one-wave
+    kernels.  Since round 5 a frame's kernels follow its own track count (rssync_kernels.hip: class_of).  include/rssync.h
+    went on telling clients the old behaviour for a round; the public headers and INTEGRATION.md must not say
+    it again.  (`RSSYNC_EXEC_BIG_MAX` legitimately speaks of "windows whose largest frame": a policy of the window executor,
+    not a statement about which kernels a frame runs.)"""
+    import re
+    retired = [r"follows the problem'?s largest frame", r"sends every frame of the problem", r"kernel\s+family follows the (problem|largest)",
+               r"the largest frame of the (whole )?problem (decides|selects|chooses)"]
+    for name in ("include/rssync.h", "include/rssync_c.h", "include/rssync_hip.h", "INTEGRATION.md"):
+        text = re.sub(r"\s+", " ", open(os.path.join(ROOT, name)).read())
+        text = re.sub(r"//|/\*|\*/| \* ", " ", text)
+        text = re.sub(r"\s+", " ", text)
+        for pat in retired:
+            assert not re.search(pat, text, flags=re.I), (name, pat)
+    h = re.sub(r"\s+", " ", open(os.path.join(ROOT, "include", "rssync.h")).read().replace("//", " "))
+    h = re.sub(r"\s+", " ", h)
+    assert "follow from ITS OWN track count" in h and "do not depend on its neighbours" in h
