@@ -152,6 +152,13 @@ int rssync_ext_executor_stats(rssync_problem* p, uint64_t* runs, uint64_t* check
  * this object, *sweeps = sweeps (PreSync / DebugPreSync / curve calls, per slice) that needed it.  Both stay 0 on ordinary
  * footage; RSSYNC_NO_FP64_ROWS=1 (read when a problem is created) switches the mechanism off. */
 int rssync_ext_near_static_stats(rssync_problem* p, uint64_t* pairs, uint64_t* sweeps);
+/* TEST-VARIANTS build of the library only (the product returns an error): later PreSync-type sweeps also store the
+ * |residual| bit patterns the LMedS selection worked on; _get returns the last sweep's, [candidate][frame of the selection]
+ * [hypothesis][cap_rows] as uint32 (0xffffffff: no such row), dims = {candidates, frames, hypotheses, cap_rows} (out NULL:
+ * only the dims).  tests/test_gpu_fuzz.py: the winner is the exact arg-min of the lower quartile, first wins
+ * (core_private.cpp:48-56) -- asserted without a tolerance. */
+int rssync_ext_debug_residuals(rssync_problem* p, int on, uint32_t cap_rows);
+int rssync_ext_debug_residuals_get(rssync_problem* p, uint32_t* out, size_t n_words, uint32_t dims[4]);
 /* Diagnostics of the bit-exactness tests (tests/test_gpu_bitexact.py).  GuessMotion's 200-hypothesis search runs
  * in fp32 and leaves one winning hypothesis index per slot (window-major, frames ascending); with recording on,
  * the winners of the last Sync / sync_windows / sync_simplified call can be read back, and set_init_override

@@ -202,6 +202,13 @@ int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, cons
                           int want_best_h);
 int rship_presync_collect(rship_ctx* c, uint32_t n_cand, double* win_costs, double* chunk_costs,
                           uint32_t* flags, double* frame_costs, int32_t* best_h);
+/* TEST-VARIANTS build of the library only (tools/k2_build_variant.sh testvariants -DRSSYNC_TEST_VARIANTS=1; the product
+ * refuses): later sweeps also store the |residual| bit patterns they worked on, [candidate][slot][hypothesis][cap_rows]
+ * (0xffffffff: no such row); _get copies the last sweep's out (dims = {candidates, slots, hypotheses, cap_rows}; out may
+ * be NULL to ask for the dims).  The anchor of tests/test_gpu_fuzz.py: the winner must be the exact arg-min of the
+ * residuals' lower quartile with the reference's first-wins rule (core_private.cpp:48-56), no tolerance. */
+int rship_debug_residuals(rship_ctx* c, int on, uint32_t cap_rows);
+int rship_debug_residuals_get(rship_ctx* c, uint32_t* out, uint64_t n_words, uint32_t dims[4]);
 /* out[0] = (frame, candidate) pairs recomputed with fp64 rows so far on this context, out[1] = sweeps that needed it */
 int rship_near_static_stats(rship_ctx* c, uint64_t out[2]);
 

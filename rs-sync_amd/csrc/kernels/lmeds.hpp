@@ -82,6 +82,13 @@ struct LmedsParams {
     const int32_t* kd64;
     const double* fd64;
     unsigned long long* redo_count; // pairs recomputed in fp64 so far (debug ABI: rship_near_static_stats)
+    // ---- TEST-VARIANTS build only (-DRSSYNC_TEST_VARIANTS=1; the product's kernels have no such code) ----
+    // dump (or null): the |residual| bit patterns of the sweep itself, [candidate][slot][hypothesis][dump_rows] -- every
+    // hypothesis of every (frame, candidate) against the tile and the directions the selection worked on -- so that a test
+    // can demand, WITHOUT A TOLERANCE, that the winner is the exact arg-min of the sorted residuals' lower quartile with
+    // the reference's first-wins rule (core_private.cpp:48-56; tests/test_gpu_fuzz.py: the anchor under flip_interval)
+    uint32_t* dump;
+    uint32_t dump_rows;
 };
 
 // fp64 ROWS FOR NEAR-STATIC FRAMES (round 6).  The reference computes the rows of P, their norms and the safe_normalize
@@ -926,6 +933,26 @@ __global__ __launch_bounds__(kBlock, R64 ? 1 : (RPT == 16 ? (WIN == 1 ? 3 : 2) :
                 if (p.best_h) p.best_h[(size_t)c * p.n_sel + sf] = bH;
             }
         }
+#if RSSYNC_TEST_VARIANTS
+        if (MODE == 0 && p.dump) {
+            // every hypothesis against this thread's own rows of the tile, in sweep_tile's very expression (the packed
+            // form, so that the compiler contracts it into the same mul + fma + fma); s_hyp still holds the candidate's
+            // directions (n_hyp <= kHyp), and both are only rewritten after the next candidate's barriers
+            const uint32_t nh = p.n_hyp < (uint32_t)kHyp ? p.n_hyp : (uint32_t)kHyp;
+            for (uint32_t h = 0; h < nh; ++h) {
+                const f4 hv = s_hyp[h];
+                uint32_t* out = p.dump + (((size_t)c * p.n_sel + sf) * p.n_hyp + h) * p.dump_rows;
+#pragma unroll 1
+                for (int j = 0; j < RPT; ++j) {
+                    const uint32_t row = j * kBlock + tid;
+                    if (row < N && row < p.dump_rows) {
+                        const v2f r01 = v2f{tile.nx[row], 0.f} * hv.x + v2f{tile.ny[row], 0.f} * hv.y + v2f{tile.nz[row], 0.f} * hv.z;
+                        out[row] = __float_as_uint(r01.x) & 0x7fffffffu;
+                    }
+                }
+            }
+        }
+#endif
         if (bad) atomicOr(p.flags, bad);
         // No barrier here.  What the next candidate overwrites before its first barrier is (a) this
         // thread's own tile rows and (b) s_key, by thread 0: every reader of s_key reads it before

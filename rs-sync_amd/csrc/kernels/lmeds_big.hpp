@@ -104,6 +104,9 @@ __global__ __launch_bounds__(kBlock) void lmeds_big_kernel(LmedsParams p) {
                     const float r = fmaf(tile.nz[row], hv.z, fmaf(tile.ny[row], hv.y, tile.nx[row] * hv.x)); // :48, as sweep_tile
                     const uint32_t a = __float_as_uint(r) & 0x7fffffffu;
                     g_key[row] = a > kInfBits ? 0xffffffffu : a; // NaN never counts
+#if RSSYNC_TEST_VARIANTS
+                    if (MODE == 0 && p.dump && row < p.dump_rows) p.dump[(((size_t)c * p.n_sel + sf) * p.n_hyp + h) * p.dump_rows + row] = a;
+#endif
                 }
                 __syncthreads();
                 const uint32_t tot = count_lt(N, T);

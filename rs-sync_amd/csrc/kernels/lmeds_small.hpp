@@ -217,6 +217,16 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
                         r2[q] = __float_as_uint(r01.x);
                         if (q + 1 < RPT) r2[q + 1] = __float_as_uint(r01.y);
                     }
+#if RSSYNC_TEST_VARIANTS
+                    if (MODE == 0 && p.dump) { // (lmeds.hpp: LmedsParams::dump -- the residuals the selection below works on)
+                        uint32_t* out = p.dump + (((size_t)c * p.n_sel + sf) * p.n_hyp + (batch + j)) * p.dump_rows;
+#pragma unroll
+                        for (int q = 0; q < RPT; ++q) {
+                            const uint32_t row = q * 64 + lane;
+                            if (row < N && row < p.dump_rows) out[row] = r2[q] & 0x7fffffffu;
+                        }
+                    }
+#endif
                     // med < least_med (core_private.cpp:51-53): more than kq |residuals| below the best so far
                     uint32_t hi2 = T;
                     const uint32_t tot = wave_count_lt(r2, hi2);

@@ -178,6 +178,10 @@ struct rship_ctx {
     struct PendRedo { bool armed = false; LmedsParams p{}; double step_knots = 0; uint32_t chunk = 1; bool uploaded = false; } pend_redo;
     std::vector<int32_t> h_kd64r;
     std::vector<double> h_fd64r;
+    // TEST-VARIANTS build: the sweep's own residuals (kernels/lmeds.hpp: LmedsParams::dump) of the last rship_presync_enqueue
+    DevBuf dump;
+    bool dump_on = false;
+    uint32_t dump_rows = 0, dump_dims[4] = {0, 0, 0, 0};
     // scratch
     DevBuf kd, frame_cost, best_h, costs, part, flags, stats;
     void* pinned = nullptr;
@@ -972,7 +976,7 @@ void rship_destroy(rship_ctx* c) {
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     DevBuf* bufs[] = {&c->coef, &c->coef64, &c->raw, &c->rays_a, &c->rays_b, &c->rays64, &c->frames, &c->sel, &c->M, &c->k, &c->grp, &c->grp_off,
                       &c->plan_idx, &c->plan_chunk_off, &c->plan_win_off, &c->chunk_out, &c->win_out, &c->loop_state, &c->kd, &c->kd64, &c->init_h,
-                      &c->frame_cost, &c->best_h, &c->costs, &c->part, &c->flags, &c->stats, &c->redo_mask, &c->redo_delays, &c->redo_count,
+                      &c->frame_cost, &c->best_h, &c->costs, &c->part, &c->flags, &c->stats, &c->redo_mask, &c->redo_delays, &c->redo_count, &c->dump,
                       &c->big_scratch, &c->mo_scratch, &c->mo_evals, &c->mo_order,
                       &c->g_ts, &c->g_rates, &c->g_us, &c->g_dq, &c->g_q, &c->g_knots, &c->g_cf, &c->g_status};
     for (DevBuf* b : bufs)
@@ -1501,6 +1505,18 @@ int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, cons
         c->pend_redo.armed = true;
         c->pend_redo.step_knots = step_knots;
         c->pend_redo.chunk = chunk;
+    }
+    if (c->dump_on) { // (TEST-VARIANTS build: rship_debug_residuals) -- the fp32 sweep's own residuals; no fp64 form of any pair
+        const uint64_t words = (uint64_t)n_cand * ns * n_hyp * c->dump_rows;
+        if (words > ((uint64_t)3 << 30) / 4) return set_err(c, "debug_residuals: more than 3 GB of residuals: sweep fewer candidates per call");
+        if (ensure(c, c->dump, (size_t)words * 4)) return 1;
+        RS_HIP(hipMemsetAsync(c->dump.p, 0xff, (size_t)words * 4, c->stream));
+        p.dump = (uint32_t*)c->dump.p;
+        p.dump_rows = c->dump_rows;
+        p.redo_mask = nullptr;
+        p.src64.coef = nullptr;
+        c->pend_redo.armed = false;
+        c->dump_dims[0] = n_cand; c->dump_dims[1] = ns; c->dump_dims[2] = n_hyp; c->dump_dims[3] = c->dump_rows;
     }
     if (launch_lmeds<0>(c, p, step_knots, chunk, &c->last_lmeds_cap, &c->last_lmeds_chunk)) return 1;
     c->pend_redo.p = p;
@@ -2468,6 +2484,30 @@ int rship_window_info(rship_ctx* c, uint32_t out[8]) {
     return 0;
 }
 
+// TEST-VARIANTS build only: every later rship_presync_enqueue also stores the |residual| bit patterns of its sweep --
+// [candidate][slot][hypothesis][cap_rows], 0xffffffff where there is no row -- for rship_debug_residuals_get (after the
+// collect).  The product build has no such code in its kernels and refuses.
+int rship_debug_residuals(rship_ctx* c, int on, uint32_t cap_rows) {
+#if RSSYNC_TEST_VARIANTS
+    if (on && !cap_rows) return set_err(c, "debug_residuals: cap_rows must be positive");
+    c->dump_on = on != 0;
+    c->dump_rows = cap_rows;
+    return 0;
+#else
+    (void)on; (void)cap_rows;
+    return set_err(c, "debug_residuals: only in the test-variants build (-DRSSYNC_TEST_VARIANTS=1)");
+#endif
+}
+int rship_debug_residuals_get(rship_ctx* c, uint32_t* out, uint64_t n_words, uint32_t dims[4]) {
+    DeviceGuard dev_guard(c);
+    for (int i = 0; i < 4; ++i) dims[i] = c->dump_dims[i];
+    const uint64_t have = (uint64_t)c->dump_dims[0] * c->dump_dims[1] * c->dump_dims[2] * c->dump_dims[3];
+    if (!out) return 0;
+    if (!have || n_words < have || !c->dump.p) return set_err(c, "debug_residuals_get: nothing stored, or the buffer is too small");
+    RS_HIP(hipStreamSynchronize(c->stream));
+    RS_HIP(hipMemcpy(out, c->dump.p, (size_t)have * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
 // out[0]: (frame, candidate) pairs of PreSync sweeps recomputed with fp64 rows so far (near-static frames: kernels/lmeds.hpp,
 // "fp64 rows"); out[1]: sweeps that went through the fp64 form.  Zero on ordinary scenes.
 int rship_near_static_stats(rship_ctx* c, uint64_t out[2]) {

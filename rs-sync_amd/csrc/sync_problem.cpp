@@ -302,6 +302,16 @@ class SyncProblemHip final : public ISyncProblem {
         out[0] = out[1] = out[2] = out[3] = 0;
         if (shards_.size() == 1 && shards_[0].ctx) (void)rship_exec_stats(shards_[0].ctx, out);
     }
+    // TEST-VARIANTS build of the library: the sweep's own residuals (rssync_hip.h: rship_debug_residuals); one device only
+    void debug_residuals(int on, uint32_t cap_rows) {
+        ensure_device();
+        if (shards_.size() != 1) panic("debug_residuals: one device only");
+        hip_check(shards_[0], rship_debug_residuals(shards_[0].ctx, on, cap_rows), "debug_residuals");
+    }
+    void debug_residuals_get(uint32_t* out, size_t n_words, uint32_t dims[4]) {
+        if (shards_.size() != 1) panic("debug_residuals: one device only");
+        hip_check(shards_[0], rship_debug_residuals_get(shards_[0].ctx, out, n_words, dims), "debug_residuals_get");
+    }
     // (frame, candidate) pairs of PreSync sweeps recomputed with fp64 rows / sweeps that needed it, over this object's devices
     void near_static_stats(uint64_t out[2]) {
         out[0] = out[1] = 0;
@@ -1851,6 +1861,13 @@ int rssync_ext_executor_stats(rssync_problem* p, uint64_t* runs, uint64_t* check
         if (checked) *checked = p->impl->executor_checked;
         if (queue) p->impl->executor_queue_stats(queue);
     });
+}
+
+int rssync_ext_debug_residuals(rssync_problem* p, int on, uint32_t cap_rows) {
+    return guarded([&] { p->impl->debug_residuals(on, cap_rows); });
+}
+int rssync_ext_debug_residuals_get(rssync_problem* p, uint32_t* out, size_t n_words, uint32_t dims[4]) {
+    return guarded([&] { p->impl->debug_residuals_get(out, n_words, dims); });
 }
 
 int rssync_ext_near_static_stats(rssync_problem* p, uint64_t* pairs, uint64_t* sweeps) {

@@ -68,6 +68,8 @@ SIGNATURES = {
     "rssync_ext_set_executor_check_every": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rssync_ext_executor_stats": (C.c_int, [C.c_void_p, _PU64, _PU64, C.POINTER(C.c_uint32)]),
     "rssync_ext_near_static_stats": (C.c_int, [C.c_void_p, _PU64, _PU64]),
+    "rssync_ext_debug_residuals": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
+    "rssync_ext_debug_residuals_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_uint32)]),
     "rssync_ext_record_init_winners": (C.c_int, [C.c_void_p, C.c_int]),
     "rssync_ext_last_init_winners": (C.c_int, [C.c_void_p, _PI32, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rssync_ext_set_init_override": (C.c_int, [C.c_void_p, _PI32, C.c_size_t]),
@@ -337,6 +339,18 @@ class SyncProblem:
         runs, chk, q = C.c_uint64(), C.c_uint64(), (C.c_uint32 * 4)()
         self._check(self._lib.rssync_ext_executor_stats(self._h, C.byref(runs), C.byref(chk), q))
         return dict(runs=runs.value, checked=chk.value, head=q[0], tail=q[1], ring_cells=q[2], waves=q[3])
+
+    def debug_residuals(self, on=True, cap_rows=0):
+        """TEST-VARIANTS build only: later sweeps also store the |residuals| their LMedS selection worked on"""
+        self._check(self._lib.rssync_ext_debug_residuals(self._h, 1 if on else 0, int(cap_rows)))
+
+    def debug_residuals_get(self):
+        """-> float32 [candidates][frames][hypotheses][cap_rows] of the last sweep (NaN where there is no row)"""
+        dims = (C.c_uint32 * 4)()
+        self._check(self._lib.rssync_ext_debug_residuals_get(self._h, None, 0, dims))
+        out = np.zeros(tuple(int(x) for x in dims), dtype=np.uint32)
+        self._check(self._lib.rssync_ext_debug_residuals_get(self._h, _p(out, C.POINTER(C.c_uint32)), out.size, dims))
+        return out.view(np.float32)
 
     def near_static_stats(self):
         """-> dict(pairs, sweeps): (frame, candidate) pairs of PreSync sweeps recomputed with fp64 rows so far (near-static

@@ -45,6 +45,23 @@ def hosttest_lib(built):
 
 
 @pytest.fixture(scope="session")
+def variants_lib(built):
+    """The TEST-VARIANTS build of the library (the product's sources with -DRSSYNC_TEST_VARIANTS=1: round 2's exact
+    selection kernels, the sweep's residual dump), built when missing or older than the sources -- build() does the same,
+    so a GPU box that receives the tree finds it ready."""
+    import ctypes
+    import subprocess
+    from rssync_amd.problem import bind
+    out = os.path.join(ROOT, "rs-sync_amd", "_variants", "lib_testvariants.so")
+    src_dir = os.path.join(ROOT, "rs-sync_amd", "csrc")
+    deps = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".hpp", ".cpp"))]
+    deps += [os.path.join(src_dir, "kernels", f) for f in os.listdir(os.path.join(src_dir, "kernels"))]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["bash", os.path.join(ROOT, "tools", "k2_build_variant.sh"), "testvariants", "-DRSSYNC_TEST_VARIANTS=1"])
+    return bind(ctypes.CDLL(out))
+
+
+@pytest.fixture(scope="session")
 def small_case(built):
     """64 frames x 256 tracks, 400 Hz gyro (BASELINE config 1), noise + 10 % outliers."""
     from rssync_amd import synth

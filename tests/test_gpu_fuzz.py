@@ -164,6 +164,61 @@ def test_random_noisy_case(seed):
         assert Gh[0] == pytest.approx(G, rel=1e-9, abs=1e-9 * abs(L))
 
 
+def exact_winners(res, counts):
+    """core_private.cpp:48-56 on the device's OWN residuals: res [candidates][frames][hypotheses][rows] of |r| (float32);
+    per (candidate, frame) the hypothesis whose sorted residuals' element at index N / 4 is smallest, the first of equals
+    (strict <).  |r| orders like the r^2 the reference sorts.  -> int32 [candidates][frames]"""
+    C_, F_, H_, _ = res.shape
+    out = np.full((C_, F_), -1, dtype=np.int32)
+    for j, n in enumerate(counts):
+        r = res[:, j, :, :n]                                        # [C][H][n]
+        q = np.partition(r, n // 4, axis=2)[:, :, n // 4]           # the element std::sort would leave at index n / 4
+        q = np.where(np.isnan(q), np.inf, q)
+        win = np.argmin(q, axis=1)                                  # first minimum
+        out[:, j] = np.where(np.isfinite(q[np.arange(C_), win]), win, -1)
+    return out
+
+
+@pytest.mark.parametrize("seed", range(300, 306 + EXTRA))
+def test_the_winner_is_the_exact_argmin_of_the_devices_own_residuals(seed, variants_lib):
+    """THE TOLERANCE-FREE ANCHOR under the flip check (a check that grows a term per failure ends up explaining
+    anything).  flip_interval() above explains device-vs-fp64 differences with the fp32 rows' conditioning; it says nothing
+    about whether the device's selection is RIGHT on its own numbers.  This does, exactly: the TEST-VARIANTS build of the
+    library dumps the |residuals| its sweep worked on -- every hypothesis of every (frame, candidate), from the same tile
+    and the same directions -- and for EVERY pair of the case the kernel's winner must be the exact arg-min of the
+    residuals' lower quartile (np.partition on the device's own floats) with the reference's first-wins rule
+    (core_private.cpp:48-56): lazy brackets, provisional bounds, contenders, early rejection, the one-wave kernels'
+    sequential search and the large-frame kernels' bisection included -- assert_array_equal, no tolerance.  And the PRODUCT
+    library (no dump code in its kernels) must return the same winners as the variants build (and its costs to fp32 rounding)."""
+    rng, g, frames, counts = draw_case(seed, clean=bool(seed % 3 == 0))
+    ids = [fr[0] for fr in frames]
+    lo, hi = ids[0], ids[-1] + 1
+    step = float(rng.choice([0.0005, 0.001, 0.002]))
+    radius = float(rng.uniform(0.004, 0.02))                         # <= 80 candidates: the dump stays below a few hundred MB
+    centre = synth.D_TRUE + float(rng.uniform(-0.01, 0.01))
+    nf = len(frames)
+    v = rssync_amd.SyncProblem(seed=seed, verbose=False, _lib=variants_lib)
+    hprod = rssync_amd.SyncProblem(seed=seed, verbose=False)
+    for p in (v, hprod):
+        p.SetGyroQuaternions(g.quats, g.fs, g.t0)
+        for fr in frames:
+            p.SetTrackResult(*fr)
+    v.debug_residuals(True, cap_rows=max(counts))
+    dv, cv, fcv, bhv = v.presync_curve(centre, lo, hi, step, radius, per_frame=nf)
+    res = v.debug_residuals_get()
+    assert res.shape == (len(dv), nf, 20, max(counts))
+    for j, n in enumerate(counts):                                   # every row of every frame was written, nothing beyond
+        assert not np.isnan(res[:, j, :, :n]).any() and np.isnan(res[:, j, :, n:]).all()
+    np.testing.assert_array_equal(bhv, exact_winners(res, counts))
+    dp, cp, fcp, bhp = hprod.presync_curve(centre, lo, hi, step, radius, per_frame=nf)
+    np.testing.assert_array_equal(bhp, bhv)
+    # (the costs agree to fp32 rounding, not bit for bit: stage D is fp32 code under -ffp-contract=fast, and the variants
+    # build's kernels -- the dump's loop follows stage D -- are scheduled and contracted differently: 7e-8 on 1 of 490 here)
+    np.testing.assert_allclose(fcp, fcv, rtol=1e-6)
+    with pytest.raises(rssync_amd.RsSyncError):                      # the product has no such code
+        hprod.debug_residuals(True, cap_rows=8)
+
+
 @pytest.mark.parametrize("seed", range(100, 106 + EXTRA))
 def test_random_clean_case_sync(seed):
     """without noise the minimum is sharp and Sync is not chaotic: both sides end at the true delay"""

@@ -19,16 +19,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def variants_lib(built):
-    from rssync_amd.problem import bind
-    out = os.path.join(ROOT, "rs-sync_amd", "_variants", "lib_testvariants.so")
-    src_dir = os.path.join(ROOT, "rs-sync_amd", "csrc")
-    deps = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".hpp", ".cpp"))]
-    deps += [os.path.join(src_dir, "kernels", f) for f in os.listdir(os.path.join(src_dir, "kernels"))]
-    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.check_call(["bash", os.path.join(ROOT, "tools", "k2_build_variant.sh"), "testvariants", "-DRSSYNC_TEST_VARIANTS=1"])
-    return bind(ctypes.CDLL(out))
+# (the `variants_lib` fixture: tests/conftest.py)
 
 
 def test_the_product_build_refuses_the_variant_switch(built, monkeypatch):

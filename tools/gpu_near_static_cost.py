@@ -57,5 +57,26 @@ for name, gyro, translation, noise in (("ordinary", g0, 0.05, 1e-3), ("slow_pan"
         res[mode] = {"presync_wall_ms": round(wall * 1e3, 3), "lmeds_kernel_ms_per_call": round(prof["lmeds"][1] / reps, 3),
                      "lmeds_launches_per_call": prof["lmeds"][0] / reps, "fp64_pairs_per_call": st["pairs"] / (reps + 1),
                      "share_of_pairs": st["pairs"] / (reps + 1) / (F * 800), "delay": r[1], "cost": r[0]}
-    out["cases"].append({"footage": name, "translation_m": translation, **res})
+    # the same sweep on the first FO frames against the oracle (fp64 throughout): which delay, how close the minimum's cost
+    FO = min(F, 48)
+    from oracle.oracle import OracleProblem
+    o = OracleProblem(seed=11, threads=min(os.cpu_count() or 1, 16), faithful=False)
+    o.SetGyroQuaternions(gyro.quats, gyro.fs, gyro.t0)
+    for fr in synth.make_frames(gyro, 0, FO, N, seed=5, noise=noise, outliers=0.1, translation=translation):
+        o.SetTrackResult(*fr)
+    ro = o.PreSync(0.0, 0, FO, 0.0005, 0.2)
+    chk = {"frames": FO, "oracle": {"delay": ro[1], "cost": ro[0]}}
+    for mode in ("fp64_rows", "fp32_rows_only"):
+        if mode == "fp32_rows_only":
+            os.environ["RSSYNC_NO_FP64_ROWS"] = "1"
+        try:
+            p = rssync_amd.SyncProblem(seed=11)
+        finally:
+            os.environ.pop("RSSYNC_NO_FP64_ROWS", None)
+        p.SetGyroQuaternions(gyro.quats, gyro.fs, gyro.t0)
+        for fr in synth.make_frames(gyro, 0, FO, N, seed=5, noise=noise, outliers=0.1, translation=translation):
+            p.SetTrackResult(*fr)
+        rh = p.PreSync(0.0, 0, FO, 0.0005, 0.2)
+        chk[mode] = {"delay": rh[1], "cost": rh[0], "same_delay": bool(rh[1] == ro[1]), "cost_rel": abs(rh[0] - ro[0]) / abs(ro[0])}
+    out["cases"].append({"footage": name, "translation_m": translation, **res, "against_the_oracle": chk})
 print(json.dumps(out, indent=1))
