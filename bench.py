@@ -466,6 +466,16 @@ def run(args):
                      "note": "set_track_result_s = the SetTrackResult loop over all frames (checks + copy into pinned "
                              "staging, upload started); pack_upload_s = waiting for that upload + packing kernel"},
         }
+        if c5:
+            # one pipeline per sweep (round 6): every orientation's integrate -> resample -> spline -> sweep -> sums enqueued
+            # back to back, one wait, one exchange.  wall_ms against the kernels' own time (HIP events) per orientation
+            n_or = len(orient_names)
+            k_ms = sum(v[1] for v in prof.values()) / max(args.steps, 1) / n_or
+            out["per_orientation"] = {"orientations": n_or, "wall_ms": round(elapsed / args.steps * 1e3 / n_or, 4), "kernels_ms": round(k_ms, 4),
+                                      "host_overhead_ms": round(elapsed / args.steps * 1e3 / n_or - k_ms, 4),
+                                      "pipeline": os.environ.get("RSSYNC_SWEEP_PIPELINE", "1") != "0",
+                                      "note": "kernels_ms = all kernels of the sweep (gyro pipeline, LMedS sweep, sums) by HIP events / orientations; "
+                                              "RSSYNC_SWEEP_PIPELINE=0 = rounds 1-5's loop (a blocking PreSync and exchange per orientation)"}
         if rehearsal:
             out["rehearsal"] = "CPU stand-in for the device ABI (%s): launcher and exchange logic only, value is NOT a " \
                                "measurement" % os.path.basename(args.rehearse_cpu)

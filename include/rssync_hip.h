@@ -129,6 +129,13 @@ int rship_gyro_uniform(rship_ctx* c, const double* quats, uint32_t n, double sam
 int rship_gyro_timestamped(rship_ctx* c, const int64_t* ts_us, const double* quats, uint32_t n, rship_gyro_result* out);
 int rship_gyro_rates_upload(rship_ctx* c, const double* ts_s, const double* rates, uint32_t n);
 int rship_gyro_rates_integrate(rship_ctx* c, const int32_t axis[3], const double sign[3], rship_gyro_result* out);
+/* rship_gyro_rates_integrate without waiting, for a BATCH of orientations (rship_presync_batch_begin): the kernels are
+ * enqueued -- the table they build is the one the next enqueued sweep reads --, *out is the grid (a function of the end
+ * timestamps alone; status = what the HOST can tell), and what the device has to complain about (non-finite input, a
+ * non-finite knot) goes to status record `slot` (1 .. 255); rship_gyro_batch_status(n, status[n]) reads records 1 .. n
+ * after the batch has been collected: status[i] as rship_gyro_rates_integrate would have returned it. */
+int rship_gyro_rates_integrate_enqueue(rship_ctx* c, const int32_t axis[3], const double sign[3], uint32_t slot, rship_gyro_result* out);
+int rship_gyro_batch_status(rship_ctx* c, uint32_t n, int32_t* status);
 /* read back: the knots [n_knots][4] / the fp64 table [n_knots][16] (tests, rssync_ext_gyro_knots) */
 int rship_gyro_knots(rship_ctx* c, double* out, uint32_t cap_knots);
 int rship_gyro_table(rship_ctx* c, double* out16, uint32_t cap_knots);
@@ -202,6 +209,14 @@ int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, cons
                           int want_best_h);
 int rship_presync_collect(rship_ctx* c, uint32_t n_cand, double* win_costs, double* chunk_costs,
                           uint32_t* flags, double* frame_costs, int32_t* best_h);
+/* A BATCH of n sweeps over the same candidates, selection and plan, collected together -- the orientation sweep of the
+ * reference's driver (core_testcode.cpp:216-224; BASELINE config 5), where between two sweeps only the gyro table changes
+ * (rship_gyro_rates_integrate_enqueue).  After _begin the next n rship_presync_enqueue calls keep their sums in slots
+ * 0 .. n-1 and nothing is waited for; _collect waits ONCE: win_costs[n][n_cand][n_win], chunk_costs[n][n_cand][n_chunks]
+ * (either may be NULL), flags[n].  A sweep whose flags carry RSHIP_NEAR_STATIC has not had its near-static pairs
+ * recomputed from the fp64 streams (that needs the host between two launches): the caller repeats that sweep alone. */
+int rship_presync_batch_begin(rship_ctx* c, uint32_t n, uint32_t n_cand);
+int rship_presync_batch_collect(rship_ctx* c, uint32_t n_cand, double* win_costs, double* chunk_costs, uint32_t* flags);
 /* TEST-VARIANTS build of the library only (tools/k2_build_variant.sh testvariants -DRSSYNC_TEST_VARIANTS=1; the product
  * refuses): later sweeps also store the |residual| bit patterns they worked on, [candidate][slot][hypothesis][cap_rows]
  * (0xffffffff: no such row); _get copies the last sweep's out (dims = {candidates, slots, hypotheses, cap_rows}; out may

@@ -178,6 +178,10 @@ struct rship_ctx {
     struct PendRedo { bool armed = false; LmedsParams p{}; double step_knots = 0; uint32_t chunk = 1; bool uploaded = false; } pend_redo;
     std::vector<int32_t> h_kd64r;
     std::vector<double> h_fd64r;
+    // A BATCH of sweeps collected together (rship_presync_batch_begin: the orientation sweep, BASELINE config 5): the results
+    // of sweep b of n go to slot b of the (n times larger) sum / flag buffers, nothing is waited for in between
+    uint32_t batch_n = 0, batch_next = 0, batch_rows = 0;
+    size_t batch_chunk_stride = 0, batch_win_stride = 0; // doubles per slot in chunk_out / win_out
     // TEST-VARIANTS build: the sweep's own residuals (kernels/lmeds.hpp: LmedsParams::dump) of the last rship_presync_enqueue
     DevBuf dump;
     bool dump_on = false;
@@ -763,15 +767,17 @@ int launch_motion64(rship_ctx* c, const Motion64Params& p_in, hipStream_t st = n
 }
 
 // rows x (chunk sums, window sums) of in[rows][cols] under the current plan, into c->chunk_out / c->win_out
-int launch_plan_sum(rship_ctx* c, const double* in, uint32_t rows, uint32_t cols) {
+// (slot b of n_slots: a batch of sweeps keeps its sums side by side -- rship_presync_batch_begin)
+int launch_plan_sum(rship_ctx* c, const double* in, uint32_t rows, uint32_t cols, uint32_t slot = 0, uint32_t n_slots = 1) {
     if (!c->plan_wins) return set_err(c, "no reduction plan set");
-    if (ensure(c, c->chunk_out, (size_t)rows * (c->plan_chunks + 1) * 8) || ensure(c, c->win_out, (size_t)rows * c->plan_wins * 8))
-        return 1;
+    const size_t cs = (size_t)rows * (c->plan_chunks + 1), ws = (size_t)rows * c->plan_wins;
+    if (n_slots > 1 && (c->chunk_out.cap < cs * n_slots * 8 || c->win_out.cap < ws * n_slots * 8)) return set_err(c, "plan sum: the batch's buffers were not sized");
+    if (n_slots == 1 && (ensure(c, c->chunk_out, cs * 8) || ensure(c, c->win_out, ws * 8))) return 1;
     ProfScope ps(c, RSHIP_K_REDUCE);
     hipLaunchKernelGGL(plan_sum_kernel, dim3(rows * c->plan_wins), dim3(64), 0, c->stream, in, cols,
                        c->plan_has_idx ? (const uint32_t*)c->plan_idx.p : nullptr, (const uint32_t*)c->plan_chunk_off.p,
-                       c->plan_chunks, (const uint32_t*)c->plan_win_off.p, c->plan_wins, (double*)c->chunk_out.p,
-                       (double*)c->win_out.p);
+                       c->plan_chunks, (const uint32_t*)c->plan_win_off.p, c->plan_wins, (double*)c->chunk_out.p + cs * slot,
+                       (double*)c->win_out.p + ws * slot);
     RS_HIP(hipGetLastError());
     return 0;
 }
@@ -1051,10 +1057,31 @@ int spline_from_knots(rship_ctx* c, uint32_t n, double sample_rate) {
 }
 
 // shared tail of the two timestamped routes: order check done, ts (us) and quats on the device
+// what the host makes of a status record (the reference's order of complaints, core_private.cpp:156-184)
+int gyro_status_to_result(rship_ctx* c, const GyroStatus* h, int grid_status, const int64_t* d_ts, rship_gyro_result* out) {
+    out->status = RSHIP_GYRO_OK;
+    if (h->bad_input) out->status = RSHIP_GYRO_BAD_INPUT;
+    else if (grid_status == RSHIP_GYRO_BAD_RATE || grid_status == RSHIP_GYRO_TOO_LARGE) out->status = grid_status;
+    else if (h->out_of_order != kNoIndex) {
+        int64_t pair[2];
+        out->status = RSHIP_GYRO_OUT_OF_ORDER;
+        out->bad_pos = h->out_of_order;
+        RS_HIP(hipMemcpy(pair, d_ts + (h->out_of_order - 1), 16, hipMemcpyDeviceToHost));
+        out->bad_a = pair[0];
+        out->bad_b = pair[1];
+    } else if (grid_status != RSHIP_GYRO_OK) out->status = grid_status;
+    else if (h->bad_knot) out->status = RSHIP_GYRO_BAD_KNOT;
+    else if (!std::isfinite(out->fs)) out->status = RSHIP_GYRO_BAD_RATE;
+    else if (!std::isfinite(out->start)) out->status = RSHIP_GYRO_BAD_START;
+    return 0;
+}
+
+// status_slot: which record of g_status the kernels report into; wait = false: nothing is read back (a batch of
+// orientations: rship_gyro_rates_integrate_enqueue, the records are looked at by rship_gyro_batch_status)
 int resample_and_solve(rship_ctx* c, const int64_t* d_ts, const double* d_quats, uint32_t n, int64_t first, int64_t last,
-                       rship_gyro_result* out) {
+                       rship_gyro_result* out, uint32_t status_slot = 0, bool wait = true) {
     const int grid_status = rs::grid_of(first, last, n, kMaxKnots, out);
-    GyroStatus* st = (GyroStatus*)c->g_status.p;
+    GyroStatus* st = (GyroStatus*)c->g_status.p + status_slot;
     const bool have_grid = grid_status == RSHIP_GYRO_OK;
     if (have_grid) {
         if (ensure(c, c->g_knots, (size_t)out->n_knots * 32)) return 1;
@@ -1068,25 +1095,17 @@ int resample_and_solve(rship_ctx* c, const int64_t* d_ts, const double* d_quats,
         RS_HIP(hipGetLastError());
         if (spline_from_knots(c, out->n_knots, out->fs)) return 1;
     }
+    if (!wait) {
+        out->status = grid_status == RSHIP_GYRO_OK ? RSHIP_GYRO_OK : grid_status; // (the device's flags: rship_gyro_batch_status)
+        return 0;
+    }
     // one look at the status; the reference's order of complaints (core_private.cpp:156-184)
     if (ensure_pinned(c, 64)) return 1;
     GyroStatus* h = (GyroStatus*)c->pinned;
-    int64_t* h_pair = (int64_t*)((char*)c->pinned + 32);
     RS_HIP(hipMemcpyAsync(h, st, sizeof(GyroStatus), hipMemcpyDeviceToHost, c->stream));
     if (sync_stream(c)) return 1;
-    out->status = RSHIP_GYRO_OK;
-    if (h->bad_input) out->status = RSHIP_GYRO_BAD_INPUT;
-    else if (grid_status == RSHIP_GYRO_BAD_RATE || grid_status == RSHIP_GYRO_TOO_LARGE) out->status = grid_status;
-    else if (h->out_of_order != kNoIndex) {
-        out->status = RSHIP_GYRO_OUT_OF_ORDER;
-        out->bad_pos = h->out_of_order;
-        RS_HIP(hipMemcpy(h_pair, d_ts + (h->out_of_order - 1), 16, hipMemcpyDeviceToHost));
-        out->bad_a = h_pair[0];
-        out->bad_b = h_pair[1];
-    } else if (grid_status != RSHIP_GYRO_OK) out->status = grid_status;
-    else if (h->bad_knot) out->status = RSHIP_GYRO_BAD_KNOT;
-    else if (!std::isfinite(out->fs)) out->status = RSHIP_GYRO_BAD_RATE;
-    else if (!std::isfinite(out->start)) out->status = RSHIP_GYRO_BAD_START;
+    const GyroStatus hs = *h;
+    if (gyro_status_to_result(c, &hs, grid_status, d_ts, out)) return 1;
     if (out->status != RSHIP_GYRO_OK) c->n_knots = 0; // whatever was built is not a table to sweep over
     return 0;
 }
@@ -1106,7 +1125,7 @@ int rship_gyro_uniform(rship_ctx* c, const double* quats, uint32_t n, double sam
 int rship_gyro_timestamped(rship_ctx* c, const int64_t* ts_us, const double* quats, uint32_t n, rship_gyro_result* out) {
     DeviceGuard dev_guard(c);
     if (n < 2) return set_err(c, "gyro: need >= 2 samples");
-    if (ensure(c, c->g_us, (size_t)n * 8) || ensure(c, c->g_q, (size_t)n * 32) || ensure(c, c->g_status, sizeof(GyroStatus))) return 1;
+    if (ensure(c, c->g_us, (size_t)n * 8) || ensure(c, c->g_q, (size_t)n * 32) || ensure(c, c->g_status, sizeof(GyroStatus) * 256)) return 1;
     RS_HIP(hipMemcpyAsync(c->g_us.p, ts_us, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipMemcpyAsync(c->g_q.p, quats, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
     {
@@ -1133,18 +1152,51 @@ int rship_gyro_rates_upload(rship_ctx* c, const double* ts_s, const double* rate
     return 0;
 }
 
+namespace {
+constexpr uint32_t kGyroStatusSlots = 256; // records of g_status: slot 0 for the plain calls, 1 .. for a batch of orientations
+int gyro_rates_integrate(rship_ctx* c, const int32_t axis[3], const double sign[3], rship_gyro_result* out, uint32_t status_slot, bool wait);
+} // namespace
 int rship_gyro_rates_integrate(rship_ctx* c, const int32_t axis[3], const double sign[3], rship_gyro_result* out) {
     DeviceGuard dev_guard(c);
+    return gyro_rates_integrate(c, axis, sign, out, 0, true);
+}
+// The same without waiting: the kernels are enqueued, the table they build is the one the NEXT enqueued sweep reads, and
+// the device's complaints (non-finite input, a non-finite knot) go to status record `slot` (1 .. 255), to be looked at by
+// rship_gyro_batch_status after the batch has been collected.  out: the grid (a function of the end timestamps alone).
+int rship_gyro_rates_integrate_enqueue(rship_ctx* c, const int32_t axis[3], const double sign[3], uint32_t slot, rship_gyro_result* out) {
+    DeviceGuard dev_guard(c);
+    if (!slot || slot >= kGyroStatusSlots) return set_err(c, "gyro: status slot out of range");
+    return gyro_rates_integrate(c, axis, sign, out, slot, false);
+}
+// statuses of the slots 1 .. n of a batch (after the stream has been waited for): out[i].status as rship_gyro_rates_integrate
+// would have reported it for the (i + 1)-th enqueued orientation
+int rship_gyro_batch_status(rship_ctx* c, uint32_t n, int32_t* status) {
+    DeviceGuard dev_guard(c);
+    if (n >= kGyroStatusSlots) return set_err(c, "gyro: too many status slots");
+    if (!n) return 0;
+    std::vector<GyroStatus> h(n);
+    RS_HIP(hipStreamSynchronize(c->stream));
+    RS_HIP(hipMemcpy(h.data(), (const GyroStatus*)c->g_status.p + 1, (size_t)n * sizeof(GyroStatus), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i) {
+        rship_gyro_result r{};
+        const int grid_status = rs::grid_of(c->g_first_us, c->g_last_us, c->g_n, kMaxKnots, &r);
+        if (gyro_status_to_result(c, &h[i], grid_status, (const int64_t*)c->g_us.p, &r)) return 1;
+        status[i] = r.status;
+    }
+    return 0;
+}
+namespace {
+int gyro_rates_integrate(rship_ctx* c, const int32_t axis[3], const double sign[3], rship_gyro_result* out, uint32_t status_slot, bool wait) {
     const uint32_t n = c->g_n;
     if (n < 2) return set_err(c, "gyro: no rates uploaded");
     for (int k = 0; k < 3; ++k)
         if (axis[k] < 0 || axis[k] > 2) return set_err(c, "gyro: axis out of range");
     if (ensure(c, c->g_us, (size_t)n * 8) || ensure(c, c->g_dq, (size_t)n * 32) || ensure(c, c->g_q, (size_t)n * 32) ||
-        ensure(c, c->g_status, sizeof(GyroStatus)) || ensure(c, c->g_cf, (size_t)(n / kScanSegment + 2) * 64))
+        ensure(c, c->g_status, sizeof(GyroStatus) * kGyroStatusSlots) || ensure(c, c->g_cf, (size_t)(n / kScanSegment + 2) * 64))
         return 1;
     GyroRatesParams p{};
     p.ts = (const double*)c->g_ts.p; p.rates = (const double*)c->g_rates.p;
-    p.us = (int64_t*)c->g_us.p; p.dq = (double*)c->g_dq.p; p.st = (GyroStatus*)c->g_status.p; p.n = n;
+    p.us = (int64_t*)c->g_us.p; p.dq = (double*)c->g_dq.p; p.st = (GyroStatus*)c->g_status.p + status_slot; p.n = n;
     for (int k = 0; k < 3; ++k) { p.axis[k] = axis[k]; p.sign[k] = sign[k]; }
     {
         ProfScope ps(c, RSHIP_K_GYRO);
@@ -1166,8 +1218,9 @@ int rship_gyro_rates_integrate(rship_ctx* c, const int32_t axis[3], const double
         }
     }
     RS_HIP(hipGetLastError());
-    return resample_and_solve(c, (const int64_t*)c->g_us.p, (const double*)c->g_q.p, n, c->g_first_us, c->g_last_us, out);
+    return resample_and_solve(c, (const int64_t*)c->g_us.p, (const double*)c->g_q.p, n, c->g_first_us, c->g_last_us, out, status_slot, wait);
 }
+} // namespace
 
 int rship_gyro_knots(rship_ctx* c, double* out, uint32_t cap_knots) {
     DeviceGuard dev_guard(c);
@@ -1429,12 +1482,26 @@ int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, cons
     if (!c->n_knots) return set_err(c, "no gyro spline uploaded");
     if (c->n_grp != 1) return set_err(c, "presync: the selection must not be grouped");
     const uint32_t ns = c->n_sel;
+    // a batch of sweeps (rship_presync_batch_begin): this one is number `bslot` of `bn`; its sums and flags go to that slot
+    const uint32_t bn = c->batch_n ? c->batch_n : 1u, bslot = c->batch_n ? c->batch_next : 0u;
+    if (c->batch_n) {
+        if (bslot >= bn) return set_err(c, "presync: more sweeps than the batch was opened for");
+        if (n_cand != c->batch_rows) return set_err(c, "presync: every sweep of a batch has the same candidates");
+        if (want_frame_costs || want_best_h) return set_err(c, "presync: no per-frame outputs inside a batch");
+        c->batch_next += 1;
+    }
     if (!n_cand || !ns) return 0; // nothing on this device: collect reports zeros
     if (ensure(c, c->frame_cost, (size_t)n_cand * ns * 8)) return 1;
     if (want_best_h && ensure(c, c->best_h, (size_t)n_cand * ns * 4)) return 1;
-    if (ensure(c, c->flags, 16)) return 1;
-    if (upload_delays(c, kd, fd, n_cand)) return 1;
-    RS_HIP(hipMemsetAsync(c->flags.p, 0, 16, c->stream));
+    if (ensure(c, c->flags, 16 + 4 * (size_t)bn)) return 1;
+    if (bslot == 0) { // (a batch shares its candidates: uploaded once)
+        if (upload_delays(c, kd, fd, n_cand)) return 1;
+        RS_HIP(hipMemsetAsync(c->flags.p, 0, 16 + 4 * (size_t)bn, c->stream));
+        if (c->batch_n) { // the batch's sums side by side
+            if (!c->plan_wins) return set_err(c, "no reduction plan set");
+            if (ensure(c, c->chunk_out, (size_t)bn * n_cand * (c->plan_chunks + 1) * 8) || ensure(c, c->win_out, (size_t)bn * n_cand * c->plan_wins * 8)) return 1;
+        }
+    }
 
     LmedsParams p{};
     p.rays_a = (const f4*)c->rays_a.p;
@@ -1466,7 +1533,7 @@ int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, cons
     p.seed = seed;
     p.frame_cost = (double*)c->frame_cost.p;
     p.best_h = want_best_h ? (int32_t*)c->best_h.p : nullptr;
-    p.flags = (uint32_t*)c->flags.p;
+    p.flags = (uint32_t*)c->flags.p + bslot;
     // the near-static watch (kernels/lmeds.hpp, "fp64 rows"): a bit per (slot, candidate) for the pairs whose rows are too
     // small for fp32 inputs; rship_presync_collect launches the fp64 form for them.  The candidates' delays split in fp64
     // (kd64 / fd64; without them the fp32 split, widened) are kept on the host until then -- except where the selection
@@ -1520,6 +1587,16 @@ int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, cons
     }
     if (launch_lmeds<0>(c, p, step_knots, chunk, &c->last_lmeds_cap, &c->last_lmeds_chunk)) return 1;
     c->pend_redo.p = p;
+    if (c->batch_n) {
+        // (inside a batch nothing is waited for, so the fp64 form cannot follow: a sweep that flags near-static pairs is
+        // reported -- RSHIP_NEAR_STATIC in its flags -- and the caller redoes THAT sweep on its own; the bitmap is cleared
+        // before the next sweep that uses it)
+        c->pend_redo.armed = false;
+        c->redo_dirty = true;
+        if (launch_plan_sum(c, p.frame_cost, n_cand, ns, bslot, bn)) return 1;
+        c->pend.rows = n_cand;
+        return 0;
+    }
     if (launch_plan_sum(c, p.frame_cost, n_cand, ns)) return 1;
     size_t end = 0;
     if (queue_sums_to_host(c, n_cand, 0, &c->pend.off_chunk, &end)) return 1;
@@ -1528,6 +1605,57 @@ int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, cons
     c->pend.rows = n_cand;
     c->pend.frame_costs = want_frame_costs != 0;
     c->pend.best_h = want_best_h != 0;
+    return 0;
+}
+
+// A batch of n sweeps over the same candidates, selection and plan whose results are collected TOGETHER (the orientation
+// sweep of BASELINE config 5, core_testcode.cpp:216-224: between two sweeps only the gyro table changes --
+// rship_gyro_rates_integrate_enqueue): after _begin, the next n rship_presync_enqueue calls return at once and keep their
+// sums in slot 0 .. n-1; rship_presync_batch_collect waits ONCE and hands everything over, win_costs[n][n_cand][n_win],
+// chunk_costs[n][n_cand][n_chunks] (either may be NULL), flags[n].  A sweep whose flags carry RSHIP_NEAR_STATIC has NOT had
+// its near-static pairs recomputed in fp64 (that needs the host between two launches): the caller repeats that sweep alone.
+int rship_presync_batch_begin(rship_ctx* c, uint32_t n, uint32_t n_cand) {
+    if (!n) { // (cancel: a caller that gives up between _begin and _collect leaves no batch open)
+        c->batch_n = c->batch_next = 0;
+        c->pend = rship_ctx::Pend{};
+        return 0;
+    }
+    if (n > 4096) return set_err(c, "presync batch: 1 .. 4096 sweeps");
+    c->batch_n = n;
+    c->batch_next = 0;
+    c->batch_rows = n_cand;
+    c->pend = rship_ctx::Pend{};
+    return 0;
+}
+int rship_presync_batch_collect(rship_ctx* c, uint32_t n_cand, double* win_costs, double* chunk_costs, uint32_t* flags) {
+    DeviceGuard dev_guard(c);
+    const uint32_t n = c->batch_n;
+    if (!n) return set_err(c, "presync batch: none open");
+    c->batch_n = 0;
+    if (flags) memset(flags, 0, (size_t)n * 4);
+    if (!c->pend.rows) { // nothing was launched (no candidates or no slots on this device)
+        if (win_costs) memset(win_costs, 0, (size_t)n * n_cand * (c->plan_wins ? c->plan_wins : 1) * 8);
+        if (chunk_costs) memset(chunk_costs, 0, (size_t)n * n_cand * c->plan_chunks * 8);
+        return 0;
+    }
+    if (c->batch_next != n || n_cand != c->batch_rows) return set_err(c, "presync batch: fewer sweeps were enqueued than the batch was opened for");
+    // the slots hold [rows][chunks + 1] / [rows][wins]; one copy each, then the host drops the padding column
+    const size_t cs = (size_t)n_cand * (c->plan_chunks + 1), ws = (size_t)n_cand * c->plan_wins;
+    const size_t b_win = n * ws * 8, b_chunk = n * cs * 8, b_flags = (size_t)n * 4;
+    if (ensure_pinned(c, b_win + b_chunk + b_flags + 64)) return 1;
+    char* h = (char*)c->pinned;
+    RS_HIP(hipMemcpyAsync(h, c->win_out.p, b_win, hipMemcpyDeviceToHost, c->stream));
+    RS_HIP(hipMemcpyAsync(h + b_win, c->chunk_out.p, b_chunk, hipMemcpyDeviceToHost, c->stream));
+    RS_HIP(hipMemcpyAsync(h + b_win + b_chunk, c->flags.p, b_flags, hipMemcpyDeviceToHost, c->stream));
+    if (sync_stream(c)) return 1;
+    if (win_costs) memcpy(win_costs, h, b_win);
+    if (chunk_costs) {
+        const double* src = (const double*)(h + b_win);
+        // (plan_sum_kernel writes chunk sums [rows][plan_chunks] densely at the head of each slot)
+        for (uint32_t b = 0; b < n; ++b) memcpy(chunk_costs + (size_t)b * n_cand * c->plan_chunks, src + (size_t)b * cs, (size_t)n_cand * c->plan_chunks * 8);
+    }
+    if (flags) memcpy(flags, h + b_win + b_chunk, b_flags);
+    c->pend.rows = 0;
     return 0;
 }
 

@@ -676,10 +676,23 @@ void SyncProblemHip::SetGyroRates(const double* ts, const double* rates, size_t 
     integrate_rates(orientation);
 }
 
+static const char* presync_panic(uint32_t flags);
+
 // The orientation-guessing block of the reference driver (core_testcode.cpp:186-224): for each
 // candidate IMU orientation re-integrate the rates, replace the gyro (tracks stay) and PreSync;
 // the caller ranks the costs.  The rates are uploaded once; an orientation is a permutation of the rate
 // axes inside the integration kernel.  The last orientation stays installed.
+//
+// Round 6: ONE pipeline instead of a blocking PreSync per orientation.  The reference's loop is sequential by construction;
+// here nothing about orientation i + 1 depends on the host having seen orientation i's costs: the grid (rate, first
+// sample, count) follows from the two end timestamps alone, so frames, selection, plan and candidates are the same for
+// every orientation.  After the first orientation (whose gyro status is waited for: is there a table at all?) everything
+// is ENQUEUED -- integrate, resample, spline, sweep, sums, per orientation -- into side-by-side result slots
+// (rship_presync_batch_begin), then ONE wait, ONE copy and, with ranks, ONE exchange of the whole [orientations][candidates]
+// matrix; the arg-min per orientation (the same lexicographic rule) comes after it.  Bits unchanged.  With 512 frames per
+// GPU (the 8-GPU shard of BASELINE config 5: ~5 ms of kernels per orientation) the blocking form cost ~10 % of the sweep.
+// An orientation whose sweep met near-static pairs (RSHIP_NEAR_STATIC: their fp64 form needs the host between two
+// launches) is repeated on its own afterwards, the plain way.
 void SyncProblemHip::orientation_sweep(const double* ts, const double* rates, size_t count,
                                        const std::vector<std::string>& orientations, double initial_delay,
                                        int64_t frame_begin, int64_t frame_end, double search_step,
@@ -691,12 +704,116 @@ void SyncProblemHip::orientation_sweep(const double* ts, const double* rates, si
         parse_orientation(o.c_str(), axis, sign);
     }
     upload_rates(ts, rates, count);
-    for (size_t i = 0; i < orientations.size(); ++i) {
+    const size_t n_or = orientations.size();
+    auto one_by_one = [&](size_t i) {
         integrate_rates(orientations[i].c_str());
         const std::pair<double, double> r = PreSync(initial_delay, frame_begin, frame_end, search_step, search_radius);
         costs[i] = r.first;
         delays[i] = r.second;
+    };
+    const char* env_pipeline = std::getenv("RSSYNC_SWEEP_PIPELINE");
+    const bool no_pipeline = env_pipeline && env_pipeline[0] == '0';
+    integrate_rates(orientations[0].c_str());
+    ensure_device();
+    select(frame_begin, frame_end);
+    std::vector<double> cand; // the candidates are whatever this double loop yields (core_private.cpp:69-70), as in PreSync
+    for (double delay = initial_delay - search_radius; delay < initial_delay + search_radius; delay += search_step) {
+        cand.push_back(delay);
+        if (cand.size() > 50000000) panic("pre-sync: more than 5e7 candidate delays");
     }
+    if (cand.empty()) panic("pre-sync: empty candidate list");
+    const size_t n = cand.size(), ns = sel_.size(), W = plan_windows_;
+    const size_t slice = std::max<size_t>(64, (size_t)(256u << 20) / (8 * std::max<size_t>(ns, 1)));
+    if (no_pipeline || n_or < 2 || n_or > 255 || n > slice || !ns || (uint64_t)n_or * n * (W + 1) > (1u << 28)) {
+        // (one orientation, a candidate list that the sweep would slice, more orientations than there are status records,
+        // or RSSYNC_SWEEP_PIPELINE=0 -- rounds 1-5's loop, kept for the A/B and the tests' comparison)
+        const std::pair<double, double> r0 = PreSync(initial_delay, frame_begin, frame_end, search_step, search_radius);
+        costs[0] = r0.first;
+        delays[0] = r0.second;
+        for (size_t i = 1; i < n_or; ++i) one_by_one(i);
+        return;
+    }
+    std::vector<int32_t> kd(n), kd64(n);
+    std::vector<float> fd(n);
+    std::vector<double> fd64(n);
+    for (size_t i = 0; i < n; ++i) {
+        const DelaySplit sp = split_delay(cand[i], fs_);
+        kd[i] = sp.kd; fd[i] = sp.fd;
+        const DelaySplit64 sp64 = split_delay64(cand[i], fs_);
+        kd64[i] = sp64.kd; fd64[i] = sp64.fd;
+    }
+    for (Shard& sh : shards_) hip_check(sh, rship_presync_batch_begin(sh.ctx, (uint32_t)n_or, (uint32_t)n), "presync batch");
+    struct CloseBatch { // a panic between here and the collect (C mirror: an exception) must not leave the contexts in a batch
+        SyncProblemHip* s;
+        bool armed = true;
+        ~CloseBatch() {
+            if (armed)
+                for (Shard& sh : s->shards_)
+                    if (sh.ctx) (void)rship_presync_batch_begin(sh.ctx, 0, 0);
+        }
+    } close_batch{this};
+    for (size_t i = 0; i < n_or; ++i) {
+        if (i > 0) {
+            int32_t axis[3];
+            double sign[3];
+            parse_orientation(orientations[i].c_str(), axis, sign);
+            rship_gyro_result r{};
+            for (Shard& sh : shards_)
+                hip_check(sh, rship_gyro_rates_integrate_enqueue(sh.ctx, axis, sign, (uint32_t)i, &r), "gyro integrate");
+            // (what the HOST can tell -- the grid -- is the first orientation's, which was accepted; the device's complaints
+            // are read after the batch)
+            if (r.status != RSHIP_GYRO_OK || r.fs != fs_ || r.start != start_ || r.n_knots != n_knots_)
+                panic("orientation sweep: the gyro grid changed between two orientations of one rate stream");
+        }
+        for (Shard& sh : shards_)
+            hip_check(sh, rship_presync_enqueue(sh.ctx, kd.data(), fd.data(), kd64.data(), fd64.data(), (uint32_t)n, 20 /* core_private.cpp:77 */,
+                                                0u, seed, 0, 0),
+                      "presync");
+    }
+    // ONE wait per device: all orientations' sums, [orientation][candidate] rows
+    std::vector<double> all(n_or * n * W + 1, 0.0);
+    std::vector<uint32_t> flags(n_or, 0u), fl_sh(n_or);
+    combine(n_or * n, W, [&](Shard& sh, double* win, double* chunk) {
+        hip_check(sh, rship_presync_batch_collect(sh.ctx, (uint32_t)n, win, chunk, fl_sh.data()), "presync batch");
+        for (size_t i = 0; i < n_or; ++i) flags[i] |= fl_sh[i];
+    }, all.data());
+    close_batch.armed = false;
+    // the device's gyro complaints, in the order the reference's loop would have met them
+    std::vector<int32_t> gst(n_or, RSHIP_GYRO_OK);
+    for (Shard& sh : shards_) {
+        std::vector<int32_t> st(n_or, RSHIP_GYRO_OK);
+        hip_check(sh, rship_gyro_batch_status(sh.ctx, (uint32_t)(n_or - 1), st.data() + 1), "gyro status");
+        for (size_t i = 1; i < n_or; ++i)
+            if (gst[i] == RSHIP_GYRO_OK) gst[i] = st[i];
+    }
+    // one exchange for the whole matrix; the flag bits ride along as small integers (five per orientation)
+    std::vector<double> buf(all.begin(), all.begin() + n_or * n * W);
+    for (size_t i = 0; i < n_or; ++i)
+        for (int b = 0; b < 5; ++b) buf.push_back((double)((flags[i] >> b) & 1u));
+    if (distributed()) reduce(buf.data(), buf.size());
+    bool redone = false;
+    for (size_t i = 0; i < n_or; ++i) {
+        if (gst[i] != RSHIP_GYRO_OK) { // (the same complaint on every rank: the rates are replicated)
+            rship_gyro_result r{};
+            r.status = gst[i];
+            accept_gyro(r);
+        }
+        const double* fl = buf.data() + n_or * n * W + 5 * i;
+        const uint32_t fa = (fl[0] > 0 ? 1u : 0u) | (fl[1] > 0 ? 2u : 0u) | (fl[2] > 0 ? 4u : 0u) | (fl[3] > 0 ? 8u : 0u);
+        if (const char* msg = presync_panic(fa)) panic(msg);
+        if (fl[4] > 0) { // near-static pairs on some rank: this orientation once more, with their fp64 form (every rank agrees: the flag was summed)
+            one_by_one(i);
+            redone = true;
+            continue;
+        }
+        const double* c = buf.data() + i * n * W; // (W == 1: select() makes one window)
+        size_t best = 0; // *std::min_element over pair(cost, delay) (core_private.cpp:89)
+        for (size_t k = 1; k < n; ++k)
+            if (std::make_pair(c[k * W], cand[k]) < std::make_pair(c[best * W], cand[best])) best = k;
+        costs[i] = c[best * W];
+        delays[i] = cand[best];
+    }
+    if (redone) integrate_rates(orientations[n_or - 1].c_str()); // the last orientation stays installed
 }
 
 // the uniform route's table (the other routes leave it built)

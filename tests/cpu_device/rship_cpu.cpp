@@ -56,6 +56,11 @@ struct rship_ctx {
     std::vector<double> win_out, chunk_out, frame_cost;
     std::vector<int32_t> best_h;
     uint32_t pend_rows = 0, pend_flags = 0;
+    // a batch of sweeps collected together (rship_presync_batch_begin)
+    uint32_t batch_n = 0, batch_rows = 0;
+    std::vector<std::vector<double>> batch_win, batch_chunk;
+    std::vector<uint32_t> batch_flags;
+    std::vector<int32_t> batch_gyro_status; // of the orientations enqueued with rship_gyro_rates_integrate_enqueue
     bool pend_grad = false;
     std::vector<int32_t> init_h; // per slot: winning hypothesis of a pending GuessMotion, or kNone
     uint64_t init_seed = 0;
@@ -275,6 +280,20 @@ int rship_gyro_rates_integrate(rship_ctx* c, const int32_t axis[3], const double
     return timestamped(c, us.data(), q.data(), n, bad, out);
 }
 
+// (the stand-in computes at once; the status is kept for rship_gyro_batch_status as the device keeps its records)
+int rship_gyro_rates_integrate_enqueue(rship_ctx* c, const int32_t axis[3], const double sign[3], uint32_t slot, rship_gyro_result* out) {
+    if (!slot || slot >= 256) return fail(c, "gyro: status slot out of range");
+    const int rc = rship_gyro_rates_integrate(c, axis, sign, out);
+    if (rc) return rc;
+    if (c->batch_gyro_status.size() < slot) c->batch_gyro_status.resize(slot, RSHIP_GYRO_OK);
+    c->batch_gyro_status[slot - 1] = out->status;
+    return 0;
+}
+int rship_gyro_batch_status(rship_ctx* c, uint32_t n, int32_t* status) {
+    for (uint32_t i = 0; i < n; ++i) status[i] = i < c->batch_gyro_status.size() ? c->batch_gyro_status[i] : RSHIP_GYRO_OK;
+    return 0;
+}
+
 int rship_gyro_knots(rship_ctx* c, double* out, uint32_t cap_knots) {
     if ((size_t)cap_knots * 4 < c->knots.size()) return fail(c, "gyro_knots: buffer too small");
     std::copy(c->knots.begin(), c->knots.end(), out);
@@ -457,6 +476,37 @@ int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, cons
     plan_sum(c, c->frame_cost, n_cand, ns);
     c->pend_rows = n_cand;
     c->pend_flags = fl;
+    if (c->batch_n) { // keep this sweep's sums for rship_presync_batch_collect
+        c->batch_win.push_back(c->win_out);
+        c->batch_chunk.push_back(c->chunk_out);
+        c->batch_flags.push_back(fl);
+    }
+    return 0;
+}
+
+int rship_presync_batch_begin(rship_ctx* c, uint32_t n, uint32_t n_cand) { // (n = 0: cancel)
+    c->batch_n = n;
+    c->batch_rows = n_cand;
+    c->batch_win.clear(); c->batch_chunk.clear(); c->batch_flags.clear();
+    c->pend_rows = 0;
+    return 0;
+}
+int rship_presync_batch_collect(rship_ctx* c, uint32_t n_cand, double* win_costs, double* chunk_costs, uint32_t* flags) {
+    const size_t nc = c->plan_chunk_off.size() - 1, nw = c->plan_win_off.size() - 1;
+    const uint32_t n = c->batch_n;
+    c->batch_n = 0;
+    if (!n) { c->err = "presync batch: none open"; return 1; }
+    if (flags) std::fill(flags, flags + n, 0u);
+    if (win_costs) std::fill(win_costs, win_costs + (size_t)n * n_cand * nw, 0.0);
+    if (chunk_costs) std::fill(chunk_costs, chunk_costs + (size_t)n * n_cand * nc, 0.0);
+    if (c->batch_win.empty()) return 0; // (no candidates or no slots on this device)
+    if (c->batch_win.size() != n) { c->err = "presync batch: fewer sweeps were enqueued than the batch was opened for"; return 1; }
+    for (uint32_t b = 0; b < n; ++b) {
+        if (win_costs) std::copy(c->batch_win[b].begin(), c->batch_win[b].begin() + (size_t)n_cand * nw, win_costs + (size_t)b * n_cand * nw);
+        if (chunk_costs) std::copy(c->batch_chunk[b].begin(), c->batch_chunk[b].begin() + (size_t)n_cand * nc, chunk_costs + (size_t)b * n_cand * nc);
+        if (flags) flags[b] = c->batch_flags[b];
+    }
+    c->pend_rows = 0;
     return 0;
 }
 

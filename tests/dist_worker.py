@@ -56,7 +56,8 @@ def main():
     mixed = dict(sync=[mc, md], iters=len(q.sync_trace()), calls=hook2.stats["calls"] - init_calls, init_calls=init_calls,
                  M=M.tolist(), k=k.tolist())
     # BASELINE config 5 with ranks (core_testcode.cpp:184-233): the gyro arrives as rates at timestamps, replicated on
-    # every rank; each orientation is a PreSync over the sharded frames = ONE exchange of its candidate costs
+    # every rank; the whole sweep is ONE pipeline (round 6): every orientation's PreSync over the sharded frames enqueued back to
+    # back, ONE exchange of the [orientations][candidates] cost matrix at the end
     F5, N5 = 12, 64
     g5 = synth.make_gyro(1.0, 1.0 + (F5 + 2) / synth.FPS, seed=77)   # t0 = 0: timestamps must be >= 0
     b5, e5 = shard(30, 30 + F5, rank, world)

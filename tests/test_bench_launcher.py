@@ -75,7 +75,7 @@ def test_a_failing_rank_fails_the_run(hosttest_lib):
 
 def test_baseline_config_is_named_and_config5_runs_with_ranks(hosttest_lib):
     """the JSON line says which BASELINE.json config it is; --workload c5 (timestamped gyro + orientation sweep,
-    frames sharded over the ranks, one exchange per orientation) gives the same ranking with 1 and 2 ranks"""
+    frames sharded over the ranks, ONE exchange for the whole pipelined sweep) gives the same ranking with 1 and 2 ranks"""
     lib = _lib(hosttest_lib)
     c5 = ["--workload", "c5", "--orientations", "4", "--steps", "1", "--warmup", "0", "--cpu-frames", "0", "--tracks", "64",
           "--search-step", "0.004", "--search-radius", "0.1"]
@@ -89,7 +89,7 @@ def test_baseline_config_is_named_and_config5_runs_with_ranks(hosttest_lib):
         assert d["result"]["best_orientation"] == "XYZ"
     assert b["result"]["best_delay"] == a["result"]["best_delay"]
     assert b["result"]["cost_ratio_best_to_second"] == pytest.approx(a["result"]["cost_ratio_best_to_second"], rel=1e-9)
-    assert b["multi_gpu"]["exchanges_per_step"] == 4           # one per orientation (its PreSync's candidate costs)
+    assert b["multi_gpu"]["exchanges_per_step"] == 1           # the [orientations][candidates] cost matrix, once (rounds 1-5: one per orientation)
     # the default workload names its config too; 2048 frames per GPU is config 4's shard size
     rc, out, err = _run([sys.executable, "bench.py", "--gpus", "1", "--frames", "16", "--rehearse-cpu", lib] + SMALL)
     assert rc == 0, err

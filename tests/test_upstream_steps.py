@@ -135,12 +135,14 @@ def test_pixels_end_to_end_recover_the_true_delay(built):
     assert abs(dh - synth.D_TRUE) < 1e-4 and abs(dh - do) < 1e-4
 
 
-def _check_orientation_sweep(make, F, N, margin, tol=0.004):
+def _check_orientation_sweep(make, F, N, margin, tol=0.004, **scene):
     """rssync_ext_orientation_sweep == set_gyro_rates + PreSync per orientation (exactly), and the
-    orientation the rays were generated with has the lowest cost (core_testcode.cpp:186-232)."""
+    orientation the rays were generated with has the lowest cost (core_testcode.cpp:186-232).  Round 6: the sweep is ONE
+    pipeline (every orientation enqueued back to back, one wait); RSSYNC_SWEEP_PIPELINE=0 keeps rounds 1-5's loop -- the
+    same numbers either way."""
     from rssync_amd import synth
     g = synth.make_gyro(1.0, 1.0 + (F + 2) / synth.FPS, seed=77)   # t0 = 0: timestamps must be >= 0
-    frames = list(synth.make_frames(g, 30, 30 + F, N, seed=77))
+    frames = list(synth.make_frames(g, 30, 30 + F, N, seed=77, **scene))
     names = list(synth.ORIENTATIONS[:9]) + ["XYZ"]
     seq, bat = make(), make()
     for p in (seq, bat):
@@ -157,6 +159,13 @@ def _check_orientation_sweep(make, F, N, margin, tol=0.004):
     assert names[order[0]] == "XYZ" and costs[order[0]] < margin * costs[order[1]]
     assert abs(delays[order[0]] - synth.D_TRUE) <= tol                  # grid step 4 ms
     np.testing.assert_array_equal(bat.gyro_knots(), seq.gyro_knots())   # the last orientation stays installed
+    os.environ["RSSYNC_SWEEP_PIPELINE"] = "0"
+    try:
+        costs0, delays0 = bat.orientation_sweep(g.times, g.rates, names, 0.0, 30, 30 + F, 0.004, 0.1)
+    finally:
+        del os.environ["RSSYNC_SWEEP_PIPELINE"]
+    np.testing.assert_array_equal(costs0, costs)
+    np.testing.assert_array_equal(delays0, delays)
     with pytest.raises(Exception, match="orientation"):
         bat.orientation_sweep(g.times, g.rates, ["XYZ", "abc"], 0.0, 30, 30 + F, 0.004, 0.1)
 
@@ -170,6 +179,21 @@ def test_orientation_sweep_on_the_host_solver(hosttest_lib, built):
 def test_orientation_sweep_on_the_device(built):
     import rssync_amd
     _check_orientation_sweep(lambda: rssync_amd.SyncProblem(seed=SEED), 24, 256, 0.95)
+
+
+@pytest.mark.gpu
+def test_orientation_sweep_with_near_static_frames(built):
+    """the pipeline cannot give an orientation's near-static pairs their fp64 rows (that needs the host between two launches,
+    kernels/lmeds.hpp "fp64 rows"): such an orientation -- here the true one, around the true delay -- is flagged and repeated
+    on its own, and the sweep still equals the per-orientation calls exactly; the last orientation stays installed"""
+    import rssync_amd
+    made = []
+
+    def make():
+        made.append(rssync_amd.SyncProblem(seed=SEED))
+        return made[-1]
+    _check_orientation_sweep(make, 16, 200, 1.0, tol=0.0081, translation=5e-5, noise=1e-6)
+    assert made[1].near_static_stats()["pairs"] > 0
 
 
 def test_a_frame_can_switch_between_rays_and_pixels(hosttest_lib, built):
