@@ -77,6 +77,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-hook-device-loop", dest="hook_device_loop", action="store_false",
                     help="with --exchange torch: Sync's loop on the host, one hook call per launch")
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed HIP-vs-oracle comparison on the CPU sample")
+    ap.add_argument("--no-driver-workload", action="store_true",
+                    help="skip the (untimed) reference-driver workload: 98 sync points of 61 x 130, PreSync + 4 x Sync each "
+                         "(core_testcode.cpp:270-316), with its CPU sample and its critical-path bound")
+    ap.add_argument("--driver-cpu-positions", type=int, default=6, help="sync points of the driver workload the oracle is timed on")
     ap.add_argument("--exchange", default="torch", choices=["native", "torch"],
                     help="multi-rank sums: torch.distributed all_reduce through a reduce hook (default: the path every "
                          "multi-rank test exercises), or the library's own RCCL communicator with Sync's loop on the "
@@ -299,6 +303,7 @@ def run(args):
     prof = prob.profile_get()
     prob.profile(False)
     near_static = prob.near_static_stats()  # (frame, candidate) pairs the sweep recomputed with fp64 rows: 0 on this scene
+    rccl_lib_name = prob.rccl_library() if exchange == "native-rccl" else None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -419,12 +424,15 @@ def run(args):
                                        "per SIMD); avg_launch_ms is this run's (HIP events)" % (name, FP64_CYCLES_PER_WAVE_INSTR)}
                     break
         kernels = {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in prof.items()}
-        cpu = parity = None
+        cpu = parity = driver = None
         if n_gpus == 1 and args.cpu_frames > 0 and not c5:
             cpu = cpu_baseline(gyro, min(args.cpu_frames, F), N, args)
             if not args.no_parity and not rehearsal:
                 parity = parity_check(gyro, min(args.cpu_frames, F), N, args, cpu.pop("_oracle"))
             cpu.pop("_oracle", None)
+        if n_gpus == 1 and not c5 and not rehearsal and not args.no_driver_workload:
+            del prob                      # (its 1.3 GB of frames are not needed any more)
+            driver = driver_workload(args)
         out = {
             "metric": "ray-residuals/sec (PreSync sweep + Sync iter), 4096 frames x 2048 tracks",
             "value": value, "unit": "ray-residuals/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -444,7 +452,7 @@ def run(args):
                           # RCCL carries the sums whenever the backend is nccl -- through the library's own communicator
                           # ("native-rccl") or through torch.distributed behind the reduce hook ("torch-nccl-hook")
                           "exchange": exchange, "rccl_ranks": world if (world > 1 and (exchange == "native-rccl" or backend == "nccl")) else 0,
-                          "rccl_library": prob.rccl_library() if exchange == "native-rccl" else
+                          "rccl_library": rccl_lib_name if exchange == "native-rccl" else
                                           ("torch.distributed's (backend nccl)" if world > 1 and backend == "nccl" else None),
                           "exchanges_per_step": x_calls / max(args.steps, 1),
                           "doubles_per_step": x_doubles / max(args.steps, 1),
@@ -456,7 +464,7 @@ def run(args):
                           "note": "exchange = how the sums over frames cross process boundaries (none within one "
                                   "process: --mode inproc adds the devices' chunk sums on the host)"},
             "roofline": roof, "roofline_flop": roof_flop, "roofline_k1": roof_k1, "roofline_k3": roof_k3, "cpu_baseline": cpu,
-            "parity": parity, "kernels": kernels,
+            "parity": parity, "driver_workload": driver, "kernels": kernels,
             "near_static": {"fp64_row_pairs": near_static["pairs"], "sweeps": near_static["sweeps"],
                             "note": "PreSync recomputes near-static (frame, candidate) pairs -- a quarter of a frame's first 64 rows "
                                     "with |P| < 2e-4 -- from the fp64 streams (core_private.cpp:19-28 is double); an ordinary "
@@ -535,6 +543,131 @@ def cpu_baseline(gyro, frames, tracks, args):
             "presync_s": round(t_pre, 2), "sync_s": round(t_sync, 2), "presync_delay": d0, "sync_delay": d1,
             "note": "the SAMPLE's results (first %d frames): compare with `parity`, not with `result` (all frames)" % frames,
             "_oracle": {"delays": delays, "costs": costs, "d0": d0, "sync_cost": c1, "sync_delay": d1, "trace": tr}}
+
+
+DRIVER_SEED = 0x5EED0006       # tools/gpu_syncpoints.py: the scene of profiles/r*_syncpoints.json
+
+
+def driver_workload(args):
+    """The reference driver's REAL workload, untimed with respect to the metric, in the driver's own bench run: a 100 s clip of
+    3000 frames x 130 tracks (core_testcode.cpp:126-132: a 200 px grid), a sync point every 30 frames with a window of 60
+    (core_testcode.cpp:270-280, README.md:36) = 98 positions, at each PreSync(+-100 ms, 1 ms) then FOUR Sync calls
+    (core_testcode.cpp:303-316).  BASELINE's 4096 x 2048 is ~1000x anything the reference was run on; this is what it WAS
+    run on.  Reported:
+      executor_ms / chain_ms  the batched call (rssync_ext_sync_points) through the window executor (one device-scheduled
+                              launch) and through the chain of launches; `identical`: the same delays and costs, bit for bit
+      critical_path           the executor is latency-bound, so its roofline is its critical path: the PreSync launch + the
+                              LONGEST window's outer iterations x the latency of one iteration of a window that has the
+                              device to itself (measured here: that window alone), against the wall time
+      cpu_sample              the oracle (faithful schedule, all host cores) on a few positions, PreSync + 4 x Sync each
+      delay_vs_oracle_ms      the HIP path, called position by position on the same sample (so that both sides count their
+                              Sync calls alike: the sampler stream follows the call number), against the oracle's delays;
+                              within_control: no further apart than rounding in another order moves the reference-order
+                              algorithm itself (2.5 x the largest control distance of profiles/r5_reassociation.json, the
+                              rule of tests/noisy_scenes.py: Sync on 61 x 130 noisy windows is a chaotic iteration)."""
+    import rssync_amd
+    from rssync_amd import synth
+    from oracle.oracle import OracleProblem
+
+    F, N, WINDOW, DIST = 3000, 130, 60, 30
+    STEP, RADIUS = 0.001, 0.1
+    gyro = synth.make_gyro(0, (F + 2) / synth.FPS, seed=DRIVER_SEED)
+    pos = list(range(0, F - WINDOW - 1, DIST))
+
+    def problem(executor=True):
+        if not executor:
+            os.environ["RSSYNC_EXECUTOR"] = "0"
+        try:
+            h = rssync_amd.SyncProblem(seed=DRIVER_SEED, verbose=False)
+        finally:
+            os.environ.pop("RSSYNC_EXECUTOR", None)
+        synth.fill(h, gyro, 0, F, N, seed=DRIVER_SEED)
+        h.upload()
+        return h
+
+    def best_of(fn, reps=3):
+        out, best = None, float("inf")
+        for _ in range(reps):
+            t = time.perf_counter()
+            out = fn()
+            best = min(best, time.perf_counter() - t)
+        return out, best
+
+    ex, ch = problem(True), problem(False)
+    for h in (ex, ch):
+        h.set_executor_check_every(0)            # (the production tripwire re-runs one call in 256 through the chain: not in a timing)
+        h.sync_points(pos, WINDOW, 0.0, STEP, RADIUS)      # warm-up
+    (ce, de), t_ex = best_of(lambda: ex.sync_points(pos, WINDOW, 0.0, STEP, RADIUS))
+    (cc, dc), t_ch = best_of(lambda: ch.sync_points(pos, WINDOW, 0.0, STEP, RADIUS))
+    iters = [len(ex.window_trace(w)) for w in range(len(pos))]
+    w_long = int(np.argmax(iters))
+    # the critical path: the PreSync launch, then the longest window's iterations at the latency of a window alone on the device
+    b = np.asarray(pos, np.int64)
+    (_, d_pre), t_pre = best_of(lambda: ex.pre_sync_windows(0.0, b, b + WINDOW, STEP, RADIUS))
+    lone = [pos[w_long]]
+    ex.sync_points(lone, WINDOW, float(d_pre[w_long]))
+    _, t_lone = best_of(lambda: ex.sync_points(lone, WINDOW, float(d_pre[w_long])), reps=5)
+    it_lone = len(ex.window_trace(0))
+    per_iter_us = t_lone / max(it_lone, 1) * 1e6
+    crit_ms = t_pre * 1e3 + max(iters) * per_iter_us * 1e-3
+    stats = ex.executor_stats()
+    out = {"positions": len(pos), "window": "%d x %d" % (WINDOW + 1, N), "frames": F, "calls_per_position": "PreSync(+-100 ms, 1 ms) + 4 x Sync",
+           "executor_ms": round(t_ex * 1e3, 3), "chain_ms": round(t_ch * 1e3, 3),
+           "identical": bool(np.array_equal(de, dc) and np.array_equal(ce, cc)),
+           "positions_per_s": round(len(pos) / t_ex, 1),
+           "outer_iterations_per_position": {"mean": float(np.mean(iters)), "max": int(max(iters))},
+           "critical_path": {"presync_ms": round(t_pre * 1e3, 3), "longest_window_iterations": int(max(iters)),
+                             "iteration_latency_us": round(per_iter_us, 2), "lone_window_iterations": int(it_lone),
+                             "lone_window_ms": round(t_lone * 1e3, 3),
+                             "critical_path_ms": round(crit_ms, 3), "wall_ms": round(t_ex * 1e3, 3),
+                             "critical_path_over_wall": round(crit_ms / (t_ex * 1e3), 3),
+                             "note": "iteration_latency_us = one window alone on the device (its four Sync calls through the executor, launch "
+                                     "and copies included) / its outer iterations: motion phase (as long as its slowest frame's L-BFGS), "
+                                     "trials, two decisions, four hand-offs -- DESIGN.md section 4"},
+           "executor": {"waves": stats["waves"], "tasks": stats["tail"]},
+           "delay_err_vs_truth_ms": {"median": float(np.median(np.abs(de - synth.D_TRUE)) * 1e3), "max": float(np.abs(de - synth.D_TRUE).max() * 1e3)}}
+    del ex, ch
+    k = max(0, min(args.driver_cpu_positions, len(pos)))
+    if k:
+        sample = [pos[int(round(i * (len(pos) - 1) / max(k - 1, 1)))] for i in range(k)]
+        cores = host_cores()
+        o = OracleProblem(seed=DRIVER_SEED, threads=cores, faithful=True)
+        synth.fill(o, gyro, 0, F, N, seed=DRIVER_SEED)
+        t0 = time.perf_counter()
+        d_ora = []
+        for p0 in sample:
+            d = o.PreSync(0.0, p0, p0 + WINDOW, STEP, RADIUS)[1]
+            for _ in range(4):
+                _, d = o.Sync(d, p0, p0 + WINDOW, 0.0, RADIUS)
+            d_ora.append(d)
+        t_cpu = time.perf_counter() - t0
+        hs = problem(True)
+        hs.set_executor_check_every(0)
+        d_hip = []
+        t0 = time.perf_counter()
+        for p0 in sample:
+            d = hs.PreSync(0.0, p0, p0 + WINDOW, STEP, RADIUS)[1]
+            for _ in range(4):
+                _, d = hs.Sync(d, p0, p0 + WINDOW, 0.0, RADIUS)
+            d_hip.append(d)
+        t_hip_seq = time.perf_counter() - t0
+        diff = np.abs(np.asarray(d_hip) - np.asarray(d_ora)) * 1e3
+        control = None
+        try:
+            raw = json.load(open(os.path.join(ROOT, "profiles", "r5_reassociation.json")))
+            control = raw["pooled_reference_workload_noisy"]["control_reference_order_started_1e-9_s_away_s"]
+        except Exception:
+            pass
+        out["cpu_sample"] = {"positions": k, "s": round(t_cpu, 2), "cores": cores, "kind": "port", "positions_per_s": round(k / t_cpu, 3),
+                             "sample": "positions %s: PreSync + 4 x Sync each, the oracle in its faithful schedule" % sample,
+                             "hip_same_calls_s": round(t_hip_seq, 4)}
+        out["gpu_over_cpu_positions_per_s"] = round((len(pos) / t_ex) / (k / t_cpu), 1)
+        out["delay_vs_oracle_ms"] = {"median": float(np.median(diff)), "p90": float(np.percentile(diff, 90)), "max": float(diff.max()),
+                                     "n": k, "within_north_star_1e-4_s": int(np.sum(diff <= 0.1))}
+        if control:
+            out["control_ms"] = {kk: float(control[kk]) * 1e3 for kk in ("median", "p90", "max") if kk in control}
+            out["within_control"] = bool(diff.max() <= 2.5 * float(control["max"]) * 1e3)
+    return out
 
 
 def parity_check(gyro, frames, tracks, args, ora):
