@@ -45,6 +45,7 @@
 #include "lens_math.hpp"
 #include "gyro_math.hpp"
 #include "window_plan.hpp"
+#include "roctx_ranges.hpp"
 
 using rs::f3;
 using rs::f4;
@@ -241,11 +242,15 @@ int ensure_pinned(rship_ctx* c, size_t bytes) {
     return 0;
 }
 
+// names of the RSHIP_K_* launch kinds: the roctx range around a kind's launches (RSSYNC_ROCTX=1, roctx_ranges.hpp)
+const char* const kKindNames[RSHIP_K_COUNT] = {"rssync:K2 lmeds sweep", "rssync:K1 loss (trials)", "rssync:K3 motion L-BFGS", "rssync:window sums",
+                                               "rssync:K2 GuessMotion search", "rssync:pack frames", "rssync:gyro pipeline", "rssync:K1 loss+gradient"};
 struct ProfScope {
     rship_ctx* c;
     int kind;
     hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(rship_ctx* c_, int kind_) : c(c_), kind(kind_) {
+    rs::RoctxRange range;
+    ProfScope(rship_ctx* c_, int kind_) : c(c_), kind(kind_), range(kKindNames[kind_]) {
         if (!c->prof) return;
         auto get = [&]() {
             hipEvent_t e = nullptr;

@@ -15,6 +15,7 @@
 #include "../../include/rssync.h"
 #include "../../include/rssync_c.h"
 #include "../../include/rssync_hip.h"
+#include "roctx_ranges.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -488,6 +489,7 @@ void SyncProblemHip::profile_get(int kind, uint64_t* launches, double* total_ms)
 // device at the first use (rship_gyro_uniform).
 void SyncProblemHip::SetGyroQuaternions(const double* data, size_t count, double sample_rate,
                                         double first_timestamp) {
+    rs::RoctxRange roctx_range("rssync:SetGyroQuaternions");
     if (count < 2) panic("set-gyro-quaternions: need at least 2 samples");
     if (count > (size_t)UINT32_MAX) panic("set-gyro-quaternions: too many samples");
     if (fs_ != sample_rate || start_ != first_timestamp) frames_dirty_ = true; // ray offsets depend on both
@@ -526,6 +528,7 @@ void SyncProblemHip::accept_gyro(const rship_gyro_result& r) {
 // core_private.cpp:142-190, on the device: order check, integer-microsecond grid, slerp, spline solve.
 // Every device of the object does the (small) work itself rather than wait for a copy.
 void SyncProblemHip::SetGyroQuaternions(const int64_t* ts, const double* quats, size_t count) {
+    rs::RoctxRange roctx_range("rssync:SetGyroQuaternions(timestamped)");
     if (count < 2) panic("set-gyro-quaternions: need at least 2 samples");
     if (count > (size_t)UINT32_MAX) panic("set-gyro-quaternions: too many samples");
     rship_gyro_result r{};
@@ -697,6 +700,7 @@ void SyncProblemHip::orientation_sweep(const double* ts, const double* rates, si
                                        const std::vector<std::string>& orientations, double initial_delay,
                                        int64_t frame_begin, int64_t frame_end, double search_step,
                                        double search_radius, double* costs, double* delays) {
+    rs::RoctxRange roctx_range("rssync:orientation_sweep");
     if (orientations.empty()) return;
     for (const std::string& o : orientations) {
         int32_t axis[3];
@@ -831,6 +835,7 @@ void SyncProblemHip::build_spline() {
 // knot and parameter range of every frame, from the time range noted at SetTrackResult) and the
 // list of raw records; the streams themselves are written by the packing kernel.
 void SyncProblemHip::pack_frames() {
+    rs::RoctxRange roctx_range("rssync:pack_frames (upload + packing kernel)");
     const size_t nf = frames_.size();
     std::vector<rship_frame> table(nf);
     std::vector<rship_pack_frame> pack(nf);
@@ -1212,6 +1217,7 @@ std::vector<double> SyncProblemHip::sweep(const std::vector<double>& delays, uin
 // core_private.cpp:205-209 -> :61-90
 std::pair<double, double> SyncProblemHip::PreSync(double initial_delay, int64_t frame_begin, int64_t frame_end,
                                                   double search_step, double search_radius) {
+    rs::RoctxRange roctx_range("rssync:PreSync");
     ensure_device();
     select(frame_begin, frame_end);
     std::vector<double> delays; // the candidates are whatever this double loop yields (:69-70)
@@ -1230,6 +1236,7 @@ std::pair<double, double> SyncProblemHip::PreSync(double initial_delay, int64_t 
 // core_private.cpp:336-361
 void SyncProblemHip::DebugPreSync(double initial_delay, int64_t frame_begin, int64_t frame_end, double search_radius,
                                   double* delays, double* costs, int point_count) {
+    rs::RoctxRange roctx_range("rssync:DebugPreSync");
     ensure_device();
     select(frame_begin, frame_end);
     std::vector<double> d((size_t)std::max(point_count, 0));
@@ -1490,6 +1497,7 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
                                   const std::vector<double>& initial, double search_center, double search_radius,
                                   std::vector<double>& costs, std::vector<double>& delays_out, uint32_t call_stride,
                                   bool simplified) {
+    rs::RoctxRange roctx_range("rssync:sync_windows");
     ensure_device();
     const size_t W = begins.size();
     select_windows(begins, ends_incl);
@@ -1676,6 +1684,7 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
 
 std::pair<double, double> SyncProblemHip::Sync(double initial_delay, int64_t frame_begin, int64_t frame_end,
                                                double search_center, double search_radius) {
+    rs::RoctxRange roctx_range("rssync:Sync");
     std::vector<double> c, d;
     sync_windows({frame_begin}, {frame_end}, {initial_delay}, search_center, search_radius, c, d);
     trace = traces[0];
@@ -1689,6 +1698,7 @@ std::pair<double, double> SyncProblemHip::Sync(double initial_delay, int64_t fra
 void SyncProblemHip::presync_windows(double initial_delay, const std::vector<int64_t>& begins,
                                      const std::vector<int64_t>& ends_excl, double search_step, double search_radius,
                                      std::vector<double>& costs, std::vector<double>& delays_out) {
+    rs::RoctxRange roctx_range("rssync:presync_windows");
     ensure_device();
     const size_t W = begins.size();
     int64_t lo = std::numeric_limits<int64_t>::max(), hi = std::numeric_limits<int64_t>::min();
@@ -1744,6 +1754,7 @@ void SyncProblemHip::presync_windows(double initial_delay, const std::vector<int
 void SyncProblemHip::sync_points(const std::vector<int64_t>& positions, int64_t window, double initial_delay,
                                  bool use_presync, double presync_step, double presync_radius, int repeats,
                                  std::vector<double>& costs, std::vector<double>& delays_out) {
+    rs::RoctxRange roctx_range("rssync:sync_points");
     const size_t W = positions.size();
     std::vector<int64_t> ends(W);
     for (size_t w = 0; w < W; ++w) ends[w] = positions[w] + window;

@@ -37,7 +37,7 @@ def hosttest_lib(built):
     out = os.path.join(out_dir, "librssync_hosttest.so")
     srcs = [os.path.join(ROOT, "rs-sync_amd", "csrc", "sync_problem.cpp"),
             os.path.join(ROOT, "tests", "cpu_device", "rship_cpu.cpp")]
-    deps = srcs + [os.path.join(ROOT, "rs-sync_amd", "csrc", h) for h in ("device_math.hpp", "lens_math.hpp", "gyro_math.hpp")] + \
+    deps = srcs + [os.path.join(ROOT, "rs-sync_amd", "csrc", h) for h in ("device_math.hpp", "lens_math.hpp", "gyro_math.hpp", "roctx_ranges.hpp")] + \
         [os.path.join(ROOT, "include", h) for h in ("rssync.h", "rssync_c.h", "rssync_hip.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", out] + srcs)
