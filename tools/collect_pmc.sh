@@ -17,7 +17,7 @@ for g in "${GROUPS_[@]}"; do
     d="$ROOT/$OUT/pass$i"
     rm -rf "$d"
     (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $g -d "$d" -o pmc --output-format csv -- \
-        python3 "$ROOT/bench.py" --steps 3 --warmup 1 --cpu-frames 0 > "$ROOT/$OUT/pass$i.log" 2>&1) || \
+        python3 "$ROOT/bench.py" --steps 3 --warmup 1 --cpu-frames 0 --no-driver-workload > "$ROOT/$OUT/pass$i.log" 2>&1) || \
         { echo "pass $i ($g) failed"; tail -5 "$ROOT/$OUT/pass$i.log"; }
     echo "pass $i done: $g"
     i=$((i + 1))

@@ -12,7 +12,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 rm -rf "$ROOT/$OUT/prof"
 (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/prof" -o bench --output-format csv -- \
-    python3 "$ROOT/bench.py" --cpu-frames 0 > "$ROOT/$OUT/bench.log" 2>&1)
+    python3 "$ROOT/bench.py" --cpu-frames 0 --no-driver-workload > "$ROOT/$OUT/bench.log" 2>&1)
 grep "^{\"metric\"" "$ROOT/$OUT/bench.log" > "$ROOT/$OUT/bench.json"
 f=$(find "$ROOT/$OUT/prof" -name "*kernel_stats.csv" | head -1)
 cp "$f" "$ROOT/$OUT/kernel_stats.csv"

@@ -14,7 +14,7 @@ for r in $(seq 1 $ROUNDS); do
     if [ "$v" = head ]; then lib=$PWD/rs-sync_amd/librssync_core.so
     elif [ "${v:0:1}" = "@" ]; then lib=$PWD/rs-sync_amd/librssync_core.so; envset=${v:1}
     else lib=$PWD/rs-sync_amd/_variants/lib_$v.so; fi
-    env "$envset" RSSYNC_LIB=$lib timeout -k 10 120 python bench.py --steps 6 --warmup 2 --cpu-frames 0 $K2_AB_ARGS > gpurun_out/ab_$v.$r.log 2>&1 || { echo "variant $v failed (round $r)"; tail -3 gpurun_out/ab_$v.$r.log; exit 1; }
+    env "$envset" RSSYNC_LIB=$lib timeout -k 10 120 python bench.py --steps 6 --warmup 2 --cpu-frames 0 --no-driver-workload $K2_AB_ARGS > gpurun_out/ab_$v.$r.log 2>&1 || { echo "variant $v failed (round $r)"; tail -3 gpurun_out/ab_$v.$r.log; exit 1; }
     python - <<PY
 import json
 for line in open('gpurun_out/ab_$v.$r.log'):
