@@ -146,6 +146,11 @@ int rssync_ext_set_executor_check_every(rssync_problem* p, uint32_t every);
  * pair (what the dynamic windows stage where that is fewer knots), 0} */
 int rssync_ext_window_info(rssync_problem* p, uint32_t out[8]);
 int rssync_ext_executor_stats(rssync_problem* p, uint64_t* runs, uint64_t* checked, uint32_t queue[4]);
+/* How often a verified call of the production sample (one executor call in RSSYNC_EXECUTOR_CHECK_EVERY, default 256) did
+ * NOT give the launch chain's bits.  Such a call reports the evidence on stderr, returns the CHAIN's results, and the object
+ * uses the chain from then on (round 6; until then it panicked).  In the check mode (RSSYNC_EXECUTOR_CHECK=1 /
+ * rssync_ext_set_executor_check) a difference is still a panic: that mode exists to find one.  Expected: 0, always. */
+int rssync_ext_executor_mismatches(rssync_problem* p, uint64_t* count);
 /* Near-static footage (a camera on a tripod, a slow pan: rows of the residual matrix below ~2e-4).  The reference computes
  * rows, norms and the safe_normalize decisions in double (core_private.cpp:19-28,45-46, inline_utils.hpp:5-11); PreSync's
  * fp32 sweep recomputes exactly those (frame, candidate) pairs from the fp64 streams.  *pairs = pairs recomputed so far on

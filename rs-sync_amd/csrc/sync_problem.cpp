@@ -295,9 +295,13 @@ class SyncProblemHip final : public ISyncProblem {
         ChainRerun(const ChainRerun&) = delete;
         ChainRerun& operator=(const ChainRerun&) = delete;
     };
-    void check_against_chain(const char* what, const std::vector<double>& c_exec, const std::vector<double>& d_exec,
+    // -> true: identical.  In the check MODE (RSSYNC_EXECUTOR_CHECK=1) a difference is a panic; for a call of the production
+    // SAMPLE (one in RSSYNC_EXECUTOR_CHECK_EVERY) it is reported on stderr, counted, the caller hands out the CHAIN's results
+    // and the object stays with the chain from then on -- a deterministic, usable outcome instead of a sporadic panic
+    bool check_against_chain(const char* what, const std::vector<double>& c_exec, const std::vector<double>& d_exec,
                              const std::vector<std::vector<double>>& tr_exec, const std::vector<double>& c_chain,
                              const std::vector<double>& d_chain);
+    uint64_t executor_mismatches = 0;
     bool executor_ok(bool simplified);
     void executor_queue_stats(uint32_t out[4]) {
         out[0] = out[1] = out[2] = out[3] = 0;
@@ -1474,7 +1478,7 @@ bool SyncProblemHip::check_this_call() {
 }
 
 // RSSYNC_EXECUTOR_CHECK: the executor's results against the launch chain's for the same call (`traces` holds the chain's)
-void SyncProblemHip::check_against_chain(const char* what, const std::vector<double>& c_exec, const std::vector<double>& d_exec,
+bool SyncProblemHip::check_against_chain(const char* what, const std::vector<double>& c_exec, const std::vector<double>& d_exec,
                                          const std::vector<std::vector<double>>& tr_exec, const std::vector<double>& c_chain,
                                          const std::vector<double>& d_chain) {
     auto same = [](const std::vector<double>& a, const std::vector<double>& b) {
@@ -1487,10 +1491,21 @@ void SyncProblemHip::check_against_chain(const char* what, const std::vector<dou
     else
         for (size_t w = 0; w < traces.size() && bad.empty(); ++w)
             if (!same(tr_exec[w], traces[w])) bad = "trace of window " + std::to_string(w);
-    if (!bad.empty())
-        panic(std::string("window executor check (") + what + "): the " + bad + " differ from the launch chain's -- a hand-off between "
-              "workgroups delivered a stale value; set RSSYNC_EXECUTOR=0 and report this");
     executor_checked += 1;
+    if (bad.empty()) return true;
+    const std::string msg = std::string("window executor check (") + what + "): the " + bad + " differ from the launch chain's -- a hand-off between "
+                            "workgroups delivered a stale value; set RSSYNC_EXECUTOR=0 and report this";
+    if (executor_check) panic(msg); // the check MODE: a difference is what it exists to find
+    // a call of the production sample: say so, hand out the chain's results (the caller), and keep to the chain
+    executor_mismatches += 1;
+    size_t w_bad = 0;
+    for (; w_bad < d_exec.size() && w_bad < d_chain.size(); ++w_bad)
+        if (std::memcmp(&d_exec[w_bad], &d_chain[w_bad], sizeof(double)) != 0) break;
+    std::cerr << "rssync: " << msg << "\nrssync: this call returns the launch chain's results and this object uses the chain from now on";
+    if (w_bad < d_exec.size() && w_bad < d_chain.size())
+        std::cerr << " (first differing window " << w_bad << ": executor " << d_exec[w_bad] << " s, chain " << d_chain[w_bad] << " s)";
+    std::cerr << std::endl;
+    return false;
 }
 
 void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl,
@@ -1506,14 +1521,23 @@ void SyncProblemHip::sync_windows(const std::vector<int64_t>& begins, const std:
         sync_exec(begins, ends_incl, initial, search_center, search_radius, 1, kStreamSyncInit + sync_calls, call_stride, costs,
                   delays_out)) {
         if (check_this_call()) { // the same call once more through the launch chain (which advances the call counter itself)
-            const std::vector<double> c_exec = costs, d_exec = delays_out;
+            const std::vector<double> c_exec = costs;
+            std::vector<double> d_exec = delays_out;
+            // (TESTS: RSSYNC_EXECUTOR_INJECT_MISMATCH=1 makes the executor's first delay wrong by one ulp, as a stale hand-off
+            // could, so that the handling of a mismatch can be exercised: tests/test_gpu_executor.py)
+            if (const char* inj = std::getenv("RSSYNC_EXECUTOR_INJECT_MISMATCH"))
+                if (inj[0] == '1' && !d_exec.empty()) { d_exec[0] = std::nextafter(d_exec[0], 1.0); delays_out[0] = d_exec[0]; }
             const std::vector<std::vector<double>> tr_exec = traces;
             std::vector<double> c_chain, d_chain;
             {
                 ChainRerun scope(this);
                 sync_windows(begins, ends_incl, initial, search_center, search_radius, c_chain, d_chain, call_stride, simplified);
             }
-            check_against_chain("sync_windows", c_exec, d_exec, tr_exec, c_chain, d_chain);
+            if (!check_against_chain("sync_windows", c_exec, d_exec, tr_exec, c_chain, d_chain)) {
+                costs = c_chain;        // (`traces` are the chain's already)
+                delays_out = d_chain;
+                use_executor = false;
+            }
         } else if (call_stride == 1) sync_calls += (uint32_t)W;
         if (verbose && W == 1) { // :330, the lines the host loop would have written
             int conv = 0;
@@ -1800,7 +1824,7 @@ void SyncProblemHip::sync_points(const std::vector<int64_t>& positions, int64_t 
     delays_out = d;
     if (checking) {
         rerun.reset();
-        check_against_chain("sync_points", c_exec, d_exec, tr_exec, costs, delays_out);
+        if (!check_against_chain("sync_points", c_exec, d_exec, tr_exec, costs, delays_out)) use_executor = false; // (costs / delays_out / traces are the chain's)
     }
 }
 
@@ -1996,6 +2020,11 @@ int rssync_ext_debug_residuals(rssync_problem* p, int on, uint32_t cap_rows) {
 }
 int rssync_ext_debug_residuals_get(rssync_problem* p, uint32_t* out, size_t n_words, uint32_t dims[4]) {
     return guarded([&] { p->impl->debug_residuals_get(out, n_words, dims); });
+}
+
+int rssync_ext_executor_mismatches(rssync_problem* p, uint64_t* count) {
+    if (count) *count = p->impl->executor_mismatches;
+    return 0;
 }
 
 int rssync_ext_near_static_stats(rssync_problem* p, uint64_t* pairs, uint64_t* sweeps) {

@@ -67,6 +67,7 @@ SIGNATURES = {
     "rssync_ext_set_executor_check": (C.c_int, [C.c_void_p, C.c_int]),
     "rssync_ext_set_executor_check_every": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rssync_ext_executor_stats": (C.c_int, [C.c_void_p, _PU64, _PU64, C.POINTER(C.c_uint32)]),
+    "rssync_ext_executor_mismatches": (C.c_int, [C.c_void_p, _PU64]),
     "rssync_ext_near_static_stats": (C.c_int, [C.c_void_p, _PU64, _PU64]),
     "rssync_ext_debug_residuals": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
     "rssync_ext_debug_residuals_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_uint32)]),
@@ -338,7 +339,9 @@ class SyncProblem:
         """-> dict(runs, checked, head, tail, ring_cells, waves) of the window executor on this object"""
         runs, chk, q = C.c_uint64(), C.c_uint64(), (C.c_uint32 * 4)()
         self._check(self._lib.rssync_ext_executor_stats(self._h, C.byref(runs), C.byref(chk), q))
-        return dict(runs=runs.value, checked=chk.value, head=q[0], tail=q[1], ring_cells=q[2], waves=q[3])
+        mm = C.c_uint64()
+        self._lib.rssync_ext_executor_mismatches(self._h, C.byref(mm))
+        return dict(runs=runs.value, checked=chk.value, head=q[0], tail=q[1], ring_cells=q[2], waves=q[3], mismatches=mm.value)
 
     def debug_residuals(self, on=True, cap_rows=0):
         """TEST-VARIANTS build only: later sweeps also store the |residuals| their LMedS selection worked on"""

@@ -133,6 +133,11 @@ f3 hypothesis(const Rows& t, uint64_t seed, int64_t frame, uint32_t stream, uint
     uint32_t i0, i1;
     rs::sample_pair(seed, frame, stream, h, (uint32_t)t.n.size(), i0, i1);
     // safe_normalize on the UN-NORMALISED cross product (core_private.cpp:45-46): P_i = nrm_i n_i
+    // (The stand-in's sweep is NOT the bit-level double of the device's: its rows come from the fp64 streams and are rounded
+    // once, its norms are stage A's, its search is sequential -- the device's fp32 kernels recompute the two norms with
+    // row_scale_general and, on near-static pairs, take all rows from the fp64 streams (kernels/lmeds.hpp, "fp64 rows").
+    // Near the 1e-12 threshold the two can decide differently in the last bits; what is bit-identical between stand-in and
+    // device is Sync's fp64 arithmetic, started from the same winners -- tests/test_gpu_bitexact.py.  ADVICE r5.)
     f3 v = rs::cross(t.n[i0], t.n[i1]);
     float nn = std::sqrt(rs::dot(v, v));
     const float ss = t.nrm[i0] * t.nrm[i1];

@@ -245,3 +245,41 @@ def test_one_call_in_n_is_verified_in_production():
     for call in range(4):
         q.Sync(0.036, 0, 30, 0.0, 0.1)
     assert q.executor_stats()["checked"] == 0
+
+
+def test_a_mismatch_in_the_production_sample_is_reported_not_fatal(monkeypatch, capfd):
+    """the production tripwire (one executor call in N re-run through the launch chain) used to PANIC on a
+    difference -- a sporadic, unreproducible failure for whoever hit it.  Now such a call says so on stderr, returns the
+    CHAIN's results, counts the event (executor_stats()['mismatches']) and the object keeps to the chain; only the check MODE
+    (RSSYNC_EXECUTOR_CHECK=1), which exists to find a difference, still panics.  The difference is injected
+    (RSSYNC_EXECUTOR_INJECT_MISMATCH=1: the executor's first delay off by one ulp, as a stale hand-off could leave it)."""
+    import rssync_amd
+    from rssync_amd import synth
+    if os.environ.get("RSSYNC_EXECUTOR_CHECK", "0") not in ("", "0"):
+        pytest.skip("the suite is being run in the check mode itself")
+    F, N = 40, 130
+    gyro = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=15)
+    frames = list(synth.make_frames(gyro, 0, F, N, seed=15))
+    ex, ch = _two(seed=35, max_outer_iters=40)
+    _fill((ex, ch), gyro, frames)
+    want = ch.Sync(0.036, 0, 30, 0.0, 0.1)
+    ex.set_executor_check_every(1)
+    monkeypatch.setenv("RSSYNC_EXECUTOR_INJECT_MISMATCH", "1")
+    capfd.readouterr()
+    got = ex.Sync(0.036, 0, 30, 0.0, 0.1)
+    monkeypatch.delenv("RSSYNC_EXECUTOR_INJECT_MISMATCH")
+    err = capfd.readouterr().err
+    assert got == want                                            # the chain's result, not the (wrong) executor's
+    assert "differ from the launch chain's" in err and "uses the chain from now on" in err
+    st = ex.executor_stats()
+    assert st["mismatches"] == 1 and st["checked"] == 1 and st["runs"] == 1
+    np.testing.assert_array_equal(_bits(ex.sync_trace()), _bits(ch.sync_trace()))
+    assert ex.Sync(0.0362, 0, 30, 0.0, 0.1) == ch.Sync(0.0362, 0, 30, 0.0, 0.1)
+    assert ex.executor_stats()["runs"] == 1                        # the object stayed with the chain
+    # the check MODE still panics on the same evidence
+    q = rssync_amd.SyncProblem(seed=35, max_outer_iters=40)
+    _fill((q,), gyro, frames)
+    q.set_executor_check(True)
+    monkeypatch.setenv("RSSYNC_EXECUTOR_INJECT_MISMATCH", "1")
+    with pytest.raises(rssync_amd.RsSyncError, match="differ from the launch chain"):
+        q.Sync(0.036, 0, 30, 0.0, 0.1)
