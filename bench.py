@@ -44,7 +44,7 @@ BYTES_PER_RR = 32      # 8 fp32 per ray pair read per (frame, de
 BYTES_PER_RR_F64 = 64  # the Sync kernels read the fp64 streams: 8 doubles per ray pair per evaluation
 FLOP_PER_RR_PRESYNC = 390       # ~230 flop per residual row + 20 hypotheses x ~8
 FP32_VECTOR_PEAK_TF = 157.3     # MI355X_MICROARCH.md: peak FP32 (vector)
-PMC_SUMMARIES = ("r5_pmc_summary.json", "r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json")
+PMC_SUMMARIES = ("r6_pmc_summary.json", "r5_pmc_summary.json", "r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json")
 N_SIMD = 1024                   # 256 CUs x 4 SIMDs
 # cycles a gfx950 SIMD needs per fp64 wave-instruction with >= 2 waves resident: measured 4.2 - 4.4 (v_fma_f64,
 # tools/ubench/valu_rate.hip -> profiles/r2_valu_rate.txt); MI355X_MICROARCH.md states no fp64 vector peak

@@ -2185,7 +2185,15 @@ static int sync_run_body(rship_ctx* c, const double* d0, int max_outer, double s
         DeviceGuard guard(c); // the current device is a per-thread setting
         while (!gr.done) {
             // (after the first block the windows still active are the stragglers: shorter blocks waste fewer empty launches)
-            const int until = std::min(max_launch, gr.it + (gr.it == 0 ? kLook : kLook / 2));
+            // With ranks an over-enqueued iteration is not just five empty launches but TWO EXCHANGES every rank has to
+            // take part in (round 5 at the benchmark's size: 8 outer iterations = 9 launches of the loop -- the first
+            // search waits once for its later trials -- enqueued as 8 + 4 = 12: 26 exchanges per step against a floor of
+            // 1 + 2 x 9 + 1 = 20).  Through the host hook every exchange drains the stream anyway, so the counter of
+            // active windows is looked at after EVERY iteration there (one more small wait per iteration, no empty
+            // iteration at all); with the RCCL communicator on the stream the blocks after the first are two iterations.
+            const int later = !ranked ? kLook / 2 : (c->loop_xchg ? 1 : 2);
+            const int first = (ranked && c->loop_xchg) ? 1 : kLook;
+            const int until = std::min(max_launch, gr.it + (gr.it == 0 ? first : later));
             while (gr.it < until)
                 if (enqueue_iteration(gr)) return 1;
             RS_HIP(hipMemcpyAsync(gr.h_nact, gr.n_active, (size_t)gr.it * 4, hipMemcpyDeviceToHost, gr.st));
