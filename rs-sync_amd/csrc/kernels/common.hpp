@@ -80,6 +80,18 @@ __device__ __forceinline__ double block_sum(float v, double* slot) {
     return slot[0] + slot[1] + slot[2] + slot[3];
 }
 
+// the same for a workgroup of NW waves (NW = 4: the very association of block_sum)
+template <int NW>
+__device__ __forceinline__ double block_sum_n(float v, double* slot) {
+    float w = wave_sum_f32(v);
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = (double)w;
+    __syncthreads();
+    double t = slot[0] + slot[1];
+#pragma unroll
+    for (int i = 2; i < NW; ++i) t += slot[i];
+    return t;
+}
+
 // Data that other workgroups write DURING the launch (the window executor, executor.hpp): per-XCD L2s are not
 // coherent and a CU's L1 is never refreshed, so such words are loaded and stored with `sc1` (relaxed agent-scope
 // atomics: the access goes past L1 and is served / written through coherently) on both sides, and a signal (a

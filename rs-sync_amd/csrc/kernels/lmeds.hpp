@@ -382,7 +382,7 @@ __device__ __forceinline__ uint32_t lmeds_row(const Spline& sp, f4 A, f4 B, uint
 }
 
 // n2min: the smallest |P|^2 (bit pattern) of this thread's rows, for hypothesis()'s bound
-template <int RPT, bool SWEEP, int CAP>
+template <int RPT, bool SWEEP, int CAP, int BLOCK = kBlock> // BLOCK: threads of the workgroup (row j of thread t = j * BLOCK + t)
 __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& rays, uint32_t N, int base, float fd,
                                                const Tile& tile, float (&nrm)[RPT], uint32_t& n2min, uint32_t& near) {
     uint32_t bad = 0;
@@ -394,8 +394,8 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
         // sits at its 96 registers: the build spilled two values and ran 0.6 ms per launch SLOWER, profiles/r4_k2_allrows_ab.txt)
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
-            const f4 A = load_ray(rays.a, voff, (uint32_t)j * kBlock * 16u), B = load_ray(rays.b, voff, (uint32_t)j * kBlock * 16u);
-            (void)lmeds_row<kPathInterior, SWEEP, CAP, true>(sp, A, B, N, j * kBlock + threadIdx.x, base, fd, tile, nrm[j], &watch, j == 0);
+            const f4 A = load_ray(rays.a, voff, (uint32_t)j * BLOCK * 16u), B = load_ray(rays.b, voff, (uint32_t)j * BLOCK * 16u);
+            (void)lmeds_row<kPathInterior, SWEEP, CAP, true>(sp, A, B, N, j * BLOCK + threadIdx.x, base, fd, tile, nrm[j], &watch, j == 0);
         }
         if (!finite_f(watch.nsum)) bad = RSHIP_BAD_P;
         // never, for orientations and rays that move: redo the wave's rows with the reciprocal and safe_normalize's select
@@ -405,9 +405,9 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
             // (not unrolled: rare code kept small)
 #pragma unroll 1
             for (int j = 0; j < RPT; ++j) {
-                const f4 A = load_ray(rays.a, voff, (uint32_t)j * kBlock * 16u), B = load_ray(rays.b, voff, (uint32_t)j * kBlock * 16u);
+                const f4 A = load_ray(rays.a, voff, (uint32_t)j * BLOCK * 16u), B = load_ray(rays.b, voff, (uint32_t)j * BLOCK * 16u);
                 float t;
-                bad |= lmeds_row<kPathInterior, SWEEP, CAP, false>(sp, A, B, N, j * kBlock + threadIdx.x, base, fd, tile, t);
+                bad |= lmeds_row<kPathInterior, SWEEP, CAP, false>(sp, A, B, N, j * BLOCK + threadIdx.x, base, fd, tile, t);
                 nrm[j] = t;
             }
         }
@@ -418,8 +418,8 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
         RowWatch watch;
 #pragma unroll 1
         for (int j = 0; j < RPT; ++j) {
-            const f4 A = load_ray(rays.a, voff, (uint32_t)j * kBlock * 16u), B = load_ray(rays.b, voff, (uint32_t)j * kBlock * 16u);
-            bad |= lmeds_row<kPathGlobal, false, CAP>(sp, A, B, N, j * kBlock + threadIdx.x, base, fd, tile, tmp[j], &watch, j == 0);
+            const f4 A = load_ray(rays.a, voff, (uint32_t)j * BLOCK * 16u), B = load_ray(rays.b, voff, (uint32_t)j * BLOCK * 16u);
+            bad |= lmeds_row<kPathGlobal, false, CAP>(sp, A, B, N, j * BLOCK + threadIdx.x, base, fd, tile, tmp[j], &watch, j == 0);
         }
 #pragma unroll
         for (int j = 0; j < RPT; ++j) nrm[j] = tmp[j];
@@ -431,14 +431,14 @@ __device__ __forceinline__ uint32_t lmeds_rows(const Spline& sp, const RayRsrc& 
 
 // stage A in its fp64 form (R64 instantiations: "fp64 rows" above): this thread's rows from the fp64 streams, unit rows to
 // the tile, norms to s_nrm (LDS, so that the loop need not be unrolled and hypothesis() can look any row's norm up)
-template <int RPT>
+template <int RPT, int BLOCK = kBlock>
 __device__ __forceinline__ uint32_t lmeds_rows64(const Rows64Src& src, uint32_t off, uint32_t N, int base, double fd, const Tile& tile,
                                                  float* s_nrm, uint32_t& n2min) {
     uint32_t bad = 0;
     n2min = 0x7f000000u;
 #pragma unroll 1
     for (int j = 0; j < RPT; ++j) {
-        const uint32_t row = j * kBlock + threadIdx.x;
+        const uint32_t row = j * BLOCK + threadIdx.x;
         if (row < N) {
             const Row64 r = row64_unit(src, (size_t)off + row, base, fd);
             if (!r.finite) bad = RSHIP_BAD_P;
@@ -538,13 +538,19 @@ constexpr int kContCap = 24; // contender records per candidate; beyond that a h
 // R64 = the fp64-rows form ("fp64 rows" above; MODE 0, WIN 0): the same grid, but a workgroup leaves at once unless the
 // fp32 launch has flagged candidates of its (frame, chunk), and evaluates only those -- stage A from the fp64 streams.
 // Not a hot kernel: compiled without an occupancy target.
-template <int RPT, int MODE, int WIN, bool LAZY = true, bool R64 = false> // MODE 0: PreSync cost per candidate; 1: GuessMotion's hypothesis search (Sync start)
-__global__ __launch_bounds__(kBlock, R64 ? 1 : (RPT == 16 ? (WIN == 1 ? 3 : 2) : lmeds_waves(RPT))) void lmeds_kernel(LmedsParams p) {
+// BLOCK = threads of the workgroup: 256 (four waves) everywhere but the WIDE shape of round 6 -- frames of 4097 .. 8192 tracks
+// as RPT = 16, BLOCK = 512: eight waves, two per SIMD.  The tile of such a frame (96 KB) allows one workgroup per CU either
+// way; as four waves of 32 rows per thread (rounds 3-5: 480 VGPRs) that was ONE wave per SIMD, which issues an instruction
+// every ~5 cycles instead of every ~2.3 (DESIGN.md section 3's table): 0.35 of the benchmark class's rate per ray.
+template <int RPT, int MODE, int WIN, bool LAZY = true, bool R64 = false, int BLOCK = kBlock> // MODE 0: PreSync cost per candidate; 1: GuessMotion's hypothesis search (Sync start)
+__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : (R64 ? 1 : (RPT == 16 ? (WIN == 1 ? 3 : 2) : lmeds_waves(RPT)))) void lmeds_kernel(LmedsParams p) {
     static_assert(!R64 || (MODE == 0 && WIN == 0 && LAZY), "the fp64-rows form exists for the PreSync sweep only");
+    static_assert(BLOCK == 256 || (BLOCK == 512 && RPT == 16), "workgroup shapes: four waves, or eight for the 8192-row tile");
+    constexpr int NWAVE = BLOCK / 64;
     constexpr int CAPW = WIN == 1 ? 0 : WIN; // the window's compile-time capacity (0 = dynamic)
     constexpr int kHyp = kHypBatch;
-    constexpr int ROWS = kBlock * RPT;
-    constexpr int NR = 4 * RPT; // residual registers per lane: a wave spans the whole tile
+    constexpr int ROWS = BLOCK * RPT;
+    constexpr int NR = ROWS / 64; // residual registers per lane: a wave spans the whole tile
     __shared__ __attribute__((aligned(16))) float s_n[3][ROWS];
     f4* s_win;
     if constexpr (CAPW != 0) {
@@ -555,7 +561,7 @@ __global__ __launch_bounds__(kBlock, R64 ? 1 : (RPT == 16 ? (WIN == 1 ? 3 : 2) :
         s_win = s_win_dynamic;
     }
     __shared__ f4 s_hyp[kHyp];
-    __shared__ double s_red[2][4];
+    __shared__ double s_red[2][NWAVE];
     // best (quantile, hypothesis) so far, packed (bits << 32 | h): a 64-bit min is exactly
     // "smaller quantile wins, ties go to the earlier hypothesis" (core_private.cpp:53 strict <)
     __shared__ unsigned long long s_key;
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(kBlock, R64 ? 1 : (RPT == 16 ? (WIN == 1 ? 3 : 2) :
         s_cchi[LAZY ? kContCap : 1];
     __shared__ uint32_t s_ncont;
     __shared__ unsigned long long s_exact;
-    __shared__ uint32_t s_min2[4]; // per wave: the smallest |P|^2 (bit pattern) of the candidate's rows (hypothesis(): smin2)
+    __shared__ uint32_t s_min2[NWAVE]; // per wave: the smallest |P|^2 (bit pattern) of the candidate's rows (hypothesis(): smin2)
     __shared__ float s_nrm[R64 ? ROWS : 1]; // R64: the rows' norms (fp64, rounded once)
     const int tid = threadIdx.x, lane = tid & 63;
 #if RSSYNC_K2_TIMING && RSSYNC_K2_COUNTERS
@@ -628,11 +634,11 @@ __global__ __launch_bounds__(kBlock, R64 ? 1 : (RPT == 16 ? (WIN == 1 ? 3 : 2) :
             kd_hi = v > kd_hi ? v : kd_hi;
         }
         stage_window_ends<CAPW>(sp, s_win, frame_knots(fr, fr.base_knot + (int)floorf(fr.tmin) + kd_lo,
-                                                       fr.base_knot + (int)floorf(fr.tmax) + kd_hi + 1, kd_lo, kd_hi));
+                                                       fr.base_knot + (int)floorf(fr.tmax) + kd_hi + 1, kd_lo, kd_hi), BLOCK);
     }
 #pragma unroll
     for (int j = 0; j < RPT; ++j) { // rows beyond N: NaN once, never rewritten
-        const uint32_t row = j * kBlock + tid;
+        const uint32_t row = j * BLOCK + tid;
         if (row >= N) s_n[0][row] = s_n[1][row] = s_n[2][row] = __uint_as_float(0x7fc00000u);
     }
     __syncthreads();
@@ -663,12 +669,12 @@ __global__ __launch_bounds__(kBlock, R64 ? 1 : (RPT == 16 ? (WIN == 1 ? 3 : 2) :
         float nrm[RPT];
         uint32_t n2min;
         if constexpr (R64) {
-            bad |= lmeds_rows64<RPT>(p.src64, fr.off, N, fr.base_knot + p.kd64[c], p.fd64[c], tile, s_nrm, n2min);
+            bad |= lmeds_rows64<RPT, BLOCK>(p.src64, fr.off, N, fr.base_knot + p.kd64[c], p.fd64[c], tile, s_nrm, n2min);
 #pragma unroll
-            for (int j = 0; j < RPT; ++j) nrm[j] = s_nrm[j * kBlock + tid]; // (this thread's own stores)
+            for (int j = 0; j < RPT; ++j) nrm[j] = s_nrm[j * BLOCK + tid]; // (this thread's own stores)
         } else {
             uint32_t near;
-            bad |= lmeds_rows<RPT, MODE == 0, CAPW>(sp, rays, N, base, fd, tile, nrm, n2min, near);
+            bad |= lmeds_rows<RPT, MODE == 0, CAPW, BLOCK>(sp, rays, N, base, fd, tile, nrm, n2min, near);
             // the near-static watch ("fp64 rows" above): thread 0's wave has counted the frame's first 64 rows
             if (RSSYNC_NEAR_WATCH && MODE == 0 && p.redo_mask && tid == 0 && near_static_fires(near, N)) {
                 atomicOr(&p.redo_mask[(size_t)sf * p.mask_words + (c >> 5)], 1u << (c & 31u));
@@ -687,9 +693,8 @@ __global__ __launch_bounds__(kBlock, R64 ? 1 : (RPT == 16 ? (WIN == 1 ? 3 : 2) :
         };
         auto frame_smin2 = [&]() -> float {
             uint32_t m = s_min2[0];
-            m = s_min2[1] < m ? s_min2[1] : m;
-            m = s_min2[2] < m ? s_min2[2] : m;
-            m = s_min2[3] < m ? s_min2[3] : m;
+#pragma unroll
+            for (int w = 1; w < NWAVE; ++w) m = s_min2[w] < m ? s_min2[w] : m;
             return smin2_of(m);
         };
 
@@ -896,12 +901,12 @@ __global__ __launch_bounds__(kBlock, R64 ? 1 : (RPT == 16 ? (WIN == 1 ? 3 : 2) :
         float ss = 0.f;
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
-            const uint32_t row = j * kBlock + tid;
+            const uint32_t row = j * BLOCK + tid;
             pm[j] = mul_zero_wins(nrm[j], rs::dot(f3{tile.nx[row], tile.ny[row], tile.nz[row]}, Mv));
             ss = fmaf(pm[j], pm[j], ss);
         }
         double ss_tot;
-        K2_TIMED(3, ss_tot = block_sum(ss, s_red[0]));
+        K2_TIMED(3, ss_tot = block_sum_n<NWAVE>(ss, s_red[0]));
         // core_private.cpp:79, 100 / ||P M|| as 100 * rsq (v_rsq_f32, 1 ulp); ss = 0 gives +inf -> clamp
         float kf = 100.0f * rs::rsqrt_fast((float)ss_tot);
         kf = (kf < 10.f) ? 10.f : ((1000.f < kf) ? 1000.f : kf);
@@ -927,7 +932,7 @@ __global__ __launch_bounds__(kBlock, R64 ? 1 : (RPT == 16 ? (WIN == 1 ? 3 : 2) :
                 bad |= finite_f(rsum) ? RSHIP_BAD_RHO : RSHIP_BAD_R;
             }
             double acc_tot;
-            K2_TIMED(3, acc_tot = block_sum(acc, s_red[1]));
+            K2_TIMED(3, acc_tot = block_sum_n<NWAVE>(acc, s_red[1]));
             if (tid == 0) {
                 p.frame_cost[(size_t)c * p.n_sel + sf] = sqrt(acc_tot); // core_private.cpp:85
                 if (p.best_h) p.best_h[(size_t)c * p.n_sel + sf] = bH;
@@ -944,7 +949,7 @@ __global__ __launch_bounds__(kBlock, R64 ? 1 : (RPT == 16 ? (WIN == 1 ? 3 : 2) :
                 uint32_t* out = p.dump + (((size_t)c * p.n_sel + sf) * p.n_hyp + h) * p.dump_rows;
 #pragma unroll 1
                 for (int j = 0; j < RPT; ++j) {
-                    const uint32_t row = j * kBlock + tid;
+                    const uint32_t row = j * BLOCK + tid;
                     if (row < N && row < p.dump_rows) {
                         const v2f r01 = v2f{tile.nx[row], 0.f} * hv.x + v2f{tile.ny[row], 0.f} * hv.y + v2f{tile.nz[row], 0.f} * hv.z;
                         out[row] = __float_as_uint(r01.x) & 0x7fffffffu;

@@ -290,6 +290,7 @@ int sync_stream(rship_ctx* c) {
 }
 
 constexpr int kMaxRpt = 32; // 8192 tracks per frame in registers / LDS; larger frames take the kernels' slow paths
+constexpr int kWideBlock = 512; // the LMedS tile kernel's workgroup for 4097 .. 8192 tracks (class 4): eight waves x 16 rows per thread (kernels/lmeds.hpp: BLOCK)
 
 // ---- size classes ---------------------------------------------------------------------------------------------
 // class of a frame of n tracks (rship_ctx::cls_slots): 0 one wave per frame, 1 .. 4 four waves with 4 / 8 / 16 / 32 rows
@@ -442,7 +443,7 @@ uint32_t lmeds_dynamic_static_lds(int rpt, bool small) {
         case 4: return static_lds_of(lmeds_kernel<4, MODE, 0>);
         case 8: return static_lds_of(lmeds_kernel<8, MODE, 0>);
         case 16: return static_lds_of(lmeds_kernel<16, MODE, 0>);
-        default: return static_lds_of(lmeds_kernel<32, MODE, 0>);
+        default: return static_lds_of(lmeds_kernel<16, MODE, 0, true, false, kWideBlock>);
     }
 }
 // static LDS of the tile kernel's compiled-in-window instantiation
@@ -452,7 +453,7 @@ uint32_t lmeds_static_lds(int rpt) {
         case 4: return static_lds_of(lmeds_kernel<4, MODE, kWinMax>);
         case 8: return static_lds_of(lmeds_kernel<8, MODE, kWinMax>);
         case 16: return static_lds_of(lmeds_kernel<16, MODE, kWinMax>);
-        default: return static_lds_of(lmeds_kernel<32, MODE, kWinMax>);
+        default: return static_lds_of(lmeds_kernel<16, MODE, kWinMax, true, false, kWideBlock>);
     }
 }
 // which LMedS kernel the frames of class k get
@@ -571,8 +572,8 @@ int launch_lmeds_class(rship_ctx* c, LmedsParams p, const ClassRange& r, const W
                     hipLaunchKernelGGL((lmeds_kernel<16, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p);
                 }
                 break;
-            case 32: allow_dynamic_lds(lmeds_kernel<32, MODE, 0>, dyn);
-                     hipLaunchKernelGGL((lmeds_kernel<32, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
+            case 32: allow_dynamic_lds(lmeds_kernel<16, MODE, 0, true, false, kWideBlock>, dyn); // (4097 .. 8192 tracks: eight waves of 16 rows per thread)
+                     hipLaunchKernelGGL((lmeds_kernel<16, MODE, 0, true, false, kWideBlock>), dim3(grid), dim3(kWideBlock), dyn, c->stream, p); break;
             default: return set_err(c, "lmeds: unsupported rows-per-thread");
         }
         RS_HIP(hipGetLastError());
@@ -584,7 +585,7 @@ int launch_lmeds_class(rship_ctx* c, LmedsParams p, const ClassRange& r, const W
             case 4: hipLaunchKernelGGL((lmeds_kernel<4, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
             case 8: hipLaunchKernelGGL((lmeds_kernel<8, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
             case 16: hipLaunchKernelGGL((lmeds_kernel<16, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-            case 32: hipLaunchKernelGGL((lmeds_kernel<32, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+            case 32: hipLaunchKernelGGL((lmeds_kernel<16, 0, kWinMax, false, false, kWideBlock>), dim3(grid), dim3(kWideBlock), 0, c->stream, p); break;
             default: return set_err(c, "lmeds: unsupported rows-per-thread");
         }
         RS_HIP(hipGetLastError());
@@ -595,7 +596,8 @@ int launch_lmeds_class(rship_ctx* c, LmedsParams p, const ClassRange& r, const W
         case 4: hipLaunchKernelGGL((lmeds_kernel<4, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
         case 8: hipLaunchKernelGGL((lmeds_kernel<8, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
         case 16: hipLaunchKernelGGL((lmeds_kernel<16, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-        case 32: hipLaunchKernelGGL((lmeds_kernel<32, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+        case 32: allow_dynamic_lds(lmeds_kernel<16, MODE, kWinMax, true, false, kWideBlock>, 0);
+                 hipLaunchKernelGGL((lmeds_kernel<16, MODE, kWinMax, true, false, kWideBlock>), dim3(grid), dim3(kWideBlock), 0, c->stream, p); break;
         default: return set_err(c, "lmeds: unsupported rows-per-thread");
     }
     RS_HIP(hipGetLastError());
@@ -651,8 +653,8 @@ int launch_lmeds_redo(rship_ctx* c, const LmedsParams& p_in, double step_knots, 
                 case 4: hipLaunchKernelGGL((lmeds_kernel<4, 0, 0, true, true>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
                 case 8: hipLaunchKernelGGL((lmeds_kernel<8, 0, 0, true, true>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
                 case 16: hipLaunchKernelGGL((lmeds_kernel<16, 0, 0, true, true>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-                case 32: allow_dynamic_lds(lmeds_kernel<32, 0, 0, true, true>, 0);
-                         hipLaunchKernelGGL((lmeds_kernel<32, 0, 0, true, true>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+                case 32: allow_dynamic_lds(lmeds_kernel<16, 0, 0, true, true, kWideBlock>, 0);
+                         hipLaunchKernelGGL((lmeds_kernel<16, 0, 0, true, true, kWideBlock>), dim3(grid), dim3(kWideBlock), 0, c->stream, p); break;
                 default: return set_err(c, "lmeds (fp64 rows): unsupported rows-per-thread");
             }
         }
@@ -950,7 +952,9 @@ int rship_create(rship_ctx** out, int device) {
     if (const char* s = std::getenv("RSSYNC_FORCE_GENERAL_SPLINE")) c->force_general = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_NO_COMPACT_WINDOW")) c->no_compact = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_NO_FP64_ROWS")) c->no_fp64_rows = s[0] && s[0] != '0';
-    if (const char* s = std::getenv("RSSYNC_EXEC_BIG_MAX")) { const int v = atoi(s); if (v >= 0) c->exec_big_max = (uint32_t)v; }
+    // (at most 4096: the executor evaluates a larger frame by ONE wave in the FOUR-wave kernels' association, kernels/exec_big.hpp,
+    // and frames of 4097 .. 8192 tracks run the tile kernel in its eight-wave shape since round 6)
+    if (const char* s = std::getenv("RSSYNC_EXEC_BIG_MAX")) { const int v = atoi(s); if (v >= 0) c->exec_big_max = (uint32_t)std::min(v, 4096); }
     if (const char* s = std::getenv("RSSYNC_EXEC_BIG_SHARE")) { const int v = atoi(s); if (v >= 1) c->exec_big_share = (uint32_t)v; }
     if (const char* s = std::getenv("RSSYNC_ONE_WAVE_MAX")) { const int v = atoi(s); if (v >= 64 && v <= 64 * kSmallMaxRpt) c->one_wave_max = (uint32_t)v; }
     if (device >= 0) {

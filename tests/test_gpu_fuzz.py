@@ -221,6 +221,34 @@ def test_the_winner_is_the_exact_argmin_of_the_devices_own_residuals(seed, varia
         hprod.debug_residuals(True, cap_rows=8)
 
 
+@pytest.mark.parametrize("noise", [1e-3, 0.0])
+def test_the_anchor_in_every_size_class(noise, variants_lib):
+    """the same anchor with one frame of every kernel family in one problem: one wave per frame (130, 400 tracks), four waves
+    with 4 / 8 / 16 rows per thread (900, 2000, 3500), EIGHT waves of 16 rows (6000, 8192: round 6's shape for 4097 .. 8192
+    tracks) and the large-frame kernel (9000) -- every winner the exact arg-min of the kernel's own residuals, first wins"""
+    counts = [130, 400, 900, 2000, 3500, 6000, 8192, 9000]
+    F = len(counts)
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=77)
+    kw = dict(noise=0.0, outliers=0.0) if noise == 0.0 else dict(noise=noise)
+    frames = [next(iter(synth.make_frames(g, fr, fr + 1, n, seed=77, **kw))) for fr, n in enumerate(counts)]
+    v = rssync_amd.SyncProblem(seed=5, verbose=False, _lib=variants_lib)
+    hprod = rssync_amd.SyncProblem(seed=5, verbose=False)
+    for p in (v, hprod):
+        p.SetGyroQuaternions(g.quats, g.fs, g.t0)
+        for fr in frames:
+            p.SetTrackResult(*fr)
+    v.debug_residuals(True, cap_rows=max(counts))
+    dv, cv, fcv, bhv = v.presync_curve(synth.D_TRUE, 0, F, 0.0005, 0.004, per_frame=F)      # 16 candidates
+    res = v.debug_residuals_get()
+    assert res.shape == (len(dv), F, 20, max(counts))
+    for j, n in enumerate(counts):
+        assert not np.isnan(res[:, j, :, :n]).any() and np.isnan(res[:, j, :, n:]).all()
+    np.testing.assert_array_equal(bhv, exact_winners(res, counts))
+    dp, cp, fcp, bhp = hprod.presync_curve(synth.D_TRUE, 0, F, 0.0005, 0.004, per_frame=F)
+    np.testing.assert_array_equal(bhp, bhv)
+    np.testing.assert_allclose(fcp, fcv, rtol=2e-6)
+
+
 @pytest.mark.parametrize("seed", range(100, 106 + EXTRA))
 def test_random_clean_case_sync(seed):
     """without noise the minimum is sharp and Sync is not chaotic: both sides end at the true delay"""

@@ -64,7 +64,12 @@ def test_no_scratch_memory_and_no_matrix_instructions(code_object, kernels):
     # 4096 tracks when its spline window is small enough for a THIRD workgroup per CU -- is compiled for three waves per SIMD,
     # 168 VGPRs, and spills 44 (32) of the 213 (194) registers it wants to scratch: measured 25 % FASTER than the spill-free
     # two-workgroup instantiation (profiles/r5_k2_class3_ab.txt), which stays for the large windows of high gyro rates.
-    allowed = re.compile(r"lmeds_kernelILi16ELi[01]ELi1ELb1ELb0EEE")
+    # ... and (round 6) the EIGHT-wave shape of the same kernel for frames of 4097 .. 8192 tracks, lmeds_kernel<16, ., ., ., ., 512>:
+    # a wave's sweep holds the whole tile's 128 residuals per lane, two waves per SIMD leave 256 VGPRs, and what does not fit
+    # -- ~200 dwords -- is spilled OUTSIDE the sweep (one load per row in stage A, the rare re-sweep of overlapping contenders,
+    # stage D's norms: tools/isa_by_line.py; the hot sweep block has no scratch access): measured 22 % FASTER than the
+    # spill-free four-wave shape at ONE wave per SIMD (480 VGPRs), profiles/r6_k2_wide_ab.txt.
+    allowed = re.compile(r"lmeds_kernelILi16ELi[01]ELi1ELb1ELb0ELi256EEE|lmeds_kernelILi16ELi[01]ELi(0|80)ELb[01]ELb[01]ELi512EEE")
     funcs = re.split(r"^[0-9a-f]+ <(\S+)>:$", dis, flags=re.M)      # [preamble, name, body, name, body, ...]
     assert len(funcs) > 100
     for name, body in zip(funcs[1::2], funcs[2::2]):
@@ -74,7 +79,10 @@ def test_no_scratch_memory_and_no_matrix_instructions(code_object, kernels):
         assert not re.search(r"\bbuffer_(load|store)\w* .*\boffen\b.*\bs\[0:3\]", body), name  # (the other form of a private access)
     assert "v_mfma" not in dis
     spilling = {n: k["vgpr_spills"] for n, k in kernels.items() if k["vgpr_spills"]}   # (accumulation registers are part of gfx950's unified file: not a spill)
-    assert set(spilling) <= {"lmeds_kernel<16, 0, 1, true, false>", "lmeds_kernel<16, 1, 1, true, false>"} and all(v <= 48 for v in spilling.values()), spilling
+    narrow = {"lmeds_kernel<16, 0, 1, true, false, 256>", "lmeds_kernel<16, 1, 1, true, false, 256>"}
+    wide = {n for n in kernels if re.match(r"lmeds_kernel<16, [01], (0|80), (true|false), (true|false), 512>$", n)}
+    assert set(spilling) <= narrow | wide, spilling
+    assert all(v <= 48 for n, v in spilling.items() if n in narrow) and all(v <= 240 for n, v in spilling.items() if n in wide), spilling
     # An executor instantiation may reserve a private segment it never touches (8 SGPRs parked in a frame slot that the final
     # code keeps in VGPR lanes, plus one dword; which instantiation it hits moves with the build): known, harmless -- no
     # scratch instruction exists in the binary (asserted above) -- and pinned so that it does not grow unnoticed.
@@ -88,7 +96,7 @@ def _waves_per_simd(vgpr):
 
 
 def test_occupancy_the_design_relies_on(kernels):
-    k2 = kernels["lmeds_kernel<8, 0, 80, true, false>"]   # the benchmark's PreSync kernel
+    k2 = kernels["lmeds_kernel<8, 0, 80, true, false, 256>"]   # the benchmark's PreSync kernel
     assert k2["vgpr"] <= 96 and k2["lds"] <= 32 * 1024 - 256, k2                  # five four-wave workgroups per CU
     assert _waves_per_simd(k2["vgpr"]) >= 5 and 160 * 1024 // (k2["lds"] + 256) >= 5
     # K1: the gradient kernel (one window in dynamic LDS) and the trial kernel (five 80-knot windows side by side in
@@ -113,18 +121,25 @@ def test_occupancy_the_design_relies_on(kernels):
     # round 6: the near-static watch (kernels/lmeds.hpp, "fp64 rows") costs the hot sweep kernels no register and no LDS --
     # the numbers above are round 5's -- because the fp64 form of the rows lives in instantiations of its own (<..., true>),
     # launched only when the sweep has flagged pairs; those are not hot and carry no occupancy target, but no scratch either
-    for rpt in (4, 8, 16, 32):
-        assert kernels["lmeds_kernel<%d, 0, 0, true, true>" % rpt]["private"] == 0
+    for rpt in (4, 8, 16):
+        assert kernels["lmeds_kernel<%d, 0, 0, true, true, 256>" % rpt]["private"] == 0
+    # the eight-wave shape for 4097 .. 8192 tracks: two waves per SIMD, one workgroup per CU (its 96 KB tile)
+    wide = kernels["lmeds_kernel<16, 0, 80, true, false, 512>"]
+    assert wide["vgpr"] <= 256 and wide["max_threads"] == 512 and 96 * 1024 <= wide["lds"] <= 112 * 1024, wide
     for rpt in (1, 2, 3, 4, 8):
         assert kernels["lmeds_small_kernel<%d, 0, 0, true>" % rpt]["private"] == 0
 
 
 def test_every_instantiation_the_launchers_name_is_in_the_binary(kernels):
     have = set(kernels)
-    for rpt in (4, 8, 16, 32):
+    for rpt in (4, 8, 16):
         for mode in (0, 1):
             for win in (80, 0) + ((1,) if rpt == 16 else ()):
-                assert "lmeds_kernel<%d, %d, %d, true, false>" % (rpt, mode, win) in have
+                assert "lmeds_kernel<%d, %d, %d, true, false, 256>" % (rpt, mode, win) in have
+    for mode in (0, 1):       # 4097 .. 8192 tracks: eight waves x 16 rows per thread (round 6; four waves x 32 until then)
+        for win in (80, 0):
+            assert "lmeds_kernel<16, %d, %d, true, false, 512>" % (mode, win) in have
+    assert not [n for n in have if re.match(r"lmeds_kernel<32,", n)]
     # frames of up to 512 tracks belong to the one-wave kernels: no four-wave instantiations for 256 / 512 rows (the tests'
     # family cross-checks run them through the 1024-row ones: same bits)
     assert not [n for n in have if re.match(r"(lmeds_kernel|loss64_kernel)<[12],", n)]
@@ -136,5 +151,6 @@ def test_every_instantiation_the_launchers_name_is_in_the_binary(kernels):
     # round 2's exact selection is a TEST variant (tools/k2_build_variant.sh testvariants), never part of the product
     assert not [n for n in have if re.match(r"lmeds_kernel<\d+, \d, \d+, false", n)]
     # the fp64-rows form exists for the PreSync sweep only (MODE 0, dynamic-window shape)
-    assert sorted(n for n in have if re.match(r"lmeds_kernel<.*, true>$", n)) == sorted("lmeds_kernel<%d, 0, 0, true, true>" % r for r in (4, 8, 16, 32))
+    assert sorted(n for n in have if re.match(r"lmeds_kernel<.*, true, \d+>$", n)) == sorted(
+        ["lmeds_kernel<%d, 0, 0, true, true, 256>" % r for r in (4, 8, 16)] + ["lmeds_kernel<16, 0, 0, true, true, 512>"])
     assert sorted(n for n in have if re.match(r"lmeds_small_kernel<.*, true>$", n)) == sorted("lmeds_small_kernel<%d, 0, 0, true>" % r for r in (1, 2, 3, 4, 8))
