@@ -952,9 +952,7 @@ int rship_create(rship_ctx** out, int device) {
     if (const char* s = std::getenv("RSSYNC_FORCE_GENERAL_SPLINE")) c->force_general = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_NO_COMPACT_WINDOW")) c->no_compact = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_NO_FP64_ROWS")) c->no_fp64_rows = s[0] && s[0] != '0';
-    // (at most 4096: the executor evaluates a larger frame by ONE wave in the FOUR-wave kernels' association, kernels/exec_big.hpp,
-    // and frames of 4097 .. 8192 tracks run the tile kernel in its eight-wave shape since round 6)
-    if (const char* s = std::getenv("RSSYNC_EXEC_BIG_MAX")) { const int v = atoi(s); if (v >= 0) c->exec_big_max = (uint32_t)std::min(v, 4096); }
+    if (const char* s = std::getenv("RSSYNC_EXEC_BIG_MAX")) { const int v = atoi(s); if (v >= 0) c->exec_big_max = (uint32_t)v; }
     if (const char* s = std::getenv("RSSYNC_EXEC_BIG_SHARE")) { const int v = atoi(s); if (v >= 1) c->exec_big_share = (uint32_t)v; }
     if (const char* s = std::getenv("RSSYNC_ONE_WAVE_MAX")) { const int v = atoi(s); if (v >= 64 && v <= 64 * kSmallMaxRpt) c->one_wave_max = (uint32_t)v; }
     if (device >= 0) {
@@ -2270,6 +2268,10 @@ int rship_exec_supported(rship_ctx* c) {
     for (uint32_t i : c->h_sel)
         if (c->h_frame_n[i] < 2) return 0;
     if (c->max_n > c->one_wave_max && c->max_n > c->exec_big_max) return 0; // (a frame that large is better off with four waves: the chain of launches)
+    // frames of 4097 .. 8192 tracks (class 4) run the search in the tile kernel's EIGHT-wave shape since round 6; the executor's
+    // one-wave emulation (kernels/exec_big.hpp) reproduces the FOUR-wave association (classes 1 .. 3) and the large-frame
+    // kernel's (class 5): a selection with a class-4 frame is the chain's whatever RSSYNC_EXEC_BIG_MAX says
+    if (c->cls_off[5] != c->cls_off[4]) return 0;
     // ... and so is a selection in which the larger frames are not the exception: a one-wave task in the four-wave
     // association is ~4x a one-wave frame's (BASELINE config 3, every frame 2048 tracks: 30 ms in the executor against
     // 9.8 ms through the chain).  Stragglers only: at most one slot in eight.
