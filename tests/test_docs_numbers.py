@@ -8,21 +8,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_baseline_table_is_what_the_profiles_give():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_baseline_tables.py"), "r5", "--check"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_baseline_tables.py"), "r6", "--check"],
                        cwd=ROOT, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
 
 
 def test_design_quotes_the_committed_kernel_statistics():
-    """the figures DESIGN.md quotes for the two rooflines and the step are the ones profiles/r5_* give (three rounds in a
+    """the figures DESIGN.md quotes for the two rooflines and the step are the ones profiles/r6_* give (three rounds in a
     row a csv was re-collected and the prose was not)"""
     import csv
     import json
     prof = os.path.join(ROOT, "profiles")
-    stats = list(csv.DictReader(open(os.path.join(prof, "r5_bench_kernel_stats.csv"))))
-    k2 = [r for r in stats if "lmeds_kernel<8, 0, 80, true>" in r["Name"]][0]
+    stats = list(csv.DictReader(open(os.path.join(prof, "r6_bench_kernel_stats.csv"))))
+    k2 = [r for r in stats if "lmeds_kernel<8, 0, 80, true, false, 256>" in r["Name"]][0]
     k1 = [r for r in stats if "loss64_kernel<8, true, false" in r["Name"]][0]
-    bench = json.load(open(os.path.join(prof, "r5_bench.json")))
+    bench = [json.loads(l) for l in open(os.path.join(prof, "r6_bench.json")) if l.startswith('{"metric"')][0]
     k2_ms, k1_us = float(k2["AverageNs"]) / 1e6, float(k1["AverageNs"]) / 1e3
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     want = ["**%.2f ms**" % k2_ms,                                                  # K2's mean launch time
@@ -35,13 +35,13 @@ def test_design_quotes_the_committed_kernel_statistics():
 
 
 def test_design_gyro_rate_table_is_the_committed_sweep():
-    """DESIGN.md section 3's gyro-rate table and its small-frame paragraphs against profiles/r5_gyro_rate_sweep.json,
+    """DESIGN.md section 3's gyro-rate table and its small-frame paragraphs against profiles/r6_gyro_rate_sweep.json,
     r4_gyro_rate_small_frames.json (round 4's measurement build, which set the 144-knot rule) and r5_gyro_rate_small_frames.json
     (the compact windows) (the table was once left behind by a re-collection within the hour)"""
     import json
     prof = os.path.join(ROOT, "profiles")
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
-    sweep = json.load(open(os.path.join(prof, "r5_gyro_rate_sweep.json")))["by_gyro_hz"]
+    sweep = json.load(open(os.path.join(prof, "r6_gyro_rate_sweep.json")))["by_gyro_hz"]
     want = []
     for hz, row in sweep.items():
         want.append("%.2f" % row["large"]["ms_per_launch"]["lmeds"])                      # K2 per launch
