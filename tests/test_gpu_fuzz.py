@@ -211,11 +211,15 @@ def test_the_winner_is_the_exact_argmin_of_the_devices_own_residuals(seed, varia
         assert not np.isnan(res[:, j, :, :n]).any() and np.isnan(res[:, j, :, n:]).all()
     np.testing.assert_array_equal(bhv, exact_winners(res, counts))
     dp, cp, fcp, bhp = hprod.presync_curve(centre, lo, hi, step, radius, per_frame=nf)
-    np.testing.assert_array_equal(bhp, bhv)
-    # (the costs agree to fp32 rounding, not bit for bit: stage D is fp32 code under -ffp-contract=fast, and the variants
-    # build's kernels -- the dump's loop follows stage D -- are scheduled and contracted differently: 7e-8 on 1 of 490 here)
-    # (... on frames of >= 48 tracks; with a handful of rows the cost is made of the defining rows' residuals, rounding noise)
+    # The product against the variants build: the same sources, but two BUILDS -- the dump's loop follows stage D, and the fp32
+    # kernels are compiled under -ffp-contract=fast, so the two schedule and contract stage A and stage D differently (costs:
+    # 7e-8 on 1 of 490 in seed 300).  On frames of >= 48 tracks the winners are the same; with a handful of rows the lower
+    # quartile sits at the hypothesis' own defining rows, whose residuals are rounding noise (1e-8): there a last bit of a row
+    # decides and the two builds may differ (seed 389: 4 of 322 pairs, all on frames of 5 .. 30 tracks) -- each build's winner
+    # being the exact arg-min of ITS OWN residuals is what the anchor above demands, of the build that can show them.
     big = np.array([n >= 48 for n in counts])
+    diff = np.argwhere(bhp != bhv)
+    assert all(not big[j] for _, j in diff), [(int(c), int(j), counts[j]) for c, j in diff]
     np.testing.assert_allclose(fcp[:, big], fcv[:, big], rtol=2e-6)
     with pytest.raises(rssync_amd.RsSyncError):                      # the product has no such code
         hprod.debug_residuals(True, cap_rows=8)
@@ -227,7 +231,8 @@ def test_random_mixtures_of_near_static_and_ordinary_frames(seed):
     eight-wave tile), each near-static (translation 3e-6 .. 3e-4 m per frame, ray noise in proportion) or ordinary, a random
     gyro rate, candidates a few microseconds apart around the truth in chunks of random length.  Against the oracle: the
     winners of every frame of >= 48 tracks agree in >= 98 % of the pairs (near-static or not), costs to 3e-3 where they do;
-    every pair of a strongly near-static frame took the fp64 form, no pair of an ordinary frame did; a second sweep finds the
+    exactly the pairs whose fp64 rows (the oracle's) say so took the fp64 form -- a near-static frame is only near-static close to
+    the true delay --, no pair of an ordinary frame did; a second sweep finds the
     bitmap clean (the same bits, the count doubled)."""
     rng = np.random.default_rng(7000 + seed)
     fs = RATES[int(rng.integers(len(RATES)))]
@@ -256,9 +261,23 @@ def test_random_mixtures_of_near_static_and_ordinary_frames(seed):
     assert same.mean() >= 0.98, (same.mean(), sizes, kind)
     np.testing.assert_allclose(fch[:, big][same], fco[:, big][same], rtol=3e-3)
     st = h.near_static_stats()
-    strong = sum(1 for k in kind if k is not None and k <= 3e-5)          # median |P| ~ translation / 20 <= 1.5e-6: far below the watch's 2e-4
-    ordinary = sum(1 for k in kind if k is None)
-    assert strong * nc <= st["pairs"] <= (F - ordinary) * nc, (st, strong, ordinary, nc, kind)
+    # which pairs SHOULD have taken the fp64 form, from the oracle's fp64 rows: a quarter or more of the frame's first 64 rows
+    # with |P| < 2e-4 (a near-static frame is only near-static close to the true delay: 0.5 ms away its rows are ordinary).
+    # Pairs whose fraction is within one row of the quarter may fall either way (the device counts fp32 rows).
+    sure = unsure = 0
+    for fr, n in enumerate(sizes):
+        if kind[fr] is None:
+            continue
+        m = min(n, 64)
+        for c in range(nc):
+            P = o.problem_matrix(fr, float(do[c]))[:m]
+            k = int(np.sum(np.einsum("ij,ij->i", P, P) < 4e-8))
+            if 4 * (k - 1) >= m:
+                sure += 1
+            elif 4 * (k + 1) >= m:
+                unsure += 1
+    assert sure <= st["pairs"] <= sure + unsure, (st, sure, unsure, nc, kind)
+    assert sure > 0 or all(k is None for k in kind) or unsure > 0 or st["pairs"] == 0
     d2, c2, fc2, bh2 = h.presync_curve(centre, 0, F, step, radius, per_frame=F)
     np.testing.assert_array_equal(fc2.view(np.uint64), fch.view(np.uint64))
     np.testing.assert_array_equal(bh2, bhh)
