@@ -154,9 +154,10 @@ int rssync_ext_executor_mismatches(rssync_problem* p, uint64_t* count);
 /* Near-static footage (a camera on a tripod, a slow pan: rows of the residual matrix below ~2e-4).  The reference computes
  * rows, norms and the safe_normalize decisions in double (core_private.cpp:19-28,45-46, inline_utils.hpp:5-11); PreSync's
  * fp32 sweep recomputes exactly those (frame, candidate) pairs from the fp64 streams.  *pairs = pairs recomputed so far on
- * this object, *sweeps = sweeps (PreSync / DebugPreSync / curve calls, per slice) that needed it.  Both stay 0 on ordinary
+ * this object, *sweeps = sweeps (PreSync / DebugPreSync / curve calls, per slice) that needed it, *searches = GuessMotion
+ * searches (one per frame and Sync call) that took their rows from the fp64 streams, in place.  All stay 0 on ordinary
  * footage; RSSYNC_NO_FP64_ROWS=1 (read when a problem is created) switches the mechanism off. */
-int rssync_ext_near_static_stats(rssync_problem* p, uint64_t* pairs, uint64_t* sweeps);
+int rssync_ext_near_static_stats(rssync_problem* p, uint64_t* pairs, uint64_t* sweeps, uint64_t* searches);
 /* TEST-VARIANTS build of the library only (the product returns an error): later PreSync-type sweeps also store the
  * |residual| bit patterns the LMedS selection worked on; _get returns the last sweep's, [candidate][frame of the selection]
  * [hypothesis][cap_rows] as uint32 (0xffffffff: no such row), dims = {candidates, frames, hypotheses, cap_rows} (out NULL:

@@ -224,15 +224,16 @@ int rship_presync_batch_collect(rship_ctx* c, uint32_t n_cand, double* win_costs
  * residuals' lower quartile with the reference's first-wins rule (core_private.cpp:48-56), no tolerance. */
 int rship_debug_residuals(rship_ctx* c, int on, uint32_t cap_rows);
 int rship_debug_residuals_get(rship_ctx* c, uint32_t* out, uint64_t n_words, uint32_t dims[4]);
-/* out[0] = (frame, candidate) pairs recomputed with fp64 rows so far on this context, out[1] = sweeps that needed it */
-int rship_near_static_stats(rship_ctx* c, uint64_t out[2]);
+/* out[0] = (frame, candidate) pairs recomputed with fp64 rows so far on this context, out[1] = sweeps that needed it,
+ * out[2] = GuessMotion searches (rship_init_motion, the window executor) that took their rows from the fp64 streams */
+int rship_near_static_stats(rship_ctx* c, uint64_t out[3]);
 
 /* FrameState::GuessMotion (core_private.cpp:125-128): the 200-hypothesis LMedS search for every selected
  * slot, in the fp32 tile kernel; kd/fd hold one delay per window (fp32 split), window w samples with
  * stream + w * stream_stride.  Only the winning hypothesis index per slot is kept (on the device); the
  * next rship_opt_motion -- or rship_finish_init -- recomputes the winning pair of rows in fp64,
  * M = safe_normalize(P[i0] x P[i1]), and GuessK (:130-133) k = clamp(100 / |P M|, 10, 1000).  Asynchronous. */
-int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_hyp,
+int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, const int32_t* kd64, const double* fd64, uint32_t n_hyp,
                       uint32_t stream, uint32_t stream_stride, uint64_t seed);
 /* finish a pending rship_init_motion at the same delays (fp64 split) without optimising */
 int rship_finish_init(rship_ctx* c, const int32_t* kd, const double* fd);

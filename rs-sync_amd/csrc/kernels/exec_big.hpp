@@ -63,14 +63,16 @@ __device__ __forceinline__ void exec_big_init(const LmedsParams& p, uint32_t sf,
 
     // ---- stage A: unit rows and norms -> the tile, as the tile kernel's four waves compute them ----
     uint32_t n2min = 0x7f000000u; // the smallest |P|^2 of the frame (hypothesis(): smin2)
+    uint32_t near = 0;            // the near-static watch of virtual wave 0 (lmeds.hpp: the frame's first 64 rows)
     if (sp.path == kPathInterior) {
         for (uint32_t vw = 0; vw < 4u; ++vw) { // virtual wave vw of lmeds_kernel: rows 256 j + 64 vw + lane
             RowWatch watch;
             for (uint32_t row = vw * 64u + lane; row < N; row += kBlock) {
                 float nrm;
-                (void)lmeds_row<kPathInterior, false, 0, true>(sp, ra[row], rb[row], N, row, base, fd, tile, nrm, &watch);
+                (void)lmeds_row<kPathInterior, false, 0, true>(sp, ra[row], rb[row], N, row, base, fd, tile, nrm, &watch, row < 64u);
                 g_nrm[row] = nrm;
             }
+            if (vw == 0u) near = watch.near;
             uint32_t vbad = finite_f(watch.nsum) ? 0u : (uint32_t)RSHIP_BAD_P;
             if (__builtin_amdgcn_ballot_w64(watch.qerr >= kNewtonMaxErr || watch.below_safe_normalize()) != 0) { // (lmeds_rows: per wave)
                 vbad = 0;
@@ -87,16 +89,36 @@ __device__ __forceinline__ void exec_big_init(const LmedsParams& p, uint32_t sf,
         RowWatch watch;
         for (uint32_t row = lane; row < N; row += 64u) {
             float nrm;
-            bad |= lmeds_row<kPathGlobal, false, 0>(sp, ra[row], rb[row], N, row, base, fd, tile, nrm, &watch);
+            bad |= lmeds_row<kPathGlobal, false, 0>(sp, ra[row], rb[row], N, row, base, fd, tile, nrm, &watch, row < 64u);
             g_nrm[row] = nrm;
         }
         n2min = watch.n2min;
+        near = watch.near;
+    }
+    // a near-static frame: the rows once more from the fp64 streams, as the launch chain's search kernel of the frame's class
+    // takes them in place (lmeds.hpp MODE 1, lmeds_big.hpp): the same decision from the same 64 rows, the same rows
+    const bool use64 = RSSYNC_NEAR_WATCH && p.src64.coef && near_static_fires(near, N);
+    int base64 = 0;
+    double fd64 = 0.0;
+    if (use64) {
+        base64 = fr.base_knot + ld_m<SC1>(&p.kd64[g]);
+        fd64 = ld_m<SC1>(&p.fd64[g]);
+        bad = 0;
+        n2min = 0x7f000000u;
+        for (uint32_t row = lane; row < N; row += 64u) {
+            const Row64 r = row64_unit(p.src64, (size_t)fr.off + row, base64, fd64);
+            if (!r.finite) bad = RSHIP_BAD_P;
+            tile.nx[row] = r.n.x; tile.ny[row] = r.n.y; tile.nz[row] = r.n.z;
+            g_nrm[row] = r.nrm;
+            n2min = min(n2min, __float_as_uint(r.n2));
+        }
+        if (lane == 0) atomicAdd(p.redo_count + 1, 1ull);
     }
     // hypothesis(): as the kernel of the frame's class has it -- the tile kernel's bound and recomputed norms (lmeds.hpp),
     // or, for a frame of more than 8192 tracks, the stored norms directly (lmeds_big.hpp)
     const float smin2 = general ? 0.f : smin2_of(wave_min_u32(n2min));
     auto row_scale = [&](uint32_t row) -> float {
-        if (general) return g_nrm[row];
+        if (general || use64) return g_nrm[row]; // (the fp64 form: the norms of stage A; the tile kernel recomputes the same value)
         return row_scale_general(p.coef, p.n_knots, ra[row], rb[row], base, fd);
     };
     __syncthreads(); // (one wave: the tile's stores are ordered before the loads below)

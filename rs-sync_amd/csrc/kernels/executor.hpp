@@ -357,6 +357,12 @@ __device__ __forceinline__ void exec_decide(const ExecParams& p, uint32_t w, Exe
                     int32_t ikd; float ifd;
                     split32_dev(s.d, p.lp.fs, &ikd, &ifd);
                     st_m<true>(&p.in_kd[w], ikd); st_m<true>(&p.in_fd[w], ifd);
+                    if (p.init.kd64) { // the same delay split in fp64, for a near-static frame's search (kernels/lmeds_small.hpp, MODE 1)
+                        int32_t kd64; double fd64;
+                        split64_dev(s.d, p.lp.fs, &kd64, &fd64);
+                        st_m<true>(const_cast<int32_t*>(&p.init.kd64[w]), kd64);
+                        st_m<true>(const_cast<double*>(&p.init.fd64[w]), fd64);
+                    }
                     L->phase = kPhInit;
                 } else {
                     split64_dev(s.d, p.lp.fs, &kd, &fd); // :333

@@ -81,7 +81,7 @@ struct LmedsParams {
     Rows64Src src64;
     const int32_t* kd64;
     const double* fd64;
-    unsigned long long* redo_count; // pairs recomputed in fp64 so far (debug ABI: rship_near_static_stats)
+    unsigned long long* redo_count; // [0] PreSync pairs recomputed in fp64 so far, [1] GuessMotion searches that took the fp64 form (debug ABI: rship_near_static_stats)
     // ---- TEST-VARIANTS build only (-DRSSYNC_TEST_VARIANTS=1; the product's kernels have no such code) ----
     // dump (or null): the |residual| bit patterns of the sweep itself, [candidate][slot][hypothesis][dump_rows] -- every
     // hypothesis of every (frame, candidate) against the tile and the directions the selection worked on -- so that a test
@@ -452,6 +452,28 @@ __device__ __forceinline__ uint32_t lmeds_rows64(const Rows64Src& src, uint32_t 
     return bad;
 }
 
+// ... and with the norms in the thread's registers (GuessMotion's search, MODE 1, which takes the fp64 form IN PLACE when the
+// watch fires: one candidate per workgroup, no second launch; not a hot kernel)
+template <int RPT, int BLOCK = kBlock>
+__device__ __forceinline__ uint32_t lmeds_rows64_reg(const Rows64Src& src, uint32_t off, uint32_t N, int base, double fd, const Tile& tile,
+                                                     float (&nrm)[RPT], uint32_t& n2min) {
+    uint32_t bad = 0;
+    n2min = 0x7f000000u;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        const uint32_t row = j * BLOCK + threadIdx.x;
+        nrm[j] = 0.f;
+        if (row < N) {
+            const Row64 r = row64_unit(src, (size_t)off + row, base, fd);
+            if (!r.finite) bad = RSHIP_BAD_P;
+            tile.nx[row] = r.n.x; tile.ny[row] = r.n.y; tile.nz[row] = r.n.z;
+            nrm[j] = r.nrm;
+            n2min = min(n2min, __float_as_uint(r.n2));
+        }
+    }
+    return bad;
+}
+
 // waves per SIMD the LMedS kernel is compiled for (second __launch_bounds__ argument).  Up to 2048 rows
 // (8 per thread) the 24 KB tile lets five workgroups share a CU; 4096 / 8192 rows (16 / 32 per thread, 48 /
 // 96 KB of tile, 64 / 128 residual registers per lane) run at two / one -- slower per row, but a frame of a
@@ -574,6 +596,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : (R64 ? 1 : (RPT == 16 ? (
     __shared__ unsigned long long s_exact;
     __shared__ uint32_t s_min2[NWAVE]; // per wave: the smallest |P|^2 (bit pattern) of the candidate's rows (hypothesis(): smin2)
     __shared__ float s_nrm[R64 ? ROWS : 1]; // R64: the rows' norms (fp64, rounded once)
+    __shared__ uint32_t s_near1;            // MODE 1: the frame is near-static (decided by wave 0, read by all)
     const int tid = threadIdx.x, lane = tid & 63;
 #if RSSYNC_K2_TIMING && RSSYNC_K2_COUNTERS
     long long k2_bar = 0, k2_by[4] = {0, 0, 0, 0};
@@ -668,6 +691,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : (R64 ? 1 : (RPT == 16 ? (
         // ---- stage A: rows of P -> LDS tile as unit rows; norms stay in registers ----
         float nrm[RPT];
         uint32_t n2min;
+        bool use64 = false;   // MODE 1: this frame's rows were taken from the fp64 streams (near-static)
+        int base64 = 0;
+        double fd64 = 0.0;
         if constexpr (R64) {
             bad |= lmeds_rows64<RPT, BLOCK>(p.src64, fr.off, N, fr.base_knot + p.kd64[c], p.fd64[c], tile, s_nrm, n2min);
 #pragma unroll
@@ -680,16 +706,34 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : (R64 ? 1 : (RPT == 16 ? (
                 atomicOr(&p.redo_mask[(size_t)sf * p.mask_words + (c >> 5)], 1u << (c & 31u));
                 bad |= RSHIP_NEAR_STATIC;
             }
+            if constexpr (MODE == 1 && RSSYNC_NEAR_WATCH) {
+                // GuessMotion's search: one candidate per workgroup, so the fp64 form of the rows is taken right here (the
+                // same decision, the same rows as the sweep's second launch; the window executor's search task does the same,
+                // kernels/lmeds_small.hpp / exec_big.hpp, so that executor and launch chain pick the same winner bit for bit)
+                if (tid == 0) s_near1 = (p.src64.coef && near_static_fires(near, N)) ? 1u : 0u;
+                __syncthreads();
+                use64 = s_near1 != 0u;
+                if (use64) {
+                    base64 = fr.base_knot + p.kd64[c * p.n_grp + g];
+                    fd64 = p.fd64[c * p.n_grp + g];
+                    bad = lmeds_rows64_reg<RPT, BLOCK>(p.src64, fr.off, N, base64, fd64, tile, nrm, n2min);
+                    if (tid == 0) atomicAdd(p.redo_count + 1, 1ull);
+                }
+            }
         }
         {   // (written before the "tile written" barrier below, read by the hypotheses' lanes after it; the next
             // candidate's write comes after this candidate's last barrier)
             const uint32_t wmin = wave_min_u32(n2min);
             if (lane == 0) s_min2[tid >> 6] = wmin;
         }
-        // |P_row| for hypothesis(), from the rays (R64: the norms of stage A, in LDS -- read after the "tile written" barrier)
+        // |P_row| for hypothesis(), from the rays (R64: the norms of stage A, in LDS -- read after the "tile written" barrier;
+        // MODE 1 in its fp64 form: the row once more in fp64, the value stage A had)
         auto row_scale = [&](uint32_t row) -> float {
             if constexpr (R64) return s_nrm[row];
-            else return row_scale_general(p.coef, p.n_knots, load_ray(rays.a, row * 16u, 0u), load_ray(rays.b, row * 16u, 0u), base, fd);
+            else {
+                if (MODE == 1 && use64) return row64_unit(p.src64, (size_t)fr.off + row, base64, fd64).nrm;
+                return row_scale_general(p.coef, p.n_knots, load_ray(rays.a, row * 16u, 0u), load_ray(rays.b, row * 16u, 0u), base, fd);
+            }
         };
         auto frame_smin2 = [&]() -> float {
             uint32_t m = s_min2[0];

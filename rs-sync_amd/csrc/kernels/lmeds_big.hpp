@@ -20,7 +20,7 @@ template <int MODE> // as lmeds_kernel: 0 PreSync cost per candidate, 1 GuessMot
 __global__ __launch_bounds__(kBlock) void lmeds_big_kernel(LmedsParams p) {
     __shared__ double s_red[2][4];
     __shared__ uint32_t s_cnt[2][4];
-    __shared__ uint32_t s_near; // MODE 0: this candidate's rows are redone in fp64 (lmeds.hpp, "fp64 rows")
+    __shared__ uint32_t s_near; // this candidate's rows are redone in fp64 (lmeds.hpp, "fp64 rows")
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t rows = p.scratch_rows; // a multiple of kBlock, >= the largest frame
     float* const mine = p.scratch + (size_t)blockIdx.x * rows * kBigScratchFloats;
@@ -77,19 +77,19 @@ __global__ __launch_bounds__(kBlock) void lmeds_big_kernel(LmedsParams p) {
             }
             // the near-static watch (lmeds.hpp, "fp64 rows"): thread 0's wave has counted the frame's first 64 rows.  This
             // kernel is the slow exact path anyway: the fp64 form of the rows is taken right here, no second launch.
-            if (MODE == 0 && tid == 0) s_near = (p.src64.coef && near_static_fires(watch.near, N)) ? 1u : 0u;
+            if (tid == 0) s_near = (p.src64.coef && near_static_fires(watch.near, N)) ? 1u : 0u;
             __syncthreads();
-            if (MODE == 0 && s_near) {
+            if (s_near) { // (MODE 1 as well: GuessMotion's search takes the fp64 form in place in every kernel family)
                 bad = 0;
-                const int base64 = fr.base_knot + p.kd64[c];
-                const double fd64 = p.fd64[c];
+                const int base64 = fr.base_knot + p.kd64[c * p.n_grp + g];
+                const double fd64 = p.fd64[c * p.n_grp + g];
                 for (uint32_t row = tid; row < N; row += kBlock) {
                     const Row64 r = row64_unit(p.src64, (size_t)fr.off + row, base64, fd64);
                     if (!r.finite) bad = RSHIP_BAD_P;
                     tile.nx[row] = r.n.x; tile.ny[row] = r.n.y; tile.nz[row] = r.n.z;
                     g_nrm[row] = r.nrm;
                 }
-                if (tid == 0) atomicAdd(p.redo_count, 1ull);
+                if (tid == 0) atomicAdd(p.redo_count + (MODE == 1 ? 1 : 0), 1ull);
                 __syncthreads();
             }
 

@@ -122,7 +122,7 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
                     else residual_row<false, kPathGlobal, false, CAP>(sp, A, B, base, fd, P, dP);
                     const float n2 = rs::dot(P, P);
                     // the near-static watch (lmeds.hpp): of the frame's first 64 rows -- the lanes active here -- how many are tiny
-                    if (RSSYNC_NEAR_WATCH && MODE == 0 && j == 0 && watch) watch->near = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(n2 < kNearStatic2));
+                    if (RSSYNC_NEAR_WATCH && j == 0 && watch) watch->near = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(n2 < kNearStatic2));
                     if (FAST) {
                         const float inv = rs::rsqrt_fast(n2);
                         nx[j] = P.x * inv; ny[j] = P.y * inv; nz[j] = P.z * inv;
@@ -142,10 +142,14 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
             }
         };
         RowWatch watch;
-        if constexpr (R64) {
-            // the fp64 form of the rows (rows64.hpp: row64_unit): unit rows and norms from the fp64 streams, rounded once
-            const int base64 = fr.base_knot + p.kd64[c];
-            const double fd64 = p.fd64[c];
+        // the fp64 form of the rows (rows64.hpp: row64_unit): unit rows and norms from the fp64 streams, rounded once.  R64: the
+        // sweep's second launch; MODE 1 (GuessMotion's search, one candidate per wave): taken IN PLACE when the watch fires -- in
+        // the launch chain's kernel and in the window executor's search task alike (the same body: the same winner)
+        int base64 = 0;
+        double fd64 = 0.0;
+        auto rows64 = [&]() {
+            bad = 0;
+            watch.n2min = 0x7f000000u;
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
                 const uint32_t row = j * 64 + lane;
@@ -160,8 +164,14 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
                     watch.n2min = min(watch.n2min, __float_as_uint(r.n2));
                 }
                 s_n[0][row] = nx[j]; s_n[1][row] = ny[j]; s_n[2][row] = nz[j];
-                s_nrm[row] = nrm[j];
+                if (s_nrm) s_nrm[row] = nrm[j];
             }
+        };
+        bool use64 = R64;
+        if constexpr (R64) {
+            base64 = fr.base_knot + p.kd64[c];
+            fd64 = p.fd64[c];
+            rows64();
         } else if (sp.path == kPathInterior) {
             rows(std::true_type{}, &watch);
             if (!finite_f(watch.nsum)) bad = RSHIP_BAD_P;
@@ -179,13 +189,23 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
                     bad |= RSHIP_NEAR_STATIC;
                 }
             }
+            if (RSSYNC_NEAR_WATCH && MODE == 1 && p.src64.coef && near_static_fires(watch.near, N)) { // (wave-uniform)
+                use64 = true;
+                base64 = fr.base_knot + ld_m<SC1>(&p.kd64[c * p.n_grp + g]);
+                fd64 = ld_m<SC1>(&p.fd64[c * p.n_grp + g]);
+                rows64();
+                if (lane == 0) atomicAdd(p.redo_count + 1, 1ull);
+            }
         }
         __syncthreads(); // the wave's rows are in LDS
         // hypothesis(): the bound from the frame's smallest |P|^2, and |P_row| from the rays (the tile kernel's values, lmeds.hpp)
         const float smin2 = smin2_of(wave_min_u32(watch.n2min));
         auto row_scale = [&](uint32_t row) -> float {
             if constexpr (R64) return s_nrm[row]; // (the norms of the fp64 rows)
-            else return row_scale_general(p.coef, p.n_knots, load_ray(rays.a, row * 16u, 0u), load_ray(rays.b, row * 16u, 0u), base, fd);
+            else {
+                if (MODE == 1 && use64) return row64_unit(p.src64, (size_t)fr.off + row, base64, fd64).nrm; // (the value stage A had)
+                return row_scale_general(p.coef, p.n_knots, load_ray(rays.a, row * 16u, 0u), load_ray(rays.b, row * 16u, 0u), base, fd);
+            }
         };
 
         // ---- the hypotheses, in order.  The previous candidate's best quantile (x1.25) is a provisional bound

@@ -172,13 +172,14 @@ struct rship_ctx {
     // NEAR-STATIC frames: rows in fp64 (kernels/lmeds.hpp, "fp64 rows").  redo_mask: one bit per (slot, candidate), all zero
     // between calls (the R64 kernels clear what they serve); redo_count: pairs recomputed (device counter);
     // what the last presync enqueue left for a redo at collect time
-    DevBuf redo_mask, redo_delays, redo_count;
+    DevBuf redo_mask, redo_delays, redo_count, init_delays64; // (redo_count: two counters -- PreSync pairs, GuessMotion searches)
     bool no_fp64_rows = false;  // RSSYNC_NO_FP64_ROWS=1 (read at creation; the "before" column of profiles/r6_near_static.json): the watch is off
     bool redo_dirty = true;     // the mask may hold bits (fresh allocation, a call that failed half-way): cleared before the next sweep
     uint64_t near_launches = 0; // sweeps that went through the fp64 form
     struct PendRedo { bool armed = false; LmedsParams p{}; double step_knots = 0; uint32_t chunk = 1; bool uploaded = false; } pend_redo;
     std::vector<int32_t> h_kd64r;
     std::vector<double> h_fd64r;
+    std::vector<uint32_t> h_init64; // staging of rship_init_motion's fp64 delays
     // A BATCH of sweeps collected together (rship_presync_batch_begin: the orientation sweep, BASELINE config 5): the results
     // of sweep b of n go to slot b of the (n times larger) sum / flag buffers, nothing is waited for in between
     uint32_t batch_n = 0, batch_next = 0, batch_rows = 0;
@@ -622,6 +623,14 @@ int launch_lmeds(rship_ctx* c, const LmedsParams& p, double step_knots, uint32_t
     return 0;
 }
 
+// the two device counters of the fp64 rows (PreSync pairs; GuessMotion searches), zeroed when first allocated
+int ensure_redo_count(rship_ctx* c) {
+    if (c->redo_count.p) return 0;
+    if (ensure(c, c->redo_count, 16)) return 1;
+    RS_HIP(hipMemsetAsync(c->redo_count.p, 0, 16, c->stream));
+    return 0;
+}
+
 // The fp64-rows form of a PreSync sweep (kernels/lmeds.hpp, "fp64 rows"): per size class the SAME grid and chunking as the
 // fp32 launch (the plan is a function of the context's state, which has not changed since), R64 instantiations; a
 // workgroup whose (frame, chunk) has no flagged candidate leaves at once.  Class 5 has taken its fp64 rows in the first
@@ -989,7 +998,7 @@ void rship_destroy(rship_ctx* c) {
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     DevBuf* bufs[] = {&c->coef, &c->coef64, &c->raw, &c->rays_a, &c->rays_b, &c->rays64, &c->frames, &c->sel, &c->M, &c->k, &c->grp, &c->grp_off,
                       &c->plan_idx, &c->plan_chunk_off, &c->plan_win_off, &c->chunk_out, &c->win_out, &c->loop_state, &c->kd, &c->kd64, &c->init_h,
-                      &c->frame_cost, &c->best_h, &c->costs, &c->part, &c->flags, &c->stats, &c->redo_mask, &c->redo_delays, &c->redo_count, &c->dump,
+                      &c->frame_cost, &c->best_h, &c->costs, &c->part, &c->flags, &c->stats, &c->redo_mask, &c->redo_delays, &c->redo_count, &c->init_delays64, &c->dump,
                       &c->big_scratch, &c->mo_scratch, &c->mo_evals, &c->mo_order,
                       &c->g_ts, &c->g_rates, &c->g_us, &c->g_dq, &c->g_q, &c->g_knots, &c->g_cf, &c->g_status};
     for (DevBuf* b : bufs)
@@ -1549,13 +1558,11 @@ int rship_presync_enqueue(rship_ctx* c, const int32_t* kd, const float* fd, cons
         const uint32_t words = (n_cand + 31u) / 32u;
         const size_t mask_bytes = (size_t)ns * words * 4;
         const void* before = c->redo_mask.p;
-        const void* cnt_before = c->redo_count.p;
-        if (ensure(c, c->redo_mask, mask_bytes) || ensure(c, c->redo_count, 8)) return 1;
+        if (ensure(c, c->redo_mask, mask_bytes) || ensure_redo_count(c)) return 1;
         if (c->redo_mask.p != before || c->redo_dirty) {
             RS_HIP(hipMemsetAsync(c->redo_mask.p, 0, c->redo_mask.cap, c->stream));
             c->redo_dirty = false;
         }
-        if (c->redo_count.p != cnt_before) RS_HIP(hipMemsetAsync(c->redo_count.p, 0, 8, c->stream));
         c->h_kd64r.assign(n_cand, 0);
         c->h_fd64r.assign(n_cand, 0.0);
         for (uint32_t i = 0; i < n_cand; ++i) {
@@ -1771,7 +1778,7 @@ int prepare_order_all(rship_ctx* c) { return prepare_order(c, {{0u, c->n_sel}});
 // FrameState::GuessMotion's hypothesis search (core_private.cpp:125-128 -> :34-59, 200 hypotheses) in the
 // fp32 tile kernel at one delay per group (kd/fd); the winners stay on the device and the next
 // rship_opt_motion / rship_finish_init turns them into M and k in fp64.  Asynchronous.
-int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_hyp, uint32_t stream,
+int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, const int32_t* kd64, const double* fd64, uint32_t n_hyp, uint32_t stream,
                       uint32_t stream_stride, uint64_t seed) {
     DeviceGuard dev_guard(c);
     if (check_ready(c)) return 1;
@@ -1798,6 +1805,26 @@ int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t
     p.n_grp = c->n_grp;
     p.best_h = (int32_t*)c->init_h.p;
     p.flags = (uint32_t*)c->flags.p;
+    // near-static frames: the search takes its rows from the fp64 streams IN PLACE (kernels/lmeds.hpp, MODE 1): the fp64
+    // split of the windows' delays (kd64 / fd64 [n_grp]; without them the fp32 split, widened)
+    if (!c->no_fp64_rows && c->rays64.p && c->coef64.p) {
+        const uint32_t ng = c->n_grp;
+        const size_t pad = ((size_t)ng + 1) / 2 * 2;
+        if (ensure(c, c->init_delays64, pad * 4 + (size_t)ng * 8) || ensure_redo_count(c)) return 1;
+        // one staged copy (as upload_delays64: kd[ng] as int32, padded to 8 bytes, then fd[ng])
+        c->h_init64.assign(pad + 2 * (size_t)ng, 0u);
+        for (uint32_t i = 0; i < ng; ++i) {
+            const int32_t k = kd64 ? kd64[i] : kd[i];
+            const double f = fd64 ? fd64[i] : (double)fd[i];
+            memcpy(&c->h_init64[i], &k, 4);
+            memcpy(&c->h_init64[pad + 2 * (size_t)i], &f, 8);
+        }
+        RS_HIP(hipMemcpyAsync(c->init_delays64.p, c->h_init64.data(), pad * 4 + (size_t)ng * 8, hipMemcpyHostToDevice, c->stream));
+        p.src64 = Rows64Src{rays64_of(c), (const d4*)c->coef64.p, (int)c->n_knots};
+        p.kd64 = (const int32_t*)c->init_delays64.p;
+        p.fd64 = (const double*)((const char*)c->init_delays64.p + pad * 4);
+        p.redo_count = (unsigned long long*)c->redo_count.p;
+    }
     if (launch_lmeds<1>(c, p, 0.0, 1u, &c->last_init_cap, nullptr)) return 1;
     c->init_pending = true;
     c->init_seed = seed;
@@ -2341,6 +2368,7 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t o_win = take(W * sizeof(ExecWin));
     const size_t o_inkd = take(W * 4), o_infd = take(W * 4), o_stream = take(W * 4);
+    const size_t o_inkd64 = take(W * 4), o_infd64 = take(W * 8); // the search's delay split in fp64 (near-static frames: fp64 rows in place)
     const size_t o_mokd = take(W * 4), o_mofd = take(W * 8), o_lgkd = take(W * 4), o_lgfd = take(W * 8);
     const size_t o_trkd = take((size_t)kMaxBt * W * 4), o_trfd = take((size_t)kMaxBt * W * 8);
     // the four control words -- queue head, queue tail, windows done, abort flag -- each on a 128-byte line of its own:
@@ -2381,8 +2409,9 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
 
     // host-side initial state: every window in its first call, its slots queued for the search
     std::vector<ExecWin> hw(W);
-    std::vector<int32_t> in_kd(W);
+    std::vector<int32_t> in_kd(W), in_kd64(W);
     std::vector<float> in_fd(W);
+    std::vector<double> in_fd64(W);
     std::vector<uint32_t> streams(W);
     std::vector<unsigned long long> queue(q_cap, 0ull);
     const double kClamp = (double)(1 << 29);
@@ -2401,6 +2430,13 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
         streams[w] = stream_first + w * stream_stride;
         // the fp32 split of the host solver (sync_problem.cpp: split_delay)
         const double D = d0[w] * c->fs;
+        in_kd64[w] = 0; in_fd64[w] = 0.0; // (sync_problem.cpp: split_delay64)
+        if (std::isfinite(D)) {
+            const double fl64 = std::floor(D);
+            if (fl64 > kClamp) in_kd64[w] = (int32_t)kClamp;
+            else if (fl64 < -kClamp) in_kd64[w] = (int32_t)-kClamp;
+            else { in_kd64[w] = (int32_t)fl64; in_fd64[w] = D - fl64; }
+        }
         if (!std::isfinite(D)) { in_kd[w] = 0; in_fd[w] = 0.f; }
         else {
             double fl = std::floor(D);
@@ -2417,6 +2453,8 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     RS_HIP(hipMemcpyAsync(base + o_win, hw.data(), W * sizeof(ExecWin), hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipMemcpyAsync(base + o_inkd, in_kd.data(), W * 4, hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipMemcpyAsync(base + o_infd, in_fd.data(), W * 4, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemcpyAsync(base + o_inkd64, in_kd64.data(), W * 4, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(hipMemcpyAsync(base + o_infd64, in_fd64.data(), W * 8, hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipMemcpyAsync(base + o_stream, streams.data(), W * 4, hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipMemcpyAsync(base + o_q, queue.data(), (size_t)q_cap * 8, hipMemcpyHostToDevice, c->stream));
     RS_HIP(hipMemcpyAsync(base + o_ctl, ctl, sizeof(ctl), hipMemcpyHostToDevice, c->stream));
@@ -2483,6 +2521,13 @@ int rship_sync_exec(rship_ctx* c, const double* d0, int repeats, uint32_t stream
     ep.init.n_grp = W;
     ep.init.best_h = (int32_t*)c->init_h.p;
     ep.init.flags = (uint32_t*)c->flags.p;
+    if (!c->no_fp64_rows && c->rays64.p && c->coef64.p) { // near-static frames: the search's rows from the fp64 streams, in place
+        if (ensure_redo_count(c)) return 1;
+        ep.init.src64 = Rows64Src{rays64_of(c), (const d4*)c->coef64.p, (int)c->n_knots};
+        ep.init.kd64 = (const int32_t*)(base + o_inkd64);
+        ep.init.fd64 = (const double*)(base + o_infd64);
+        ep.init.redo_count = (unsigned long long*)c->redo_count.p;
+    }
     // The search's fp32 window must put every frame on the SAME spline path as the launch chain's search kernel does
     // (interior and general path round differently in fp32: a near-tie between hypotheses could fall the other way and
     // the executor would no longer return the chain's bits -- caught by RSSYNC_EXECUTOR_CHECK on a randomised case at
@@ -2656,15 +2701,17 @@ int rship_debug_residuals_get(rship_ctx* c, uint32_t* out, uint64_t n_words, uin
     return 0;
 }
 // out[0]: (frame, candidate) pairs of PreSync sweeps recomputed with fp64 rows so far (near-static frames: kernels/lmeds.hpp,
-// "fp64 rows"); out[1]: sweeps that went through the fp64 form.  Zero on ordinary scenes.
-int rship_near_static_stats(rship_ctx* c, uint64_t out[2]) {
+// "fp64 rows"); out[1]: sweeps that went through the fp64 form; out[2]: GuessMotion searches (one per frame and Sync call) that
+// took their rows from the fp64 streams.  Zero on ordinary scenes.
+int rship_near_static_stats(rship_ctx* c, uint64_t out[3]) {
     DeviceGuard dev_guard(c);
-    out[0] = out[1] = 0;
+    out[0] = out[1] = out[2] = 0;
     if (c->redo_count.p) {
         RS_HIP(hipStreamSynchronize(c->stream));
-        unsigned long long v = 0;
-        RS_HIP(hipMemcpy(&v, c->redo_count.p, 8, hipMemcpyDeviceToHost));
-        out[0] = v;
+        unsigned long long v[2] = {0, 0};
+        RS_HIP(hipMemcpy(v, c->redo_count.p, 16, hipMemcpyDeviceToHost));
+        out[0] = v[0];
+        out[2] = v[1];
     }
     out[1] = c->near_launches;
     return 0;

@@ -318,14 +318,15 @@ class SyncProblemHip final : public ISyncProblem {
         hip_check(shards_[0], rship_debug_residuals_get(shards_[0].ctx, out, n_words, dims), "debug_residuals_get");
     }
     // (frame, candidate) pairs of PreSync sweeps recomputed with fp64 rows / sweeps that needed it, over this object's devices
-    void near_static_stats(uint64_t out[2]) {
-        out[0] = out[1] = 0;
+    void near_static_stats(uint64_t out[3]) {
+        out[0] = out[1] = out[2] = 0;
         for (Shard& sh : shards_)
             if (sh.ctx) {
-                uint64_t v[2] = {0, 0};
+                uint64_t v[3] = {0, 0, 0};
                 (void)rship_near_static_stats(sh.ctx, v);
                 out[0] += v[0];
                 out[1] = std::max(out[1], v[1]);
+                out[2] += v[2];
             }
     }
     bool sync_exec(const std::vector<int64_t>& begins, const std::vector<int64_t>& ends_incl, const std::vector<double>& initial,
@@ -1285,12 +1286,16 @@ static void split_all(const std::vector<double>& delays, double fs, std::vector<
 }
 
 void SyncProblemHip::init_motion(const std::vector<double>& delays, uint32_t call_stride) {
-    std::vector<int32_t> kd;
+    std::vector<int32_t> kd, kd64;
     std::vector<float> fd;
+    std::vector<double> fd64; // (the same delays in full precision: a near-static frame's search takes its rows from the fp64 streams)
     split_all(delays, fs_, kd, fd);
+    split_all64(delays, fs_, kd64, fd64);
+    for (double& f : fd64)
+        if (f != f) f = 0.0; // (split_all64 marks a window that is switched off with NaN; the search has no such windows)
     for (Shard& sh : shards_)
         if (!sh.sel.empty())
-            hip_check(sh, rship_init_motion(sh.ctx, kd.data(), fd.data(), 200 /* core_private.cpp:127 */,
+            hip_check(sh, rship_init_motion(sh.ctx, kd.data(), fd.data(), kd64.data(), fd64.data(), 200 /* core_private.cpp:127 */,
                                             kStreamSyncInit + sync_calls, call_stride, seed),
                       "init motion");
     if (record_init || !init_override.empty()) exchange_init_winners();
@@ -2027,12 +2032,13 @@ int rssync_ext_executor_mismatches(rssync_problem* p, uint64_t* count) {
     return 0;
 }
 
-int rssync_ext_near_static_stats(rssync_problem* p, uint64_t* pairs, uint64_t* sweeps) {
+int rssync_ext_near_static_stats(rssync_problem* p, uint64_t* pairs, uint64_t* sweeps, uint64_t* searches) {
     return guarded([&] {
-        uint64_t v[2];
+        uint64_t v[3];
         p->impl->near_static_stats(v);
         if (pairs) *pairs = v[0];
         if (sweeps) *sweeps = v[1];
+        if (searches) *searches = v[2];
     });
 }
 

@@ -68,7 +68,7 @@ SIGNATURES = {
     "rssync_ext_set_executor_check_every": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rssync_ext_executor_stats": (C.c_int, [C.c_void_p, _PU64, _PU64, C.POINTER(C.c_uint32)]),
     "rssync_ext_executor_mismatches": (C.c_int, [C.c_void_p, _PU64]),
-    "rssync_ext_near_static_stats": (C.c_int, [C.c_void_p, _PU64, _PU64]),
+    "rssync_ext_near_static_stats": (C.c_int, [C.c_void_p, _PU64, _PU64, _PU64]),
     "rssync_ext_debug_residuals": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
     "rssync_ext_debug_residuals_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_uint32)]),
     "rssync_ext_record_init_winners": (C.c_int, [C.c_void_p, C.c_int]),
@@ -358,9 +358,9 @@ class SyncProblem:
     def near_static_stats(self):
         """-> dict(pairs, sweeps): (frame, candidate) pairs of PreSync sweeps recomputed with fp64 rows so far (near-static
         frames, |P| below ~2e-4: core_private.cpp:19-28,45-46 are double), and the sweeps that needed it.  0 on ordinary scenes."""
-        a, b = C.c_uint64(), C.c_uint64()
-        self._check(self._lib.rssync_ext_near_static_stats(self._h, C.byref(a), C.byref(b)))
-        return dict(pairs=a.value, sweeps=b.value)
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self._lib.rssync_ext_near_static_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(pairs=a.value, sweeps=b.value, searches=c.value)
 
     def record_init_winners(self, on=True):
         self._lib.rssync_ext_record_init_winners(self._h, 1 if on else 0)

@@ -533,7 +533,7 @@ int rship_presync_collect(rship_ctx* c, uint32_t n_cand, double* win_costs, doub
     return 0;
 }
 
-int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, uint32_t n_hyp, uint32_t stream,
+int rship_init_motion(rship_ctx* c, const int32_t* kd, const float* fd, const int32_t* /*kd64*/, const double* /*fd64*/, uint32_t n_hyp, uint32_t stream,
                       uint32_t stream_stride, uint64_t seed) {
     c->init_h.assign(c->sel.size(), kNone);
     for (size_t s = 0; s < c->sel.size(); ++s) {
@@ -760,7 +760,7 @@ int rship_exec_supported(rship_ctx*) { return 0; } // the window executor is a d
 int rship_exec_stats(rship_ctx*, uint32_t out[4]) { out[0] = out[1] = out[2] = out[3] = 0; return 0; }
 int rship_debug_residuals(rship_ctx* c, int, uint32_t) { c->err = "debug_residuals: not in the CPU stand-in"; return 1; }
 int rship_debug_residuals_get(rship_ctx* c, uint32_t*, uint64_t, uint32_t dims[4]) { dims[0] = dims[1] = dims[2] = dims[3] = 0; c->err = "debug_residuals: not in the CPU stand-in"; return 1; }
-int rship_near_static_stats(rship_ctx*, uint64_t out[2]) { out[0] = out[1] = 0; return 0; } // (the stand-in's sweep is its own sequential fp32 search)
+int rship_near_static_stats(rship_ctx*, uint64_t out[3]) { out[0] = out[1] = out[2] = 0; return 0; } // (the stand-in's sweep is its own sequential fp32 search)
 int rship_window_info(rship_ctx*, uint32_t out[8]) { for (int i = 0; i < 8; ++i) out[i] = 0; return 0; }
 int rship_sync_exec(rship_ctx* c, const double*, int, uint32_t, uint32_t, uint64_t, int, double, double, double*, double*, int32_t*,
                     double*, uint32_t) {

@@ -1013,7 +1013,7 @@ def test_near_static_camera_the_hypothesis_rule_on_unnormalised_rows():
     np.testing.assert_allclose(ch, co, rtol=2e-3)
     # exactly the near-static frames' pairs went through the fp64 form: 8 frames x 20 candidates, none of the ordinary frames'
     st = h.near_static_stats()
-    assert st["pairs"] == 8 * len(do) and st["sweeps"] == 1, st
+    assert st["pairs"] == 8 * len(do) and st["sweeps"] == 1 and st["searches"] == 0, st
     # ... and with the mechanism off (RSSYNC_NO_FP64_ROWS=1: round 5's sweep) the fp32 rows show what they cost here
     os.environ["RSSYNC_NO_FP64_ROWS"] = "1"
     try:
@@ -1089,7 +1089,7 @@ def test_near_static_pairs_in_chunks_that_straddle_the_mask_words(N, F, n_cand):
     n_cand = len(dh)
     assert h.window_info()["presync_chunk"] == 3, h.window_info()           # (32 is not a multiple of it)
     st = h.near_static_stats()
-    assert st == dict(pairs=H * n_cand, sweeps=1), st
+    assert st == dict(pairs=H * n_cand, sweeps=1, searches=0), st
     sub = np.arange(0, n_cand, 17)                              # the oracle on a sample of the candidates (its own streams follow the index)
     same = []
     for ci in sub:
@@ -1099,8 +1099,60 @@ def test_near_static_pairs_in_chunks_that_straddle_the_mask_words(N, F, n_cand):
     d2, c2, fc2, bh2 = h.presync_curve(synth.D_TRUE, 0, F, step, 2e-5, per_frame=F)
     np.testing.assert_array_equal(fc2.view(np.uint64), fch.view(np.uint64))
     np.testing.assert_array_equal(bh2, bhh)
-    assert h.near_static_stats() == dict(pairs=2 * H * n_cand, sweeps=2)
+    assert h.near_static_stats() == dict(pairs=2 * H * n_cand, sweeps=2, searches=0)
     assert h.PreSync(synth.D_TRUE, 0, F, 1e-6, 2e-5)[1] == o.PreSync(synth.D_TRUE, 0, F, 1e-6, 2e-5)[1]
+
+
+@pytest.mark.parametrize("N", [130, 400, 600, 2000, 5000, 9000])
+def test_guess_motion_on_near_static_frames_takes_its_rows_from_the_fp64_streams(N, monkeypatch):
+    """GuessMotion's 200-hypothesis search (core_private.cpp:125-128 -> :34-59) at the start of every Sync call is the same
+    LMedS on the same rows as the sweep's: on near-static frames it takes the fp64 form IN PLACE (one candidate per workgroup:
+    no second launch; kernels/lmeds.hpp MODE 1, lmeds_small.hpp, lmeds_big.hpp), in every kernel family -- and the window
+    executor's search task does the same (exec_big.hpp for frames of more than 512 tracks), so that executor and launch chain
+    pick the same winners bit for bit.  Against the oracle's fp64 search: the winners agree on every frame but a few near-ties
+    (round 5, fp32 rows: about one frame in five differs here); ordinary frames beside them never take the form."""
+    import rssync_amd
+    from rssync_amd import synth
+    from oracle.oracle import OracleProblem
+    F = 16 if N <= 2000 else 6
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=19)
+    H = F // 2
+    frames = list(synth.make_frames(g, 0, H, N, seed=19, noise=1e-6, outliers=0.1, translation=5e-5))
+    frames += list(synth.make_frames(g, H, F, N, seed=19, noise=1e-3, outliers=0.1))
+    monkeypatch.setenv("RSSYNC_EXEC_BIG_SHARE", "1")
+    monkeypatch.setenv("RSSYNC_EXEC_BIG_MAX", "16384")
+    res = {}
+    for name, env in (("executor", {}), ("chain", {"RSSYNC_EXECUTOR": "0"}), ("fp32", {"RSSYNC_EXECUTOR": "0", "RSSYNC_NO_FP64_ROWS": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        p = rssync_amd.SyncProblem(seed=SEED, max_outer_iters=4)
+        for k in env:
+            monkeypatch.delenv(k)
+        p.SetGyroQuaternions(g.quats, g.fs, g.t0)
+        for fr in frames:
+            p.SetTrackResult(*fr)
+        p.record_init_winners(name != "executor")      # (recording keeps a problem out of the executor: the chain's winners are read this way)
+        r = p.Sync(synth.D_TRUE, 0, F - 1, 0.0, 0.1)
+        res[name] = (r, p.sync_trace().copy(), p.last_init_winners() if name != "executor" else None, p.near_static_stats(), p.executor_stats()["runs"])
+    o = OracleProblem(seed=SEED, max_outer_iters=4, threads=min(os.cpu_count() or 1, 16), faithful=False)
+    o.SetGyroQuaternions(g.quats, g.fs, g.t0)
+    for fr in frames:
+        o.SetTrackResult(*fr)
+    o.Sync(synth.D_TRUE, 0, F - 1, 0.0, 0.1)
+    wo = o.last_init_winners()
+    # the chain: exactly the near-static frames took the fp64 form; its winners are the oracle's (a near-tie may differ)
+    assert res["chain"][3]["searches"] == H and res["fp32"][3]["searches"] == 0, (res["chain"][3], res["fp32"][3])
+    same = res["chain"][2] == wo
+    assert same[:H].mean() >= 0.85 and same.mean() >= 0.85, (same, N)
+    # the ordinary frames' winners do not depend on the mechanism
+    np.testing.assert_array_equal(res["chain"][2][H:], res["fp32"][2][H:])
+    # the window executor (where the selection is its to take: class 4 is the chain's) == the chain, bit for bit
+    if res["executor"][4]:
+        assert res["executor"][0] == res["chain"][0]
+        np.testing.assert_array_equal(res["executor"][1].view(np.uint64), res["chain"][1].view(np.uint64))
+        assert res["executor"][3]["searches"] == H
+    else:
+        assert N in (5000,), N           # (frames of 4097 .. 8192 tracks: the eight-wave tile kernel; the executor leaves them to the chain)
 
 
 @pytest.mark.parametrize("N", [130, 600, 1500, 3000])
@@ -1127,8 +1179,9 @@ def test_ordinary_scenes_never_take_the_fp64_rows(N):
                 q.SetTrackResult(*fr)
             r = q.presync_curve(synth.D_TRUE, 0, F, 5e-4, 0.1, per_frame=F)      # 400 candidates, the true delay among them
             r2 = q.PreSync(0.0, 0, F, 0.002, 0.05)
-            assert q.near_static_stats() == dict(pairs=0, sweeps=0)
-            res.append((r, r2))
+            r3 = q.Sync(r2[1], 0, F - 1, 0.0, 0.1)        # (GuessMotion's search watches too)
+            assert q.near_static_stats() == dict(pairs=0, sweeps=0, searches=0)
+            res.append((r, r2, r3))
         np.testing.assert_array_equal(res[0][0][2].view(np.uint64), res[1][0][2].view(np.uint64))
         np.testing.assert_array_equal(res[0][0][3], res[1][0][3])
-        assert res[0][1] == res[1][1]
+        assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
