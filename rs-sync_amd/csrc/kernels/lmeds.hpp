@@ -452,28 +452,6 @@ __device__ __forceinline__ uint32_t lmeds_rows64(const Rows64Src& src, uint32_t 
     return bad;
 }
 
-// ... and with the norms in the thread's registers (GuessMotion's search, MODE 1, which takes the fp64 form IN PLACE when the
-// watch fires: one candidate per workgroup, no second launch; not a hot kernel)
-template <int RPT, int BLOCK = kBlock>
-__device__ __forceinline__ uint32_t lmeds_rows64_reg(const Rows64Src& src, uint32_t off, uint32_t N, int base, double fd, const Tile& tile,
-                                                     float (&nrm)[RPT], uint32_t& n2min) {
-    uint32_t bad = 0;
-    n2min = 0x7f000000u;
-#pragma unroll
-    for (int j = 0; j < RPT; ++j) {
-        const uint32_t row = j * BLOCK + threadIdx.x;
-        nrm[j] = 0.f;
-        if (row < N) {
-            const Row64 r = row64_unit(src, (size_t)off + row, base, fd);
-            if (!r.finite) bad = RSHIP_BAD_P;
-            tile.nx[row] = r.n.x; tile.ny[row] = r.n.y; tile.nz[row] = r.n.z;
-            nrm[j] = r.nrm;
-            n2min = min(n2min, __float_as_uint(r.n2));
-        }
-    }
-    return bad;
-}
-
 // waves per SIMD the LMedS kernel is compiled for (second __launch_bounds__ argument).  Up to 2048 rows
 // (8 per thread) the 24 KB tile lets five workgroups share a CU; 4096 / 8192 rows (16 / 32 per thread, 48 /
 // 96 KB of tile, 64 / 128 residual registers per lane) run at two / one -- slower per row, but a frame of a
@@ -565,7 +543,9 @@ constexpr int kContCap = 24; // contender records per candidate; beyond that a h
 // way; as four waves of 32 rows per thread (rounds 3-5: 480 VGPRs) that was ONE wave per SIMD, which issues an instruction
 // every ~5 cycles instead of every ~2.3 (DESIGN.md section 3's table): 0.35 of the benchmark class's rate per ray.
 template <int RPT, int MODE, int WIN, bool LAZY = true, bool R64 = false, int BLOCK = kBlock> // MODE 0: PreSync cost per candidate; 1: GuessMotion's hypothesis search (Sync start)
-__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : (R64 ? 1 : (RPT == 16 ? (WIN == 1 ? 3 : 2) : lmeds_waves(RPT)))) void lmeds_kernel(LmedsParams p) {
+// (MODE 1, GuessMotion's search -- one candidate per workgroup, 0.5 % of a bench step -- holds the fp64 form of the rows as a
+// branch: compiled for four waves per SIMD up to 2048 rows, so that the branch does not spill; measured no slower)
+__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : (R64 ? 1 : (RPT == 16 ? (WIN == 1 ? 3 : 2) : (MODE == 1 ? 4 : lmeds_waves(RPT))))) void lmeds_kernel(LmedsParams p) {
     static_assert(!R64 || (MODE == 0 && WIN == 0 && LAZY), "the fp64-rows form exists for the PreSync sweep only");
     static_assert(BLOCK == 256 || (BLOCK == 512 && RPT == 16), "workgroup shapes: four waves, or eight for the 8192-row tile");
     constexpr int NWAVE = BLOCK / 64;
@@ -595,7 +575,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : (R64 ? 1 : (RPT == 16 ? (
     __shared__ uint32_t s_ncont;
     __shared__ unsigned long long s_exact;
     __shared__ uint32_t s_min2[NWAVE]; // per wave: the smallest |P|^2 (bit pattern) of the candidate's rows (hypothesis(): smin2)
-    __shared__ float s_nrm[R64 ? ROWS : 1]; // R64: the rows' norms (fp64, rounded once)
+    __shared__ float s_nrm[(R64 || MODE == 1) ? ROWS : 1]; // the fp64 form's norms (rounded once): R64, and MODE 1 when it takes that form in place
     __shared__ uint32_t s_near1;            // MODE 1: the frame is near-static (decided by wave 0, read by all)
     const int tid = threadIdx.x, lane = tid & 63;
 #if RSSYNC_K2_TIMING && RSSYNC_K2_COUNTERS
@@ -716,7 +696,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : (R64 ? 1 : (RPT == 16 ? (
                 if (use64) {
                     base64 = fr.base_knot + p.kd64[c * p.n_grp + g];
                     fd64 = p.fd64[c * p.n_grp + g];
-                    bad = lmeds_rows64_reg<RPT, BLOCK>(p.src64, fr.off, N, base64, fd64, tile, nrm, n2min);
+                    bad = lmeds_rows64<RPT, BLOCK>(p.src64, fr.off, N, base64, fd64, tile, s_nrm, n2min);
+#pragma unroll
+                    for (int j = 0; j < RPT; ++j) nrm[j] = s_nrm[j * BLOCK + tid]; // (this thread's own stores)
                     if (tid == 0) atomicAdd(p.redo_count + 1, 1ull);
                 }
             }
@@ -726,12 +708,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : (R64 ? 1 : (RPT == 16 ? (
             const uint32_t wmin = wave_min_u32(n2min);
             if (lane == 0) s_min2[tid >> 6] = wmin;
         }
-        // |P_row| for hypothesis(), from the rays (R64: the norms of stage A, in LDS -- read after the "tile written" barrier;
-        // MODE 1 in its fp64 form: the row once more in fp64, the value stage A had)
+        // |P_row| for hypothesis(), from the rays (R64, and MODE 1 in its fp64 form: the norms of stage A, in LDS -- read after the
+        // "tile written" barrier)
         auto row_scale = [&](uint32_t row) -> float {
             if constexpr (R64) return s_nrm[row];
             else {
-                if (MODE == 1 && use64) return row64_unit(p.src64, (size_t)fr.off + row, base64, fd64).nrm;
+                if (MODE == 1 && use64) return s_nrm[row];
                 return row_scale_general(p.coef, p.n_knots, load_ray(rays.a, row * 16u, 0u), load_ray(rays.b, row * 16u, 0u), base, fd);
             }
         };

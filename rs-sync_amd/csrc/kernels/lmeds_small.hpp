@@ -316,7 +316,8 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
 }
 
 template <int RPT, int MODE, int CAP = kWinMax, bool R64 = false>
-__global__ __launch_bounds__(64, R64 ? 1 : (RPT <= 3 ? 6 : (RPT == 4 ? 5 : 3))) void lmeds_small_kernel(LmedsParams p) {
+// (MODE 1 -- GuessMotion's search, with the fp64 form of the rows as a branch -- at four waves per SIMD: no spills)
+__global__ __launch_bounds__(64, R64 ? 1 : (MODE == 1 ? (RPT <= 4 ? 4 : 3) : (RPT <= 3 ? 6 : (RPT == 4 ? 5 : 3)))) void lmeds_small_kernel(LmedsParams p) {
     __shared__ LmedsSmallLds<RPT, CAP> lds;
     __shared__ float s_nrm[R64 ? 64 * RPT : 1];
     f4* dyn = nullptr;
