@@ -2021,7 +2021,9 @@ static int sync_run_body(rship_ctx* c, const double* d0, int max_outer, double s
     // (the reference's ~130-track frames), one for frames of 1024 tracks and more (dense trackers: every unneeded
     // trial of 4096 x 2048 ray pairs is 0.06 ms).  Only the batching depends on it, never a result.  In rank mode every
     // rank must batch its trials alike -- the sums of a trial come from all of them -- and no rank knows the others'
-    // frames: always five there (at the benchmark's size every search needs six trials anyway).
+    // frames: always five there.  (Round 6 tried six, to spare a first search that waits its two extra exchanges: no step of the
+    // benchmark's shapes has such a search -- the first search's own guess, syncloop.hpp step_decide, already asks for six --
+    // 18 exchanges at 8 iterations and 22 at 10 with either floor, profiles/r6_multi_rank_rehearsal.json; not adopted.)
     int nf_floor = (!ranked && c->max_n >= 1024u) ? 1 : kHalfBt;
     if (const char* e = std::getenv("RSSYNC_LOOP_TRIALS_FLOOR")) { const int v = atoi(e); if (v >= 1 && v <= kMaxBt) nf_floor = v; }
     const int max_launch = 2 * max_outer; // a window whose line search needs its later trials waits one iteration for them
