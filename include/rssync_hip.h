@@ -228,6 +228,13 @@ int rship_debug_residuals_get(rship_ctx* c, uint32_t* out, uint64_t n_words, uin
  * out[2] = GuessMotion searches (rship_init_motion, the window executor) that took their rows from the fp64 streams */
 int rship_near_static_stats(rship_ctx* c, uint64_t out[3]);
 
+/* out[k] = rows / 256 of the LMedS tile the last PreSync sweep used for size class k (class 0, the one-wave kernel: rows per
+ * lane; 0: class not in the selection, or class 5).  Classes 1 .. 4 sweep in their own shape (4, 8, 16, 32) or, where the
+ * largest frame of the class in the selection needs no more rows, in a sub-shape (3, 5 .. 7, 9 .. 15; 18, 20 .. 30 in eight
+ * waves), class 0 above 256 tracks with 5 .. 8 rows per lane: the same bits, fewer rows swept (RSSYNC_NO_SUBSHAPES=1: always
+ * the class's own). */
+int rship_lmeds_shapes(rship_ctx* c, uint32_t out[6]);
+
 /* FrameState::GuessMotion (core_private.cpp:125-128): the 200-hypothesis LMedS search for every selected
  * slot, in the fp32 tile kernel; kd/fd hold one delay per window (fp32 split), window w samples with
  * stream + w * stream_stride.  Only the winning hypothesis index per slot is kept (on the device); the

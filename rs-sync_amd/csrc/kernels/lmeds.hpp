@@ -462,7 +462,10 @@ __device__ __forceinline__ uint32_t lmeds_rows64(const Rows64Src& src, uint32_t 
 #ifndef RSSYNC_K2_WAVES16   // (workgroups per CU the planner may aim at for 16 rows per thread: 3 = with a small window in dynamic LDS, lmeds_kernel<16, ., 1>; 2: never)
 #define RSSYNC_K2_WAVES16 3
 #endif
-__host__ __device__ constexpr int lmeds_waves(int rpt) { return rpt == 4 ? RSSYNC_K2_WAVES4 : (rpt <= 8 ? 5 : (rpt == 16 ? RSSYNC_K2_WAVES16 : 1)); }
+// (round 6, the SUB-SHAPES: any number of rows per thread from 3 to 15 -- 9 to 15 in the eight-wave shape -- for selections whose
+// largest frame of a class needs no more; a thread adds its rows in order and rows beyond the frame add exact zeros, so the shape
+// changes speed, never a bit: rssync_kernels.hip, lmeds_shape)
+__host__ __device__ constexpr int lmeds_waves(int rpt) { return rpt <= 4 ? RSSYNC_K2_WAVES4 : (rpt <= 8 ? 5 : (rpt <= 16 ? RSSYNC_K2_WAVES16 : 1)); }
 __host__ __device__ constexpr int loss_waves(int rpt, bool grad) { return (grad || rpt >= 8) ? 3 : 4; }
 
 constexpr int kMaxChunk = 32; // candidates per workgroup (rship: chunk <= kMaxChunk); 64 and 100 measured: no change
@@ -545,9 +548,10 @@ constexpr int kContCap = 24; // contender records per candidate; beyond that a h
 template <int RPT, int MODE, int WIN, bool LAZY = true, bool R64 = false, int BLOCK = kBlock> // MODE 0: PreSync cost per candidate; 1: GuessMotion's hypothesis search (Sync start)
 // (MODE 1, GuessMotion's search -- one candidate per workgroup, 0.5 % of a bench step -- holds the fp64 form of the rows as a
 // branch: compiled for four waves per SIMD up to 2048 rows, so that the branch does not spill; measured no slower)
-__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : (R64 ? 1 : (RPT == 16 ? (WIN == 1 ? 3 : 2) : (MODE == 1 ? 4 : lmeds_waves(RPT))))) void lmeds_kernel(LmedsParams p) {
+__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : (R64 ? 1 : (RPT == 16 ? (WIN == 1 ? 3 : 2) : (MODE == 1 && RPT <= 8 ? 4 : lmeds_waves(RPT))))) void lmeds_kernel(LmedsParams p) {
     static_assert(!R64 || (MODE == 0 && WIN == 0 && LAZY), "the fp64-rows form exists for the PreSync sweep only");
-    static_assert(BLOCK == 256 || (BLOCK == 512 && RPT == 16), "workgroup shapes: four waves, or eight for the 8192-row tile");
+    static_assert(BLOCK == 256 || (BLOCK == 512 && RPT >= 9 && RPT <= 16), "workgroup shapes: four waves, or eight for tiles of 4608 .. 8192 rows");
+    static_assert(BLOCK == 512 || RPT <= 16, "four waves: up to 16 rows per thread");
     constexpr int NWAVE = BLOCK / 64;
     constexpr int CAPW = WIN == 1 ? 0 : WIN; // the window's compile-time capacity (0 = dynamic)
     constexpr int kHyp = kHypBatch;

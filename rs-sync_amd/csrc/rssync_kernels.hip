@@ -148,10 +148,12 @@ struct rship_ctx {
     bool no_small_loss = false;   // RSSYNC_NO_SMALL_LOSS=1 (A/B): frames of up to 512 tracks in the four-wave loss kernel
     bool exact_select = false;   // RSSYNC_K2_EXACT_SELECT=1 (read once, at creation; only in the -DRSSYNC_TEST_VARIANTS=1 build): PreSync's
                                  // tile kernel with round 2's exact selection of every quartile instead of the lazy one (tests: identical results)
+    bool no_subshapes = false;   // RSSYNC_NO_SUBSHAPES=1 (read once, at creation): every class sweeps in its own shape (A/B, tests)
     bool no_small_lmeds = false; // RSSYNC_NO_SMALL_LMEDS=1 (read once, at creation): the tile kernel for every frame size (A/B tests)
     float max_span = 0.f; // widest frame, in knots (frame table)
     float max_ends = 0.f; // the same counting only the two ends' ranges of each pair (rship_frame::range_a / range_b)
     int lds_per_cu = 160 * 1024;
+    uint32_t last_lmeds_shape[kNumClasses] = {}; // rship_lmeds_shapes: rows / 256 of the tile the last PreSync sweep gave each class (0: none launched, or not the tile kernel)
     uint32_t last_lmeds_cap = 0, last_lmeds_chunk = 0, last_init_cap = 0; // rship_window_info: what the last launches used
     // native exchange (RCCL through dlopen)
     void* rccl_lib = nullptr;
@@ -429,6 +431,36 @@ void allow_dynamic_lds(K kernel, size_t bytes) { // (more than 64 KB in all need
 // the largest number of workgroups per CU whose LDS share still holds the widest ELIGIBLE frame (window_plan.hpp:
 // plan_window_frames) and a chunk of at least eight candidates, then the longest chunk (<= 32) that fits.  A frame that
 // no window can hold takes the general path (table from L2), alone or in company.
+// The tile kernel's SHAPES, by code = rows of the tile / 256.  Four waves: 4 / 8 / 16 rows per thread (classes 1 .. 3); eight
+// waves of 16 rows (class 4, code 32).  Round 6, the SUB-SHAPES (PreSync's sweep only, MODE 0): every number of rows per thread
+// from 3 to 15, and eight waves of 9 .. 15 (codes 18, 20 .. 30), for selections whose largest frame of the class needs no more
+// rows (lmeds_shape below): a smaller tile, fewer residual registers, and no sweep over rows that no frame has.
+template <int R, int B>
+struct TileShape { static constexpr int rpt = R, block = B; };
+template <int MODE, class F>
+bool with_tile_shape(int code, F&& f) {
+    switch (code) {
+        case 4: f(TileShape<4, kBlock>{}); return true;
+        case 8: f(TileShape<8, kBlock>{}); return true;
+        case 16: f(TileShape<16, kBlock>{}); return true;
+        case 32: f(TileShape<16, kWideBlock>{}); return true;
+        default: break;
+    }
+    if constexpr (MODE == 0) {
+        switch (code) {
+#define RS_SUB4(G) case G: f(TileShape<G, kBlock>{}); return true;
+#define RS_SUB8(G) case 2 * G: f(TileShape<G, kWideBlock>{}); return true;
+            RS_SUB4(3) RS_SUB4(5) RS_SUB4(6) RS_SUB4(7) RS_SUB4(9) RS_SUB4(10) RS_SUB4(11) RS_SUB4(12) RS_SUB4(13) RS_SUB4(14) RS_SUB4(15)
+            RS_SUB8(9) RS_SUB8(10) RS_SUB8(11) RS_SUB8(12) RS_SUB8(13) RS_SUB8(14) RS_SUB8(15)
+#undef RS_SUB4
+#undef RS_SUB8
+            default: break;
+        }
+    }
+    return false;
+}
+// workgroups per CU the window planner may aim at for a shape (the second __launch_bounds__ argument of its kernels)
+int tile_shape_wgs(int code) { return code > 16 ? 1 : (code == 16 ? 2 : lmeds_waves(code)); }
 template <int MODE>
 uint32_t lmeds_dynamic_static_lds(int rpt, bool small) {
     if (small) {
@@ -437,25 +469,28 @@ uint32_t lmeds_dynamic_static_lds(int rpt, bool small) {
             case 2: return static_lds_of(lmeds_small_kernel<2, MODE, 0>);
             case 3: return static_lds_of(lmeds_small_kernel<3, MODE, 0>);
             case 4: return static_lds_of(lmeds_small_kernel<4, MODE, 0>);
-            default: return static_lds_of(lmeds_small_kernel<8, MODE, 0>);
+            default: break;
         }
+        if constexpr (MODE == 0) { // (the one-wave sub-shapes: lmeds_shape)
+            switch (rpt) {
+                case 5: return static_lds_of(lmeds_small_kernel<5, 0, 0>);
+                case 6: return static_lds_of(lmeds_small_kernel<6, 0, 0>);
+                case 7: return static_lds_of(lmeds_small_kernel<7, 0, 0>);
+                default: break;
+            }
+        }
+        return static_lds_of(lmeds_small_kernel<8, MODE, 0>);
     }
-    switch (rpt) {
-        case 4: return static_lds_of(lmeds_kernel<4, MODE, 0>);
-        case 8: return static_lds_of(lmeds_kernel<8, MODE, 0>);
-        case 16: return static_lds_of(lmeds_kernel<16, MODE, 0>);
-        default: return static_lds_of(lmeds_kernel<16, MODE, 0, true, false, kWideBlock>);
-    }
+    uint32_t v = 0;
+    with_tile_shape<MODE>(rpt, [&](auto sh) { v = static_lds_of(lmeds_kernel<decltype(sh)::rpt, MODE, 0, true, false, decltype(sh)::block>); });
+    return v;
 }
 // static LDS of the tile kernel's compiled-in-window instantiation
 template <int MODE>
 uint32_t lmeds_static_lds(int rpt) {
-    switch (rpt) {
-        case 4: return static_lds_of(lmeds_kernel<4, MODE, kWinMax>);
-        case 8: return static_lds_of(lmeds_kernel<8, MODE, kWinMax>);
-        case 16: return static_lds_of(lmeds_kernel<16, MODE, kWinMax>);
-        default: return static_lds_of(lmeds_kernel<16, MODE, kWinMax, true, false, kWideBlock>);
-    }
+    uint32_t v = 0;
+    with_tile_shape<MODE>(rpt, [&](auto sh) { v = static_lds_of(lmeds_kernel<decltype(sh)::rpt, MODE, kWinMax, true, false, decltype(sh)::block>); });
+    return v;
 }
 // which LMedS kernel the frames of class k get
 enum class LmedsKind { Small, Tile, Big };
@@ -471,6 +506,29 @@ int lmeds_rpt(const rship_ctx* c, int k) {
     if (kind == LmedsKind::Big) return 0;
     return k == 0 ? rpt_for(c->cls_max_n[0]) : class_rpt(k);
 }
+// ... and the SHAPE its launch takes (with_tile_shape's code): the class's own, or -- PreSync's sweep over classes 1 .. 4 -- the
+// smallest sub-shape that holds the largest frame of the class IN THE SELECTION (the one-wave kernels have always followed
+// cls_max_n[0] this way).  A clip of 1500-track frames sweeps 1536 rows per hypothesis instead of 2048, one of 5000-track
+// frames 5120 instead of 8192; the bits are those of the class's own shape (a thread adds its rows in order, rows beyond the
+// frame add exact zeros; the eight-wave shapes among themselves alike).  RSSYNC_NO_SUBSHAPES=1: the class's own shape always.
+template <int MODE>
+int lmeds_shape(const rship_ctx* c, int k) {
+    const int full = lmeds_rpt(c, k);
+    if (MODE != 0 || c->no_subshapes) return full;
+    if (lmeds_kind(c, k) == LmedsKind::Small) { // 257 .. 512 tracks: 5 / 6 / 7 rows per lane where the selection's largest small frame needs no more than that
+        const int need = (int)((c->cls_max_n[0] + 63u) / 64u);
+        return (need >= 5 && need <= 7) ? need : full;
+    }
+    if (k < 1 || k > 4 || lmeds_kind(c, k) != LmedsKind::Tile) return full;
+#if RSSYNC_TEST_VARIANTS
+    if (c->exact_select) return full; // (the exact-selection variant exists in the classes' own shapes only)
+#endif
+    const int need = (int)((c->cls_max_n[k] + (uint32_t)kBlock - 1u) / (uint32_t)kBlock);
+    static const int kCodes[] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26, 28, 30, 32};
+    for (int code : kCodes)
+        if (code >= need && code <= full) return code;
+    return full;
+}
 
 template <int MODE>
 WinPlan plan_lmeds_window(rship_ctx* c, int k, double step_knots, uint32_t chunk_want) {
@@ -481,14 +539,14 @@ WinPlan plan_lmeds_window(rship_ctx* c, int k, double step_knots, uint32_t chunk
         return w;
     }
     const bool small = kind == LmedsKind::Small;
-    const int rpt = lmeds_rpt(c, k);
+    const int rpt = lmeds_shape<MODE>(c, k);
     uint32_t lo, hi;
     class_bounds(c, k, &lo, &hi);
     const std::vector<rs::FrameDims>& d = plan_dims(c);
     // (the kernel's LDS footprint is only asked for when the compiled-in window does not do: plan_window's first test)
     const bool fits80 = rs::plan_fit((double)kWinMax, class_span(c, k), step_knots, chunk_want) >= std::min(8u, chunk_want);
     const uint32_t fixed = (fits80 || c->force_general) ? 0u : lmeds_dynamic_static_lds<MODE>(rpt, small);
-    rs::WinPlan wp = rs::plan_window_frames(d.data(), d.size(), lo, hi, step_knots, chunk_want, small, small ? 20 : (rpt == 16 ? 2 : lmeds_waves(rpt)), fixed,
+    rs::WinPlan wp = rs::plan_window_frames(d.data(), d.size(), lo, hi, step_knots, chunk_want, small, small ? 20 : tile_shape_wgs(rpt), fixed,
                                             c->lds_per_cu, c->force_general);
     if (!small && !wp.cap && fits80 && !c->force_general && rpt == 16) {
         // the compiled-in window does, but a smaller one in dynamic LDS lets a third workgroup share the CU (window_plan.hpp)
@@ -504,7 +562,8 @@ template <int MODE>
 int launch_lmeds_class(rship_ctx* c, LmedsParams p, const ClassRange& r, const WinPlan& wp) {
     const int k = r.k;
     const LmedsKind kind = lmeds_kind(c, k);
-    const int rpt = lmeds_rpt(c, k);
+    const int rpt = lmeds_shape<MODE>(c, k);
+    if (MODE == 0) c->last_lmeds_shape[k] = kind == LmedsKind::Big ? 0u : (uint32_t)rpt; // (class 0: rows per lane of the one-wave kernel)
     p.slots = r.list;
     p.n_slots = r.count;
     p.chunk = wp.chunk;
@@ -524,6 +583,10 @@ int launch_lmeds_class(rship_ctx* c, LmedsParams p, const ClassRange& r, const W
                 case 2: hipLaunchKernelGGL((lmeds_small_kernel<2, MODE, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break;
                 case 3: hipLaunchKernelGGL((lmeds_small_kernel<3, MODE, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break;
                 case 4: hipLaunchKernelGGL((lmeds_small_kernel<4, MODE, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break;
+                // (5 .. 7: PreSync's sub-shapes, lmeds_shape; GuessMotion's search never asks for them)
+                case 5: if constexpr (MODE == 0) { hipLaunchKernelGGL((lmeds_small_kernel<5, 0, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break; }
+                case 6: if constexpr (MODE == 0) { hipLaunchKernelGGL((lmeds_small_kernel<6, 0, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break; }
+                case 7: if constexpr (MODE == 0) { hipLaunchKernelGGL((lmeds_small_kernel<7, 0, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break; }
                 default: hipLaunchKernelGGL((lmeds_small_kernel<8, MODE, 0>), dim3(g1), dim3(64), dyn, c->stream, p); break;
             }
         } else {
@@ -532,6 +595,9 @@ int launch_lmeds_class(rship_ctx* c, LmedsParams p, const ClassRange& r, const W
                 case 2: hipLaunchKernelGGL((lmeds_small_kernel<2, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
                 case 3: hipLaunchKernelGGL((lmeds_small_kernel<3, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
                 case 4: hipLaunchKernelGGL((lmeds_small_kernel<4, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
+                case 5: if constexpr (MODE == 0) { hipLaunchKernelGGL((lmeds_small_kernel<5, 0>), dim3(g1), dim3(64), 0, c->stream, p); break; }
+                case 6: if constexpr (MODE == 0) { hipLaunchKernelGGL((lmeds_small_kernel<6, 0>), dim3(g1), dim3(64), 0, c->stream, p); break; }
+                case 7: if constexpr (MODE == 0) { hipLaunchKernelGGL((lmeds_small_kernel<7, 0>), dim3(g1), dim3(64), 0, c->stream, p); break; }
                 default: hipLaunchKernelGGL((lmeds_small_kernel<8, MODE>), dim3(g1), dim3(64), 0, c->stream, p); break;
             }
         }
@@ -559,23 +625,15 @@ int launch_lmeds_class(rship_ctx* c, LmedsParams p, const ClassRange& r, const W
     if (grid64 > 0x7fffffffull) return set_err(c, "lmeds: grid too large");
     const uint32_t grid = (uint32_t)grid64;
     if (wp.cap) { // the window in dynamic LDS (gyro rates above ~1.7 kHz)
-        switch (rpt) {
-            case 4: allow_dynamic_lds(lmeds_kernel<4, MODE, 0>, dyn);
-                    hipLaunchKernelGGL((lmeds_kernel<4, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
-            case 8: allow_dynamic_lds(lmeds_kernel<8, MODE, 0>, dyn);
-                    hipLaunchKernelGGL((lmeds_kernel<8, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p); break;
-            case 16:
-                if (wp.extra_wg) { // (a window small enough for a third workgroup per CU: the instantiation compiled for three)
-                    allow_dynamic_lds(lmeds_kernel<16, MODE, 1>, dyn);
-                    hipLaunchKernelGGL((lmeds_kernel<16, MODE, 1>), dim3(grid), dim3(kBlock), dyn, c->stream, p);
-                } else {
-                    allow_dynamic_lds(lmeds_kernel<16, MODE, 0>, dyn);
-                    hipLaunchKernelGGL((lmeds_kernel<16, MODE, 0>), dim3(grid), dim3(kBlock), dyn, c->stream, p);
-                }
-                break;
-            case 32: allow_dynamic_lds(lmeds_kernel<16, MODE, 0, true, false, kWideBlock>, dyn); // (4097 .. 8192 tracks: eight waves of 16 rows per thread)
-                     hipLaunchKernelGGL((lmeds_kernel<16, MODE, 0, true, false, kWideBlock>), dim3(grid), dim3(kWideBlock), dyn, c->stream, p); break;
-            default: return set_err(c, "lmeds: unsupported rows-per-thread");
+        if (rpt == 16 && wp.extra_wg) { // (a window small enough for a third workgroup per CU: the instantiation compiled for three)
+            allow_dynamic_lds(lmeds_kernel<16, MODE, 1>, dyn);
+            hipLaunchKernelGGL((lmeds_kernel<16, MODE, 1>), dim3(grid), dim3(kBlock), dyn, c->stream, p);
+        } else if (!with_tile_shape<MODE>(rpt, [&](auto sh) {
+                       constexpr int R = decltype(sh)::rpt, B = decltype(sh)::block;
+                       allow_dynamic_lds(lmeds_kernel<R, MODE, 0, true, false, B>, dyn);
+                       hipLaunchKernelGGL((lmeds_kernel<R, MODE, 0, true, false, B>), dim3(grid), dim3(B), dyn, c->stream, p);
+                   })) {
+            return set_err(c, "lmeds: unsupported rows-per-thread");
         }
         RS_HIP(hipGetLastError());
         return 0;
@@ -593,14 +651,12 @@ int launch_lmeds_class(rship_ctx* c, LmedsParams p, const ClassRange& r, const W
         return 0;
     }
 #endif
-    switch (rpt) {
-        case 4: hipLaunchKernelGGL((lmeds_kernel<4, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-        case 8: hipLaunchKernelGGL((lmeds_kernel<8, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-        case 16: hipLaunchKernelGGL((lmeds_kernel<16, MODE, kWinMax>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
-        case 32: allow_dynamic_lds(lmeds_kernel<16, MODE, kWinMax, true, false, kWideBlock>, 0);
-                 hipLaunchKernelGGL((lmeds_kernel<16, MODE, kWinMax, true, false, kWideBlock>), dim3(grid), dim3(kWideBlock), 0, c->stream, p); break;
-        default: return set_err(c, "lmeds: unsupported rows-per-thread");
-    }
+    if (!with_tile_shape<MODE>(rpt, [&](auto sh) {
+            constexpr int R = decltype(sh)::rpt, B = decltype(sh)::block;
+            if (B != kBlock) allow_dynamic_lds(lmeds_kernel<R, MODE, kWinMax, true, false, B>, 0);
+            hipLaunchKernelGGL((lmeds_kernel<R, MODE, kWinMax, true, false, B>), dim3(grid), dim3(B), 0, c->stream, p);
+        }))
+        return set_err(c, "lmeds: unsupported rows-per-thread");
     RS_HIP(hipGetLastError());
     return 0;
 }
@@ -948,6 +1004,7 @@ int rship_create(rship_ctx** out, int device) {
     if (e != hipSuccess || ndev == 0) return 2; // no GPU: the product path has no CPU fallback
     rship_ctx* c = new rship_ctx();
     if (const char* s = std::getenv("RSSYNC_NO_SMALL_LMEDS")) c->no_small_lmeds = s[0] && s[0] != '0';
+    if (const char* s = std::getenv("RSSYNC_NO_SUBSHAPES")) c->no_subshapes = s[0] && s[0] != '0';
     if (const char* s = std::getenv("RSSYNC_K2_EXACT_SELECT")) c->exact_select = s[0] && s[0] != '0';
 #if !RSSYNC_TEST_VARIANTS
     if (c->exact_select) { // (a test that asked for the variant must not silently compare the product with itself)
@@ -2675,6 +2732,13 @@ int rship_window_info(rship_ctx* c, uint32_t out[8]) {
     out[3] = c->last_lmeds_chunk;
     out[4] = c->last_init_cap;
     out[5] = loss_nb_run(c, mk);
+    return 0;
+}
+
+// out[k] = rows / 256 of the LMedS tile the last PreSync sweep used for size class k (class 0 with its one-wave kernel: rows
+// per lane; 0: the class was not in the selection, or is class 5): which of the kernels' shapes ran (lmeds_shape)
+int rship_lmeds_shapes(rship_ctx* c, uint32_t out[6]) {
+    for (int k = 0; k < kNumClasses; ++k) out[k] = c->last_lmeds_shape[k];
     return 0;
 }
 

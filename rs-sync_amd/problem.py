@@ -327,6 +327,15 @@ class SyncProblem:
                     presync_chunk=q[3], init_window_knots=q[4] or 80, trial_delays_per_pass=q[5], frame_ends_knots=q[6],
                     fp64_window_compact=bool(q[7]))
 
+    def lmeds_shapes(self):
+        """-> list of 6: rows / 256 of the LMedS tile the last PreSync sweep used per size class (include/rssync_hip.h:
+        rship_lmeds_shapes; 0 = class absent or not the tile kernel)"""
+        q = (C.c_uint32 * 6)()
+        fn = self._lib.rship_lmeds_shapes
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]
+        self._check(fn(C.c_void_p(self.device_context()), q))
+        return list(q)
+
     def set_executor_check(self, on=True):
         """debug mode: every call the window executor runs is re-run by the launch chain and must give the same bits"""
         self._check(self._lib.rssync_ext_set_executor_check(self._h, 1 if on else 0))

@@ -760,6 +760,7 @@ int rship_exec_supported(rship_ctx*) { return 0; } // the window executor is a d
 int rship_exec_stats(rship_ctx*, uint32_t out[4]) { out[0] = out[1] = out[2] = out[3] = 0; return 0; }
 int rship_debug_residuals(rship_ctx* c, int, uint32_t) { c->err = "debug_residuals: not in the CPU stand-in"; return 1; }
 int rship_debug_residuals_get(rship_ctx* c, uint32_t*, uint64_t, uint32_t dims[4]) { dims[0] = dims[1] = dims[2] = dims[3] = 0; c->err = "debug_residuals: not in the CPU stand-in"; return 1; }
+int rship_lmeds_shapes(rship_ctx*, uint32_t out[6]) { for (int k = 0; k < 6; ++k) out[k] = 0; return 0; } // (no tile kernel here)
 int rship_near_static_stats(rship_ctx*, uint64_t out[3]) { out[0] = out[1] = out[2] = 0; return 0; } // (the stand-in's sweep is its own sequential fp32 search)
 int rship_window_info(rship_ctx*, uint32_t out[8]) { for (int i = 0; i < 8; ++i) out[i] = 0; return 0; }
 int rship_sync_exec(rship_ctx* c, const double*, int, uint32_t, uint32_t, uint64_t, int, double, double, double*, double*, int32_t*,

@@ -69,7 +69,10 @@ def test_no_scratch_memory_and_no_matrix_instructions(code_object, kernels):
     # -- ~200 dwords -- is spilled OUTSIDE the sweep (one load per row in stage A, the rare re-sweep of overlapping contenders,
     # stage D's norms: tools/isa_by_line.py; the hot sweep block has no scratch access): measured 22 % FASTER than the
     # spill-free four-wave shape at ONE wave per SIMD (480 VGPRs), profiles/r6_k2_wide_ab.txt.
-    allowed = re.compile(r"lmeds_kernelILi16ELi[01]ELi1ELb1ELb0ELi256EEE|lmeds_kernelILi16ELi[01]ELi(0|80)ELb[01]ELb[01]ELi512EEE")
+    # ... and its sub-shapes of 11 .. 15 rows per thread (21 .. 160 dwords; 9 and 10 rows spill nothing), and the four-wave sub-shapes
+    # of 13 .. 15 rows per thread, compiled like lmeds_kernel<16, ., 1> for three workgroups per CU (16 .. 40 dwords).
+    allowed = re.compile(r"lmeds_kernelILi16ELi[01]ELi1ELb1ELb0ELi256EEE|lmeds_kernelILi1[1-6]ELi[01]ELi(0|80)ELb[01]ELb[01]ELi512EEE"
+                         r"|lmeds_kernelILi1[345]ELi0ELi(0|80)ELb1ELb0ELi256EEE")
     funcs = re.split(r"^[0-9a-f]+ <(\S+)>:$", dis, flags=re.M)      # [preamble, name, body, name, body, ...]
     assert len(funcs) > 100
     for name, body in zip(funcs[1::2], funcs[2::2]):
@@ -79,8 +82,9 @@ def test_no_scratch_memory_and_no_matrix_instructions(code_object, kernels):
         assert not re.search(r"\bbuffer_(load|store)\w* .*\boffen\b.*\bs\[0:3\]", body), name  # (the other form of a private access)
     assert "v_mfma" not in dis
     spilling = {n: k["vgpr_spills"] for n, k in kernels.items() if k["vgpr_spills"]}   # (accumulation registers are part of gfx950's unified file: not a spill)
-    narrow = {"lmeds_kernel<16, 0, 1, true, false, 256>", "lmeds_kernel<16, 1, 1, true, false, 256>"}
-    wide = {n for n in kernels if re.match(r"lmeds_kernel<16, [01], (0|80), (true|false), (true|false), 512>$", n)}
+    narrow = {"lmeds_kernel<16, 0, 1, true, false, 256>", "lmeds_kernel<16, 1, 1, true, false, 256>"} | {
+        "lmeds_kernel<%d, 0, %d, true, false, 256>" % (r, w) for r in (13, 14, 15) for w in (0, 80)}
+    wide = {n for n in kernels if re.match(r"lmeds_kernel<1[1-6], [01], (0|80), (true|false), (true|false), 512>$", n)}
     assert set(spilling) <= narrow | wide, spilling
     assert all(v <= 48 for n, v in spilling.items() if n in narrow) and all(v <= 240 for n, v in spilling.items() if n in wide), spilling
     # An executor instantiation may reserve a private segment it never touches (8 SGPRs parked in a frame slot that the final
@@ -128,6 +132,18 @@ def test_occupancy_the_design_relies_on(kernels):
     assert wide["vgpr"] <= 256 and wide["max_threads"] == 512 and 96 * 1024 <= wide["lds"] <= 112 * 1024, wide
     for rpt in (1, 2, 3, 4, 8):
         assert kernels["lmeds_small_kernel<%d, 0, 0, true>" % rpt]["private"] == 0
+    # round 6, the sub-shapes of PreSync's sweep (rssync_kernels.hip: lmeds_shape): 768 / 1536 / 3072-row tiles in four waves run
+    # at least the workgroups per CU of their class's own shape (6 / 5 / 2-3), 5120-row tiles in eight waves without a spill
+    for rpt in range(3, 16):
+        need = 6 if rpt <= 4 else (5 if rpt <= 8 else 3)
+        for win in (80, 0):
+            k = kernels["lmeds_kernel<%d, 0, %d, true, false, 256>" % (rpt, win)]
+            assert _waves_per_simd(k["vgpr"]) >= need and 160 * 1024 // (k["lds"] + 256) >= need, (rpt, k)
+            assert k["private"] == 0 or rpt >= 13, (rpt, k)
+    for rpt in (9, 10):
+        for win in (80, 0):
+            k = kernels["lmeds_kernel<%d, 0, %d, true, false, 512>" % (rpt, win)]
+            assert k["vgpr"] <= 256 and k["private"] == 0 and k["max_threads"] == 512, k
 
 
 def test_every_instantiation_the_launchers_name_is_in_the_binary(kernels):
@@ -140,6 +156,11 @@ def test_every_instantiation_the_launchers_name_is_in_the_binary(kernels):
         for win in (80, 0):
             assert "lmeds_kernel<16, %d, %d, true, false, 512>" % (mode, win) in have
     assert not [n for n in have if re.match(r"lmeds_kernel<32,", n)]
+    # the sub-shapes: PreSync's sweep only (MODE 0), both window forms; GuessMotion's search and the fp64-rows form keep the classes' own
+    for rpt, block in [(r, 256) for r in range(3, 16)] + [(r, 512) for r in range(9, 16)]:
+        for win in (80, 0):
+            assert "lmeds_kernel<%d, 0, %d, true, false, %d>" % (rpt, win, block) in have
+    assert not [n for n in have if re.match(r"lmeds_kernel<(3|5|6|7|9|1[0-5]), 1,", n) or re.match(r"lmeds_kernel<(3|5|6|7|9|1[0-5]), 0, 0, true, true", n)]
     # frames of up to 512 tracks belong to the one-wave kernels: no four-wave instantiations for 256 / 512 rows (the tests'
     # family cross-checks run them through the 1024-row ones: same bits)
     assert not [n for n in have if re.match(r"(lmeds_kernel|loss64_kernel)<[12],", n)]
