@@ -548,10 +548,10 @@ constexpr int kContCap = 24; // contender records per candidate; beyond that a h
 template <int RPT, int MODE, int WIN, bool LAZY = true, bool R64 = false, int BLOCK = kBlock> // MODE 0: PreSync cost per candidate; 1: GuessMotion's hypothesis search (Sync start)
 // (MODE 1, GuessMotion's search -- one candidate per workgroup, 0.5 % of a bench step -- holds the fp64 form of the rows as a
 // branch: compiled for four waves per SIMD up to 2048 rows, so that the branch does not spill; measured no slower)
-__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : (R64 ? 1 : (RPT == 16 ? (WIN == 1 ? 3 : 2) : (MODE == 1 && RPT <= 8 ? 4 : lmeds_waves(RPT))))) void lmeds_kernel(LmedsParams p) {
+__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : (R64 ? 1 : (RPT >= 16 ? (WIN == 1 ? 3 : 2) : (MODE == 1 && RPT <= 8 ? 4 : lmeds_waves(RPT))))) void lmeds_kernel(LmedsParams p) {
     static_assert(!R64 || (MODE == 0 && WIN == 0 && LAZY), "the fp64-rows form exists for the PreSync sweep only");
     static_assert(BLOCK == 256 || (BLOCK == 512 && RPT >= 9 && RPT <= 16), "workgroup shapes: four waves, or eight for tiles of 4608 .. 8192 rows");
-    static_assert(BLOCK == 512 || RPT <= 16, "four waves: up to 16 rows per thread");
+    static_assert(BLOCK == 512 || RPT <= 24, "four waves: up to 24 rows per thread");
     constexpr int NWAVE = BLOCK / 64;
     constexpr int CAPW = WIN == 1 ? 0 : WIN; // the window's compile-time capacity (0 = dynamic)
     constexpr int kHyp = kHypBatch;

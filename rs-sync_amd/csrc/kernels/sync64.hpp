@@ -663,7 +663,7 @@ __device__ __forceinline__ void opt_motion64_body(const Motion64Params& p, uint3
 }
 
 template <int RPT, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? (RPT == 0 ? 2 : (RPT <= 8 ? 3 : (RPT == 16 ? 2 : 1))) : (NW == 1 ? (RPT >= 8 ? 3 : 4) : 2)) void opt_motion64_kernel(Motion64Params p) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? (RPT == 0 ? 2 : (RPT <= 8 ? 3 : (RPT <= 24 ? 2 : 1))) : (NW == 1 ? (RPT >= 8 ? 3 : 4) : 2)) void opt_motion64_kernel(Motion64Params p) {
     __shared__ MotionLds<NW> lds;
     extern __shared__ d4 s_motion_win[]; // [4 * win_cap]
     opt_motion64_body<RPT, NW>(p, p.order ? p.order[blockIdx.x + p.slot0] : blockIdx.x + p.slot0, lds, s_motion_win, nullptr,

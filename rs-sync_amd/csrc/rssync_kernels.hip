@@ -121,7 +121,7 @@ struct rship_ctx {
     int lbfgs_reeval = 0; // RSHIP_OPT_LBFGS_REEVAL
     // SIZE CLASSES (round 5).  Which kernel family a frame runs in -- and with it the association of its sums -- follows
     // from the frame's OWN track count: class 0 = up to one_wave_max tracks (the one-wave kernels), 1 .. 4 = the four-wave
-    // kernels with 4 / 8 / 16 / 32 rows per thread (up to 1024 / 2048 / 4096 / 8192 tracks), 5 = more than 8192 (rows in
+    // kernels with 4 / 8 / 16-24 / 32 rows per thread (up to 1024 / 2048 / 6144 / 8192 tracks), 5 = more than 8192 (rows in
     // global memory).  A selection is cut into one slot list per class (cls_slots, ascending slots inside a class) and
     // every launch covers one class; the plan of the sums indexes by slot and does not notice.  The reference evaluates
     // each frame in its own lambda (core_private.cpp:73-86, :231-238, :263-295): a frame's result must not depend on what
@@ -293,11 +293,17 @@ int sync_stream(rship_ctx* c) {
 }
 
 constexpr int kMaxRpt = 32; // 8192 tracks per frame in registers / LDS; larger frames take the kernels' slow paths
-constexpr int kWideBlock = 512; // the LMedS tile kernel's workgroup for 4097 .. 8192 tracks (class 4): eight waves x 16 rows per thread (kernels/lmeds.hpp: BLOCK)
+// Rows per thread up to which PreSync's tile kernel runs as FOUR waves (class 3: 2049 .. 6144 tracks).  Round 6 (second half):
+// until then class 3 ended at 4096 tracks and 4097 .. 8192 ran as eight waves, ONE workgroup per CU; a tile of up to 6144 rows
+// (72 KB) still lets TWO four-wave workgroups share a CU, whose barrier phases cover each other: 17.1 .. 19.0 ms per 2^21 ray
+// pairs at 4097 .. 6000 tracks against 22.9 .. 25.6 as eight waves (profiles/r6_k2_class3_6144_ab.txt).  Above 6144 rows only
+// one workgroup fits whatever its shape, and eight waves are the better one (class 4).
+constexpr int kFourWaveMaxRpt = 24;
+constexpr int kWideBlock = 512; // the LMedS tile kernel's workgroup for 6145 .. 8192 tracks (class 4): eight waves x 16 rows per thread (kernels/lmeds.hpp: BLOCK)
 
 // ---- size classes ---------------------------------------------------------------------------------------------
-// class of a frame of n tracks (rship_ctx::cls_slots): 0 one wave per frame, 1 .. 4 four waves with 4 / 8 / 16 / 32 rows
-// per thread, 5 rows in global memory.  A thread adds its rows in order and rows beyond the frame add exact zeros, so a
+// class of a frame of n tracks (rship_ctx::cls_slots): 0 one wave per frame, 1 .. 4 four waves with 4 / 8 / 16-24 / 32 rows
+// per thread (PreSync's tile kernel runs class 4 -- 6145 .. 8192 tracks -- as EIGHT waves of 16), 5 rows in global memory.  A thread adds its rows in order and rows beyond the frame add exact zeros, so a
 // frame's sums do not depend on the rows-per-thread instantiation INSIDE a family (one wave / four waves): the classes
 // 1 .. 4 differ in speed only (registers, workgroups per CU), 0 and 5 in the association (0) and the fp32 spline path (5).
 int class_of(const rship_ctx* c, uint32_t n) {
@@ -305,19 +311,25 @@ int class_of(const rship_ctx* c, uint32_t n) {
     if (n <= c->one_wave_max) return 0;
     if (n <= 4u * kBlock) return 1;
     if (n <= 8u * kBlock) return 2;
-    if (n <= 16u * kBlock) return 3;
+    if (n <= (uint32_t)kFourWaveMaxRpt * kBlock) return 3;
     if (n <= (uint32_t)kMaxRpt * kBlock) return 4;
     return 5;
 }
 // track counts of class k (both ends inclusive)
 void class_bounds(const rship_ctx* c, int k, uint32_t* lo, uint32_t* hi) {
     if (c->force_big) { *lo = k == 5 ? 0u : 1u; *hi = k == 5 ? 0xffffffffu : 0u; return; }
-    const uint32_t top[6] = {c->one_wave_max, 4u * kBlock, 8u * kBlock, 16u * kBlock, (uint32_t)kMaxRpt * kBlock, 0xffffffffu};
+    const uint32_t top[6] = {c->one_wave_max, 4u * kBlock, 8u * kBlock, (uint32_t)kFourWaveMaxRpt * kBlock, (uint32_t)kMaxRpt * kBlock, 0xffffffffu};
     *hi = top[k];
     *lo = k == 0 ? 0u : top[k - 1] + 1u;
 }
 // rows per thread of the four-wave kernels of class k (0 = as many as the frame needs: class 5)
-int class_rpt(int k) { return k == 5 ? 0 : (4 << (k - 1)); }
+// (class 3, 2049 .. 6144 tracks: 16 while the selection's largest frame of the class has at most 4096 tracks, else 24 -- the
+// same bits, a thread adds its rows in order and rows beyond the frame add exact zeros)
+int class_rpt(const rship_ctx* c, int k) {
+    if (k == 5) return 0;
+    if (k == 3) return c->cls_max_n[3] > 16u * kBlock ? kFourWaveMaxRpt : 16;
+    return 4 << (k - 1);
+}
 // rows per lane of the one-wave kernels: 1 .. 4 up to 256 tracks, 8 for 257 .. 512 (rows beyond the frame contribute
 // exact zeros, so one instantiation serves them all with the same bits)
 int small_rpt(uint32_t n_all) { const uint32_t r = std::max(1u, (n_all + 63u) / 64u); return r <= 4u ? (int)r : 8; }
@@ -431,10 +443,10 @@ void allow_dynamic_lds(K kernel, size_t bytes) { // (more than 64 KB in all need
 // the largest number of workgroups per CU whose LDS share still holds the widest ELIGIBLE frame (window_plan.hpp:
 // plan_window_frames) and a chunk of at least eight candidates, then the longest chunk (<= 32) that fits.  A frame that
 // no window can hold takes the general path (table from L2), alone or in company.
-// The tile kernel's SHAPES, by code = rows of the tile / 256.  Four waves: 4 / 8 / 16 rows per thread (classes 1 .. 3); eight
-// waves of 16 rows (class 4, code 32).  Round 6, the SUB-SHAPES (PreSync's sweep only, MODE 0): every number of rows per thread
-// from 3 to 15, and eight waves of 9 .. 15 (codes 18, 20 .. 30), for selections whose largest frame of the class needs no more
-// rows (lmeds_shape below): a smaller tile, fewer residual registers, and no sweep over rows that no frame has.
+// The tile kernel's SHAPES, by code = rows of the tile / 256.  Four waves: 4 / 8 / 16 or 24 rows per thread (classes 1 .. 3);
+// eight waves of 16 rows (class 4, code 32).  Round 6, the SUB-SHAPES (PreSync's sweep only, MODE 0): every number of rows per
+// thread from 3 to 23, and eight waves of 13 .. 15 (codes 26, 28, 30), for selections whose largest frame of the class needs no
+// more rows (lmeds_shape below): a smaller tile, fewer residual registers, and no sweep over rows that no frame has.
 template <int R, int B>
 struct TileShape { static constexpr int rpt = R, block = B; };
 template <int MODE, class F>
@@ -443,6 +455,7 @@ bool with_tile_shape(int code, F&& f) {
         case 4: f(TileShape<4, kBlock>{}); return true;
         case 8: f(TileShape<8, kBlock>{}); return true;
         case 16: f(TileShape<16, kBlock>{}); return true;
+        case 24: f(TileShape<24, kBlock>{}); return true;
         case 32: f(TileShape<16, kWideBlock>{}); return true;
         default: break;
     }
@@ -451,7 +464,8 @@ bool with_tile_shape(int code, F&& f) {
 #define RS_SUB4(G) case G: f(TileShape<G, kBlock>{}); return true;
 #define RS_SUB8(G) case 2 * G: f(TileShape<G, kWideBlock>{}); return true;
             RS_SUB4(3) RS_SUB4(5) RS_SUB4(6) RS_SUB4(7) RS_SUB4(9) RS_SUB4(10) RS_SUB4(11) RS_SUB4(12) RS_SUB4(13) RS_SUB4(14) RS_SUB4(15)
-            RS_SUB8(9) RS_SUB8(10) RS_SUB8(11) RS_SUB8(12) RS_SUB8(13) RS_SUB8(14) RS_SUB8(15)
+            RS_SUB4(17) RS_SUB4(18) RS_SUB4(19) RS_SUB4(20) RS_SUB4(21) RS_SUB4(22) RS_SUB4(23)
+            RS_SUB8(13) RS_SUB8(14) RS_SUB8(15)
 #undef RS_SUB4
 #undef RS_SUB8
             default: break;
@@ -460,7 +474,7 @@ bool with_tile_shape(int code, F&& f) {
     return false;
 }
 // workgroups per CU the window planner may aim at for a shape (the second __launch_bounds__ argument of its kernels)
-int tile_shape_wgs(int code) { return code > 16 ? 1 : (code == 16 ? 2 : lmeds_waves(code)); }
+int tile_shape_wgs(int code) { return code > kFourWaveMaxRpt ? 1 : (code >= 16 ? 2 : lmeds_waves(code)); }
 template <int MODE>
 uint32_t lmeds_dynamic_static_lds(int rpt, bool small) {
     if (small) {
@@ -504,7 +518,7 @@ int lmeds_rpt(const rship_ctx* c, int k) {
     const LmedsKind kind = lmeds_kind(c, k);
     if (kind == LmedsKind::Small) return small_rpt(c->cls_max_n[0]);
     if (kind == LmedsKind::Big) return 0;
-    return k == 0 ? rpt_for(c->cls_max_n[0]) : class_rpt(k);
+    return k == 0 ? rpt_for(c->cls_max_n[0]) : class_rpt(c, k);
 }
 // ... and the SHAPE its launch takes (with_tile_shape's code): the class's own, or -- PreSync's sweep over classes 1 .. 4 -- the
 // smallest sub-shape that holds the largest frame of the class IN THE SELECTION (the one-wave kernels have always followed
@@ -524,7 +538,7 @@ int lmeds_shape(const rship_ctx* c, int k) {
     if (c->exact_select) return full; // (the exact-selection variant exists in the classes' own shapes only)
 #endif
     const int need = (int)((c->cls_max_n[k] + (uint32_t)kBlock - 1u) / (uint32_t)kBlock);
-    static const int kCodes[] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26, 28, 30, 32};
+    static const int kCodes[] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 26, 28, 30, 32};
     for (int code : kCodes)
         if (code >= need && code <= full) return code;
     return full;
@@ -644,6 +658,8 @@ int launch_lmeds_class(rship_ctx* c, LmedsParams p, const ClassRange& r, const W
             case 4: hipLaunchKernelGGL((lmeds_kernel<4, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
             case 8: hipLaunchKernelGGL((lmeds_kernel<8, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
             case 16: hipLaunchKernelGGL((lmeds_kernel<16, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+            case 24: allow_dynamic_lds(lmeds_kernel<24, 0, kWinMax, false>, 0);
+                     hipLaunchKernelGGL((lmeds_kernel<24, 0, kWinMax, false>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
             case 32: hipLaunchKernelGGL((lmeds_kernel<16, 0, kWinMax, false, false, kWideBlock>), dim3(grid), dim3(kWideBlock), 0, c->stream, p); break;
             default: return set_err(c, "lmeds: unsupported rows-per-thread");
         }
@@ -653,7 +669,7 @@ int launch_lmeds_class(rship_ctx* c, LmedsParams p, const ClassRange& r, const W
 #endif
     if (!with_tile_shape<MODE>(rpt, [&](auto sh) {
             constexpr int R = decltype(sh)::rpt, B = decltype(sh)::block;
-            if (B != kBlock) allow_dynamic_lds(lmeds_kernel<R, MODE, kWinMax, true, false, B>, 0);
+            if (B != kBlock || R > 16) allow_dynamic_lds(lmeds_kernel<R, MODE, kWinMax, true, false, B>, 0);
             hipLaunchKernelGGL((lmeds_kernel<R, MODE, kWinMax, true, false, B>), dim3(grid), dim3(B), 0, c->stream, p);
         }))
         return set_err(c, "lmeds: unsupported rows-per-thread");
@@ -718,6 +734,8 @@ int launch_lmeds_redo(rship_ctx* c, const LmedsParams& p_in, double step_knots, 
                 case 4: hipLaunchKernelGGL((lmeds_kernel<4, 0, 0, true, true>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
                 case 8: hipLaunchKernelGGL((lmeds_kernel<8, 0, 0, true, true>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
                 case 16: hipLaunchKernelGGL((lmeds_kernel<16, 0, 0, true, true>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
+                case 24: allow_dynamic_lds(lmeds_kernel<24, 0, 0, true, true>, 0);
+                         hipLaunchKernelGGL((lmeds_kernel<24, 0, 0, true, true>), dim3(grid), dim3(kBlock), 0, c->stream, p); break;
                 case 32: allow_dynamic_lds(lmeds_kernel<16, 0, 0, true, true, kWideBlock>, 0);
                          hipLaunchKernelGGL((lmeds_kernel<16, 0, 0, true, true, kWideBlock>), dim3(grid), dim3(kWideBlock), 0, c->stream, p); break;
                 default: return set_err(c, "lmeds (fp64 rows): unsupported rows-per-thread");
@@ -764,7 +782,7 @@ int launch_loss64(rship_ctx* c, const Loss64Params& p_in, hipStream_t st = nullp
             RS_HIP(hipGetLastError());
             continue;
         }
-        const int rpt = k == 0 ? rpt_for(c->cls_max_n[0]) : class_rpt(k);
+        const int rpt = k == 0 ? rpt_for(c->cls_max_n[0]) : class_rpt(c, k);
 #define RS_LOSS_CASE(R)                                                                                                        \
     case R:                                                                                                                    \
         if constexpr (!GRAD) {                                                                                                 \
@@ -777,6 +795,7 @@ int launch_loss64(rship_ctx* c, const Loss64Params& p_in, hipStream_t st = nullp
             RS_LOSS_CASE(4)
             RS_LOSS_CASE(8)
             RS_LOSS_CASE(16)
+            RS_LOSS_CASE(24)
             RS_LOSS_CASE(32)
             default: return set_err(c, "loss: unsupported rows-per-thread");
         }
@@ -820,7 +839,8 @@ int launch_motion64(rship_ctx* c, const Motion64Params& p_in, hipStream_t st = n
             else hipLaunchKernelGGL((opt_motion64_kernel<8, 1>), dim3(cnt), dim3(64), dyn, st, p);
         } else if (k == 1) hipLaunchKernelGGL((opt_motion64_kernel<4, 4>), dim3(cnt), dim3(256), dyn, st, p);
         else if (k == 2) hipLaunchKernelGGL((opt_motion64_kernel<8, 4>), dim3(cnt), dim3(256), dyn, st, p);
-        else if (k == 3) hipLaunchKernelGGL((opt_motion64_kernel<16, 4>), dim3(cnt), dim3(256), dyn, st, p);
+        else if (k == 3 && class_rpt(c, 3) == 16) hipLaunchKernelGGL((opt_motion64_kernel<16, 4>), dim3(cnt), dim3(256), dyn, st, p);
+        else if (k == 3) hipLaunchKernelGGL((opt_motion64_kernel<24, 4>), dim3(cnt), dim3(256), dyn, st, p);
         else if (k == 4) hipLaunchKernelGGL((opt_motion64_kernel<32, 4>), dim3(cnt), dim3(256), dyn, st, p);
         else { // rows of P in global memory (per entry of the class's list, set up by fill_motion), as many per thread as the frame needs
             if (!p.scratch || p.scratch_rows < c->cls_max_n[5]) return set_err(c, "motion: no scratch for frames of more than 8192 tracks");
@@ -2354,7 +2374,7 @@ int rship_exec_supported(rship_ctx* c) {
     for (uint32_t i : c->h_sel)
         if (c->h_frame_n[i] < 2) return 0;
     if (c->max_n > c->one_wave_max && c->max_n > c->exec_big_max) return 0; // (a frame that large is better off with four waves: the chain of launches)
-    // frames of 4097 .. 8192 tracks (class 4) run the search in the tile kernel's EIGHT-wave shape since round 6; the executor's
+    // frames of 6145 .. 8192 tracks (class 4) run the search in the tile kernel's EIGHT-wave shape since round 6; the executor's
     // one-wave emulation (kernels/exec_big.hpp) reproduces the FOUR-wave association (classes 1 .. 3) and the large-frame
     // kernel's (class 5): a selection with a class-4 frame is the chain's whatever RSSYNC_EXEC_BIG_MAX says
     if (c->cls_off[5] != c->cls_off[4]) return 0;

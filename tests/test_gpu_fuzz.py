@@ -289,9 +289,9 @@ def test_random_mixtures_of_near_static_and_ordinary_frames(seed):
 @pytest.mark.parametrize("noise", [1e-3, 0.0])
 def test_the_anchor_in_every_size_class(noise, variants_lib):
     """the same anchor with one frame of every kernel family in one problem: one wave per frame (130, 400 tracks), four waves
-    with 4 / 8 / 16 rows per thread (900, 2000, 3500), EIGHT waves of 16 rows (6000, 8192: round 6's shape for 4097 .. 8192
-    tracks) and the large-frame kernel (9000) -- every winner the exact arg-min of the kernel's own residuals, first wins"""
-    counts = [130, 400, 900, 2000, 3500, 6000, 8192, 9000]
+    with 4 / 8 / 16 / 24 rows per thread (900, 2000, 3500, 6000), EIGHT waves of 16 rows (7000, 8192: round 6's shape for 6145 ..
+    8192 tracks) and the large-frame kernel (9000) -- every winner the exact arg-min of the kernel's own residuals, first wins"""
+    counts = [130, 400, 900, 2000, 3500, 6000, 7000, 8192, 9000]
     F = len(counts)
     g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=77)
     kw = dict(noise=0.0, outliers=0.0) if noise == 0.0 else dict(noise=noise)

@@ -52,7 +52,8 @@ def _curves(p, F, step, radius, d0=0.0):
     (16, 2047, 0.001, 0.06, {"noise": 0.0, "outliers": 0.0}),      # noise-free: clusters of (near-)equal residuals
     (40, 600, 0.001, 0.06, {}),                                    # 4 rows per thread
     (30, 300, 0.002, 0.1, {}),                                     # 2 rows per thread
-    (6, 5000, 0.002, 0.05, {}),                                    # 32 rows per thread
+    (6, 5000, 0.002, 0.05, {}),                                    # 24 rows per thread (four waves: 4097 .. 6144 tracks)
+    (4, 7000, 0.002, 0.05, {}),                                    # eight waves x 16 rows per thread (6145 .. 8192 tracks)
     (8, 3000, 0.002, 0.05, {"noise": 3e-3, "outliers": 0.3}),      # 16 rows per thread, heavy outliers
 ])
 def test_lazy_selection_equals_exact_selection(built, _two, F, N, step, radius, kw):

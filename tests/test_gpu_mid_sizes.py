@@ -201,10 +201,10 @@ def test_simplified_mode(N):
         assert G[j] == pytest.approx(sum(p[2] for p in per), rel=1e-6, abs=1e-6 * abs(L[j]))
 
 
-@pytest.mark.parametrize("N", [2049, 4096, 5000])
+@pytest.mark.parametrize("N", [2049, 4096, 5000, 6144, 6145, 7000])
 def test_more_than_2048_tracks_per_frame(N):
-    """frames of a dense tracker: 16 / 32 rows per thread (tile of 48 / 96 KB, 64 / 128 residual registers per
-    lane); same checks as at the other sizes, on a handful of frames"""
+    """frames of a dense tracker: 16 / 24 rows per thread in four waves (up to 6144 tracks), eight waves of 16 above (tiles of
+    48 / 72 / 96 KB, 64 / 96 / 128 residual registers per lane); same checks as at the other sizes, on a handful of frames"""
     from rssync_amd import synth
     F = 6
     h, o = _pair(F, N, seed=70 + N, max_outer_iters=12)
@@ -226,7 +226,12 @@ def test_more_than_2048_tracks_per_frame(N):
         assert Lh[j] == pytest.approx(sum(p[0] for p in per), rel=1e-12)
         assert Gh[j] == pytest.approx(sum(p[2] for p in per), rel=1e-10, abs=1e-10 * abs(Lh[j]))
     c1, d1 = h.Sync(0.036, 0, F - 1, 0.0, 0.2)
-    assert np.isfinite(c1) and abs(d1 - synth.D_TRUE) < 2e-3
+    co1, do1 = o.Sync(0.036, 0, F - 1, 0.0, 0.2)
+    # against the oracle within the north star's 1e-4 s (measured: 2e-12); against the truth only roughly -- six frames of
+    # > 6000 tracks and twelve outer iterations leave the reference's momentum step (core_private.cpp:299-302) 3.6 ms away,
+    # the oracle exactly as far
+    assert np.isfinite(c1) and abs(d1 - do1) < 1e-4 and abs(c1 - co1) <= 1e-6 * abs(co1), (c1, d1, co1, do1)
+    assert abs(d1 - synth.D_TRUE) < (2e-3 if N <= 5000 else 5e-3)
 
 
 def _check_large_frames(h, o, F, N_of, scene_name, n_cand_step=0.01):

@@ -18,8 +18,9 @@ pytestmark = pytest.mark.gpu
 
 SEED = 123
 THREADS = min(os.cpu_count() or 1, 16)
-# one frame of every class: one wave (96, 300), four waves with 4 / 8 / 16 / 32 rows per thread, rows in global memory
-COUNTS = [96, 300, 600, 1500, 3000, 5000, 9000]
+# one frame of every class: one wave (96, 300), four waves with 4 / 8 / 16 / 24 rows per thread (600, 1500, 3000, 5000), the
+# class whose PreSync tile runs as eight waves (7000), rows in global memory (9000)
+COUNTS = [96, 300, 600, 1500, 3000, 5000, 7000, 9000]
 
 
 def _frames(gyro, counts, seed, **kw):
@@ -42,7 +43,7 @@ def test_a_frames_bits_do_not_depend_on_its_neighbours():
     g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=31)
     frames = _frames(g, COUNTS, seed=31, noise=5e-4, outliers=0.08)
     mixed = _problem(g, frames, max_outer_iters=8)
-    d, c, fc, bh = mixed.presync_curve(0.03, 0, F, 0.001, 0.012, per_frame=F)       # 24 candidates x 7 frames
+    d, c, fc, bh = mixed.presync_curve(0.03, 0, F, 0.001, 0.012, per_frame=F)       # 24 candidates x 8 frames
     M, k = mixed.init_motion(0.0362, 0, F - 1)
     L, G = mixed.loss([0.0362, 0.03, 0.041], grad=True)
     per_frame_loss = []
@@ -207,7 +208,7 @@ def test_every_route_through_the_library_on_a_problem_of_mixed_classes():
     gives the plain route's bits, and the simplified mode agrees with the oracle."""
     from rssync_amd import synth
     from oracle.oracle import OracleProblem
-    counts = [96, 600, 300, 1500, 130, 3000, 5000, 9000, 200, 2048]       # classes interleaved along the table
+    counts = [96, 600, 300, 1500, 130, 3000, 5000, 7000, 9000, 200, 2048]       # classes interleaved along the table
     F = len(counts)
     g = synth.make_gyro(0.0, (F + 2) / synth.FPS, seed=37)
     frames = _frames(g, counts, seed=37, noise=4e-4, outliers=0.06)

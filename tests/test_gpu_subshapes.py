@@ -1,9 +1,9 @@
 """The LMedS tile kernel's SUB-SHAPES (round 6): speed, never a bit.
 
-A frame of 513 .. 8192 tracks is swept by the four-wave tile kernel of its size class: 4 / 8 / 16 rows per thread, eight
-waves of 16 above 4096 tracks (rssync_kernels.hip: class_of).  A clip whose frames have 1500 tracks swept 2048 rows per
+A frame of 513 .. 8192 tracks is swept by the tile kernel of its size class: four waves of 4 / 8 / 24 rows per thread, eight
+waves of 16 above 6144 tracks (rssync_kernels.hip: class_of).  A clip whose frames have 1500 tracks swept 2048 rows per
 hypothesis that way, one of 4100-track frames 8192.  Now PreSync's launch for a class takes the smallest shape that holds
-the LARGEST frame of the class in the selection -- any number of rows per thread from 3 to 16, eight waves of 9 .. 16
+the LARGEST frame of the class in the selection -- any number of rows per thread from 3 to 24, eight waves of 13 .. 16
 (lmeds_shape, with_tile_shape) -- as the one-wave kernels have always followed the selection's largest small frame.  A thread adds its
 rows in order and a row beyond the frame adds an exact zero, and the winner is an exact arg-min whatever the tile's size:
 the reference's per-frame results (core_private.cpp:73-86) must come out bit for bit as from the class's own shape
@@ -22,16 +22,16 @@ def _case(n):
     if n <= 512:                       # one wave per frame: rows per lane (1 .. 4, then 8 -- or 5 .. 7 as sub-shapes)
         need = (n + 63) // 64
         return (n, 0, need, need if need <= 4 else 8)
-    cls = 1 if n <= 1024 else (2 if n <= 2048 else (3 if n <= 4096 else 4))
-    own = 4 << (cls - 1)
+    cls = 1 if n <= 1024 else (2 if n <= 2048 else (3 if n <= 6144 else 4))
     need = (n + 255) // 256
     if cls == 4:
         need += need & 1               # eight waves: tiles of 512 x rows-per-thread
+    own = {1: 4, 2: 8, 3: 16 if n <= 4096 else 24, 4: 32}[cls]      # (class 3's own shape follows the selection's largest frame too: 16 or 24)
     return (n, cls, max(need, 3), own)
 
 
-CASES = [_case(n) for n in [200, 257, 300, 350, 400, 448, 449, 512] + [513, 700, 768, 769, 1000] + [256 * g - 10 for g in range(5, 17)] + [1536, 1537, 2049, 4096]
-         + [4097] + [256 * g - 10 for g in range(18, 33, 2)] + [4608, 4609, 8192]]
+CASES = [_case(n) for n in [200, 257, 300, 350, 400, 448, 449, 512] + [513, 700, 768, 769, 1000] + [256 * g - 10 for g in range(5, 25)]
+         + [1536, 1537, 2049, 4096, 4097, 6144] + [6145] + [256 * g - 10 for g in range(26, 33, 2)] + [6656, 6657, 8192]]
 
 
 def _problem(gyro, frames, env=None):
@@ -65,7 +65,7 @@ def _clip(n_max, lo, seed, **kw):
 
 @pytest.mark.parametrize("n_max,cls,shape,own", CASES)
 def test_a_sub_shape_gives_the_bits_of_the_class_shape(n_max, cls, shape, own):
-    lo = {0: 100, 1: 513, 2: 1025, 3: 2049, 4: 4097}[cls]
+    lo = {0: 100, 1: 513, 2: 1025, 3: 2049, 4: 6145}[cls]
     g, frames, counts = _clip(n_max, lo, seed=n_max, noise=5e-4, outliers=0.08)
     F = len(frames)
     sub = _problem(g, frames)
@@ -102,8 +102,8 @@ def test_the_shape_follows_the_selection_not_the_problem():
 def test_sub_shapes_with_the_window_in_dynamic_lds():
     """gyro at 4 kHz: the spline window moves to dynamic LDS (WIN = 0 instantiations of the sub-shapes)"""
     from rssync_amd import synth
-    for n_max, cls, shape in ((1400, 2, 6), (2600, 3, 11), (4500, 4, 18)):
-        lo = {2: 1025, 3: 2049, 4: 4097}[cls]
+    for n_max, cls, shape in ((1400, 2, 6), (2600, 3, 11), (4500, 3, 18), (7000, 4, 28)):
+        lo = {2: 1025, 3: 2049, 4: 6145}[cls]
         counts = [n_max, lo]
         g = synth.make_gyro(0.0, 4 / synth.FPS, seed=9, fs=4000.0)
         frames = [next(iter(synth.make_frames(g, fr, fr + 1, n, seed=9, noise=5e-4, outliers=0.05))) for fr, n in enumerate(counts)]
