@@ -49,7 +49,8 @@ class ISyncProblem {
     // Any count, as in the reference (core_private.cpp:192-203), up to the indexing bound
     // of 2^24 tracks per frame (rship_max_tracks() in rssync_hip.h).  A frame's kernels follow
     // from ITS OWN track count (size classes): up to 512 tracks one wave per
-    // frame, up to 8192 four waves; only the frames of more than 8192 tracks themselves run the
+    // frame, up to 8192 a workgroup of four waves (PreSync's sweep of a frame of more than 6144
+    // tracks: eight); only the frames of more than 8192 tracks themselves run the
     // slower, exact variants of the kernels -- a correctness path, not a tuned one -- whatever
     // else the problem holds, and a frame's results do not depend on its neighbours.
     virtual void SetTrackResult(int64_t frame, const double* ts_a, const double* ts_b,
