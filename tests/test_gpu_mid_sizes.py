@@ -227,13 +227,22 @@ def test_more_than_2048_tracks_per_frame(N):
         assert Gh[j] == pytest.approx(sum(p[2] for p in per), rel=1e-10, abs=1e-10 * abs(Lh[j]))
     c1, d1 = h.Sync(0.036, 0, F - 1, 0.0, 0.2)
     co1, do1 = o.Sync(0.036, 0, F - 1, 0.0, 0.2)
-    # against the oracle within the north star's 1e-4 s (measured: 2e-12); against the truth only roughly -- six frames of
-    # > 6000 tracks and twelve outer iterations leave the reference's momentum step (core_private.cpp:299-302) 3.6 ms away,
-    # the oracle exactly as far
-    # (the cost only to 5e-3: a GuessMotion search that picks another of two near-tied hypotheses than the oracle's starts that
-    # frame's L-BFGS elsewhere -- 1.1e-3 at 2049 tracks, 1e-14 at 6144)
-    assert np.isfinite(c1) and abs(d1 - do1) < 1e-4 and abs(c1 - co1) <= 5e-3 * abs(co1), (c1, d1, co1, do1)
-    assert abs(d1 - synth.D_TRUE) < (2e-3 if N <= 5000 else 5e-3)
+    # Against the oracle's own Sync, loosely: both are cut off after twelve outer iterations of a six-frame problem, far from
+    # converged, and each runs its OWN GuessMotion searches (on different sampler streams even: h has made a Sync-side call
+    # before, o has not) -- a search that picks another hypothesis starts that frame's L-BFGS elsewhere (measured: delays 2e-12
+    # apart at 6144 tracks, 5e-6 at 2049, 1.1e-4 at 4096; costs 1e-14 .. 5e-3).  Against the truth only where six frames pin it:
+    # with > 6000 tracks per frame the reference's momentum step (core_private.cpp:299-302) is still 3.6 .. 6.3 ms away after
+    # twelve iterations, the oracle's exactly as far.
+    assert np.isfinite(c1) and abs(d1 - do1) < 5e-4 and abs(c1 - co1) <= 2e-2 * abs(co1), (c1, d1, co1, do1)
+    if N <= 5000:
+        assert abs(d1 - synth.D_TRUE) < 2e-3
+    # ... and LIKE FOR LIKE, the north star's bound with room to spare: a fresh pair, the oracle's winners installed (the first
+    # Sync-side call of both: the same sampler stream), the same twelve iterations -- fp64 K1 / K3 against the oracle's fp64
+    h2, o2 = _pair(F, N, seed=70 + N, max_outer_iters=12)
+    co2, do2 = o2.Sync(0.036, 0, F - 1, 0.0, 0.2)
+    h2.set_init_override(o2.last_init_winners())
+    c2, d2 = h2.Sync(0.036, 0, F - 1, 0.0, 0.2)
+    assert abs(d2 - do2) < 1e-6 and abs(c2 - co2) <= 1e-6 * abs(co2), (c2, d2, co2, do2)
 
 
 def _check_large_frames(h, o, F, N_of, scene_name, n_cand_step=0.01):
