@@ -465,7 +465,18 @@ __device__ __forceinline__ uint32_t lmeds_rows64(const Rows64Src& src, uint32_t 
 // (round 6, the SUB-SHAPES: any number of rows per thread from 3 to 15 -- 9 to 15 in the eight-wave shape -- for selections whose
 // largest frame of a class needs no more; a thread adds its rows in order and rows beyond the frame add exact zeros, so the shape
 // changes speed, never a bit: rssync_kernels.hip, lmeds_shape)
-__host__ __device__ constexpr int lmeds_waves(int rpt) { return rpt <= 4 ? RSSYNC_K2_WAVES4 : (rpt <= 8 ? 5 : (rpt <= 16 ? RSSYNC_K2_WAVES16 : 1)); }
+#ifndef RSSYNC_SUBSHAPE_TUNE   // (0: the sub-shapes of 5 / 6 rows per thread compiled for five waves per SIMD like 8, 9 / 10 for three like 16: the A/B of profiles/r6_k2_subshape_waves_ab.txt)
+#define RSSYNC_SUBSHAPE_TUNE 1
+#endif
+__host__ __device__ constexpr int lmeds_waves(int rpt) {
+#if RSSYNC_SUBSHAPE_TUNE
+    // 1280 / 1536-row tiles: 79-80 VGPRs and <= 25.4 KB let SIX workgroups share a CU (-7 % per launch); 2304 / 2560-row tiles: 127-128
+    // VGPRs without a spill and <= 37.7 KB let FOUR (-17 %)
+    if (rpt == 5 || rpt == 6) return 6;
+    if (rpt == 9 || rpt == 10) return 4;
+#endif
+    return rpt <= 4 ? RSSYNC_K2_WAVES4 : (rpt <= 8 ? 5 : (rpt <= 16 ? RSSYNC_K2_WAVES16 : 1));
+}
 __host__ __device__ constexpr int loss_waves(int rpt, bool grad) { return (grad || rpt >= 8) ? 3 : 4; }
 
 constexpr int kMaxChunk = 32; // candidates per workgroup (rship: chunk <= kMaxChunk); 64 and 100 measured: no change

@@ -578,6 +578,10 @@ int launch_lmeds_class(rship_ctx* c, LmedsParams p, const ClassRange& r, const W
     const LmedsKind kind = lmeds_kind(c, k);
     const int rpt = lmeds_shape<MODE>(c, k);
     if (MODE == 0) c->last_lmeds_shape[k] = kind == LmedsKind::Big ? 0u : (uint32_t)rpt; // (class 0: rows per lane of the one-wave kernel)
+    // the tile (the lanes' rows) must hold the largest frame of the list: the kernels index LDS / registers by row without a bound of
+    // their own, and since the sub-shapes the capacity follows the selection, not just the class
+    if (kind != LmedsKind::Big && (uint32_t)rpt * (kind == LmedsKind::Small ? 64u : (uint32_t)kBlock) < c->cls_max_n[k])
+        return set_err(c, "lmeds: the shape chosen for a size class does not hold its largest frame");
     p.slots = r.list;
     p.n_slots = r.count;
     p.chunk = wp.chunk;
