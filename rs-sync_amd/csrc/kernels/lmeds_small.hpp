@@ -17,6 +17,9 @@
 
 namespace {
 
+#ifndef RSSYNC_K2S_KEEP_RAYS   // (1: a chunk's rays stay in registers across its candidates, up to four rows per lane: A/B of profiles/r6_k2s_keep_rays_ab.txt)
+#define RSSYNC_K2S_KEEP_RAYS 0
+#endif
 constexpr int kSmallMaxRpt = 8; // 512 tracks (instantiated: 1, 2, 3, 4 rows per lane, and 8 for 257 .. 512 tracks)
 
 // LDS of one wave's work on a (frame, chunk): the kernel below owns one; the window executor (executor.hpp) lends its own
@@ -95,6 +98,16 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
 
     uint32_t prev_best = kInfBits;
     const uint32_t voff = (uint32_t)lane * 16u;
+    // the frame's rays, fetched once per chunk instead of once per candidate where that is few registers (8 per row)
+    constexpr bool KEEP = RSSYNC_K2S_KEEP_RAYS && RPT <= 4 && MODE == 0 && !R64;
+    f4 keepA[KEEP ? RPT : 1], keepB[KEEP ? RPT : 1];
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            keepA[j] = load_ray(rays.a, voff, (uint32_t)j * 64u * 16u);
+            keepB[j] = load_ray(rays.b, voff, (uint32_t)j * 64u * 16u);
+        }
+    }
     for (uint32_t c = c0; c < c1; ++c) {
         if constexpr (R64) {
             if (!((redo >> (c - c0)) & 1u)) continue;
@@ -112,7 +125,9 @@ __device__ __forceinline__ void lmeds_small_body(const LmedsParams& p, uint32_t 
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
                 const uint32_t row = j * 64 + lane;
-                const f4 A = load_ray(rays.a, voff, (uint32_t)j * 64u * 16u), B = load_ray(rays.b, voff, (uint32_t)j * 64u * 16u);
+                f4 A, B;
+                if constexpr (KEEP) { A = keepA[j]; B = keepB[j]; }
+                else { A = load_ray(rays.a, voff, (uint32_t)j * 64u * 16u); B = load_ray(rays.b, voff, (uint32_t)j * 64u * 16u); }
                 const float nan = __uint_as_float(0x7fc00000u);
                 nx[j] = ny[j] = nz[j] = nan; // rows beyond N: their residuals compare above every threshold
                 nrm[j] = 0.f;
