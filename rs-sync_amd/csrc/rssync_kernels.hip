@@ -306,14 +306,11 @@ constexpr int kWideBlock = 512; // the LMedS tile kernel's workgroup for 6145 ..
 // per thread (PreSync's tile kernel runs class 4 -- 6145 .. 8192 tracks -- as EIGHT waves of 16), 5 rows in global memory.  A thread adds its rows in order and rows beyond the frame add exact zeros, so a
 // frame's sums do not depend on the rows-per-thread instantiation INSIDE a family (one wave / four waves): the classes
 // 1 .. 4 differ in speed only (registers, workgroups per CU), 0 and 5 in the association (0) and the fp32 spline path (5).
+static_assert(rs::kPlanBlock == (uint32_t)kBlock && rs::kPlanFourWaveMaxRpt == (uint32_t)kFourWaveMaxRpt && rs::kPlanMaxRpt == (uint32_t)kMaxRpt,
+              "window_plan.hpp (the rules, checked on the CPU by tests/test_window_plan.py) and this file disagree on the size classes");
 int class_of(const rship_ctx* c, uint32_t n) {
     if (c->force_big) return 5;
-    if (n <= c->one_wave_max) return 0;
-    if (n <= 4u * kBlock) return 1;
-    if (n <= 8u * kBlock) return 2;
-    if (n <= (uint32_t)kFourWaveMaxRpt * kBlock) return 3;
-    if (n <= (uint32_t)kMaxRpt * kBlock) return 4;
-    return 5;
+    return rs::plan_class_of(n, c->one_wave_max);
 }
 // track counts of class k (both ends inclusive)
 void class_bounds(const rship_ctx* c, int k, uint32_t* lo, uint32_t* hi) {
@@ -325,14 +322,10 @@ void class_bounds(const rship_ctx* c, int k, uint32_t* lo, uint32_t* hi) {
 // rows per thread of the four-wave kernels of class k (0 = as many as the frame needs: class 5)
 // (class 3, 2049 .. 6144 tracks: 16 while the selection's largest frame of the class has at most 4096 tracks, else 24 -- the
 // same bits, a thread adds its rows in order and rows beyond the frame add exact zeros)
-int class_rpt(const rship_ctx* c, int k) {
-    if (k == 5) return 0;
-    if (k == 3) return c->cls_max_n[3] > 16u * kBlock ? kFourWaveMaxRpt : 16;
-    return 4 << (k - 1);
-}
+int class_rpt(const rship_ctx* c, int k) { return rs::plan_class_shape(k, c->cls_max_n[k]); }
 // rows per lane of the one-wave kernels: 1 .. 4 up to 256 tracks, 8 for 257 .. 512 (rows beyond the frame contribute
 // exact zeros, so one instantiation serves them all with the same bits)
-int small_rpt(uint32_t n_all) { const uint32_t r = std::max(1u, (n_all + 63u) / 64u); return r <= 4u ? (int)r : 8; }
+int small_rpt(uint32_t n_all) { return rs::plan_small_rows(n_all, false); }
 // rows per thread of a 256-thread workgroup that cover max_n tracks (a power of two, at least four): the four-wave
 // kernels on frames of class 0 (RSSYNC_NO_SMALL_LMEDS / _LOSS: the tests' cross-checks of the two families)
 int rpt_for(uint32_t max_n) {
@@ -522,26 +515,19 @@ int lmeds_rpt(const rship_ctx* c, int k) {
 }
 // ... and the SHAPE its launch takes (with_tile_shape's code): the class's own, or -- PreSync's sweep over classes 1 .. 4 -- the
 // smallest sub-shape that holds the largest frame of the class IN THE SELECTION (the one-wave kernels have always followed
-// cls_max_n[0] this way).  A clip of 1500-track frames sweeps 1536 rows per hypothesis instead of 2048, one of 5000-track
-// frames 5120 instead of 8192; the bits are those of the class's own shape (a thread adds its rows in order, rows beyond the
+// cls_max_n[0] this way).  A clip of 1500-track frames sweeps 1536 rows per hypothesis instead of 2048, one of 4500-track
+// frames 4608 instead of 6144 (the rule itself: window_plan.hpp, plan_sub_shape -- checked on the CPU); the bits are those of the class's own shape (a thread adds its rows in order, rows beyond the
 // frame add exact zeros; the eight-wave shapes among themselves alike).  RSSYNC_NO_SUBSHAPES=1: the class's own shape always.
 template <int MODE>
 int lmeds_shape(const rship_ctx* c, int k) {
     const int full = lmeds_rpt(c, k);
     if (MODE != 0 || c->no_subshapes) return full;
-    if (lmeds_kind(c, k) == LmedsKind::Small) { // 257 .. 512 tracks: 5 / 6 / 7 rows per lane where the selection's largest small frame needs no more than that
-        const int need = (int)((c->cls_max_n[0] + 63u) / 64u);
-        return (need >= 5 && need <= 7) ? need : full;
-    }
+    if (lmeds_kind(c, k) == LmedsKind::Small) return rs::plan_small_rows(c->cls_max_n[0], true); // (257 .. 512 tracks: 5 / 6 / 7 rows per lane where that is enough)
     if (k < 1 || k > 4 || lmeds_kind(c, k) != LmedsKind::Tile) return full;
 #if RSSYNC_TEST_VARIANTS
     if (c->exact_select) return full; // (the exact-selection variant exists in the classes' own shapes only)
 #endif
-    const int need = (int)((c->cls_max_n[k] + (uint32_t)kBlock - 1u) / (uint32_t)kBlock);
-    static const int kCodes[] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 26, 28, 30, 32};
-    for (int code : kCodes)
-        if (code >= need && code <= full) return code;
-    return full;
+    return rs::plan_sub_shape(k, c->cls_max_n[k]);
 }
 
 template <int MODE>

@@ -21,6 +21,46 @@ constexpr uint32_t kPlanCap64Max = 384;   // fp64 windows: 48 KB
 #endif
 constexpr uint32_t kPlanCap64SmallMax = RSSYNC_PLAN_CAP64_SMALL_MAX; // problems of small frames: the 80-knot window beyond this (measured: below)
 
+// ---- size classes and the shapes of PreSync's LMedS kernels ("size classes", "sub-shapes") ----
+// Which kernel family a frame runs in follows from its OWN track count (core_private.cpp:73-86 evaluates every frame in its
+// own lambda): class 0 up to one_wave_max tracks (one wave per frame), 1 .. 3 four waves (up to 1024 / 2048 / 6144 tracks),
+// 4 up to 8192 (PreSync's tile kernel as eight waves), 5 beyond (rows in global memory).
+constexpr uint32_t kPlanBlock = 256;           // threads of a four-wave workgroup = rows per "row of the tile per thread"
+constexpr uint32_t kPlanFourWaveMaxRpt = 24;   // class 3 ends at 24 x 256 = 6144 tracks: two four-wave workgroups still share a CU
+constexpr uint32_t kPlanMaxRpt = 32;           // 8192 tracks: the largest tile in LDS
+inline int plan_class_of(uint32_t n, uint32_t one_wave_max) {
+    if (n <= one_wave_max) return 0;
+    if (n <= 4u * kPlanBlock) return 1;
+    if (n <= 8u * kPlanBlock) return 2;
+    if (n <= kPlanFourWaveMaxRpt * kPlanBlock) return 3;
+    if (n <= kPlanMaxRpt * kPlanBlock) return 4;
+    return 5;
+}
+// The tile kernel's shape is named by its CODE = rows of the tile / 256.  A class's OWN shape: 4, 8, 16 -- or 24 once the
+// selection's largest frame of class 3 has more than 4096 tracks --, 32 (eight waves of 16 rows per thread).  0: class 5.
+inline int plan_class_shape(int k, uint32_t cls_max_n) {
+    if (k <= 0 || k >= 5) return 0;
+    if (k == 3) return cls_max_n > 16u * kPlanBlock ? (int)kPlanFourWaveMaxRpt : 16;
+    return 4 << (k - 1);
+}
+// ... and the SUB-SHAPE PreSync's sweep takes: the smallest shape that holds the largest frame of the class in the selection
+// (3 .. 24 in four waves: any number of rows per thread; 26 .. 32 in eight: even codes) -- the same bits, fewer rows swept
+inline int plan_sub_shape(int k, uint32_t cls_max_n) {
+    const int own = plan_class_shape(k, cls_max_n);
+    if (!own) return 0;
+    int need = (int)((cls_max_n + kPlanBlock - 1u) / kPlanBlock);
+    if (need < 3) need = 3;
+    if (k == 4) need += need & 1;
+    return need < own ? need : own;
+}
+// rows per lane of the one-wave kernels for a selection whose largest small frame has max_n tracks: 1 .. 4 up to 256 tracks,
+// 8 beyond (the family's own), or -- PreSync's sweep -- 5 .. 7 where that is enough
+inline int plan_small_rows(uint32_t max_n, bool sub_shapes) {
+    const uint32_t r = std::max(1u, (max_n + 63u) / 64u);
+    if (r <= 4u) return (int)r;
+    return (sub_shapes && r <= 7u) ? (int)r : 8;
+}
+
 struct WinPlan {
     uint32_t cap = 0;   // 0: the compiled-in 80-knot window; otherwise knots of dynamic LDS (64 bytes each)
     uint32_t chunk = 1; // candidates per workgroup

@@ -32,6 +32,10 @@ void one_wave_window(unsigned n, float span, float ends, int may_compact, unsign
 }
 unsigned long exec_region(unsigned cap64, int compact, unsigned search_cap) { return (unsigned long)rs::exec_region_for(cap64, compact != 0, search_cap); }
 unsigned exec_stage() { return rs::kPlanExecStage; }
+int class_of(unsigned n, unsigned one_wave_max) { return rs::plan_class_of(n, one_wave_max); }
+int class_shape(int k, unsigned max_n) { return rs::plan_class_shape(k, max_n); }
+int sub_shape(int k, unsigned max_n) { return rs::plan_sub_shape(k, max_n); }
+int small_rows(unsigned max_n, int sub) { return rs::plan_small_rows(max_n, sub != 0); }
 }
 '''
 LDS = 160 * 1024
@@ -213,3 +217,40 @@ def test_the_executors_region_holds_the_staging_area_and_the_search_window(lib):
     assert lib.exec_region(112, 1, 0) == 10240 and lib.exec_region(144, 1, 0) == 10240
     assert lib.exec_region(112, 1, 116) == 10240 and lib.exec_region(112, 1, 128) == 10240
     assert lib.exec_region(80, 0, 0) == 10240 and lib.exec_region(144, 0, 0) == 144 * 128 and lib.exec_region(208, 1, 0) == 208 * 64
+
+
+def test_size_classes_and_the_shapes_of_presyncs_kernels(lib):
+    """rssync_kernels.hip's class_of / class_rpt / lmeds_shape are these rules (window_plan.hpp): a frame's class follows from
+    its own track count (core_private.cpp:73-86: every frame in its own lambda); the shape PreSync's launch takes for a class
+    holds the largest frame of the class in the selection, is the smallest that does, never exceeds the class's own, and -- in
+    the eight-wave family -- is a whole number of rows per thread of a 512-thread workgroup.  (The kernels index the tile by
+    row without a bound of their own: a shape too small would be an out-of-bounds write in LDS.)"""
+    for f in (lib.class_of, lib.class_shape, lib.sub_shape, lib.small_rows):
+        f.restype = ctypes.c_int
+    lib.class_of.argtypes = [ctypes.c_uint, ctypes.c_uint]
+    lib.class_shape.argtypes = [ctypes.c_int, ctypes.c_uint]
+    lib.sub_shape.argtypes = [ctypes.c_int, ctypes.c_uint]
+    lib.small_rows.argtypes = [ctypes.c_uint, ctypes.c_int]
+    tops = {0: 512, 1: 1024, 2: 2048, 3: 6144, 4: 8192}
+    prev = 0
+    for n in range(2, 9001):
+        k = lib.class_of(n, 512)
+        assert k >= prev and (k == 5) == (n > 8192) and (k == 5 or n <= tops[k]) and (k == 0 or n > tops[k - 1] if k < 5 else True), (n, k)
+        prev = k
+        if k == 0:
+            r, r_sub = lib.small_rows(n, 0), lib.small_rows(n, 1)
+            assert 64 * r >= n and 64 * r_sub >= n and r_sub <= r and r in (1, 2, 3, 4, 8)
+            assert r_sub == max(1, -(-n // 64)) or (r_sub == 8 and n > 448), (n, r_sub)
+            continue
+        if k == 5:
+            assert lib.class_shape(5, n) == 0 and lib.sub_shape(5, n) == 0
+            continue
+        own, sub = lib.class_shape(k, n), lib.sub_shape(k, n)
+        assert own == {1: 4, 2: 8, 3: 16 if n <= 4096 else 24, 4: 32}[k]
+        assert 256 * sub >= n and sub <= own and sub >= 3, (n, k, sub, own)
+        step = 2 if k == 4 else 1
+        assert sub == 3 or 256 * (sub - step) < n, (n, k, sub)            # the smallest that holds the frame
+        assert k != 4 or sub % 2 == 0
+        assert (sub <= 24) == (k <= 3)                                    # four waves up to 24 rows per thread, eight above
+    # the one-wave family's boundary is a setting (RSSYNC_ONE_WAVE_MAX): class 0 follows it, the others do not move
+    assert lib.class_of(300, 256) == 1 and lib.class_of(256, 256) == 0 and lib.class_of(1025, 256) == 2
