@@ -674,6 +674,7 @@ template <int MODE>
 int launch_lmeds(rship_ctx* c, const LmedsParams& p, double step_knots, uint32_t chunk_want, uint32_t* main_cap, uint32_t* main_chunk) {
     ProfScope ps(c, MODE == 1 ? RSHIP_K_INIT : RSHIP_K_LMEDS);
     const int mk = main_class(c);
+    if (MODE == 0) memset(c->last_lmeds_shape, 0, sizeof(c->last_lmeds_shape)); // (rship_lmeds_shapes: 0 for the classes this sweep does not launch)
     for (const ClassRange& r : class_ranges(c)) {
         const WinPlan wp = plan_lmeds_window<MODE>(c, r.k, step_knots, chunk_want);
         if (r.k == mk) {
