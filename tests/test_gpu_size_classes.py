@@ -3,8 +3,8 @@
 The reference evaluates every frame in its own lambda (core_private.cpp:73-86 PreSync, :231-238 / :245-250 the loss
 sums, :263-295 the per-frame L-BFGS): nothing about frame i knows frame j's track count.  Rounds 2-4 picked the kernel
 family -- and with it the order of a frame's sums -- from the LARGEST frame of the whole problem.  Now a selection is cut
-into one slot list per size class ({<= 512 tracks: one wave per frame}, {<= 1024, 2048, 4096, 8192: four waves with 4 / 8
-/ 16 / 32 rows per thread}, {more: rows in global memory}) and every class runs its own kernels
+into one slot list per size class ({<= 512 tracks: one wave per frame}, {<= 1024, 2048, 6144, 8192: four waves with 4 / 8
+/ 16-24 / 32 rows per thread}, {more: rows in global memory}) and every class runs its own kernels
 (rssync_kernels.hip: class_of, class_ranges).  These tests demand, bit for bit, that a frame gives the same PreSync
 costs and winners, the same GuessMotion / GuessK, the same loss and derivative and the same Sync trace whether it is
 evaluated ALONE in a problem or among frames of every other class -- and that the whole still matches the oracle.
