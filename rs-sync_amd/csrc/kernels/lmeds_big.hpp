@@ -6,15 +6,23 @@
 // lmeds_kernel, but the tile of unit rows lives in global memory (a per-workgroup scratch of 20 B per row: three
 // coordinates, the norm, the residual key), the hypotheses of a candidate are taken in order by the whole
 // workgroup, and the quartile of a hypothesis that beats the bound is found by counting passes of the whole
-// workgroup over the keys (bisection of the bit pattern: at most 31 passes).  A launch is a fixed number of
-// workgroups that walk over the (frame, chunk) items, so the scratch does not grow with the problem.
-// Nothing here is tuned: a tracker that produces such frames spends its time elsewhere (the reference sorts
-// 10^4 residuals per hypothesis on one core).
+// workgroup over the keys.  A launch is a fixed number of workgroups that walk over the (frame, chunk) items, so the
+// scratch does not grow with the problem.
+// Round 6 gave it the two cheap devices of the tile kernels -- the previous candidate's winning quartile (x 1.25) as a
+// provisional bound (a candidate nothing beats it in is redone without it: the arg-min stays exact), and narrow_kth's secant
+// pivots instead of plain bisection of the bit pattern (~6 counting passes per quartile instead of 31) -- and nothing else:
+// 184 -> 122 ms per 2^21 ray pairs x 800 candidates at 9000 tracks (profiles/r6_k2_big_ab.txt); the tile kernels are 5 .. 11
+// times faster per ray still -- the rows on the general spline path, every thread computing every direction, the keys in
+// global memory remain (a tracker that produces such frames spends its time elsewhere: the reference sorts 10^4 residuals
+// per hypothesis on one core).
 #pragma once
 
 namespace {
 
 constexpr uint32_t kBigScratchFloats = 5; // per row: nx, ny, nz, |P|, key
+#ifndef RSSYNC_BIG_OLD_SELECT   // (1: rounds 3-5's selection -- no provisional bound, plain bisection of the bit pattern: the A/B of profiles/r6_k2_big_ab.txt)
+#define RSSYNC_BIG_OLD_SELECT 0
+#endif
 
 template <int MODE> // as lmeds_kernel: 0 PreSync cost per candidate, 1 GuessMotion's search
 __global__ __launch_bounds__(kBlock) void lmeds_big_kernel(LmedsParams p) {
@@ -41,6 +49,31 @@ __global__ __launch_bounds__(kBlock) void lmeds_big_kernel(LmedsParams p) {
         return tot;
     };
 
+    // smallest (key - base) over the frame's keys, wrapping (a key below base wraps to a huge difference), over the whole workgroup
+    auto min_above = [&](uint32_t N, uint32_t base) -> uint32_t {
+        uint32_t mn = 0xffffffffu;
+        for (uint32_t row = tid; row < N; row += kBlock) { const uint32_t d = g_key[row] - base; mn = d < mn ? d : mn; }
+        const uint32_t w = wave_min_u32(mn);
+        if (lane == 0) s_cnt[buf][wave] = w;
+        __syncthreads();
+        uint32_t m = s_cnt[buf][0];
+        for (int q = 1; q < 4; ++q) m = s_cnt[buf][q] < m ? s_cnt[buf][q] : m;
+        buf ^= 1;
+        return m;
+    };
+    // largest finite key (0 if none), over the whole workgroup
+    auto max_finite = [&](uint32_t N) -> uint32_t {
+        uint32_t mx = 0u;
+        for (uint32_t row = tid; row < N; row += kBlock) { const uint32_t k = g_key[row]; mx = (k < kInfBits && k > mx) ? k : mx; }
+        const uint32_t w = ~wave_min_u32(~mx);
+        if (lane == 0) s_cnt[buf][wave] = w;
+        __syncthreads();
+        uint32_t m = s_cnt[buf][0];
+        for (int q = 1; q < 4; ++q) m = s_cnt[buf][q] > m ? s_cnt[buf][q] : m;
+        buf ^= 1;
+        return m;
+    };
+
     Spline sp;
     sp.g = p.coef;
     sp.n = p.n_knots;
@@ -61,6 +94,7 @@ __global__ __launch_bounds__(kBlock) void lmeds_big_kernel(LmedsParams p) {
         const f4* rb = p.rays_b + fr.off;
         const uint32_t c0 = chunk * p.chunk;
         const uint32_t c1 = (c0 + p.chunk < p.n_cand) ? c0 + p.chunk : p.n_cand;
+        uint32_t prev_best = kInfBits; // winning quartile of the previous candidate of this chunk
 
         for (uint32_t c = c0; c < c1; ++c) {
             const int base = fr.base_knot + p.kd[c * p.n_grp + g];
@@ -93,10 +127,20 @@ __global__ __launch_bounds__(kBlock) void lmeds_big_kernel(LmedsParams p) {
                 __syncthreads();
             }
 
-            // ---- stage C: hypotheses in order; (T, bH) = best (quartile, index) so far, strict < (core_private.cpp:53) ----
-            uint32_t T = kInfBits;
-            int bH = -1;
-            f3 Mv = f3{0, 0, 0};
+            // ---- stage C: hypotheses in order; (T, bH) = best (quartile, index) so far, strict < (core_private.cpp:53).  The
+            // previous candidate's winning quartile x 1.25 is a provisional bound, as in the tile kernels (lmeds.hpp): a
+            // hypothesis with at most kq residuals below it is turned away after one counting pass; if nothing beats it the
+            // candidate is redone without it, so the result is the exact arg-min either way.  (Every value below is uniform
+            // over the workgroup: the counts come from LDS sums, the pivots from the same arithmetic in every thread.) ----
+            uint32_t guess = kInfBits;
+            if (!RSSYNC_BIG_OLD_SELECT && prev_best < 0x7e000000u && prev_best > 0x00800000u) guess = __float_as_uint(__uint_as_float(prev_best) * 1.25f);
+            uint32_t T;
+            int bH;
+            f3 Mv;
+            for (;;) {
+            T = guess;
+            bH = -1;
+            Mv = f3{0, 0, 0};
             for (uint32_t h = 0; h < p.n_hyp; ++h) {
                 // (uniform: every thread computes it; the rows' norms are at hand: no bound, the reference's rule directly)
                 const f3 hv = hypothesis(tile, p.seed, fr.id, stream, h, N, 0.f, [&](uint32_t row) -> float { return g_nrm[row]; });
@@ -110,11 +154,40 @@ __global__ __launch_bounds__(kBlock) void lmeds_big_kernel(LmedsParams p) {
                 }
                 __syncthreads();
                 const uint32_t tot = count_lt(N, T);
-                if (tot > kq) { // quartile_h < T: find it.  Bracket [lo, hi): count(< lo) <= kq < count(< hi)
-                    uint32_t lo = 0u, hi = T;
-                    while (hi - lo > 1u) {
-                        const uint32_t mid = lo + ((hi - lo) >> 1);
-                        if (count_lt(N, mid) > kq) hi = mid; else lo = mid;
+                if (tot > kq) { // quartile_h < T: find it.  Bracket [lo, hi): count(< lo) = c_lo <= kq < c_hi = count(< hi)
+                    uint32_t lo = 0u, c_lo = 0u, hi = T, c_hi = tot;
+                    if (hi == kInfBits) { // no bound yet: start the bracket at the largest residual (count(< hi) is still tot)
+                        const uint32_t mx = max_finite(N);
+                        hi = mx + 1u;
+                    }
+                    uint32_t a1 = lo, c1n = c_lo, a2 = hi, c2n = c_hi; // the two most recent (pivot, count) points (lmeds.hpp: narrow_kth)
+                    for (int it = 0;; ++it) {
+                        if (hi - lo == 1u) break;
+                        if (c_hi - c_lo == 1u) { // the single element in [lo, hi): the smallest key >= lo
+                            lo += min_above(N, lo);
+                            hi = lo + 1u;
+                            break;
+                        }
+                        uint32_t piv = 0;
+                        if (!RSSYNC_BIG_OLD_SELECT && it < 24) {
+                            if (c2n != c1n) { // secant through the last two points, aimed at rank kq + 1/2
+                                const float num = 0.5f * (float)(int)(2 * kq + 1 - 2 * c2n);
+                                const float a3 = fmaf(num * (__uint_as_float(a2) - __uint_as_float(a1)), rs::rcp_fast((float)(int)(c2n - c1n)), __uint_as_float(a2));
+                                piv = __float_as_uint(a3);
+                            }
+                            if (!(piv > lo && piv < hi)) { // interpolate inside the bracket instead
+                                const float num = 0.5f * (float)(int)(2 * kq + 1 - 2 * c_lo);
+                                const float a3 = fmaf(num * (__uint_as_float(hi) - __uint_as_float(lo)), rs::rcp_fast((float)(c_hi - c_lo)), __uint_as_float(lo));
+                                piv = __float_as_uint(a3);
+                            }
+                        }
+                        if (!(piv > lo && piv < hi)) piv = lo + ((hi - lo) >> 1); // bit bisection: guaranteed finish
+                        piv = uniform_u32(piv); // (the same in every lane by construction; said to the compiler)
+                        const uint32_t cnt = count_lt(N, piv);
+                        a1 = a2; c1n = c2n;
+                        a2 = piv; c2n = cnt;
+                        if (cnt <= kq) { lo = piv; c_lo = cnt; }
+                        else { hi = piv; c_hi = cnt; }
                     }
                     T = lo;
                     bH = (int)h;
@@ -122,6 +195,10 @@ __global__ __launch_bounds__(kBlock) void lmeds_big_kernel(LmedsParams p) {
                 }
                 __syncthreads(); // keys are rewritten by the next hypothesis
             }
+            if (guess == kInfBits || bH >= 0) break;
+            guess = kInfBits; // nothing beat the provisional bound: once more without it
+            }
+            prev_best = bH >= 0 ? T : kInfBits;
             if (!(finite_f(Mv.x) && finite_f(Mv.y) && finite_f(Mv.z))) bad |= RSHIP_BAD_M;
             if (MODE == 1) {
                 if (tid == 0) p.best_h[sf] = bH;
