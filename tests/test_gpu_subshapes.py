@@ -131,3 +131,32 @@ def test_near_static_frames_in_a_sub_shape():
     assert sub.lmeds_shapes()[2] == 6
     for x, y in zip(a, b):
         np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("seed", range(8 + int(os.environ.get("RSSYNC_FUZZ_CASES", "0"))))
+def test_random_mixed_selections(seed):
+    """random clips -- 3 to 10 frames of ragged track counts from 40 to 7800 in one problem (up to five size classes at once), random
+    gyro rate, random sweep -- with and without sub-shapes: every per-frame cost, every winner, the curve, PreSync's result and the
+    Sync that follows, bit for bit"""
+    from rssync_amd import synth
+    rng = np.random.default_rng(4242 + seed)
+    F = int(rng.integers(3, 11))
+    fs = float(rng.choice([200.0, 400.0, 1000.0, 3200.0]))
+    tops = rng.choice([300, 450, 640, 900, 1300, 1800, 2300, 3100, 4500, 5700, 6500, 7800], size=F)
+    counts = [int(rng.integers(max(40, t // 2), t + 1)) for t in tops]
+    g = synth.make_gyro(0.0, (F + 2) / synth.FPS, fs=fs, seed=seed)
+    frames = [next(iter(synth.make_frames(g, fr, fr + 1, n, seed=seed, noise=float(rng.choice([0.0, 5e-4, 2e-3])), outliers=0.08)))
+              for fr, n in enumerate(counts)]
+    sub = _problem(g, frames)
+    full = _problem(g, frames, env={"RSSYNC_NO_SUBSHAPES": "1"})
+    step = float(rng.choice([0.0005, 0.001, 0.002]))
+    radius = float(rng.uniform(0.005, 0.03))
+    lo = int(rng.integers(0, F - 2))
+    a = sub.presync_curve(0.03, lo, F, step, radius, per_frame=F - lo)
+    b = full.presync_curve(0.03, lo, F, step, radius, per_frame=F - lo)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y, err_msg=str(counts))
+    ra, rb = sub.PreSync(0.0, 0, F, 0.002, 0.08), full.PreSync(0.0, 0, F, 0.002, 0.08)
+    assert ra == rb, counts
+    assert sub.Sync(ra[1], 0, F - 1, 0.0, 0.2) == full.Sync(rb[1], 0, F - 1, 0.0, 0.2), counts
+    np.testing.assert_array_equal(sub.sync_trace(), full.sync_trace())
