@@ -1150,7 +1150,8 @@ def test_guess_motion_on_near_static_frames_takes_its_rows_from_the_fp64_streams
     if res["executor"][4]:
         assert res["executor"][0] == res["chain"][0]
         np.testing.assert_array_equal(res["executor"][1].view(np.uint64), res["chain"][1].view(np.uint64))
-        assert res["executor"][3]["searches"] == H
+        # (with RSSYNC_EXECUTOR_CHECK=1 every executor call is run again by the chain, whose searches count as well)
+        assert res["executor"][3]["searches"] == (2 * H if os.environ.get("RSSYNC_EXECUTOR_CHECK", "0") not in ("", "0") else H)
     else:
         assert N in (7000,), N           # (frames of 6145 .. 8192 tracks: the eight-wave tile kernel; the executor leaves them to the chain)
 
