@@ -160,3 +160,22 @@ def test_random_mixed_selections(seed):
     assert ra == rb, counts
     assert sub.Sync(ra[1], 0, F - 1, 0.0, 0.2) == full.Sync(rb[1], 0, F - 1, 0.0, 0.2), counts
     np.testing.assert_array_equal(sub.sync_trace(), full.sync_trace())
+
+
+def test_sub_shapes_on_the_general_spline_path():
+    """candidate delays seconds away, beyond either end of the gyro track (minispline.cpp:49-54: the extrapolation branches): the
+    rows take the kernels' general path (table from L2, the careful form of the row) -- in a sub-shape as in the class's own"""
+    from rssync_amd import synth
+    for n_max, cls, shape in ((700, 1, 3), (1400, 2, 6), (2700, 3, 11), (4500, 3, 18), (7000, 4, 28)):
+        lo = {1: 513, 2: 1025, 3: 2049, 4: 6145}[cls]
+        counts = [n_max, lo + 7]
+        g = synth.make_gyro(0.0, 4 / synth.FPS, seed=13)
+        frames = [next(iter(synth.make_frames(g, fr, fr + 1, n, seed=13, noise=5e-4, outliers=0.05))) for fr, n in enumerate(counts)]
+        sub = _problem(g, frames)
+        full = _problem(g, frames, env={"RSSYNC_NO_SUBSHAPES": "1"})
+        for centre in (-2.5, 1.02, 3.0):       # before the track, across its end, after it
+            a = sub.presync_curve(centre, 0, 2, 0.004, 0.05, per_frame=2)
+            b = full.presync_curve(centre, 0, 2, 0.004, 0.05, per_frame=2)
+            assert sub.lmeds_shapes()[cls] == shape
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x, y, err_msg="%d tracks, delays around %g s" % (n_max, centre))
