@@ -8,18 +8,20 @@
 // workgroup, and the quartile of a hypothesis that beats the bound is found by counting passes of the whole
 // workgroup over the keys.  A launch is a fixed number of workgroups that walk over the (frame, chunk) items, so the
 // scratch does not grow with the problem.
-// Round 6 gave it the two cheap devices of the tile kernels -- the previous candidate's winning quartile (x 1.25) as a
-// provisional bound (a candidate nothing beats it in is redone without it: the arg-min stays exact), and narrow_kth's secant
-// pivots instead of plain bisection of the bit pattern (~6 counting passes per quartile instead of 31) -- and nothing else:
-// 184 -> 122 ms per 2^21 ray pairs x 800 candidates at 9000 tracks (profiles/r6_k2_big_ab.txt); the tile kernels are 5 .. 11
-// times faster per ray still -- the rows on the general spline path, every thread computing every direction, the keys in
-// global memory remain (a tracker that produces such frames spends its time elsewhere: the reference sorts 10^4 residuals
-// per hypothesis on one core).
+// Round 6 gave it three cheap devices -- the previous candidate's winning quartile (x 1.25) as a provisional bound, as in the tile
+// kernels (a candidate nothing beats it in is redone without it: the arg-min stays exact); narrow_kth's secant pivots instead
+// of plain bisection of the bit pattern (~6 counting passes per quartile instead of 31); and ONE pass over the rows that counts
+// all twenty hypotheses of a batch against the bound, so that only the survivors' keys are ever written and read (the tiles of
+// all workgroups together exceed the L2: twenty sweeps per candidate were HBM traffic) -- and a direction is computed by one
+// thread instead of by all 256: 218 -> 85 ms per 2^21 ray pairs x 800 candidates at 9000 tracks (profiles/r6_k2_big_ab.txt).
+// The eight-wave tile kernel is 3.5 times faster per ray still (a tracker that produces such frames spends its time
+// elsewhere: the reference sorts 10^4 residuals per hypothesis on one core).
 #pragma once
 
 namespace {
 
 constexpr uint32_t kBigScratchFloats = 5; // per row: nx, ny, nz, |P|, key
+constexpr int kBigBatch = 20; // hypotheses whose residuals one pass over the rows counts against the bound (PreSync tries 20 per candidate, GuessMotion 200: core_private.cpp:77,127)
 #ifndef RSSYNC_BIG_OLD_SELECT   // (1: rounds 3-5's selection -- no provisional bound, plain bisection of the bit pattern: the A/B of profiles/r6_k2_big_ab.txt)
 #define RSSYNC_BIG_OLD_SELECT 0
 #endif
@@ -29,6 +31,8 @@ __global__ __launch_bounds__(kBlock) void lmeds_big_kernel(LmedsParams p) {
     __shared__ double s_red[2][4];
     __shared__ uint32_t s_cnt[2][4];
     __shared__ uint32_t s_near; // this candidate's rows are redone in fp64 (lmeds.hpp, "fp64 rows")
+    __shared__ f4 s_hv[kBigBatch];        // the directions of the current batch of hypotheses
+    __shared__ uint32_t s_bc[kBigBatch];  // ... and how many of the frame's |residuals| lie below the bound the batch started with
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t rows = p.scratch_rows; // a multiple of kBlock, >= the largest frame
     float* const mine = p.scratch + (size_t)blockIdx.x * rows * kBigScratchFloats;
@@ -141,59 +145,98 @@ __global__ __launch_bounds__(kBlock) void lmeds_big_kernel(LmedsParams p) {
             T = guess;
             bH = -1;
             Mv = f3{0, 0, 0};
-            for (uint32_t h = 0; h < p.n_hyp; ++h) {
-                // (uniform: every thread computes it; the rows' norms are at hand: no bound, the reference's rule directly)
-                const f3 hv = hypothesis(tile, p.seed, fr.id, stream, h, N, 0.f, [&](uint32_t row) -> float { return g_nrm[row]; });
-                for (uint32_t row = tid; row < N; row += kBlock) {
-                    const float r = fmaf(tile.nz[row], hv.z, fmaf(tile.ny[row], hv.y, tile.nx[row] * hv.x)); // :48, as sweep_tile
-                    const uint32_t a = __float_as_uint(r) & 0x7fffffffu;
-                    g_key[row] = a > kInfBits ? 0xffffffffu : a; // NaN never counts
-#if RSSYNC_TEST_VARIANTS
-                    if (MODE == 0 && p.dump && row < p.dump_rows) p.dump[(((size_t)c * p.n_sel + sf) * p.n_hyp + h) * p.dump_rows + row] = a;
-#endif
+            for (uint32_t batch = 0; batch < p.n_hyp; batch += (uint32_t)kBigBatch) {
+                const uint32_t nb = (p.n_hyp - batch < (uint32_t)kBigBatch) ? p.n_hyp - batch : (uint32_t)kBigBatch;
+                // the batch's directions, one thread each (the rows' norms are at hand: no bound, the reference's rule directly)
+                __syncthreads(); // (the previous batch's readers of s_hv / s_bc are done; stage A's rows are visible)
+                if ((uint32_t)tid < (uint32_t)kBigBatch) {
+                    f3 v = f3{0, 0, 0};
+                    if ((uint32_t)tid < nb) v = hypothesis(tile, p.seed, fr.id, stream, batch + tid, N, 0.f, [&](uint32_t row) -> float { return g_nrm[row]; });
+                    s_hv[tid] = f4{v.x, v.y, v.z, 0.f};
+                    s_bc[tid] = 0u;
                 }
                 __syncthreads();
-                const uint32_t tot = count_lt(N, T);
-                if (tot > kq) { // quartile_h < T: find it.  Bracket [lo, hi): count(< lo) = c_lo <= kq < c_hi = count(< hi)
-                    uint32_t lo = 0u, c_lo = 0u, hi = T, c_hi = tot;
-                    if (hi == kInfBits) { // no bound yet: start the bracket at the largest residual (count(< hi) is still tot)
-                        const uint32_t mx = max_finite(N);
-                        hi = mx + 1u;
-                    }
-                    uint32_t a1 = lo, c1n = c_lo, a2 = hi, c2n = c_hi; // the two most recent (pivot, count) points (lmeds.hpp: narrow_kth)
-                    for (int it = 0;; ++it) {
-                        if (hi - lo == 1u) break;
-                        if (c_hi - c_lo == 1u) { // the single element in [lo, hi): the smallest key >= lo
-                            lo += min_above(N, lo);
-                            hi = lo + 1u;
-                            break;
+                // ONE pass over the rows for the whole batch (round 6): how many |residuals| of each hypothesis lie below the bound
+                // the batch starts with.  T only falls while the batch is worked through, so a hypothesis with at most kq below
+                // THIS bound is out for certain -- without its keys ever being written or read (the tiles of all workgroups
+                // together exceed the L2: 20 passes over rows and keys per candidate were HBM traffic).  No bound yet: all stay.
+                const uint32_t T0 = T;
+                if (!RSSYNC_BIG_OLD_SELECT && T0 != kInfBits) {
+                    uint32_t cnt[kBigBatch];
+#pragma unroll
+                    for (int q = 0; q < kBigBatch; ++q) cnt[q] = 0u;
+                    for (uint32_t row = tid; row < N; row += kBlock) {
+                        const float x = tile.nx[row], y = tile.ny[row], z = tile.nz[row];
+#pragma unroll
+                        for (int q = 0; q < kBigBatch; ++q) {
+                            const f4 hv = s_hv[q];
+                            const float r = fmaf(z, hv.z, fmaf(y, hv.y, x * hv.x)); // :48, as sweep_tile (the keys' very expression)
+                            cnt[q] += ((__float_as_uint(r) & 0x7fffffffu) < T0) ? 1u : 0u; // (a NaN's pattern is above every bound)
                         }
-                        uint32_t piv = 0;
-                        if (!RSSYNC_BIG_OLD_SELECT && it < 24) {
-                            if (c2n != c1n) { // secant through the last two points, aimed at rank kq + 1/2
-                                const float num = 0.5f * (float)(int)(2 * kq + 1 - 2 * c2n);
-                                const float a3 = fmaf(num * (__uint_as_float(a2) - __uint_as_float(a1)), rs::rcp_fast((float)(int)(c2n - c1n)), __uint_as_float(a2));
-                                piv = __float_as_uint(a3);
-                            }
-                            if (!(piv > lo && piv < hi)) { // interpolate inside the bracket instead
-                                const float num = 0.5f * (float)(int)(2 * kq + 1 - 2 * c_lo);
-                                const float a3 = fmaf(num * (__uint_as_float(hi) - __uint_as_float(lo)), rs::rcp_fast((float)(c_hi - c_lo)), __uint_as_float(lo));
-                                piv = __float_as_uint(a3);
-                            }
-                        }
-                        if (!(piv > lo && piv < hi)) piv = lo + ((hi - lo) >> 1); // bit bisection: guaranteed finish
-                        piv = uniform_u32(piv); // (the same in every lane by construction; said to the compiler)
-                        const uint32_t cnt = count_lt(N, piv);
-                        a1 = a2; c1n = c2n;
-                        a2 = piv; c2n = cnt;
-                        if (cnt <= kq) { lo = piv; c_lo = cnt; }
-                        else { hi = piv; c_hi = cnt; }
                     }
-                    T = lo;
-                    bH = (int)h;
-                    Mv = hv;
+#pragma unroll
+                    for (int q = 0; q < kBigBatch; ++q) {
+                        const uint32_t w = wave_sum_u32(cnt[q]);
+                        if (lane == 0 && w) atomicAdd(&s_bc[q], w);
+                    }
+                    __syncthreads();
                 }
-                __syncthreads(); // keys are rewritten by the next hypothesis
+                for (uint32_t j = 0; j < nb; ++j) {
+                    if (!RSSYNC_BIG_OLD_SELECT && T0 != kInfBits && s_bc[j] <= kq) continue; // (uniform: an LDS word)
+                    const uint32_t h = batch + j;
+                    const f4 hv4 = s_hv[j];
+                    const f3 hv = f3{hv4.x, hv4.y, hv4.z};
+                    for (uint32_t row = tid; row < N; row += kBlock) {
+                        const float r = fmaf(tile.nz[row], hv.z, fmaf(tile.ny[row], hv.y, tile.nx[row] * hv.x)); // :48, as sweep_tile
+                        const uint32_t a = __float_as_uint(r) & 0x7fffffffu;
+                        g_key[row] = a > kInfBits ? 0xffffffffu : a; // NaN never counts
+#if RSSYNC_TEST_VARIANTS
+                        if (MODE == 0 && p.dump && row < p.dump_rows) p.dump[(((size_t)c * p.n_sel + sf) * p.n_hyp + h) * p.dump_rows + row] = a;
+#endif
+                    }
+                    __syncthreads();
+                    const uint32_t tot = count_lt(N, T);
+                    if (tot > kq) { // quartile_h < T: find it.  Bracket [lo, hi): count(< lo) = c_lo <= kq < c_hi = count(< hi)
+                        uint32_t lo = 0u, c_lo = 0u, hi = T, c_hi = tot;
+                        if (hi == kInfBits) { // no bound yet: start the bracket at the largest residual (count(< hi) is still tot)
+                            const uint32_t mx = max_finite(N);
+                            hi = mx + 1u;
+                        }
+                        uint32_t a1 = lo, c1n = c_lo, a2 = hi, c2n = c_hi; // the two most recent (pivot, count) points (lmeds.hpp: narrow_kth)
+                        for (int it = 0;; ++it) {
+                            if (hi - lo == 1u) break;
+                            if (c_hi - c_lo == 1u) { // the single element in [lo, hi): the smallest key >= lo
+                                lo += min_above(N, lo);
+                                hi = lo + 1u;
+                                break;
+                            }
+                            uint32_t piv = 0;
+                            if (!RSSYNC_BIG_OLD_SELECT && it < 24) {
+                                if (c2n != c1n) { // secant through the last two points, aimed at rank kq + 1/2
+                                    const float num = 0.5f * (float)(int)(2 * kq + 1 - 2 * c2n);
+                                    const float a3 = fmaf(num * (__uint_as_float(a2) - __uint_as_float(a1)), rs::rcp_fast((float)(int)(c2n - c1n)), __uint_as_float(a2));
+                                    piv = __float_as_uint(a3);
+                                }
+                                if (!(piv > lo && piv < hi)) { // interpolate inside the bracket instead
+                                    const float num = 0.5f * (float)(int)(2 * kq + 1 - 2 * c_lo);
+                                    const float a3 = fmaf(num * (__uint_as_float(hi) - __uint_as_float(lo)), rs::rcp_fast((float)(c_hi - c_lo)), __uint_as_float(lo));
+                                    piv = __float_as_uint(a3);
+                                }
+                            }
+                            if (!(piv > lo && piv < hi)) piv = lo + ((hi - lo) >> 1); // bit bisection: guaranteed finish
+                            piv = uniform_u32(piv); // (the same in every lane by construction; said to the compiler)
+                            const uint32_t cnt2 = count_lt(N, piv);
+                            a1 = a2; c1n = c2n;
+                            a2 = piv; c2n = cnt2;
+                            if (cnt2 <= kq) { lo = piv; c_lo = cnt2; }
+                            else { hi = piv; c_hi = cnt2; }
+                        }
+                        T = lo;
+                        bH = (int)h;
+                        Mv = hv;
+                    }
+                    __syncthreads(); // keys are rewritten by the next hypothesis
+                }
             }
             if (guess == kInfBits || bH >= 0) break;
             guess = kInfBits; // nothing beat the provisional bound: once more without it
