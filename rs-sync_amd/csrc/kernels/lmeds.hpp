@@ -552,7 +552,8 @@ constexpr int kContCap = 24; // contender records per candidate; beyond that a h
 // R64 = the fp64-rows form ("fp64 rows" above; MODE 0, WIN 0): the same grid, but a workgroup leaves at once unless the
 // fp32 launch has flagged candidates of its (frame, chunk), and evaluates only those -- stage A from the fp64 streams.
 // Not a hot kernel: compiled without an occupancy target.
-// BLOCK = threads of the workgroup: 256 (four waves) everywhere but the WIDE shape of round 6 -- frames of 4097 .. 8192 tracks
+// BLOCK = threads of the workgroup: 256 (four waves) everywhere but the WIDE shape of round 6 -- frames of 6145 .. 8192 tracks
+// (4097 .. 8192 at first; tiles of up to 6144 rows leave a CU TWO four-wave workgroups and stay four waves: RPT up to 24)
 // as RPT = 16, BLOCK = 512: eight waves, two per SIMD.  The tile of such a frame (96 KB) allows one workgroup per CU either
 // way; as four waves of 32 rows per thread (rounds 3-5: 480 VGPRs) that was ONE wave per SIMD, which issues an instruction
 // every ~5 cycles instead of every ~2.3 (DESIGN.md section 3's table): 0.35 of the benchmark class's rate per ray.

@@ -613,7 +613,9 @@ int launch_lmeds_class(rship_ctx* c, LmedsParams p, const ClassRange& r, const W
         // workgroups share by walking over the (frame, chunk) items of the class
         const uint32_t rows = big_rows(c->cls_max_n[k]);
         const uint64_t total = (uint64_t)r.count * p.n_chunks;
-        uint64_t g1 = total < 2048 ? total : 2048;
+        uint64_t cap_wgs = 2048;
+        if (const char* e = std::getenv("RSSYNC_BIG_WGS")) { const long v = atol(e); if (v >= 64 && v <= 8192) cap_wgs = (uint64_t)v; } // (A/B: how many tiles are live at once)
+        uint64_t g1 = total < cap_wgs ? total : cap_wgs;
         const uint64_t per_wg = (uint64_t)rows * kBigScratchFloats * 4;
         const uint64_t fit = ((uint64_t)4 << 30) / per_wg; // at most 4 GB of tiles
         if (g1 > fit) g1 = fit ? fit : 1;

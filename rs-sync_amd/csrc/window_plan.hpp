@@ -70,7 +70,7 @@ struct WinPlan {
 
 // Frames whose knots fit the compiled-in window can still be better off with a SMALLER window in dynamic LDS: where the
 // kernel's LDS, not its registers, decides how many workgroups share a CU and the compiled-in window is the difference
-// (round 5: lmeds_kernel<16, ...>, 2049 .. 4096 tracks -- 48 KB of tile + the 5 KB window = two workgroups per CU, with a
+// (round 5: lmeds_kernel<16, ...>, 3841 .. 4096 tracks since round 6's sub-shapes -- 48 KB of tile + the 5 KB window = two workgroups per CU, with a
 // window of the ~30 knots a 400 Hz frame and its chunk touch three).  static_lds / dyn_fixed_lds: the two instantiations'
 // static LDS; wg_cap: workgroups per CU the kernel's registers allow.  -> knots of the dynamic window, or 0 = keep the
 // compiled-in one.  The dynamic window then stages whole pairs, as the compiled-in one does: the same frames take the
